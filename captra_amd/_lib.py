@@ -1,0 +1,133 @@
+"""ctypes binding of libcaptra_hip.so (the C ABI declared in include/captra_hip.h).
+
+The product path has NO CPU fallback: if the shared library is missing or a launch fails this
+module raises.  Tensors are handed over as raw device pointers plus the current torch HIP stream,
+which is what the reference's glue does with `at::cuda::getCurrentCUDAStream()`
+(network/models/pointnet_lib/src/ball_query.cpp:22).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+import torch
+
+_PKG = Path(__file__).resolve().parent
+LIB_PATH = _PKG / "lib" / "libcaptra_hip.so"
+
+_lib = None
+
+_INT, _LL, _F, _P = C.c_int, C.c_longlong, C.c_float, C.c_void_p
+
+# name -> argtypes (all return int unless listed in _VOID / _OTHER)
+_SIGNATURES = {
+    "captra_furthest_point_sampling": [_INT, _INT, _INT, _P, _P, _P, _P],
+    "captra_ball_query": [_INT, _INT, _INT, _F, _INT, _P, _P, _P, _P],
+    "captra_group_points": [_INT, _INT, _INT, _INT, _INT, _P, _P, _P, _P],
+    "captra_group_points_grad": [_INT, _INT, _INT, _INT, _INT, _P, _P, _P, _P],
+    "captra_gather_points": [_INT, _INT, _INT, _INT, _P, _P, _P, _P],
+    "captra_gather_points_grad": [_INT, _INT, _INT, _INT, _P, _P, _P, _P],
+    "captra_knn": [_INT, _INT, _INT, _INT, _P, _P, _P, _P, _P],
+    "captra_three_nn": [_INT, _INT, _INT, _P, _P, _P, _P, _P],
+    "captra_three_interpolate": [_INT, _INT, _INT, _INT, _P, _P, _P, _P, _P],
+    "captra_three_interpolate_grad": [_INT, _INT, _INT, _INT, _P, _P, _P, _P, _P],
+    "captra_canonicalize": [_INT, _INT, _INT, _P, _P, _P, _P, _P, _P, _P, _P],
+    "captra_ball_query_multi": [_INT, _INT, _INT, _INT, _P, _P, _P, _P, _P, _P],
+    "captra_pointwise_mlp": [_INT, _INT, _INT, _LL, _P, _P, _P, _INT, _P, _P],
+    "captra_sa_group_mlp": [_INT, _INT, _INT, _INT, _INT, _INT, _P, _P, _P, _P, _P, _P, _P, _P],
+    "captra_mlp_max": [_INT, _INT, _INT, _INT, _INT, _P, _P, _P, _P, _INT, _INT, _P],
+    "captra_fp_interpolate_concat": [_INT, _INT, _INT, _INT, _INT, _P, _P, _P, _P, _P, _P],
+    "captra_part_fit_st": [_INT, _INT, _INT, _INT, _P, _P, _P, _P, _P, _P, _P, _P],
+    "captra_procrustes_rot3": [_INT, _INT, _P, _P, _P, _P],
+}
+
+
+class CaptraHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libcaptra_hip.so once; raise loudly if it is not built."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise CaptraHipError(
+                f"{LIB_PATH} is missing — run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `python captra_amd/build.py`). captra_amd has no CPU fallback.")
+        l = C.CDLL(str(LIB_PATH))
+        for name, args in _SIGNATURES.items():
+            try:
+                fn = getattr(l, name)
+            except AttributeError:
+                continue  # a stale build: call() raises when the symbol is actually needed
+            fn.argtypes = args
+            fn.restype = _INT
+        l.captra_error_string.argtypes = [_INT]
+        l.captra_error_string.restype = C.c_char_p
+        l.captra_version.restype = C.c_char_p
+        l.captra_prof_enable.argtypes = [_INT]
+        l.captra_prof_enable.restype = None
+        l.captra_prof_reset.restype = None
+        l.captra_prof_read.argtypes = [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
+        l.captra_prof_read.restype = _INT
+        l.captra_prof_names.argtypes = [C.c_char_p, _INT]
+        l.captra_prof_names.restype = _INT
+        _lib = l
+    return _lib
+
+
+def stream_ptr() -> int:
+    """Raw hipStream_t of torch's current stream on the current device."""
+    return torch.cuda.current_stream().cuda_stream
+
+
+def check(err: int, what: str) -> None:
+    if err != 0:
+        msg = lib().captra_error_string(err)
+        raise CaptraHipError(f"{what} failed: {msg.decode() if msg else err} (code {err})")
+
+
+def require_device(*tensors) -> None:
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise CaptraHipError("captra_amd ops need tensors in GPU memory (got a CPU tensor); "
+                                 "there is no CPU fallback in the product path")
+        if not t.is_contiguous():
+            raise CaptraHipError("captra_amd ops need contiguous tensors")
+
+
+def ptr(t) -> int | None:
+    return None if t is None else t.data_ptr()
+
+
+def call(name: str, *args) -> None:
+    """Invoke a launcher with the current stream appended and raise on a non-zero return."""
+    try:
+        fn = getattr(lib(), name)
+    except AttributeError as e:
+        raise CaptraHipError(f"{LIB_PATH} does not export {name}: rebuild it (python captra_amd/build.py)") from e
+    check(fn(*args, stream_ptr()), name)
+
+
+# ---- profiling helpers ---------------------------------------------------------------------------
+def prof_enable(on: bool) -> None:
+    lib().captra_prof_enable(1 if on else 0)
+
+
+def prof_reset() -> None:
+    lib().captra_prof_reset()
+
+
+def prof_read(name: str) -> tuple[float, int]:
+    ms, n = C.c_double(0.0), C.c_longlong(0)
+    lib().captra_prof_read(name.encode(), C.byref(ms), C.byref(n))
+    return ms.value, n.value
+
+
+def prof_names() -> list[str]:
+    buf = C.create_string_buffer(4096)
+    lib().captra_prof_names(buf, 4096)
+    s = buf.value.decode()
+    return [x for x in s.split(",") if x]

@@ -1,0 +1,55 @@
+// Shared device/host helpers for libcaptra_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define CAPTRA_WAVE 64
+
+typedef void *captra_stream_t;
+
+// ---- profiling hooks (prof.cpp) -------------------------------------------------------------
+// CAPTRA_LAUNCH brackets a kernel launch with HIP events on the launch stream when profiling
+// is enabled (captra_prof_enable).  Outside profiling it costs one relaxed load.
+struct CaptraProfScope {
+    int slot;
+    hipStream_t stream;
+    CaptraProfScope(const char *name, hipStream_t s);
+    ~CaptraProfScope();
+};
+
+#define CAPTRA_LAUNCH(name, kernel, grid, block, shmem, stream, ...)                     \
+    do {                                                                                 \
+        CaptraProfScope _scope(name, stream);                                            \
+        hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);             \
+    } while (0)
+
+static inline int captra_last_error() { return (int)hipGetLastError(); }
+
+// ---- device helpers ---------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+// squared distance exactly as the reference kernels and the oracle write it:
+// ((dx*dx + dy*dy) + dz*dz), every operation rounded separately (build uses -ffp-contract=off).
+__device__ __forceinline__ float dist2_unfused(float ax, float ay, float az, float bx, float by,
+                                               float bz) {
+    float dx = ax - bx, dy = ay - by, dz = az - bz;
+    float xx = dx * dx, yy = dy * dy, zz = dz * dz;
+    return (xx + yy) + zz;
+}
+
+// 64-bit shuffle helpers (wave64)
+__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int mask) {
+    unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+    lo = __shfl_xor(lo, mask, 64);
+    hi = __shfl_xor(hi, mask, 64);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        unsigned long long o = shfl_xor_u64(v, off);
+        v = o > v ? o : v;
+    }
+    return v;
+}

@@ -1,0 +1,157 @@
+// Grouping / gathering (indexed row copies) and their scatter-add gradients for gfx950.
+//
+// Replaces group_points_kernel_fast (reference group_points_gpu.cu:47-66) and
+// gather_points_kernel_fast (sampling_gpu.cu:8-24), which launch one thread per output element
+// over a (positions, C, B) grid and re-read idx for every channel.  This is a pure data-movement
+// op bounded by the HBM write of out (4*C*M*K bytes): here a workgroup stages a chunk of
+// `cc` channel rows of points[b] (contiguous cc*N floats) into LDS with 16-byte coalesced loads,
+// reads each idx quad ONCE, gathers the cc rows from LDS and writes 16-byte coalesced stores.
+#include "common.h"
+
+namespace {
+
+constexpr int GP_THREADS = 256;
+constexpr int GP_LDS_BYTES = 64 * 1024;  // channel-chunk staging budget (2 workgroups / CU)
+constexpr int GP_POS_PER_BLOCK = 4096;   // output positions handled by one workgroup
+
+// VEC = 4: npos % 4 == 0 and 16-byte aligned idx/out rows; VEC = 1 otherwise.
+template <int VEC>
+__global__ __launch_bounds__(GP_THREADS) void group_points_kernel(int c, int n, long long npos, int cc,
+                                                                  const float *__restrict__ points,
+                                                                  const int *__restrict__ idx,
+                                                                  float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float rows[];
+    const int b = blockIdx.z;
+    const int c0 = blockIdx.y * cc;
+    const int ccv = (c - c0) < cc ? (c - c0) : cc;
+    const long long p0 = (long long)blockIdx.x * GP_POS_PER_BLOCK;
+    const long long p1 = (p0 + GP_POS_PER_BLOCK) < npos ? (p0 + GP_POS_PER_BLOCK) : npos;
+    const int tid = threadIdx.x;
+
+    const float *src = points + ((size_t)b * c + c0) * n;
+    const size_t nstage = (size_t)ccv * n;
+    if ((nstage & 3) == 0 && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
+        const float4 *s4 = reinterpret_cast<const float4 *>(src);
+        float4 *d4 = reinterpret_cast<float4 *>(rows);
+        for (size_t e = tid; e < nstage / 4; e += GP_THREADS) d4[e] = s4[e];
+    } else {
+        for (size_t e = tid; e < nstage; e += GP_THREADS) rows[e] = src[e];
+    }
+    __syncthreads();
+
+    const int *idx_b = idx + (size_t)b * npos;
+    float *out_b = out + ((size_t)b * c + c0) * npos;
+    if (VEC == 4) {
+        for (long long p = p0 + (long long)tid * 4; p < p1; p += GP_THREADS * 4) {
+            const int4 id = *reinterpret_cast<const int4 *>(idx_b + p);
+            for (int ch = 0; ch < ccv; ++ch) {
+                const float *row = rows + (size_t)ch * n;
+                float4 v = make_float4(row[id.x], row[id.y], row[id.z], row[id.w]);
+                *reinterpret_cast<float4 *>(out_b + (size_t)ch * npos + p) = v;
+            }
+        }
+    } else {
+        for (long long p = p0 + tid; p < p1; p += GP_THREADS) {
+            const int id = idx_b[p];
+            for (int ch = 0; ch < ccv; ++ch) out_b[(size_t)ch * npos + p] = rows[(size_t)ch * n + id];
+        }
+    }
+}
+
+// Rows too long for LDS staging (n*4 > budget): gather straight from global / L2.
+__global__ __launch_bounds__(GP_THREADS) void group_points_direct_kernel(int c, int n, long long npos,
+                                                                         const float *__restrict__ points,
+                                                                         const int *__restrict__ idx,
+                                                                         float *__restrict__ out) {
+    const int b = blockIdx.z;
+    const long long p = (long long)blockIdx.x * GP_THREADS + threadIdx.x;
+    if (p >= npos) return;
+    const int id = idx[(size_t)b * npos + p];
+    const float *src = points + (size_t)b * c * n;
+    float *dst = out + (size_t)b * c * npos;
+    for (int ch = blockIdx.y; ch < c; ch += gridDim.y) dst[(size_t)ch * npos + p] = src[(size_t)ch * n + id];
+}
+
+__global__ __launch_bounds__(GP_THREADS) void group_points_grad_kernel(int c, int n, long long npos,
+                                                                       const float *__restrict__ grad_out,
+                                                                       const int *__restrict__ idx,
+                                                                       float *__restrict__ grad_points) {
+    const int b = blockIdx.z;
+    const long long p = (long long)blockIdx.x * GP_THREADS + threadIdx.x;
+    if (p >= npos) return;
+    const int id = idx[(size_t)b * npos + p];
+    for (int ch = blockIdx.y; ch < c; ch += gridDim.y)
+        atomicAdd(grad_points + ((size_t)b * c + ch) * n + id, grad_out[((size_t)b * c + ch) * npos + p]);
+}
+
+int launch_group(int b, int c, int n, long long npos, const float *points, const int *idx, float *out,
+                 hipStream_t s) {
+    if (b < 0 || c < 0 || n < 0 || npos < 0) return -1;
+    if (b == 0 || c == 0 || npos == 0) return 0;
+    if (n == 0) return -1;
+    const size_t row_bytes = (size_t)n * sizeof(float);
+    if (row_bytes > (size_t)GP_LDS_BYTES) {
+        dim3 grid((unsigned)((npos + GP_THREADS - 1) / GP_THREADS), c < 64 ? c : 64, b);
+        CAPTRA_LAUNCH("group_points", group_points_direct_kernel, grid, dim3(GP_THREADS), 0, s, c, n, npos,
+                      points, idx, out);
+        return captra_last_error();
+    }
+    int cc = (int)(GP_LDS_BYTES / row_bytes);
+    if (cc > c) cc = c;
+    if (cc > 32) cc = 32;
+    dim3 grid((unsigned)((npos + GP_POS_PER_BLOCK - 1) / GP_POS_PER_BLOCK), (c + cc - 1) / cc, b);
+    size_t shmem = (size_t)cc * row_bytes;
+    const bool vec = (npos % 4 == 0) && ((reinterpret_cast<uintptr_t>(idx) & 15) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(group_points_kernel<4>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, GP_LDS_BYTES);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(group_points_kernel<1>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, GP_LDS_BYTES);
+        attr_set = true;
+    }
+    if (vec) {
+        CAPTRA_LAUNCH("group_points", group_points_kernel<4>, grid, dim3(GP_THREADS), shmem, s, c, n, npos, cc,
+                      points, idx, out);
+    } else {
+        CAPTRA_LAUNCH("group_points", group_points_kernel<1>, grid, dim3(GP_THREADS), shmem, s, c, n, npos, cc,
+                      points, idx, out);
+    }
+    return captra_last_error();
+}
+
+int launch_group_grad(int b, int c, int n, long long npos, const float *grad_out, const int *idx,
+                      float *grad_points, hipStream_t s) {
+    if (b < 0 || c < 0 || n < 0 || npos < 0) return -1;
+    if (b == 0 || c == 0 || npos == 0) return 0;
+    dim3 grid((unsigned)((npos + GP_THREADS - 1) / GP_THREADS), c < 64 ? c : 64, b);
+    CAPTRA_LAUNCH("group_points_grad", group_points_grad_kernel, grid, dim3(GP_THREADS), 0, s, c, n, npos,
+                  grad_out, idx, grad_points);
+    return captra_last_error();
+}
+
+}  // namespace
+
+extern "C" int captra_group_points(int b, int c, int n, int npoints, int nsample, const float *points,
+                                   const int *idx, float *out, captra_stream_t stream) {
+    return launch_group(b, c, n, (long long)npoints * nsample, points, idx, out, (hipStream_t)stream);
+}
+
+extern "C" int captra_group_points_grad(int b, int c, int n, int npoints, int nsample,
+                                        const float *grad_out, const int *idx, float *grad_points,
+                                        captra_stream_t stream) {
+    return launch_group_grad(b, c, n, (long long)npoints * nsample, grad_out, idx, grad_points,
+                             (hipStream_t)stream);
+}
+
+// gather = group with one sample per centre (out (B,C,npoints))
+extern "C" int captra_gather_points(int b, int c, int n, int npoints, const float *points, const int *idx,
+                                    float *out, captra_stream_t stream) {
+    return launch_group(b, c, n, (long long)npoints, points, idx, out, (hipStream_t)stream);
+}
+
+extern "C" int captra_gather_points_grad(int b, int c, int n, int npoints, const float *grad_out,
+                                         const int *idx, float *grad_points, captra_stream_t stream) {
+    return launch_group_grad(b, c, n, (long long)npoints, grad_out, idx, grad_points, (hipStream_t)stream);
+}

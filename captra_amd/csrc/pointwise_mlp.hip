@@ -1,0 +1,335 @@
+// Shared-MLP layers (1x1 conv + folded BatchNorm + activation) as exact-fp32 MFMA GEMMs on gfx950.
+//
+// Replaces the Conv2d/Conv1d(1x1) -> BatchNorm -> ReLU runs of the reference
+// (network/models/pointnet_utils.py:242-246, 296-298, 336-340; backbones.py:68), which the
+// reference executes as separate ATen kernels over a MATERIALISED grouped tensor.
+//
+// One kernel template, three operand-load prologues and two epilogues:
+//   PRO_PLAIN  x (B,cin,L) dense
+//   PRO_GROUP  x gathered on the fly through the ball-query index list, centre subtracted,
+//              [feat, xyz] concatenated — the (B,cin,M,K) grouped tensor is never written
+//              (replaces group_operation + '-=' + cat, pointnet_utils.py:234-240)
+//   EPI_STORE  y (B,cout,L) = act(acc)
+//   EPI_MAXK   y[b][co][m] = max over the K neighbours of relu(acc) — the last layer's (B,cout,M,K)
+//              activation is never written (replaces torch.max(-1), pointnet_utils.py:246)
+//
+// GEMM mapping: rows = output channels (A = W^T tile [k][co] in LDS), cols = positions
+// (B = X tile [k][pos] in LDS), v_mfma_f32_32x32x2_f32.  Both fragments are read with
+// conflict-free ds_read_b32 (lane l -> row k0+(l>>5), column base+(l&31)).
+// Arithmetic contract (include/captra_hip.h): acc = bias; acc = fmaf(W[co][k], x[k][pos], acc)
+// for k ascending — exactly what a chain of 32x32x2 f32 MFMAs computes — then the activation.
+// K is never split across waves, so the result is bit-identical to the oracle's fmaf loop.
+//
+// Pipeline: register-staged prefetch (global loads of chunk c+1 are issued before the MFMAs of
+// chunk c and written to LDS after them), 2-4 workgroups per CU for latency hiding.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int PW_THREADS = 256;
+constexpr int PW_BK = 32;
+
+enum { PRO_PLAIN = 0, PRO_GROUP = 1 };
+enum { EPI_STORE = 0, EPI_MAXK = 1 };
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_SIGMOID_M05 = 2 };
+
+struct PwParams {
+    int cin, cout;
+    long long L;          // positions per cloud (= M*K for grouped layers)
+    const float *x;       // PRO_PLAIN: (B,cin,L)
+    const float *wt;      // (cin,cout)
+    const float *bias;    // (cout)
+    float *y;
+    int act;
+    // PRO_GROUP
+    int n, m, k, cfeat;
+    const float *feat;    // (B,cfeat,N) or null
+    const float *xyz_cn;  // (B,3,N)
+    const float *new_xyz; // (B,M,3)
+    const int *idx;       // (B,M,K)
+    // EPI_MAXK
+    int y_ctotal, co_off; // y is (B,y_ctotal,M), this layer writes channels [co_off, co_off+cout)
+};
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == ACT_RELU) return v > 0.f ? v : 0.f;
+    if (act == ACT_SIGMOID_M05) return 1.0f / (1.0f + expf(-v)) - 0.5f;
+    return v;
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+// max over each row of 16 lanes, result in every lane of the row
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, dpp_f<0xB1>(v));
+    v = fmaxf(v, dpp_f<0x4E>(v));
+    v = fmaxf(v, dpp_f<0x141>(v));
+    v = fmaxf(v, dpp_f<0x140>(v));
+    return v;
+}
+
+// BM x BN output tile per workgroup, 4 waves arranged WGM x WGN, wave tile (TM*32) x (TN*32).
+template <int BM, int BN, int WGM, int WGN, int PRO, int EPI, bool VECX>
+__global__ __launch_bounds__(PW_THREADS) void pw_mlp_kernel(PwParams p) {
+    constexpr int TM = BM / WGM / 32;
+    constexpr int TN = BN / WGN / 32;
+    static_assert(WGM * WGN == 4, "4 waves");
+    static_assert(TM >= 1 && TN >= 1, "tile");
+    constexpr int XELEMS = PW_BK * BN / PW_THREADS;  // X floats staged per thread per chunk
+    constexpr int WELEMS = PW_BK * BM / PW_THREADS;  // W floats staged per thread per chunk
+
+    __shared__ __attribute__((aligned(16))) float Ws[PW_BK * BM];
+    __shared__ __attribute__((aligned(16))) float Xs[PW_BK * BN];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int b = blockIdx.z;
+    const int co0 = blockIdx.y * BM;
+    const long long pos0 = (long long)blockIdx.x * BN;
+
+    // ---- per-thread staging coordinates ------------------------------------------------------
+    // W tile: element e = tid + i*256 -> (row e / BM, col e % BM): consecutive threads = consecutive co
+    // X tile, scalar form: element e = tid + i*256 -> (row e / BN, col e % BN)
+    // X tile, vector form: float4 e = tid + i*256 -> (row e / (BN/4), col4 e % (BN/4))
+    float wreg[WELEMS];
+    float xreg[XELEMS];
+
+    // PRO_GROUP: BN is a multiple of 256 or divides it, so a thread's column is fixed
+    int g_id = 0;
+    float g_c[3] = {0.f, 0.f, 0.f};
+    bool g_live = false;
+    if (PRO == PRO_GROUP) {
+        const int col = tid % BN;
+        const long long pos = pos0 + col;
+        g_live = pos < p.L;
+        if (g_live) {
+            g_id = p.idx[(size_t)b * p.L + pos];
+            const int centre = (int)(pos / p.k);
+            const float *c = p.new_xyz + ((size_t)b * p.m + centre) * 3;
+            g_c[0] = c[0];
+            g_c[1] = c[1];
+            g_c[2] = c[2];
+        }
+    }
+
+    auto load_chunk = [&](int kc) {
+#pragma unroll
+        for (int i = 0; i < WELEMS; ++i) {
+            const int e = tid + i * PW_THREADS;
+            const int row = e / BM, col = e % BM;
+            const int kg = kc + row, co = co0 + col;
+            wreg[i] = (kg < p.cin && co < p.cout) ? p.wt[(size_t)kg * p.cout + co] : 0.f;
+        }
+        if (PRO == PRO_PLAIN) {
+            if (VECX) {
+#pragma unroll
+                for (int i = 0; i < XELEMS / 4; ++i) {
+                    const int e = tid + i * PW_THREADS;
+                    const int row = e / (BN / 4), c4 = e % (BN / 4);
+                    const int kg = kc + row;
+                    const long long pos = pos0 + c4 * 4;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (kg < p.cin && pos < p.L)  // L % 4 == 0: a float4 is all-in or all-out
+                        v = *reinterpret_cast<const float4 *>(p.x + ((size_t)b * p.cin + kg) * p.L + pos);
+                    xreg[i * 4 + 0] = v.x;
+                    xreg[i * 4 + 1] = v.y;
+                    xreg[i * 4 + 2] = v.z;
+                    xreg[i * 4 + 3] = v.w;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < XELEMS; ++i) {
+                    const int e = tid + i * PW_THREADS;
+                    const int row = e / BN, col = e % BN;
+                    const int kg = kc + row;
+                    const long long pos = pos0 + col;
+                    xreg[i] = (kg < p.cin && pos < p.L) ? p.x[((size_t)b * p.cin + kg) * p.L + pos] : 0.f;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < XELEMS; ++i) {
+                const int e = tid + i * PW_THREADS;
+                const int row = e / BN;
+                const int kg = kc + row;
+                float v = 0.f;
+                if (g_live) {
+                    if (kg < p.cfeat) {
+                        v = p.feat[((size_t)b * p.cfeat + kg) * p.n + g_id];
+                    } else if (kg < p.cfeat + 3) {
+                        const int a = kg - p.cfeat;
+                        const float ctr = a == 0 ? g_c[0] : (a == 1 ? g_c[1] : g_c[2]);
+                        v = p.xyz_cn[((size_t)b * 3 + a) * p.n + g_id] - ctr;
+                    }
+                }
+                xreg[i] = v;
+            }
+        }
+    };
+
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int i = 0; i < WELEMS; ++i) Ws[tid + i * PW_THREADS] = wreg[i];
+        if (PRO == PRO_PLAIN && VECX) {
+#pragma unroll
+            for (int i = 0; i < XELEMS / 4; ++i)
+                *reinterpret_cast<float4 *>(Xs + (size_t)(tid + i * PW_THREADS) * 4) =
+                    make_float4(xreg[i * 4], xreg[i * 4 + 1], xreg[i * 4 + 2], xreg[i * 4 + 3]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < XELEMS; ++i) Xs[tid + i * PW_THREADS] = xreg[i];
+        }
+    };
+
+    // ---- accumulators start at the bias (the fmaf chain's C input) ------------------------------
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = co0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const float bv = row < p.cout ? p.bias[row] : 0.f;
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) acc[tm][tn][r] = bv;
+        }
+    }
+
+    const int nchunks = (p.cin + PW_BK - 1) / PW_BK;
+    load_chunk(0);
+    for (int c = 0; c < nchunks; ++c) {
+        __syncthreads();  // previous chunk's MFMAs have consumed the LDS tiles
+        store_chunk();
+        __syncthreads();
+        if (c + 1 < nchunks) load_chunk((c + 1) * PW_BK);  // in flight during the MFMAs below
+        const int kleft = p.cin - c * PW_BK;
+        const int ksteps = kleft >= PW_BK ? PW_BK : ((kleft + 1) & ~1);
+        const float *wrow = Ws + (lane >> 5) * BM + wm * TM * 32 + (lane & 31);
+        const float *xrow = Xs + (lane >> 5) * BN + wn * TN * 32 + (lane & 31);
+        for (int kk = 0; kk < ksteps; kk += 2) {
+            float a[TM], bb[TN];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) a[tm] = wrow[kk * BM + tm * 32];
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) bb[tn] = xrow[kk * BN + tn * 32];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], bb[tn], acc[tm][tn], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue -------------------------------------------------------------------------------
+    if (EPI == EPI_STORE) {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                const long long col = pos0 + (wn * TN + tn) * 32 + (lane & 31);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = co0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (row < p.cout && col < p.L)
+                        p.y[((size_t)b * p.cout + row) * p.L + col] = apply_act(acc[tm][tn][r], p.act);
+                }
+            }
+    } else {
+        // max over groups of K consecutive positions; K % 32 == 0 and BN % K == 0 (host checks).
+        // Stage 1: per 32-position MFMA tile, reduce over the 32 lanes that hold one output row.
+        // Stage 2: combine the K/32 tiles of a group through LDS (reusing the X staging buffer).
+        __syncthreads();  // everyone is done reading Xs
+        float *red = Xs;  // [BM][BN/32]
+        constexpr int NT = BN / 32;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                const long long colbase = pos0 + (wn * TN + tn) * 32;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[tm][tn][r];
+                    v = v > 0.f ? v : 0.f;  // ReLU (the only activation followed by a max in the path)
+                    if (colbase + (lane & 31) >= p.L) v = 0.f;
+                    v = row16_max(v);
+                    v = fmaxf(v, __shfl_xor(v, 16, 64));
+                    if ((lane & 31) == 0) {
+                        const int rl = (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        red[rl * NT + wn * TN + tn] = v;
+                    }
+                }
+            }
+        __syncthreads();
+        const int tiles_per_group = p.k / 32;
+        const int groups = BN / p.k;
+        for (int e = tid; e < BM * groups; e += PW_THREADS) {
+            const int rl = e / groups, g = e % groups;
+            const int row = co0 + rl;
+            const long long centre = pos0 / p.k + g;
+            if (row < p.cout && centre < p.m) {
+                float v = red[rl * NT + g * tiles_per_group];
+                for (int t = 1; t < tiles_per_group; ++t) v = fmaxf(v, red[rl * NT + g * tiles_per_group + t]);
+                p.y[((size_t)b * p.y_ctotal + p.co_off + row) * p.m + centre] = v;
+            }
+        }
+    }
+}
+
+template <int PRO, int EPI, bool VECX>
+int launch_pw(int b, const PwParams &p, hipStream_t s, const char *name) {
+    // tile choice by output-channel count: wide tiles for wide layers, BN=256 for narrow ones
+    if (p.cout > 64) {
+        dim3 grid((unsigned)((p.L + 127) / 128), (p.cout + 127) / 128, b);
+        CAPTRA_LAUNCH(name, (pw_mlp_kernel<128, 128, 2, 2, PRO, EPI, VECX>), grid, dim3(PW_THREADS), 0, s, p);
+    } else if (p.cout > 32) {
+        dim3 grid((unsigned)((p.L + 255) / 256), (p.cout + 63) / 64, b);
+        CAPTRA_LAUNCH(name, (pw_mlp_kernel<64, 256, 1, 4, PRO, EPI, VECX>), grid, dim3(PW_THREADS), 0, s, p);
+    } else {
+        dim3 grid((unsigned)((p.L + 255) / 256), 1, b);
+        CAPTRA_LAUNCH(name, (pw_mlp_kernel<32, 256, 1, 4, PRO, EPI, VECX>), grid, dim3(PW_THREADS), 0, s, p);
+    }
+    return captra_last_error();
+}
+
+}  // namespace
+
+extern "C" int captra_pointwise_mlp(int b, int cin, int cout, long long l, const float *x, const float *wt,
+                                    const float *bias, int act, float *y, captra_stream_t stream) {
+    if (b < 0 || cin < 1 || cout < 1 || l < 0 || act < 0 || act > 2) return -1;
+    if (b == 0 || l == 0) return 0;
+    PwParams p = {};
+    p.cin = cin; p.cout = cout; p.L = l; p.x = x; p.wt = wt; p.bias = bias; p.y = y; p.act = act;
+    const bool vec = (l % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+    if (vec) return launch_pw<PRO_PLAIN, EPI_STORE, true>(b, p, (hipStream_t)stream, "pointwise_mlp");
+    return launch_pw<PRO_PLAIN, EPI_STORE, false>(b, p, (hipStream_t)stream, "pointwise_mlp");
+}
+
+extern "C" int captra_sa_group_mlp(int b, int n, int m, int k, int cfeat, int cout, const float *feat,
+                                   const float *xyz_cn, const float *new_xyz, const int *idx, const float *wt,
+                                   const float *bias, float *y, captra_stream_t stream) {
+    if (b < 0 || n < 1 || m < 0 || k < 1 || cfeat < 0 || cout < 1) return -1;
+    if (cfeat > 0 && feat == nullptr) return -1;
+    if (b == 0 || m == 0) return 0;
+    PwParams p = {};
+    p.cin = cfeat + 3; p.cout = cout; p.L = (long long)m * k; p.wt = wt; p.bias = bias; p.y = y; p.act = ACT_RELU;
+    p.n = n; p.m = m; p.k = k; p.cfeat = cfeat; p.feat = feat; p.xyz_cn = xyz_cn; p.new_xyz = new_xyz; p.idx = idx;
+    return launch_pw<PRO_GROUP, EPI_STORE, false>(b, p, (hipStream_t)stream, "sa_group_mlp");
+}
+
+extern "C" int captra_mlp_max(int b, int cin, int cout, int m, int k, const float *x, const float *wt,
+                              const float *bias, float *y, int y_ctotal, int co_off, captra_stream_t stream) {
+    if (b < 0 || cin < 1 || cout < 1 || m < 0 || k < 1 || y_ctotal < co_off + cout || co_off < 0) return -1;
+    if (k % 32 != 0 || 128 % k != 0) return -2;  // fused max needs K in {32, 64, 128}
+    if (b == 0 || m == 0) return 0;
+    PwParams p = {};
+    p.cin = cin; p.cout = cout; p.L = (long long)m * k; p.x = x; p.wt = wt; p.bias = bias; p.y = y; p.act = ACT_RELU;
+    p.m = m; p.k = k; p.y_ctotal = y_ctotal; p.co_off = co_off;
+    const bool vec = ((reinterpret_cast<uintptr_t>(x) & 15) == 0);  // L = m*k is a multiple of 32
+    if (vec) return launch_pw<PRO_PLAIN, EPI_MAXK, true>(b, p, (hipStream_t)stream, "mlp_max");
+    return launch_pw<PRO_PLAIN, EPI_MAXK, false>(b, p, (hipStream_t)stream, "mlp_max");
+}

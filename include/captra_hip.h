@@ -1,0 +1,174 @@
+/*
+ * captra_hip.h — C ABI of libcaptra_hip.so, the MI355X (gfx950 / CDNA4) implementation of
+ * CAPTRA's per-frame point-cloud hot path.
+ *
+ * Every entry point takes plain device pointers, sizes and a HIP stream; nothing here knows
+ * about torch.  Each function states which interface of the reference it replaces
+ * (paths relative to the reference checkout, network/models/pointnet_lib/src/ unless noted).
+ *
+ * Conventions
+ *   - all tensors are dense, row-major, fp32 / int32, resident in device memory;
+ *   - the caller owns every buffer (outputs and scratch included), the callee only writes;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); launches are
+ *     asynchronous, no entry point synchronises;
+ *   - the return value is a hipError_t as int: 0 on success.  Nothing ever calls exit()
+ *     (the reference launchers do, e.g. ball_query_gpu.cu:62-66);
+ *   - 64-bit offset arithmetic throughout (the reference uses int and overflows past 2^31
+ *     elements).
+ */
+#ifndef CAPTRA_HIP_H
+#define CAPTRA_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *captra_stream_t; /* hipStream_t */
+
+/* ------------------------------------------------------------------------------------------
+ * Section 1 — the ten pointnet2_cuda operators (pointnet2_api.cpp:10-25)
+ * ---------------------------------------------------------------------------------------- */
+
+/* Replaces furthest_point_sampling_wrapper (sampling.cpp:38-49, kernel sampling_gpu.cu:93-209).
+ * xyz (B,N,3) f32; temp (B,N) f32 running min-distance, pre-filled by the caller (1e10,
+ * pointnet2_utils.py:27) and left holding the final min distances; idx (B,M) i32.
+ * idx[:,0] = 0; round j picks argmax_k temp[k] with strict '>' and LOWEST index on ties
+ * (SURVEY.md §8 a1 contract); distance = ((dx*dx + dy*dy) + dz*dz), unfused fp32. */
+int captra_furthest_point_sampling(int b, int n, int m, const float *xyz, float *temp, int *idx,
+                                   captra_stream_t stream);
+
+/* Replaces ball_query_wrapper (ball_query.cpp:14-25, kernel ball_query_gpu.cu:9-45).
+ * new_xyz (B,M,3), xyz (B,N,3) f32 -> idx (B,M,nsample) i32: the first `nsample` points k
+ * (ascending k) with ((cx-x)^2 + (cy-y)^2) + (cz-z)^2 < radius*radius (strict), remaining
+ * slots filled with the first hit; a ball with no hit is written as all zeros (the reference
+ * leaves the caller's pre-zeroed buffer untouched, pointnet2_utils.py:261). */
+int captra_ball_query(int b, int n, int m, float radius, int nsample, const float *new_xyz,
+                      const float *xyz, int *idx, captra_stream_t stream);
+
+/* Replaces group_points_wrapper (group_points.cpp:25-36, kernel group_points_gpu.cu:47-66).
+ * points (B,C,N) f32, idx (B,npoints,nsample) i32 -> out (B,C,npoints,nsample). */
+int captra_group_points(int b, int c, int n, int npoints, int nsample, const float *points,
+                        const int *idx, float *out, captra_stream_t stream);
+
+/* Replaces group_points_grad_wrapper (group_points.cpp:11-22, kernel group_points_gpu.cu:8-25).
+ * grad_out (B,C,npoints,nsample), idx -> grad_points (B,C,N) += scatter (caller pre-zeroes). */
+int captra_group_points_grad(int b, int c, int n, int npoints, int nsample, const float *grad_out,
+                             const int *idx, float *grad_points, captra_stream_t stream);
+
+/* Replaces gather_points_wrapper (sampling.cpp:11-21, kernel sampling_gpu.cu:8-24).
+ * points (B,C,N), idx (B,npoints) -> out (B,C,npoints). */
+int captra_gather_points(int b, int c, int n, int npoints, const float *points, const int *idx,
+                         float *out, captra_stream_t stream);
+
+/* Replaces gather_points_grad_wrapper (sampling.cpp:24-35, kernel sampling_gpu.cu:46-63). */
+int captra_gather_points_grad(int b, int c, int n, int npoints, const float *grad_out,
+                              const int *idx, float *grad_points, captra_stream_t stream);
+
+/* Replaces knn_wrapper (interpolate.cpp:26-36, kernel interpolate_gpu.cu:9-57).
+ * unknown (B,N,3), known (B,M,3) -> dist2 (B,N,k) squared distances ascending, idx (B,N,k);
+ * strict '<' insertion, so the lower index wins ties.  1 <= k <= 200 (reference limit). */
+int captra_knn(int b, int n, int m, int k, const float *unknown, const float *known, float *dist2,
+               int *idx, captra_stream_t stream);
+
+/* Replaces three_nn_wrapper (interpolate.cpp:14-24, kernel interpolate_gpu.cu:81-124).
+ * unknown (B,N,3), known (B,M,3) -> dist2 (B,N,3) SQUARED distances, idx (B,N,3). */
+int captra_three_nn(int b, int n, int m, const float *unknown, const float *known, float *dist2,
+                    int *idx, captra_stream_t stream);
+
+/* Replaces three_interpolate_wrapper (interpolate.cpp:39-53, kernel interpolate_gpu.cu:149-169).
+ * points (B,C,M), idx (B,N,3), weight (B,N,3) -> out (B,C,N) = (w0*p0 + w1*p1) + w2*p2. */
+int captra_three_interpolate(int b, int c, int m, int n, const float *points, const int *idx,
+                             const float *weight, float *out, captra_stream_t stream);
+
+/* Replaces three_interpolate_grad_wrapper (interpolate.cpp:55-68, kernel interpolate_gpu.cu:192-214).
+ * grad_out (B,C,N), idx, weight (B,N,3) -> grad_points (B,C,M) += scatter (caller pre-zeroes). */
+int captra_three_interpolate_grad(int b, int c, int n, int m, const float *grad_out, const int *idx,
+                                  const float *weight, float *grad_points, captra_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Section 2 — fused operators of the tracking path (no single reference kernel; each replaces
+ * a run of ATen ops in network/models/pointnet_utils.py, networks.py, pose_utils/procrustes.py)
+ * ---------------------------------------------------------------------------------------- */
+
+/* Canonicalise clouds with the previous pose: out = R^T ((pts + mean) - t) / s
+ * (networks.py:38-41 and 184-187).  pts (B,3,N) channel-major as the track loop holds it;
+ * mean (B,3); rot (B*P,3,3); trans (B*P,3); scale (B*P); cloud q = b*P + p reads pts[b].
+ * Writes out_cn (B*P,3,N) channel-major (network input) and out_n3 (B*P,N,3) point-major
+ * (what FPS / ball query / three_nn consume).  Either output may be NULL. */
+int captra_canonicalize(int b, int p, int n, const float *pts, const float *mean, const float *rot,
+                        const float *trans, const float *scale, float *out_cn, float *out_n3,
+                        captra_stream_t stream);
+
+/* Ball query for up to 4 radii in ONE scan of xyz (PointNetSetAbstractionMsg's loop over
+ * radius_list, pointnet_utils.py:228-233).  idx_r (r = 0..nr-1) is (B,M,nsample[r]) i32 with
+ * exactly the contents captra_ball_query(radius[r], nsample[r]) would produce. */
+int captra_ball_query_multi(int b, int n, int m, int nr, const float *radius, const int *nsample,
+                            const float *new_xyz, const float *xyz, int *const *idx,
+                            captra_stream_t stream);
+
+/* One shared-MLP layer, y = act(W x + bias), as an exact-fp32 MFMA GEMM over positions
+ * (Conv2d/Conv1d 1x1 + folded BatchNorm + ReLU, pointnet_utils.py:242-245, 296-298).
+ *   x (B, cin, L) f32, wt (cin, cout) f32 = W^T with BN folded in, bias (cout) -> y (B, cout, L).
+ *   act: 0 none, 1 ReLU, 2 sigmoid(x) - 0.5 (networks.py:46).
+ * Arithmetic contract: acc = bias; for k in 0..cin-1: acc = fmaf(W[co][k], x[k][l], acc)
+ * (what v_mfma_f32_32x32x2_f32 computes), then the activation. */
+int captra_pointwise_mlp(int b, int cin, int cout, long long l, const float *x, const float *wt,
+                         const float *bias, int act, float *y, captra_stream_t stream);
+
+/* First layer of a set-abstraction scale with the group-and-concat fused into the operand load
+ * (group_operation + "-= centre" + cat, pointnet_utils.py:234-240):
+ *   x[b][ci][m][k] = feat[b][ci][idx[b][m][k]]                 for ci <  cfeat
+ *                  = xyz_cn[b][ci-cfeat][idx] - new_xyz[b][m]   for ci >= cfeat   (3 channels)
+ * feat (B,cfeat,N) or NULL when cfeat == 0; xyz_cn (B,3,N); new_xyz (B,M,3); idx (B,M,K).
+ * y (B,cout,M,K) = relu(W x + bias), same arithmetic contract as captra_pointwise_mlp. */
+int captra_sa_group_mlp(int b, int n, int m, int k, int cfeat, int cout, const float *feat,
+                        const float *xyz_cn, const float *new_xyz, const int *idx, const float *wt,
+                        const float *bias, float *y, captra_stream_t stream);
+
+/* Last layer of a set-abstraction scale with the max over the K neighbours fused into the
+ * epilogue (pointnet_utils.py:245-246): x (B,cin,M,K) -> y[b][co_off+co][m] =
+ * max_k relu(W x + bias), y being (B, y_ctotal, M) so that the scales of one SA level write
+ * straight into the concatenated tensor (pointnet_utils.py:249). */
+int captra_mlp_max(int b, int cin, int cout, int m, int k, const float *x, const float *wt,
+                   const float *bias, float *y, int y_ctotal, int co_off, captra_stream_t stream);
+
+/* Feature propagation input: three_nn + inverse-distance weights + three_interpolate + concat
+ * (pointnet_utils.py:280-294, CUDA semantics: weights from sqrt(d2)).
+ * unknown (B,N,3), known (B,S,3), feat_known (B,c2,S), skip (B,c1,N) or NULL ->
+ * out (B,c1+c2,N) = cat([skip, interpolated]). */
+int captra_fp_interpolate_concat(int b, int n, int s, int c1, int c2, const float *unknown,
+                                 const float *known, const float *skip, const float *feat_known,
+                                 float *out, captra_stream_t stream);
+
+/* Masked Procrustes scale + translation fit for all (trajectory, part) pairs on device
+ * (part_fit_st_no_ransac pose_fit.py:38-53 -> transform_pts_mask procrustes.py:132-164 with a
+ * given rotation; sym adds the in-plane 2x2 SVD of procrustes.py:167-228).  No host round trip.
+ *   labels (B,N) i32 (values >= P are background); src = predicted NOCS (B,P,3,N) channel-major;
+ *   tgt = camera points (B,3,N); rot (B,P,3,3).
+ *   -> scale (B,P), trans (B,P,3), valid (B,P) i32 = (count > 3) && finite(scale, trans). */
+int captra_part_fit_st(int b, int p, int n, int sym, const int *labels, const float *src,
+                       const float *tgt, const float *rot, float *scale, float *trans, int *valid,
+                       captra_stream_t stream);
+
+/* Batched 3x3 orthogonal Procrustes: R = U diag(1,1,det(U V^T)) V^T with U S V^T = tgt^T src
+ * (rotate_pts_batch procrustes.py:25-56).  src, tgt (nb,N,3) -> rot (nb,3,3).  One-sided Jacobi. */
+int captra_procrustes_rot3(int nb, int n, const float *src, const float *tgt, float *rot,
+                           captra_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Section 3 — introspection
+ * ---------------------------------------------------------------------------------------- */
+const char *captra_error_string(int err);
+const char *captra_version(void);
+/* Per-kernel HIP-event timing: when enabled every launcher brackets its kernel with events on
+ * its own stream.  captra_prof_read synchronises the recorded events and returns accumulated
+ * milliseconds / launch count for `name` (the kernel family, e.g. "ball_query"). */
+void captra_prof_enable(int on);
+void captra_prof_reset(void);
+int captra_prof_read(const char *name, double *total_ms, long long *launches);
+int captra_prof_names(char *buf, int buflen);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CAPTRA_HIP_H */

@@ -1,0 +1,69 @@
+"""Seeded synthetic clouds shared by tests, golden generation and bench.py."""
+from __future__ import annotations
+
+import numpy as np
+
+
+def s_nocs(i: int, n_obj: int = 3277, n_bg: int = 819):
+    """S-nocs(seed): y-axis cylinder (r=0.18, h=0.90, caps, area-uniform, jitter 0.003) labelled 0
+    plus background points in the ball |x|<0.6 with y<-0.45 labelled 1; random permutation;
+    mean-subtracted.  Returns (points (N,3) f32, labels (N,) i64, mean (3,) f32)."""
+    rng = np.random.default_rng(1000 + i)
+    r, h = 0.18, 0.90
+    a_side, a_cap = 2 * np.pi * r * h, np.pi * r * r
+    p_side = a_side / (a_side + 2 * a_cap)
+    u = rng.random(n_obj)
+    which = np.where(u < p_side, 0, np.where(u < p_side + (1 - p_side) / 2, 1, 2))
+    th = rng.random(n_obj) * 2 * np.pi
+    rad = np.where(which == 0, r, r * np.sqrt(rng.random(n_obj)))
+    y = np.where(which == 0, (rng.random(n_obj) - 0.5) * h, np.where(which == 1, h / 2, -h / 2))
+    obj = np.stack([rad * np.cos(th), y, rad * np.sin(th)], -1) + rng.normal(0, 0.003, (n_obj, 3))
+    bg = []
+    while len(bg) < n_bg:
+        c = (rng.random((4 * n_bg, 3)) * 2 - 1) * 0.6
+        c = c[(np.linalg.norm(c, axis=1) < 0.6) & (c[:, 1] < -0.45)]
+        bg.extend(c.tolist())
+    bg = np.asarray(bg[:n_bg])
+    pts = np.concatenate([obj, bg], 0).astype(np.float32)
+    lab = np.concatenate([np.zeros(n_obj, np.int64), np.ones(n_bg, np.int64)])
+    perm = rng.permutation(len(pts))
+    pts, lab = pts[perm], lab[perm]
+    mean = pts.mean(0, keepdims=True).astype(np.float32)
+    return (pts - mean).astype(np.float32), lab, mean[0]
+
+
+def s_nocs_dup(i: int, n_unique: int = 3000, n: int = 4096):
+    """S-nocs-dup: n_unique points of S-nocs tiled up to n (mirrors nocs_data_process.py:105-106)."""
+    pts, lab, mean = s_nocs(i)
+    idx = np.arange(n_unique)
+    while len(idx) < n:
+        idx = np.concatenate([idx, idx])
+    idx = idx[:n]
+    return pts[idx], lab[idx], mean
+
+
+def s_arti(i: int, parts: int = 4, per_part: int = 1024):
+    """S-arti(seed): `parts` boxes of per_part surface-ish points each, labels 0..parts-1."""
+    rng = np.random.default_rng(2000 + i)
+    pts, lab = [], []
+    for p in range(parts):
+        size = np.array([0.5, 0.12, 0.4]) * (0.8 + 0.4 * rng.random(3))
+        centre = np.array([0.0, -0.3 + 0.2 * p, 0.05 * p])
+        q = (rng.random((per_part, 3)) - 0.5) * size
+        face = rng.integers(0, 3, per_part)
+        sign = rng.integers(0, 2, per_part) * 2 - 1
+        q[np.arange(per_part), face] = sign * size[face] / 2
+        pts.append(q + centre)
+        lab.append(np.full(per_part, p, np.int64))
+    pts = np.concatenate(pts).astype(np.float32)
+    lab = np.concatenate(lab)
+    perm = rng.permutation(len(pts))
+    pts, lab = pts[perm], lab[perm]
+    mean = pts.mean(0, keepdims=True).astype(np.float32)
+    return (pts - mean).astype(np.float32), lab, mean[0]
+
+
+def s_uni(i: int, n: int = 16384):
+    """S-uni16k(seed): n points uniform in [-0.5,0.5]^3."""
+    rng = np.random.default_rng(3000 + i)
+    return (rng.random((n, 3), dtype=np.float32) - 0.5).astype(np.float32)

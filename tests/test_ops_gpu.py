@@ -1,0 +1,250 @@
+"""Parity of the ten pointnet2_cuda operators (HIP, through the C ABI) against the CPU oracle.
+
+Bit-exact for index outputs (FPS, ball query, three_nn idx, knn idx) and for pure copies
+(group, gather); exact-equal for squared distances and interpolation as well, since both sides
+evaluate the same separately-rounded fp32 expression.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ops as O
+from tests import clouds
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pn(device):
+    from captra_amd.pointnet_lib import pointnet2_utils as pn
+    return pn
+
+
+def _dev(a, device):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+
+
+def _nocs_batch(ids, dup=False):
+    fn = clouds.s_nocs_dup if dup else clouds.s_nocs
+    return np.stack([fn(i)[0] for i in ids]).astype(np.float32)
+
+
+# ------------------------------------------------------------------------------------------ FPS
+@pytest.mark.parametrize("n,m", [(4096, 512), (512, 128), (4096, 1), (100, 37), (64, 64), (1000, 300), (5000, 64)])
+def test_fps_uniform(pn, device, n, m):
+    rng = np.random.default_rng(n * 7 + m)
+    xyz = (rng.random((3, n, 3), dtype=np.float32) - 0.5).astype(np.float32)
+    got = pn.furthest_point_sample(_dev(xyz, device), m).cpu().numpy()
+    ref = O.furthest_point_sample(xyz, m)
+    assert got.dtype == np.int32
+    np.testing.assert_array_equal(got, ref)
+
+
+def test_fps_nocs_and_duplicates(pn, device):
+    xyz = np.concatenate([_nocs_batch(range(4)), _nocs_batch(range(4), dup=True)])
+    got = pn.furthest_point_sample(_dev(xyz, device), 512).cpu().numpy()
+    np.testing.assert_array_equal(got, O.furthest_point_sample(xyz, 512))
+
+
+def test_fps_all_points_identical(pn, device):
+    xyz = np.full((2, 777, 3), 0.25, np.float32)
+    got = pn.furthest_point_sample(_dev(xyz, device), 16).cpu().numpy()
+    np.testing.assert_array_equal(got, O.furthest_point_sample(xyz, 16))
+    assert (got == 0).all()  # every distance is 0: the lowest index wins every round
+
+
+@pytest.mark.parametrize("waves", [1, 2, 4, 8, 16])
+def test_fps_every_wave_configuration(pn, device, waves):
+    import ctypes
+    from captra_amd import _lib
+    xyz = _nocs_batch(range(2))
+    ref = O.furthest_point_sample(xyz, 128)
+    _lib.lib().captra_fps_set_waves(ctypes.c_int(waves))
+    try:
+        got = pn.furthest_point_sample(_dev(xyz, device), 128).cpu().numpy()
+    finally:
+        _lib.lib().captra_fps_set_waves(ctypes.c_int(0))
+    np.testing.assert_array_equal(got, ref)
+
+
+def test_fps_big_cloud_fallback(pn, device):
+    xyz = clouds.s_uni(0, 40000)[None]
+    got = pn.furthest_point_sample(_dev(xyz, device), 64).cpu().numpy()
+    np.testing.assert_array_equal(got, O.furthest_point_sample(xyz, 64))
+
+
+def test_fps_temp_is_left_with_min_distances(device):
+    from captra_amd import pointnet2_cuda
+    xyz = _nocs_batch(range(2))
+    B, N, _ = xyz.shape
+    temp = torch.full((B, N), 1e10, device=device)
+    idx = torch.empty(B, 64, dtype=torch.int32, device=device)
+    pointnet2_cuda.furthest_point_sampling_wrapper(B, N, 64, _dev(xyz, device), temp, idx)
+    t_ref = np.full((B, N), 1e10, np.float32)
+    O.furthest_point_sample(xyz, 64, temp=t_ref)
+    np.testing.assert_array_equal(temp.cpu().numpy(), t_ref)
+
+
+# ----------------------------------------------------------------------------------- ball query
+SA_PAIRS = [(0.05, 32), (0.1, 64), (0.2, 128)]
+
+
+@pytest.mark.parametrize("radius,k", SA_PAIRS)
+def test_ball_query_sa1(pn, device, radius, k):
+    xyz = _nocs_batch(range(3))
+    centres = O.furthest_point_sample(xyz, 512)
+    new_xyz = np.take_along_axis(xyz, centres[..., None].astype(np.int64), 1)
+    got = pn.ball_query(radius, k, _dev(xyz, device), _dev(new_xyz, device)).cpu().numpy()
+    np.testing.assert_array_equal(got, O.ball_query(radius, k, xyz, new_xyz))
+
+
+@pytest.mark.parametrize("radius,k", [(0.2, 64), (0.4, 128)])
+def test_ball_query_sa2(pn, device, radius, k):
+    xyz = _nocs_batch(range(3))
+    l1 = O.furthest_point_sample(xyz, 512)
+    xyz1 = np.take_along_axis(xyz, l1[..., None].astype(np.int64), 1)
+    l2 = O.furthest_point_sample(xyz1, 128)
+    xyz2 = np.take_along_axis(xyz1, l2[..., None].astype(np.int64), 1)
+    got = pn.ball_query(radius, k, _dev(xyz1, device), _dev(xyz2, device)).cpu().numpy()
+    np.testing.assert_array_equal(got, O.ball_query(radius, k, xyz1, xyz2))
+
+
+@pytest.mark.parametrize("n,m,k,radius", [(1, 1, 4, 0.5), (63, 5, 7, 0.3), (65, 33, 1, 0.2), (1000, 37, 200, 0.6),
+                                            (9000, 40, 16, 0.05), (20000, 20, 300, 0.2)])
+def test_ball_query_ragged_and_multi_tile(pn, device, n, m, k, radius):
+    rng = np.random.default_rng(n + m)
+    xyz = (rng.random((2, n, 3), dtype=np.float32) - 0.5).astype(np.float32)
+    new_xyz = (rng.random((2, m, 3), dtype=np.float32) - 0.5).astype(np.float32)
+    got = pn.ball_query(radius, k, _dev(xyz, device), _dev(new_xyz, device)).cpu().numpy()
+    np.testing.assert_array_equal(got, O.ball_query(radius, k, xyz, new_xyz))
+
+
+def test_ball_query_empty_balls_are_zero(pn, device):
+    xyz = _nocs_batch(range(1))
+    new_xyz = np.full((1, 9, 3), 5.0, np.float32)  # far from every point
+    idx = pn.ball_query(0.1, 16, _dev(xyz, device), _dev(new_xyz, device)).cpu().numpy()
+    assert (idx == 0).all()
+
+
+def test_ball_query_multi_radius_equals_single(device):
+    import ctypes
+    from captra_amd import _lib
+    xyz = _nocs_batch(range(2))
+    centres = O.furthest_point_sample(xyz, 512)
+    new_xyz = np.take_along_axis(xyz, centres[..., None].astype(np.int64), 1)
+    d_xyz, d_new = _dev(xyz, device), _dev(new_xyz, device)
+    outs = [torch.full((2, 512, k), -1, dtype=torch.int32, device=device) for _, k in SA_PAIRS]
+    radii = (ctypes.c_float * 3)(*[r for r, _ in SA_PAIRS])
+    ns = (ctypes.c_int * 3)(*[k for _, k in SA_PAIRS])
+    ptrs = (ctypes.c_void_p * 3)(*[o.data_ptr() for o in outs])
+    _lib.call("captra_ball_query_multi", 2, 4096, 512, 3, ctypes.cast(radii, ctypes.c_void_p),
+              ctypes.cast(ns, ctypes.c_void_p), d_new.data_ptr(), d_xyz.data_ptr(), ctypes.cast(ptrs, ctypes.c_void_p))
+    for o, (r, k) in zip(outs, SA_PAIRS):
+        np.testing.assert_array_equal(o.cpu().numpy(), O.ball_query(r, k, xyz, new_xyz))
+
+
+# -------------------------------------------------------------------------------- group / gather
+@pytest.mark.parametrize("c,n,m,k", [(3, 4096, 512, 32), (6, 4096, 512, 128), (323, 512, 128, 64), (5, 100, 7, 3),
+                                       (2, 20000, 16, 8), (40, 512, 128, 128)])
+def test_group_points(pn, device, c, n, m, k):
+    rng = np.random.default_rng(c + n)
+    feat = rng.standard_normal((2, c, n)).astype(np.float32)
+    idx = rng.integers(0, n, (2, m, k)).astype(np.int32)
+    got = pn.grouping_operation(_dev(feat, device), _dev(idx, device)).cpu().numpy()
+    np.testing.assert_array_equal(got, O.grouping_operation(feat, idx))
+
+
+def test_gather_points(pn, device):
+    rng = np.random.default_rng(5)
+    feat = rng.standard_normal((3, 7, 4096)).astype(np.float32)
+    idx = rng.integers(0, 4096, (3, 511)).astype(np.int32)
+    got = pn.gather_operation(_dev(feat, device), _dev(idx, device)).cpu().numpy()
+    np.testing.assert_array_equal(got, O.gather_operation(feat, idx))
+
+
+def test_group_and_gather_grad(pn, device):
+    rng = np.random.default_rng(6)
+    feat = torch.from_numpy(rng.standard_normal((2, 5, 300)).astype(np.float32)).to(device).requires_grad_()
+    idx = rng.integers(0, 300, (2, 17, 9)).astype(np.int32)
+    g = rng.standard_normal((2, 5, 17, 9)).astype(np.float32)
+    out = pn.grouping_operation(feat, _dev(idx, device))
+    out.backward(_dev(g, device))
+    np.testing.assert_allclose(feat.grad.cpu().numpy(), O.grouping_operation_grad(g, idx, 300), rtol=1e-5, atol=1e-5)
+
+    feat2 = torch.from_numpy(rng.standard_normal((2, 5, 300)).astype(np.float32)).to(device).requires_grad_()
+    idx2 = rng.integers(0, 300, (2, 40)).astype(np.int32)
+    g2 = rng.standard_normal((2, 5, 40)).astype(np.float32)
+    pn.gather_operation(feat2, _dev(idx2, device)).backward(_dev(g2, device))
+    np.testing.assert_allclose(feat2.grad.cpu().numpy(), O.gather_operation_grad(g2, idx2, 300), rtol=1e-5, atol=1e-5)
+
+
+# ----------------------------------------------------------------------- three_nn / interpolate
+@pytest.mark.parametrize("n,m", [(512, 128), (4096, 512), (100, 3), (70, 2), (5000, 4500)])
+def test_three_nn(pn, device, n, m):
+    rng = np.random.default_rng(n + m)
+    unknown = (rng.random((2, n, 3), dtype=np.float32) - 0.5).astype(np.float32)
+    known = (rng.random((2, m, 3), dtype=np.float32) - 0.5).astype(np.float32)
+    dist, idx = pn.three_nn(_dev(unknown, device), _dev(known, device))
+    d2_ref, idx_ref = O.three_nn(unknown, known)
+    assert idx.dtype == torch.int32
+    np.testing.assert_array_equal(idx.cpu().numpy(), idx_ref)
+    np.testing.assert_allclose(dist.cpu().numpy(), np.sqrt(d2_ref), rtol=2e-7, atol=0)  # op layer returns sqrt
+    # the kernel itself writes squared distances: exact
+    from captra_amd import pointnet2_cuda
+    d2 = torch.empty(2, n, 3, device=device)
+    ii = torch.empty(2, n, 3, dtype=torch.int32, device=device)
+    pointnet2_cuda.three_nn_wrapper(2, n, m, _dev(unknown, device), _dev(known, device), d2, ii)
+    np.testing.assert_array_equal(d2.cpu().numpy(), d2_ref)
+
+
+def test_three_nn_subset_known_has_zero_distance_first(pn, device):
+    xyz = _nocs_batch(range(2))
+    l1 = O.furthest_point_sample(xyz, 512)
+    xyz1 = np.take_along_axis(xyz, l1[..., None].astype(np.int64), 1)
+    dist, idx = pn.three_nn(_dev(xyz, device), _dev(xyz1, device))
+    d2_ref, idx_ref = O.three_nn(xyz, xyz1)
+    np.testing.assert_array_equal(idx.cpu().numpy(), idx_ref)
+    np.testing.assert_allclose(dist.cpu().numpy(), np.sqrt(d2_ref), rtol=2e-7, atol=0)
+
+
+@pytest.mark.parametrize("k", [1, 3, 16, 200])
+def test_knn(pn, device, k):
+    rng = np.random.default_rng(k)
+    unknown = (rng.random((2, 300, 3), dtype=np.float32) - 0.5).astype(np.float32)
+    known = (rng.random((2, 257, 3), dtype=np.float32) - 0.5).astype(np.float32)
+    dist, idx = pn.knn(k, _dev(unknown, device), _dev(known, device))
+    d2_ref, idx_ref = O.knn(k, unknown, known)
+    np.testing.assert_array_equal(idx.cpu().numpy(), idx_ref)
+    np.testing.assert_allclose(dist.cpu().numpy(), np.sqrt(d2_ref), rtol=2e-7, atol=0)
+
+
+@pytest.mark.parametrize("c,m,n", [(256, 128, 512), (128, 512, 4096), (3, 5, 11), (70, 20000, 300)])
+def test_three_interpolate(pn, device, c, m, n):
+    rng = np.random.default_rng(c + m + n)
+    feat = rng.standard_normal((2, c, m)).astype(np.float32)
+    idx = rng.integers(0, m, (2, n, 3)).astype(np.int32)
+    w = rng.random((2, n, 3), dtype=np.float32)
+    w /= w.sum(-1, keepdims=True)
+    got = pn.three_interpolate(_dev(feat, device), _dev(idx, device), _dev(w, device)).cpu().numpy()
+    np.testing.assert_array_equal(got, O.three_interpolate(feat, idx, w))
+
+
+def test_three_interpolate_grad(pn, device):
+    rng = np.random.default_rng(9)
+    feat = torch.from_numpy(rng.standard_normal((2, 6, 50)).astype(np.float32)).to(device).requires_grad_()
+    idx = rng.integers(0, 50, (2, 80, 3)).astype(np.int32)
+    w = rng.random((2, 80, 3), dtype=np.float32)
+    g = rng.standard_normal((2, 6, 80)).astype(np.float32)
+    pn.three_interpolate(feat, _dev(idx, device), _dev(w, device)).backward(_dev(g, device))
+    np.testing.assert_allclose(feat.grad.cpu().numpy(), O.three_interpolate_grad(g, idx, w, 50), rtol=1e-5, atol=1e-5)
+
+
+# -------------------------------------------------------------------------------------- errors
+def test_cpu_tensor_is_rejected_loudly(pn):
+    with pytest.raises(RuntimeError):
+        pn.furthest_point_sample(torch.zeros(1, 10, 3), 2)
+
+
+def test_bad_k_raises(pn, device):
+    with pytest.raises(RuntimeError):
+        pn.knn(201, torch.zeros(1, 4, 3, device=device), torch.zeros(1, 4, 3, device=device))
