@@ -37,7 +37,7 @@ _SIGNATURES = {
     "captra_sa_group_mlp": [_INT, _INT, _INT, _INT, _INT, _INT, _P, _P, _P, _P, _P, _P, _P, _P],
     "captra_mlp_max": [_INT, _INT, _INT, _INT, _INT, _P, _P, _P, _P, _INT, _INT, _P],
     "captra_fp_interpolate_concat": [_INT, _INT, _INT, _INT, _INT, _P, _P, _P, _P, _P, _P],
-    "captra_part_fit_st": [_INT, _INT, _INT, _INT, _P, _P, _P, _P, _P, _P, _P, _P],
+    "captra_part_fit_st": [_INT, _INT, _INT, _INT, _P, _P, _P, _INT, _P, _P, _P, _P, _P, _P],
     "captra_procrustes_rot3": [_INT, _INT, _P, _P, _P, _P],
 }
 

@@ -1,0 +1,73 @@
+"""PointNet++ MSG encoder-decoder of CoordinateNet / RotationNet.
+
+Mirrors `PointNet2Msg` of the reference's network/models/backbones.py:15-69: same constructor
+(`cfg, out_dim, net_type, use_xyz_feat`), same sub-module names (sa1, sa2, sa3, fp3, fp2, fp1,
+conv1, bn1) and therefore the same state-dict keys; forward [B,3(+C),N] -> [B,out_dim,N].
+The point-major (B,N,3) copies that FPS / ball query / three_nn consume are produced once per
+level and handed down instead of being re-derived by transposes inside every module.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import fused
+from .fold import fold_conv_bn
+from .pointnet_utils import (PointNetFeaturePropagation, PointNetSetAbstraction, PointNetSetAbstractionMsg,
+                             _FoldCache)
+
+
+class PointNet2Msg(_FoldCache, nn.Module):
+    def __init__(self, cfg, out_dim, net_type="camera", use_xyz_feat=False):
+        super().__init__()
+        net_cfg = cfg["pointnet"][net_type]
+        self.out_dim = out_dim
+        self.in_dim = 3 if use_xyz_feat else 0
+        self.use_xyz_feat = use_xyz_feat
+        self.sa1 = PointNetSetAbstractionMsg(npoint=net_cfg["sa1"]["npoint"],
+                                             radius_list=net_cfg["sa1"]["radius_list"],
+                                             nsample_list=net_cfg["sa1"]["nsample_list"],
+                                             in_channel=self.in_dim + 3,
+                                             mlp_list=net_cfg["sa1"]["mlp_list"])
+        self.sa2 = PointNetSetAbstractionMsg(npoint=net_cfg["sa2"]["npoint"],
+                                             radius_list=net_cfg["sa2"]["radius_list"],
+                                             nsample_list=net_cfg["sa2"]["nsample_list"],
+                                             in_channel=self.sa1.out_channel + 3,
+                                             mlp_list=net_cfg["sa2"]["mlp_list"])
+        self.sa3 = PointNetSetAbstraction(npoint=None, radius=None, nsample=None,
+                                          in_channel=self.sa2.out_channel + 3,
+                                          mlp=net_cfg["sa3"]["mlp"], group_all=True)
+        self.fp3 = PointNetFeaturePropagation(in_channel=self.sa2.out_channel + self.sa3.out_channel,
+                                              mlp=net_cfg["fp3"]["mlp"])
+        self.fp2 = PointNetFeaturePropagation(in_channel=self.sa1.out_channel + self.fp3.out_channel,
+                                              mlp=net_cfg["fp2"]["mlp"])
+        self.fp1 = PointNetFeaturePropagation(in_channel=self.in_dim + 3 + self.fp2.out_channel,
+                                              mlp=net_cfg["fp1"]["mlp"])
+        self.conv1 = nn.Conv1d(self.fp1.out_channel, self.out_dim, 1)
+        self.bn1 = nn.BatchNorm1d(self.out_dim)
+        self.device = cfg["device"]
+        self._folded = None
+
+    def forward(self, input, input_n3=None):
+        """input (B,3(+C),N); `input_n3` optionally the (B,N,3) copy of input[:, :3]."""
+        l0_xyz = input[:, :3] if input.shape[1] > 3 else input
+        l0_xyz = l0_xyz.contiguous()
+        l0_points = input if self.use_xyz_feat else input[:, 3:]
+        if input_n3 is None:
+            input_n3 = l0_xyz.transpose(1, 2).contiguous()
+        l1_xyz, l1_points = self.sa1(l0_xyz, l0_points, xyz_n3=input_n3)
+        l1_n3 = self.sa1.last_new_xyz_n3
+        l2_xyz, l2_points = self.sa2(l1_xyz, l1_points, xyz_n3=l1_n3)
+        l2_n3 = self.sa2.last_new_xyz_n3
+        l3_xyz, l3_points = self.sa3(l2_xyz, l2_points)
+
+        l2_points = self.fp3(l2_xyz, l3_xyz, l2_points, l3_points)
+        l1_points = self.fp2(l1_xyz, l2_xyz, l1_points, l2_points, xyz1_n3=l1_n3, xyz2_n3=l2_n3)
+        skip0 = torch.cat([l0_xyz, l0_points], dim=1) if l0_points.shape[1] > 0 else l0_xyz
+        l0_points = self.fp1(l0_xyz, l1_xyz, skip0, l1_points, xyz1_n3=input_n3, xyz2_n3=l1_n3)
+        if (not self.training) and l0_points.is_cuda:
+            if self._folded is None:
+                self._folded = fold_conv_bn(self.conv1, self.bn1, l0_points.device)
+            return fused.pointwise_mlp(l0_points.contiguous(), *self._folded, fused.ACT_RELU)
+        return F.relu(self.bn1(self.conv1(l0_points)))

@@ -1,0 +1,152 @@
+"""1x1-conv MLP builders and the per-part rotation regressor.
+
+Mirrors the used subset of the reference's network/models/blocks.py: `get_point_mlp`
+(l.118-135), `MLPConv1d` (l.148-165), `RotationRegressor` (l.168-193).  Layers sit at the same
+nn.Sequential indices as in the reference so that state-dict keys coincide
+(`seg_head.0.weight`, `nocs_head.3.bias`, `rtvec_head.0.model.4.weight`, ...).
+In eval mode on the GPU the 1x1 convs run through the fp32 MFMA kernel (BatchNorm folded).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import fused
+from .fold import fold_conv_bn
+from .pose_utils.rotations import compute_rotation_matrix_from_ortho6d, normalize_vector
+
+_ACTI = {"relu": lambda: nn.ReLU(inplace=True), "lrelu": lambda: nn.LeakyReLU(0.2, inplace=True),
+         "tanh": nn.Tanh, "sigmoid": nn.Sigmoid, "softplus": nn.Softplus}
+
+
+def _acti_layers(acti):
+    return [] if acti == "none" else [_ACTI[acti]()]
+
+
+def _norm_layers(norm, dim, channel_per_group=2):
+    if norm == "bn":
+        return [nn.BatchNorm1d(dim)]
+    if norm == "gn":
+        return [nn.GroupNorm(dim // channel_per_group, dim)]
+    if norm == "in":
+        return [nn.InstanceNorm1d(dim, affine=True)]
+    assert norm == "none", norm
+    return []
+
+
+def get_conv_block(kernel_size, in_channels, out_channels, dropout=None, norm="none", acti="none"):
+    """[conv, (dropout), (norm), (acti)] — 'valid' padding only (all the hot path uses)."""
+    layers = [nn.Conv1d(in_channels, out_channels, kernel_size=kernel_size, bias=True)]
+    if dropout is not None:
+        layers.append(nn.Dropout(p=dropout))
+    return layers + _norm_layers(norm, out_channels) + _acti_layers(acti)
+
+
+def get_point_mlp(in_dim, out_dim, dims, acti="none", dropout=True, last_bn=False, keep_list=False):
+    """1x1 convs; hidden layers BN + (dropout 0.5) + ReLU, last layer `acti`."""
+    dropout = 0.5 if dropout else None
+    dims = [in_dim] + list(dims) + [out_dim]
+    layers = []
+    for i in range(len(dims) - 2):
+        layers += get_conv_block(1, dims[i], dims[i + 1], dropout=dropout, norm="bn", acti="relu")
+    layers += get_conv_block(1, dims[-2], dims[-1], norm="bn" if last_bn else "none", acti=acti)
+    return layers if keep_list else nn.Sequential(*layers)
+
+
+def run_point_mlp(seq: nn.Sequential, x: torch.Tensor, cache: dict) -> torch.Tensor:
+    """Evaluate a get_point_mlp / MLPConv1d Sequential on (B,C,N) through the fused kernels:
+    Conv(+BatchNorm)(+ReLU | Sigmoid) groups become one MFMA launch; GroupNorm(+ReLU) stays a
+    separate normalisation step after an activation-free conv."""
+    mods = list(seq)
+    i = 0
+    x = x.contiguous()
+    while i < len(mods):
+        conv = mods[i]
+        assert isinstance(conv, nn.Conv1d), type(conv)
+        j = i + 1
+        while j < len(mods) and isinstance(mods[j], nn.Dropout):
+            j += 1                                   # identity in eval mode
+        bn = mods[j] if j < len(mods) and isinstance(mods[j], nn.BatchNorm1d) else None
+        if bn is not None:
+            j += 1
+        gn = mods[j] if j < len(mods) and isinstance(mods[j], nn.GroupNorm) else None
+        if gn is not None:
+            j += 1
+        act = fused.ACT_NONE
+        sigmoid_tail = False
+        if j < len(mods) and isinstance(mods[j], nn.ReLU):
+            act, j = fused.ACT_RELU, j + 1
+        elif j < len(mods) and isinstance(mods[j], nn.Sigmoid):
+            sigmoid_tail, j = True, j + 1
+        key = id(conv)
+        if key not in cache:
+            cache[key] = fold_conv_bn(conv, bn, x.device)
+        wt, bias = cache[key]
+        if gn is not None:
+            x = fused.pointwise_mlp(x, wt, bias, fused.ACT_NONE)
+            x = F.group_norm(x, gn.num_groups, gn.weight, gn.bias, gn.eps)
+            if act == fused.ACT_RELU:
+                x = F.relu(x, inplace=True)
+        else:
+            x = fused.pointwise_mlp(x, wt, bias, act)
+            if sigmoid_tail:
+                x = torch.sigmoid(x)
+        i = j
+    return x
+
+
+class MLPConv1d(nn.Module):
+    def __init__(self, in_channel, mlp, bn=True, gn=False, activation="relu", last_activation="none"):
+        super().__init__()
+        norm = "gn" if gn else ("bn" if bn else "none")
+        layers, last = [], in_channel
+        for i, width in enumerate(mlp):
+            is_last = i == len(mlp) - 1
+            layers += get_conv_block(1, last, width, norm="none" if is_last else norm,
+                                     acti=last_activation if is_last else activation)
+            last = width
+        self.model = nn.Sequential(*layers)
+        self.out_channel = last
+        self._cache = {}
+
+    def train(self, mode=True):
+        self._cache = {}
+        return super().train(mode)
+
+    def _load_from_state_dict(self, *a, **k):
+        self._cache = {}
+        return super()._load_from_state_dict(*a, **k)
+
+    def _apply(self, fn, *a, **k):
+        self._cache = {}
+        return super()._apply(fn, *a, **k)
+
+    def forward(self, input):
+        if (not self.training) and input.is_cuda:
+            return run_point_mlp(self.model, input, self._cache)
+        return self.model(input)
+
+
+class RotationRegressor(nn.Module):
+    """P heads, each 128 -> 512 -> 512 -> 256 -> (3 | 6) with GroupNorm(C/2); per-point output is
+    normalised (symmetric: unit y-axis) or turned into a rotation matrix (ortho6d)."""
+
+    def __init__(self, in_dim, num_parts, symmetric=False):
+        super().__init__()
+        rot_dim = 3 if symmetric else 6
+        self.sym = symmetric
+        self.rtvec_head = nn.ModuleList([MLPConv1d(in_dim, [512, 512, 256, rot_dim], bn=True, gn=True,
+                                                   last_activation="none") for _ in range(num_parts)])
+        self.num_parts = num_parts
+
+    def forward(self, feat):
+        """feat (B,in_dim,N) -> (B,P,3,N) unit vectors or (B,P,9,N) row-major rotation matrices."""
+        raw = torch.stack([head(feat) for head in self.rtvec_head], dim=1)          # (B,P,R,N)
+        per_point = raw.transpose(-1, -2)                                            # (B,P,N,R)
+        shape = per_point.shape
+        if self.sym:
+            out = normalize_vector(per_point.reshape(-1, 3)).reshape(shape)
+        else:
+            out = compute_rotation_matrix_from_ortho6d(per_point.reshape(-1, 6)).reshape(shape[:-1] + (9,))
+        return out.transpose(-1, -2)

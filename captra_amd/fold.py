@@ -1,0 +1,25 @@
+"""Fold eval-mode BatchNorm into the preceding 1x1 convolution (done once at load time).
+
+y = gamma * (W x + b - mean) / sqrt(var + eps) + beta  ==  W' x + b'  with
+W' = W * gamma / sqrt(var + eps),  b' = (b - mean) * gamma / sqrt(var + eps) + beta.
+Computed in float64 on the host, stored as the fp32 TRANSPOSE W'^T (cin, cout) that the MFMA
+kernels stage row-wise.  Replaces the separate Conv -> BatchNorm -> ReLU ATen calls of
+pointnet_utils.py:242-245.
+"""
+from __future__ import annotations
+
+import torch
+
+
+def fold_conv_bn(conv, bn=None, device=None):
+    """conv: nn.Conv1d/Conv2d with 1x1 kernel; bn: BatchNorm or None -> (wt (cin,cout), bias (cout))."""
+    w = conv.weight.detach().double().reshape(conv.weight.shape[0], -1).cpu()      # (cout, cin)
+    b = conv.bias.detach().double().cpu() if conv.bias is not None else torch.zeros(w.shape[0], dtype=torch.float64)
+    if bn is not None:
+        g = bn.weight.detach().double().cpu() if bn.weight is not None else torch.ones_like(b)
+        beta = bn.bias.detach().double().cpu() if bn.bias is not None else torch.zeros_like(b)
+        inv = g / torch.sqrt(bn.running_var.detach().double().cpu() + bn.eps)
+        w = w * inv.unsqueeze(1)
+        b = (b - bn.running_mean.detach().double().cpu()) * inv + beta
+    dev = device if device is not None else conv.weight.device
+    return w.t().contiguous().float().to(dev), b.float().to(dev)

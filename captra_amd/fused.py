@@ -1,0 +1,101 @@
+"""Tensor-level wrappers of the fused tracking-path kernels (Section 2 of include/captra_hip.h).
+
+Each function allocates its output with torch (caching allocator = plumbing), validates device /
+contiguity, and launches on torch's current stream.  No CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+ACT_NONE, ACT_RELU, ACT_SIGMOID_M05 = 0, 1, 2
+
+
+def canonicalize(pts, mean, rot, trans, scale, num_parts: int = 1, want_cn=True, want_n3=True):
+    """pts (B,3,N), mean (B,3[,1]), rot (B*P,3,3), trans (B*P,3[,1]), scale (B*P) ->
+    (out_cn (B*P,3,N), out_n3 (B*P,N,3)) = R^T((pts+mean)-t)/s  (networks.py:38-41, 184-187)."""
+    B, _, N = pts.shape
+    Q = B * num_parts
+    mean = mean.reshape(B, 3).contiguous()
+    rot = rot.reshape(Q, 3, 3).contiguous()
+    trans = trans.reshape(Q, 3).contiguous()
+    scale = scale.reshape(Q).contiguous()
+    L.require_device(pts, mean, rot, trans, scale)
+    out_cn = torch.empty(Q, 3, N, dtype=torch.float32, device=pts.device) if want_cn else None
+    out_n3 = torch.empty(Q, N, 3, dtype=torch.float32, device=pts.device) if want_n3 else None
+    with torch.cuda.device(pts.device):
+        L.call("captra_canonicalize", B, num_parts, N, L.ptr(pts), L.ptr(mean), L.ptr(rot), L.ptr(trans), L.ptr(scale),
+               L.ptr(out_cn), L.ptr(out_n3))
+    return out_cn, out_n3
+
+
+def ball_query_multi(radii, nsamples, xyz_n3, new_xyz_n3):
+    """One scan of xyz for all radii -> [idx_r (B,M,K_r) int32]."""
+    L.require_device(xyz_n3, new_xyz_n3)
+    B, N, _ = xyz_n3.shape
+    M = new_xyz_n3.shape[1]
+    nr = len(radii)
+    outs = [torch.empty(B, M, int(k), dtype=torch.int32, device=xyz_n3.device) for k in nsamples]
+    c_r = (C.c_float * nr)(*[float(r) for r in radii])
+    c_k = (C.c_int * nr)(*[int(k) for k in nsamples])
+    c_p = (C.c_void_p * nr)(*[o.data_ptr() for o in outs])
+    with torch.cuda.device(xyz_n3.device):
+        L.call("captra_ball_query_multi", B, N, M, nr, C.cast(c_r, C.c_void_p), C.cast(c_k, C.c_void_p),
+               L.ptr(new_xyz_n3), L.ptr(xyz_n3), C.cast(c_p, C.c_void_p))
+    return outs
+
+
+def pointwise_mlp(x, wt, bias, act: int = ACT_RELU, out=None):
+    """x (B,cin,*) , wt (cin,cout), bias (cout) -> (B,cout,*) = act(W x + b) (exact-fp32 MFMA)."""
+    L.require_device(x, wt, bias)
+    B, cin = x.shape[0], x.shape[1]
+    cout = wt.shape[1]
+    assert wt.shape[0] == cin, (wt.shape, x.shape)
+    l = x.numel() // max(B * cin, 1)
+    if out is None:
+        out = torch.empty((B, cout) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        L.call("captra_pointwise_mlp", B, cin, cout, l, L.ptr(x), L.ptr(wt), L.ptr(bias), act, L.ptr(out))
+    return out
+
+
+def sa_group_mlp(feat, xyz_cn, new_xyz_n3, idx, wt, bias):
+    """First SA layer with group + centre-subtract + concat fused into the load -> (B,cout,M,K)."""
+    L.require_device(feat, xyz_cn, new_xyz_n3, idx, wt, bias)
+    B, _, N = xyz_cn.shape
+    _, M, K = idx.shape
+    cfeat = 0 if feat is None else feat.shape[1]
+    cout = wt.shape[1]
+    assert wt.shape[0] == cfeat + 3
+    y = torch.empty(B, cout, M, K, dtype=torch.float32, device=xyz_cn.device)
+    with torch.cuda.device(xyz_cn.device):
+        L.call("captra_sa_group_mlp", B, N, M, K, cfeat, cout, L.ptr(feat), L.ptr(xyz_cn), L.ptr(new_xyz_n3), L.ptr(idx),
+               L.ptr(wt), L.ptr(bias), L.ptr(y))
+    return y
+
+
+def mlp_max(x, wt, bias, out, co_off: int):
+    """Last SA layer + max over K: x (B,cin,M,K) -> out[:, co_off:co_off+cout, :] (out is (B,Ctot,M))."""
+    L.require_device(x, wt, bias, out)
+    B, cin, M, K = x.shape
+    cout = wt.shape[1]
+    with torch.cuda.device(x.device):
+        L.call("captra_mlp_max", B, cin, cout, M, K, L.ptr(x), L.ptr(wt), L.ptr(bias), L.ptr(out), out.shape[1], co_off)
+    return out
+
+
+def fp_interpolate_concat(unknown_n3, known_n3, skip, feat_known):
+    """three_nn + inverse-distance weights + interpolate + cat([skip, interp]) -> (B,c1+c2,N)."""
+    L.require_device(unknown_n3, known_n3, skip, feat_known)
+    B, N, _ = unknown_n3.shape
+    S = known_n3.shape[1]
+    c1 = 0 if skip is None else skip.shape[1]
+    c2 = feat_known.shape[1]
+    out = torch.empty(B, c1 + c2, N, dtype=torch.float32, device=unknown_n3.device)
+    with torch.cuda.device(unknown_n3.device):
+        L.call("captra_fp_interpolate_concat", B, N, S, c1, c2, L.ptr(unknown_n3), L.ptr(known_n3), L.ptr(skip),
+               L.ptr(feat_known), L.ptr(out))
+    return out

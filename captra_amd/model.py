@@ -1,0 +1,206 @@
+"""The tracking loop: `EvalTrackModel` (and its `BaseModel`) on the MI355X path.
+
+Mirrors the contract of the reference's network/models/model.py: `BaseModel` (l.27-104) and
+`EvalTrackModel` (l.311-600): `set_data(data)`, `test(save, no_eval, epoch)`, attributes
+`pred_dict = {'poses': [pose]*T, 'npcs_pred': [None, {...}]*}` and `loss_dict`.
+`data` is a list over frames of dicts
+  {'points' (B,3,N), 'labels' (B,N), 'nocs' (B,3,N),
+   'meta': {'path': [str]*B, 'nocs2camera': [{'rotation' (B,3,3), 'translation' (B,3,1), 'scale' (B,)}]*P,
+            'points_mean' (B,3,1), 'nocs_corners' (B,P,2,3)}}.
+Frame i consumes the pose predicted for frame i-1 (strictly sequential, model.py:408-478);
+trajectories of one batch are independent, which is what shards over GPUs (parallel.py).
+
+Out of scope here (SURVEY.md §8f "next"): the on-the-fly depth crop of `nocs_otf` (model.py:425-452,
+needs cv2 + the dataset) and the IoU/segmentation losses of compute_loss (loss.py, bbox_utils.py).
+"""
+from __future__ import annotations
+
+import pickle
+from copy import deepcopy
+from os.path import join as pjoin
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .networks import CoordNet, PartCanonNet
+from .pose_utils.part_dof_utils import add_noise_to_part_dof, eval_part_full, part_model_batch_to_part
+from .utils import Timer, add_dict, cvt_torch, divide_dict, ensure_dirs, get_ith_from_batch
+
+
+class BaseModel(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.num_parts = int(cfg["num_parts"])
+        self.num_joints = int(cfg["num_joints"])
+        self.device = cfg["device"]
+        self.network_type = cfg["network"]["type"]
+        raw = cfg["pose_perturb"]
+        self.pose_perturb_cfg = {"type": raw["type"], "scale": raw["s"], "translation": raw["t"],
+                                 "rotation": float(np.deg2rad(raw["r"]))}
+        self.sym = cfg["obj_sym"]
+        self.cfg = cfg
+        self.feed_dict = {}
+        self.pred_dict = {}
+        self.loss_dict = {}
+        self.per_diff_dict = {}
+
+    def record_per_diff(self, data, per_diff):
+        for i, path in enumerate(data["meta"]["path"]):
+            instance, track_num, frame_i = path.split(".")[-2].split("/")[-3:]
+            self.per_diff_dict.setdefault(f"{instance}_{track_num}_{frame_i}", {}).update(get_ith_from_batch(per_diff, i))
+
+
+class EvalTrackModel(BaseModel):
+    def __init__(self, cfg):
+        super().__init__(cfg)
+        self.net = PartCanonNet(cfg)
+        self.npcs_net = CoordNet(cfg)
+        self.tree = cfg["obj_tree"]
+        self.root = [p for p in range(len(self.tree)) if self.tree[p] == -1][0]
+        self.gt_init = cfg["init_frame"]["gt"]
+        self.nocs_otf = bool(cfg.get("nocs_otf", False))
+        self.radius = cfg["data_radius"]
+        self.track_cfg = cfg["track_cfg"]
+        self.npcs_feed_dict = []
+        self.timer = Timer(True)
+        self.time_dict = {"npcs_net": 0.0, "rot_all": 0.0}
+
+    # ---- host -> device ------------------------------------------------------------------------
+    def _gt_part(self, frame):
+        return part_model_batch_to_part(cvt_torch(frame["meta"]["nocs2camera"], self.device), self.num_parts, self.device)
+
+    def _convert_pose_frame(self, frame, first):
+        out = {"meta": frame["meta"], "gt_part": self._gt_part(frame)}
+        if first:
+            for key in ("points", "nocs"):
+                if key in frame:
+                    out[key] = frame[key].float().to(self.device)
+        else:
+            out["points"] = frame["points"].float().to(self.device)
+            out["points_mean"] = frame["meta"]["points_mean"].float().to(self.device)
+            if "nocs" in frame:
+                out["npcs"] = frame["nocs"].float().to(self.device)
+        if "labels" in frame:
+            out["labels"] = frame["labels"].long().to(self.device)
+        return out
+
+    def _convert_npcs_frame(self, frame):
+        out = {"meta": frame["meta"], "points_mean": frame["meta"]["points_mean"].float().to(self.device)}
+        for key in ("points", "nocs"):
+            if key in frame:
+                out[key] = frame[key].float().to(self.device)
+        if "labels" in frame:
+            out["labels"] = frame["labels"].long().to(self.device)
+        return out
+
+    def set_data(self, data):
+        self.feed_dict = [self._convert_pose_frame(f, i == 0) for i, f in enumerate(data)]
+        self.npcs_feed_dict = [self._convert_npcs_frame(f) for f in data]
+
+    # ---- the loop ------------------------------------------------------------------------------
+    def _initial_pose(self):
+        gt_part = self.feed_dict[0]["gt_part"]
+        if self.gt_init:
+            return gt_part
+        part = add_noise_to_part_dof(gt_part, self.pose_perturb_cfg)
+        if "crop_pose" in self.feed_dict[0]["meta"]:
+            crop = part_model_batch_to_part(cvt_torch(self.feed_dict[0]["meta"]["crop_pose"], self.device),
+                                            self.num_parts, self.device)
+            part["translation"], part["scale"] = crop["translation"], crop["scale"]
+        return part
+
+    def track_step(self, input, npcs_input, last_pose):
+        """One frame for all B trajectories: CoordNet -> labels -> RotationNet -> pose fit."""
+        npcs_input["canon_pose"] = {k: last_pose[k][:, self.root].clone() for k in ("rotation", "translation", "scale")}
+        npcs_input["init_part"] = last_pose
+        npcs_pred = self.npcs_net(npcs_input)
+        pred_npcs = npcs_pred["nocs"].reshape(len(npcs_pred["nocs"]), self.num_parts, 3, -1)
+        input["state"] = {"part": last_pose}
+        input["pred_labels"] = torch.argmax(npcs_pred["seg"], dim=-2)
+        input["pred_nocs"] = pred_npcs
+        input["pred_label_conf"] = npcs_pred["seg"][:, 0]
+        if self.track_cfg["gt_label"] or self.track_cfg["nocs2d_label"]:
+            input["pred_labels"] = npcs_input["labels"]
+        return npcs_pred, self.net(input, test_mode=True)["part"]
+
+    def forward(self, save=False):
+        if self.nocs_otf:
+            raise NotImplementedError("nocs_otf (on-the-fly depth crop, reference model.py:425-452) is a "
+                                      "'next' row of SURVEY.md §8(f); feed pre-cropped clouds instead")
+        pred_poses = [self._initial_pose()]
+        npcs_pred = [None]
+        frame_nums = []
+        self.timer.tick()
+        with torch.no_grad():
+            for i, input in enumerate(self.feed_dict):
+                frame_nums.append([p.split(".")[-2].split("/")[-1] for p in input["meta"]["path"]])
+                if i == 0:
+                    continue
+                # the reference draws (and discards) a perturbed pose every frame (model.py:414);
+                # draw it too so that seeded runs consume the generator identically
+                add_noise_to_part_dof(self.feed_dict[i - 1]["gt_part"], self.pose_perturb_cfg)
+                last_pose = {k: v.clone() for k, v in pred_poses[-1].items()}
+                cur_npcs, pose = self.track_step(input, self.npcs_feed_dict[i], last_pose)
+                npcs_pred.append(cur_npcs)
+                pred_poses.append(pose)
+        self.pred_dict = {"poses": pred_poses, "npcs_pred": npcs_pred}
+        if save:
+            self._save(frame_nums)
+
+    def _save(self, frame_nums):
+        """Per-trajectory pickle {'pred': {'poses','corners'}, 'gt': {'poses','corners'}, 'frame_nums'}
+        (reference model.py:482-509).  Predicted NOCS corners = per-part min/max of the predicted
+        coordinates of the points labelled with that part."""
+        gt_corners = self.feed_dict[0]["meta"]["nocs_corners"].cpu().numpy()
+        corner_list = [None]
+        for i in range(1, len(self.pred_dict["poses"])):
+            pred = self.pred_dict["npcs_pred"][i]
+            labels = torch.argmax(pred["seg"], dim=-2)
+            nocs = pred["nocs"].reshape(len(labels), self.num_parts, 3, -1)
+            corners = np.zeros((len(labels), self.num_parts, 2, 3), np.float32)
+            for p in range(self.num_parts):
+                m = (labels == p).unsqueeze(1)
+                lo = torch.where(m, nocs[:, p], torch.full_like(nocs[:, p], float("inf"))).min(dim=-1)[0]
+                hi = torch.where(m, nocs[:, p], torch.full_like(nocs[:, p], float("-inf"))).max(dim=-1)[0]
+                empty = ~m.any(dim=-1)
+                corners[:, p, 0] = torch.where(empty, torch.zeros_like(lo), lo).cpu().numpy()
+                corners[:, p, 1] = torch.where(empty, torch.zeros_like(hi), hi).cpu().numpy()
+            corner_list.append(corners)
+        to_np = lambda pose: {k: v.detach().cpu().numpy() for k, v in pose.items()}
+        save_dict = {"pred": {"poses": [to_np(p) for p in self.pred_dict["poses"]], "corners": corner_list},
+                     "gt": {"poses": [to_np(f["gt_part"]) for f in self.feed_dict], "corners": gt_corners},
+                     "frame_nums": frame_nums}
+        save_path = pjoin(self.cfg["experiment_dir"], "results", "data")
+        ensure_dirs([save_path])
+        for i, path in enumerate(self.feed_dict[0]["meta"]["path"]):
+            instance, track_num = path.split(".")[-2].split("/")[-3:-1]
+            with open(pjoin(save_path, f"{instance}_{track_num}.pkl"), "wb") as f:
+                pickle.dump(get_ith_from_batch(save_dict, i, to_single=False), f)
+
+    def compute_loss(self, per_instance=False):
+        """Pose-error part of the reference's compute_loss (model.py:511-593): rdiff / tdiff / sdiff /
+        5deg5cm per part, averaged over frames 1..T-1, for the prediction and for its initialisation."""
+        avg_pred, avg_init, all_pred, all_init = {}, {}, {}, {}
+        poses = self.pred_dict["poses"]
+        for i, pose in enumerate(poses):
+            diff, per = eval_part_full(self.feed_dict[i]["gt_part"], pose, per_instance=per_instance, yaxis_only=self.sym)
+            all_pred[i] = deepcopy(diff)
+            if i == 0:
+                continue
+            add_dict(avg_pred, diff)
+            if per_instance:
+                self.record_per_diff(self.feed_dict[i], per)
+            init_diff, _ = eval_part_full(self.feed_dict[i]["gt_part"], poses[i - 1], per_instance=False, yaxis_only=self.sym)
+            add_dict(avg_init, init_diff)
+            all_init[i] = deepcopy(init_diff)
+        n = max(len(poses) - 1, 1)
+        self.loss_dict = {"avg_pred": divide_dict(avg_pred, n), "avg_init": divide_dict(avg_init, n),
+                          "frame_pred": all_pred, "frame_init": all_init}
+
+    def test(self, save=False, no_eval=False, epoch=0):
+        self.forward(save=save)
+        if no_eval:
+            self.loss_dict = {}
+        else:
+            self.compute_loss(per_instance=save)

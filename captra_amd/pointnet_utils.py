@@ -1,0 +1,300 @@
+"""Point-set functions and modules of the PointNet++ backbone, on HIP kernels.
+
+Mirrors the public surface of the reference's network/models/pointnet_utils.py: the functions
+`knn_point` (l.12), `three_nn` (l.35), `three_interpolate` (l.46), `gather_operation` (l.100),
+`group_operation` (l.106), `farthest_point_sample` (l.112), `query_ball_point` (l.141) and the
+modules `PointNetSetAbstractionMsg` (l.191), `PointNetFeaturePropagation` (l.253),
+`PointNetSetAbstraction` (l.302) with identical constructor arguments and parameter names, so a
+reference state dict loads unchanged.
+
+Differences by design:
+  * there is no import-time CUDA/CPU switch (reference l.8-10): every function runs the HIP
+    operator and raises on CPU tensors;
+  * `gather_operation` / `group_operation` call the kernels (the reference bypasses its own CUDA
+    kernels with torch indexing, l.100-109);
+  * `three_nn` follows the CUDA semantics (sqrt of the squared distance, pointnet2_utils.py:134),
+    which is what the released checkpoints were trained with;
+  * in eval mode the modules run a FUSED path: BatchNorm folded into the conv weights once,
+    group-and-concat fused into the first layer's operand load, max-over-K fused into the last
+    layer's epilogue, all three radii of a level served by one ball-query scan.  In train mode
+    they run layer by layer with autograd (torch convs over the HIP grouping op).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import fused
+from .fold import fold_conv_bn
+from .pointnet_lib import pointnet2_utils as futils
+
+
+# ---------------------------------------------------------------------------------------------
+# functions (same names / argument order as the reference)
+# ---------------------------------------------------------------------------------------------
+def knn_point(k, pos2, pos1):
+    """k nearest of pos1 (B,N,3) for every query pos2 (B,M,3) -> (L2 distances (B,M,k), idx long)."""
+    val, idx = futils.knn(k, pos2, pos1)
+    return val, idx.long()
+
+
+def three_nn(xyz1, xyz2):
+    """3 nearest of xyz2 (B,M,3) for every xyz1 (B,N,3) -> (distances (B,N,3), idx long)."""
+    dists, idx = futils.three_nn(xyz1, xyz2)
+    return dists, idx.long()
+
+
+def three_interpolate(points, idx, weight):
+    """points (B,C,M), idx (B,N,3), weight (B,N,3) -> (B,C,N)."""
+    return futils.three_interpolate(points, idx.int(), weight)
+
+
+def gather_operation(feature, idx):
+    """feature (B,C,N), idx (B,npoint) -> (B,C,npoint)."""
+    return futils.gather_operation(feature, idx.int())
+
+
+def group_operation(feature, idx):
+    """feature (B,C,N), idx (B,npoint,nsample) -> (B,C,npoint,nsample)."""
+    return futils.grouping_operation(feature, idx.int())
+
+
+def farthest_point_sample(xyz, npoint):
+    """xyz (B,N,3) -> (B,npoint) long; starts at index 0 like the CUDA kernel (sampling_gpu.cu:113)."""
+    return futils.furthest_point_sample(xyz, npoint).long()
+
+
+def query_ball_point(radius, nsample, xyz, new_xyz):
+    """xyz (B,N,3), new_xyz (B,S,3) -> (B,S,nsample) long."""
+    return futils.ball_query(radius, nsample, xyz, new_xyz).long()
+
+
+def index_points(points, idx):
+    """points (B,N,C), idx (B,S...) -> (B,S...,C) (pure indexing helper)."""
+    B = points.shape[0]
+    view = [B] + [1] * (idx.dim() - 1)
+    batch = torch.arange(B, dtype=torch.long, device=points.device).view(view).expand_as(idx)
+    return points[batch, idx, :]
+
+
+def sample_and_group_all(xyz, points):
+    """xyz (B,N,3), points (B,N,D) -> (new_xyz zeros (B,1,3), (B,1,N,3+D)) — xyz first."""
+    B, N, C = xyz.shape
+    new_xyz = torch.zeros(B, 1, C, device=xyz.device, dtype=xyz.dtype)
+    grouped = xyz.view(B, 1, N, C)
+    if points is not None:
+        grouped = torch.cat([grouped, points.view(B, 1, N, -1)], dim=-1)
+    return new_xyz, grouped
+
+
+# ---------------------------------------------------------------------------------------------
+# modules
+# ---------------------------------------------------------------------------------------------
+class _FoldCache:
+    """Mixin: folded (conv+BN) weights, rebuilt lazily after load_state_dict()/train()/to()."""
+
+    def _invalidate(self):
+        self._folded = None
+
+    def train(self, mode: bool = True):
+        self._invalidate()
+        return super().train(mode)
+
+    def _apply(self, fn, *a, **k):
+        self._invalidate()
+        return super()._apply(fn, *a, **k)
+
+    def _load_from_state_dict(self, *a, **k):
+        self._invalidate()
+        return super()._load_from_state_dict(*a, **k)
+
+
+def _has_points(points):
+    return points is not None and points.shape[1] > 0
+
+
+class PointNetSetAbstractionMsg(_FoldCache, nn.Module):
+    """Multi-scale-grouping set abstraction (reference pointnet_utils.py:191-250)."""
+
+    def __init__(self, npoint, radius_list, nsample_list, in_channel, mlp_list, knn=False):
+        super().__init__()
+        self.npoint = npoint
+        self.radius_list = list(radius_list)
+        self.nsample_list = list(nsample_list)
+        self.conv_blocks = nn.ModuleList()
+        self.bn_blocks = nn.ModuleList()
+        self.out_channel = 0
+        for widths in mlp_list:
+            convs, bns = nn.ModuleList(), nn.ModuleList()
+            last = in_channel
+            for w in widths:
+                convs.append(nn.Conv2d(last, w, 1))
+                bns.append(nn.BatchNorm2d(w))
+                last = w
+            self.out_channel += last
+            self.conv_blocks.append(convs)
+            self.bn_blocks.append(bns)
+        self.knn = knn
+        self._folded = None
+
+    def _fold(self, device):
+        if self._folded is None:
+            self._folded = [[fold_conv_bn(c, b, device) for c, b in zip(convs, bns)]
+                            for convs, bns in zip(self.conv_blocks, self.bn_blocks)]
+        return self._folded
+
+    def _can_fuse(self, xyz):
+        return (not self.training) and (not self.knn) and xyz.is_cuda and \
+            all(k % 32 == 0 and 128 % k == 0 for k in self.nsample_list)
+
+    def forward(self, xyz, points, xyz_n3=None):
+        """xyz (B,3,N), points (B,D,N) or None -> (new_xyz (B,3,S), features (B,D',S)).
+        `xyz_n3` optionally passes the (B,N,3) copy the caller already has."""
+        if not _has_points(points):
+            points = None
+        if xyz_n3 is None:
+            xyz_n3 = xyz.transpose(1, 2).contiguous()
+        fps_idx = futils.furthest_point_sample(xyz_n3, self.npoint)                      # (B,S) int32
+        new_xyz_n3 = torch.gather(xyz_n3, 1, fps_idx.long().unsqueeze(-1).expand(-1, -1, 3))  # (B,S,3)
+        new_xyz = new_xyz_n3.transpose(1, 2).contiguous()
+        self.last_new_xyz_n3 = new_xyz_n3
+        if self._can_fuse(xyz):
+            return new_xyz, self._forward_fused(xyz.contiguous(), xyz_n3, points, new_xyz_n3)
+        return new_xyz, self._forward_layers(xyz, xyz_n3, points, new_xyz, new_xyz_n3)
+
+    # eval: fused kernels
+    def _forward_fused(self, xyz_cn, xyz_n3, points, new_xyz_n3):
+        folded = self._fold(xyz_cn.device)
+        B, S = xyz_cn.shape[0], self.npoint
+        idx_list = fused.ball_query_multi(self.radius_list, self.nsample_list, xyz_n3, new_xyz_n3)
+        out = torch.empty(B, self.out_channel, S, dtype=torch.float32, device=xyz_cn.device)
+        feat = points.contiguous() if points is not None else None
+        off = 0
+        for layers, idx in zip(folded, idx_list):
+            y = fused.sa_group_mlp(feat, xyz_cn, new_xyz_n3, idx, *layers[0])
+            for wt, bias in layers[1:-1]:
+                y = fused.pointwise_mlp(y, wt, bias, fused.ACT_RELU)
+            fused.mlp_max(y, layers[-1][0], layers[-1][1], out, off)
+            off += layers[-1][0].shape[1]
+        return out
+
+    # train / generic: layer by layer, differentiable
+    def _forward_layers(self, xyz, xyz_n3, points, new_xyz, new_xyz_n3):
+        B, C, N = xyz.shape
+        S = self.npoint
+        outs = []
+        for i, radius in enumerate(self.radius_list):
+            K = self.nsample_list[i]
+            if self.knn:
+                _, group_idx = futils.knn(K, new_xyz_n3, xyz_n3)
+            else:
+                group_idx = futils.ball_query(radius, K, xyz_n3, new_xyz_n3)
+            grouped_xyz = futils.grouping_operation(xyz, group_idx) - new_xyz.view(B, C, S, 1)
+            if points is not None:
+                grouped = torch.cat([futils.grouping_operation(points, group_idx), grouped_xyz], dim=1)
+            else:
+                grouped = grouped_xyz
+            for conv, bn in zip(self.conv_blocks[i], self.bn_blocks[i]):
+                grouped = F.relu(bn(conv(grouped)))
+            outs.append(grouped.max(dim=-1)[0])
+        return torch.cat(outs, dim=1)
+
+
+class PointNetFeaturePropagation(_FoldCache, nn.Module):
+    """3-NN inverse-distance interpolation + skip concat + shared MLP (reference l.253-299)."""
+
+    def __init__(self, in_channel, mlp):
+        super().__init__()
+        self.mlp_convs = nn.ModuleList()
+        self.mlp_bns = nn.ModuleList()
+        last = in_channel
+        for w in mlp:
+            self.mlp_convs.append(nn.Conv1d(last, w, 1))
+            self.mlp_bns.append(nn.BatchNorm1d(w))
+            last = w
+        self.out_channel = last
+        self._folded = None
+
+    def _fold(self, device):
+        if self._folded is None:
+            self._folded = [fold_conv_bn(c, b, device) for c, b in zip(self.mlp_convs, self.mlp_bns)]
+        return self._folded
+
+    def forward(self, xyz1, xyz2, points1, points2, xyz1_n3=None, xyz2_n3=None):
+        """xyz1 (B,3,N) dense, xyz2 (B,3,S) sparse, points1 (B,D1,N) or None, points2 (B,D2,S)
+        -> (B,D',N)."""
+        B, _, N = xyz1.shape
+        S = xyz2.shape[2]
+        if not _has_points(points1):
+            points1 = None
+        fuse = (not self.training) and xyz1.is_cuda
+        if S == 1:
+            interpolated = points2.expand(-1, -1, N) if points2.shape[2] == 1 else points2.repeat(1, 1, N)
+            new_points = torch.cat([points1, interpolated], dim=1) if points1 is not None else interpolated.contiguous()
+        else:
+            if xyz1_n3 is None:
+                xyz1_n3 = xyz1.transpose(1, 2).contiguous()
+            if xyz2_n3 is None:
+                xyz2_n3 = xyz2.transpose(1, 2).contiguous()
+            if fuse:
+                new_points = fused.fp_interpolate_concat(xyz1_n3, xyz2_n3,
+                                                         None if points1 is None else points1.contiguous(),
+                                                         points2.contiguous())
+            else:
+                dist, idx = futils.three_nn(xyz1_n3, xyz2_n3)
+                recip = 1.0 / (dist + 1e-8)
+                weight = recip / recip.sum(dim=2, keepdim=True)
+                interpolated = futils.three_interpolate(points2, idx, weight)
+                new_points = torch.cat([points1, interpolated], dim=1) if points1 is not None else interpolated
+        if fuse:
+            new_points = new_points.contiguous()
+            for wt, bias in self._fold(xyz1.device):
+                new_points = fused.pointwise_mlp(new_points, wt, bias, fused.ACT_RELU)
+            return new_points
+        for conv, bn in zip(self.mlp_convs, self.mlp_bns):
+            new_points = F.relu(bn(conv(new_points)))
+        return new_points
+
+
+class PointNetSetAbstraction(_FoldCache, nn.Module):
+    """group_all set abstraction: concat [xyz, feat], shared MLP, max over all points (l.302-343)."""
+
+    def __init__(self, npoint, radius, nsample, in_channel, mlp, group_all, knn=False):
+        super().__init__()
+        self.npoint, self.radius, self.nsample = npoint, radius, nsample
+        self.mlp_convs = nn.ModuleList()
+        self.mlp_bns = nn.ModuleList()
+        last = in_channel
+        for w in mlp:
+            self.mlp_convs.append(nn.Conv2d(last, w, 1))
+            self.mlp_bns.append(nn.BatchNorm2d(w))
+            last = w
+        self.out_channel = last
+        self.group_all = group_all
+        self.knn = knn
+        self._folded = None
+
+    def _fold(self, device):
+        if self._folded is None:
+            self._folded = [fold_conv_bn(c, b, device) for c, b in zip(self.mlp_convs, self.mlp_bns)]
+        return self._folded
+
+    def forward(self, xyz, points):
+        """xyz (B,3,N), points (B,D,N) -> (new_xyz zeros (B,3,1), features (B,D',1))."""
+        assert self.group_all, "only group_all is implemented (as in the reference, l.330)"
+        B, C, N = xyz.shape
+        x = torch.cat([xyz, points], dim=1) if _has_points(points) else xyz       # (B,3+D,N), xyz first
+        new_xyz = torch.zeros(B, C, 1, device=xyz.device, dtype=xyz.dtype)
+        if (not self.training) and xyz.is_cuda and N % 32 == 0 and 128 % N == 0:
+            folded = self._fold(xyz.device)
+            y = x.contiguous().view(B, x.shape[1], 1, N)
+            for wt, bias in folded[:-1]:
+                y = fused.pointwise_mlp(y, wt, bias, fused.ACT_RELU)
+            out = torch.empty(B, self.out_channel, 1, dtype=torch.float32, device=xyz.device)
+            fused.mlp_max(y, folded[-1][0], folded[-1][1], out, 0)
+            return new_xyz, out
+        y = x.unsqueeze(-1)                                                        # (B,3+D,N,1)
+        for conv, bn in zip(self.mlp_convs, self.mlp_bns):
+            y = F.relu(bn(conv(y)))
+        return new_xyz, y.max(dim=2)[0]

@@ -1,0 +1,82 @@
+"""Part pose containers: compose, perturb, evaluate.
+
+Mirrors the used subset of the reference's pose_utils/part_dof_utils.py:
+`part_model_batch_to_part` (l.70-75), `add_noise_to_part_dof` (l.78-98),
+`merge_reenact_canon_part_pose` (l.124-134), `convert_pred_rtvec_to_matrix` (l.137-141),
+`eval_part_full` (l.54-67, the 5°5cm accuracy gate).
+A part pose is a dict {'rotation' (B,P,3,3), 'translation' (B,P,3,1), 'scale' (B,P)}.
+"""
+from __future__ import annotations
+
+import torch
+
+from .metrics import rot_diff_degree, scale_diff, trans_diff
+from .rotations import (compute_rotation_matrix_from_3d, compute_rotation_matrix_from_matrix,
+                        noisy_rot_matrix)
+
+
+def part_model_batch_to_part(part, num_parts: int, device):
+    """[{'scale' (B,), 'translation' (B,3,1), 'rotation' (B,3,3)}]*P -> stacked over a part axis."""
+    dim = part[0]["translation"].dim() - 2
+    return {key: torch.stack([torch.as_tensor(part[p][key]) for p in range(num_parts)], dim=dim).float().to(device)
+            for key in part[0].keys()}
+
+
+def _cpu_random_like(base: torch.Tensor, rand_type: str) -> torch.Tensor:
+    """Noise comes from the CPU generator (seed-stable across devices), then moves to base.device."""
+    if rand_type == "uniform":
+        r = torch.rand(base.shape) * 2.0 - 1.0
+    elif rand_type == "normal":
+        r = torch.randn(base.shape)
+    else:
+        raise ValueError(rand_type)
+    return r.to(base.device)
+
+
+def add_noise_to_part_dof(part: dict, cfg: dict) -> dict:
+    """cfg: {'type', 'rotation' [rad], 'scale', 'translation'}.  Draw order (rotation angle,
+    jitter quaternion, scale, translation norm, translation direction) is the reference's."""
+    rand_type = cfg["type"]
+    out = {"rotation": noisy_rot_matrix(part["rotation"], cfg["rotation"], type=rand_type).reshape(part["rotation"].shape)}
+    out["scale"] = part["scale"] + _cpu_random_like(part["scale"], rand_type) * cfg["scale"]
+    norm = _cpu_random_like(part["scale"], rand_type) * cfg["translation"]           # (B,P)
+    direction = _cpu_random_like(part["translation"].squeeze(-1), rand_type)          # (B,P,3)
+    direction = direction / torch.clamp(direction.norm(dim=-1, keepdim=True), min=1e-9)
+    out["translation"] = part["translation"] + (direction * norm.unsqueeze(-1)).unsqueeze(-1)
+    return out
+
+
+def merge_reenact_canon_part_pose(part_dof: dict, delta: dict) -> dict:
+    """Apply a canonical-frame delta to a pose: R = R_prev ΔR (and s, t when present)."""
+    pose = {k: v.clone() for k, v in part_dof.items()}
+    if "rotation" in delta:
+        pose["rotation"] = torch.matmul(part_dof["rotation"], delta["rotation"])
+    if "scale" in delta:
+        pose["scale"] = delta["scale"].squeeze(-1) * part_dof["scale"]
+    if "trans" in delta:
+        pose["translation"] = part_dof["translation"] + part_dof["scale"][..., None, None] * torch.matmul(
+            part_dof["rotation"], delta["trans"].unsqueeze(-1))
+    return pose
+
+
+def convert_pred_rtvec_to_matrix(pred: torch.Tensor, sym: bool) -> torch.Tensor:
+    """(…, D) -> (…, 3, 3): D=3 y-axis for symmetric objects, D=9 matrix to re-orthogonalise."""
+    if sym:
+        return compute_rotation_matrix_from_3d(pred.reshape(-1, pred.shape[-1])).reshape(pred.shape[:-1] + (3, 3))
+    return compute_rotation_matrix_from_matrix(pred.reshape(-1, 3, 3)).reshape(pred.shape[:-1] + (3, 3))
+
+
+def eval_part_model(gt: dict, pred: dict, yaxis_only: bool = False) -> dict:
+    return {"sdiff": scale_diff(gt["scale"], pred["scale"]),
+            "tdiff": trans_diff(gt["translation"], pred["translation"]),
+            "rdiff": rot_diff_degree(gt["rotation"], pred["rotation"], yaxis_only=yaxis_only)}
+
+
+def eval_part_full(gt: dict, pred: dict, per_instance: bool = False, yaxis_only: bool = False):
+    """Per-part errors + 5°5cm / 10°10cm hit rates; returns (batch means, per-instance values)."""
+    d = eval_part_model(gt, pred, yaxis_only=yaxis_only)
+    d["5deg5cm"] = torch.logical_and(d["rdiff"] <= 5.0, d["tdiff"] <= 0.05).float()
+    d["10deg10cm"] = torch.logical_and(d["rdiff"] <= 10.0, d["tdiff"] <= 0.10).float()
+    flat = {f"{k}_{i}": v[..., i] for k, v in d.items() for i in range(v.shape[-1])}
+    per = {k: v.clone() for k, v in flat.items()} if per_instance else {}
+    return {k: v.mean(dim=0) for k, v in flat.items()}, per

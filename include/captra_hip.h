@@ -101,7 +101,8 @@ int captra_canonicalize(int b, int p, int n, const float *pts, const float *mean
 
 /* Ball query for up to 4 radii in ONE scan of xyz (PointNetSetAbstractionMsg's loop over
  * radius_list, pointnet_utils.py:228-233).  idx_r (r = 0..nr-1) is (B,M,nsample[r]) i32 with
- * exactly the contents captra_ball_query(radius[r], nsample[r]) would produce. */
+ * exactly the contents captra_ball_query(radius[r], nsample[r]) would produce.
+ * radius, nsample and the idx pointer table are HOST arrays (read at launch time). */
 int captra_ball_query_multi(int b, int n, int m, int nr, const float *radius, const int *nsample,
                             const float *new_xyz, const float *xyz, int *const *idx,
                             captra_stream_t stream);
@@ -144,11 +145,12 @@ int captra_fp_interpolate_concat(int b, int n, int s, int c1, int c2, const floa
  * (part_fit_st_no_ransac pose_fit.py:38-53 -> transform_pts_mask procrustes.py:132-164 with a
  * given rotation; sym adds the in-plane 2x2 SVD of procrustes.py:167-228).  No host round trip.
  *   labels (B,N) i32 (values >= P are background); src = predicted NOCS (B,P,3,N) channel-major;
- *   tgt = camera points (B,3,N); rot (B,P,3,3).
- *   -> scale (B,P), trans (B,P,3), valid (B,P) i32 = (count > 3) && finite(scale, trans). */
+ *   tgt = camera points, (B,3,N) shared by the parts (tgt_per_part = 0, what the track loop has)
+ *   or (B,P,3,N) (tgt_per_part = 1); rot (B,P,3,3); given_scale (B,P) or NULL (pose_fit.py:38).
+ *   -> scale (B,P), trans (B,P,3), valid (B,P) i32 = (count > 3) && finite(scale, trans, rot). */
 int captra_part_fit_st(int b, int p, int n, int sym, const int *labels, const float *src,
-                       const float *tgt, const float *rot, float *scale, float *trans, int *valid,
-                       captra_stream_t stream);
+                       const float *tgt, int tgt_per_part, const float *rot, const float *given_scale,
+                       float *scale, float *trans, int *valid, captra_stream_t stream);
 
 /* Batched 3x3 orthogonal Procrustes: R = U diag(1,1,det(U V^T)) V^T with U S V^T = tgt^T src
  * (rotate_pts_batch procrustes.py:25-56).  src, tgt (nb,N,3) -> rot (nb,3,3).  One-sided Jacobi. */

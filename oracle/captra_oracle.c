@@ -356,12 +356,13 @@ static void rot2d_from_cov(const double M[4], double R2[4]) {
 }
 
 EXPORT void oracle_part_fit_st(int b, int p, int n, int sym, const int *labels, const float *src,
-                               const float *tgt, const float *rot, float *scale, float *trans, int *valid) {
+                               const float *tgt, int tgt_per_part, const float *rot, const float *given_scale,
+                               float *scale, float *trans, int *valid) {
     for (int bi = 0; bi < b; ++bi)
         for (int pi = 0; pi < p; ++pi) {
             const int q = bi * p + pi;
             const float *S = src + (size_t)q * 3 * n;   /* (3,N) predicted NOCS of part pi */
-            const float *T = tgt + (size_t)bi * 3 * n;  /* (3,N) camera points */
+            const float *T = tgt + (size_t)(tgt_per_part ? q : bi) * 3 * n; /* (3,N) camera points */
             const int *lab = labels + (size_t)bi * n;
             double R[9];
             for (int i = 0; i < 9; ++i) R[i] = rot[(size_t)q * 9 + i];
@@ -429,7 +430,7 @@ EXPORT void oracle_part_fit_st(int b, int p, int n, int sym, const int *labels, 
                         dn += rs[a] * rs[a];
                     }
                 }
-            const double sca = num / (dn + 1e-6);
+            const double sca = given_scale ? (double)given_scale[q] : num / (dn + 1e-6);
             /* translate_pts_mask(scale * R src, target, w) procrustes.py:123-129,159-162 */
             double tr[3] = {0, 0, 0};
             for (int i = 0; i < n; ++i)

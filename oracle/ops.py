@@ -191,14 +191,18 @@ def fp_interpolate_concat(unknown, known, skip, feat_known):
     return out
 
 
-def part_fit_st(labels, src, tgt, rot, sym):
-    """labels (B,N) int, src (B,P,3,N), tgt (B,3,N), rot (B,P,3,3) -> scale (B,P), trans (B,P,3), valid (B,P)."""
+def part_fit_st(labels, src, tgt, rot, sym, given_scale=None):
+    """labels (B,N) int, src (B,P,3,N), tgt (B,3,N) or (B,P,3,N), rot (B,P,3,3)
+    -> scale (B,P), trans (B,P,3), valid (B,P)."""
     labels, src, tgt, rot = _i(labels), _f(src), _f(tgt), _f(rot)
     B, P, _, N = src.shape
+    per_part = 1 if tgt.ndim == 4 else 0
+    gs = None if given_scale is None else _f(given_scale)
     scale = np.empty((B, P), np.float32)
     trans = np.empty((B, P, 3), np.float32)
     valid = np.empty((B, P), np.int32)
-    lib().oracle_part_fit_st(C.c_int(B), C.c_int(P), C.c_int(N), C.c_int(1 if sym else 0), _p(labels), _p(src), _p(tgt), _p(rot), _p(scale), _p(trans), _p(valid))
+    lib().oracle_part_fit_st(C.c_int(B), C.c_int(P), C.c_int(N), C.c_int(1 if sym else 0), _p(labels), _p(src), _p(tgt),
+                             C.c_int(per_part), _p(rot), _p(gs), _p(scale), _p(trans), _p(valid))
     return scale, trans, valid
 
 

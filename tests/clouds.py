@@ -67,3 +67,76 @@ def s_uni(i: int, n: int = 16384):
     """S-uni16k(seed): n points uniform in [-0.5,0.5]^3."""
     rng = np.random.default_rng(3000 + i)
     return (rng.random((n, 3), dtype=np.float32) - 0.5).astype(np.float32)
+
+
+# ---------------------------------------------------------------------------------------------
+# synthetic trajectories in the track loop's data contract (SURVEY.md §8b "Loop API")
+# ---------------------------------------------------------------------------------------------
+def _rot_y(a):
+    c, s = np.cos(a), np.sin(a)
+    return np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]])
+
+
+def _rot_x(a):
+    c, s = np.cos(a), np.sin(a)
+    return np.array([[1, 0, 0], [0, c, -s], [0, s, c]])
+
+
+def make_trajectory(kind: str, batch: int, frames: int, seed: int = 0):
+    """List over frames of frame dicts (torch tensors on the CPU).
+
+    kind 'nocs': S-nocs clouds (P=1, labels 0 = object, 1 = background);
+    kind 'arti': S-arti clouds (P=4 boxes).
+    Canonical (NOCS) coordinates are the cloud itself scaled into the unit-diagonal box; the
+    ground-truth pose of frame t is a smooth rigid motion about 1 m in front of the camera:
+    cam = s * R_t * nocs + t_t.  'points' are mean-subtracted camera points."""
+    import torch
+    rng = np.random.default_rng(5000 + seed)
+    P = 1 if kind == "nocs" else 4
+    canon, labels = [], []
+    for b in range(batch):
+        pts, lab, _ = (s_nocs if kind == "nocs" else s_arti)(seed * 100 + b)
+        extent = np.linalg.norm(pts.max(0) - pts.min(0))
+        canon.append(pts / extent)
+        labels.append(lab)
+    canon = np.stack(canon).astype(np.float32)            # (B,N,3) NOCS coordinates
+    labels = np.stack(labels)
+    N = canon.shape[1]
+    scale = (0.30 + 0.05 * rng.random(batch)).astype(np.float32)
+    base_t = np.stack([rng.normal(0, 0.05, batch), rng.normal(0, 0.05, batch), 1.0 + 0.1 * rng.random(batch)], -1)
+    rate = rng.normal(0, 0.03, (batch, 2))
+    vel = rng.normal(0, 0.01, (batch, 3))
+    data = []
+    for t in range(frames):
+        rot = np.stack([_rot_y(0.4 + rate[b, 0] * t) @ _rot_x(0.2 + rate[b, 1] * t) for b in range(batch)]).astype(np.float32)
+        trans = (base_t + vel * t).astype(np.float32)
+        cam = scale[:, None, None] * np.einsum("bij,bnj->bni", rot, canon) + trans[:, None, :]
+        if P > 1:
+            # articulated: part p slides along its local x by a part-specific offset
+            for p in range(P):
+                off = 0.02 * p * (1 + 0.2 * t)
+                cam[labels == p] += (rot[:, :, 0] * off)[np.nonzero(labels == p)[0]]
+        mean = cam.mean(1, keepdims=True)
+        part_poses = []
+        for p in range(P):
+            tp = trans.copy()
+            if P > 1:
+                tp = tp + rot[:, :, 0] * (0.02 * p * (1 + 0.2 * t))
+            part_poses.append({"rotation": torch.from_numpy(rot.copy()),
+                               "translation": torch.from_numpy(tp.astype(np.float32)).unsqueeze(-1),
+                               "scale": torch.from_numpy(scale.copy())})
+        corners = np.zeros((batch, P, 2, 3), np.float32)
+        for b in range(batch):
+            for p in range(P):
+                sel = canon[b][labels[b] == p]
+                corners[b, p, 0], corners[b, p, 1] = sel.min(0), sel.max(0)
+        data.append({
+            "points": torch.from_numpy((cam - mean).transpose(0, 2, 1).astype(np.float32).copy()),
+            "labels": torch.from_numpy(labels.copy()),
+            "nocs": torch.from_numpy(canon.transpose(0, 2, 1).copy()),
+            "meta": {"path": [f"synthetic/inst{seed * 100 + b}/track0/{t:04d}.npz" for b in range(batch)],
+                     "nocs2camera": part_poses,
+                     "points_mean": torch.from_numpy(mean.transpose(0, 2, 1).astype(np.float32).copy()),
+                     "nocs_corners": torch.from_numpy(corners)},
+        })
+    return data

@@ -1,0 +1,214 @@
+"""Pin the CPU oracle against the golden vectors captured from the reference's own CPU path
+(tests/golden/make_golden.py).  Runs without a GPU.
+
+Tolerances: index outputs bit-exact (ball-query rows flagged boundary-ambiguous at capture time
+are skipped — the reference's CPU and CUDA distance forms differ there); network
+outputs 1e-4 max-abs (the north-star tolerance for NOCS coordinates / rotation matrices).
+"""
+import hashlib
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import model as OM
+from oracle import ops as O
+from tests import clouds
+from tests.weights import make_state_dict
+
+G = Path(__file__).resolve().parent / "golden"
+SA1 = [(0.05, 32), (0.1, 64), (0.2, 128)]
+SA2 = [(0.2, 64), (0.4, 128)]
+TOL = 1e-4
+
+
+def nocs_batch(ids, dup=False):
+    fn = clouds.s_nocs_dup if dup else clouds.s_nocs
+    return np.stack([fn(i)[0] for i in ids]).astype(np.float32)
+
+
+@pytest.fixture(scope="module")
+def levels():
+    xyz = np.concatenate([nocs_batch([0, 1]), nocs_batch([0, 1], dup=True)])
+    l1 = O.furthest_point_sample(xyz, 512)
+    xyz1 = np.take_along_axis(xyz, l1[..., None].astype(np.int64), 1)
+    l2 = O.furthest_point_sample(xyz1, 128)
+    xyz2 = np.take_along_axis(xyz1, l2[..., None].astype(np.int64), 1)
+    return xyz, l1, xyz1, l2, xyz2
+
+
+def test_g1_fps_indices_bit_exact(levels):
+    _, l1, _, l2, _ = levels
+    g = np.load(G / "g1_fps.npz")
+    # clean clouds AND clouds with duplicated points (lowest-index tie rule = the CPU path's)
+    np.testing.assert_array_equal(l1, g["l1"].astype(np.int32))
+    np.testing.assert_array_equal(l2, g["l2"].astype(np.int32))
+
+
+def test_g2_ball_query_bit_exact_away_from_the_boundary(levels):
+    xyz, _, xyz1, _, xyz2 = levels
+    g = np.load(G / "g2_ball_query.npz")
+    for lvl, pairs, pts, ctr in (("sa1", SA1, xyz[:2], xyz1[:2]), ("sa2", SA2, xyz1[:2], xyz2[:2])):
+        for r, k in pairs:
+            mine = O.ball_query(r, k, pts, ctr)
+            ref = g[f"{lvl}_{k}"].astype(np.int32)
+            keep = ~g[f"{lvl}_{k}_ambiguous"]
+            assert keep.mean() > 0.98
+            np.testing.assert_array_equal(mine[keep], ref[keep])
+
+
+def test_g3_group_gather_hash(levels):
+    _, l1, _, _, _ = levels
+    g = np.load(G / "g3_group.npz")
+    rng = np.random.default_rng(33)
+    feat = rng.standard_normal((2, 6, 4096)).astype(np.float32)
+    idx = np.load(G / "g2_ball_query.npz")["sa1_32"].astype(np.int32)
+    grouped = O.grouping_operation(feat, idx)
+    gathered = O.gather_operation(feat, l1[:2])
+    assert hashlib.sha1(grouped.tobytes()).hexdigest() == str(g["grouped_sha"])
+    assert hashlib.sha1(gathered.tobytes()).hexdigest() == str(g["gathered_sha"])
+    np.testing.assert_array_equal(grouped[:, :, ::64, ::8], g["grouped_slice"])
+    np.testing.assert_array_equal(gathered[:, :, ::16], g["gathered_slice"])
+
+
+def test_g4_three_nn_and_interpolate(levels):
+    xyz, _, xyz1, _, xyz2 = levels
+    g = np.load(G / "g4_three_nn.npz")
+    for tag, unk, kn in (("fp1", xyz[:2], xyz1[:2]), ("fp2", xyz1[:2], xyz2[:2])):
+        d2, idx = O.three_nn(unk, kn)
+        ref_idx, ref_d2 = g[f"{tag}_idx"].astype(np.int32), g[f"{tag}_d2"]
+        # the reference CPU path sorts expanded-form distances: equal up to its ~1e-7 rounding,
+        # so indices may swap only between neighbours that are that close
+        np.testing.assert_allclose(d2, np.maximum(ref_d2, 0), atol=5e-7, rtol=0)
+        differ = idx != ref_idx
+        assert differ.mean() < 1e-3
+        if differ.any():
+            assert np.abs(d2[differ] - np.maximum(ref_d2, 0)[differ]).max() < 5e-7
+    # interpolation on the reference's own neighbours/weights
+    rng = np.random.default_rng(33)
+    rng.standard_normal((2, 6, 4096))          # same stream position as make_golden.py
+    f1 = rng.standard_normal((2, 16, 512)).astype(np.float32)
+    dist = np.sqrt(np.maximum(g["fp1_d2"], 0))
+    recip = 1.0 / (dist + np.float32(1e-8))
+    w = (recip / recip.sum(-1, keepdims=True)).astype(np.float32)
+    out = O.three_interpolate(f1, g["fp1_idx"].astype(np.int32), w)
+    np.testing.assert_allclose(out, g["interp"], atol=2e-6, rtol=0)
+
+
+def _cfg(cat="1", objcfg="obj_info_nocs.yml"):
+    from captra_amd.configs import make_config   # configuration DATA only
+    return make_config(cat, objcfg)
+
+
+def _backbone_shapes(cfg, use_xyz):
+    from captra_amd.backbones import PointNet2Msg  # only to enumerate parameter names/shapes
+    return {k: tuple(v.shape) for k, v in PointNet2Msg(cfg, 128, use_xyz_feat=use_xyz).state_dict().items()}
+
+
+@pytest.mark.parametrize("tag,use_xyz,seed", [("rot", False, 12), ("coord", True, 11)])
+def test_g56_backbone_levels_and_output(tag, use_xyz, seed):
+    g = np.load(G / "g56_backbone.npz")
+    cfg = _cfg()
+    sd = {"bb." + k: v for k, v in make_state_dict(_backbone_shapes(cfg, use_xyz), seed=seed).items()}
+    cloud_cn = np.ascontiguousarray(nocs_batch([0, 1]).transpose(0, 2, 1))
+    out, lv = OM.backbone(sd, "bb", cfg["pointnet"]["camera"], cloud_cn, use_xyz, mlp="torch", want_levels=True)
+    for name in ("sa1", "sa2", "sa3"):
+        ref = g[f"{tag}_{name}"]
+        err = np.abs(lv[name] - ref)
+        # a boundary-ambiguous ball may swap one neighbour: allow a few pooled features to move
+        assert (err > TOL).mean() < 2e-3, (name, err.max(), (err > TOL).mean())
+    err = np.abs(out[:, :, ::8] - g[f"{tag}_out"])
+    assert err.max() < TOL, (err.max(), (err > TOL).mean())
+    assert np.median(err) < 1e-5
+    # against the reference's own CPU three_nn (expanded-form distances): same except at points
+    # that coincide with a sampled centre, where that form turns d2 = 0 into O(1e-8) noise
+    err_cpu = np.abs(out[:, :, ::8] - g[f"{tag}_out_cpuform"])
+    assert (err_cpu > TOL).mean() < 5e-3 and err_cpu.max() < 5e-3, (err_cpu.max(), (err_cpu > TOL).mean())
+
+
+def _track_setup(tag):
+    cat, objcfg, kind, frames = {"bottle": ("1", "obj_info_nocs.yml", "nocs", 5),
+                                 "camera": ("3", "obj_info_nocs.yml", "nocs", 3),
+                                 "drawers": ("drawers", "obj_info_sapien.yml", "arti", 3)}[tag]
+    cfg = _cfg(cat, objcfg)
+    keys = json.load(open(G / "state_dict_keys.json"))[tag]
+    from captra_amd.model import EvalTrackModel   # only to enumerate parameter names/shapes
+    shapes = {k: tuple(v.shape) for k, v in EvalTrackModel(cfg).state_dict().items()}
+    assert sorted(shapes) == keys, "state-dict key names differ from the reference's"
+    sd = make_state_dict(shapes, seed=7)
+    data = clouds.make_trajectory(kind, 2, frames, seed=0)
+    return cfg, sd, data
+
+
+def _init_pose(cfg, data):
+    """The noisy initial pose, drawn with the same seed and draw order as the reference run."""
+    from captra_amd.pose_utils.part_dof_utils import add_noise_to_part_dof, part_model_batch_to_part
+    torch.manual_seed(1234)
+    gt = part_model_batch_to_part(data[0]["meta"]["nocs2camera"], cfg["num_parts"], "cpu")
+    pp = cfg["pose_perturb"]
+    noisy = add_noise_to_part_dof(gt, {"type": pp["type"], "scale": pp["s"], "translation": pp["t"],
+                                       "rotation": float(np.deg2rad(pp["r"]))})
+    return {k: v.numpy() for k, v in noisy.items()}
+
+
+@pytest.mark.parametrize("tag", ["bottle", "camera", "drawers"])
+def test_g9_initial_pose_noise_matches_reference_draws(tag):
+    cfg, _, data = _track_setup(tag)
+    g = np.load(G / "g9_track.npz")
+    init = _init_pose(cfg, data)
+    for key in ("rotation", "translation", "scale"):
+        np.testing.assert_allclose(init[key], g[f"{tag}_0_{key}"], atol=1e-6, rtol=0)
+
+
+@pytest.mark.parametrize("tag", ["bottle", "camera", "drawers"])
+def test_g7_single_step_and_g9_trajectory(tag):
+    cfg, sd, data = _track_setup(tag)
+    g7, g9 = np.load(G / "g7_step.npz"), np.load(G / "g9_track.npz")
+    nframes = len(data)
+    # teacher-forced: every step starts from the REFERENCE's previous pose, so that one flipped
+    # neighbour cannot compound; checks seg / NOCS of step 1 and the pose of every step
+    for i in range(1, nframes):
+        prev = {k: g9[f"{tag}_{i - 1}_{k}"] for k in ("rotation", "translation", "scale")}
+        gt_labels = data[i]["labels"].numpy() if tag == "drawers" else None   # golden uses track_cfg.gt_label there
+        pose, aux = OM.track_step(sd, cfg, data[i]["points"].numpy(), data[i]["meta"]["points_mean"].numpy(), prev, "torch",
+                                  gt_labels=gt_labels)
+        if i == 1:
+            np.testing.assert_array_equal(aux["seg"].argmax(1), g7[f"{tag}_labels"].astype(np.int64))
+            err = np.abs(aux["nocs"] - g7[f"{tag}_nocs"])
+            assert (err > TOL).mean() < 2e-3 and np.median(err) < 1e-5, (err.max(), (err > TOL).mean())
+            np.testing.assert_allclose(aux["seg"], g7[f"{tag}_seg"], atol=1e-3)
+        np.testing.assert_allclose(pose["rotation"], g9[f"{tag}_{i}_rotation"], atol=TOL, rtol=0)
+        np.testing.assert_allclose(pose["scale"], g9[f"{tag}_{i}_scale"], atol=TOL, rtol=1e-4)
+        np.testing.assert_allclose(pose["translation"], g9[f"{tag}_{i}_translation"], atol=TOL, rtol=1e-4)
+
+
+def test_g8_pose_fit_and_procrustes():
+    g = np.load(G / "g8_pose_fit.npz")
+    rng = np.random.default_rng(88)
+    B, P, N = 3, 2, 600
+    src = (rng.random((B, P, N, 3)) - 0.5).astype(np.float32)
+    Rgt = np.stack([clouds._rot_y(0.3 * (b + 1)) @ clouds._rot_x(0.2 * (p + 1)) for b in range(B) for p in range(P)]).reshape(B, P, 3, 3).astype(np.float32)
+    tgt1 = (0.7 * np.einsum("bpij,bpnj->bpni", Rgt, src) + np.array([0.1, -0.2, 1.0])).astype(np.float32)
+    tgt1 += rng.normal(0, 0.01, tgt1.shape).astype(np.float32)
+    labels = g["labels"].astype(np.int32)
+    src_cn = np.ascontiguousarray(src.transpose(0, 1, 3, 2))
+    tgt_cn = np.ascontiguousarray(tgt1[:, 0].transpose(0, 2, 1))
+    for sym in (False, True):
+        scale, trans, valid = O.part_fit_st(labels, src_cn, tgt_cn, Rgt, sym)
+        ref_valid = g[f"fit_sym{int(sym)}_valid"]
+        np.testing.assert_array_equal(valid.astype(bool), ref_valid)
+        # degenerate masks (<= 3 points, empty part) are part of the fixture: invalid there
+        assert not ref_valid[1, 0] and not ref_valid[1, 1] and not ref_valid[2, 0]
+        np.testing.assert_allclose(scale[ref_valid], g[f"fit_sym{int(sym)}_scale"][ref_valid], atol=1e-5, rtol=1e-5)
+        np.testing.assert_allclose(trans[ref_valid], g[f"fit_sym{int(sym)}_trans"][ref_valid][..., 0], atol=1e-5, rtol=1e-5)
+        # an empty part yields scale 0 and translation 0 in the reference as well
+        np.testing.assert_allclose(scale[2, 0], g[f"fit_sym{int(sym)}_scale"][2, 0], atol=1e-6)
+    s3 = src[:, :, :200].reshape(B * P, 200, 3)
+    t3 = tgt1[:, :, :200].reshape(B * P, 200, 3)
+    sc, tc = s3 - s3.mean(1, keepdims=True), t3 - t3.mean(1, keepdims=True)
+    np.testing.assert_allclose(O.procrustes_rot3(sc, tc), g["rot3"], atol=2e-5)
+    tc_ref = tc.copy()
+    tc_ref[..., 2] *= -1
+    np.testing.assert_allclose(O.procrustes_rot3(sc, tc_ref), g["rot3_reflect"], atol=2e-5)
