@@ -1,0 +1,220 @@
+#!/usr/bin/env python
+"""Headline benchmark: tracked frames/s on 4096-point clouds (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): one rigid NOCS category (bottle: 1 part, symmetric),
+4096 points per frame, 32 independent trajectories per GPU, fp32, synthetic S-nocs clouds
+ resident in HBM, seeded random weights of the real architecture.
+One STEP = one frame of the track loop for every trajectory of the rank: CoordNet (canonicalise,
+PointNet++ MSG backbone, seg/NOCS heads) -> labels -> RotationNet (P backbone clouds, rotation heads,
+masked pooling, orthogonalisation) -> per-part Procrustes scale/translation fit; the pose feeds
+the next step (frame i needs pose i-1, reference model.py:408-478).  Trajectories shard over
+GPUs with no data-path dependency; the per-frame pose records are all-gathered with RCCL so that
+every rank holds the full result ("weak" scaling: 32 trajectories per GPU).
+
+Prints ONE JSON line on rank 0 (see the keys below).  `roofline` describes the dominant kernel
+family of the step, measured with HIP events on the launch stream inside the timed region;
+`cpu_baseline` is the CPU oracle (oracle/, a port of the reference's CPU path) timed on the host
+cores of rank 0 at N=1 on a bounded sample of the same workload at batch 1.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak (= fp32 vector peak)
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec
+
+
+def build_workload(batch: int, device, frames: int = 8, category: str = "1"):
+    from captra_amd.configs import make_config
+    from captra_amd.trainer import Trainer
+    from tests import clouds
+    from tests.weights import make_state_dict
+
+    cfg = make_config(category, experiment_dir="/tmp/captra_bench")
+    cfg["device"] = device
+    trainer = Trainer(cfg)
+    shapes = {k: tuple(v.shape) for k, v in trainer.model.state_dict().items()}
+    sd = make_state_dict(shapes, seed=7)
+    trainer.model.load_state_dict(sd)
+    model = trainer.model.eval()
+    # distinct clouds per trajectory (8 base objects tiled), `frames` frames cycled by the loop
+    base = clouds.make_trajectory("nocs", min(batch, 8), frames, seed=0)
+    reps = (batch + len(base[0]["points"]) - 1) // len(base[0]["points"])
+
+    def tile(t):
+        return t.repeat((reps,) + (1,) * (t.dim() - 1))[:batch].contiguous()
+
+    data = []
+    for f in base:
+        meta = {"path": (f["meta"]["path"] * reps)[:batch],
+                "nocs2camera": [{k: tile(v) for k, v in part.items()} for part in f["meta"]["nocs2camera"]],
+                "points_mean": tile(f["meta"]["points_mean"]), "nocs_corners": tile(f["meta"]["nocs_corners"])}
+        data.append({"points": tile(f["points"]), "labels": tile(f["labels"]), "nocs": tile(f["nocs"]), "meta": meta})
+    model.set_data(data)           # host -> HBM once, before any timed region
+    return cfg, sd, model, data
+
+
+def cpu_baseline(cfg, sd, budget_s: float = 15.0):
+    """The CPU oracle (port of the reference's CPU path: C geometry + torch-CPU shared MLPs) on
+    batch 1 of the same workload, timed on this host's cores."""
+    from oracle import model as OM
+    from tests import clouds
+    data = clouds.make_trajectory("nocs", 1, 6, seed=0)
+    pose = {k: v.numpy() for k, v in
+            {"rotation": data[0]["meta"]["nocs2camera"][0]["rotation"].unsqueeze(1),
+             "translation": data[0]["meta"]["nocs2camera"][0]["translation"].unsqueeze(1),
+             "scale": data[0]["meta"]["nocs2camera"][0]["scale"].unsqueeze(1)}.items()}
+    OM.track_step(sd, cfg, data[1]["points"].numpy(), data[1]["meta"]["points_mean"].numpy(), pose, "torch")   # warm-up
+    frames, t0 = 0, time.time()
+    while True:
+        f = data[1 + frames % 5]
+        pose, _ = OM.track_step(sd, cfg, f["points"].numpy(), f["meta"]["points_mean"].numpy(), pose, "torch")
+        frames += 1
+        if time.time() - t0 > budget_s or frames >= 200:
+            break
+    dt = time.time() - t0
+    return {"value": round(frames / dt, 4), "unit": "frames/s", "cores": int(torch.get_num_threads()), "kind": "port",
+            "sample": f"{frames} frames of the bottle workload at batch 1 (4096 pts), oracle/model.py track_step, "
+                      f"{dt:.1f} s wall, host has {os.cpu_count()} logical cores"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="trajectories per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--cpu-budget", type=float, default=15.0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=device)   # RCCL on ROCm
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from captra_amd import _lib, fused
+    from captra_amd.parallel import PoseExchange
+
+    cfg, sd, model, data = build_workload(args.batch, device)
+    B, P = args.batch, cfg["num_parts"]
+    exchange = PoseExchange(B, P, device, world, rank)
+    nframes = len(model.feed_dict)
+    pose = {k: v.clone() for k, v in model.feed_dict[0]["gt_part"].items()}
+
+    def step(i, pose):
+        f = 1 + i % (nframes - 1)
+        with torch.no_grad():
+            _, new_pose = model.track_step(model.feed_dict[f], model.npcs_feed_dict[f], pose)
+        exchange.all_gather(new_pose)          # every rank ends the step holding all poses
+        return new_pose
+
+    for i in range(args.warmup):
+        pose = step(i, pose)
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    timing = not args.no_kernel_timing
+    sync()
+    if timing:
+        _lib.prof_reset()
+        _lib.prof_enable(True)
+        fused.work_reset(True)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        pose = step(args.warmup + i, pose)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if timing:
+        _lib.prof_enable(False)
+        fused.WORK["on"] = False
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert all(torch.isfinite(v).all() for v in pose.values()), "non-finite pose"
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    frames = B * world * args.steps
+    out = {
+        "metric": "tracked frames/sec (4096-pt clouds)", "value": round(frames / elapsed, 2), "unit": "frames/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "NOCS-REAL275-shaped rigid category 'bottle' (1 part, symmetric), 4096 pts/frame, "
+                               f"batch={B} trajectories per GPU, fp32 (BASELINE.json configs[1])",
+                   "points": 4096, "trajectories_per_gpu": B, "parallelism": f"dp{world} (trajectory-sharded, RCCL all-gather of poses)",
+                   "weights": "random-init default_rng(7), real architecture (3.94 M params)"},
+    }
+    if timing:
+        fams = {}
+        for name in _lib.prof_names():
+            ms, n = _lib.prof_read(name)
+            if n:
+                fams[name] = {"ms_total": ms, "launches": n}
+        total_ms = sum(v["ms_total"] for v in fams.values())
+        # the three MFMA shared-MLP entry points are one kernel template (pointwise_mlp.hip)
+        mlp = ["pointwise_mlp", "sa_group_mlp", "mlp_max"]
+        mlp_ms = sum(fams[k]["ms_total"] for k in mlp if k in fams)
+        mlp_launches = sum(fams[k]["launches"] for k in mlp if k in fams)
+        mlp_flops = sum(fused.WORK["flops"].get(k, 0.0) for k in mlp)
+        dominant = max(fams, key=lambda k: fams[k]["ms_total"]) if fams else None
+        if mlp_ms > 0:
+            ach = mlp_flops / (mlp_ms * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                               "kernel": "pw_mlp_kernel (pointwise_mlp + sa_group_mlp + mlp_max entry points), fp32 MFMA 32x32x2",
+                               "avg_launch_us": round(1e3 * mlp_ms / max(mlp_launches, 1), 2),
+                               "flops_per_launch": round(mlp_flops / max(mlp_launches, 1)),
+                               "share_of_kernel_time": round(mlp_ms / max(total_ms, 1e-9), 3), "dominant_family": dominant}
+        if "ball_query" in fams:
+            bq = fams["ball_query"]
+            nbytes = fused.WORK["bytes"].get("ball_query", 0.0)
+            gbs = nbytes / (bq["ms_total"] * 1e-3) / 1e9
+            out["roofline_ball_query"] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                          "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None,
+                                          "avg_launch_us": round(1e3 * bq["ms_total"] / bq["launches"], 2)}
+        out["kernel_ms_per_step"] = {k: round(v["ms_total"] / args.steps, 3) for k, v in sorted(fams.items(), key=lambda kv: -kv[1]["ms_total"])}
+        out["kernel_ms_per_step"]["_sum_captra_kernels"] = round(total_ms / args.steps, 3)
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(cfg, sd, args.cpu_budget)
+        out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -13,6 +13,22 @@ from . import _lib as L
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID_M05 = 0, 1, 2
 
+# Algorithmic work accounting (bench.py's roofline object): per kernel family, the flops / bytes the
+# launches of this process asked for.  Off by default; costs one dict update per launch when on.
+WORK = {"on": False, "flops": {}, "bytes": {}}
+
+
+def work_reset(on: bool = True) -> None:
+    WORK["on"] = on
+    WORK["flops"].clear()
+    WORK["bytes"].clear()
+
+
+def _work(name: str, flops: float = 0.0, nbytes: float = 0.0) -> None:
+    if WORK["on"]:
+        WORK["flops"][name] = WORK["flops"].get(name, 0.0) + flops
+        WORK["bytes"][name] = WORK["bytes"].get(name, 0.0) + nbytes
+
 
 def canonicalize(pts, mean, rot, trans, scale, num_parts: int = 1, want_cn=True, want_n3=True):
     """pts (B,3,N), mean (B,3[,1]), rot (B*P,3,3), trans (B*P,3[,1]), scale (B*P) ->
@@ -45,6 +61,8 @@ def ball_query_multi(radii, nsamples, xyz_n3, new_xyz_n3):
     with torch.cuda.device(xyz_n3.device):
         L.call("captra_ball_query_multi", B, N, M, nr, C.cast(c_r, C.c_void_p), C.cast(c_k, C.c_void_p),
                L.ptr(new_xyz_n3), L.ptr(xyz_n3), C.cast(c_p, C.c_void_p))
+    # ball_query = 12N + 12M + 4MK bytes per cloud and radius
+    _work("ball_query", nbytes=B * sum(12 * N + 12 * M + 4 * M * int(k) for k in nsamples))
     return outs
 
 
@@ -59,6 +77,7 @@ def pointwise_mlp(x, wt, bias, act: int = ACT_RELU, out=None):
         out = torch.empty((B, cout) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
         L.call("captra_pointwise_mlp", B, cin, cout, l, L.ptr(x), L.ptr(wt), L.ptr(bias), act, L.ptr(out))
+    _work("pointwise_mlp", flops=2.0 * B * cin * cout * l, nbytes=4.0 * B * l * (cin + cout))
     return out
 
 
@@ -74,6 +93,8 @@ def sa_group_mlp(feat, xyz_cn, new_xyz_n3, idx, wt, bias):
     with torch.cuda.device(xyz_cn.device):
         L.call("captra_sa_group_mlp", B, N, M, K, cfeat, cout, L.ptr(feat), L.ptr(xyz_cn), L.ptr(new_xyz_n3), L.ptr(idx),
                L.ptr(wt), L.ptr(bias), L.ptr(y))
+    _work("sa_group_mlp", flops=2.0 * B * (cfeat + 3) * cout * M * K,
+          nbytes=4.0 * B * ((cfeat + 3) * N + M * K + 3 * M + cout * M * K))
     return y
 
 
@@ -84,6 +105,7 @@ def mlp_max(x, wt, bias, out, co_off: int):
     cout = wt.shape[1]
     with torch.cuda.device(x.device):
         L.call("captra_mlp_max", B, cin, cout, M, K, L.ptr(x), L.ptr(wt), L.ptr(bias), L.ptr(out), out.shape[1], co_off)
+    _work("mlp_max", flops=2.0 * B * cin * cout * M * K, nbytes=4.0 * B * (cin * M * K + cout * M))
     return out
 
 

@@ -1,0 +1,67 @@
+"""Multi-GPU layer of the track loop: trajectory sharding + RCCL all-gather of per-frame poses.
+
+The reference is single-process / single-GPU (`cuda:%d`, configs/config.py:68; no torch.distributed
+anywhere).  The path shards over the batch of independent trajectories and nowhere
+else (frame i needs pose i-1; a cloud is never split): trajectory b lives on rank b mod G with a
+full copy of both nets' weights (15.8 MB), so the data path has NO collective.  The only exchange
+is the result: after each frame every rank contributes its packed pose records
+[R(9) t(3) s(1) valid(1)] x P fp32 per trajectory and receives everyone's — 56·P bytes per
+trajectory, latency-bound on xGMI.  One process per GPU, `torch.distributed`
+backend "nccl" (= RCCL on ROCm) on the GPU box, "gloo" in the CPU tests.
+"""
+from __future__ import annotations
+
+import torch
+
+POSE_RECORD = 14  # floats per (trajectory, part): rotation 9, translation 3, scale 1, valid 1
+
+
+def shard_range(total: int, world: int, rank: int) -> range:
+    """Contiguous, balanced share of `total` trajectories for `rank` (first `total % world` ranks get one more)."""
+    base, extra = divmod(total, world)
+    start = rank * base + min(rank, extra)
+    return range(start, start + base + (1 if rank < extra else 0))
+
+
+def pack_pose(pose: dict, valid: torch.Tensor | None = None) -> torch.Tensor:
+    """{'rotation' (B,P,3,3), 'translation' (B,P,3,1), 'scale' (B,P)} -> (B,P,14) fp32."""
+    B, P = pose["scale"].shape
+    v = torch.ones(B, P, 1, dtype=torch.float32, device=pose["scale"].device) if valid is None else valid.float().reshape(B, P, 1)
+    return torch.cat([pose["rotation"].reshape(B, P, 9).float(), pose["translation"].reshape(B, P, 3).float(),
+                      pose["scale"].reshape(B, P, 1).float(), v], dim=-1).contiguous()
+
+
+def unpack_pose(rec: torch.Tensor) -> tuple[dict, torch.Tensor]:
+    """(B,P,14) -> (pose dict, valid (B,P) bool)."""
+    B, P, _ = rec.shape
+    pose = {"rotation": rec[..., 0:9].reshape(B, P, 3, 3), "translation": rec[..., 9:12].reshape(B, P, 3, 1),
+            "scale": rec[..., 12]}
+    return pose, rec[..., 13] > 0.5
+
+
+class PoseExchange:
+    """All-gather of the packed pose records of one frame.  Buffers are allocated once; with
+    world == 1 it degenerates to a local copy so that the single-GPU step does the same packing."""
+
+    def __init__(self, batch_per_rank: int, num_parts: int, device, world: int = 1, rank: int = 0):
+        self.world, self.rank = world, rank
+        self.local = torch.empty(batch_per_rank, num_parts, POSE_RECORD, dtype=torch.float32, device=device)
+        self.gathered = torch.empty(world * batch_per_rank, num_parts, POSE_RECORD, dtype=torch.float32, device=device)
+        self.handle = None
+
+    def all_gather(self, pose: dict, valid: torch.Tensor | None = None, async_op: bool = False) -> torch.Tensor:
+        self.local.copy_(pack_pose(pose, valid))
+        if self.world == 1:
+            self.gathered.copy_(self.local)
+            return self.gathered
+        import torch.distributed as dist
+        self.handle = dist.all_gather_into_tensor(self.gathered, self.local, async_op=async_op)
+        if not async_op:
+            self.handle = None
+        return self.gathered
+
+    def wait(self) -> torch.Tensor:
+        if self.handle is not None:
+            self.handle.wait()
+            self.handle = None
+        return self.gathered

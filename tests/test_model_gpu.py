@@ -1,0 +1,314 @@
+"""GPU parity of the fused kernels, the backbone, the networks and the track loop.
+
+Three layers of evidence:
+  1. fused kernels vs the C oracle on the same inputs — BIT-EXACT for the MFMA shared-MLP layers
+     (both are the k-ascending fmaf chain), canonicalisation and FP interpolation; 1e-5 for the
+     pose-fit reductions (different summation order);
+  2. captra_amd modules vs the golden vectors captured from the reference (1e-4, the north-star
+     tolerance on NOCS coordinates and rotation matrices);
+  3. the EvalTrackModel / Trainer loop vs the golden trajectories, teacher-forced per step and
+     free-running.
+"""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import model as OM
+from oracle import ops as O
+from tests import clouds
+from tests.weights import make_state_dict
+
+pytestmark = pytest.mark.gpu
+G = Path(__file__).resolve().parent / "golden"
+TOL = 1e-4
+
+
+def _dev(a, device):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+
+
+def nocs_batch(ids):
+    return np.stack([clouds.s_nocs(i)[0] for i in ids]).astype(np.float32)
+
+
+# ------------------------------------------------------------------------------ fused kernels
+@pytest.mark.parametrize("cin,cout,L,act", [(3, 32, 4096, 1), (6, 64, 1000, 1), (64, 96, 2048, 1), (128, 128, 512, 1),
+                                             (323, 128, 8192, 1), (515, 256, 128, 1), (1536, 256, 128, 1),
+                                             (128, 2, 4096, 0), (128, 3, 777, 2), (256, 6, 4096, 0), (134, 128, 4100, 1),
+                                             (196, 256, 640, 1), (1, 1, 1, 0), (33, 200, 130, 1)])
+def test_pointwise_mlp_bit_exact(device, cin, cout, L, act):
+    from captra_amd import fused
+    rng = np.random.default_rng(cin * 1000 + cout)
+    x = rng.standard_normal((2, cin, L)).astype(np.float32)
+    wt = (rng.standard_normal((cin, cout)) / np.sqrt(cin)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    got = fused.pointwise_mlp(_dev(x, device), _dev(wt, device), _dev(b, device), act).cpu().numpy()
+    ref = O.pointwise_mlp(x, wt, b, act)
+    if act == 2:
+        np.testing.assert_allclose(got, ref, atol=2e-7, rtol=0)      # expf differs in the last ulp
+    else:
+        np.testing.assert_array_equal(got, ref)
+
+
+@pytest.mark.parametrize("cfeat,cout,n,m,k", [(0, 32, 4096, 512, 32), (3, 64, 4096, 512, 64), (3, 64, 4096, 512, 128),
+                                               (320, 128, 512, 128, 64), (320, 128, 512, 128, 128), (5, 40, 300, 37, 32)])
+def test_sa_group_mlp_bit_exact(device, cfeat, cout, n, m, k):
+    from captra_amd import fused
+    rng = np.random.default_rng(cfeat + cout + k)
+    B = 2
+    xyz_cn = (rng.random((B, 3, n), dtype=np.float32) - 0.5)
+    feat = rng.standard_normal((B, cfeat, n)).astype(np.float32) if cfeat else None
+    new_xyz = (rng.random((B, m, 3), dtype=np.float32) - 0.5)
+    idx = rng.integers(0, n, (B, m, k)).astype(np.int32)
+    wt = (rng.standard_normal((cfeat + 3, cout)) / np.sqrt(cfeat + 3)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    got = fused.sa_group_mlp(None if feat is None else _dev(feat, device), _dev(xyz_cn, device), _dev(new_xyz, device),
+                             _dev(idx, device), _dev(wt, device), _dev(b, device)).cpu().numpy()
+    ref = O.pointwise_mlp(O.sa_group(feat, xyz_cn, new_xyz, idx), wt, b, 1)
+    np.testing.assert_array_equal(got, ref)
+
+
+@pytest.mark.parametrize("cin,cout,m,k", [(32, 64, 512, 32), (64, 128, 512, 64), (96, 128, 512, 128), (128, 256, 128, 64),
+                                           (196, 256, 128, 128), (512, 1024, 1, 128), (16, 40, 37, 32)])
+def test_mlp_max_bit_exact(device, cin, cout, m, k):
+    from captra_amd import fused
+    rng = np.random.default_rng(cin + cout + m)
+    x = rng.standard_normal((2, cin, m, k)).astype(np.float32)
+    wt = (rng.standard_normal((cin, cout)) / np.sqrt(cin)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    out = torch.full((2, cout + 7, m), -1.0, device=device)
+    fused.mlp_max(_dev(x, device), _dev(wt, device), _dev(b, device), out, 5)
+    ref = O.max_over_k(O.pointwise_mlp(x, wt, b, 1))
+    got = out.cpu().numpy()
+    np.testing.assert_array_equal(got[:, 5:5 + cout], ref)
+    assert (got[:, :5] == -1).all() and (got[:, 5 + cout:] == -1).all()     # neighbours untouched
+
+
+def test_mlp_max_rejects_unsupported_k(device):
+    from captra_amd import _lib, fused
+    with pytest.raises(_lib.CaptraHipError):
+        fused.mlp_max(torch.zeros(1, 4, 3, 48, device=device), torch.zeros(4, 8, device=device),
+                      torch.zeros(8, device=device), torch.zeros(1, 8, 3, device=device), 0)
+
+
+@pytest.mark.parametrize("P", [1, 4])
+def test_canonicalize_bit_exact(device, P):
+    from captra_amd import fused
+    rng = np.random.default_rng(P)
+    B, N = 3, 4096
+    pts = (rng.random((B, 3, N), dtype=np.float32) - 0.5)
+    mean = rng.standard_normal((B, 3)).astype(np.float32)
+    rot = np.stack([clouds._rot_y(0.1 * i) @ clouds._rot_x(0.2 * i) for i in range(B * P)]).astype(np.float32)
+    trans = rng.standard_normal((B * P, 3)).astype(np.float32)
+    scale = (0.2 + rng.random(B * P)).astype(np.float32)
+    cn, n3 = fused.canonicalize(_dev(pts, device), _dev(mean, device), _dev(rot, device), _dev(trans, device), _dev(scale, device), P)
+    rcn, rn3 = O.canonicalize(pts, mean, rot, trans, scale, P)
+    np.testing.assert_array_equal(cn.cpu().numpy(), rcn)
+    np.testing.assert_array_equal(n3.cpu().numpy(), rn3)
+
+
+@pytest.mark.parametrize("n,s,c1,c2", [(512, 128, 320, 256), (4096, 512, 3, 128), (4096, 512, 6, 128), (300, 7, 0, 5), (1500, 6000, 2, 9)])
+def test_fp_interpolate_concat_bit_exact(device, n, s, c1, c2):
+    from captra_amd import fused
+    rng = np.random.default_rng(n + s)
+    B = 2
+    unknown = (rng.random((B, n, 3), dtype=np.float32) - 0.5)
+    known = (rng.random((B, s, 3), dtype=np.float32) - 0.5)
+    known[:, : min(s, n) // 2] = unknown[:, : min(s, n) // 2]          # exact coincidences (d = 0)
+    skip = rng.standard_normal((B, c1, n)).astype(np.float32) if c1 else None
+    fk = rng.standard_normal((B, c2, s)).astype(np.float32)
+    got = fused.fp_interpolate_concat(_dev(unknown, device), _dev(known, device), None if skip is None else _dev(skip, device),
+                                      _dev(fk, device)).cpu().numpy()
+    np.testing.assert_array_equal(got, O.fp_interpolate_concat(unknown, known, skip, fk))
+
+
+@pytest.mark.parametrize("sym", [False, True])
+def test_part_fit_st_vs_oracle_and_golden(device, sym):
+    from captra_amd.pose_utils.pose_fit import part_fit_st_cn, part_fit_st_no_ransac
+    g = np.load(G / "g8_pose_fit.npz")
+    rng = np.random.default_rng(88)
+    B, P, N = 3, 2, 600
+    src = (rng.random((B, P, N, 3)) - 0.5).astype(np.float32)
+    Rgt = np.stack([clouds._rot_y(0.3 * (b + 1)) @ clouds._rot_x(0.2 * (p + 1)) for b in range(B) for p in range(P)]).reshape(B, P, 3, 3).astype(np.float32)
+    tgt1 = (0.7 * np.einsum("bpij,bpnj->bpni", Rgt, src) + np.array([0.1, -0.2, 1.0])).astype(np.float32)
+    tgt1 += rng.normal(0, 0.01, tgt1.shape).astype(np.float32)
+    tgt = np.repeat(tgt1[:, :1], P, axis=1)
+    labels = g["labels"].astype(np.int64)
+    # reference-signature entry point
+    model, valid = part_fit_st_no_ransac(_dev(labels, device), _dev(src, device), _dev(tgt, device), _dev(Rgt, device),
+                                         {"num_parts": P, "sym": sym})
+    ref_valid = g[f"fit_sym{int(sym)}_valid"]
+    np.testing.assert_array_equal(valid.cpu().numpy(), ref_valid)
+    np.testing.assert_allclose(model["scale"].cpu().numpy()[ref_valid], g[f"fit_sym{int(sym)}_scale"][ref_valid], atol=1e-5, rtol=1e-5)
+    np.testing.assert_allclose(model["translation"].cpu().numpy()[ref_valid], g[f"fit_sym{int(sym)}_trans"][ref_valid], atol=1e-5, rtol=1e-5)
+    # channel-major fast path vs the oracle
+    src_cn = np.ascontiguousarray(src.transpose(0, 1, 3, 2))
+    tgt_cn = np.ascontiguousarray(tgt1[:, 0].transpose(0, 2, 1))
+    s, t, v = part_fit_st_cn(_dev(labels.astype(np.int32), device), _dev(src_cn, device), _dev(tgt_cn, device), _dev(Rgt, device), sym)
+    so, to, vo = O.part_fit_st(labels, src_cn, tgt_cn, Rgt, sym)
+    np.testing.assert_array_equal(v.cpu().numpy(), vo.astype(bool))
+    np.testing.assert_allclose(s.cpu().numpy(), so, atol=1e-5, rtol=1e-5)
+    np.testing.assert_allclose(t.cpu().numpy()[..., 0], to, atol=1e-5, rtol=1e-5)
+
+
+def test_procrustes_rot3_vs_golden(device):
+    from captra_amd.pose_utils.procrustes import rotate_pts_batch
+    g = np.load(G / "g8_pose_fit.npz")
+    rng = np.random.default_rng(88)
+    B, P, N = 3, 2, 600
+    src = (rng.random((B, P, N, 3)) - 0.5).astype(np.float32)
+    Rgt = np.stack([clouds._rot_y(0.3 * (b + 1)) @ clouds._rot_x(0.2 * (p + 1)) for b in range(B) for p in range(P)]).reshape(B, P, 3, 3).astype(np.float32)
+    tgt1 = (0.7 * np.einsum("bpij,bpnj->bpni", Rgt, src) + np.array([0.1, -0.2, 1.0])).astype(np.float32)
+    tgt1 += rng.normal(0, 0.01, tgt1.shape).astype(np.float32)
+    s3 = src[:, :, :200].reshape(B * P, 200, 3)
+    t3 = tgt1[:, :, :200].reshape(B * P, 200, 3)
+    sc, tc = s3 - s3.mean(1, keepdims=True), t3 - t3.mean(1, keepdims=True)
+    got = rotate_pts_batch(_dev(sc, device), _dev(tc, device)).cpu().numpy()
+    np.testing.assert_allclose(got, g["rot3"], atol=2e-5)
+    tc_ref = tc.copy()
+    tc_ref[..., 2] *= -1
+    got = rotate_pts_batch(_dev(sc, device), _dev(tc_ref, device)).cpu().numpy()
+    np.testing.assert_allclose(got, g["rot3_reflect"], atol=2e-5)
+    assert np.allclose(np.linalg.det(got), 1.0, atol=1e-5)              # proper rotation even for det(M) < 0
+
+
+# ---------------------------------------------------------------------------------- backbone
+@pytest.mark.parametrize("tag,use_xyz,seed", [("rot", False, 12), ("coord", True, 11)])
+def test_backbone_vs_golden_and_oracle(device, tag, use_xyz, seed):
+    from captra_amd.backbones import PointNet2Msg
+    from captra_amd.configs import make_config
+    g = np.load(G / "g56_backbone.npz")
+    cfg = make_config("1")
+    net = PointNet2Msg(cfg, 128, use_xyz_feat=use_xyz)
+    sd = make_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, seed=seed)
+    net.load_state_dict(sd)
+    net = net.to(device).eval()
+    cloud = nocs_batch([0, 1])
+    cloud_cn = _dev(cloud.transpose(0, 2, 1), device)
+    with torch.no_grad():
+        l1_xyz, l1_points = net.sa1(cloud_cn, cloud_cn if use_xyz else None)
+        l2_xyz, l2_points = net.sa2(l1_xyz, l1_points)
+        _, l3_points = net.sa3(l2_xyz, l2_points)
+        out = net(cloud_cn)
+    for name, got in (("sa1", l1_points), ("sa2", l2_points), ("sa3", l3_points)):
+        np.testing.assert_allclose(got.cpu().numpy(), g[f"{tag}_{name}"], atol=TOL, rtol=0)
+    np.testing.assert_allclose(out.cpu().numpy()[:, :, ::8], g[f"{tag}_out"], atol=TOL, rtol=0)
+    # and bit-exact against the oracle's exact-arithmetic mode
+    ref = OM.backbone({"bb." + k: v for k, v in sd.items()}, "bb", cfg["pointnet"]["camera"],
+                      np.ascontiguousarray(cloud.transpose(0, 2, 1)), use_xyz, mlp="exact")
+    np.testing.assert_array_equal(out.cpu().numpy(), ref)
+
+
+def test_backbone_train_mode_path_matches_fused(device):
+    """The layer-by-layer (autograd) path and the fused eval path agree in eval statistics."""
+    from captra_amd.backbones import PointNet2Msg
+    from captra_amd.configs import make_config
+    cfg = make_config("1")
+    net = PointNet2Msg(cfg, 128, use_xyz_feat=True)
+    net.load_state_dict(make_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, seed=3))
+    net = net.to(device).eval()
+    cloud_cn = _dev(nocs_batch([2]).transpose(0, 2, 1), device)
+    with torch.no_grad():
+        fused_out = net(cloud_cn)
+        for m in net.modules():
+            m.training = True
+        # BatchNorm layers must keep using running statistics for the comparison
+        for m in net.modules():
+            if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+                m.training = False
+        layer_out = net(cloud_cn)
+    np.testing.assert_allclose(layer_out.cpu().numpy(), fused_out.cpu().numpy(), atol=TOL, rtol=0)
+
+
+# ------------------------------------------------------------------------------- track loop
+SETUPS = {"bottle": ("1", "obj_info_nocs.yml", "nocs", 5), "camera": ("3", "obj_info_nocs.yml", "nocs", 3),
+          "drawers": ("drawers", "obj_info_sapien.yml", "arti", 3)}
+
+
+def _trainer(tag, device):
+    from captra_amd.configs import make_config
+    from captra_amd.trainer import Trainer
+    cat, objcfg, kind, frames = SETUPS[tag]
+    cfg = make_config(cat, objcfg, experiment_dir="/tmp/captra_test_exp")
+    cfg["track_cfg"]["gt_label"] = (tag == "drawers")
+    trainer = Trainer(cfg)
+    shapes = {k: tuple(v.shape) for k, v in trainer.model.state_dict().items()}
+    assert sorted(shapes) == json.load(open(G / "state_dict_keys.json"))[tag]
+    sd = make_state_dict(shapes, seed=7)
+    trainer.model.load_state_dict(sd)
+    return trainer, cfg, sd, clouds.make_trajectory(kind, 2, frames, seed=0)
+
+
+@pytest.mark.parametrize("tag", ["bottle", "camera", "drawers"])
+def test_track_loop_vs_golden(device, tag):
+    trainer, cfg, sd, data = _trainer(tag, device)
+    g7, g9 = np.load(G / "g7_step.npz"), np.load(G / "g9_track.npz")
+    torch.manual_seed(1234)
+    pred_dict, loss_dict = trainer.test(data, save=False, no_eval=False)
+    poses = pred_dict["poses"]
+    assert len(poses) == len(data)
+    # initial (noisy) pose: same seed, same draw order as the reference
+    for key in ("rotation", "translation", "scale"):
+        np.testing.assert_allclose(poses[0][key].cpu().numpy(), g9[f"{tag}_0_{key}"], atol=1e-6, rtol=0)
+    # CoordNet outputs of frame 1
+    n1 = pred_dict["npcs_pred"][1]
+    np.testing.assert_array_equal(torch.argmax(n1["seg"], dim=-2).cpu().numpy(), g7[f"{tag}_labels"].astype(np.int64))
+    np.testing.assert_allclose(n1["nocs"].cpu().numpy(), g7[f"{tag}_nocs"], atol=TOL, rtol=0)
+    np.testing.assert_allclose(n1["seg"].cpu().numpy(), g7[f"{tag}_seg"], atol=1e-3, rtol=0)
+    # free-running trajectory against the reference's
+    # (free-running errors compound through the pose hand-over; with random weights the drawers
+    # poses leave the physical regime after frame 1 — negative scales — and amplify rounding noise,
+    # so later frames of that fixture are only sanity-bounded here; every frame is checked at 1e-4
+    # in the teacher-forced test below)
+    for i in range(1, len(poses)):
+        loose = tag == "drawers" and i >= 2
+        for key in ("rotation", "scale", "translation"):
+            np.testing.assert_allclose(poses[i][key].cpu().numpy(), g9[f"{tag}_{i}_{key}"], atol=5e-2 if loose else 5 * TOL,
+                                       rtol=5e-2 if loose else 5e-4, err_msg=f"{tag} frame {i} {key}")
+    assert "avg_pred" in loss_dict and any(k.startswith("5deg5cm") for k in loss_dict["avg_pred"])
+
+
+@pytest.mark.parametrize("tag", ["bottle", "camera", "drawers"])
+def test_track_step_teacher_forced_vs_golden_and_oracle(device, tag):
+    trainer, cfg, sd, data = _trainer(tag, device)
+    g9 = np.load(G / "g9_track.npz")
+    model = trainer.model.eval()
+    model.set_data(data)
+    for i in range(1, len(data)):
+        prev = {k: _dev(g9[f"{tag}_{i - 1}_{k}"], device) for k in ("rotation", "translation", "scale")}
+        with torch.no_grad():
+            _, pose = model.track_step(model.feed_dict[i], model.npcs_feed_dict[i], prev)
+        for key in ("rotation", "scale", "translation"):
+            np.testing.assert_allclose(pose[key].cpu().numpy(), g9[f"{tag}_{i}_{key}"], atol=TOL, rtol=1e-4,
+                                       err_msg=f"{tag} frame {i} {key}")
+        # oracle (exact arithmetic) on the same step
+        prev_np = {k: g9[f"{tag}_{i - 1}_{k}"] for k in ("rotation", "translation", "scale")}
+        gt_labels = data[i]["labels"].numpy() if tag == "drawers" else None
+        opose, _ = OM.track_step(sd, cfg, data[i]["points"].numpy(), data[i]["meta"]["points_mean"].numpy(), prev_np, "exact",
+                                 gt_labels=gt_labels)
+        for key in ("rotation", "scale", "translation"):
+            np.testing.assert_allclose(pose[key].cpu().numpy(), opose[key], atol=2e-5, rtol=1e-4, err_msg=f"oracle {key}")
+
+
+def test_checkpoint_roundtrip_and_coordnet_key_mapping(device, tmp_path):
+    """Trainer.save / resume incl. loading a CoordNet experiment under npcs_net.* (trainer.py:159-169)."""
+    from captra_amd.configs import make_config
+    from captra_amd.trainer import Trainer
+    coord_dir, rot_dir = tmp_path / "coord", tmp_path / "rot"
+    cfg = make_config("1", experiment_dir=str(rot_dir), **{"coord_exp/dir": str(coord_dir)})
+    src = Trainer(cfg)
+    sd = make_state_dict({k: tuple(v.shape) for k, v in src.model.state_dict().items()}, seed=5)
+    # a CoordNet experiment stores its weights as net.* ; a RotationNet experiment as net.* too
+    (coord_dir / "ckpt").mkdir(parents=True)
+    (rot_dir / "ckpt").mkdir(parents=True)
+    coord_state = {"net" + k[len("npcs_net"):]: v for k, v in sd.items() if k.startswith("npcs_net.")}
+    rot_state = {k: v for k, v in sd.items() if k.startswith("net.")}
+    torch.save({"epoch": 3, "iteration": 10, "model": coord_state}, coord_dir / "ckpt" / "model_0003.pt")
+    torch.save({"epoch": 7, "iteration": 20, "model": rot_state, "optimizer": {}}, rot_dir / "ckpt" / "model_0007.pt")
+    dst = Trainer(cfg)
+    assert dst.resume() == 7
+    for k, v in dst.model.state_dict().items():
+        np.testing.assert_array_equal(v.cpu().numpy(), sd[k].numpy(), err_msg=k)

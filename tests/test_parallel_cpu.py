@@ -1,0 +1,68 @@
+"""Multi-process cover of the N>1 path on CPU: gloo backend, world_size 2 (runs without a GPU)."""
+import os
+import socket
+
+import torch
+import torch.multiprocessing as mp
+
+from captra_amd.parallel import POSE_RECORD, PoseExchange, pack_pose, shard_range, unpack_pose
+
+
+def test_shard_range_partitions_exactly():
+    for total in (0, 1, 7, 32, 33, 256):
+        for world in (1, 2, 3, 8):
+            got = [i for r in range(world) for i in shard_range(total, world, r)]
+            assert got == list(range(total))
+            sizes = [len(shard_range(total, world, r)) for r in range(world)]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _fake_pose(b, p, seed):
+    g = torch.Generator().manual_seed(seed)
+    return {"rotation": torch.randn(b, p, 3, 3, generator=g), "translation": torch.randn(b, p, 3, 1, generator=g),
+            "scale": torch.rand(b, p, generator=g) + 0.5}
+
+
+def test_pack_unpack_roundtrip():
+    pose = _fake_pose(5, 4, 0)
+    valid = torch.tensor([[True, False, True, True]] * 5)
+    rec = pack_pose(pose, valid)
+    assert rec.shape == (5, 4, POSE_RECORD)
+    back, v = unpack_pose(rec)
+    for k in pose:
+        assert torch.equal(back[k], pose[k])
+    assert torch.equal(v, valid)
+
+
+def _worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        B, P = 3, 2
+        ex = PoseExchange(B, P, "cpu", world, rank)
+        for frame in range(3):                       # a few frames, sync and async flavours
+            pose = _fake_pose(B, P, 100 * frame + rank)
+            out = ex.all_gather(pose, async_op=(frame % 2 == 1))
+            out = ex.wait()
+            for r in range(world):
+                exp = pack_pose(_fake_pose(B, P, 100 * frame + r))
+                assert torch.equal(out[r * B:(r + 1) * B], exp), (frame, r)
+        ret[rank] = True
+    finally:
+        dist.destroy_process_group()
+
+
+def test_pose_all_gather_gloo_world2():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert ret.get(0) and ret.get(1)
