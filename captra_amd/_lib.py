@@ -33,9 +33,11 @@ _SIGNATURES = {
     "captra_three_interpolate_grad": [_INT, _INT, _INT, _INT, _P, _P, _P, _P, _P],
     "captra_canonicalize": [_INT, _INT, _INT, _P, _P, _P, _P, _P, _P, _P, _P],
     "captra_ball_query_multi": [_INT, _INT, _INT, _INT, _P, _P, _P, _P, _P, _P],
+    "captra_pack_weights": [_INT, _INT, _P, _P, _P, _P, _P],
     "captra_pointwise_mlp": [_INT, _INT, _INT, _LL, _P, _P, _P, _INT, _P, _P],
     "captra_sa_group_mlp": [_INT, _INT, _INT, _INT, _INT, _INT, _P, _P, _P, _P, _P, _P, _P, _P],
     "captra_mlp_max": [_INT, _INT, _INT, _INT, _INT, _P, _P, _P, _P, _INT, _INT, _P],
+    "captra_sa_scale_fused": [_INT] * 8 + [_P] * 11 + [_INT, _INT, _P],
     "captra_fp_interpolate_concat": [_INT, _INT, _INT, _INT, _INT, _P, _P, _P, _P, _P, _P],
     "captra_part_fit_st": [_INT, _INT, _INT, _INT, _P, _P, _P, _INT, _P, _P, _P, _P, _P, _P],
     "captra_procrustes_rot3": [_INT, _INT, _P, _P, _P, _P],

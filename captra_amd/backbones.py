@@ -69,5 +69,5 @@ class PointNet2Msg(_FoldCache, nn.Module):
         if (not self.training) and l0_points.is_cuda:
             if self._folded is None:
                 self._folded = fold_conv_bn(self.conv1, self.bn1, l0_points.device)
-            return fused.pointwise_mlp(l0_points.contiguous(), *self._folded, fused.ACT_RELU)
+            return fused.pointwise_mlp(l0_points.contiguous(), self._folded, fused.ACT_RELU)
         return F.relu(self.bn1(self.conv1(l0_points)))

@@ -82,14 +82,14 @@ def run_point_mlp(seq: nn.Sequential, x: torch.Tensor, cache: dict) -> torch.Ten
         key = id(conv)
         if key not in cache:
             cache[key] = fold_conv_bn(conv, bn, x.device)
-        wt, bias = cache[key]
+        lin = cache[key]
         if gn is not None:
-            x = fused.pointwise_mlp(x, wt, bias, fused.ACT_NONE)
+            x = fused.pointwise_mlp(x, lin, fused.ACT_NONE)
             x = F.group_norm(x, gn.num_groups, gn.weight, gn.bias, gn.eps)
             if act == fused.ACT_RELU:
                 x = F.relu(x, inplace=True)
         else:
-            x = fused.pointwise_mlp(x, wt, bias, act)
+            x = fused.pointwise_mlp(x, lin, act)
             if sigmoid_tail:
                 x = torch.sigmoid(x)
         i = j

@@ -4,7 +4,7 @@
 // (network/models/pointnet_utils.py:242-246, 296-298, 336-340; backbones.py:68), which the
 // reference executes as separate ATen kernels over a MATERIALISED grouped tensor.
 //
-// One kernel template, three operand-load prologues and two epilogues:
+// One kernel template, two operand-load prologues and two epilogues:
 //   PRO_PLAIN  x (B,cin,L) dense
 //   PRO_GROUP  x gathered on the fly through the ball-query index list, centre subtracted,
 //              [feat, xyz] concatenated — the (B,cin,M,K) grouped tensor is never written
@@ -20,8 +20,14 @@
 // for k ascending — exactly what a chain of 32x32x2 f32 MFMAs computes — then the activation.
 // K is never split across waves, so the result is bit-identical to the oracle's fmaf loop.
 //
+// Weights arrive PACKED (captra_hip.h "packed weights"): W^T zero-padded to (ceil32(cin), ceil128(cout))
+// and the bias to ceil128(cout).  Every weight/bias access is therefore in bounds and needs no mask,
+// X rows beyond cin are clamped to the last real row (they meet zero weights), positions beyond L
+// are clamped (their columns are never stored): the staging code is pointer bumps + 16-byte loads
+// with no predicates, which is what keeps the VALU out of the MFMA pipe's way.
+//
 // Pipeline: register-staged prefetch (global loads of chunk c+1 are issued before the MFMAs of
-// chunk c and written to LDS after them), 2-4 workgroups per CU for latency hiding.
+// chunk c and written to LDS after them), 2 workgroups per CU.
 #include "common.h"
 
 namespace {
@@ -36,11 +42,11 @@ enum { EPI_STORE = 0, EPI_MAXK = 1 };
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_SIGMOID_M05 = 2 };
 
 struct PwParams {
-    int cin, cout;
+    int cin, cout, ldw;   // ldw = ceil128(cout): row stride of the packed weights
     long long L;          // positions per cloud (= M*K for grouped layers)
     const float *x;       // PRO_PLAIN: (B,cin,L)
-    const float *wt;      // (cin,cout)
-    const float *bias;    // (cout)
+    const float *wt;      // packed (ceil32(cin), ldw)
+    const float *bias;    // packed (ldw)
     float *y;
     int act;
     // PRO_GROUP
@@ -79,8 +85,10 @@ __global__ __launch_bounds__(PW_THREADS) void pw_mlp_kernel(PwParams p) {
     constexpr int TN = BN / WGN / 32;
     static_assert(WGM * WGN == 4, "4 waves");
     static_assert(TM >= 1 && TN >= 1, "tile");
-    constexpr int XELEMS = PW_BK * BN / PW_THREADS;  // X floats staged per thread per chunk
-    constexpr int WELEMS = PW_BK * BM / PW_THREADS;  // W floats staged per thread per chunk
+    constexpr int W4 = PW_BK * BM / 4 / PW_THREADS;  // float4 of W staged per thread per chunk
+    constexpr int X4 = PW_BK * BN / 4 / PW_THREADS;  // float4 of X staged per thread per chunk (vector form)
+    constexpr int X1 = PW_BK * BN / PW_THREADS;      // floats of X staged per thread per chunk (scalar forms)
+    static_assert(W4 >= 1, "W tile too small for 16-byte staging");
 
     __shared__ __attribute__((aligned(16))) float Ws[PW_BK * BM];
     __shared__ __attribute__((aligned(16))) float Xs[PW_BK * BN];
@@ -93,97 +101,97 @@ __global__ __launch_bounds__(PW_THREADS) void pw_mlp_kernel(PwParams p) {
     const int co0 = blockIdx.y * BM;
     const long long pos0 = (long long)blockIdx.x * BN;
 
-    // ---- per-thread staging coordinates ------------------------------------------------------
-    // W tile: element e = tid + i*256 -> (row e / BM, col e % BM): consecutive threads = consecutive co
-    // X tile, scalar form: element e = tid + i*256 -> (row e / BN, col e % BN)
-    // X tile, vector form: float4 e = tid + i*256 -> (row e / (BN/4), col4 e % (BN/4))
-    float wreg[WELEMS];
-    float xreg[XELEMS];
+    // ---- staging pointers, set up once; per chunk they advance by a constant stride ----------------
+    // W: float4 e = tid + i*256 -> row e / (BM/4), col4 e % (BM/4); always in bounds (packed weights)
+    const float *wptr[W4];
+#pragma unroll
+    for (int i = 0; i < W4; ++i) {
+        const int e = tid + i * PW_THREADS;
+        wptr[i] = p.wt + (size_t)(e / (BM / 4)) * p.ldw + co0 + (e % (BM / 4)) * 4;
+    }
+    const size_t wstep = (size_t)PW_BK * p.ldw;
+    float4 wreg[W4];
+
+    // X (plain): rows clamped to cin-1 (they meet zero weight rows), columns clamped into [0, L)
+    float4 xreg4[VECX ? X4 : 1];
+    float xreg1[VECX ? 1 : X1];
+    int xrow_local[VECX ? X4 : X1];
+    long long xcol[VECX ? X4 : X1];
+    const float *xbase = p.x + (size_t)b * p.cin * p.L;
 
     // PRO_GROUP: BN is a multiple of 256 or divides it, so a thread's column is fixed
     int g_id = 0;
     float g_c[3] = {0.f, 0.f, 0.f};
-    bool g_live = false;
     if (PRO == PRO_GROUP) {
-        const int col = tid % BN;
-        const long long pos = pos0 + col;
-        g_live = pos < p.L;
-        if (g_live) {
-            g_id = p.idx[(size_t)b * p.L + pos];
-            const int centre = (int)(pos / p.k);
-            const float *c = p.new_xyz + ((size_t)b * p.m + centre) * 3;
-            g_c[0] = c[0];
-            g_c[1] = c[1];
-            g_c[2] = c[2];
+        long long pos = pos0 + tid % BN;
+        if (pos >= p.L) pos = p.L - 1;  // clamped column: computed, never stored
+        g_id = p.idx[(size_t)b * p.L + pos];
+        const float *c = p.new_xyz + ((size_t)b * p.m + (int)(pos / p.k)) * 3;
+        g_c[0] = c[0];
+        g_c[1] = c[1];
+        g_c[2] = c[2];
+    } else if (VECX) {
+#pragma unroll
+        for (int i = 0; i < X4; ++i) {
+            const int e = tid + i * PW_THREADS;
+            xrow_local[i] = e / (BN / 4);
+            const long long pos = pos0 + (e % (BN / 4)) * 4;
+            xcol[i] = pos < p.L ? pos : (p.L - 4);  // L % 4 == 0: a float4 is all-in or all-out
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < X1; ++i) {
+            const int e = tid + i * PW_THREADS;
+            xrow_local[i] = e / BN;
+            const long long pos = pos0 + e % BN;
+            xcol[i] = pos < p.L ? pos : (p.L - 1);
         }
     }
 
     auto load_chunk = [&](int kc) {
 #pragma unroll
-        for (int i = 0; i < WELEMS; ++i) {
-            const int e = tid + i * PW_THREADS;
-            const int row = e / BM, col = e % BM;
-            const int kg = kc + row, co = co0 + col;
-            wreg[i] = (kg < p.cin && co < p.cout) ? p.wt[(size_t)kg * p.cout + co] : 0.f;
+        for (int i = 0; i < W4; ++i) {
+            wreg[i] = *reinterpret_cast<const float4 *>(wptr[i]);
+            wptr[i] += wstep;
         }
         if (PRO == PRO_PLAIN) {
             if (VECX) {
 #pragma unroll
-                for (int i = 0; i < XELEMS / 4; ++i) {
-                    const int e = tid + i * PW_THREADS;
-                    const int row = e / (BN / 4), c4 = e % (BN / 4);
-                    const int kg = kc + row;
-                    const long long pos = pos0 + c4 * 4;
-                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (kg < p.cin && pos < p.L)  // L % 4 == 0: a float4 is all-in or all-out
-                        v = *reinterpret_cast<const float4 *>(p.x + ((size_t)b * p.cin + kg) * p.L + pos);
-                    xreg[i * 4 + 0] = v.x;
-                    xreg[i * 4 + 1] = v.y;
-                    xreg[i * 4 + 2] = v.z;
-                    xreg[i * 4 + 3] = v.w;
+                for (int i = 0; i < X4; ++i) {
+                    const int kg = min(kc + xrow_local[i], p.cin - 1);
+                    xreg4[i] = *reinterpret_cast<const float4 *>(xbase + (size_t)kg * p.L + xcol[i]);
                 }
             } else {
 #pragma unroll
-                for (int i = 0; i < XELEMS; ++i) {
-                    const int e = tid + i * PW_THREADS;
-                    const int row = e / BN, col = e % BN;
-                    const int kg = kc + row;
-                    const long long pos = pos0 + col;
-                    xreg[i] = (kg < p.cin && pos < p.L) ? p.x[((size_t)b * p.cin + kg) * p.L + pos] : 0.f;
+                for (int i = 0; i < X1; ++i) {
+                    const int kg = min(kc + xrow_local[i], p.cin - 1);
+                    xreg1[i] = xbase[(size_t)kg * p.L + xcol[i]];
                 }
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < XELEMS; ++i) {
-                const int e = tid + i * PW_THREADS;
-                const int row = e / BN;
-                const int kg = kc + row;
-                float v = 0.f;
-                if (g_live) {
-                    if (kg < p.cfeat) {
-                        v = p.feat[((size_t)b * p.cfeat + kg) * p.n + g_id];
-                    } else if (kg < p.cfeat + 3) {
-                        const int a = kg - p.cfeat;
-                        const float ctr = a == 0 ? g_c[0] : (a == 1 ? g_c[1] : g_c[2]);
-                        v = p.xyz_cn[((size_t)b * 3 + a) * p.n + g_id] - ctr;
-                    }
-                }
-                xreg[i] = v;
+            for (int i = 0; i < X1; ++i) {
+                const int kg = kc + (tid + i * PW_THREADS) / BN;
+                // rows >= cfeat+3 are clamped onto the last xyz row: finite values against zero weights
+                const bool is_feat = kg < p.cfeat;
+                const int a = min(max(kg - p.cfeat, 0), 2);
+                const float *rowp = is_feat ? (p.feat + ((size_t)b * p.cfeat + kg) * p.n) : (p.xyz_cn + ((size_t)b * 3 + a) * p.n);
+                const float raw = rowp[g_id];
+                const float ctr = a == 0 ? g_c[0] : (a == 1 ? g_c[1] : g_c[2]);
+                xreg1[i] = is_feat ? raw : (raw - ctr);
             }
         }
     };
 
     auto store_chunk = [&]() {
 #pragma unroll
-        for (int i = 0; i < WELEMS; ++i) Ws[tid + i * PW_THREADS] = wreg[i];
+        for (int i = 0; i < W4; ++i) *reinterpret_cast<float4 *>(Ws + (size_t)(tid + i * PW_THREADS) * 4) = wreg[i];
         if (PRO == PRO_PLAIN && VECX) {
 #pragma unroll
-            for (int i = 0; i < XELEMS / 4; ++i)
-                *reinterpret_cast<float4 *>(Xs + (size_t)(tid + i * PW_THREADS) * 4) =
-                    make_float4(xreg[i * 4], xreg[i * 4 + 1], xreg[i * 4 + 2], xreg[i * 4 + 3]);
+            for (int i = 0; i < X4; ++i) *reinterpret_cast<float4 *>(Xs + (size_t)(tid + i * PW_THREADS) * 4) = xreg4[i];
         } else {
 #pragma unroll
-            for (int i = 0; i < XELEMS; ++i) Xs[tid + i * PW_THREADS] = xreg[i];
+            for (int i = 0; i < X1; ++i) Xs[tid + i * PW_THREADS] = xreg1[i];
         }
     };
 
@@ -191,10 +199,10 @@ __global__ __launch_bounds__(PW_THREADS) void pw_mlp_kernel(PwParams p) {
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
+        const float *bp = p.bias + co0 + (wm * TM + tm) * 32 + 4 * (lane >> 5);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row = co0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            const float bv = row < p.cout ? p.bias[row] : 0.f;
+            const float bv = bp[(r & 3) + 8 * (r >> 2)];  // packed bias: in bounds, zero beyond cout
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn) acc[tm][tn][r] = bv;
         }
@@ -228,17 +236,21 @@ __global__ __launch_bounds__(PW_THREADS) void pw_mlp_kernel(PwParams p) {
     // ---- epilogue -------------------------------------------------------------------------------
     if (EPI == EPI_STORE) {
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
+        for (int tm = 0; tm < TM; ++tm) {
+            const int row0 = co0 + (wm * TM + tm) * 32 + 4 * (lane >> 5);
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn) {
                 const long long col = pos0 + (wn * TN + tn) * 32 + (lane & 31);
+                if (col < p.L) {
+                    float *yp = p.y + ((size_t)b * p.cout + row0) * p.L + col;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = co0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    if (row < p.cout && col < p.L)
-                        p.y[((size_t)b * p.cout + row) * p.L + col] = apply_act(acc[tm][tn][r], p.act);
+                    for (int r = 0; r < 16; ++r) {
+                        const int ro = (r & 3) + 8 * (r >> 2);
+                        if (row0 + ro < p.cout) yp[(size_t)ro * p.L] = apply_act(acc[tm][tn][r], p.act);
+                    }
                 }
             }
+        }
     } else {
         // max over groups of K consecutive positions; K % 32 == 0 and BN % K == 0 (host checks).
         // Stage 1: per 32-position MFMA tile, reduce over the 32 lanes that hold one output row.
@@ -250,12 +262,11 @@ __global__ __launch_bounds__(PW_THREADS) void pw_mlp_kernel(PwParams p) {
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn) {
-                const long long colbase = pos0 + (wn * TN + tn) * 32;
+                const bool col_ok = pos0 + (wn * TN + tn) * 32 + (lane & 31) < p.L;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     float v = acc[tm][tn][r];
-                    v = v > 0.f ? v : 0.f;  // ReLU (the only activation followed by a max in the path)
-                    if (colbase + (lane & 31) >= p.L) v = 0.f;
+                    v = (v > 0.f && col_ok) ? v : 0.f;  // ReLU (the only activation followed by a max in the path)
                     v = row16_max(v);
                     v = fmaxf(v, __shfl_xor(v, 16, 64));
                     if ((lane & 31) == 0) {
@@ -296,38 +307,62 @@ int launch_pw(int b, const PwParams &p, hipStream_t s, const char *name) {
     return captra_last_error();
 }
 
+__global__ void pack_weights_kernel(int cin, int cout, int kp, int cp, const float *__restrict__ wt,
+                                    const float *__restrict__ bias, float *__restrict__ wt_packed,
+                                    float *__restrict__ bias_packed) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < kp * cp) {
+        const int k = e / cp, c = e % cp;
+        wt_packed[e] = (k < cin && c < cout) ? wt[(size_t)k * cout + c] : 0.f;
+    }
+    if (e < cp) bias_packed[e] = e < cout ? bias[e] : 0.f;
+}
+
 }  // namespace
 
-extern "C" int captra_pointwise_mlp(int b, int cin, int cout, long long l, const float *x, const float *wt,
-                                    const float *bias, int act, float *y, captra_stream_t stream) {
+extern "C" int captra_pack_weights(int cin, int cout, const float *wt, const float *bias, float *wt_packed,
+                                   float *bias_packed, captra_stream_t stream) {
+    if (cin < 1 || cout < 1) return -1;
+    const int kp = (cin + 31) / 32 * 32, cp = (cout + 127) / 128 * 128;
+    const int n = kp * cp;
+    CAPTRA_LAUNCH("pack_weights", pack_weights_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, cin,
+                  cout, kp, cp, wt, bias, wt_packed, bias_packed);
+    return captra_last_error();
+}
+
+extern "C" int captra_pointwise_mlp(int b, int cin, int cout, long long l, const float *x, const float *wt_packed,
+                                    const float *bias_packed, int act, float *y, captra_stream_t stream) {
     if (b < 0 || cin < 1 || cout < 1 || l < 0 || act < 0 || act > 2) return -1;
     if (b == 0 || l == 0) return 0;
     PwParams p = {};
-    p.cin = cin; p.cout = cout; p.L = l; p.x = x; p.wt = wt; p.bias = bias; p.y = y; p.act = act;
+    p.cin = cin; p.cout = cout; p.ldw = (cout + 127) / 128 * 128; p.L = l; p.x = x; p.wt = wt_packed; p.bias = bias_packed;
+    p.y = y; p.act = act;
     const bool vec = (l % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
     if (vec) return launch_pw<PRO_PLAIN, EPI_STORE, true>(b, p, (hipStream_t)stream, "pointwise_mlp");
     return launch_pw<PRO_PLAIN, EPI_STORE, false>(b, p, (hipStream_t)stream, "pointwise_mlp");
 }
 
 extern "C" int captra_sa_group_mlp(int b, int n, int m, int k, int cfeat, int cout, const float *feat,
-                                   const float *xyz_cn, const float *new_xyz, const int *idx, const float *wt,
-                                   const float *bias, float *y, captra_stream_t stream) {
+                                   const float *xyz_cn, const float *new_xyz, const int *idx, const float *wt_packed,
+                                   const float *bias_packed, float *y, captra_stream_t stream) {
     if (b < 0 || n < 1 || m < 0 || k < 1 || cfeat < 0 || cout < 1) return -1;
     if (cfeat > 0 && feat == nullptr) return -1;
     if (b == 0 || m == 0) return 0;
     PwParams p = {};
-    p.cin = cfeat + 3; p.cout = cout; p.L = (long long)m * k; p.wt = wt; p.bias = bias; p.y = y; p.act = ACT_RELU;
+    p.cin = cfeat + 3; p.cout = cout; p.ldw = (cout + 127) / 128 * 128; p.L = (long long)m * k; p.wt = wt_packed;
+    p.bias = bias_packed; p.y = y; p.act = ACT_RELU;
     p.n = n; p.m = m; p.k = k; p.cfeat = cfeat; p.feat = feat; p.xyz_cn = xyz_cn; p.new_xyz = new_xyz; p.idx = idx;
     return launch_pw<PRO_GROUP, EPI_STORE, false>(b, p, (hipStream_t)stream, "sa_group_mlp");
 }
 
-extern "C" int captra_mlp_max(int b, int cin, int cout, int m, int k, const float *x, const float *wt,
-                              const float *bias, float *y, int y_ctotal, int co_off, captra_stream_t stream) {
+extern "C" int captra_mlp_max(int b, int cin, int cout, int m, int k, const float *x, const float *wt_packed,
+                              const float *bias_packed, float *y, int y_ctotal, int co_off, captra_stream_t stream) {
     if (b < 0 || cin < 1 || cout < 1 || m < 0 || k < 1 || y_ctotal < co_off + cout || co_off < 0) return -1;
     if (k % 32 != 0 || 128 % k != 0) return -2;  // fused max needs K in {32, 64, 128}
     if (b == 0 || m == 0) return 0;
     PwParams p = {};
-    p.cin = cin; p.cout = cout; p.L = (long long)m * k; p.x = x; p.wt = wt; p.bias = bias; p.y = y; p.act = ACT_RELU;
+    p.cin = cin; p.cout = cout; p.ldw = (cout + 127) / 128 * 128; p.L = (long long)m * k; p.x = x; p.wt = wt_packed;
+    p.bias = bias_packed; p.y = y; p.act = ACT_RELU;
     p.m = m; p.k = k; p.y_ctotal = y_ctotal; p.co_off = co_off;
     const bool vec = ((reinterpret_cast<uintptr_t>(x) & 15) == 0);  // L = m*k is a multiple of 32
     if (vec) return launch_pw<PRO_PLAIN, EPI_MAXK, true>(b, p, (hipStream_t)stream, "mlp_max");

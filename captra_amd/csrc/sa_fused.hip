@@ -1,0 +1,283 @@
+// One whole set-abstraction scale in ONE kernel for gfx950:
+//   ball-query neighbour list -> gather + centre-subtract + concat -> (1x1 conv + folded BN + ReLU) x 3
+//   -> max over the K neighbours,
+// i.e. the body of PointNetSetAbstractionMsg.forward's loop over radii (reference
+// network/models/pointnet_utils.py:228-248), which the reference runs as ~12 ATen kernels over a
+// materialised (B,C,S,K) tensor per scale.  Here neither the grouped tensor nor the two intermediate
+// activations ever reach HBM: a workgroup owns 128 consecutive positions (= 128/K centres) and
+// processes them as two 64-position sub-tiles whose gathered input X1 and activations H1, H2 live in
+// LDS in the [channel][position] layout that is directly the B operand of the next layer's MFMA;
+// only the pooled (C3 x centres) result is written.
+//
+// Operand flow (what keeps the matrix pipe fed):
+//   B operand  = activations, resident in LDS, read with conflict-free ds_read_b32;
+//   A operand  = weights, read STRAIGHT FROM GLOBAL MEMORY (L1/L2-resident: a scale's weights are
+//                75-470 KB and every workgroup re-reads them) into the MFMA source registers, one
+//                16-deep K chunk ahead of the MFMAs that consume it (buffer loads, scalar k offset).  No LDS staging of weights, hence
+//                no per-chunk barriers: a sub-tile needs 4 workgroup barriers in total.
+//   packed weights (captra_hip.h): zero-padded to (ceil32(cin), ceil128(cout)), so A loads need no mask.
+//
+// HBM traffic per scale and cloud: idx (4MK) + gathered rows + weights (both L2-resident) + 4*C3*M
+// output, instead of 4*M*K*(C1 + 2*C2 + ...) bytes of activations.
+//
+// Arithmetic is the same k-ascending fmaf chain as pw_mlp_kernel (accumulator initialised with the
+// bias, v_mfma_f32_32x32x2_f32, K never split across waves), so results are bit-identical to the
+// layer-by-layer path and to the oracle.
+//
+// Workgroup: 512 threads = 8 waves arranged 4 (output-channel rows of 32) x 2 (position columns of 32);
+// a layer is computed in output-channel tiles of 128; one 16-register accumulator per wave (the
+// 32x32x2 f32 MFMA's dependent-issue latency equals its issue interval, 64 cycles), two waves per SIMD.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int SF_POS = 128;     // positions per workgroup (= 128/K centres), processed in sub-tiles of T = 32*WN
+constexpr int SF_BK = 16;       // K chunk = 8 MFMA k-steps prefetched as one register set
+constexpr int SF_BM = 128;      // output-channel tile
+constexpr int SF_MAXC = 256;
+
+struct SaParams {
+    int n, m, k, cfeat;
+    int c1, c2, c3;
+    const float *feat;     // (B,cfeat,N) or null
+    const float *xyz_cn;   // (B,3,N)
+    const float *new_xyz;  // (B,M,3)
+    const int *idx;        // (B,M,K)
+    const float *w1, *b1, *w2, *b2, *w3, *b3;  // packed: w (ceil32(cin), ceil128(cout)), b (ceil128(cout)), zero padded
+    float *out;            // (B,out_ctotal,M)
+    int out_ctotal, co_off;
+};
+
+template <int CTRL>
+__device__ __forceinline__ float dppf(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float row16_maxf(float v) {
+    v = fmaxf(v, dppf<0xB1>(v));
+    v = fmaxf(v, dppf<0x4E>(v));
+    v = fmaxf(v, dppf<0x141>(v));
+    v = fmaxf(v, dppf<0x140>(v));
+    return v;
+}
+
+// One layer on one 64-position sub-tile: Hin [cin padded to 32 with ZERO rows][64] in LDS -> Hout / red.
+//   LAST:  ReLU + max over each 32-position column block into red[row][slot]; otherwise ReLU -> Hout.
+// K runs in steps of 32 (two halves of 8 MFMA k-steps); every step is full because the activation rows
+// beyond cin are zero in LDS and the packed weights are zero there too: the inner loop is branch-free.
+// The A operand (weights) is fetched with buffer loads whose per-k offset is a SCALAR register: no VALU
+// address arithmetic, one chunk ahead of its use.  No barrier inside: the caller separates layers.
+template <bool LAST, int WN>
+__device__ __forceinline__ void sa_layer(int cin, int cout, const float *__restrict__ wt, const float *__restrict__ bias,
+                                         const float *Hin, float *Hout, float *red, int red_slot, bool col_ok) {
+    constexpr int SF_T = 32 * WN;
+    constexpr int SF_SLOTS = SF_POS / 32;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int npairs = (cin + 31) / 32;
+    const int ldw = (cout + 127) / 128 * 128;
+    const int kp = (cin + 31) / 32 * 32;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)wt, 0, kp * ldw * 4, 0x00020000);
+    const float *xrow = Hin + (lane >> 5) * SF_T + wn * 32 + (lane & 31);
+    const int kstep_bytes = 2 * ldw * 4;
+
+    for (int co0 = 0; co0 < cout; co0 += SF_BM) {
+        if ((co0 + wm * 32) >= cout) continue;  // wave-uniform: this wave's 32 rows are all padding
+        f32x16 acc;
+        {
+            const float *bp = bias + co0 + wm * 32 + 4 * (lane >> 5);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = bp[(r & 3) + 8 * (r >> 2)];  // packed bias: in bounds
+        }
+        // A fragment of k-step j of chunk c: W^T[c*16 + 2j + (lane>>5)][co0 + wm*32 + (lane&31)]
+        const int voff = (((lane >> 5) * ldw) + co0 + wm * 32 + (lane & 31)) * 4;
+        float a[8], an[8], bv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, j * kstep_bytes, 0));
+        // K advances 32 per iteration as two 8-MFMA halves; the two register sets alternate roles (no
+        // rotation copies) and each prefetch is consumed one half (8 MFMAs = 512+ cycles) after it was
+        // issued.  Both halves are unconditional (K is padded to 32 with zero rows on both operands): a
+        // conditional second half would let the compiler sink its prefetch into the branch, next to the
+        // use.  sched_barriers pin the order [prefetch loads][B reads][MFMAs] inside each half.
+        for (int c = 0; c < npairs; ++c) {
+            {
+                const int sn = (2 * c + 1) * 8 * kstep_bytes;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) an[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, sn + j * kstep_bytes, 0));
+                __builtin_amdgcn_sched_barrier(0);
+                const float *xr = xrow + (size_t)(2 * c) * SF_BK * SF_T;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bv[j] = xr[j * 2 * SF_T];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], bv[j], acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            {
+                const int sn = (c + 1 < npairs ? 2 * c + 2 : 2 * c + 1) * 8 * kstep_bytes;  // past the end: harmless re-read
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, sn + j * kstep_bytes, 0));
+                __builtin_amdgcn_sched_barrier(0);
+                const float *xr = xrow + (size_t)(2 * c + 1) * SF_BK * SF_T;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bv[j] = xr[j * 2 * SF_T];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(an[j], bv[j], acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (!LAST) {
+            float *hp = Hout + (size_t)(co0 + wm * 32 + 4 * (lane >> 5)) * SF_T + wn * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ro = (r & 3) + 8 * (r >> 2);
+                const float v = acc[r] > 0.f ? acc[r] : 0.f;
+                if (co0 + wm * 32 + 4 * (lane >> 5) + ro < cout) hp[(size_t)ro * SF_T] = v;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = (acc[r] > 0.f && col_ok) ? acc[r] : 0.f;
+                v = row16_maxf(v);
+                v = fmaxf(v, __shfl_xor(v, 16, 64));
+                const int row = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if ((lane & 31) == 0 && row < cout) red[row * SF_SLOTS + red_slot + wn] = v;
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ int pad32(int c) { return (c + 31) & ~31; }
+
+// zero rows [c, pad32(c)) of a [rows][64] LDS buffer (<= 31 rows)
+template <int WN>
+__device__ __forceinline__ void zero_pad_rows(float *buf, int c) {
+    constexpr int SF_T = 32 * WN;
+    const int n = (pad32(c) - c) * SF_T;
+    for (int e = threadIdx.x; e < n; e += 256 * WN) buf[(size_t)c * SF_T + e] = 0.f;
+}
+
+template <int WN>
+__global__ __launch_bounds__(256 * WN) void sa_fused_kernel(SaParams p) {
+    constexpr int SF_T = 32 * WN;
+    constexpr int SF_THREADS = 256 * WN;
+    constexpr int SF_SUBS = SF_POS / SF_T;
+    constexpr int SF_SLOTS = SF_POS / 32;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int cin1 = p.cfeat + 3;
+    const int rows_a = max(pad32(cin1), pad32(p.c2));  // region A: X1, later H2
+    float *red = lds;                               // [256][4]
+    float *RA = red + SF_MAXC * SF_SLOTS;           // [rows_a][T]
+    float *RB = RA + (size_t)rows_a * SF_T;         // H1 [pad32(c1)][64]
+
+    const int b = blockIdx.y;
+    const long long L = (long long)p.m * p.k;
+    const long long pos0 = (long long)blockIdx.x * SF_POS;
+    const int tid = threadIdx.x;
+    const int wn = (tid >> 6) % WN;
+    const int lane = tid & 63;
+    const int gcol = tid % SF_T;   // gather: this thread's position within the sub-tile
+    const int grow = tid / SF_T;   // ... and its first row (8 row groups)
+
+    zero_pad_rows<WN>(RB, p.c1);  // H1's pad rows stay zero for the whole kernel (layers write rows < c1 only)
+
+    for (int sub = 0; sub < SF_SUBS; ++sub) {
+        const long long base = pos0 + (long long)sub * SF_T;
+        // ---- gather X1 = [feat rows | xyz rows - centre] for the 64 positions of this sub-tile --------
+        {
+            long long pos = base + gcol;
+            if (pos >= L) pos = L - 1;  // clamped column: computed, masked at the max, never stored
+            const int id = p.idx[(size_t)b * L + pos];
+            const float *ctr = p.new_xyz + ((size_t)b * p.m + (int)(pos / p.k)) * 3;
+            const float *fb = p.feat + (size_t)b * p.cfeat * p.n + id;
+            float *xcol = RA + gcol;
+            int kg = grow;
+            for (; kg + 56 < p.cfeat; kg += 64) {       // 8 independent loads in flight per lane
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = fb[(size_t)(kg + 8 * u) * p.n];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) xcol[(size_t)(kg + 8 * u) * SF_T] = v[u];
+            }
+            for (; kg < p.cfeat; kg += 8) xcol[(size_t)kg * SF_T] = fb[(size_t)kg * p.n];
+            if (grow < 3) {
+                const int a = grow;
+                xcol[(size_t)(p.cfeat + a) * SF_T] = p.xyz_cn[((size_t)b * 3 + a) * p.n + id] - ctr[a];
+            }
+            zero_pad_rows<WN>(RA, cin1);
+        }
+        __syncthreads();  // X1 complete (and the previous sub-tile's layer 3 is done with region A)
+        sa_layer<false, WN>(cin1, p.c1, p.w1, p.b1, RA, RB, red, 0, true);
+        __syncthreads();  // H1 complete, X1 dead
+        sa_layer<false, WN>(p.c1, p.c2, p.w2, p.b2, RB, RA, red, 0, true);
+        zero_pad_rows<WN>(RA, p.c2);
+        __syncthreads();  // H2 complete
+        const bool col_ok = (base + wn * 32 + (lane & 31)) < L;
+        sa_layer<true, WN>(p.c2, p.c3, p.w3, p.b3, RA, nullptr, red, sub * WN, col_ok);
+        __syncthreads();  // region A free for the next gather, red visible
+    }
+    // combine the 32-position maxima of each group of K positions
+    const int tiles_per_group = p.k / 32;
+    const int groups = SF_POS / p.k;
+    for (int e = tid; e < p.c3 * groups; e += SF_THREADS) {
+        const int row = e / groups, gi = e % groups;
+        const long long centre = pos0 / p.k + gi;
+        if (centre < p.m) {
+            float v = red[row * SF_SLOTS + gi * tiles_per_group];
+            for (int t = 1; t < tiles_per_group; ++t) v = fmaxf(v, red[row * SF_SLOTS + gi * tiles_per_group + t]);
+            p.out[((size_t)b * p.out_ctotal + p.co_off + row) * p.m + centre] = v;
+        }
+    }
+}
+
+}  // namespace
+
+// experiment knob (not part of the ABI): force the sub-tile width, 0 = heuristic
+static int g_sa_wn = 0;
+extern "C" void captra_sa_fused_set_wn(int wn) { g_sa_wn = wn; }
+
+// One SA scale, fused (see include/captra_hip.h).
+extern "C" int captra_sa_scale_fused(int b, int n, int m, int k, int cfeat, int c1, int c2, int c3,
+                                     const float *feat, const float *xyz_cn, const float *new_xyz, const int *idx,
+                                     const float *w1, const float *b1, const float *w2, const float *b2,
+                                     const float *w3, const float *b3, float *out, int out_ctotal, int co_off,
+                                     captra_stream_t stream) {
+    if (b < 0 || n < 1 || m < 0 || k < 1 || cfeat < 0 || c1 < 1 || c2 < 1 || c3 < 1) return -1;
+    if (cfeat > 0 && feat == nullptr) return -1;
+    if (out_ctotal < co_off + c3 || co_off < 0) return -1;
+    if (k % 32 != 0 || 128 % k != 0 || c1 > SF_MAXC || c2 > SF_MAXC || c3 > SF_MAXC) return -2;
+    if (b == 0 || m == 0) return 0;
+    SaParams p;
+    p.n = n; p.m = m; p.k = k; p.cfeat = cfeat; p.c1 = c1; p.c2 = c2; p.c3 = c3;
+    p.feat = feat; p.xyz_cn = xyz_cn; p.new_xyz = new_xyz; p.idx = idx;
+    p.w1 = w1; p.b1 = b1; p.w2 = w2; p.b2 = b2; p.w3 = w3; p.b3 = b3;
+    p.out = out; p.out_ctotal = out_ctotal; p.co_off = co_off;
+    const int cin1 = cfeat + 3;
+    const int pa = (cin1 + 31) & ~31, pc2 = (c2 + 31) & ~31, pc1 = (c1 + 31) & ~31;
+    const int rows_a = pa > pc2 ? pa : pc2;
+    const long long L = (long long)m * k;
+    dim3 grid((unsigned)((L + SF_POS - 1) / SF_POS), b);
+    // sub-tile width: 64 positions (8 waves) when two such workgroups still fit in a CU's LDS, else 32
+    // positions (4 waves): independent workgroups on a CU are what hides the gather / first-load latency
+    const size_t lds64 = ((size_t)SF_MAXC * (SF_POS / 32) + (size_t)(rows_a + pc1) * 64) * sizeof(float);
+    const size_t lds32 = ((size_t)SF_MAXC * (SF_POS / 32) + (size_t)(rows_a + pc1) * 32) * sizeof(float);
+    int wn = (2 * lds64 <= 160 * 1024) ? 2 : 1;
+    if (g_sa_wn == 1 || g_sa_wn == 2) wn = g_sa_wn;
+    if ((wn == 2 ? lds64 : lds32) > 160 * 1024) return -2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(sa_fused_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(sa_fused_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    if (wn == 2) {
+        CAPTRA_LAUNCH("sa_scale_fused", sa_fused_kernel<2>, grid, dim3(512), lds64, (hipStream_t)stream, p);
+    } else {
+        CAPTRA_LAUNCH("sa_scale_fused", sa_fused_kernel<1>, grid, dim3(256), lds32, (hipStream_t)stream, p);
+    }
+    return captra_last_error();
+}

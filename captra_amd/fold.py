@@ -11,8 +11,24 @@ from __future__ import annotations
 import torch
 
 
-def fold_conv_bn(conv, bn=None, device=None):
-    """conv: nn.Conv1d/Conv2d with 1x1 kernel; bn: BatchNorm or None -> (wt (cin,cout), bias (cout))."""
+class PackedLinear:
+    """A layer's weights in the layout the MFMA kernels stage (include/captra_hip.h "packed weights"):
+    W'^T zero-padded to (ceil32(cin), ceil128(cout)), bias zero-padded to ceil128(cout)."""
+
+    __slots__ = ("wt", "bias", "cin", "cout")
+
+    def __init__(self, wt_dense: torch.Tensor, bias_dense: torch.Tensor):
+        cin, cout = wt_dense.shape
+        kp, cp = (cin + 31) // 32 * 32, (cout + 127) // 128 * 128
+        wt = torch.zeros(kp, cp, dtype=torch.float32, device=wt_dense.device)
+        wt[:cin, :cout] = wt_dense
+        bias = torch.zeros(cp, dtype=torch.float32, device=wt_dense.device)
+        bias[:cout] = bias_dense
+        self.wt, self.bias, self.cin, self.cout = wt.contiguous(), bias.contiguous(), cin, cout
+
+
+def fold_conv_bn(conv, bn=None, device=None) -> PackedLinear:
+    """conv: nn.Conv1d/Conv2d with 1x1 kernel; bn: BatchNorm or None -> PackedLinear on `device`."""
     w = conv.weight.detach().double().reshape(conv.weight.shape[0], -1).cpu()      # (cout, cin)
     b = conv.bias.detach().double().cpu() if conv.bias is not None else torch.zeros(w.shape[0], dtype=torch.float64)
     if bn is not None:
@@ -22,4 +38,4 @@ def fold_conv_bn(conv, bn=None, device=None):
         w = w * inv.unsqueeze(1)
         b = (b - bn.running_mean.detach().double().cpu()) * inv + beta
     dev = device if device is not None else conv.weight.device
-    return w.t().contiguous().float().to(dev), b.float().to(dev)
+    return PackedLinear(w.t().contiguous().float().to(dev), b.float().to(dev))

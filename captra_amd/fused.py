@@ -10,6 +10,7 @@ import ctypes as C
 import torch
 
 from . import _lib as L
+from .fold import PackedLinear
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID_M05 = 0, 1, 2
 
@@ -66,12 +67,18 @@ def ball_query_multi(radii, nsamples, xyz_n3, new_xyz_n3):
     return outs
 
 
-def pointwise_mlp(x, wt, bias, act: int = ACT_RELU, out=None):
-    """x (B,cin,*) , wt (cin,cout), bias (cout) -> (B,cout,*) = act(W x + b) (exact-fp32 MFMA)."""
+def pack(wt_dense, bias_dense) -> PackedLinear:
+    """Dense W^T (cin,cout) + bias (cout) -> the packed layout the kernels take."""
+    return PackedLinear(wt_dense.float(), bias_dense.float())
+
+
+def pointwise_mlp(x, lin: PackedLinear, act: int = ACT_RELU, out=None):
+    """x (B,cin,*), packed layer -> (B,cout,*) = act(W x + b) (exact-fp32 MFMA)."""
+    wt, bias = lin.wt, lin.bias
     L.require_device(x, wt, bias)
     B, cin = x.shape[0], x.shape[1]
-    cout = wt.shape[1]
-    assert wt.shape[0] == cin, (wt.shape, x.shape)
+    cout = lin.cout
+    assert lin.cin == cin, (lin.cin, x.shape)
     l = x.numel() // max(B * cin, 1)
     if out is None:
         out = torch.empty((B, cout) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
@@ -81,14 +88,15 @@ def pointwise_mlp(x, wt, bias, act: int = ACT_RELU, out=None):
     return out
 
 
-def sa_group_mlp(feat, xyz_cn, new_xyz_n3, idx, wt, bias):
+def sa_group_mlp(feat, xyz_cn, new_xyz_n3, idx, lin: PackedLinear):
     """First SA layer with group + centre-subtract + concat fused into the load -> (B,cout,M,K)."""
+    wt, bias = lin.wt, lin.bias
     L.require_device(feat, xyz_cn, new_xyz_n3, idx, wt, bias)
     B, _, N = xyz_cn.shape
     _, M, K = idx.shape
     cfeat = 0 if feat is None else feat.shape[1]
-    cout = wt.shape[1]
-    assert wt.shape[0] == cfeat + 3
+    cout = lin.cout
+    assert lin.cin == cfeat + 3
     y = torch.empty(B, cout, M, K, dtype=torch.float32, device=xyz_cn.device)
     with torch.cuda.device(xyz_cn.device):
         L.call("captra_sa_group_mlp", B, N, M, K, cfeat, cout, L.ptr(feat), L.ptr(xyz_cn), L.ptr(new_xyz_n3), L.ptr(idx),
@@ -98,14 +106,41 @@ def sa_group_mlp(feat, xyz_cn, new_xyz_n3, idx, wt, bias):
     return y
 
 
-def mlp_max(x, wt, bias, out, co_off: int):
+def mlp_max(x, lin: PackedLinear, out, co_off: int):
     """Last SA layer + max over K: x (B,cin,M,K) -> out[:, co_off:co_off+cout, :] (out is (B,Ctot,M))."""
+    wt, bias = lin.wt, lin.bias
     L.require_device(x, wt, bias, out)
     B, cin, M, K = x.shape
-    cout = wt.shape[1]
+    cout = lin.cout
+    assert lin.cin == cin
     with torch.cuda.device(x.device):
         L.call("captra_mlp_max", B, cin, cout, M, K, L.ptr(x), L.ptr(wt), L.ptr(bias), L.ptr(out), out.shape[1], co_off)
     _work("mlp_max", flops=2.0 * B * cin * cout * M * K, nbytes=4.0 * B * (cin * M * K + cout * M))
+    return out
+
+
+USE_SA_FUSED = True   # one launch per SA scale (sa_fused.hip); False = layer-by-layer kernels (A/B, tests)
+
+
+def sa_scale_fusable(k: int, layers) -> bool:
+    return USE_SA_FUSED and len(layers) == 3 and k % 32 == 0 and 128 % k == 0 and all(l.cout <= 256 for l in layers)
+
+
+def sa_scale_fused(feat, xyz_cn, new_xyz_n3, idx, layers, out, co_off: int):
+    """Whole SA scale in one launch: layers = [PackedLinear] * 3; writes out[:, co_off:co_off+c3, :]."""
+    L.require_device(feat, xyz_cn, new_xyz_n3, idx, out, *[t for l in layers for t in (l.wt, l.bias)])
+    B, _, N = xyz_cn.shape
+    _, M, K = idx.shape
+    cfeat = 0 if feat is None else feat.shape[1]
+    l1, l2, l3 = layers
+    (w1, b1), (w2, b2), (w3, b3) = (l1.wt, l1.bias), (l2.wt, l2.bias), (l3.wt, l3.bias)
+    c1, c2, c3 = l1.cout, l2.cout, l3.cout
+    assert l1.cin == cfeat + 3 and l2.cin == c1 and l3.cin == c2
+    with torch.cuda.device(xyz_cn.device):
+        L.call("captra_sa_scale_fused", B, N, M, K, cfeat, c1, c2, c3, L.ptr(feat), L.ptr(xyz_cn), L.ptr(new_xyz_n3),
+               L.ptr(idx), L.ptr(w1), L.ptr(b1), L.ptr(w2), L.ptr(b2), L.ptr(w3), L.ptr(b3), L.ptr(out), out.shape[1], co_off)
+    _work("sa_scale_fused", flops=2.0 * B * M * K * ((cfeat + 3) * c1 + c1 * c2 + c2 * c3),
+          nbytes=4.0 * B * ((cfeat + 3) * N + M * K + 3 * M + c3 * M))
     return out
 
 

@@ -172,11 +172,15 @@ class PointNetSetAbstractionMsg(_FoldCache, nn.Module):
         feat = points.contiguous() if points is not None else None
         off = 0
         for layers, idx in zip(folded, idx_list):
-            y = fused.sa_group_mlp(feat, xyz_cn, new_xyz_n3, idx, *layers[0])
-            for wt, bias in layers[1:-1]:
-                y = fused.pointwise_mlp(y, wt, bias, fused.ACT_RELU)
-            fused.mlp_max(y, layers[-1][0], layers[-1][1], out, off)
-            off += layers[-1][0].shape[1]
+            if fused.sa_scale_fusable(idx.shape[2], layers):
+                fused.sa_scale_fused(feat, xyz_cn, new_xyz_n3, idx, layers, out, off)
+                off += layers[-1].cout
+                continue
+            y = fused.sa_group_mlp(feat, xyz_cn, new_xyz_n3, idx, layers[0])
+            for lin in layers[1:-1]:
+                y = fused.pointwise_mlp(y, lin, fused.ACT_RELU)
+            fused.mlp_max(y, layers[-1], out, off)
+            off += layers[-1].cout
         return out
 
     # train / generic: layer by layer, differentiable
@@ -249,8 +253,8 @@ class PointNetFeaturePropagation(_FoldCache, nn.Module):
                 new_points = torch.cat([points1, interpolated], dim=1) if points1 is not None else interpolated
         if fuse:
             new_points = new_points.contiguous()
-            for wt, bias in self._fold(xyz1.device):
-                new_points = fused.pointwise_mlp(new_points, wt, bias, fused.ACT_RELU)
+            for lin in self._fold(xyz1.device):
+                new_points = fused.pointwise_mlp(new_points, lin, fused.ACT_RELU)
             return new_points
         for conv, bn in zip(self.mlp_convs, self.mlp_bns):
             new_points = F.relu(bn(conv(new_points)))
@@ -289,10 +293,10 @@ class PointNetSetAbstraction(_FoldCache, nn.Module):
         if (not self.training) and xyz.is_cuda and N % 32 == 0 and 128 % N == 0:
             folded = self._fold(xyz.device)
             y = x.contiguous().view(B, x.shape[1], 1, N)
-            for wt, bias in folded[:-1]:
-                y = fused.pointwise_mlp(y, wt, bias, fused.ACT_RELU)
+            for lin in folded[:-1]:
+                y = fused.pointwise_mlp(y, lin, fused.ACT_RELU)
             out = torch.empty(B, self.out_channel, 1, dtype=torch.float32, device=xyz.device)
-            fused.mlp_max(y, folded[-1][0], folded[-1][1], out, 0)
+            fused.mlp_max(y, folded[-1], out, 0)
             return new_xyz, out
         y = x.unsqueeze(-1)                                                        # (B,3+D,N,1)
         for conv, bn in zip(self.mlp_convs, self.mlp_bns):

@@ -107,9 +107,17 @@ int captra_ball_query_multi(int b, int n, int m, int nr, const float *radius, co
                             const float *new_xyz, const float *xyz, int *const *idx,
                             captra_stream_t stream);
 
+/* PACKED WEIGHTS.  The shared-MLP kernels take a layer's weights as W^T (cin rows, cout columns) with
+ * BatchNorm folded in, zero-padded to (ceil32(cin), ceil128(cout)) row-major, and the bias zero-padded
+ * to ceil128(cout), so that every tile they stage is in bounds and needs no predicate.
+ * captra_pack_weights builds that image on device from dense wt (cin,cout) / bias (cout);
+ * wt_packed has ceil32(cin)*ceil128(cout) floats, bias_packed ceil128(cout). */
+int captra_pack_weights(int cin, int cout, const float *wt, const float *bias, float *wt_packed,
+                        float *bias_packed, captra_stream_t stream);
+
 /* One shared-MLP layer, y = act(W x + bias), as an exact-fp32 MFMA GEMM over positions
  * (Conv2d/Conv1d 1x1 + folded BatchNorm + ReLU, pointnet_utils.py:242-245, 296-298).
- *   x (B, cin, L) f32, wt (cin, cout) f32 = W^T with BN folded in, bias (cout) -> y (B, cout, L).
+ *   x (B, cin, L) f32, wt / bias PACKED (see above) -> y (B, cout, L).
  *   act: 0 none, 1 ReLU, 2 sigmoid(x) - 0.5 (networks.py:46).
  * Arithmetic contract: acc = bias; for k in 0..cin-1: acc = fmaf(W[co][k], x[k][l], acc)
  * (what v_mfma_f32_32x32x2_f32 computes), then the activation. */
@@ -132,6 +140,17 @@ int captra_sa_group_mlp(int b, int n, int m, int k, int cfeat, int cout, const f
  * straight into the concatenated tensor (pointnet_utils.py:249). */
 int captra_mlp_max(int b, int cin, int cout, int m, int k, const float *x, const float *wt,
                    const float *bias, float *y, int y_ctotal, int co_off, captra_stream_t stream);
+
+/* One whole set-abstraction scale in one launch: gather + centre-subtract + concat, three shared-MLP
+ * layers and the max over the K neighbours (the loop body of PointNetSetAbstractionMsg.forward,
+ * pointnet_utils.py:228-248).  Neither the grouped tensor nor the intermediate activations touch HBM.
+ * Shapes as captra_sa_group_mlp / captra_mlp_max; w_i / b_i PACKED (see captra_pack_weights);
+ * k in {32, 64, 128}, c_i <= 256.  out (B,out_ctotal,M) receives channels [co_off, co_off + c3).
+ * Bit-identical to captra_sa_group_mlp -> captra_pointwise_mlp -> captra_mlp_max. */
+int captra_sa_scale_fused(int b, int n, int m, int k, int cfeat, int c1, int c2, int c3, const float *feat,
+                          const float *xyz_cn, const float *new_xyz, const int *idx, const float *w1,
+                          const float *b1, const float *w2, const float *b2, const float *w3, const float *b3,
+                          float *out, int out_ctotal, int co_off, captra_stream_t stream);
 
 /* Feature propagation input: three_nn + inverse-distance weights + three_interpolate + concat
  * (pointnet_utils.py:280-294, CUDA semantics: weights from sqrt(d2)).

@@ -45,7 +45,7 @@ def test_pointwise_mlp_bit_exact(device, cin, cout, L, act):
     x = rng.standard_normal((2, cin, L)).astype(np.float32)
     wt = (rng.standard_normal((cin, cout)) / np.sqrt(cin)).astype(np.float32)
     b = rng.standard_normal(cout).astype(np.float32)
-    got = fused.pointwise_mlp(_dev(x, device), _dev(wt, device), _dev(b, device), act).cpu().numpy()
+    got = fused.pointwise_mlp(_dev(x, device), fused.pack(_dev(wt, device), _dev(b, device)), act).cpu().numpy()
     ref = O.pointwise_mlp(x, wt, b, act)
     if act == 2:
         np.testing.assert_allclose(got, ref, atol=2e-7, rtol=0)      # expf differs in the last ulp
@@ -66,7 +66,7 @@ def test_sa_group_mlp_bit_exact(device, cfeat, cout, n, m, k):
     wt = (rng.standard_normal((cfeat + 3, cout)) / np.sqrt(cfeat + 3)).astype(np.float32)
     b = rng.standard_normal(cout).astype(np.float32)
     got = fused.sa_group_mlp(None if feat is None else _dev(feat, device), _dev(xyz_cn, device), _dev(new_xyz, device),
-                             _dev(idx, device), _dev(wt, device), _dev(b, device)).cpu().numpy()
+                             _dev(idx, device), fused.pack(_dev(wt, device), _dev(b, device))).cpu().numpy()
     ref = O.pointwise_mlp(O.sa_group(feat, xyz_cn, new_xyz, idx), wt, b, 1)
     np.testing.assert_array_equal(got, ref)
 
@@ -80,18 +80,67 @@ def test_mlp_max_bit_exact(device, cin, cout, m, k):
     wt = (rng.standard_normal((cin, cout)) / np.sqrt(cin)).astype(np.float32)
     b = rng.standard_normal(cout).astype(np.float32)
     out = torch.full((2, cout + 7, m), -1.0, device=device)
-    fused.mlp_max(_dev(x, device), _dev(wt, device), _dev(b, device), out, 5)
+    fused.mlp_max(_dev(x, device), fused.pack(_dev(wt, device), _dev(b, device)), out, 5)
     ref = O.max_over_k(O.pointwise_mlp(x, wt, b, 1))
     got = out.cpu().numpy()
     np.testing.assert_array_equal(got[:, 5:5 + cout], ref)
     assert (got[:, :5] == -1).all() and (got[:, 5 + cout:] == -1).all()     # neighbours untouched
 
 
+@pytest.mark.parametrize("cfeat,chans,n,m,k", [(0, (32, 32, 64), 4096, 512, 32), (3, (64, 64, 128), 4096, 512, 64),
+                                                (0, (64, 96, 128), 4096, 512, 128), (320, (128, 128, 256), 512, 128, 64),
+                                                (320, (128, 196, 256), 512, 128, 128), (5, (34, 62, 250), 300, 37, 32),
+                                                (2, (33, 47, 35), 100, 3, 64)])
+def test_sa_scale_fused_bit_exact(device, cfeat, chans, n, m, k):
+    """The one-launch SA scale equals gather -> 3 x (conv+BN+ReLU) -> max of the oracle, bit for bit,
+    including odd channel counts, a ragged last tile and channel offsets in the output."""
+    from captra_amd import fused
+    rng = np.random.default_rng(cfeat + sum(chans) + k)
+    B = 2
+    xyz_cn = (rng.random((B, 3, n), dtype=np.float32) - 0.5)
+    feat = rng.standard_normal((B, cfeat, n)).astype(np.float32) if cfeat else None
+    new_xyz = (rng.random((B, m, 3), dtype=np.float32) - 0.5)
+    idx = rng.integers(0, n, (B, m, k)).astype(np.int32)
+    dims = (cfeat + 3,) + chans
+    layers = [((rng.standard_normal((dims[i], dims[i + 1])) / np.sqrt(dims[i])).astype(np.float32),
+               rng.standard_normal(dims[i + 1]).astype(np.float32)) for i in range(3)]
+    out = torch.full((B, chans[2] + 9, m), -1.0, device=device)
+    fused.sa_scale_fused(None if feat is None else _dev(feat, device), _dev(xyz_cn, device), _dev(new_xyz, device),
+                         _dev(idx, device), [fused.pack(_dev(w, device), _dev(b, device)) for w, b in layers], out, 4)
+    x = O.sa_group(feat, xyz_cn, new_xyz, idx)
+    for w, b in layers:
+        x = O.pointwise_mlp(x, w, b, 1)
+    ref = O.max_over_k(x)
+    got = out.cpu().numpy()
+    np.testing.assert_array_equal(got[:, 4:4 + chans[2]], ref)
+    assert (got[:, :4] == -1).all() and (got[:, 4 + chans[2]:] == -1).all()
+
+
+def test_backbone_layer_by_layer_kernels_equal_fused_scale(device):
+    """USE_SA_FUSED off routes the SA scales through sa_group_mlp / pointwise_mlp / mlp_max: same bits."""
+    from captra_amd import fused
+    from captra_amd.backbones import PointNet2Msg
+    from captra_amd.configs import make_config
+    cfg = make_config("1")
+    net = PointNet2Msg(cfg, 128, use_xyz_feat=True)
+    net.load_state_dict(make_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, seed=4))
+    net = net.to(device).eval()
+    cloud_cn = _dev(nocs_batch([3]).transpose(0, 2, 1), device)
+    with torch.no_grad():
+        a = net(cloud_cn).cpu().numpy()
+        fused.USE_SA_FUSED = False
+        try:
+            b = net(cloud_cn).cpu().numpy()
+        finally:
+            fused.USE_SA_FUSED = True
+    np.testing.assert_array_equal(a, b)
+
+
 def test_mlp_max_rejects_unsupported_k(device):
     from captra_amd import _lib, fused
     with pytest.raises(_lib.CaptraHipError):
-        fused.mlp_max(torch.zeros(1, 4, 3, 48, device=device), torch.zeros(4, 8, device=device),
-                      torch.zeros(8, device=device), torch.zeros(1, 8, 3, device=device), 0)
+        fused.mlp_max(torch.zeros(1, 4, 3, 48, device=device), fused.pack(torch.zeros(4, 8, device=device),
+                      torch.zeros(8, device=device)), torch.zeros(1, 8, 3, device=device), 0)
 
 
 @pytest.mark.parametrize("P", [1, 4])

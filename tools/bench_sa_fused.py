@@ -1,0 +1,65 @@
+"""Micro-benchmark of one fused SA scale launch (sa_fused.hip) at the bench workload's shapes.
+Usage: python tools/bench_sa_fused.py [--which sa2s2|sa2s1|sa1s3|sa1s2|sa1s1|all] [--clouds 64] [--iters 10] [--layered]"""
+import argparse
+import sys
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from captra_amd import _lib, fused  # noqa: E402
+
+SHAPES = {  # name: (cfeat, (c1,c2,c3), n, m, k)
+    "sa1s1": (3, (32, 32, 64), 4096, 512, 32), "sa1s2": (3, (64, 64, 128), 4096, 512, 64),
+    "sa1s3": (3, (64, 96, 128), 4096, 512, 128), "sa2s1": (320, (128, 128, 256), 512, 128, 64),
+    "sa2s2": (320, (128, 196, 256), 512, 128, 128),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--which", default="all")
+    ap.add_argument("--clouds", type=int, default=64)
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--layered", action="store_true")
+    ap.add_argument("--wn", type=int, default=0)
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    import ctypes
+    _lib.lib().captra_sa_fused_set_wn(ctypes.c_int(a.wn))
+    B = a.clouds
+    names = list(SHAPES) if a.which == "all" else [a.which]
+    for name in names:
+        cfeat, ch, n, m, k = SHAPES[name]
+        g = torch.Generator(device="cpu").manual_seed(0)
+        xyz = (torch.rand(B, 3, n, generator=g) - 0.5).to(dev)
+        feat = torch.randn(B, cfeat, n, generator=g).to(dev) if cfeat else None
+        new_xyz = (torch.rand(B, m, 3, generator=g) - 0.5).to(dev)
+        idx = torch.randint(0, n, (B, m, k), generator=g, dtype=torch.int32).to(dev)
+        dims = (cfeat + 3,) + ch
+        layers = [fused.pack((torch.randn(dims[i], dims[i + 1], generator=g) / dims[i] ** 0.5).to(dev), torch.randn(dims[i + 1], generator=g).to(dev)) for i in range(3)]
+        out = torch.empty(B, ch[2], m, device=dev)
+
+        def run():
+            if a.layered:
+                y = fused.sa_group_mlp(feat, xyz, new_xyz, idx, layers[0])
+                y = fused.pointwise_mlp(y, layers[1], fused.ACT_RELU)
+                fused.mlp_max(y, layers[2], out, 0)
+            else:
+                fused.sa_scale_fused(feat, xyz, new_xyz, idx, layers, out, 0)
+
+        for _ in range(2):
+            run()
+        torch.cuda.synchronize()
+        _lib.prof_reset(); _lib.prof_enable(True)
+        for _ in range(a.iters):
+            run()
+        torch.cuda.synchronize()
+        _lib.prof_enable(False)
+        ms = sum(_lib.prof_read(nm)[0] for nm in _lib.prof_names()) / a.iters
+        flops = 2.0 * B * m * k * sum(dims[i] * dims[i + 1] for i in range(3))
+        print(f"{name:6s} {'layered' if a.layered else 'fused':7s} {ms * 1e3:9.1f} us  {flops / ms / 1e9:7.1f} TFLOP/s  ({flops / 1e9:.1f} GFLOP)", flush=True)
+
+
+if __name__ == "__main__":
+    main()
