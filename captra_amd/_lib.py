@@ -38,7 +38,10 @@ _SIGNATURES = {
     "captra_sa_group_mlp": [_INT, _INT, _INT, _INT, _INT, _INT, _P, _P, _P, _P, _P, _P, _P, _P],
     "captra_mlp_max": [_INT, _INT, _INT, _INT, _INT, _P, _P, _P, _P, _INT, _INT, _P],
     "captra_sa_scale_fused": [_INT] * 8 + [_P] * 11 + [_INT, _INT, _P],
-    "captra_fp_interpolate_concat": [_INT, _INT, _INT, _INT, _INT, _P, _P, _P, _P, _P, _P],
+    "captra_three_nn_weights": [_INT, _INT, _INT, _P, _P, _P, _P, _P],
+    "captra_interp_concat": [_INT, _INT, _INT, _INT, _INT, _P, _P, _P, _P, _P, _P],
+    "captra_fp_interpolate_concat": [_INT, _INT, _INT, _INT, _INT, _P, _P, _P, _P, _P, _P, _P, _P],
+    "captra_group_norm_relu": [_INT, _INT, _INT, _INT, _F, _INT, _P, _P, _P, _P, _P],
     "captra_part_fit_st": [_INT, _INT, _INT, _INT, _P, _P, _P, _INT, _P, _P, _P, _P, _P, _P],
     "captra_procrustes_rot3": [_INT, _INT, _P, _P, _P, _P],
 }

@@ -49,23 +49,27 @@ class PointNet2Msg(_FoldCache, nn.Module):
         self.device = cfg["device"]
         self._folded = None
 
-    def forward(self, input, input_n3=None):
-        """input (B,3(+C),N); `input_n3` optionally the (B,N,3) copy of input[:, :3]."""
+    def forward(self, input, input_n3=None, geom=None):
+        """input (B,3(+C),N); `input_n3` optionally the (B,N,3) copy of input[:, :3]; `geom` optionally
+        the `last_geom` of another PointNet2Msg that ran on the SAME cloud (FPS picks, ball-query lists
+        and 3-NN weights depend on coordinates only): those kernels are then skipped."""
+        geom = geom or {}
         l0_xyz = input[:, :3] if input.shape[1] > 3 else input
         l0_xyz = l0_xyz.contiguous()
         l0_points = input if self.use_xyz_feat else input[:, 3:]
         if input_n3 is None:
             input_n3 = l0_xyz.transpose(1, 2).contiguous()
-        l1_xyz, l1_points = self.sa1(l0_xyz, l0_points, xyz_n3=input_n3)
+        l1_xyz, l1_points = self.sa1(l0_xyz, l0_points, xyz_n3=input_n3, geom=geom.get("sa1"))
         l1_n3 = self.sa1.last_new_xyz_n3
-        l2_xyz, l2_points = self.sa2(l1_xyz, l1_points, xyz_n3=l1_n3)
+        l2_xyz, l2_points = self.sa2(l1_xyz, l1_points, xyz_n3=l1_n3, geom=geom.get("sa2"))
         l2_n3 = self.sa2.last_new_xyz_n3
         l3_xyz, l3_points = self.sa3(l2_xyz, l2_points)
 
         l2_points = self.fp3(l2_xyz, l3_xyz, l2_points, l3_points)
-        l1_points = self.fp2(l1_xyz, l2_xyz, l1_points, l2_points, xyz1_n3=l1_n3, xyz2_n3=l2_n3)
+        l1_points = self.fp2(l1_xyz, l2_xyz, l1_points, l2_points, xyz1_n3=l1_n3, xyz2_n3=l2_n3, nn=geom.get("fp2"))
         skip0 = torch.cat([l0_xyz, l0_points], dim=1) if l0_points.shape[1] > 0 else l0_xyz
-        l0_points = self.fp1(l0_xyz, l1_xyz, skip0, l1_points, xyz1_n3=input_n3, xyz2_n3=l1_n3)
+        l0_points = self.fp1(l0_xyz, l1_xyz, skip0, l1_points, xyz1_n3=input_n3, xyz2_n3=l1_n3, nn=geom.get("fp1"))
+        self.last_geom = {"sa1": self.sa1.last_geom, "sa2": self.sa2.last_geom, "fp2": self.fp2.last_nn, "fp1": self.fp1.last_nn}
         if (not self.training) and l0_points.is_cuda:
             if self._folded is None:
                 self._folded = fold_conv_bn(self.conv1, self.bn1, l0_points.device)

@@ -85,9 +85,13 @@ def run_point_mlp(seq: nn.Sequential, x: torch.Tensor, cache: dict) -> torch.Ten
         lin = cache[key]
         if gn is not None:
             x = fused.pointwise_mlp(x, lin, fused.ACT_NONE)
-            x = F.group_norm(x, gn.num_groups, gn.weight, gn.bias, gn.eps)
-            if act == fused.ACT_RELU:
-                x = F.relu(x, inplace=True)
+            cpg = x.shape[1] // gn.num_groups
+            if x.shape[2] % 4 == 0 and cpg * x.shape[2] <= 16384:
+                x = fused.group_norm_relu(x, gn.num_groups, gn.weight, gn.bias, gn.eps, relu=(act == fused.ACT_RELU))
+            else:
+                x = F.group_norm(x, gn.num_groups, gn.weight, gn.bias, gn.eps)
+                if act == fused.ACT_RELU:
+                    x = F.relu(x, inplace=True)
         else:
             x = fused.pointwise_mlp(x, lin, act)
             if sigmoid_tail:

@@ -1,9 +1,8 @@
 // Elementwise / small fused operators of the tracking path for gfx950:
 //   captra_canonicalize            networks.py:38-41, 184-187
-//   captra_fp_interpolate_concat   pointnet_utils.py:280-294 (three_nn + weights + interpolate + cat)
+//   captra_three_nn_weights / captra_interp_concat / captra_fp_interpolate_concat
+//                                  pointnet_utils.py:280-294 (three_nn + weights + interpolate + cat)
 //   captra_group_norm_relu         blocks.py:70-71 (GroupNorm(C/2, C)) + ReLU of MLPConv1d
-//   captra_rot_head_pool           blocks.py:183-192 + networks.py:127-138 (per-point rotation
-//                                  representation, masked mean over the part's points)
 #include "common.h"
 
 #include <math.h>
@@ -40,118 +39,194 @@ __global__ __launch_bounds__(256) void canonicalize_kernel(int p, int n, const f
 }
 
 // ---------------------------------------------------------------------------------------------
-// feature-propagation input: 3-NN of each unknown point among `known`, weights
-// w_j = (1/(sqrt(d2_j)+1e-8)) / sum, out = cat([skip, sum_j w_j feat_known[:, idx_j]])
-// One workgroup = 1024 unknown points (4 per thread); `known` then feature rows staged in LDS.
+// feature-propagation input, two kernels so that the geometric half can be shared by networks that
+// see the same cloud (CoordNet and the root part's RotationNet cloud):
+//   three_nn_weights: 3-NN of each unknown point among `known` + weights w_j = (1/(sqrt(d2_j)+1e-8)) / sum
+//                     (pointnet_utils.py:284-287 with the CUDA three_nn semantics)
+//   interp_concat:    out = cat([skip, sum_j w_j feat_known[:, idx_j]])   (pointnet_utils.py:289-294)
 // ---------------------------------------------------------------------------------------------
-constexpr int FP_THREADS = 256;
-constexpr int FP_PPT = 4;
-constexpr int FP_LDS_FLOATS = 16 * 1024;  // 64 KiB, shared by the xyz tile and the feature-row chunk
-constexpr int FP_XYZ_TILE = FP_LDS_FLOATS / 3;
+constexpr int NW_THREADS = 256;
+constexpr int NW_TILE = 4096;  // known points per LDS tile (48 KiB)
 
-__global__ __launch_bounds__(FP_THREADS) void fp_interp_concat_kernel(int n, int s, int c1, int c2, int cc,
-                                                                      const float *__restrict__ unknown,
+__global__ __launch_bounds__(NW_THREADS) void three_nn_weights_kernel(int n, int s, const float *__restrict__ unknown,
                                                                       const float *__restrict__ known,
-                                                                      const float *__restrict__ skip,
-                                                                      const float *__restrict__ feat_known,
-                                                                      float *__restrict__ out) {
-    __shared__ __attribute__((aligned(16))) float lds[FP_LDS_FLOATS];
+                                                                      int *__restrict__ idx, float *__restrict__ weight) {
+    __shared__ __attribute__((aligned(16))) float xs[NW_TILE];
+    __shared__ __attribute__((aligned(16))) float ys[NW_TILE];
+    __shared__ __attribute__((aligned(16))) float zs[NW_TILE];
     const int b = blockIdx.y;
     const int tid = threadIdx.x;
-    const int p0 = blockIdx.x * (FP_THREADS * FP_PPT);
-    const int ct = c1 + c2;
-
-    float ux[FP_PPT], uy[FP_PPT], uz[FP_PPT];
-    float b1[FP_PPT], b2[FP_PPT], b3[FP_PPT];
-    int i1[FP_PPT], i2[FP_PPT], i3[FP_PPT];
-#pragma unroll
-    for (int j = 0; j < FP_PPT; ++j) {
-        const int pt = p0 + tid + j * FP_THREADS;
-        ux[j] = uy[j] = uz[j] = 0.f;
-        if (pt < n) {
-            const float *u = unknown + ((size_t)b * n + pt) * 3;
-            ux[j] = u[0]; uy[j] = u[1]; uz[j] = u[2];
-        }
-        b1[j] = b2[j] = b3[j] = INFINITY;
-        i1[j] = i2[j] = i3[j] = 0;
+    const int pt = blockIdx.x * NW_THREADS + tid;
+    const bool live = pt < n;
+    float ux = 0.f, uy = 0.f, uz = 0.f;
+    if (live) {
+        const float *u = unknown + ((size_t)b * n + pt) * 3;
+        ux = u[0]; uy = u[1]; uz = u[2];
     }
+    float b1 = INFINITY, b2 = INFINITY, b3 = INFINITY;
+    int i1 = 0, i2 = 0, i3 = 0;
     const float *kn = known + (size_t)b * s * 3;
-    for (int t0 = 0; t0 < s; t0 += FP_XYZ_TILE) {
-        const int tn = (s - t0) < FP_XYZ_TILE ? (s - t0) : FP_XYZ_TILE;
-        float *xs = lds, *ys = lds + FP_XYZ_TILE, *zs = lds + 2 * FP_XYZ_TILE;
+    for (int t0 = 0; t0 < s; t0 += NW_TILE) {
+        const int tn = (s - t0) < NW_TILE ? (s - t0) : NW_TILE;
         if (t0 > 0) __syncthreads();
-        for (int e = tid; e < tn * 3; e += FP_THREADS) {
+        for (int e = tid; e < tn * 3; e += NW_THREADS) {
             const float v = kn[(size_t)t0 * 3 + e];
             const int pp = e / 3, comp = e - pp * 3;
             (comp == 0 ? xs : (comp == 1 ? ys : zs))[pp] = v;
         }
         __syncthreads();
         for (int k = 0; k < tn; ++k) {
-            const float kx = xs[k], ky = ys[k], kz = zs[k];
+            const float d = dist2_unfused(ux, uy, uz, xs[k], ys[k], zs[k]);
             const int kk = t0 + k;
-#pragma unroll
-            for (int j = 0; j < FP_PPT; ++j) {
-                const float d = dist2_unfused(ux[j], uy[j], uz[j], kx, ky, kz);
-                if (d < b1[j]) {
-                    b3[j] = b2[j]; i3[j] = i2[j];
-                    b2[j] = b1[j]; i2[j] = i1[j];
-                    b1[j] = d;     i1[j] = kk;
-                } else if (d < b2[j]) {
-                    b3[j] = b2[j]; i3[j] = i2[j];
-                    b2[j] = d;     i2[j] = kk;
-                } else if (d < b3[j]) {
-                    b3[j] = d;     i3[j] = kk;
-                }
+            if (d < b1) {
+                b3 = b2; i3 = i2;
+                b2 = b1; i2 = i1;
+                b1 = d;  i1 = kk;
+            } else if (d < b2) {
+                b3 = b2; i3 = i2;
+                b2 = d;  i2 = kk;
+            } else if (d < b3) {
+                b3 = d;  i3 = kk;
             }
         }
     }
-    float w1[FP_PPT], w2[FP_PPT], w3[FP_PPT];
-#pragma unroll
-    for (int j = 0; j < FP_PPT; ++j) {
-        const float r0 = 1.0f / (sqrtf(b1[j]) + 1e-8f);
-        const float r1 = 1.0f / (sqrtf(b2[j]) + 1e-8f);
-        const float r2 = 1.0f / (sqrtf(b3[j]) + 1e-8f);
+    if (live) {
+        const float r0 = 1.0f / (sqrtf(b1) + 1e-8f);
+        const float r1 = 1.0f / (sqrtf(b2) + 1e-8f);
+        const float r2 = 1.0f / (sqrtf(b3) + 1e-8f);
         const float norm = (r0 + r1) + r2;
-        w1[j] = r0 / norm; w2[j] = r1 / norm; w3[j] = r2 / norm;
+        int *ii = idx + ((size_t)b * n + pt) * 3;
+        float *ww = weight + ((size_t)b * n + pt) * 3;
+        ii[0] = i1; ii[1] = i2; ii[2] = i3;
+        ww[0] = r0 / norm; ww[1] = r1 / norm; ww[2] = r2 / norm;
     }
-    // skip connection copied into channels [0, c1)
-    for (int ch = 0; ch < c1; ++ch) {
-#pragma unroll
-        for (int j = 0; j < FP_PPT; ++j) {
-            const int pt = p0 + tid + j * FP_THREADS;
-            if (pt < n) out[((size_t)b * ct + ch) * n + pt] = skip[((size_t)b * c1 + ch) * n + pt];
-        }
+}
+
+constexpr int IC_THREADS = 256;
+constexpr int IC_POS = 1024;           // positions per workgroup (4 per lane)
+constexpr int IC_LDS_FLOATS = 8 * 1024;  // 32 KiB of feature rows per workgroup
+
+// grid (pos tiles, channel chunks, B): channel chunk cb covers output channels [cb*cc, cb*cc+cc) of the
+// concatenated tensor; channels < c1 are copied from skip, the rest interpolated from LDS-staged rows.
+__global__ __launch_bounds__(IC_THREADS) void interp_concat_kernel(int n, int s, int c1, int c2, int cc,
+                                                                   const float *__restrict__ skip,
+                                                                   const float *__restrict__ feat_known,
+                                                                   const int *__restrict__ idx,
+                                                                   const float *__restrict__ weight,
+                                                                   float *__restrict__ out) {
+    __shared__ __attribute__((aligned(16))) float rows[IC_LDS_FLOATS];
+    const int b = blockIdx.z;
+    const int tid = threadIdx.x;
+    const int p0 = blockIdx.x * IC_POS;
+    const int ct = c1 + c2;
+    const int ch0 = blockIdx.y * cc;
+    const int ch1 = (ch0 + cc) < ct ? (ch0 + cc) : ct;
+    // interpolated part of this chunk: feature channels [f0, f1)
+    const int f0 = (ch0 > c1 ? ch0 : c1) - c1, f1 = (ch1 > c1 ? ch1 : c1) - c1;
+    if (f1 > f0) {
+        const float *src = feat_known + ((size_t)b * c2 + f0) * s;
+        const size_t nstage = (size_t)(f1 - f0) * s;
+        for (size_t e = tid; e < nstage; e += IC_THREADS) rows[e] = src[e];
     }
-    // interpolated features into channels [c1, c1+c2)
-    const float *fk = feat_known + (size_t)b * c2 * s;
-    if (cc > 0) {
-        for (int ch0 = 0; ch0 < c2; ch0 += cc) {
-            const int ccv = (c2 - ch0) < cc ? (c2 - ch0) : cc;
-            __syncthreads();
-            const size_t nstage = (size_t)ccv * s;
-            for (size_t e = tid; e < nstage; e += FP_THREADS) lds[e] = fk[(size_t)ch0 * s + e];
-            __syncthreads();
-            for (int ch = 0; ch < ccv; ++ch) {
-                const float *row = lds + (size_t)ch * s;
+    __syncthreads();
+    int j0[4], j1[4], j2[4];
+    float w0[4], w1[4], w2[4];
 #pragma unroll
-                for (int j = 0; j < FP_PPT; ++j) {
-                    const int pt = p0 + tid + j * FP_THREADS;
-                    if (pt < n)
-                        out[((size_t)b * ct + c1 + ch0 + ch) * n + pt] =
-                            (w1[j] * row[i1[j]] + w2[j] * row[i2[j]]) + w3[j] * row[i3[j]];
-                }
+    for (int u = 0; u < 4; ++u) {
+        int pt = p0 + tid + u * IC_THREADS;
+        if (pt >= n) pt = n - 1;
+        const int *ii = idx + ((size_t)b * n + pt) * 3;
+        const float *ww = weight + ((size_t)b * n + pt) * 3;
+        j0[u] = ii[0]; j1[u] = ii[1]; j2[u] = ii[2];
+        w0[u] = ww[0]; w1[u] = ww[1]; w2[u] = ww[2];
+    }
+    for (int ch = ch0; ch < ch1; ++ch) {
+        float *orow = out + ((size_t)b * ct + ch) * n;
+        if (ch < c1) {
+            const float *srow = skip + ((size_t)b * c1 + ch) * n;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int pt = p0 + tid + u * IC_THREADS;
+                if (pt < n) orow[pt] = srow[pt];
+            }
+        } else {
+            const float *row = rows + (size_t)(ch - c1 - f0) * s;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int pt = p0 + tid + u * IC_THREADS;
+                if (pt < n) orow[pt] = (w0[u] * row[j0[u]] + w1[u] * row[j1[u]]) + w2[u] * row[j2[u]];
             }
         }
-    } else {
-        for (int ch = 0; ch < c2; ++ch) {
-            const float *row = fk + (size_t)ch * s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// GroupNorm (groups of `cpg` consecutive channels) + optional ReLU over (B,C,N), one workgroup per
+// (cloud, group): the group's cpg*N values are read once into registers, mean and centred variance
+// reduced in the workgroup, normalised values written once.  Replaces torch's three kernels
+// (moments, affine, clamp) after the rotation-head convs (blocks.py:70-71, 148-165).
+// ---------------------------------------------------------------------------------------------
+constexpr int GN_THREADS = 256;
+constexpr int GN_MAXV = 16;  // float4 per thread: supports cpg*N <= 256*16*4 = 16384 values per group
+
+__device__ __forceinline__ float block_sum(float v, float *smem) {
 #pragma unroll
-            for (int j = 0; j < FP_PPT; ++j) {
-                const int pt = p0 + tid + j * FP_THREADS;
-                if (pt < n)
-                    out[((size_t)b * ct + c1 + ch) * n + pt] =
-                        (w1[j] * row[i1[j]] + w2[j] * row[i2[j]]) + w3[j] * row[i3[j]];
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) smem[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (smem[0] + smem[1]) + (smem[2] + smem[3]);
+}
+
+__global__ __launch_bounds__(GN_THREADS) void group_norm_relu_kernel(int c, int n, int cpg, float eps, int relu,
+                                                                     const float *__restrict__ x,
+                                                                     const float *__restrict__ gamma,
+                                                                     const float *__restrict__ beta,
+                                                                     float *__restrict__ y) {
+    __shared__ float smem[4];
+    const int groups = c / cpg;
+    const int b = blockIdx.x / groups, g = blockIdx.x % groups;
+    const size_t base = ((size_t)b * c + (size_t)g * cpg) * n;   // the group's values are contiguous
+    const int total = cpg * n;                                      // multiple of 4 (host checks)
+    const int nv = total / 4;
+    const float4 *x4 = reinterpret_cast<const float4 *>(x + base);
+    float4 v[GN_MAXV];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < GN_MAXV; ++i) {
+        const int e = threadIdx.x + i * GN_THREADS;
+        v[i] = e < nv ? x4[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+        sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mean = block_sum(sum, smem) / (float)total;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < GN_MAXV; ++i) {
+        const int e = threadIdx.x + i * GN_THREADS;
+        if (e < nv) {
+            const float dx = v[i].x - mean, dy = v[i].y - mean, dz = v[i].z - mean, dw = v[i].w - mean;
+            sq += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+        }
+    }
+    const float var = block_sum(sq, smem) / (float)total;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    float4 *y4 = reinterpret_cast<float4 *>(y + base);
+#pragma unroll
+    for (int i = 0; i < GN_MAXV; ++i) {
+        const int e = threadIdx.x + i * GN_THREADS;
+        if (e < nv) {
+            const int ch = g * cpg + (e * 4) / n;   // n % 4 == 0: a float4 never straddles channels
+            const float ga = gamma[ch] * rstd, be = beta[ch];
+            float4 o;
+            o.x = (v[i].x - mean) * ga + be;
+            o.y = (v[i].y - mean) * ga + be;
+            o.z = (v[i].z - mean) * ga + be;
+            o.w = (v[i].w - mean) * ga + be;
+            if (relu) {
+                o.x = o.x > 0.f ? o.x : 0.f; o.y = o.y > 0.f ? o.y : 0.f;
+                o.z = o.z > 0.f ? o.z : 0.f; o.w = o.w > 0.f ? o.w : 0.f;
             }
+            y4[e] = o;
         }
     }
 }
@@ -169,17 +244,48 @@ extern "C" int captra_canonicalize(int b, int p, int n, const float *pts, const 
     return captra_last_error();
 }
 
-extern "C" int captra_fp_interpolate_concat(int b, int n, int s, int c1, int c2, const float *unknown,
-                                            const float *known, const float *skip, const float *feat_known,
-                                            float *out, captra_stream_t stream) {
-    if (b < 0 || n < 0 || s < 0 || c1 < 0 || c2 < 0) return -1;
-    if (c1 > 0 && skip == nullptr) return -1;
+extern "C" int captra_three_nn_weights(int b, int n, int s, const float *unknown, const float *known, int *idx,
+                                      float *weight, captra_stream_t stream) {
+    if (b < 0 || n < 0 || s < 0) return -1;
     if (b == 0 || n == 0) return 0;
     if (s == 0) return -1;
-    int cc = FP_LDS_FLOATS / s;
+    dim3 grid((n + NW_THREADS - 1) / NW_THREADS, b);
+    CAPTRA_LAUNCH("three_nn_weights", three_nn_weights_kernel, grid, dim3(NW_THREADS), 0, (hipStream_t)stream, n, s,
+                  unknown, known, idx, weight);
+    return captra_last_error();
+}
+
+extern "C" int captra_interp_concat(int b, int n, int s, int c1, int c2, const float *skip, const float *feat_known,
+                                    const int *idx, const float *weight, float *out, captra_stream_t stream) {
+    if (b < 0 || n < 0 || s < 1 || c1 < 0 || c2 < 0) return -1;
+    if (c1 > 0 && skip == nullptr) return -1;
+    if (b == 0 || n == 0 || c1 + c2 == 0) return 0;
+    if (s > IC_LDS_FLOATS) return -2;
+    int cc = IC_LDS_FLOATS / s;   // channels per chunk: their feature rows fit the LDS buffer
     if (cc > 32) cc = 32;
-    dim3 grid((n + FP_THREADS * FP_PPT - 1) / (FP_THREADS * FP_PPT), b);
-    CAPTRA_LAUNCH("fp_interpolate_concat", fp_interp_concat_kernel, grid, dim3(FP_THREADS), 0, (hipStream_t)stream,
-                  n, s, c1, c2, cc, unknown, known, skip, feat_known, out);
+    dim3 grid((n + IC_POS - 1) / IC_POS, (c1 + c2 + cc - 1) / cc, b);
+    CAPTRA_LAUNCH("interp_concat", interp_concat_kernel, grid, dim3(IC_THREADS), 0, (hipStream_t)stream, n, s, c1, c2,
+                  cc, skip, feat_known, idx, weight, out);
+    return captra_last_error();
+}
+
+extern "C" int captra_fp_interpolate_concat(int b, int n, int s, int c1, int c2, const float *unknown,
+                                            const float *known, const float *skip, const float *feat_known,
+                                            int *idx_scratch, float *weight_scratch, float *out,
+                                            captra_stream_t stream) {
+    int err = captra_three_nn_weights(b, n, s, unknown, known, idx_scratch, weight_scratch, stream);
+    if (err) return err;
+    return captra_interp_concat(b, n, s, c1, c2, skip, feat_known, idx_scratch, weight_scratch, out, stream);
+}
+
+extern "C" int captra_group_norm_relu(int b, int c, int n, int channels_per_group, float eps, int relu,
+                                      const float *x, const float *gamma, const float *beta, float *y,
+                                      captra_stream_t stream) {
+    if (b < 0 || c < 1 || n < 1 || channels_per_group < 1 || c % channels_per_group != 0) return -1;
+    if (n % 4 != 0 || (long long)channels_per_group * n > (long long)GN_THREADS * GN_MAXV * 4) return -2;
+    if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(y) & 15)) return -2;
+    if (b == 0) return 0;
+    CAPTRA_LAUNCH("group_norm_relu", group_norm_relu_kernel, dim3(b * (c / channels_per_group)), dim3(GN_THREADS), 0,
+                  (hipStream_t)stream, c, n, channels_per_group, eps, relu, x, gamma, beta, y);
     return captra_last_error();
 }

@@ -144,15 +144,47 @@ def sa_scale_fused(feat, xyz_cn, new_xyz_n3, idx, layers, out, co_off: int):
     return out
 
 
-def fp_interpolate_concat(unknown_n3, known_n3, skip, feat_known):
-    """three_nn + inverse-distance weights + interpolate + cat([skip, interp]) -> (B,c1+c2,N)."""
-    L.require_device(unknown_n3, known_n3, skip, feat_known)
+def three_nn_weights(unknown_n3, known_n3):
+    """3-NN + normalised inverse-distance weights -> (idx (B,N,3) int32, weight (B,N,3))."""
+    L.require_device(unknown_n3, known_n3)
     B, N, _ = unknown_n3.shape
     S = known_n3.shape[1]
-    c1 = 0 if skip is None else skip.shape[1]
-    c2 = feat_known.shape[1]
-    out = torch.empty(B, c1 + c2, N, dtype=torch.float32, device=unknown_n3.device)
+    idx = torch.empty(B, N, 3, dtype=torch.int32, device=unknown_n3.device)
+    w = torch.empty(B, N, 3, dtype=torch.float32, device=unknown_n3.device)
     with torch.cuda.device(unknown_n3.device):
-        L.call("captra_fp_interpolate_concat", B, N, S, c1, c2, L.ptr(unknown_n3), L.ptr(known_n3), L.ptr(skip),
-               L.ptr(feat_known), L.ptr(out))
+        L.call("captra_three_nn_weights", B, N, S, L.ptr(unknown_n3), L.ptr(known_n3), L.ptr(idx), L.ptr(w))
+    _work("three_nn_weights", nbytes=B * (12.0 * N + 12.0 * S + 24.0 * N))
+    return idx, w
+
+
+def interp_concat(skip, feat_known, idx, weight):
+    """cat([skip (B,c1,N), sum_j w_j feat_known (B,c2,S)[:, idx_j]]) -> (B,c1+c2,N)."""
+    L.require_device(skip, feat_known, idx, weight)
+    B, N, _ = idx.shape
+    c2, S = feat_known.shape[1], feat_known.shape[2]
+    c1 = 0 if skip is None else skip.shape[1]
+    out = torch.empty(B, c1 + c2, N, dtype=torch.float32, device=feat_known.device)
+    with torch.cuda.device(feat_known.device):
+        L.call("captra_interp_concat", B, N, S, c1, c2, L.ptr(skip), L.ptr(feat_known), L.ptr(idx), L.ptr(weight), L.ptr(out))
+    _work("interp_concat", nbytes=4.0 * B * (c1 * N + c2 * S + 6 * N + (c1 + c2) * N))
     return out
+
+
+def fp_interpolate_concat(unknown_n3, known_n3, skip, feat_known, nn=None):
+    """three_nn + inverse-distance weights + interpolate + cat([skip, interp]) -> (B,c1+c2,N).
+    `nn` = (idx, weight) from three_nn_weights, when another network already computed them."""
+    if nn is None:
+        nn = three_nn_weights(unknown_n3, known_n3)
+    return interp_concat(skip, feat_known, nn[0], nn[1])
+
+
+def group_norm_relu(x, num_groups: int, gamma, beta, eps: float, relu: bool = True):
+    """GroupNorm(num_groups) + optional ReLU over x (B,C,N) in one pass."""
+    L.require_device(x, gamma, beta)
+    B, C, N = x.shape
+    y = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        L.call("captra_group_norm_relu", B, C, N, C // num_groups, float(eps), 1 if relu else 0, L.ptr(x), L.ptr(gamma),
+               L.ptr(beta), L.ptr(y))
+    _work("group_norm_relu", nbytes=8.0 * B * C * N)
+    return y

@@ -65,6 +65,9 @@ class EvalTrackModel(BaseModel):
         self.npcs_feed_dict = []
         self.timer = Timer(True)
         self.time_dict = {"npcs_net": 0.0, "rot_all": 0.0}
+        # single-part objects: RotationNet canonicalises with the very pose CoordNet used, so both nets see
+        # the same cloud and FPS / ball query / 3-NN run once per frame instead of twice
+        self.share_geometry = True
 
     # ---- host -> device ------------------------------------------------------------------------
     def _gt_part(self, frame):
@@ -122,6 +125,9 @@ class EvalTrackModel(BaseModel):
         input["pred_label_conf"] = npcs_pred["seg"][:, 0]
         if self.track_cfg["gt_label"] or self.track_cfg["nocs2d_label"]:
             input["pred_labels"] = npcs_input["labels"]
+        input.pop("shared_geometry", None)
+        if self.share_geometry and self.num_parts == 1 and not self.npcs_net.training:
+            input["shared_geometry"] = (self.npcs_net.last_canon, self.npcs_net.backbone.last_geom)
         return npcs_pred, self.net(input, test_mode=True)["part"]
 
     def forward(self, save=False):

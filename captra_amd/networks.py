@@ -64,6 +64,7 @@ class CoordNet(nn.Module):
         translation (B,3,1), scale (B,)}, [...]} -> {'seg' (B,P+e,N) softmax, 'nocs' (B,3P,N), 'points'}."""
         canon_pose = input["canon_pose"]
         cam_cn, cam_n3 = _canonicalize(input["points"], input["points_mean"], canon_pose)
+        self.last_canon = (cam_cn, cam_n3)
         feat = self.backbone(cam_cn, input_n3=cam_n3)
         seg_logits, nocs = self._heads(feat)
         pred = {"seg": F.softmax(seg_logits, dim=1), "nocs": nocs - 0.5, "points": cam_cn}
@@ -120,9 +121,9 @@ class RotationRegressionBackbone(nn.Module):
         self.pose_pred = RotationRegressor(cfg["network"]["backbone_out_dim"], self.num_parts, symmetric=self.sym)
         self.cfg = cfg
 
-    def forward(self, cam, cam_labels, cam_n3=None):
+    def forward(self, cam, cam_labels, cam_n3=None, geom=None):
         """cam (B,3,N), cam_labels (B,N) -> {'rtvec' (B,P,D) masked mean, 'point_rtvec' (B,P,D,N)}."""
-        feat = self.encoder(cam, input_n3=cam_n3)
+        feat = self.encoder(cam, input_n3=cam_n3, geom=geom)
         P = self.num_parts
         labels = cam_labels.long()
         part_mask = (labels.unsqueeze(1) == torch.arange(P, device=labels.device).view(1, P, 1)).float().unsqueeze(-2)
@@ -162,9 +163,16 @@ class PartCanonNet(nn.Module):
         B = len(input["points"])
 
         # every part sees the whole cloud, canonicalised with that part's previous pose
-        cam_cn, cam_n3 = _canonicalize(input["points"], input["points_mean"], canon_pose, num_parts=P)
+        # `shared` = (canonicalised cloud, backbone geometry) of CoordNet, valid when this net's clouds are
+        # the same clouds (one part: the part's previous pose IS the CoordNet's canonical pose)
+        shared = input.get("shared_geometry") if P == 1 else None
+        if shared is not None:
+            (cam_cn, cam_n3), geom = shared
+        else:
+            cam_cn, cam_n3 = _canonicalize(input["points"], input["points_mean"], canon_pose, num_parts=P)
+            geom = None
         seg_rep = cam_seg.unsqueeze(1).expand(-1, P, -1).reshape(B * P, -1)
-        pred = self.regress_net(cam_cn, seg_rep, cam_n3=cam_n3)
+        pred = self.regress_net(cam_cn, seg_rep, cam_n3=cam_n3, geom=geom)
 
         out = {"rotation": convert_pred_rtvec_to_matrix(pred["rtvec"], self.sym)}       # (B*P,P,3,3)
         if self.return_point_rotation or not test_mode:

@@ -148,26 +148,33 @@ class PointNetSetAbstractionMsg(_FoldCache, nn.Module):
         return (not self.training) and (not self.knn) and xyz.is_cuda and \
             all(k % 32 == 0 and 128 % k == 0 for k in self.nsample_list)
 
-    def forward(self, xyz, points, xyz_n3=None):
+    def forward(self, xyz, points, xyz_n3=None, geom=None):
         """xyz (B,3,N), points (B,D,N) or None -> (new_xyz (B,3,S), features (B,D',S)).
-        `xyz_n3` optionally passes the (B,N,3) copy the caller already has."""
+        `xyz_n3` optionally passes the (B,N,3) copy the caller already has; `geom` the sampling and
+        neighbour lists another network computed on the SAME cloud (FPS and ball query depend on the
+        coordinates only).  The geometry used is left in `self.last_geom`."""
         if not _has_points(points):
             points = None
         if xyz_n3 is None:
             xyz_n3 = xyz.transpose(1, 2).contiguous()
-        fps_idx = futils.furthest_point_sample(xyz_n3, self.npoint)                      # (B,S) int32
-        new_xyz_n3 = torch.gather(xyz_n3, 1, fps_idx.long().unsqueeze(-1).expand(-1, -1, 3))  # (B,S,3)
-        new_xyz = new_xyz_n3.transpose(1, 2).contiguous()
+        if geom is None:
+            fps_idx = futils.furthest_point_sample(xyz_n3, self.npoint)                      # (B,S) int32
+            new_xyz_n3 = torch.gather(xyz_n3, 1, fps_idx.long().unsqueeze(-1).expand(-1, -1, 3))  # (B,S,3)
+            geom = {"new_xyz_n3": new_xyz_n3, "new_xyz": new_xyz_n3.transpose(1, 2).contiguous(), "idx_list": None}
+        new_xyz_n3, new_xyz = geom["new_xyz_n3"], geom["new_xyz"]
         self.last_new_xyz_n3 = new_xyz_n3
+        self.last_geom = geom
         if self._can_fuse(xyz):
-            return new_xyz, self._forward_fused(xyz.contiguous(), xyz_n3, points, new_xyz_n3)
+            return new_xyz, self._forward_fused(xyz.contiguous(), xyz_n3, points, new_xyz_n3, geom)
         return new_xyz, self._forward_layers(xyz, xyz_n3, points, new_xyz, new_xyz_n3)
 
     # eval: fused kernels
-    def _forward_fused(self, xyz_cn, xyz_n3, points, new_xyz_n3):
+    def _forward_fused(self, xyz_cn, xyz_n3, points, new_xyz_n3, geom):
         folded = self._fold(xyz_cn.device)
         B, S = xyz_cn.shape[0], self.npoint
-        idx_list = fused.ball_query_multi(self.radius_list, self.nsample_list, xyz_n3, new_xyz_n3)
+        if geom["idx_list"] is None:
+            geom["idx_list"] = fused.ball_query_multi(self.radius_list, self.nsample_list, xyz_n3, new_xyz_n3)
+        idx_list = geom["idx_list"]
         out = torch.empty(B, self.out_channel, S, dtype=torch.float32, device=xyz_cn.device)
         feat = points.contiguous() if points is not None else None
         off = 0
@@ -225,9 +232,11 @@ class PointNetFeaturePropagation(_FoldCache, nn.Module):
             self._folded = [fold_conv_bn(c, b, device) for c, b in zip(self.mlp_convs, self.mlp_bns)]
         return self._folded
 
-    def forward(self, xyz1, xyz2, points1, points2, xyz1_n3=None, xyz2_n3=None):
+    def forward(self, xyz1, xyz2, points1, points2, xyz1_n3=None, xyz2_n3=None, nn=None):
         """xyz1 (B,3,N) dense, xyz2 (B,3,S) sparse, points1 (B,D1,N) or None, points2 (B,D2,S)
-        -> (B,D',N)."""
+        -> (B,D',N).  `nn` = (idx, weight) of fused.three_nn_weights on the same coordinates, when
+        another network already computed them; what was used is left in `self.last_nn`."""
+        self.last_nn = None
         B, _, N = xyz1.shape
         S = xyz2.shape[2]
         if not _has_points(points1):
@@ -242,9 +251,11 @@ class PointNetFeaturePropagation(_FoldCache, nn.Module):
             if xyz2_n3 is None:
                 xyz2_n3 = xyz2.transpose(1, 2).contiguous()
             if fuse:
-                new_points = fused.fp_interpolate_concat(xyz1_n3, xyz2_n3,
-                                                         None if points1 is None else points1.contiguous(),
-                                                         points2.contiguous())
+                if nn is None:
+                    nn = fused.three_nn_weights(xyz1_n3, xyz2_n3)
+                self.last_nn = nn
+                new_points = fused.interp_concat(None if points1 is None else points1.contiguous(),
+                                                 points2.contiguous(), nn[0], nn[1])
             else:
                 dist, idx = futils.three_nn(xyz1_n3, xyz2_n3)
                 recip = 1.0 / (dist + 1e-8)

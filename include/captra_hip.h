@@ -152,13 +152,27 @@ int captra_sa_scale_fused(int b, int n, int m, int k, int cfeat, int c1, int c2,
                           const float *b1, const float *w2, const float *b2, const float *w3, const float *b3,
                           float *out, int out_ctotal, int co_off, captra_stream_t stream);
 
-/* Feature propagation input: three_nn + inverse-distance weights + three_interpolate + concat
- * (pointnet_utils.py:280-294, CUDA semantics: weights from sqrt(d2)).
- * unknown (B,N,3), known (B,S,3), feat_known (B,c2,S), skip (B,c1,N) or NULL ->
- * out (B,c1+c2,N) = cat([skip, interpolated]). */
+/* Feature propagation input (pointnet_utils.py:280-294, CUDA semantics: weights from sqrt(d2), SURVEY.md
+ * §2.2), in two halves so that networks looking at the same cloud share the geometric one:
+ *   captra_three_nn_weights: unknown (B,N,3), known (B,S,3) -> idx (B,N,3) i32, weight (B,N,3) f32 with
+ *       w_j = (1/(sqrt(d2_j)+1e-8)) / sum_j(...);
+ *   captra_interp_concat: skip (B,c1,N) or NULL, feat_known (B,c2,S), idx, weight ->
+ *       out (B,c1+c2,N) = cat([skip, sum_j w_j feat_known[:, idx_j]]);
+ *   captra_fp_interpolate_concat: both, with caller-provided scratch idx (B,N,3) / weight (B,N,3). */
+int captra_three_nn_weights(int b, int n, int s, const float *unknown, const float *known, int *idx,
+                            float *weight, captra_stream_t stream);
+int captra_interp_concat(int b, int n, int s, int c1, int c2, const float *skip, const float *feat_known,
+                         const int *idx, const float *weight, float *out, captra_stream_t stream);
 int captra_fp_interpolate_concat(int b, int n, int s, int c1, int c2, const float *unknown,
                                  const float *known, const float *skip, const float *feat_known,
-                                 float *out, captra_stream_t stream);
+                                 int *idx_scratch, float *weight_scratch, float *out, captra_stream_t stream);
+
+/* GroupNorm over groups of `channels_per_group` consecutive channels of x (B,C,N) + optional ReLU
+ * (nn.GroupNorm(C/2, C) + ReLU of the rotation heads, blocks.py:70-71, 148-165): one pass, the
+ * group's values stay in registers between the statistics and the normalisation.
+ * N % 4 == 0 and channels_per_group * N <= 16384. */
+int captra_group_norm_relu(int b, int c, int n, int channels_per_group, float eps, int relu, const float *x,
+                           const float *gamma, const float *beta, float *y, captra_stream_t stream);
 
 /* Masked Procrustes scale + translation fit for all (trajectory, part) pairs on device
  * (part_fit_st_no_ransac pose_fit.py:38-53 -> transform_pts_mask procrustes.py:132-164 with a

@@ -174,6 +174,37 @@ def test_fp_interpolate_concat_bit_exact(device, n, s, c1, c2):
     np.testing.assert_array_equal(got, O.fp_interpolate_concat(unknown, known, skip, fk))
 
 
+@pytest.mark.parametrize("B,C,N,groups,relu", [(2, 512, 4096, 256, True), (3, 256, 4096, 128, True), (2, 8, 100, 4, False),
+                                                (1, 6, 64, 1, True)])
+def test_group_norm_relu_vs_torch(device, B, C, N, groups, relu):
+    from captra_amd import fused
+    rng = np.random.default_rng(C + N)
+    x = _dev((rng.standard_normal((B, C, N)) * 3 + 1).astype(np.float32), device)
+    gamma = _dev(rng.uniform(0.5, 1.5, C).astype(np.float32), device)
+    beta = _dev(rng.normal(0, 0.3, C).astype(np.float32), device)
+    got = fused.group_norm_relu(x, groups, gamma, beta, 1e-5, relu)
+    ref = torch.nn.functional.group_norm(x.double(), groups, gamma.double(), beta.double(), 1e-5)
+    if relu:
+        ref = torch.relu(ref)
+    np.testing.assert_allclose(got.cpu().numpy(), ref.float().cpu().numpy(), atol=2e-6, rtol=2e-6)
+
+
+@pytest.mark.parametrize("tag", ["bottle", "camera"])
+def test_shared_geometry_is_bit_identical(device, tag):
+    """For single-part objects RotationNet reuses CoordNet's FPS / ball-query / 3-NN results: same poses."""
+    trainer, cfg, sd, data = _trainer(tag, device)
+    model = trainer.model.eval()
+    outs = []
+    for share in (True, False):
+        model.share_geometry = share
+        torch.manual_seed(7)
+        trainer.test(data, save=False, no_eval=True)
+        outs.append([{k: v.cpu().numpy() for k, v in p.items()} for p in model.pred_dict["poses"]])
+    for a, b in zip(*outs):
+        for k in a:
+            np.testing.assert_array_equal(a[k], b[k])
+
+
 @pytest.mark.parametrize("sym", [False, True])
 def test_part_fit_st_vs_oracle_and_golden(device, sym):
     from captra_amd.pose_utils.pose_fit import part_fit_st_cn, part_fit_st_no_ransac
