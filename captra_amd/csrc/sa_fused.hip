@@ -48,6 +48,7 @@ struct SaParams {
     const float *w1, *b1, *w2, *b2, *w3, *b3;  // packed: w (ceil32(cin), ceil128(cout)), b (ceil128(cout)), zero padded
     float *out;            // (B,out_ctotal,M)
     int out_ctotal, co_off;
+    int ablate;            // debug/profiling only: bit mask of phases to skip (0 in production)
 };
 
 template <int CTRL>
@@ -70,14 +71,15 @@ __device__ __forceinline__ float row16_maxf(float v) {
 // address arithmetic, one chunk ahead of its use.  No barrier inside: the caller separates layers.
 template <bool LAST, int WN>
 __device__ __forceinline__ void sa_layer(int cin, int cout, const float *__restrict__ wt, const float *__restrict__ bias,
-                                         const float *Hin, float *Hout, float *red, int red_slot, bool col_ok) {
+                                         const float *Hin, float *Hout, float *red, int red_slot, bool col_ok,
+                                         bool ablate_epi = false) {
     constexpr int SF_T = 32 * WN;
     constexpr int SF_SLOTS = SF_POS / 32;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
-    const int npairs = (cin + 31) / 32;
+    const int nsets = (cin + 31) / 32;
     const int ldw = (cout + 127) / 128 * 128;
     const int kp = (cin + 31) / 32 * 32;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)wt, 0, kp * ldw * 4, 0x00020000);
@@ -92,44 +94,38 @@ __device__ __forceinline__ void sa_layer(int cin, int cout, const float *__restr
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = bp[(r & 3) + 8 * (r >> 2)];  // packed bias: in bounds
         }
-        // A fragment of k-step j of chunk c: W^T[c*16 + 2j + (lane>>5)][co0 + wm*32 + (lane&31)]
+        // A fragment of k-step j of set c: W^T[c*32 + 2j + (lane>>5)][co0 + wm*32 + (lane&31)]
         const int voff = (((lane >> 5) * ldw) + co0 + wm * 32 + (lane & 31)) * 4;
-        float a[8], an[8], bv[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) a[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, j * kstep_bytes, 0));
-        // K advances 32 per iteration as two 8-MFMA halves; the two register sets alternate roles (no
-        // rotation copies) and each prefetch is consumed one half (8 MFMAs = 512+ cycles) after it was
-        // issued.  Both halves are unconditional (K is padded to 32 with zero rows on both operands): a
-        // conditional second half would let the compiler sink its prefetch into the branch, next to the
-        // use.  sched_barriers pin the order [prefetch loads][B reads][MFMAs] inside each half.
-        for (int c = 0; c < npairs; ++c) {
-            {
-                const int sn = (2 * c + 1) * 8 * kstep_bytes;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) an[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, sn + j * kstep_bytes, 0));
-                __builtin_amdgcn_sched_barrier(0);
-                const float *xr = xrow + (size_t)(2 * c) * SF_BK * SF_T;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) bv[j] = xr[j * 2 * SF_T];
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], bv[j], acc, 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            {
-                const int sn = (c + 1 < npairs ? 2 * c + 2 : 2 * c + 1) * 8 * kstep_bytes;  // past the end: harmless re-read
-#pragma unroll
-                for (int j = 0; j < 8; ++j) a[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, sn + j * kstep_bytes, 0));
-                __builtin_amdgcn_sched_barrier(0);
-                const float *xr = xrow + (size_t)(2 * c + 1) * SF_BK * SF_T;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) bv[j] = xr[j * 2 * SF_T];
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(an[j], bv[j], acc, 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+        constexpr int KS = 16;  // k-steps per register set (32 K): the prefetch distance is 16 MFMAs = 1024+ cycles
+        float s0[KS], s1[KS], bv[KS];
+        const int set_bytes = KS * kstep_bytes;
+#define SA_LOAD_SET(dst, set_index)                                                                                        \
+    _Pragma("unroll") for (int j = 0; j < KS; ++j) dst[j] = __builtin_bit_cast(                                           \
+        float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, (set_index) * set_bytes + j * kstep_bytes, 0));            \
+    __builtin_amdgcn_sched_barrier(0);
+#define SA_MFMA_SET(src, set_index)                                                                                        \
+    {                                                                                                                      \
+        const float *xr = xrow + (size_t)(set_index) * 32 * SF_T;                                                          \
+        _Pragma("unroll") for (int j = 0; j < KS; ++j) bv[j] = xr[j * 2 * SF_T];                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                                 \
+        _Pragma("unroll") for (int j = 0; j < KS; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(src[j], bv[j], acc, 0, 0, 0); \
+        __builtin_amdgcn_sched_barrier(0);                                                                                 \
+    }
+        // Two register sets alternate; every prefetch is issued one set (16 MFMAs) before its use and
+        // both halves of the loop body are unconditional, so the compiler cannot sink a prefetch into a
+        // branch next to its use.  An odd trailing set was prefetched by the last iteration's second
+        // slot (or by the prologue when there is a single set) and is consumed by the tail.
+        SA_LOAD_SET(s0, 0)
+        for (int c = 0; c + 1 < nsets; c += 2) {
+            SA_LOAD_SET(s1, c + 1)
+            SA_MFMA_SET(s0, c)
+            SA_LOAD_SET(s0, (c + 2 < nsets ? c + 2 : nsets - 1))
+            SA_MFMA_SET(s1, c + 1)
         }
+        if (nsets & 1) SA_MFMA_SET(s0, nsets - 1)
+#undef SA_LOAD_SET
+#undef SA_MFMA_SET
+        if (ablate_epi) continue;
         if (!LAST) {
             float *hp = Hout + (size_t)(co0 + wm * 32 + 4 * (lane >> 5)) * SF_T + wn * 32 + (lane & 31);
 #pragma unroll
@@ -196,6 +192,7 @@ __global__ __launch_bounds__(256 * WN) void sa_fused_kernel(SaParams p) {
             const float *fb = p.feat + (size_t)b * p.cfeat * p.n + id;
             float *xcol = RA + gcol;
             int kg = grow;
+            if (p.ablate & 1) kg = 1 << 30;                 // ablation: no feature gather
             for (; kg + 56 < p.cfeat; kg += 64) {       // 8 independent loads in flight per lane
                 float v[8];
 #pragma unroll
@@ -211,13 +208,13 @@ __global__ __launch_bounds__(256 * WN) void sa_fused_kernel(SaParams p) {
             zero_pad_rows<WN>(RA, cin1);
         }
         __syncthreads();  // X1 complete (and the previous sub-tile's layer 3 is done with region A)
-        sa_layer<false, WN>(cin1, p.c1, p.w1, p.b1, RA, RB, red, 0, true);
+        if (!(p.ablate & 8)) sa_layer<false, WN>(cin1, p.c1, p.w1, p.b1, RA, RB, red, 0, true, p.ablate & 2);
         __syncthreads();  // H1 complete, X1 dead
-        sa_layer<false, WN>(p.c1, p.c2, p.w2, p.b2, RB, RA, red, 0, true);
+        if (!(p.ablate & 16)) sa_layer<false, WN>(p.c1, p.c2, p.w2, p.b2, RB, RA, red, 0, true, p.ablate & 2);
         zero_pad_rows<WN>(RA, p.c2);
         __syncthreads();  // H2 complete
         const bool col_ok = (base + wn * 32 + (lane & 31)) < L;
-        sa_layer<true, WN>(p.c2, p.c3, p.w3, p.b3, RA, nullptr, red, sub * WN, col_ok);
+        if (!(p.ablate & 32)) sa_layer<true, WN>(p.c2, p.c3, p.w3, p.b3, RA, nullptr, red, sub * WN, col_ok, p.ablate & 4);
         __syncthreads();  // region A free for the next gather, red visible
     }
     // combine the 32-position maxima of each group of K positions
@@ -238,7 +235,9 @@ __global__ __launch_bounds__(256 * WN) void sa_fused_kernel(SaParams p) {
 
 // experiment knob (not part of the ABI): force the sub-tile width, 0 = heuristic
 static int g_sa_wn = 0;
+static int g_sa_ablate = 0;
 extern "C" void captra_sa_fused_set_wn(int wn) { g_sa_wn = wn; }
+extern "C" void captra_sa_fused_set_ablate(int mask) { g_sa_ablate = mask; }
 
 // One SA scale, fused (see include/captra_hip.h).
 extern "C" int captra_sa_scale_fused(int b, int n, int m, int k, int cfeat, int c1, int c2, int c3,
@@ -255,7 +254,7 @@ extern "C" int captra_sa_scale_fused(int b, int n, int m, int k, int cfeat, int 
     p.n = n; p.m = m; p.k = k; p.cfeat = cfeat; p.c1 = c1; p.c2 = c2; p.c3 = c3;
     p.feat = feat; p.xyz_cn = xyz_cn; p.new_xyz = new_xyz; p.idx = idx;
     p.w1 = w1; p.b1 = b1; p.w2 = w2; p.b2 = b2; p.w3 = w3; p.b3 = b3;
-    p.out = out; p.out_ctotal = out_ctotal; p.co_off = co_off;
+    p.out = out; p.out_ctotal = out_ctotal; p.co_off = co_off; p.ablate = g_sa_ablate;
     const int cin1 = cfeat + 3;
     const int pa = (cin1 + 31) & ~31, pc2 = (c2 + 31) & ~31, pc1 = (c1 + 31) & ~31;
     const int rows_a = pa > pc2 ? pa : pc2;

@@ -23,10 +23,12 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--layered", action="store_true")
     ap.add_argument("--wn", type=int, default=0)
+    ap.add_argument("--ablate", type=int, default=0, help="debug: phases to skip (1 gather, 2 mid epilogues, 4 last epilogue, 8/16/32 layer 1/2/3)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     import ctypes
     _lib.lib().captra_sa_fused_set_wn(ctypes.c_int(a.wn))
+    _lib.lib().captra_sa_fused_set_ablate(ctypes.c_int(a.ablate))
     B = a.clouds
     names = list(SHAPES) if a.which == "all" else [a.which]
     for name in names:
