@@ -120,6 +120,7 @@ class RotationRegressionBackbone(nn.Module):
         self.sym = cfg["obj_sym"]
         self.pose_pred = RotationRegressor(cfg["network"]["backbone_out_dim"], self.num_parts, symmetric=self.sym)
         self.cfg = cfg
+        self._default = None
 
     def forward(self, cam, cam_labels, cam_n3=None, geom=None):
         """cam (B,3,N), cam_labels (B,N) -> {'rtvec' (B,P,D) masked mean, 'point_rtvec' (B,P,D,N)}."""
@@ -130,8 +131,10 @@ class RotationRegressionBackbone(nn.Module):
         valid = (part_mask.sum(dim=(-1, -2)) > 0).float().unsqueeze(-1)                 # (B,P,1)
         raw = self.pose_pred(feat)                                                     # (B,P,D,N)
         pooled = (raw * part_mask).sum(-1) / torch.clamp_min(part_mask.sum(-1), 1.0)  # (B,P,D)
-        default = torch.tensor((0.0, 1.0, 0.0)) if self.sym else torch.eye(3).reshape(-1)
-        pooled = valid * pooled + (1.0 - valid) * default.to(raw.device).reshape(1, 1, -1)
+        if self._default is None or self._default.device != raw.device:   # built once: no host->device copy per frame
+            d = torch.tensor((0.0, 1.0, 0.0)) if self.sym else torch.eye(3).reshape(-1)
+            self._default = d.to(raw.device).reshape(1, 1, -1)
+        pooled = valid * pooled + (1.0 - valid) * self._default
         return {"rtvec": pooled, "point_rtvec": raw}
 
 

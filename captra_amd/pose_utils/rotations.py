@@ -18,7 +18,8 @@ def normalize_vector(v: torch.Tensor) -> torch.Tensor:
     mag = torch.linalg.vector_norm(v, dim=1)
     ok = (mag > _TINY).to(v.dtype).unsqueeze(1)
     unit = v / torch.clamp_min(mag, _TINY).unsqueeze(1)
-    backup = v.new_tensor([1.0, 0.0, 0.0]).expand_as(v)
+    backup = torch.zeros_like(v)          # (1,0,0) built on device: no host->device copy, hipGraph-capturable
+    backup[:, 0] = 1.0
     return unit * ok + backup * (1.0 - ok)
 
 

@@ -205,6 +205,26 @@ def test_shared_geometry_is_bit_identical(device, tag):
             np.testing.assert_array_equal(a[k], b[k])
 
 
+@pytest.mark.parametrize("tag", ["bottle", "drawers"])
+def test_hipgraph_replay_equals_eager(device, tag):
+    """The captured step replays to exactly the poses of the eager step, frame after frame."""
+    from captra_amd.graph import TrackStepGraph
+    trainer, cfg, sd, data = _trainer(tag, device)
+    model = trainer.model.eval()
+    model.track_cfg["gt_label"] = False
+    model.set_data(data)
+    pose0 = {k: v.clone() for k, v in model.feed_dict[0]["gt_part"].items()}
+    g = TrackStepGraph(model, model.feed_dict[1]["points"], model.feed_dict[1]["points_mean"], pose0)
+    pe, pg = pose0, pose0
+    for i in range(1, len(data)):
+        f, nf = model.feed_dict[i], model.npcs_feed_dict[i]
+        with torch.no_grad():
+            _, pe = model.track_step(f, nf, pe)
+        pg = {k: v.clone() for k, v in g.replay(f["points"], f["points_mean"], pg).items()}
+        for k in pe:
+            np.testing.assert_array_equal(pe[k].cpu().numpy(), pg[k].cpu().numpy(), err_msg=f"frame {i} {k}")
+
+
 @pytest.mark.parametrize("sym", [False, True])
 def test_part_fit_st_vs_oracle_and_golden(device, sym):
     from captra_amd.pose_utils.pose_fit import part_fit_st_cn, part_fit_st_no_ransac
