@@ -307,6 +307,121 @@ int launch_pw(int b, const PwParams &p, hipStream_t s, const char *name) {
     return captra_last_error();
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Direct-operand variant for dense layers (x (B,cin,L) -> y (B,cout,L)): NO LDS and NO barriers.
+// Both MFMA operands are fetched with buffer loads straight into the MFMA source registers, one
+// register set (8 k-steps) ahead of the MFMAs that consume it:
+//   A = packed weights (L1/L2-resident), scalar k offset;
+//   B = activations: lane l reads x[k0 + 2j + (l>>5)][pos + (l&31)] — each half-wave one 128-byte row
+//       segment; rows beyond cin fall outside the buffer's num_records and read as 0 (and meet zero
+//       weight rows anyway), columns beyond L are clamped (computed, never stored).
+// A wave owns a (TM*32) x (TN*32) tile with TM*TN independent accumulators; the four waves of a
+// workgroup (WGM x WGN) share operand rows through L1.  Same k-ascending fmaf chain -> same bits.
+// ---------------------------------------------------------------------------------------------
+template <int TM, int TN, int WGM, int WGN>
+__global__ __launch_bounds__(256) void pw_direct_kernel(PwParams p) {
+    static_assert(WGM * WGN == 4, "4 waves");
+    constexpr int KS = 8;  // k-steps per register set
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int b = blockIdx.z;
+    const int co0 = (blockIdx.y * WGM + wm) * TM * 32;
+    const long long pos0 = ((long long)blockIdx.x * WGN + wn) * TN * 32;
+    if (co0 >= p.cout) return;  // wave-uniform; no barriers in this kernel
+
+    const int kp = (p.cin + 31) / 32 * 32;
+    const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc((void *)p.wt, 0, kp * p.ldw * 4, 0x00020000);
+    const float *xb = p.x + (size_t)b * p.cin * p.L;
+    const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc((void *)xb, 0, (int)((long long)p.cin * p.L * 4), 0x00020000);
+    const int wstep = 2 * p.ldw * 4;          // bytes per k-step in W
+    const int xstep = (int)(2 * p.L * 4);     // bytes per k-step in X
+    int wvoff[TM], xvoff[TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) wvoff[tm] = (((lane >> 5) * p.ldw) + co0 + tm * 32 + (lane & 31)) * 4;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        long long col = pos0 + tn * 32 + (lane & 31);
+        if (col >= p.L) col = p.L - 1;
+        xvoff[tn] = (int)(((long long)(lane >> 5) * p.L + col) * 4);
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+        const float *bp = p.bias + co0 + tm * 32 + 4 * (lane >> 5);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float bv = bp[(r & 3) + 8 * (r >> 2)];
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) acc[tm][tn][r] = bv;
+        }
+    }
+
+    float a0[TM][KS], a1[TM][KS], b0[TN][KS], b1[TN][KS];
+    const int nsets = (p.cin + 2 * KS - 1) / (2 * KS);
+#define PW_LOAD_SET(A, Bv, si)                                                                                           \
+    _Pragma("unroll") for (int j = 0; j < KS; ++j) {                                                                    \
+        _Pragma("unroll") for (int tm = 0; tm < TM; ++tm) A[tm][j] = __builtin_bit_cast(                                 \
+            float, __builtin_amdgcn_raw_buffer_load_b32(wsrc, wvoff[tm], ((si) * KS + j) * wstep, 0));                   \
+        _Pragma("unroll") for (int tn = 0; tn < TN; ++tn) Bv[tn][j] = __builtin_bit_cast(                                \
+            float, __builtin_amdgcn_raw_buffer_load_b32(xsrc, xvoff[tn] + ((si) * KS + j) * xstep, 0, 0));               \
+    }                                                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);
+#define PW_MFMA_SET(A, Bv)                                                                                               \
+    _Pragma("unroll") for (int j = 0; j < KS; ++j)                                                                      \
+        _Pragma("unroll") for (int tm = 0; tm < TM; ++tm)                                                               \
+            _Pragma("unroll") for (int tn = 0; tn < TN; ++tn)                                                           \
+                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[tm][j], Bv[tn][j], acc[tm][tn], 0, 0, 0);           \
+    __builtin_amdgcn_sched_barrier(0);
+    PW_LOAD_SET(a0, b0, 0)
+    for (int c = 0; c + 1 < nsets; c += 2) {
+        PW_LOAD_SET(a1, b1, c + 1)
+        PW_MFMA_SET(a0, b0)
+        PW_LOAD_SET(a0, b0, (c + 2 < nsets ? c + 2 : nsets - 1))
+        PW_MFMA_SET(a1, b1)
+    }
+    if (nsets & 1) { PW_MFMA_SET(a0, b0) }
+#undef PW_LOAD_SET
+#undef PW_MFMA_SET
+
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+        const int row0 = co0 + tm * 32 + 4 * (lane >> 5);
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const long long col = pos0 + tn * 32 + (lane & 31);
+            if (col < p.L) {
+                float *yp = p.y + ((size_t)b * p.cout + row0) * p.L + col;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ro = (r & 3) + 8 * (r >> 2);
+                    if (row0 + ro < p.cout) yp[(size_t)ro * p.L] = apply_act(acc[tm][tn][r], p.act);
+                }
+            }
+        }
+    }
+}
+
+static int g_pw_direct = 1;  // experiment knob: 0 = LDS-staged kernel for dense layers too
+
+int launch_pw_direct(int b, const PwParams &p, hipStream_t s) {
+    if ((long long)p.cin * p.L * 4 >= (1ll << 31)) return -3;  // buffer offsets are 32-bit: fall back
+    if (p.cout > 64) {
+        dim3 grid((unsigned)((p.L + 127) / 128), (p.cout + 127) / 128, b);
+        CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<2, 2, 2, 2>), grid, dim3(256), 0, s, p);
+    } else if (p.cout > 32) {
+        dim3 grid((unsigned)((p.L + 255) / 256), 1, b);
+        CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<2, 2, 1, 4>), grid, dim3(256), 0, s, p);
+    } else {
+        dim3 grid((unsigned)((p.L + 255) / 256), 1, b);
+        CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<1, 2, 1, 4>), grid, dim3(256), 0, s, p);
+    }
+    return captra_last_error();
+}
+
 __global__ void pack_weights_kernel(int cin, int cout, int kp, int cp, const float *__restrict__ wt,
                                     const float *__restrict__ bias, float *__restrict__ wt_packed,
                                     float *__restrict__ bias_packed) {
@@ -319,6 +434,8 @@ __global__ void pack_weights_kernel(int cin, int cout, int kp, int cp, const flo
 }
 
 }  // namespace
+
+extern "C" void captra_pw_set_direct(int on) { g_pw_direct = on; }
 
 extern "C" int captra_pack_weights(int cin, int cout, const float *wt, const float *bias, float *wt_packed,
                                    float *bias_packed, captra_stream_t stream) {
@@ -337,6 +454,10 @@ extern "C" int captra_pointwise_mlp(int b, int cin, int cout, long long l, const
     PwParams p = {};
     p.cin = cin; p.cout = cout; p.ldw = (cout + 127) / 128 * 128; p.L = l; p.x = x; p.wt = wt_packed; p.bias = bias_packed;
     p.y = y; p.act = act;
+    if (g_pw_direct) {
+        const int err = launch_pw_direct(b, p, (hipStream_t)stream);
+        if (err != -3) return err;
+    }
     const bool vec = (l % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
     if (vec) return launch_pw<PRO_PLAIN, EPI_STORE, true>(b, p, (hipStream_t)stream, "pointwise_mlp");
     return launch_pw<PRO_PLAIN, EPI_STORE, false>(b, p, (hipStream_t)stream, "pointwise_mlp");
