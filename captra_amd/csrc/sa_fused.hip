@@ -63,13 +63,21 @@ __device__ __forceinline__ float row16_maxf(float v) {
     return v;
 }
 
-// One layer on one 64-position sub-tile: Hin [cin padded to 32 with ZERO rows][64] in LDS -> Hout / red.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dppf_rm(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
+
+// One layer on one T-position sub-tile: Hin [cin padded with ZERO rows][T] in LDS -> Hout / red.
 //   LAST:  ReLU + max over each 32-position column block into red[row][slot]; otherwise ReLU -> Hout.
-// K runs in steps of 32 (two halves of 8 MFMA k-steps); every step is full because the activation rows
-// beyond cin are zero in LDS and the packed weights are zero there too: the inner loop is branch-free.
-// The A operand (weights) is fetched with buffer loads whose per-k offset is a SCALAR register: no VALU
-// address arithmetic, one chunk ahead of its use.  No barrier inside: the caller separates layers.
-template <bool LAST, int WN>
+//   TM:    output-channel tiles of 128 rows processed at once (TM independent accumulator chains per wave
+//          that share every B read); TM = 2 for layers wider than 128 channels.
+//   KS:    MFMA k-steps per register set (2*KS K rows); 16 normally, 4 for a first layer with cin <= 8
+//          (the xyz-only SA1 input), which would otherwise spend 16 k-steps on 3.
+// Every set is full because the activation rows beyond cin are zero in LDS and the packed weights are
+// zero there too: the inner loop is branch-free.  The A operand (weights) is fetched with buffer loads
+// whose per-k offset is a SCALAR register, one set ahead of its use.  No barrier inside.
+template <bool LAST, int WN, int TM, int KS>
 __device__ __forceinline__ void sa_layer(int cin, int cout, const float *__restrict__ wt, const float *__restrict__ bias,
                                          const float *Hin, float *Hout, float *red, int red_slot, bool col_ok,
                                          bool ablate_epi = false) {
@@ -79,42 +87,51 @@ __device__ __forceinline__ void sa_layer(int cin, int cout, const float *__restr
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
-    const int nsets = (cin + 31) / 32;
+    const int nsets = (cin + 2 * KS - 1) / (2 * KS);
     const int ldw = (cout + 127) / 128 * 128;
     const int kp = (cin + 31) / 32 * 32;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)wt, 0, kp * ldw * 4, 0x00020000);
     const float *xrow = Hin + (lane >> 5) * SF_T + wn * 32 + (lane & 31);
     const int kstep_bytes = 2 * ldw * 4;
+    const int set_bytes = KS * kstep_bytes;
 
-    for (int co0 = 0; co0 < cout; co0 += SF_BM) {
-        if ((co0 + wm * 32) >= cout) continue;  // wave-uniform: this wave's 32 rows are all padding
-        f32x16 acc;
-        {
-            const float *bp = bias + co0 + wm * 32 + 4 * (lane >> 5);
+    for (int co0 = 0; co0 < cout; co0 += TM * SF_BM) {
+        if ((co0 + wm * 32) >= cout) continue;  // wave-uniform: this wave's rows are all padding
+        f32x16 acc[TM];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = bp[(r & 3) + 8 * (r >> 2)];  // packed bias: in bounds
+        for (int tm = 0; tm < TM; ++tm) {
+            const float *bp = bias + co0 + tm * SF_BM + wm * 32 + 4 * (lane >> 5);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tm][r] = bp[(r & 3) + 8 * (r >> 2)];  // packed bias: in bounds (ldw)
         }
-        // A fragment of k-step j of set c: W^T[c*32 + 2j + (lane>>5)][co0 + wm*32 + (lane&31)]
-        const int voff = (((lane >> 5) * ldw) + co0 + wm * 32 + (lane & 31)) * 4;
-        constexpr int KS = 16;  // k-steps per register set (32 K): the prefetch distance is 16 MFMAs = 1024+ cycles
-        float s0[KS], s1[KS], bv[KS];
-        const int set_bytes = KS * kstep_bytes;
+        // A fragment of k-step j of set c, tile tm: W^T[c*2KS + 2j + (lane>>5)][co0 + tm*128 + wm*32 + (lane&31)]
+        int voff[TM];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            int col = co0 + tm * SF_BM + wm * 32 + (lane & 31);
+            if (col >= ldw) col = ldw - 1;  // second tile entirely beyond the padded width: any in-bounds column (result discarded)
+            voff[tm] = (((lane >> 5) * ldw) + col) * 4;
+        }
+        float s0[TM][KS], s1[TM][KS], bv[KS];
 #define SA_LOAD_SET(dst, set_index)                                                                                        \
-    _Pragma("unroll") for (int j = 0; j < KS; ++j) dst[j] = __builtin_bit_cast(                                           \
-        float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, (set_index) * set_bytes + j * kstep_bytes, 0));            \
+    _Pragma("unroll") for (int j = 0; j < KS; ++j)                                                                        \
+        _Pragma("unroll") for (int tm = 0; tm < TM; ++tm) dst[tm][j] = __builtin_bit_cast(                                \
+            float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff[tm], (set_index) * set_bytes + j * kstep_bytes, 0));    \
     __builtin_amdgcn_sched_barrier(0);
 #define SA_MFMA_SET(src, set_index)                                                                                        \
     {                                                                                                                      \
-        const float *xr = xrow + (size_t)(set_index) * 32 * SF_T;                                                          \
+        const float *xr = xrow + (size_t)(set_index) * (2 * KS) * SF_T;                                                    \
         _Pragma("unroll") for (int j = 0; j < KS; ++j) bv[j] = xr[j * 2 * SF_T];                                          \
         __builtin_amdgcn_sched_barrier(0);                                                                                 \
-        _Pragma("unroll") for (int j = 0; j < KS; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(src[j], bv[j], acc, 0, 0, 0); \
+        _Pragma("unroll") for (int j = 0; j < KS; ++j)                                                                    \
+            _Pragma("unroll") for (int tm = 0; tm < TM; ++tm)                                                             \
+                acc[tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(src[tm][j], bv[j], acc[tm], 0, 0, 0);                       \
         __builtin_amdgcn_sched_barrier(0);                                                                                 \
     }
-        // Two register sets alternate; every prefetch is issued one set (16 MFMAs) before its use and
-        // both halves of the loop body are unconditional, so the compiler cannot sink a prefetch into a
-        // branch next to its use.  An odd trailing set was prefetched by the last iteration's second
-        // slot (or by the prologue when there is a single set) and is consumed by the tail.
+        // Two register sets alternate; every prefetch is issued one set before its use and both halves of
+        // the loop body are unconditional, so the compiler cannot sink a prefetch into a branch next to its
+        // use.  An odd trailing set was prefetched by the last iteration's second slot (or by the prologue
+        // when there is a single set) and is consumed by the tail.
         SA_LOAD_SET(s0, 0)
         for (int c = 0; c + 1 < nsets; c += 2) {
             SA_LOAD_SET(s1, c + 1)
@@ -126,24 +143,43 @@ __device__ __forceinline__ void sa_layer(int cin, int cout, const float *__restr
 #undef SA_LOAD_SET
 #undef SA_MFMA_SET
         if (ablate_epi) continue;
-        if (!LAST) {
-            float *hp = Hout + (size_t)(co0 + wm * 32 + 4 * (lane >> 5)) * SF_T + wn * 32 + (lane & 31);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ro = (r & 3) + 8 * (r >> 2);
-                const float v = acc[r] > 0.f ? acc[r] : 0.f;
-                if (co0 + wm * 32 + 4 * (lane >> 5) + ro < cout) hp[(size_t)ro * SF_T] = v;
-            }
-        } else {
+        for (int tm = 0; tm < TM; ++tm) {
+            const int rbase = co0 + tm * SF_BM + wm * 32 + 4 * (lane >> 5);
+            if (!LAST) {
+                float *hp = Hout + (size_t)rbase * SF_T + wn * 32 + (lane & 31);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = (acc[r] > 0.f && col_ok) ? acc[r] : 0.f;
-                v = row16_maxf(v);
-                v = fmaxf(v, __shfl_xor(v, 16, 64));
-                const int row = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if ((lane & 31) == 0 && row < cout) red[row * SF_SLOTS + red_slot + wn] = v;
+                for (int r = 0; r < 16; ++r) {
+                    const int ro = (r & 3) + 8 * (r >> 2);
+                    const float v = acc[tm][r] > 0.f ? acc[tm][r] : 0.f;
+                    if (rbase + ro < cout) hp[(size_t)ro * SF_T] = v;
+                }
+            } else {
+                // max over the 32 positions of this MFMA tile: 4 DPP steps inside each row of 16 lanes, then
+                // row_bcast15 folds row 0 into row 1 and row 2 into row 3 (no LDS permute); lanes 16 / 48 write
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = (acc[tm][r] > 0.f && col_ok) ? acc[tm][r] : 0.f;
+                    v = row16_maxf(v);
+                    v = fmaxf(v, dppf_rm<0x142, 0xA>(v));
+                    const int row = rbase + (r & 3) + 8 * (r >> 2);
+                    if ((lane & 31) == 16 && row < cout) red[row * SF_SLOTS + red_slot + wn] = v;
+                }
             }
         }
+    }
+}
+
+// dispatch on the layer's shape: wide layers run two output tiles at once, a tiny first layer uses short sets
+template <bool LAST, int WN>
+__device__ __forceinline__ void sa_layer_any(int cin, int cout, const float *wt, const float *bias, const float *Hin,
+                                             float *Hout, float *red, int red_slot, bool col_ok, bool ablate_epi) {
+    if (cin <= 8) {
+        sa_layer<LAST, WN, 1, 4>(cin, cout, wt, bias, Hin, Hout, red, red_slot, col_ok, ablate_epi);
+    } else if (cout > SF_BM) {
+        sa_layer<LAST, WN, 2, 8>(cin, cout, wt, bias, Hin, Hout, red, red_slot, col_ok, ablate_epi);
+    } else {
+        sa_layer<LAST, WN, 1, 16>(cin, cout, wt, bias, Hin, Hout, red, red_slot, col_ok, ablate_epi);
     }
 }
 
@@ -158,7 +194,7 @@ __device__ __forceinline__ void zero_pad_rows(float *buf, int c) {
 }
 
 template <int WN>
-__global__ __launch_bounds__(256 * WN) void sa_fused_kernel(SaParams p) {
+__global__ __launch_bounds__(256 * WN) __attribute__((amdgpu_waves_per_eu(4, 8))) void sa_fused_kernel(SaParams p) {
     constexpr int SF_T = 32 * WN;
     constexpr int SF_THREADS = 256 * WN;
     constexpr int SF_SUBS = SF_POS / SF_T;
@@ -208,13 +244,13 @@ __global__ __launch_bounds__(256 * WN) void sa_fused_kernel(SaParams p) {
             zero_pad_rows<WN>(RA, cin1);
         }
         __syncthreads();  // X1 complete (and the previous sub-tile's layer 3 is done with region A)
-        if (!(p.ablate & 8)) sa_layer<false, WN>(cin1, p.c1, p.w1, p.b1, RA, RB, red, 0, true, p.ablate & 2);
+        if (!(p.ablate & 8)) sa_layer_any<false, WN>(cin1, p.c1, p.w1, p.b1, RA, RB, red, 0, true, p.ablate & 2);
         __syncthreads();  // H1 complete, X1 dead
-        if (!(p.ablate & 16)) sa_layer<false, WN>(p.c1, p.c2, p.w2, p.b2, RB, RA, red, 0, true, p.ablate & 2);
+        if (!(p.ablate & 16)) sa_layer_any<false, WN>(p.c1, p.c2, p.w2, p.b2, RB, RA, red, 0, true, p.ablate & 2);
         zero_pad_rows<WN>(RA, p.c2);
         __syncthreads();  // H2 complete
         const bool col_ok = (base + wn * 32 + (lane & 31)) < L;
-        if (!(p.ablate & 32)) sa_layer<true, WN>(p.c2, p.c3, p.w3, p.b3, RA, nullptr, red, sub * WN, col_ok, p.ablate & 4);
+        if (!(p.ablate & 32)) sa_layer_any<true, WN>(p.c2, p.c3, p.w3, p.b3, RA, nullptr, red, sub * WN, col_ok, p.ablate & 4);
         __syncthreads();  // region A free for the next gather, red visible
     }
     // combine the 32-position maxima of each group of K positions

@@ -1,0 +1,24 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): kernel trace + PMC passes of the bench workload.
+#   tools/profile_round.sh <tag>      -> gpurun_out/<tag>_{trace,fetch,write,sq}/…  + text summaries
+set -u
+TAG=${1:-r01}
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out
+mkdir -p $OUT
+export TMPDIR=/tmp
+BENCH="python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timing"
+BENCH_EAGER="python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-graph"
+cd /tmp
+# 1. kernel trace + stats of the bench command (hipGraph replay path)
+rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_trace -o bench -- $BENCH > $OUT/${TAG}_trace.log 2>&1
+DB=$(ls $OUT/${TAG}_trace/*.db 2>/dev/null | head -1)
+[ -n "$DB" ] && python $ROOT/tools/rocpd_summary.py $DB --step-trace 1 > $OUT/${TAG}_bench_kernel_trace_stats.txt 2>&1
+# 2. PMC passes (separate runs, counters only; eager launches so every dispatch is a kernel node the tool sees)
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_fetch -o p -- $BENCH_EAGER > $OUT/${TAG}_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_write -o p -- $BENCH_EAGER > $OUT/${TAG}_write.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_INSTS_MFMA \
+    --kernel-trace --output-format csv -d $OUT/${TAG}_sq -o p -- $BENCH_EAGER > $OUT/${TAG}_sq.log 2>&1
+cd $ROOT
+python tools/pmc_summary.py $OUT/${TAG}_fetch $OUT/${TAG}_write $OUT/${TAG}_sq > $OUT/${TAG}_bench_pmc_summary.txt 2>&1
+echo done
