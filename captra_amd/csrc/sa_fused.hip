@@ -49,6 +49,7 @@ struct SaParams {
     float *out;            // (B,out_ctotal,M)
     int out_ctotal, co_off;
     int ablate;            // debug/profiling only: bit mask of phases to skip (0 in production)
+    unsigned long long *prof;  // debug/profiling only: per-phase wave-cycle totals (PROF kernels), else null
 };
 
 template <int CTRL>
@@ -68,25 +69,65 @@ __device__ __forceinline__ float dppf_rm(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
 }
 
+// Issue the loads of a layer's FIRST register set (16 values per lane) -- called one phase ahead of the
+// layer that consumes it (before the previous layer's epilogue and the barrier), so the L2 latency of a
+// layer's first weights is never exposed.  Layout of pre[] (must match sa_layer): cout <= 128: k-steps
+// 0..15 of the wave's 32-column tile; cout > 128: k-steps 0..7 of tile 0 then of tile 1 (+128 columns).
+template <int WN>
+__device__ __forceinline__ void sa_prefetch_first(float (&pre)[16], const float *__restrict__ wt, int cin, int cout) {
+    const int lane = threadIdx.x & 63;
+    const int wm = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) / WN;
+    if (wm * 32 >= cout) return;  // wave-uniform: this wave sits the layer out
+    const int ldw = (cout + 127) / 128 * 128;
+    const int kp = (cin + 31) / 32 * 32;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)wt, 0, kp * ldw * 4, 0x00020000);
+    const int kstep_bytes = 2 * ldw * 4;
+    if (cout > SF_BM) {
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm) {
+            int col = tm * SF_BM + wm * 32 + (lane & 31);
+            if (col >= ldw) col = ldw - 1;
+            const int voff = (((lane >> 5) * ldw) + col) * 4;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                pre[tm * 8 + j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, j * kstep_bytes, 0));
+        }
+    } else {
+        const int voff = (((lane >> 5) * ldw) + wm * 32 + (lane & 31)) * 4;
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            pre[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, j * kstep_bytes, 0));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 // One layer on one T-position sub-tile: Hin [cin padded with ZERO rows][T] in LDS -> Hout / red.
 //   LAST:  ReLU + max over each 32-position column block into red[row][slot]; otherwise ReLU -> Hout.
-//   TM:    output-channel tiles of 128 rows processed at once (TM independent accumulator chains per wave
-//          that share every B read); TM = 2 for layers wider than 128 channels.
-//   KS:    MFMA k-steps per register set (2*KS K rows); 16 normally, 4 for a first layer with cin <= 8
-//          (the xyz-only SA1 input), which would otherwise spend 16 k-steps on 3.
+//   TM:    output-channel tiles of 128 rows computed at once (TM independent accumulator chains per wave
+//          that share every B read); TM = 2 for layers wider than 128 channels (SF_MAXC = 256 = 2 tiles,
+//          so a layer is always ONE pass).  A register set is 16 values: 16 k-steps (TM 1) or 8 x 2 tiles.
+//   SMALL: cin <= 8 (the xyz-only SA1 input): only the first 4 k-steps of the single set are executed.
 // Every set is full because the activation rows beyond cin are zero in LDS and the packed weights are
 // zero there too: the inner loop is branch-free.  The A operand (weights) is fetched with buffer loads
-// whose per-k offset is a SCALAR register, one set ahead of its use.  No barrier inside.
-template <bool LAST, int WN, int TM, int KS>
-__device__ __forceinline__ void sa_layer(int cin, int cout, const float *__restrict__ wt, const float *__restrict__ bias,
+// whose per-k offset is a SCALAR register, one set ahead of its use; the first set arrives in pre[]
+// (sa_prefetch_first, issued a phase earlier) and the NEXT layer's first set is requested into pre[]
+// as soon as this layer's last MFMA is issued.  The bias comes from LDS.  No barrier inside.
+template <bool LAST, int WN, int TM, bool SMALL>
+__device__ __forceinline__ void sa_layer(int cin, int cout, const float *__restrict__ wt, const float *bias_lds,
                                          const float *Hin, float *Hout, float *red, int red_slot, bool col_ok,
-                                         bool ablate_epi = false) {
+                                         float (&pre)[16], const float *__restrict__ next_wt, int next_cin, int next_cout,
+                                         bool ablate_epi) {
     constexpr int SF_T = 32 * WN;
     constexpr int SF_SLOTS = SF_POS / 32;
+    constexpr int KS = 16 / TM;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
+    if (wm * 32 >= cout) {  // wave-uniform: this wave's rows are all padding; it still feeds the pipeline
+        sa_prefetch_first<WN>(pre, next_wt, next_cin, next_cout);
+        return;
+    }
     const int nsets = (cin + 2 * KS - 1) / (2 * KS);
     const int ldw = (cout + 127) / 128 * 128;
     const int kp = (cin + 31) / 32 * 32;
@@ -95,91 +136,100 @@ __device__ __forceinline__ void sa_layer(int cin, int cout, const float *__restr
     const int kstep_bytes = 2 * ldw * 4;
     const int set_bytes = KS * kstep_bytes;
 
-    for (int co0 = 0; co0 < cout; co0 += TM * SF_BM) {
-        if ((co0 + wm * 32) >= cout) continue;  // wave-uniform: this wave's rows are all padding
-        f32x16 acc[TM];
+    f32x16 acc[TM];
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-            const float *bp = bias + co0 + tm * SF_BM + wm * 32 + 4 * (lane >> 5);
+    for (int tm = 0; tm < TM; ++tm) {
+        const float4 *bp = reinterpret_cast<const float4 *>(bias_lds + tm * SF_BM + wm * 32 + 4 * (lane >> 5));
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[tm][r] = bp[(r & 3) + 8 * (r >> 2)];  // packed bias: in bounds (ldw)
+        for (int q = 0; q < 4; ++q) {  // accumulator register 4q+i holds row 8q + i (+4 for the upper half-wave)
+            const float4 b4 = bp[2 * q];
+            acc[tm][4 * q + 0] = b4.x; acc[tm][4 * q + 1] = b4.y; acc[tm][4 * q + 2] = b4.z; acc[tm][4 * q + 3] = b4.w;
         }
-        // A fragment of k-step j of set c, tile tm: W^T[c*2KS + 2j + (lane>>5)][co0 + tm*128 + wm*32 + (lane&31)]
-        int voff[TM];
+    }
+    // A fragment of k-step j of set c, tile tm: W^T[c*2KS + 2j + (lane>>5)][tm*128 + wm*32 + (lane&31)]
+    int voff[TM];
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-            int col = co0 + tm * SF_BM + wm * 32 + (lane & 31);
-            if (col >= ldw) col = ldw - 1;  // second tile entirely beyond the padded width: any in-bounds column (result discarded)
-            voff[tm] = (((lane >> 5) * ldw) + col) * 4;
-        }
-        float s0[TM][KS], s1[TM][KS], bv[KS];
+    for (int tm = 0; tm < TM; ++tm) {
+        int col = tm * SF_BM + wm * 32 + (lane & 31);
+        if (col >= ldw) col = ldw - 1;  // (unreachable for TM = 2: ldw = 256) keep every address in bounds
+        voff[tm] = (((lane >> 5) * ldw) + col) * 4;
+    }
+    float s0[TM][KS], s1[TM][KS], bv[KS];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int j = 0; j < KS; ++j) s0[tm][j] = pre[tm * KS + j];
 #define SA_LOAD_SET(dst, set_index)                                                                                        \
     _Pragma("unroll") for (int j = 0; j < KS; ++j)                                                                        \
         _Pragma("unroll") for (int tm = 0; tm < TM; ++tm) dst[tm][j] = __builtin_bit_cast(                                \
             float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff[tm], (set_index) * set_bytes + j * kstep_bytes, 0));    \
     __builtin_amdgcn_sched_barrier(0);
-#define SA_MFMA_SET(src, set_index)                                                                                        \
+#define SA_MFMA_SET(src, set_index, NSTEP)                                                                                 \
     {                                                                                                                      \
         const float *xr = xrow + (size_t)(set_index) * (2 * KS) * SF_T;                                                    \
-        _Pragma("unroll") for (int j = 0; j < KS; ++j) bv[j] = xr[j * 2 * SF_T];                                          \
+        _Pragma("unroll") for (int j = 0; j < NSTEP; ++j) bv[j] = xr[j * 2 * SF_T];                                       \
         __builtin_amdgcn_sched_barrier(0);                                                                                 \
-        _Pragma("unroll") for (int j = 0; j < KS; ++j)                                                                    \
+        _Pragma("unroll") for (int j = 0; j < NSTEP; ++j)                                                                 \
             _Pragma("unroll") for (int tm = 0; tm < TM; ++tm)                                                             \
                 acc[tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(src[tm][j], bv[j], acc[tm], 0, 0, 0);                       \
         __builtin_amdgcn_sched_barrier(0);                                                                                 \
     }
+    if (SMALL) {
+        SA_MFMA_SET(s0, 0, 4)
+    } else {
         // Two register sets alternate; every prefetch is issued one set before its use and both halves of
         // the loop body are unconditional, so the compiler cannot sink a prefetch into a branch next to its
-        // use.  An odd trailing set was prefetched by the last iteration's second slot (or by the prologue
+        // use.  An odd trailing set was prefetched by the last iteration's second slot (or arrived in pre[]
         // when there is a single set) and is consumed by the tail.
-        SA_LOAD_SET(s0, 0)
         for (int c = 0; c + 1 < nsets; c += 2) {
             SA_LOAD_SET(s1, c + 1)
-            SA_MFMA_SET(s0, c)
+            SA_MFMA_SET(s0, c, KS)
             SA_LOAD_SET(s0, (c + 2 < nsets ? c + 2 : nsets - 1))
-            SA_MFMA_SET(s1, c + 1)
+            SA_MFMA_SET(s1, c + 1, KS)
         }
-        if (nsets & 1) SA_MFMA_SET(s0, nsets - 1)
+        if (nsets & 1) SA_MFMA_SET(s0, nsets - 1, KS)
+    }
 #undef SA_LOAD_SET
 #undef SA_MFMA_SET
-        if (ablate_epi) continue;
+    sa_prefetch_first<WN>(pre, next_wt, next_cin, next_cout);
+    if (ablate_epi) return;
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-            const int rbase = co0 + tm * SF_BM + wm * 32 + 4 * (lane >> 5);
-            if (!LAST) {
-                float *hp = Hout + (size_t)rbase * SF_T + wn * 32 + (lane & 31);
+    for (int tm = 0; tm < TM; ++tm) {
+        const int rbase = tm * SF_BM + wm * 32 + 4 * (lane >> 5);
+        if (!LAST) {
+            float *hp = Hout + (size_t)rbase * SF_T + wn * 32 + (lane & 31);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int ro = (r & 3) + 8 * (r >> 2);
-                    const float v = acc[tm][r] > 0.f ? acc[tm][r] : 0.f;
-                    if (rbase + ro < cout) hp[(size_t)ro * SF_T] = v;
-                }
-            } else {
-                // max over the 32 positions of this MFMA tile: 4 DPP steps inside each row of 16 lanes, then
-                // row_bcast15 folds row 0 into row 1 and row 2 into row 3 (no LDS permute); lanes 16 / 48 write
+            for (int r = 0; r < 16; ++r) {
+                const int ro = (r & 3) + 8 * (r >> 2);
+                const float v = acc[tm][r] > 0.f ? acc[tm][r] : 0.f;
+                if (rbase + ro < cout) hp[(size_t)ro * SF_T] = v;
+            }
+        } else {
+            // max over the 32 positions of this MFMA tile: 4 DPP steps inside each row of 16 lanes, then
+            // row_bcast15 folds row 0 into row 1 and row 2 into row 3 (no LDS permute); lanes 16 / 48 write
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float v = (acc[tm][r] > 0.f && col_ok) ? acc[tm][r] : 0.f;
-                    v = row16_maxf(v);
-                    v = fmaxf(v, dppf_rm<0x142, 0xA>(v));
-                    const int row = rbase + (r & 3) + 8 * (r >> 2);
-                    if ((lane & 31) == 16 && row < cout) red[row * SF_SLOTS + red_slot + wn] = v;
-                }
+            for (int r = 0; r < 16; ++r) {
+                float v = (acc[tm][r] > 0.f && col_ok) ? acc[tm][r] : 0.f;
+                v = row16_maxf(v);
+                v = fmaxf(v, dppf_rm<0x142, 0xA>(v));
+                const int row = rbase + (r & 3) + 8 * (r >> 2);
+                if ((lane & 31) == 16 && row < cout) red[row * SF_SLOTS + red_slot + wn] = v;
             }
         }
     }
 }
 
-// dispatch on the layer's shape: wide layers run two output tiles at once, a tiny first layer uses short sets
+// dispatch on the layer's shape: wide layers run two output tiles at once, a tiny first layer runs 4 k-steps
 template <bool LAST, int WN>
-__device__ __forceinline__ void sa_layer_any(int cin, int cout, const float *wt, const float *bias, const float *Hin,
-                                             float *Hout, float *red, int red_slot, bool col_ok, bool ablate_epi) {
-    if (cin <= 8) {
-        sa_layer<LAST, WN, 1, 4>(cin, cout, wt, bias, Hin, Hout, red, red_slot, col_ok, ablate_epi);
-    } else if (cout > SF_BM) {
-        sa_layer<LAST, WN, 2, 8>(cin, cout, wt, bias, Hin, Hout, red, red_slot, col_ok, ablate_epi);
+__device__ __forceinline__ void sa_layer_any(int cin, int cout, const float *wt, const float *bias_lds, const float *Hin,
+                                             float *Hout, float *red, int red_slot, bool col_ok, float (&pre)[16],
+                                             const float *next_wt, int next_cin, int next_cout, bool ablate_epi) {
+    if (cout > SF_BM) {
+        sa_layer<LAST, WN, 2, false>(cin, cout, wt, bias_lds, Hin, Hout, red, red_slot, col_ok, pre, next_wt, next_cin, next_cout, ablate_epi);
+    } else if (cin <= 8) {
+        sa_layer<LAST, WN, 1, true>(cin, cout, wt, bias_lds, Hin, Hout, red, red_slot, col_ok, pre, next_wt, next_cin, next_cout, ablate_epi);
     } else {
-        sa_layer<LAST, WN, 1, 16>(cin, cout, wt, bias, Hin, Hout, red, red_slot, col_ok, ablate_epi);
+        sa_layer<LAST, WN, 1, false>(cin, cout, wt, bias_lds, Hin, Hout, red, red_slot, col_ok, pre, next_wt, next_cin, next_cout, ablate_epi);
     }
 }
 
@@ -193,7 +243,15 @@ __device__ __forceinline__ void zero_pad_rows(float *buf, int c) {
     for (int e = threadIdx.x; e < n; e += 256 * WN) buf[(size_t)c * SF_T + e] = 0.f;
 }
 
-template <int WN>
+// PROF: every wave accumulates s_memtime deltas per phase (gather, barrier, layer 1, barrier, layer 2, barrier,
+// layer 3, barrier; slot 8 = whole kernel, slot 9 = waves) into p.prof -- a measurement build of the same code.
+#define SA_TICK(slot)                                                     \
+    if (PROF) {                                                           \
+        const unsigned long long t_now = __builtin_amdgcn_s_memtime();    \
+        t_acc[slot] += t_now - t_last;                                    \
+        t_last = t_now;                                                   \
+    }
+template <int WN, bool PROF>
 __global__ __launch_bounds__(256 * WN) __attribute__((amdgpu_waves_per_eu(4, 8))) void sa_fused_kernel(SaParams p) {
     constexpr int SF_T = 32 * WN;
     constexpr int SF_THREADS = 256 * WN;
@@ -203,7 +261,8 @@ __global__ __launch_bounds__(256 * WN) __attribute__((amdgpu_waves_per_eu(4, 8))
     const int cin1 = p.cfeat + 3;
     const int rows_a = max(pad32(cin1), pad32(p.c2));  // region A: X1, later H2
     float *red = lds;                               // [256][4]
-    float *RA = red + SF_MAXC * SF_SLOTS;           // [rows_a][T]
+    float *bias_lds = red + SF_MAXC * SF_SLOTS;     // [3][256]: the three packed bias vectors
+    float *RA = bias_lds + 3 * SF_MAXC;             // [rows_a][T]
     float *RB = RA + (size_t)rows_a * SF_T;         // H1 [pad32(c1)][64]
 
     const int b = blockIdx.y;
@@ -215,10 +274,22 @@ __global__ __launch_bounds__(256 * WN) __attribute__((amdgpu_waves_per_eu(4, 8))
     const int gcol = tid % SF_T;   // gather: this thread's position within the sub-tile
     const int grow = tid / SF_T;   // ... and its first row (8 row groups)
 
+    unsigned long long t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long t_last = PROF ? __builtin_amdgcn_s_memtime() : 0ull;
+    const unsigned long long t_begin = t_last;
+    float pre[16];  // the next layer's first weight set, in flight across epilogues / barriers / the gather
+    sa_prefetch_first<WN>(pre, p.w1, cin1, p.c1);
+    for (int e = tid; e < 3 * SF_MAXC; e += SF_THREADS) {
+        const int l = e / SF_MAXC, c = e % SF_MAXC;
+        const int cl = l == 0 ? p.c1 : (l == 1 ? p.c2 : p.c3);
+        const float *bl = l == 0 ? p.b1 : (l == 1 ? p.b2 : p.b3);
+        bias_lds[e] = c < ((cl + 127) / 128 * 128) ? bl[c] : 0.f;
+    }
     zero_pad_rows<WN>(RB, p.c1);  // H1's pad rows stay zero for the whole kernel (layers write rows < c1 only)
 
     for (int sub = 0; sub < SF_SUBS; ++sub) {
         const long long base = pos0 + (long long)sub * SF_T;
+        if (PROF) t_last = __builtin_amdgcn_s_memtime();
         // ---- gather X1 = [feat rows | xyz rows - centre] for the 64 positions of this sub-tile --------
         {
             long long pos = base + gcol;
@@ -243,15 +314,23 @@ __global__ __launch_bounds__(256 * WN) __attribute__((amdgpu_waves_per_eu(4, 8))
             }
             zero_pad_rows<WN>(RA, cin1);
         }
+        SA_TICK(0)
         __syncthreads();  // X1 complete (and the previous sub-tile's layer 3 is done with region A)
-        if (!(p.ablate & 8)) sa_layer_any<false, WN>(cin1, p.c1, p.w1, p.b1, RA, RB, red, 0, true, p.ablate & 2);
+        SA_TICK(1)
+        if (!(p.ablate & 8)) sa_layer_any<false, WN>(cin1, p.c1, p.w1, bias_lds, RA, RB, red, 0, true, pre, p.w2, p.c1, p.c2, p.ablate & 2);
+        SA_TICK(2)
         __syncthreads();  // H1 complete, X1 dead
-        if (!(p.ablate & 16)) sa_layer_any<false, WN>(p.c1, p.c2, p.w2, p.b2, RB, RA, red, 0, true, p.ablate & 2);
+        SA_TICK(3)
+        if (!(p.ablate & 16)) sa_layer_any<false, WN>(p.c1, p.c2, p.w2, bias_lds + SF_MAXC, RB, RA, red, 0, true, pre, p.w3, p.c2, p.c3, p.ablate & 2);
         zero_pad_rows<WN>(RA, p.c2);
+        SA_TICK(4)
         __syncthreads();  // H2 complete
+        SA_TICK(5)
         const bool col_ok = (base + wn * 32 + (lane & 31)) < L;
-        if (!(p.ablate & 32)) sa_layer_any<true, WN>(p.c2, p.c3, p.w3, p.b3, RA, nullptr, red, sub * WN, col_ok, p.ablate & 4);
+        if (!(p.ablate & 32)) sa_layer_any<true, WN>(p.c2, p.c3, p.w3, bias_lds + 2 * SF_MAXC, RA, nullptr, red, sub * WN, col_ok, pre, p.w1, cin1, p.c1, p.ablate & 4);
+        SA_TICK(6)
         __syncthreads();  // region A free for the next gather, red visible
+        SA_TICK(7)
     }
     // combine the 32-position maxima of each group of K positions
     const int tiles_per_group = p.k / 32;
@@ -265,7 +344,13 @@ __global__ __launch_bounds__(256 * WN) __attribute__((amdgpu_waves_per_eu(4, 8))
             p.out[((size_t)b * p.out_ctotal + p.co_off + row) * p.m + centre] = v;
         }
     }
+    if (PROF && p.prof != nullptr && lane == 0 && (blockIdx.x + blockIdx.y) % 61 == 0) {  // a sample of the blocks
+        for (int i = 0; i < 8; ++i) atomicAdd(p.prof + i, t_acc[i]);
+        atomicAdd(p.prof + 8, __builtin_amdgcn_s_memtime() - t_begin);
+        atomicAdd(p.prof + 9, 1ull);
+    }
 }
+#undef SA_TICK
 
 }  // namespace
 
@@ -274,6 +359,8 @@ static int g_sa_wn = 0;
 static int g_sa_ablate = 0;
 extern "C" void captra_sa_fused_set_wn(int wn) { g_sa_wn = wn; }
 extern "C" void captra_sa_fused_set_ablate(int mask) { g_sa_ablate = mask; }
+static unsigned long long *g_sa_prof = nullptr;  // device buffer of 10 counters; non-null selects the PROF kernels
+extern "C" void captra_sa_fused_set_prof(unsigned long long *dev_counters) { g_sa_prof = dev_counters; }
 
 // One SA scale, fused (see include/captra_hip.h).
 extern "C" int captra_sa_scale_fused(int b, int n, int m, int k, int cfeat, int c1, int c2, int c3,
@@ -290,7 +377,7 @@ extern "C" int captra_sa_scale_fused(int b, int n, int m, int k, int cfeat, int 
     p.n = n; p.m = m; p.k = k; p.cfeat = cfeat; p.c1 = c1; p.c2 = c2; p.c3 = c3;
     p.feat = feat; p.xyz_cn = xyz_cn; p.new_xyz = new_xyz; p.idx = idx;
     p.w1 = w1; p.b1 = b1; p.w2 = w2; p.b2 = b2; p.w3 = w3; p.b3 = b3;
-    p.out = out; p.out_ctotal = out_ctotal; p.co_off = co_off; p.ablate = g_sa_ablate;
+    p.out = out; p.out_ctotal = out_ctotal; p.co_off = co_off; p.ablate = g_sa_ablate; p.prof = g_sa_prof;
     const int cin1 = cfeat + 3;
     const int pa = (cin1 + 31) & ~31, pc2 = (c2 + 31) & ~31, pc1 = (c1 + 31) & ~31;
     const int rows_a = pa > pc2 ? pa : pc2;
@@ -298,21 +385,29 @@ extern "C" int captra_sa_scale_fused(int b, int n, int m, int k, int cfeat, int 
     dim3 grid((unsigned)((L + SF_POS - 1) / SF_POS), b);
     // sub-tile width: 64 positions (8 waves) when two such workgroups still fit in a CU's LDS, else 32
     // positions (4 waves): independent workgroups on a CU are what hides the gather / first-load latency
-    const size_t lds64 = ((size_t)SF_MAXC * (SF_POS / 32) + (size_t)(rows_a + pc1) * 64) * sizeof(float);
-    const size_t lds32 = ((size_t)SF_MAXC * (SF_POS / 32) + (size_t)(rows_a + pc1) * 32) * sizeof(float);
+    const size_t lds64 = ((size_t)SF_MAXC * (SF_POS / 32) + 3 * SF_MAXC + (size_t)(rows_a + pc1) * 64) * sizeof(float);
+    const size_t lds32 = ((size_t)SF_MAXC * (SF_POS / 32) + 3 * SF_MAXC + (size_t)(rows_a + pc1) * 32) * sizeof(float);
     int wn = (2 * lds64 <= 160 * 1024) ? 2 : 1;
     if (g_sa_wn == 1 || g_sa_wn == 2) wn = g_sa_wn;
     if ((wn == 2 ? lds64 : lds32) > 160 * 1024) return -2;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(sa_fused_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void *>(sa_fused_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(sa_fused_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(sa_fused_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(sa_fused_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(sa_fused_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    if (wn == 2) {
-        CAPTRA_LAUNCH("sa_scale_fused", sa_fused_kernel<2>, grid, dim3(512), lds64, (hipStream_t)stream, p);
+    if (p.prof != nullptr) {
+        if (wn == 2) {
+            CAPTRA_LAUNCH("sa_scale_fused", (sa_fused_kernel<2, true>), grid, dim3(512), lds64, (hipStream_t)stream, p);
+        } else {
+            CAPTRA_LAUNCH("sa_scale_fused", (sa_fused_kernel<1, true>), grid, dim3(256), lds32, (hipStream_t)stream, p);
+        }
+    } else if (wn == 2) {
+        CAPTRA_LAUNCH("sa_scale_fused", (sa_fused_kernel<2, false>), grid, dim3(512), lds64, (hipStream_t)stream, p);
     } else {
-        CAPTRA_LAUNCH("sa_scale_fused", sa_fused_kernel<1>, grid, dim3(256), lds32, (hipStream_t)stream, p);
+        CAPTRA_LAUNCH("sa_scale_fused", (sa_fused_kernel<1, false>), grid, dim3(256), lds32, (hipStream_t)stream, p);
     }
     return captra_last_error();
 }

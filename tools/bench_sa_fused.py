@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--layered", action="store_true")
     ap.add_argument("--wn", type=int, default=0)
+    ap.add_argument("--phases", action="store_true", help="debug: in-kernel s_memtime phase breakdown (PROF kernels)")
     ap.add_argument("--ablate", type=int, default=0, help="debug: phases to skip (1 gather, 2 mid epilogues, 4 last epilogue, 8/16/32 layer 1/2/3)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -53,6 +54,18 @@ def main():
         for _ in range(2):
             run()
         torch.cuda.synchronize()
+        if a.phases and not a.layered:
+            cnt = torch.zeros(10, dtype=torch.int64, device=dev)
+            _lib.lib().captra_sa_fused_set_prof(ctypes.c_void_p(cnt.data_ptr()))
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); run(); e1.record()
+            torch.cuda.synchronize()
+            print(f"  PROF kernel took {e0.elapsed_time(e1) * 1e3:.1f} us")
+            _lib.lib().captra_sa_fused_set_prof(ctypes.c_void_p(0))
+            c = cnt.tolist()
+            waves = max(c[9], 1)
+            labels = ["gather", "bar", "L1", "bar", "L2", "bar", "L3", "bar"]
+            print(f"  {name}: per-wave cycles, kernel {c[8] / waves:.0f}: " + "  ".join(f"{l} {c[i] / waves:.0f}" for i, l in enumerate(labels)))
         _lib.prof_reset(); _lib.prof_enable(True)
         for _ in range(a.iters):
             run()
