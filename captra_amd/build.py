@@ -32,6 +32,9 @@ HIPCC_FLAGS = [
     "-std=c++17",
     "-fPIC",
     "-ffp-contract=off",
+    # sa_fused.hip's register-resident kernels are fully unrolled by design (activations are statically indexed
+    # registers): lift LLVM's cap on "#pragma unroll" bodies, else the widest shape falls back to scratch arrays
+    "-mllvm", "-pragma-unroll-threshold=200000",
     "-fno-fast-math",
     "-Wall",
     "-Wno-unused-function",

@@ -352,6 +352,292 @@ __global__ __launch_bounds__(256 * WN) __attribute__((amdgpu_waves_per_eu(4, 8))
 }
 #undef SA_TICK
 
+// =====================================================================================================
+// Register-resident variant: sa_wave_kernel<CF, C1, C2, C3>  (channel counts are template constants)
+//
+// Each WAVE owns 32 positions (one 32-neighbour slice of one centre) and carries them through all three
+// layers by itself.  The MFMA accumulator layout (register r of lane l = row 8(r>>2)+(r&3)+4(l>>5),
+// column l&31) becomes the next layer's B operand (lane-half h of k-step j = row 2j+h) with ONE
+// v_permlane32_swap per register pair, so the activations H1, H2 never leave the vector registers:
+// no LDS traffic for activations, no workgroup barrier between layers, and the four waves of a workgroup
+// run decoupled until the final 128-position max combine.  The gathered input is loaded from global
+// memory directly in B-operand layout (lane = position, half = row parity): a 6-row SA1 input is three
+// registers; the 323-row SA2 input streams through two 4-k-step register sets next to the weight sets.
+// The A operand (weights) streams from L2 exactly as in sa_fused_kernel, one 16-register set ahead, with
+// the hand-over between layers prefetched before the epilogue.  Same k-ascending fmaf chain: bit-identical.
+// =====================================================================================================
+constexpr int pad32c(int c) { return (c + 31) / 32 * 32; }
+constexpr int pad128c(int c) { return (c + 127) / 128 * 128; }
+
+struct SwParams {
+    int n, m, k;
+    const float *feat, *xyz_cn, *new_xyz;
+    const int *idx;
+    const float *w1, *b1, *w2, *b2, *w3, *b3;
+    float *out;
+    int out_ctotal, co_off;
+};
+
+constexpr int SW_KS = 8;  // k-steps per register set and tile; a set = 2 tiles x 8 = 16 registers
+
+template <int CIN, int COUT>
+struct SwShape {
+    static constexpr int KST = (CIN + 1) / 2;                 // MFMA k-steps (2 rows each)
+    static constexpr int NSETS = (KST + SW_KS - 1) / SW_KS;
+    static constexpr int NT = (COUT + 31) / 32;               // 32-row output tiles
+    static constexpr int NPASS = (NT + 1) / 2;                // two tiles (independent accumulators) per pass
+    static constexpr int STEPS = NPASS * NSETS;
+    static constexpr int LDW = pad128c(COUT), KP = pad32c(CIN);
+};
+
+// loads of set `c` of pass `ps` into dst[tm*8 + j]
+template <int CIN, int COUT>
+__device__ __forceinline__ void sw_load_set(float (&dst)[16], const __amdgpu_buffer_rsrc_t rsrc, int voff, int ps, int c) {
+    using S = SwShape<CIN, COUT>;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int j = 0; j < SW_KS; ++j) {
+            const int kk = c * SW_KS + j, t = 2 * ps + tm;
+            if (kk < S::KST && t < S::NT)
+                dst[tm * SW_KS + j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, ((2 * kk) * S::LDW + 32 * t) * 4, 0));
+        }
+}
+
+template <int CIN, int COUT>
+__device__ __forceinline__ void sw_first_set(float (&dst)[16], const float *wt, int lane) {
+    using S = SwShape<CIN, COUT>;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)wt, 0, S::KP * S::LDW * 4, 0x00020000);
+    sw_load_set<CIN, COUT>(dst, rsrc, ((lane >> 5) * S::LDW + (lane & 31)) * 4, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+__device__ __forceinline__ void sw_bias_init(f32x16 &acc, const float *bias_lds, int t, int lane) {
+    const float4 *bp = reinterpret_cast<const float4 *>(bias_lds + 32 * t + 4 * (lane >> 5));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 b4 = bp[2 * q];
+        acc[4 * q + 0] = b4.x; acc[4 * q + 1] = b4.y; acc[4 * q + 2] = b4.z; acc[4 * q + 3] = b4.w;
+    }
+}
+
+// ReLU, then turn output tile t (rows 32t..32t+31) into B operands hout[16t..16t+15] (k-step = row pair)
+template <int NOUT>
+__device__ __forceinline__ void sw_mid_epilogue(const f32x16 &acc, int t, float (&hout)[NOUT]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float a[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = acc[4 * q + i] > 0.f ? acc[4 * q + i] : 0.f;
+        // registers (4q, 4q+1) hold rows (8q, 8q+1) in the lower half-wave and (8q+4, 8q+5) in the upper one
+        const auto p01 = __builtin_amdgcn_permlane32_swap(__float_as_uint(a[0]), __float_as_uint(a[1]), false, false);
+        const auto p23 = __builtin_amdgcn_permlane32_swap(__float_as_uint(a[2]), __float_as_uint(a[3]), false, false);
+        const int k0 = 16 * t + 4 * q;
+        if (k0 + 0 < NOUT) hout[k0 + 0] = __uint_as_float(p01[0]);  // rows 8q,   8q+1
+        if (k0 + 1 < NOUT) hout[k0 + 1] = __uint_as_float(p23[0]);  // rows 8q+2, 8q+3
+        if (k0 + 2 < NOUT) hout[k0 + 2] = __uint_as_float(p01[1]);  // rows 8q+4, 8q+5
+        if (k0 + 3 < NOUT) hout[k0 + 3] = __uint_as_float(p23[1]);  // rows 8q+6, 8q+7
+    }
+}
+
+// ReLU + max over the wave's 32 positions of output tile t -> red[row][wave]
+template <int COUT>
+__device__ __forceinline__ void sw_last_epilogue(const f32x16 &acc, int t, float *red, int wave, int lane) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float v = acc[r] > 0.f ? acc[r] : 0.f;
+        v = row16_maxf(v);
+        v = fmaxf(v, dppf_rm<0x142, 0xA>(v));
+        const int row = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if ((lane & 31) == 16 && row < COUT) red[row * 4 + wave] = v;
+    }
+}
+
+// One layer whose input activations are B-operand registers hin[].  START = parity of the register set
+// that holds this layer's first weight set (loaded by the previous phase); `next` loads the following
+// layer's first set into the set after this layer's last one.
+template <int CIN, int COUT, bool LAST, int START, int NIN, int NOUT, typename Next>
+__device__ __forceinline__ void sw_layer_reg(const float *wt, const float *bias_lds, const float (&hin)[NIN], float (&hout)[NOUT],
+                                             float (&s)[2][16], float *red, int wave, int lane, Next next) {
+    using S = SwShape<CIN, COUT>;
+    static_assert(NIN >= S::KST, "input operand array too small");
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)wt, 0, S::KP * S::LDW * 4, 0x00020000);
+    const int voff = ((lane >> 5) * S::LDW + (lane & 31)) * 4;
+    f32x16 acc[2];
+#pragma unroll
+    for (int g = 0; g < S::STEPS; ++g) {
+        const int ps = g / S::NSETS, c = g % S::NSETS;
+        if (c == 0) {
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+                if (2 * ps + tm < S::NT) sw_bias_init(acc[tm], bias_lds, 2 * ps + tm, lane);
+        }
+        if (g + 1 < S::STEPS) {
+            sw_load_set<CIN, COUT>(s[(START + g + 1) & 1], rsrc, voff, (g + 1) / S::NSETS, (g + 1) % S::NSETS);
+        } else {
+            next(s[(START + g + 1) & 1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < SW_KS; ++j)
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm) {
+                const int kk = c * SW_KS + j;
+                if (kk < S::KST && 2 * ps + tm < S::NT)
+                    acc[tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(s[(START + g) & 1][tm * SW_KS + j], hin[kk], acc[tm], 0, 0, 0);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        if (c == S::NSETS - 1) {
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+                if (2 * ps + tm < S::NT) {
+                    if (LAST) sw_last_epilogue<COUT>(acc[tm], 2 * ps + tm, red, wave, lane);
+                    else sw_mid_epilogue<NOUT>(acc[tm], 2 * ps + tm, hout);
+                }
+        }
+    }
+}
+
+// First layer of a wide input (CF feature rows + 3 xyz rows, CF % 8 == 0, C1 <= 128): the B operand is
+// gathered from global memory chunk by chunk (4 k-steps = 8 feature rows of the wave's 32 neighbours),
+// double-buffered beside the matching weight chunk; all C1/32 output tiles accumulate at once so every
+// gathered value is loaded exactly once.
+template <int CF, int C1, int NOUT, typename Next>
+__device__ __forceinline__ void sw_layer1_gather(const SwParams &p, int b, int id, const float (&ctr)[3], const float *bias_lds,
+                                                 float (&hout)[NOUT], int lane, Next next) {
+    constexpr int CIN = CF + 3;
+    using S = SwShape<CIN, C1>;
+    constexpr int NT = S::NT;
+    static_assert(NT <= 4 && CF % 8 == 0, "unsupported first-layer shape");
+    constexpr int NCH = CF / 8;
+    const int half = lane >> 5;
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)p.w1, 0, S::KP * S::LDW * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc((void *)(p.feat + (size_t)b * CF * p.n), 0, CF * p.n * 4, 0x00020000);
+    const int voff_w = (half * S::LDW + (lane & 31)) * 4;
+    const int voff_f = (half * p.n + id) * 4;
+    const int kstep_f = 2 * p.n * 4;
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) sw_bias_init(acc[t], bias_lds, t, lane);
+    // tail operands: rows CF..CF+3 = (x, y | z, pad) relative to the centre
+    float at[2][NT], bt[2];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            at[jj][t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, voff_w, ((CF + 2 * jj) * S::LDW + 32 * t) * 4, 0));
+        const int a = 2 * jj + half;
+        bt[jj] = a < 3 ? p.xyz_cn[((size_t)b * 3 + a) * p.n + id] - ctr[a] : 0.f;
+    }
+    float A0[NT][4], A1[NT][4], B0[4], B1[4];
+#define SW_LOAD_CHUNK(A, B, ch)                                                                                            \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                       \
+        B[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rf, voff_f, ((ch) * 4 + j) * kstep_f, 0));   \
+        _Pragma("unroll") for (int t = 0; t < NT; ++t) A[t][j] = __builtin_bit_cast(                                       \
+            float, __builtin_amdgcn_raw_buffer_load_b32(rw, voff_w, (ch) * (8 * S::LDW * 4) + (2 * j * S::LDW + 32 * t) * 4, 0)); \
+    }                                                                                                                      \
+    __builtin_amdgcn_sched_barrier(0);
+#define SW_MFMA_CHUNK(A, B)                                                                                                \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                         \
+        _Pragma("unroll") for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[t][j], B[j], acc[t], 0, 0, 0); \
+    __builtin_amdgcn_sched_barrier(0);
+    SW_LOAD_CHUNK(A0, B0, 0)
+#pragma unroll 1
+    for (int ch = 0; ch + 1 < NCH; ch += 2) {
+        SW_LOAD_CHUNK(A1, B1, ch + 1)
+        SW_MFMA_CHUNK(A0, B0)
+        SW_LOAD_CHUNK(A0, B0, (ch + 2 < NCH ? ch + 2 : NCH - 1))
+        SW_MFMA_CHUNK(A1, B1)
+    }
+    if (NCH & 1) { SW_MFMA_CHUNK(A0, B0) }
+#undef SW_LOAD_CHUNK
+#undef SW_MFMA_CHUNK
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(at[jj][t], bt[jj], acc[t], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    next();
+#pragma unroll
+    for (int t = 0; t < NT; ++t) sw_mid_epilogue<NOUT>(acc[t], t, hout);
+}
+
+// live registers peak in layer 2 at about (C1 + C2)/2 activations + 64: beyond the 256 a wave gets at two
+// waves per SIMD, run one wave per SIMD with the whole 512-register file instead of spilling
+constexpr int sw_waves_per_simd(int c1, int c2) { return (c1 + c2) / 2 + 80 > 230 ? 1 : 2; }
+
+template <int CF, int C1, int C2, int C3>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, sw_waves_per_simd(C1, C2) == 1 ? 1 : 8)))
+void sa_wave_kernel(SwParams p) {
+    constexpr int CIN1 = CF + 3;
+    constexpr bool SMALL1 = CIN1 <= 8;
+    using S1 = SwShape<CIN1, C1>;
+    using S2 = SwShape<C1, C2>;
+    using S3 = SwShape<C2, C3>;
+    __shared__ float red[C3 * 4];
+    __shared__ __attribute__((aligned(16))) float bias_lds[3 * SF_MAXC];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.y;
+    const long long L = (long long)p.m * p.k;
+    const long long pos0 = (long long)blockIdx.x * SF_POS;
+    const long long wpos = pos0 + wave * 32;          // this wave's 32 positions: one slice of one centre
+    const bool active = wpos < L;                     // wave-uniform (L is a multiple of 32)
+
+    float s[2][16];
+    int id = 0;
+    float ctr[3] = {0.f, 0.f, 0.f};
+    if (active) {
+        id = p.idx[(size_t)b * L + wpos + (lane & 31)];
+        const float *cp = p.new_xyz + ((size_t)b * p.m + (int)(wpos / p.k)) * 3;
+        ctr[0] = cp[0]; ctr[1] = cp[1]; ctr[2] = cp[2];
+        if (SMALL1) sw_first_set<CIN1, C1>(s[0], p.w1, lane);
+    }
+    for (int e = tid; e < 3 * SF_MAXC; e += 256) {
+        const int l = e / SF_MAXC, c = e % SF_MAXC;
+        const int cl = l == 0 ? C1 : (l == 1 ? C2 : C3);
+        const float *bl = l == 0 ? p.b1 : (l == 1 ? p.b2 : p.b3);
+        bias_lds[e] = c < pad128c(cl) ? bl[c] : 0.f;
+    }
+    __syncthreads();
+    if (active) {
+        float h1[S2::KST], h2[S3::KST], none[1];
+        auto next2 = [&](float (&dst)[16]) { sw_first_set<C1, C2>(dst, p.w2, lane); };
+        auto next3 = [&](float (&dst)[16]) { sw_first_set<C2, C3>(dst, p.w3, lane); };
+        auto next_none = [&](float (&)[16]) {};
+        constexpr int START2 = SMALL1 ? (S1::STEPS & 1) : 0;
+        constexpr int START3 = (START2 + S2::STEPS) & 1;
+        if constexpr (SMALL1) {
+            float x1[S1::KST];
+#pragma unroll
+            for (int j = 0; j < S1::KST; ++j) {
+                const int row = 2 * j + (lane >> 5);
+                float v = 0.f;
+                if (row < CF) v = p.feat[((size_t)b * CF + row) * p.n + id];
+                else if (row < CIN1) v = p.xyz_cn[((size_t)b * 3 + (row - CF)) * p.n + id] - (row - CF == 0 ? ctr[0] : (row - CF == 1 ? ctr[1] : ctr[2]));
+                x1[j] = v;
+            }
+            sw_layer_reg<CIN1, C1, false, 0>(p.w1, bias_lds, x1, h1, s, red, wave, lane, next2);
+        } else {
+            sw_layer1_gather<CF, C1>(p, b, id, ctr, bias_lds, h1, lane, [&]() { sw_first_set<C1, C2>(s[0], p.w2, lane); });
+        }
+        sw_layer_reg<C1, C2, false, START2>(p.w2, bias_lds + SF_MAXC, h1, h2, s, red, wave, lane, next3);
+        sw_layer_reg<C2, C3, true, START3>(p.w3, bias_lds + 2 * SF_MAXC, h2, none, s, red, wave, lane, next_none);
+    }
+    __syncthreads();
+    const int tiles_per_group = p.k / 32;
+    const int groups = SF_POS / p.k;
+    for (int e = tid; e < C3 * groups; e += 256) {
+        const int row = e / groups, gi = e % groups;
+        const long long centre = pos0 / p.k + gi;
+        if (centre < p.m) {
+            float v = red[row * 4 + gi * tiles_per_group];
+            for (int t = 1; t < tiles_per_group; ++t) v = fmaxf(v, red[row * 4 + gi * tiles_per_group + t]);
+            p.out[((size_t)b * p.out_ctotal + p.co_off + row) * p.m + centre] = v;
+        }
+    }
+}
+
 }  // namespace
 
 // experiment knob (not part of the ABI): force the sub-tile width, 0 = heuristic
@@ -359,6 +645,8 @@ static int g_sa_wn = 0;
 static int g_sa_ablate = 0;
 extern "C" void captra_sa_fused_set_wn(int wn) { g_sa_wn = wn; }
 extern "C" void captra_sa_fused_set_ablate(int mask) { g_sa_ablate = mask; }
+static int g_sa_mode = 0;  // 0 = heuristic (register-resident kernels where instantiated), 1 = always the generic LDS kernel
+extern "C" void captra_sa_fused_set_mode(int mode) { g_sa_mode = mode; }
 static unsigned long long *g_sa_prof = nullptr;  // device buffer of 10 counters; non-null selects the PROF kernels
 extern "C" void captra_sa_fused_set_prof(unsigned long long *dev_counters) { g_sa_prof = dev_counters; }
 
@@ -378,6 +666,26 @@ extern "C" int captra_sa_scale_fused(int b, int n, int m, int k, int cfeat, int 
     p.feat = feat; p.xyz_cn = xyz_cn; p.new_xyz = new_xyz; p.idx = idx;
     p.w1 = w1; p.b1 = b1; p.w2 = w2; p.b2 = b2; p.w3 = w3; p.b3 = b3;
     p.out = out; p.out_ctotal = out_ctotal; p.co_off = co_off; p.ablate = g_sa_ablate; p.prof = g_sa_prof;
+    if (g_sa_mode != 1 && g_sa_prof == nullptr && g_sa_ablate == 0) {
+        // register-resident kernels for the channel shapes of the CAPTRA backbone (network/models/pointnet_utils.py
+        // PointNet2Msg config); any other shape takes the generic LDS kernel below
+        SwParams q;
+        q.n = n; q.m = m; q.k = k; q.feat = feat; q.xyz_cn = xyz_cn; q.new_xyz = new_xyz; q.idx = idx;
+        q.w1 = w1; q.b1 = b1; q.w2 = w2; q.b2 = b2; q.w3 = w3; q.b3 = b3; q.out = out; q.out_ctotal = out_ctotal; q.co_off = co_off;
+        const long long Lw = (long long)m * k;
+        dim3 gridw((unsigned)((Lw + SF_POS - 1) / SF_POS), b);
+#define SW_CASE(CF_, C1_, C2_, C3_)                                                                                  \
+    if (cfeat == CF_ && c1 == C1_ && c2 == C2_ && c3 == C3_ && (long long)cfeat * n * 4 < (1ll << 31)) {             \
+        CAPTRA_LAUNCH("sa_scale_fused", (sa_wave_kernel<CF_, C1_, C2_, C3_>), gridw, dim3(256), 0, (hipStream_t)stream, q); \
+        return captra_last_error();                                                                                  \
+    }
+        SW_CASE(3, 32, 32, 64)
+        SW_CASE(3, 64, 64, 128)
+        SW_CASE(3, 64, 96, 128)
+        SW_CASE(320, 128, 128, 256)
+        SW_CASE(320, 128, 196, 256)
+#undef SW_CASE
+    }
     const int cin1 = cfeat + 3;
     const int pa = (cin1 + 31) & ~31, pc2 = (c2 + 31) & ~31, pc1 = (c1 + 31) & ~31;
     const int rows_a = pa > pc2 ? pa : pc2;

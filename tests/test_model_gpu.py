@@ -90,10 +90,24 @@ def test_mlp_max_bit_exact(device, cin, cout, m, k):
 @pytest.mark.parametrize("cfeat,chans,n,m,k", [(0, (32, 32, 64), 4096, 512, 32), (3, (64, 64, 128), 4096, 512, 64),
                                                 (0, (64, 96, 128), 4096, 512, 128), (320, (128, 128, 256), 512, 128, 64),
                                                 (320, (128, 196, 256), 512, 128, 128), (5, (34, 62, 250), 300, 37, 32),
-                                                (2, (33, 47, 35), 100, 3, 64)])
-def test_sa_scale_fused_bit_exact(device, cfeat, chans, n, m, k):
+                                                (2, (33, 47, 35), 100, 3, 64), (3, (32, 32, 64), 300, 37, 32),
+                                                (3, (64, 96, 128), 700, 41, 128), (320, (128, 196, 256), 200, 5, 64)])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_sa_scale_fused_bit_exact(device, cfeat, chans, n, m, k, mode):
     """The one-launch SA scale equals gather -> 3 x (conv+BN+ReLU) -> max of the oracle, bit for bit,
-    including odd channel counts, a ragged last tile and channel offsets in the output."""
+    including odd channel counts, a ragged last tile and channel offsets in the output.  mode 0 = production
+    dispatch (register-resident sa_wave_kernel for the CAPTRA channel shapes, generic LDS kernel otherwise),
+    mode 1 = the generic LDS kernel for every shape."""
+    import ctypes
+    from captra_amd import _lib, fused
+    _lib.lib().captra_sa_fused_set_mode(ctypes.c_int(mode))
+    try:
+        _sa_scale_fused_case(device, cfeat, chans, n, m, k)
+    finally:
+        _lib.lib().captra_sa_fused_set_mode(ctypes.c_int(0))
+
+
+def _sa_scale_fused_case(device, cfeat, chans, n, m, k):
     from captra_amd import fused
     rng = np.random.default_rng(cfeat + sum(chans) + k)
     B = 2

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--layered", action="store_true")
     ap.add_argument("--wn", type=int, default=0)
+    ap.add_argument("--mode", type=int, default=0, help="0 = register-resident kernels where instantiated, 1 = generic LDS kernel")
     ap.add_argument("--phases", action="store_true", help="debug: in-kernel s_memtime phase breakdown (PROF kernels)")
     ap.add_argument("--ablate", type=int, default=0, help="debug: phases to skip (1 gather, 2 mid epilogues, 4 last epilogue, 8/16/32 layer 1/2/3)")
     a = ap.parse_args()
@@ -51,6 +52,15 @@ def main():
             else:
                 fused.sa_scale_fused(feat, xyz, new_xyz, idx, layers, out, 0)
 
+        if not a.layered:
+            _lib.lib().captra_sa_fused_set_mode(ctypes.c_int(1))
+            run()
+            ref = out.clone()
+            _lib.lib().captra_sa_fused_set_mode(ctypes.c_int(a.mode))
+            out.zero_()
+            run()
+            torch.cuda.synchronize()
+            print(f"  {name}: mode {a.mode} vs generic LDS kernel: bit-exact = {torch.equal(ref, out)}  (max |diff| {float((ref - out).abs().max()):.3g})")
         for _ in range(2):
             run()
         torch.cuda.synchronize()
