@@ -409,7 +409,13 @@ static int g_pw_direct = 1;  // experiment knob: 0 = LDS-staged kernel for dense
 
 int launch_pw_direct(int b, const PwParams &p, hipStream_t s) {
     if ((long long)p.cin * p.L * 4 >= (1ll << 31)) return -3;  // buffer offsets are 32-bit: fall back
-    if (p.cout > 64) {
+    // 64x64 wave tiles (4 accumulator chains) unless that leaves most SIMDs without a wave: the small-L layers
+    // (SA3 / FP3 / FP2: 128-512 points per cloud) then take 32x32 wave tiles, 4x the waves, same bits
+    const long long waves22 = ((p.L + 63) / 64) * ((p.cout + 63) / 64) * b;
+    if (p.cout > 64 && waves22 < 2048) {
+        dim3 grid((unsigned)((p.L + 63) / 64), (p.cout + 63) / 64, b);
+        CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<1, 1, 2, 2>), grid, dim3(256), 0, s, p);
+    } else if (p.cout > 64) {
         dim3 grid((unsigned)((p.L + 127) / 128), (p.cout + 127) / 128, b);
         CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<2, 2, 2, 2>), grid, dim3(256), 0, s, p);
     } else if (p.cout > 32) {

@@ -440,16 +440,43 @@ __device__ __forceinline__ void sw_mid_epilogue(const f32x16 &acc, int t, float 
     }
 }
 
+// Non-negative floats order like their bit patterns, so after ReLU the 32-position max runs in the integer
+// domain: v_max_i32 with a DPP source operand (one instruction per step, no NaN-canonicalising extra max).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_max_i32(int v) {
+    // full row mask: every lane has a valid source (quad_perm / mirrors), so "old" is dead and bound_ctrl lets the
+    // compiler fold the DPP move into the max; partial row mask (row_bcast): masked-off lanes keep v
+    const int o = ROW_MASK == 0xF ? __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true)
+                                  : __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xF, false);
+    return o > v ? o : v;
+}
+
 // ReLU + max over the wave's 32 positions of output tile t -> red[row][wave]
 template <int COUT>
 __device__ __forceinline__ void sw_last_epilogue(const f32x16 &acc, int t, float *red, int wave, int lane) {
+    int v[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        float v = acc[r] > 0.f ? acc[r] : 0.f;
-        v = row16_maxf(v);
-        v = fmaxf(v, dppf_rm<0x142, 0xA>(v));
-        const int row = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if ((lane & 31) == 16 && row < COUT) red[row * 4 + wave] = v;
+        const int x = __float_as_int(acc[r]);
+        v[r] = x > 0 ? x : 0;  // ReLU on the bit pattern: negative floats (and -0) are negative integers
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = dpp_max_i32<0xB1, 0xF>(v[r]);   // quad_perm [1,0,3,2]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = dpp_max_i32<0x4E, 0xF>(v[r]);   // quad_perm [2,3,0,1]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = dpp_max_i32<0x141, 0xF>(v[r]);  // row_half_mirror
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = dpp_max_i32<0x140, 0xF>(v[r]);  // row_mirror: every lane holds its row-of-16 max
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = dpp_max_i32<0x142, 0xA>(v[r]);  // row_bcast15 into rows 1, 3: the 32-lane max
+    if ((lane & 31) == 16) {
+        float *rp = red + (32 * t + 4 * (lane >> 5)) * 4 + wave;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ro = (r & 3) + 8 * (r >> 2);
+            if (32 * t + ro + 4 < COUT || 32 * t + ro + 4 * (lane >> 5) < COUT) rp[ro * 4] = __int_as_float(v[r]);
+        }
     }
 }
 
@@ -679,6 +706,9 @@ extern "C" int captra_sa_scale_fused(int b, int n, int m, int k, int cfeat, int 
         CAPTRA_LAUNCH("sa_scale_fused", (sa_wave_kernel<CF_, C1_, C2_, C3_>), gridw, dim3(256), 0, (hipStream_t)stream, q); \
         return captra_last_error();                                                                                  \
     }
+        SW_CASE(0, 32, 32, 64)
+        SW_CASE(0, 64, 64, 128)
+        SW_CASE(0, 64, 96, 128)
         SW_CASE(3, 32, 32, 64)
         SW_CASE(3, 64, 64, 128)
         SW_CASE(3, 64, 96, 128)

@@ -13,6 +13,7 @@ SHAPES = {  # name: (cfeat, (c1,c2,c3), n, m, k)
     "sa1s1": (3, (32, 32, 64), 4096, 512, 32), "sa1s2": (3, (64, 64, 128), 4096, 512, 64),
     "sa1s3": (3, (64, 96, 128), 4096, 512, 128), "sa2s1": (320, (128, 128, 256), 512, 128, 64),
     "sa2s2": (320, (128, 196, 256), 512, 128, 128),
+    "sa1s1x": (0, (32, 32, 64), 4096, 512, 32), "sa1s2x": (0, (64, 64, 128), 4096, 512, 64), "sa1s3x": (0, (64, 96, 128), 4096, 512, 128),
 }
 
 
