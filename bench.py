@@ -118,6 +118,82 @@ def cpu_baseline(cfg, sd, budget_s: float = 15.0):
                       f"{dt:.1f} s wall with {best} threads (fastest of 8/16/32/64), host has {ncpu} logical cores"}
 
 
+def hbm_ops_roofline(batch: int, device, reps: int = 5):
+    """The drop-in ops ball_query + group_points (SURVEY.md §8d "materialised-op" byte definition: ball query
+    12N + 12M + 4MK, group 4CN + 4MK + 4CMK bytes per cloud) on the workload's SA1 / SA2 shapes for one frame
+    of both nets, timed with HIP events on the launch stream (captra_prof).  The product path does not run
+    group_points at all (the SA kernels gather inside their operand load): this is the op-level figure."""
+    import torch
+    from captra_amd import _lib
+    from captra_amd import pointnet2_cuda as pc
+    from tests import clouds
+    B = batch
+    pts = torch.from_numpy(np.stack([clouds.s_nocs(1000 + i)[0] for i in range(min(B, 8))])).to(device)
+    pts = pts.repeat((B + pts.shape[0] - 1) // pts.shape[0], 1, 1)[:B].contiguous()        # (B,N,3)
+    gen = torch.Generator(device="cpu").manual_seed(3)
+    levels = [  # (N, M, [(radius, K)], feature channel counts grouped per frame: rot net xyz, coord net xyz + C0)
+        (4096, 512, [(0.05, 32), (0.1, 64), (0.2, 128)], [3, 3, 3]),
+        (512, 128, [(0.2, 64), (0.4, 128)], [3, 320, 3, 320]),
+    ]
+    nbytes = {"ball_query": 0.0, "group_points": 0.0}
+    work = []
+    xyz = pts
+    for (n, m, rk, chans) in levels:
+        xyz = xyz[:, :n].contiguous()
+        new_xyz = xyz[:, :m].contiguous()
+        feats = {c: torch.randn(B, c, n, generator=gen).to(device) for c in set(chans)}
+        for (r, k) in rk:
+            idx = torch.zeros(B, m, k, dtype=torch.int32, device=device)
+            outs = {c: torch.empty(B, c, m, k, device=device) for c in set(chans)}
+            work.append((n, m, r, k, new_xyz, xyz, idx, feats, outs, chans))
+            nbytes["ball_query"] += B * (12.0 * n + 12.0 * m + 4.0 * m * k)
+            for c in chans:
+                nbytes["group_points"] += B * (4.0 * c * n + 4.0 * m * k + 4.0 * c * m * k)
+
+    def run():
+        for (n, m, r, k, new_xyz, xyz_l, idx, feats, outs, chans) in work:
+            pc.ball_query_wrapper(B, n, m, r, k, new_xyz, xyz_l, idx)
+            for c in chans:
+                pc.group_points_wrapper(B, c, n, m, k, feats[c], idx, outs[c])
+
+    run()
+    torch.cuda.synchronize()
+    _lib.prof_reset()
+    _lib.prof_enable(True)
+    for _ in range(reps):
+        run()
+    torch.cuda.synchronize()
+    _lib.prof_enable(False)
+    ms = {k: _lib.prof_read(k)[0] / reps for k in nbytes}
+    tot_b, tot_ms = sum(nbytes.values()), sum(ms.values())
+    out = {"bound": "hbm", "unit": "GB/s", "peak": PEAK_HBM_GBS,
+           "achieved": round(tot_b / (tot_ms * 1e-3) / 1e9, 1), "frac": round(tot_b / (tot_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+           "bytes_per_frame": round(tot_b / B), "us_per_frame": round(1e3 * tot_ms / B, 2),
+           "ops": {k: {"GB/s": round(nbytes[k] / (ms[k] * 1e-3) / 1e9, 1), "ms": round(ms[k], 3)} for k in nbytes},
+           "note": "drop-in captra_ball_query + captra_group_points on the SA1/SA2 shapes of one frame (both nets), materialised-op bytes; "
+                   "not part of the timed step (the fused SA kernels never materialise the grouped tensor)"}
+    return out
+
+
+def pmc_traffic(kernel_prefixes):
+    """HBM bytes per launch of the MFMA family from the newest committed PMC summary (profiles/*_bench_pmc.json,
+    written by tools/profile_round.sh from separate rocprofv3 --pmc passes): 2 x FETCH_SIZE (gfx950 correction,
+    MI355X_MICROARCH.md) + WRITE_SIZE, KiB -> bytes, averaged over the family's launches."""
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_bench_pmc.json")))
+    if not files:
+        return None, None
+    with open(files[-1]) as fh:
+        data = json.load(fh)
+    tot, n = 0.0, 0
+    for name, c in data.get("kernels", {}).items():
+        if name.startswith(tuple(kernel_prefixes)) and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            k = min(c["FETCH_SIZE"]["dispatches"], c["WRITE_SIZE"]["dispatches"])
+            tot += k * 1024.0 * (2.0 * c["FETCH_SIZE"]["mean"] + c["WRITE_SIZE"]["mean"])
+            n += k
+    return (tot / n if n else None), os.path.basename(files[-1])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -246,10 +322,14 @@ def main():
             ach = mlp_flops / (mlp_ms * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-                               "kernel": "fp32 MFMA 32x32x2 shared-MLP kernels: sa_fused_kernel + pw_mlp_kernel",
+                               "kernel": "fp32 MFMA 32x32x2 shared-MLP kernels: sa_wave_kernel (dominant) + pw_direct_kernel + pw_mlp_kernel",
                                "avg_launch_us": round(1e3 * mlp_ms / max(mlp_launches, 1), 2),
                                "flops_per_launch": round(mlp_flops / max(mlp_launches, 1)),
                                "share_of_kernel_time": round(mlp_ms / max(total_ms, 1e-9), 3), "dominant_family": dominant}
+            traffic, src = pmc_traffic(["sa_wave_kernel", "sa_fused_kernel", "pw_direct_kernel", "pw_mlp_kernel"])
+            if traffic is not None:
+                out["roofline"]["traffic"] = round(traffic)
+                out["roofline"]["traffic_source"] = f"profiles/{src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch)"
         if "ball_query" in fams:
             bq = fams["ball_query"]
             nbytes = fused.WORK["bytes"].get("ball_query", 0.0)
@@ -259,6 +339,8 @@ def main():
                                           "avg_launch_us": round(1e3 * bq["ms_total"] / bq["launches"], 2)}
         out["kernel_ms_per_step"] = {k: round(v["ms_total"] / args.steps, 3) for k, v in sorted(fams.items(), key=lambda kv: -kv[1]["ms_total"])}
         out["kernel_ms_per_step"]["_sum_captra_kernels"] = round(total_ms / args.steps, 3)
+    if world == 1 and timing:
+        out["hbm_ops"] = hbm_ops_roofline(B, device)
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, sd, args.cpu_budget)
         out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)

@@ -20,5 +20,5 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_wri
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_INSTS_MFMA \
     --kernel-trace --output-format csv -d $OUT/${TAG}_sq -o p -- $BENCH_EAGER > $OUT/${TAG}_sq.log 2>&1
 cd $ROOT
-python tools/pmc_summary.py $OUT/${TAG}_fetch $OUT/${TAG}_write $OUT/${TAG}_sq > $OUT/${TAG}_bench_pmc_summary.txt 2>&1
+python tools/pmc_summary.py $OUT/${TAG}_fetch $OUT/${TAG}_write $OUT/${TAG}_sq --json $OUT/${TAG}_bench_pmc.json > $OUT/${TAG}_bench_pmc_summary.txt 2>&1
 echo done
