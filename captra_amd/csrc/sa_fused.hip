@@ -370,7 +370,7 @@ constexpr int pad32c(int c) { return (c + 31) / 32 * 32; }
 constexpr int pad128c(int c) { return (c + 127) / 128 * 128; }
 
 struct SwParams {
-    int n, m, k;
+    int b, n, m, k;
     const float *feat, *xyz_cn, *new_xyz;
     const int *idx;
     const float *w1, *b1, *w2, *b2, *w3, *b3;
@@ -452,7 +452,7 @@ __device__ __forceinline__ int dpp_max_i32(int v) {
 }
 
 // ReLU + max over the wave's 32 positions of output tile t -> red[row][wave]
-template <int COUT>
+template <int COUT, int RED_STRIDE = 4>
 __device__ __forceinline__ void sw_last_epilogue(const f32x16 &acc, int t, float *red, int wave, int lane) {
     int v[16];
 #pragma unroll
@@ -471,11 +471,11 @@ __device__ __forceinline__ void sw_last_epilogue(const f32x16 &acc, int t, float
 #pragma unroll
     for (int r = 0; r < 16; ++r) v[r] = dpp_max_i32<0x142, 0xA>(v[r]);  // row_bcast15 into rows 1, 3: the 32-lane max
     if ((lane & 31) == 16) {
-        float *rp = red + (32 * t + 4 * (lane >> 5)) * 4 + wave;
+        float *rp = red + (32 * t + 4 * (lane >> 5)) * RED_STRIDE + wave;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int ro = (r & 3) + 8 * (r >> 2);
-            if (32 * t + ro + 4 < COUT || 32 * t + ro + 4 * (lane >> 5) < COUT) rp[ro * 4] = __int_as_float(v[r]);
+            if (32 * t + ro + 4 < COUT || 32 * t + ro + 4 * (lane >> 5) < COUT) rp[ro * RED_STRIDE] = __int_as_float(v[r]);
         }
     }
 }
@@ -665,6 +665,169 @@ void sa_wave_kernel(SwParams p) {
     }
 }
 
+// =====================================================================================================
+// sa_wave_lds_kernel<CF, C1, C2, C3>: the register-resident kernel for scales whose weights fit in LDS
+// (the three SA1 scales: 13-74 KB).  The L1 cannot hold a scale's weights (74 KB for the widest) while 16
+// waves per CU stream them at different phases, so in sa_wave_kernel ~70 % of the A-operand lines come from
+// L2.  Here a persistent 8-wave workgroup stages the three weight matrices ONCE in LDS in MFMA-fragment
+// order -- element ((t*KQ + q)*64 + lane)*4 + i = W'^T[2(4q+i) + (lane>>5)][32t + (lane&31)] -- so a lane
+// fetches the A operands of four consecutive k-steps with one conflict-free ds_read_b128, and walks
+// 256-position tiles (8 waves x 32 neighbours), prefetching the next tile's neighbour ids and centre.
+// Everything else (gather in B-operand layout, activations in registers via v_permlane32_swap, integer DPP
+// max) is sa_wave_kernel's.  Same k-ascending fmaf chain: same bits.
+// =====================================================================================================
+constexpr int SL_WAVES = 8;
+constexpr int SL_POS = SL_WAVES * 32;
+
+template <int CIN, int COUT>
+struct SlShape {
+    static constexpr int KST = (CIN + 1) / 2;
+    static constexpr int KQ = (KST + 3) / 4;      // quads of k-steps
+    static constexpr int NT = (COUT + 31) / 32;
+    static constexpr int NPASS = (NT + 1) / 2;
+    static constexpr int FLOATS = NT * KQ * 256;  // fragment-ordered weights
+    static constexpr int LDW = pad128c(COUT);
+};
+
+template <int CIN, int COUT>
+__device__ __forceinline__ void sl_stage_weights(float *dst, const float *__restrict__ wt, int tid) {
+    using S = SlShape<CIN, COUT>;
+    // consecutive threads read consecutive columns of one packed row (coalesced); the LDS write is the permuted one
+    for (int e = tid; e < S::FLOATS; e += SL_WAVES * 64) {
+        const int l31 = e & 31, i = (e >> 5) & 3, half = (e >> 7) & 1, tq = e >> 8;
+        const int q = tq % S::KQ, t = tq / S::KQ;
+        const int kk = 4 * q + i;
+        const float v = kk < S::KST ? wt[(size_t)(2 * kk + half) * S::LDW + 32 * t + l31] : 0.f;
+        dst[((tq * 64) + half * 32 + l31) * 4 + i] = v;
+    }
+}
+
+template <int CIN, int COUT, bool LAST, int NIN, int NOUT>
+__device__ __forceinline__ void sl_layer(const float *wl, const float *bias_lds, const float (&hin)[NIN], float (&hout)[NOUT],
+                                         float *red, int wave, int lane) {
+    using S = SlShape<CIN, COUT>;
+    static_assert(NIN >= S::KST, "input operand array too small");
+    const float4 *wq = reinterpret_cast<const float4 *>(wl) + lane;
+#pragma unroll
+    for (int ps = 0; ps < S::NPASS; ++ps) {
+        f32x16 acc[2];
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+            if (2 * ps + tm < S::NT) sw_bias_init(acc[tm], bias_lds, 2 * ps + tm, lane);
+        float a[2][2][4];
+#define SL_LOAD_QUAD(buf, q)                                                                   \
+    _Pragma("unroll") for (int tm = 0; tm < 2; ++tm) if (2 * ps + tm < S::NT) {                \
+        const float4 v4 = wq[((2 * ps + tm) * S::KQ + (q)) * 64];                              \
+        a[buf][tm][0] = v4.x; a[buf][tm][1] = v4.y; a[buf][tm][2] = v4.z; a[buf][tm][3] = v4.w; \
+    }
+        SL_LOAD_QUAD(0, 0)
+#pragma unroll
+        for (int q = 0; q < S::KQ; ++q) {
+            if (q + 1 < S::KQ) { SL_LOAD_QUAD((q + 1) & 1, q + 1) }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int tm = 0; tm < 2; ++tm) {
+                    const int kk = 4 * q + i;
+                    if (kk < S::KST && 2 * ps + tm < S::NT)
+                        acc[tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q & 1][tm][i], hin[kk], acc[tm], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#undef SL_LOAD_QUAD
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+            if (2 * ps + tm < S::NT) {
+                if (LAST) sw_last_epilogue<COUT, SL_WAVES>(acc[tm], 2 * ps + tm, red, wave, lane);
+                else sw_mid_epilogue<NOUT>(acc[tm], 2 * ps + tm, hout);
+            }
+    }
+}
+
+template <int CF, int C1, int C2, int C3>
+constexpr int sl_lds_floats() {
+    return SlShape<CF + 3, C1>::FLOATS + SlShape<C1, C2>::FLOATS + SlShape<C2, C3>::FLOATS + pad32c(C1) + pad32c(C2) + pad32c(C3) + C3 * SL_WAVES;
+}
+
+template <int CF, int C1, int C2, int C3>
+__global__ __launch_bounds__(SL_WAVES * 64) __attribute__((amdgpu_waves_per_eu(4, 8))) void sa_wave_lds_kernel(SwParams p) {
+    constexpr int CIN1 = CF + 3;
+    static_assert(CIN1 <= 8, "LDS-weight variant is for the small-input scales");
+    using S1 = SlShape<CIN1, C1>;
+    using S2 = SlShape<C1, C2>;
+    using S3 = SlShape<C2, C3>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *wl1 = lds, *wl2 = wl1 + S1::FLOATS, *wl3 = wl2 + S2::FLOATS;
+    float *bias1 = wl3 + S3::FLOATS, *bias2 = bias1 + pad32c(C1), *bias3 = bias2 + pad32c(C2);
+    float *red = bias3 + pad32c(C3);  // [C3][8 waves]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long long L = (long long)p.m * p.k;
+    const int tiles_per_cloud = (int)((L + SL_POS - 1) / SL_POS);
+    const long long total = (long long)p.b * tiles_per_cloud;
+
+    int id = 0;
+    float ctr[3] = {0.f, 0.f, 0.f};
+    auto load_task = [&](long long tile, int &id_o, float (&ctr_o)[3]) {
+        if (tile >= total) return;
+        const int tb = (int)(tile / tiles_per_cloud);
+        const long long wp = (tile % tiles_per_cloud) * SL_POS + wave * 32;
+        if (wp >= L) return;
+        id_o = p.idx[(size_t)tb * L + wp + (lane & 31)];
+        const float *cp = p.new_xyz + ((size_t)tb * p.m + (int)(wp / p.k)) * 3;
+        ctr_o[0] = cp[0]; ctr_o[1] = cp[1]; ctr_o[2] = cp[2];
+    };
+    long long tile = blockIdx.x;
+    load_task(tile, id, ctr);
+    sl_stage_weights<CIN1, C1>(wl1, p.w1, tid);
+    sl_stage_weights<C1, C2>(wl2, p.w2, tid);
+    sl_stage_weights<C2, C3>(wl3, p.w3, tid);
+    for (int e = tid; e < pad32c(C1); e += SL_WAVES * 64) bias1[e] = p.b1[e];  // packed biases are zero-padded to ceil128
+    for (int e = tid; e < pad32c(C2); e += SL_WAVES * 64) bias2[e] = p.b2[e];
+    for (int e = tid; e < pad32c(C3); e += SL_WAVES * 64) bias3[e] = p.b3[e];
+    __syncthreads();
+
+    for (; tile < total; tile += gridDim.x) {
+        const int b = (int)(tile / tiles_per_cloud);
+        const long long pos0 = (tile % tiles_per_cloud) * SL_POS;
+        const bool active = pos0 + wave * 32 < L;  // wave-uniform (L is a multiple of 32)
+        int id_n = 0;
+        float ctr_n[3] = {0.f, 0.f, 0.f};
+        if (active) {
+            float x1[S1::KST], h1[S2::KST], h2[S3::KST], none[1];
+#pragma unroll
+            for (int j = 0; j < S1::KST; ++j) {
+                const int row = 2 * j + (lane >> 5);
+                float v = 0.f;
+                if (row < CF) v = p.feat[((size_t)b * CF + row) * p.n + id];
+                else if (row < CIN1) v = p.xyz_cn[((size_t)b * 3 + (row - CF)) * p.n + id] - (row - CF == 0 ? ctr[0] : (row - CF == 1 ? ctr[1] : ctr[2]));
+                x1[j] = v;
+            }
+            load_task(tile + gridDim.x, id_n, ctr_n);
+            sl_layer<CIN1, C1, false>(wl1, bias1, x1, h1, red, wave, lane);
+            sl_layer<C1, C2, false>(wl2, bias2, h1, h2, red, wave, lane);
+            sl_layer<C2, C3, true>(wl3, bias3, h2, none, red, wave, lane);
+        } else {
+            load_task(tile + gridDim.x, id_n, ctr_n);
+        }
+        __syncthreads();  // every wave's 32-position maxima are in red
+        const int tiles_per_group = p.k / 32;
+        const int groups = SL_POS / p.k;
+        for (int e = tid; e < C3 * groups; e += SL_WAVES * 64) {
+            const int row = e / groups, gi = e % groups;
+            const long long centre = pos0 / p.k + gi;
+            if (centre < p.m) {
+                float v = red[row * SL_WAVES + gi * tiles_per_group];
+                for (int t = 1; t < tiles_per_group; ++t) v = fmaxf(v, red[row * SL_WAVES + gi * tiles_per_group + t]);
+                p.out[((size_t)b * p.out_ctotal + p.co_off + row) * p.m + centre] = v;
+            }
+        }
+        __syncthreads();  // red is free for the next tile
+        id = id_n; ctr[0] = ctr_n[0]; ctr[1] = ctr_n[1]; ctr[2] = ctr_n[2];
+    }
+}
+
 }  // namespace
 
 // experiment knob (not part of the ABI): force the sub-tile width, 0 = heuristic
@@ -672,7 +835,8 @@ static int g_sa_wn = 0;
 static int g_sa_ablate = 0;
 extern "C" void captra_sa_fused_set_wn(int wn) { g_sa_wn = wn; }
 extern "C" void captra_sa_fused_set_ablate(int mask) { g_sa_ablate = mask; }
-static int g_sa_mode = 0;  // 0 = heuristic (register-resident kernels where instantiated), 1 = always the generic LDS kernel
+static int g_sa_mode = 0;  // 0 = heuristic (register-resident kernels where instantiated), 1 = always the generic LDS kernel,
+                           // 2 = register-resident kernels with streamed weights only (no LDS-weight variant)
 extern "C" void captra_sa_fused_set_mode(int mode) { g_sa_mode = mode; }
 static unsigned long long *g_sa_prof = nullptr;  // device buffer of 10 counters; non-null selects the PROF kernels
 extern "C" void captra_sa_fused_set_prof(unsigned long long *dev_counters) { g_sa_prof = dev_counters; }
@@ -697,10 +861,38 @@ extern "C" int captra_sa_scale_fused(int b, int n, int m, int k, int cfeat, int 
         // register-resident kernels for the channel shapes of the CAPTRA backbone (network/models/pointnet_utils.py
         // PointNet2Msg config); any other shape takes the generic LDS kernel below
         SwParams q;
-        q.n = n; q.m = m; q.k = k; q.feat = feat; q.xyz_cn = xyz_cn; q.new_xyz = new_xyz; q.idx = idx;
+        q.b = b; q.n = n; q.m = m; q.k = k; q.feat = feat; q.xyz_cn = xyz_cn; q.new_xyz = new_xyz; q.idx = idx;
         q.w1 = w1; q.b1 = b1; q.w2 = w2; q.b2 = b2; q.w3 = w3; q.b3 = b3; q.out = out; q.out_ctotal = out_ctotal; q.co_off = co_off;
         const long long Lw = (long long)m * k;
         dim3 gridw((unsigned)((Lw + SF_POS - 1) / SF_POS), b);
+        // small-input scales: persistent workgroups with the weights resident in LDS (mode 2 = streaming kernel for all)
+#define SL_CASE(CF_, C1_, C2_, C3_)                                                                                   \
+    if (g_sa_mode != 2 && cfeat == CF_ && c1 == C1_ && c2 == C2_ && c3 == C3_ && SL_POS % k == 0) {                    \
+        auto kern = sa_wave_lds_kernel<CF_, C1_, C2_, C3_>;                                                            \
+        constexpr int lds_bytes = sl_lds_floats<CF_, C1_, C2_, C3_>() * 4;                                             \
+        static int resident = 0;                                                                                       \
+        if (resident == 0) {                                                                                           \
+            int per_cu = 0, dev = 0;                                                                                   \
+            hipDeviceProp_t prop;                                                                                      \
+            (void)hipGetDevice(&dev);                                                                                  \
+            (void)hipGetDeviceProperties(&prop, dev);                                                                  \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); \
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, SL_WAVES * 64, lds_bytes);                \
+            resident = (per_cu > 0 ? per_cu : 1) * (prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);    \
+        }                                                                                                              \
+        const long long tiles = ((Lw + SL_POS - 1) / SL_POS) * b;                                                      \
+        q.b = b;                                                                                                       \
+        CAPTRA_LAUNCH("sa_scale_fused", kern, dim3((unsigned)(tiles < resident ? tiles : resident)), dim3(SL_WAVES * 64), lds_bytes, \
+                      (hipStream_t)stream, q);                                                                         \
+        return captra_last_error();                                                                                    \
+    }
+        SL_CASE(0, 32, 32, 64)
+        SL_CASE(0, 64, 64, 128)
+        SL_CASE(0, 64, 96, 128)
+        SL_CASE(3, 32, 32, 64)
+        SL_CASE(3, 64, 64, 128)
+        SL_CASE(3, 64, 96, 128)
+#undef SL_CASE
 #define SW_CASE(CF_, C1_, C2_, C3_)                                                                                  \
     if (cfeat == CF_ && c1 == C1_ && c2 == C2_ && c3 == C3_ && (long long)cfeat * n * 4 < (1ll << 31)) {             \
         CAPTRA_LAUNCH("sa_scale_fused", (sa_wave_kernel<CF_, C1_, C2_, C3_>), gridw, dim3(256), 0, (hipStream_t)stream, q); \
