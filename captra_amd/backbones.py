@@ -68,10 +68,13 @@ class PointNet2Msg(_FoldCache, nn.Module):
         l2_points = self.fp3(l2_xyz, l3_xyz, l2_points, l3_points)
         l1_points = self.fp2(l1_xyz, l2_xyz, l1_points, l2_points, xyz1_n3=l1_n3, xyz2_n3=l2_n3, nn=geom.get("fp2"))
         skip0 = torch.cat([l0_xyz, l0_points], dim=1) if l0_points.shape[1] > 0 else l0_xyz
-        l0_points = self.fp1(l0_xyz, l1_xyz, skip0, l1_points, xyz1_n3=input_n3, xyz2_n3=l1_n3, nn=geom.get("fp1"))
+        fuse = (not self.training) and l0_xyz.is_cuda
+        if fuse and self._folded is None:
+            self._folded = fold_conv_bn(self.conv1, self.bn1, l0_xyz.device)
+        # fused path: conv1 + bn1 + ReLU rides at the end of FP1's MLP (one launch for the three layers)
+        l0_points = self.fp1(l0_xyz, l1_xyz, skip0, l1_points, xyz1_n3=input_n3, xyz2_n3=l1_n3, nn=geom.get("fp1"),
+                             tail=self._folded if fuse else None)
         self.last_geom = {"sa1": self.sa1.last_geom, "sa2": self.sa2.last_geom, "fp2": self.fp2.last_nn, "fp1": self.fp1.last_nn}
-        if (not self.training) and l0_points.is_cuda:
-            if self._folded is None:
-                self._folded = fold_conv_bn(self.conv1, self.bn1, l0_points.device)
-            return fused.pointwise_mlp(l0_points.contiguous(), self._folded, fused.ACT_RELU)
+        if fuse:
+            return l0_points
         return F.relu(self.bn1(self.conv1(l0_points)))

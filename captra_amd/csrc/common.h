@@ -53,3 +53,12 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
     }
     return v;
 }
+
+// activation codes of the shared-MLP entry points (include/captra_hip.h: CAPTRA_ACT_*)
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_SIGMOID_M05 = 2 };
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == ACT_RELU) return v > 0.f ? v : 0.f;
+    if (act == ACT_SIGMOID_M05) return 1.0f / (1.0f + expf(-v)) - 0.5f;
+    return v;
+}

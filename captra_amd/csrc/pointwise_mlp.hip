@@ -39,7 +39,6 @@ constexpr int PW_BK = 32;
 
 enum { PRO_PLAIN = 0, PRO_GROUP = 1 };
 enum { EPI_STORE = 0, EPI_MAXK = 1 };
-enum { ACT_NONE = 0, ACT_RELU = 1, ACT_SIGMOID_M05 = 2 };
 
 struct PwParams {
     int cin, cout, ldw;   // ldw = ceil128(cout): row stride of the packed weights
@@ -58,12 +57,6 @@ struct PwParams {
     // EPI_MAXK
     int y_ctotal, co_off; // y is (B,y_ctotal,M), this layer writes channels [co_off, co_off+cout)
 };
-
-__device__ __forceinline__ float apply_act(float v, int act) {
-    if (act == ACT_RELU) return v > 0.f ? v : 0.f;
-    if (act == ACT_SIGMOID_M05) return 1.0f / (1.0f + expf(-v)) - 0.5f;
-    return v;
-}
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_f(float v) {

@@ -28,10 +28,10 @@
 // a layer is computed in output-channel tiles of 128; one 16-register accumulator per wave (the
 // 32x32x2 f32 MFMA's dependent-issue latency equals its issue interval, 64 cycles), two waves per SIMD.
 #include "common.h"
+#include "wave_mlp.h"
 
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int SF_POS = 128;     // positions per workgroup (= 128/K centres), processed in sub-tiles of T = 32*WN
 constexpr int SF_BK = 16;       // K chunk = 8 MFMA k-steps prefetched as one register set
@@ -51,23 +51,6 @@ struct SaParams {
     int ablate;            // debug/profiling only: bit mask of phases to skip (0 in production)
     unsigned long long *prof;  // debug/profiling only: per-phase wave-cycle totals (PROF kernels), else null
 };
-
-template <int CTRL>
-__device__ __forceinline__ float dppf(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xF, 0xF, false));
-}
-__device__ __forceinline__ float row16_maxf(float v) {
-    v = fmaxf(v, dppf<0xB1>(v));
-    v = fmaxf(v, dppf<0x4E>(v));
-    v = fmaxf(v, dppf<0x141>(v));
-    v = fmaxf(v, dppf<0x140>(v));
-    return v;
-}
-
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dppf_rm(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
-}
 
 // Issue the loads of a layer's FIRST register set (16 values per lane) -- called one phase ahead of the
 // layer that consumes it (before the previous layer's epilogue and the barrier), so the L2 latency of a
@@ -366,9 +349,6 @@ __global__ __launch_bounds__(256 * WN) __attribute__((amdgpu_waves_per_eu(4, 8))
 // The A operand (weights) streams from L2 exactly as in sa_fused_kernel, one 16-register set ahead, with
 // the hand-over between layers prefetched before the epilogue.  Same k-ascending fmaf chain: bit-identical.
 // =====================================================================================================
-constexpr int pad32c(int c) { return (c + 31) / 32 * 32; }
-constexpr int pad128c(int c) { return (c + 127) / 128 * 128; }
-
 struct SwParams {
     int b, n, m, k;
     const float *feat, *xyz_cn, *new_xyz;
@@ -377,153 +357,6 @@ struct SwParams {
     float *out;
     int out_ctotal, co_off;
 };
-
-constexpr int SW_KS = 8;  // k-steps per register set and tile; a set = 2 tiles x 8 = 16 registers
-
-template <int CIN, int COUT>
-struct SwShape {
-    static constexpr int KST = (CIN + 1) / 2;                 // MFMA k-steps (2 rows each)
-    static constexpr int NSETS = (KST + SW_KS - 1) / SW_KS;
-    static constexpr int NT = (COUT + 31) / 32;               // 32-row output tiles
-    static constexpr int NPASS = (NT + 1) / 2;                // two tiles (independent accumulators) per pass
-    static constexpr int STEPS = NPASS * NSETS;
-    static constexpr int LDW = pad128c(COUT), KP = pad32c(CIN);
-};
-
-// loads of set `c` of pass `ps` into dst[tm*8 + j]
-template <int CIN, int COUT>
-__device__ __forceinline__ void sw_load_set(float (&dst)[16], const __amdgpu_buffer_rsrc_t rsrc, int voff, int ps, int c) {
-    using S = SwShape<CIN, COUT>;
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-        for (int j = 0; j < SW_KS; ++j) {
-            const int kk = c * SW_KS + j, t = 2 * ps + tm;
-            if (kk < S::KST && t < S::NT)
-                dst[tm * SW_KS + j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, ((2 * kk) * S::LDW + 32 * t) * 4, 0));
-        }
-}
-
-template <int CIN, int COUT>
-__device__ __forceinline__ void sw_first_set(float (&dst)[16], const float *wt, int lane) {
-    using S = SwShape<CIN, COUT>;
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)wt, 0, S::KP * S::LDW * 4, 0x00020000);
-    sw_load_set<CIN, COUT>(dst, rsrc, ((lane >> 5) * S::LDW + (lane & 31)) * 4, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-}
-
-__device__ __forceinline__ void sw_bias_init(f32x16 &acc, const float *bias_lds, int t, int lane) {
-    const float4 *bp = reinterpret_cast<const float4 *>(bias_lds + 32 * t + 4 * (lane >> 5));
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const float4 b4 = bp[2 * q];
-        acc[4 * q + 0] = b4.x; acc[4 * q + 1] = b4.y; acc[4 * q + 2] = b4.z; acc[4 * q + 3] = b4.w;
-    }
-}
-
-// ReLU, then turn output tile t (rows 32t..32t+31) into B operands hout[16t..16t+15] (k-step = row pair)
-template <int NOUT>
-__device__ __forceinline__ void sw_mid_epilogue(const f32x16 &acc, int t, float (&hout)[NOUT]) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        float a[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) a[i] = acc[4 * q + i] > 0.f ? acc[4 * q + i] : 0.f;
-        // registers (4q, 4q+1) hold rows (8q, 8q+1) in the lower half-wave and (8q+4, 8q+5) in the upper one
-        const auto p01 = __builtin_amdgcn_permlane32_swap(__float_as_uint(a[0]), __float_as_uint(a[1]), false, false);
-        const auto p23 = __builtin_amdgcn_permlane32_swap(__float_as_uint(a[2]), __float_as_uint(a[3]), false, false);
-        const int k0 = 16 * t + 4 * q;
-        if (k0 + 0 < NOUT) hout[k0 + 0] = __uint_as_float(p01[0]);  // rows 8q,   8q+1
-        if (k0 + 1 < NOUT) hout[k0 + 1] = __uint_as_float(p23[0]);  // rows 8q+2, 8q+3
-        if (k0 + 2 < NOUT) hout[k0 + 2] = __uint_as_float(p01[1]);  // rows 8q+4, 8q+5
-        if (k0 + 3 < NOUT) hout[k0 + 3] = __uint_as_float(p23[1]);  // rows 8q+6, 8q+7
-    }
-}
-
-// Non-negative floats order like their bit patterns, so after ReLU the 32-position max runs in the integer
-// domain: v_max_i32 with a DPP source operand (one instruction per step, no NaN-canonicalising extra max).
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ int dpp_max_i32(int v) {
-    // full row mask: every lane has a valid source (quad_perm / mirrors), so "old" is dead and bound_ctrl lets the
-    // compiler fold the DPP move into the max; partial row mask (row_bcast): masked-off lanes keep v
-    const int o = ROW_MASK == 0xF ? __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true)
-                                  : __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xF, false);
-    return o > v ? o : v;
-}
-
-// ReLU + max over the wave's 32 positions of output tile t -> red[row][wave]
-template <int COUT, int RED_STRIDE = 4>
-__device__ __forceinline__ void sw_last_epilogue(const f32x16 &acc, int t, float *red, int wave, int lane) {
-    int v[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int x = __float_as_int(acc[r]);
-        v[r] = x > 0 ? x : 0;  // ReLU on the bit pattern: negative floats (and -0) are negative integers
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = dpp_max_i32<0xB1, 0xF>(v[r]);   // quad_perm [1,0,3,2]
-#pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = dpp_max_i32<0x4E, 0xF>(v[r]);   // quad_perm [2,3,0,1]
-#pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = dpp_max_i32<0x141, 0xF>(v[r]);  // row_half_mirror
-#pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = dpp_max_i32<0x140, 0xF>(v[r]);  // row_mirror: every lane holds its row-of-16 max
-#pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = dpp_max_i32<0x142, 0xA>(v[r]);  // row_bcast15 into rows 1, 3: the 32-lane max
-    if ((lane & 31) == 16) {
-        float *rp = red + (32 * t + 4 * (lane >> 5)) * RED_STRIDE + wave;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int ro = (r & 3) + 8 * (r >> 2);
-            if (32 * t + ro + 4 < COUT || 32 * t + ro + 4 * (lane >> 5) < COUT) rp[ro * RED_STRIDE] = __int_as_float(v[r]);
-        }
-    }
-}
-
-// One layer whose input activations are B-operand registers hin[].  START = parity of the register set
-// that holds this layer's first weight set (loaded by the previous phase); `next` loads the following
-// layer's first set into the set after this layer's last one.
-template <int CIN, int COUT, bool LAST, int START, int NIN, int NOUT, typename Next>
-__device__ __forceinline__ void sw_layer_reg(const float *wt, const float *bias_lds, const float (&hin)[NIN], float (&hout)[NOUT],
-                                             float (&s)[2][16], float *red, int wave, int lane, Next next) {
-    using S = SwShape<CIN, COUT>;
-    static_assert(NIN >= S::KST, "input operand array too small");
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)wt, 0, S::KP * S::LDW * 4, 0x00020000);
-    const int voff = ((lane >> 5) * S::LDW + (lane & 31)) * 4;
-    f32x16 acc[2];
-#pragma unroll
-    for (int g = 0; g < S::STEPS; ++g) {
-        const int ps = g / S::NSETS, c = g % S::NSETS;
-        if (c == 0) {
-#pragma unroll
-            for (int tm = 0; tm < 2; ++tm)
-                if (2 * ps + tm < S::NT) sw_bias_init(acc[tm], bias_lds, 2 * ps + tm, lane);
-        }
-        if (g + 1 < S::STEPS) {
-            sw_load_set<CIN, COUT>(s[(START + g + 1) & 1], rsrc, voff, (g + 1) / S::NSETS, (g + 1) % S::NSETS);
-        } else {
-            next(s[(START + g + 1) & 1]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < SW_KS; ++j)
-#pragma unroll
-            for (int tm = 0; tm < 2; ++tm) {
-                const int kk = c * SW_KS + j;
-                if (kk < S::KST && 2 * ps + tm < S::NT)
-                    acc[tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(s[(START + g) & 1][tm * SW_KS + j], hin[kk], acc[tm], 0, 0, 0);
-            }
-        __builtin_amdgcn_sched_barrier(0);
-        if (c == S::NSETS - 1) {
-#pragma unroll
-            for (int tm = 0; tm < 2; ++tm)
-                if (2 * ps + tm < S::NT) {
-                    if (LAST) sw_last_epilogue<COUT>(acc[tm], 2 * ps + tm, red, wave, lane);
-                    else sw_mid_epilogue<NOUT>(acc[tm], 2 * ps + tm, hout);
-                }
-        }
-    }
-}
 
 // First layer of a wide input (CF feature rows + 3 xyz rows, CF % 8 == 0, C1 <= 128): the B operand is
 // gathered from global memory chunk by chunk (4 k-steps = 8 feature rows of the wave's 32 neighbours),
@@ -644,12 +477,12 @@ void sa_wave_kernel(SwParams p) {
                 else if (row < CIN1) v = p.xyz_cn[((size_t)b * 3 + (row - CF)) * p.n + id] - (row - CF == 0 ? ctr[0] : (row - CF == 1 ? ctr[1] : ctr[2]));
                 x1[j] = v;
             }
-            sw_layer_reg<CIN1, C1, false, 0>(p.w1, bias_lds, x1, h1, s, red, wave, lane, next2);
+            sw_layer_reg<CIN1, C1, SW_EPI_MID, 0>(p.w1, bias_lds, x1, h1, s, red, wave, lane, next2);
         } else {
             sw_layer1_gather<CF, C1>(p, b, id, ctr, bias_lds, h1, lane, [&]() { sw_first_set<C1, C2>(s[0], p.w2, lane); });
         }
-        sw_layer_reg<C1, C2, false, START2>(p.w2, bias_lds + SF_MAXC, h1, h2, s, red, wave, lane, next3);
-        sw_layer_reg<C2, C3, true, START3>(p.w3, bias_lds + 2 * SF_MAXC, h2, none, s, red, wave, lane, next_none);
+        sw_layer_reg<C1, C2, SW_EPI_MID, START2>(p.w2, bias_lds + SF_MAXC, h1, h2, s, red, wave, lane, next3);
+        sw_layer_reg<C2, C3, SW_EPI_MAX, START3>(p.w3, bias_lds + 2 * SF_MAXC, h2, none, s, red, wave, lane, next_none);
     }
     __syncthreads();
     const int tiles_per_group = p.k / 32;

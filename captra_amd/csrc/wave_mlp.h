@@ -1,0 +1,207 @@
+// Register-resident shared-MLP building blocks for gfx950 (wave64, v_mfma_f32_32x32x2_f32), shared by
+// sa_fused.hip (set-abstraction scales) and mlp_chain.hip (dense layer chains).
+//
+// A wave owns 32 positions and carries them through consecutive 1x1-conv layers.  The MFMA accumulator layout
+// (register r of lane l = row 8(r>>2)+(r&3)+4(l>>5), column l&31) becomes the next layer's B operand (lane-half h
+// of k-step j = row 2j+h) with one v_permlane32_swap per register pair (sw_mid_epilogue), so activations never
+// leave the vector registers.  Weights are the packed W'^T of captra_pack_weights (ceil32(cin) x ceil128(cout),
+// zero padded) streamed with buffer loads (scalar k offset) one 16-register set ahead of the MFMAs (sw_layer_reg).
+// Accumulators start from the bias and K ascends within one wave: the k-ascending fmaf chain of the oracle.
+#pragma once
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int CTRL>
+__device__ __forceinline__ float dppf(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float row16_maxf(float v) {
+    v = fmaxf(v, dppf<0xB1>(v));
+    v = fmaxf(v, dppf<0x4E>(v));
+    v = fmaxf(v, dppf<0x141>(v));
+    v = fmaxf(v, dppf<0x140>(v));
+    return v;
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dppf_rm(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
+
+constexpr int pad32c(int c) { return (c + 31) / 32 * 32; }
+constexpr int pad128c(int c) { return (c + 127) / 128 * 128; }
+
+constexpr int SW_KS = 8;  // k-steps per register set and tile; a set = 2 tiles x 8 = 16 registers
+
+template <int CIN, int COUT>
+struct SwShape {
+    static constexpr int KST = (CIN + 1) / 2;                 // MFMA k-steps (2 rows each)
+    static constexpr int NSETS = (KST + SW_KS - 1) / SW_KS;
+    static constexpr int NT = (COUT + 31) / 32;               // 32-row output tiles
+    static constexpr int NPASS = (NT + 1) / 2;                // two tiles (independent accumulators) per pass
+    static constexpr int STEPS = NPASS * NSETS;
+    static constexpr int LDW = pad128c(COUT), KP = pad32c(CIN);
+};
+
+// loads of set `c` of pass `ps` into dst[tm*8 + j]
+template <int CIN, int COUT>
+__device__ __forceinline__ void sw_load_set(float (&dst)[16], const __amdgpu_buffer_rsrc_t rsrc, int voff, int ps, int c) {
+    using S = SwShape<CIN, COUT>;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int j = 0; j < SW_KS; ++j) {
+            const int kk = c * SW_KS + j, t = 2 * ps + tm;
+            if (kk < S::KST && t < S::NT)
+                dst[tm * SW_KS + j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, ((2 * kk) * S::LDW + 32 * t) * 4, 0));
+        }
+}
+
+template <int CIN, int COUT>
+__device__ __forceinline__ void sw_first_set(float (&dst)[16], const float *wt, int lane) {
+    using S = SwShape<CIN, COUT>;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)wt, 0, S::KP * S::LDW * 4, 0x00020000);
+    sw_load_set<CIN, COUT>(dst, rsrc, ((lane >> 5) * S::LDW + (lane & 31)) * 4, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+__device__ __forceinline__ void sw_bias_init(f32x16 &acc, const float *bias_lds, int t, int lane) {
+    const float4 *bp = reinterpret_cast<const float4 *>(bias_lds + 32 * t + 4 * (lane >> 5));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 b4 = bp[2 * q];
+        acc[4 * q + 0] = b4.x; acc[4 * q + 1] = b4.y; acc[4 * q + 2] = b4.z; acc[4 * q + 3] = b4.w;
+    }
+}
+
+// ReLU, then turn output tile t (rows 32t..32t+31) into B operands hout[16t..16t+15] (k-step = row pair)
+template <int NOUT>
+__device__ __forceinline__ void sw_mid_epilogue(const f32x16 &acc, int t, float (&hout)[NOUT]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float a[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = acc[4 * q + i] > 0.f ? acc[4 * q + i] : 0.f;
+        // registers (4q, 4q+1) hold rows (8q, 8q+1) in the lower half-wave and (8q+4, 8q+5) in the upper one
+        const auto p01 = __builtin_amdgcn_permlane32_swap(__float_as_uint(a[0]), __float_as_uint(a[1]), false, false);
+        const auto p23 = __builtin_amdgcn_permlane32_swap(__float_as_uint(a[2]), __float_as_uint(a[3]), false, false);
+        const int k0 = 16 * t + 4 * q;
+        if (k0 + 0 < NOUT) hout[k0 + 0] = __uint_as_float(p01[0]);  // rows 8q,   8q+1
+        if (k0 + 1 < NOUT) hout[k0 + 1] = __uint_as_float(p23[0]);  // rows 8q+2, 8q+3
+        if (k0 + 2 < NOUT) hout[k0 + 2] = __uint_as_float(p01[1]);  // rows 8q+4, 8q+5
+        if (k0 + 3 < NOUT) hout[k0 + 3] = __uint_as_float(p23[1]);  // rows 8q+6, 8q+7
+    }
+}
+
+// Non-negative floats order like their bit patterns, so after ReLU the 32-position max runs in the integer
+// domain: v_max_i32 with a DPP source operand (one instruction per step, no NaN-canonicalising extra max).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_max_i32(int v) {
+    // full row mask: every lane has a valid source (quad_perm / mirrors), so "old" is dead and bound_ctrl lets the
+    // compiler fold the DPP move into the max; partial row mask (row_bcast): masked-off lanes keep v
+    const int o = ROW_MASK == 0xF ? __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true)
+                                  : __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xF, false);
+    return o > v ? o : v;
+}
+
+// ReLU + max over the wave's 32 positions of output tile t -> red[row][wave]
+template <int COUT, int RED_STRIDE = 4>
+__device__ __forceinline__ void sw_last_epilogue(const f32x16 &acc, int t, float *red, int wave, int lane) {
+    int v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int x = __float_as_int(acc[r]);
+        v[r] = x > 0 ? x : 0;  // ReLU on the bit pattern: negative floats (and -0) are negative integers
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = dpp_max_i32<0xB1, 0xF>(v[r]);   // quad_perm [1,0,3,2]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = dpp_max_i32<0x4E, 0xF>(v[r]);   // quad_perm [2,3,0,1]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = dpp_max_i32<0x141, 0xF>(v[r]);  // row_half_mirror
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = dpp_max_i32<0x140, 0xF>(v[r]);  // row_mirror: every lane holds its row-of-16 max
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = dpp_max_i32<0x142, 0xA>(v[r]);  // row_bcast15 into rows 1, 3: the 32-lane max
+    if ((lane & 31) == 16) {
+        float *rp = red + (32 * t + 4 * (lane >> 5)) * RED_STRIDE + wave;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ro = (r & 3) + 8 * (r >> 2);
+            if (32 * t + ro + 4 < COUT || 32 * t + ro + 4 * (lane >> 5) < COUT) rp[ro * RED_STRIDE] = __int_as_float(v[r]);
+        }
+    }
+}
+
+// One layer whose input activations are B-operand registers hin[].  START = parity of the register set
+// that holds this layer's first weight set (loaded by the previous phase); `next` loads the following
+// layer's first set into the set after this layer's last one.
+enum { SW_EPI_MID = 0, SW_EPI_MAX = 1, SW_EPI_STORE = 2 };
+
+// destination of a SW_EPI_STORE layer: y points at this wave's first column of output row 0
+struct SwStore {
+    float *y = nullptr;
+    long long ld = 0;   // elements between output rows
+    bool col_ok = true; // this lane's column exists
+    int act = 1;        // ACT_* of common.h
+};
+
+// act + store of output tile t: rows 32t.. of y[row*ld + lane&31]
+template <int COUT>
+__device__ __forceinline__ void sw_store_epilogue(const f32x16 &acc, int t, const SwStore &st, int lane) {
+    if (!st.col_ok) return;
+    float *yp = st.y + (size_t)(32 * t + 4 * (lane >> 5)) * st.ld + (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int ro = (r & 3) + 8 * (r >> 2);
+        if (32 * t + ro + 4 < COUT || 32 * t + ro + 4 * (lane >> 5) < COUT) yp[(size_t)ro * st.ld] = apply_act(acc[r], st.act);
+    }
+}
+
+template <int CIN, int COUT, int EPI, int START, int NIN, int NOUT, typename Next>
+__device__ __forceinline__ void sw_layer_reg(const float *wt, const float *bias_lds, const float (&hin)[NIN], float (&hout)[NOUT],
+                                             float (&s)[2][16], float *red, int wave, int lane, Next next, const SwStore &st = SwStore()) {
+    using S = SwShape<CIN, COUT>;
+    static_assert(NIN >= S::KST, "input operand array too small");
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)wt, 0, S::KP * S::LDW * 4, 0x00020000);
+    const int voff = ((lane >> 5) * S::LDW + (lane & 31)) * 4;
+    f32x16 acc[2];
+#pragma unroll
+    for (int g = 0; g < S::STEPS; ++g) {
+        const int ps = g / S::NSETS, c = g % S::NSETS;
+        if (c == 0) {
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+                if (2 * ps + tm < S::NT) sw_bias_init(acc[tm], bias_lds, 2 * ps + tm, lane);
+        }
+        if (g + 1 < S::STEPS) {
+            sw_load_set<CIN, COUT>(s[(START + g + 1) & 1], rsrc, voff, (g + 1) / S::NSETS, (g + 1) % S::NSETS);
+        } else {
+            next(s[(START + g + 1) & 1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < SW_KS; ++j)
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm) {
+                const int kk = c * SW_KS + j;
+                if (kk < S::KST && 2 * ps + tm < S::NT)
+                    acc[tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(s[(START + g) & 1][tm * SW_KS + j], hin[kk], acc[tm], 0, 0, 0);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        if (c == S::NSETS - 1) {
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+                if (2 * ps + tm < S::NT) {
+                    if (EPI == SW_EPI_MAX) sw_last_epilogue<COUT>(acc[tm], 2 * ps + tm, red, wave, lane);
+                    else if (EPI == SW_EPI_STORE) sw_store_epilogue<COUT>(acc[tm], 2 * ps + tm, st, lane);
+                    else sw_mid_epilogue<NOUT>(acc[tm], 2 * ps + tm, hout);
+                }
+        }
+    }
+}
+
+}  // namespace

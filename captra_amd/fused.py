@@ -88,6 +88,33 @@ def pointwise_mlp(x, lin: PackedLinear, act: int = ACT_RELU, out=None):
     return out
 
 
+USE_MLP_CHAIN = True     # three dense layers in one launch where the shape is instantiated (else layer by layer)
+_CHAIN3_SHAPES = {(134, 128, 128, 128), (131, 128, 128, 128)}   # csrc/mlp_chain.hip CHAIN_CASE list
+
+
+def mlp_chain3(x, layers, act3: int = ACT_RELU):
+    """x (B,c0,*) -> act3(W3 relu(W2 relu(W1 x + b1) + b2) + b3) (B,c3,*): one launch when (c0,c1,c2,c3) is an
+    instantiated shape of captra_mlp_chain3, otherwise three captra_pointwise_mlp launches (same bits)."""
+    assert len(layers) == 3
+    shape = (layers[0].cin, layers[0].cout, layers[1].cout, layers[2].cout)
+    assert x.shape[1] == shape[0] and layers[1].cin == shape[1] and layers[2].cin == shape[2], (x.shape, shape)
+    B = x.shape[0]
+    l = x.numel() // max(B * shape[0], 1)
+    if not (USE_MLP_CHAIN and shape in _CHAIN3_SHAPES and shape[0] * l * 4 < (1 << 31)):
+        y = pointwise_mlp(x, layers[0], ACT_RELU)
+        y = pointwise_mlp(y, layers[1], ACT_RELU)
+        return pointwise_mlp(y, layers[2], act3)
+    L.require_device(x, *(t for lin in layers for t in (lin.wt, lin.bias)))
+    out = torch.empty((B, shape[3]) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        L.call("captra_mlp_chain3", B, shape[0], shape[1], shape[2], shape[3], l, L.ptr(x),
+               L.ptr(layers[0].wt), L.ptr(layers[0].bias), L.ptr(layers[1].wt), L.ptr(layers[1].bias),
+               L.ptr(layers[2].wt), L.ptr(layers[2].bias), act3, L.ptr(out))
+    _work("mlp_chain3", flops=2.0 * B * l * (shape[0] * shape[1] + shape[1] * shape[2] + shape[2] * shape[3]),
+          nbytes=4.0 * B * l * (shape[0] + shape[3]))
+    return out
+
+
 def sa_group_mlp(feat, xyz_cn, new_xyz_n3, idx, lin: PackedLinear):
     """First SA layer with group + centre-subtract + concat fused into the load -> (B,cout,M,K)."""
     wt, bias = lin.wt, lin.bias

@@ -152,6 +152,15 @@ int captra_sa_scale_fused(int b, int n, int m, int k, int cfeat, int c1, int c2,
                           const float *b1, const float *w2, const float *b2, const float *w3, const float *b3,
                           float *out, int out_ctotal, int co_off, captra_stream_t stream);
 
+/* Three dense layers in one launch: y (B,c3,l) = act3(W3 relu(W2 relu(W1 x + b1) + b2) + b3), x (B,c0,l); packed
+ * weights (captra_pack_weights).  Replaces the FP1 shared MLP + conv1/bn1/ReLU tail of PointNet2Msg
+ * (pointnet_utils.py:296-298, backbones.py:66-68) without the two intermediate (B,128,l) tensors.  Instantiated
+ * for (c0,c1,c2,c3) = (134,128,128,128) and (131,128,128,128); returns -2 for any other shape (run the layers
+ * with captra_pointwise_mlp then).  Bit-identical to three captra_pointwise_mlp calls. */
+int captra_mlp_chain3(int b, int c0, int c1, int c2, int c3, long long l, const float *x, const float *w1,
+                      const float *b1, const float *w2, const float *b2, const float *w3, const float *b3, int act3,
+                      float *y, captra_stream_t stream);
+
 /* Feature propagation input (pointnet_utils.py:280-294, CUDA semantics: weights from sqrt(d2), SURVEY.md
  * §2.2), in two halves so that networks looking at the same cloud share the geometric one:
  *   captra_three_nn_weights: unknown (B,N,3), known (B,S,3) -> idx (B,N,3) i32, weight (B,N,3) f32 with

@@ -130,6 +130,34 @@ def _sa_scale_fused_case(device, cfeat, chans, n, m, k):
     assert (got[:, :4] == -1).all() and (got[:, 4 + chans[2]:] == -1).all()
 
 
+@pytest.mark.parametrize("c0,l,act3", [(134, 4096, 1), (131, 1000, 1), (134, 77, 0), (131, 4096, 2), (100, 256, 1)])
+def test_mlp_chain3_bit_exact(device, c0, l, act3):
+    """Three dense layers in one launch == the oracle's layer-by-layer fmaf chains == three captra_pointwise_mlp
+    launches, bit for bit; ragged L, every final activation, and the fallback for a shape that is not instantiated."""
+    from captra_amd import fused
+    rng = np.random.default_rng(c0 + l + act3)
+    B = 3
+    x = rng.standard_normal((B, c0, l)).astype(np.float32)
+    dims = (c0, 128, 128, 128)
+    layers = [((rng.standard_normal((dims[i], dims[i + 1])) / np.sqrt(dims[i])).astype(np.float32),
+               rng.standard_normal(dims[i + 1]).astype(np.float32)) for i in range(3)]
+    packed = [fused.pack(_dev(w, device), _dev(b, device)) for w, b in layers]
+    got = fused.mlp_chain3(_dev(x, device), packed, act3).cpu().numpy()
+    ref = x
+    for i, (w, b) in enumerate(layers):
+        ref = O.pointwise_mlp(ref, w, b, 1 if i < 2 else act3)
+    if act3 == 2:   # sigmoid: device expf vs libm expf, not an exactness contract
+        np.testing.assert_allclose(got, ref, rtol=0, atol=2e-7)
+    else:
+        np.testing.assert_array_equal(got, ref)
+    fused.USE_MLP_CHAIN = False
+    try:
+        layered = fused.mlp_chain3(_dev(x, device), packed, act3).cpu().numpy()
+    finally:
+        fused.USE_MLP_CHAIN = True
+    np.testing.assert_array_equal(got, layered)
+
+
 def test_backbone_layer_by_layer_kernels_equal_fused_scale(device):
     """USE_SA_FUSED off routes the SA scales through sa_group_mlp / pointwise_mlp / mlp_max: same bits."""
     from captra_amd import fused
@@ -143,10 +171,12 @@ def test_backbone_layer_by_layer_kernels_equal_fused_scale(device):
     with torch.no_grad():
         a = net(cloud_cn).cpu().numpy()
         fused.USE_SA_FUSED = False
+        fused.USE_MLP_CHAIN = False
         try:
             b = net(cloud_cn).cpu().numpy()
         finally:
             fused.USE_SA_FUSED = True
+            fused.USE_MLP_CHAIN = True
     np.testing.assert_array_equal(a, b)
 
 

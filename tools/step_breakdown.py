@@ -61,6 +61,9 @@ def main():
         elif name == "captra_sa_scale_fused":
             b, n, m, k, cf, c1, c2, c3 = ints[:8]
             tf = f"{2.0 * b * m * k * ((cf + 3) * c1 + c1 * c2 + c2 * c3) / us / 1e6:8.1f}"
+        elif name == "captra_mlp_chain3":
+            b, c0, c1, c2, c3, l = ints[:6]
+            tf = f"{2.0 * b * l * (c0 * c1 + c1 * c2 + c2 * c3) / us / 1e6:8.1f}"
         elif name == "captra_mlp_max":
             b, cin, cout, m, k = ints[:5]
             tf = f"{2.0 * b * cin * cout * m * k / us / 1e6:8.1f}"
