@@ -356,7 +356,15 @@ struct SwParams {
     const float *w1, *b1, *w2, *b2, *w3, *b3;
     float *out;
     int out_ctotal, co_off;
+    unsigned long long *prof;  // debug: per-phase wave-cycle totals of a sample of waves (sa_wave_kernel), else null
 };
+
+#define SW_TICK(slot)                                                         \
+    if (p.prof != nullptr) {                                                  \
+        const unsigned long long t_now = __builtin_amdgcn_s_memtime();        \
+        if (lane == 0 && sampled) atomicAdd(p.prof + (slot), t_now - t_last); \
+        t_last = t_now;                                                       \
+    }
 
 // First layer of a wide input (CF feature rows + 3 xyz rows, CF % 8 == 0, C1 <= 128): the B operand is
 // gathered from global memory chunk by chunk (4 k-steps = 8 feature rows of the wave's 32 neighbours),
@@ -447,6 +455,10 @@ void sa_wave_kernel(SwParams p) {
     float s[2][16];
     int id = 0;
     float ctr[3] = {0.f, 0.f, 0.f};
+    const bool sampled = (blockIdx.x + blockIdx.y) % 61 == 0;
+    unsigned long long t_last = p.prof != nullptr ? __builtin_amdgcn_s_memtime() : 0ull;
+    const unsigned long long t_first = t_last;
+    const unsigned long long r_first = p.prof != nullptr ? __builtin_amdgcn_s_memrealtime() : 0ull;
     if (active) {
         id = p.idx[(size_t)b * L + wpos + (lane & 31)];
         const float *cp = p.new_xyz + ((size_t)b * p.m + (int)(wpos / p.k)) * 3;
@@ -460,6 +472,7 @@ void sa_wave_kernel(SwParams p) {
         bias_lds[e] = c < pad128c(cl) ? bl[c] : 0.f;
     }
     __syncthreads();
+    SW_TICK(0)
     if (active) {
         float h1[S2::KST], h2[S3::KST], none[1];
         auto next2 = [&](float (&dst)[16]) { sw_first_set<C1, C2>(dst, p.w2, lane); };
@@ -481,10 +494,19 @@ void sa_wave_kernel(SwParams p) {
         } else {
             sw_layer1_gather<CF, C1>(p, b, id, ctr, bias_lds, h1, lane, [&]() { sw_first_set<C1, C2>(s[0], p.w2, lane); });
         }
+        SW_TICK(1)
         sw_layer_reg<C1, C2, SW_EPI_MID, START2>(p.w2, bias_lds + SF_MAXC, h1, h2, s, red, wave, lane, next3);
+        SW_TICK(2)
         sw_layer_reg<C2, C3, SW_EPI_MAX, START3>(p.w3, bias_lds + 2 * SF_MAXC, h2, none, s, red, wave, lane, next_none);
+        SW_TICK(3)
     }
     __syncthreads();
+    SW_TICK(4)
+    if (p.prof != nullptr && lane == 0 && sampled) {
+        atomicAdd(p.prof + 9, 1ull);
+        atomicAdd(p.prof + 5, t_last - t_first);                                  // shader cycles of this wave's life
+        atomicAdd(p.prof + 6, __builtin_amdgcn_s_memrealtime() - r_first);        // same span in 100 MHz ticks
+    }
     const int tiles_per_group = p.k / 32;
     const int groups = SF_POS / p.k;
     for (int e = tid; e < C3 * groups; e += 256) {
@@ -690,12 +712,12 @@ extern "C" int captra_sa_scale_fused(int b, int n, int m, int k, int cfeat, int 
     p.feat = feat; p.xyz_cn = xyz_cn; p.new_xyz = new_xyz; p.idx = idx;
     p.w1 = w1; p.b1 = b1; p.w2 = w2; p.b2 = b2; p.w3 = w3; p.b3 = b3;
     p.out = out; p.out_ctotal = out_ctotal; p.co_off = co_off; p.ablate = g_sa_ablate; p.prof = g_sa_prof;
-    if (g_sa_mode != 1 && g_sa_prof == nullptr && g_sa_ablate == 0) {
+    if (g_sa_mode != 1 && g_sa_ablate == 0) {
         // register-resident kernels for the channel shapes of the CAPTRA backbone (network/models/pointnet_utils.py
         // PointNet2Msg config); any other shape takes the generic LDS kernel below
         SwParams q;
         q.b = b; q.n = n; q.m = m; q.k = k; q.feat = feat; q.xyz_cn = xyz_cn; q.new_xyz = new_xyz; q.idx = idx;
-        q.w1 = w1; q.b1 = b1; q.w2 = w2; q.b2 = b2; q.w3 = w3; q.b3 = b3; q.out = out; q.out_ctotal = out_ctotal; q.co_off = co_off;
+        q.w1 = w1; q.b1 = b1; q.w2 = w2; q.b2 = b2; q.w3 = w3; q.b3 = b3; q.out = out; q.out_ctotal = out_ctotal; q.co_off = co_off; q.prof = g_sa_prof;
         const long long Lw = (long long)m * k;
         dim3 gridw((unsigned)((Lw + SF_POS - 1) / SF_POS), b);
         // small-input scales: persistent workgroups with the weights resident in LDS (mode 2 = streaming kernel for all)

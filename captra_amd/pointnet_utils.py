@@ -306,14 +306,17 @@ class PointNetSetAbstraction(_FoldCache, nn.Module):
         B, C, N = xyz.shape
         x = torch.cat([xyz, points], dim=1) if _has_points(points) else xyz       # (B,3+D,N), xyz first
         new_xyz = torch.zeros(B, C, 1, device=xyz.device, dtype=xyz.dtype)
-        if (not self.training) and xyz.is_cuda and N % 32 == 0 and 128 % N == 0:
+        if (not self.training) and xyz.is_cuda and N % 32 == 0 and (128 % N == 0 or N % 128 == 0):
+            # the fused max handles groups of 32 / 64 / 128 positions: a larger cloud is pooled as N/128 groups
+            # of 128 and the group maxima are maxed again (max is exact, so the split does not change a bit)
             folded = self._fold(xyz.device)
-            y = x.contiguous().view(B, x.shape[1], 1, N)
+            groups, k = (1, N) if N <= 128 else (N // 128, 128)
+            y = x.contiguous().view(B, x.shape[1], groups, k)
             for lin in folded[:-1]:
                 y = fused.pointwise_mlp(y, lin, fused.ACT_RELU)
-            out = torch.empty(B, self.out_channel, 1, dtype=torch.float32, device=xyz.device)
+            out = torch.empty(B, self.out_channel, groups, dtype=torch.float32, device=xyz.device)
             fused.mlp_max(y, folded[-1], out, 0)
-            return new_xyz, out
+            return new_xyz, (out if groups == 1 else out.max(dim=2, keepdim=True)[0])
         y = x.unsqueeze(-1)                                                        # (B,3+D,N,1)
         for conv, bn in zip(self.mlp_convs, self.mlp_bns):
             y = F.relu(bn(conv(y)))

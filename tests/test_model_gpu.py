@@ -346,6 +346,30 @@ def test_backbone_vs_golden_and_oracle(device, tag, use_xyz, seed):
     np.testing.assert_array_equal(out.cpu().numpy(), ref)
 
 
+def test_backbone_16384_point_clouds_bit_exact_vs_oracle(device):
+    """BASELINE.json configs[4] shape: S-uni16k clouds (16384 points uniform in a cube), sa1.npoint 2048,
+    sa2.npoint 512, radii / nsample / MLPs unchanged.  FPS runs 2047 rounds over 16384 points,
+    the ball query scans two LDS tiles, every SA scale has 4x the centres: the backbone output still equals the
+    oracle's exact mode bit for bit."""
+    import copy
+    from captra_amd.backbones import PointNet2Msg
+    from captra_amd.configs import make_config
+    cfg = copy.deepcopy(make_config("1"))
+    cfg["pointnet"]["camera"]["sa1"]["npoint"] = 2048
+    cfg["pointnet"]["camera"]["sa2"]["npoint"] = 512
+    net = PointNet2Msg(cfg, 128, use_xyz_feat=False)
+    sd = make_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, seed=21)
+    net.load_state_dict(sd)
+    net = net.to(device).eval()
+    cloud = np.stack([clouds.s_uni(5, 16384)]).astype(np.float32)              # (1,N,3)
+    cloud_cn = np.ascontiguousarray(cloud.transpose(0, 2, 1))
+    with torch.no_grad():
+        out = net(_dev(cloud_cn, device)).cpu().numpy()
+    ref = OM.backbone({"bb." + k: v for k, v in sd.items()}, "bb", cfg["pointnet"]["camera"], cloud_cn, False, mlp="exact")
+    assert out.shape == (1, 128, 16384)
+    np.testing.assert_array_equal(out, ref)
+
+
 def test_backbone_train_mode_path_matches_fused(device):
     """The layer-by-layer (autograd) path and the fused eval path agree in eval statistics."""
     from captra_amd.backbones import PointNet2Msg
@@ -456,3 +480,49 @@ def test_checkpoint_roundtrip_and_coordnet_key_mapping(device, tmp_path):
     assert dst.resume() == 7
     for k, v in dst.model.state_dict().items():
         np.testing.assert_array_equal(v.cpu().numpy(), sd[k].numpy(), err_msg=k)
+
+
+def test_track_cli_matches_trainer_and_writes_result_pickles(device, tmp_path):
+    """`python -m captra_amd.track` (counterpart of network/test.py): trajectory .npz files -> resume both experiments
+    -> Trainer.test per batch -> the reference's result pickles; its poses equal a direct Trainer.test call."""
+    import pickle
+    from captra_amd import track
+    from captra_amd.configs import make_config
+    from captra_amd.trainer import Trainer
+    from captra_amd.trajectory_io import save_trajectory_npz
+    coord_dir, rot_dir, data_dir = tmp_path / "coord", tmp_path / "rot", tmp_path / "data"
+    for d in (coord_dir / "ckpt", rot_dir / "ckpt", data_dir):
+        d.mkdir(parents=True)
+    # zero pose-perturbation amplitudes: the initial pose is then independent of the RNG state at the draw
+    zero_noise = {"pose_perturb/r": 0.0, "pose_perturb/t": 0.0, "pose_perturb/s": 0.0}
+    cfg = make_config("1", experiment_dir=str(rot_dir), **{"coord_exp/dir": str(coord_dir)}, **zero_noise)
+    src = Trainer(cfg)
+    sd = make_state_dict({k: tuple(v.shape) for k, v in src.model.state_dict().items()}, seed=9)
+    torch.save({"epoch": 1, "iteration": 1, "model": {"net" + k[len("npcs_net"):]: v for k, v in sd.items() if k.startswith("npcs_net.")}},
+               coord_dir / "ckpt" / "model_0001.pt")
+    torch.save({"epoch": 2, "iteration": 1, "model": {k: v for k, v in sd.items() if k.startswith("net.")}},
+               rot_dir / "ckpt" / "model_0002.pt")
+    frames = clouds.make_trajectory("nocs", 2, 4, seed=3)
+    for b in range(2):
+        save_trajectory_npz(str(data_dir / f"traj{b}.npz"), frames, b)
+    torch.manual_seed(0)
+    np.random.seed(0)
+    res = track.main(["--obj_category", "1", "--experiment_dir", str(rot_dir), "--coord_exp/dir", str(coord_dir),
+                      "--batch_size", "2", "--data", str(data_dir), "--save",
+                      "--pose_perturb/r", "0", "--pose_perturb/t", "0", "--pose_perturb/s", "0"])
+    assert res["frames"] == 8 and any(k.startswith("avg_pred/") for k in res["loss"]), res
+    out = sorted((rot_dir / "results" / "data").glob("*.pkl"))
+    assert len(out) == 2
+    # the same trajectories through Trainer.test directly (same seeds -> same initial pose noise)
+    ref = Trainer(cfg)
+    ref.resume()
+    torch.manual_seed(0)
+    np.random.seed(0)
+    pred, _ = ref.test(clouds.make_trajectory("nocs", 2, 4, seed=3))
+    with open(out[0], "rb") as fh:
+        saved = pickle.load(fh)
+    assert set(saved) == {"pred", "gt", "frame_nums"} and len(saved["pred"]["poses"]) == 4
+    for i in range(4):
+        for key in ("rotation", "translation", "scale"):
+            np.testing.assert_array_equal(np.asarray(saved["pred"]["poses"][i][key]).reshape(-1),
+                                          pred["poses"][i][key][0].cpu().numpy().reshape(-1))

@@ -66,3 +66,25 @@ def test_pose_all_gather_gloo_world2():
         p.join(120)
         assert p.exitcode == 0
     assert ret.get(0) and ret.get(1)
+
+
+def test_trajectory_npz_roundtrip(tmp_path):
+    """captra_amd/trajectory_io.py: frame dicts -> one .npz per trajectory -> batched frame dicts, unchanged."""
+    import numpy as np
+    import torch
+    from captra_amd.trajectory_io import load_trajectory_npz, save_trajectory_npz, stack_trajectories
+    from tests import clouds
+    frames = clouds.make_trajectory("arti", 3, 3, seed=1)
+    for b in range(3):
+        save_trajectory_npz(str(tmp_path / f"t{b}.npz"), frames, b)
+    back = stack_trajectories([load_trajectory_npz(str(tmp_path / f"t{b}.npz")) for b in range(3)])
+    assert len(back) == len(frames)
+    for f0, f1 in zip(frames, back):
+        for k in ("points", "labels", "nocs"):
+            assert torch.equal(f0[k], f1[k]) and f0[k].dtype == f1[k].dtype
+        assert f0["meta"]["path"] == f1["meta"]["path"]
+        assert torch.equal(f0["meta"]["points_mean"], f1["meta"]["points_mean"])
+        assert torch.equal(f0["meta"]["nocs_corners"], f1["meta"]["nocs_corners"])
+        for p0, p1 in zip(f0["meta"]["nocs2camera"], f1["meta"]["nocs2camera"]):
+            for k in ("rotation", "translation", "scale"):
+                np.testing.assert_array_equal(p0[k].numpy(), p1[k].numpy())

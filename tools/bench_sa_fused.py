@@ -75,8 +75,11 @@ def main():
             _lib.lib().captra_sa_fused_set_prof(ctypes.c_void_p(0))
             c = cnt.tolist()
             waves = max(c[9], 1)
-            labels = ["gather", "bar", "L1", "bar", "L2", "bar", "L3", "bar"]
-            print(f"  {name}: per-wave cycles, kernel {c[8] / waves:.0f}: " + "  ".join(f"{l} {c[i] / waves:.0f}" for i, l in enumerate(labels)))
+            labels = ["gather", "bar", "L1", "bar", "L2", "bar", "L3", "bar"] if a.mode == 1 else ["start", "L1", "L2", "L3", "end-barrier"]
+            tot = c[8] / waves if a.mode == 1 else sum(c[:len(labels)]) / waves
+            if a.mode != 1 and c[6]:
+                print(f"  wave life: {c[5] / waves:.0f} shader cycles in {c[6] / waves / 100:.1f} us (s_memrealtime) -> shader clock {c[5] / c[6] * 0.1:.3f} GHz")
+            print(f"  {name}: per-wave cycles, kernel {tot:.0f}: " + "  ".join(f"{l} {c[i] / waves:.0f}" for i, l in enumerate(labels)))
         _lib.prof_reset(); _lib.prof_enable(True)
         for _ in range(a.iters):
             run()
