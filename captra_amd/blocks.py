@@ -144,9 +144,15 @@ class RotationRegressor(nn.Module):
                                                    last_activation="none") for _ in range(num_parts)])
         self.num_parts = num_parts
 
+    def raw(self, feat):
+        """feat (B,in_dim,N) -> (B,P,R,N): the heads' raw outputs (R = 3 | 6), before the per-point normalisation."""
+        if self.num_parts == 1:
+            return self.rtvec_head[0](feat).unsqueeze(1)
+        return torch.stack([head(feat) for head in self.rtvec_head], dim=1)
+
     def forward(self, feat):
         """feat (B,in_dim,N) -> (B,P,3,N) unit vectors or (B,P,9,N) row-major rotation matrices."""
-        raw = torch.stack([head(feat) for head in self.rtvec_head], dim=1)          # (B,P,R,N)
+        raw = self.raw(feat)                                                         # (B,P,R,N)
         per_point = raw.transpose(-1, -2)                                            # (B,P,N,R)
         shape = per_point.shape
         if self.sym:

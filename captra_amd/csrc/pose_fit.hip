@@ -276,7 +276,120 @@ __global__ __launch_bounds__(PF_THREADS) void procrustes_rot3_kernel(int n, cons
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Rotation read-out of the tracking step in one launch (one workgroup per (trajectory, part)):
+//   per point:  unit y-axis (symmetric, 3 outputs)  or  ortho6d -> rotation matrix (6 outputs)
+//               blocks.py:147-156 (RotationRegressor.forward), rotations.py:302-343
+//   pooled   =  masked mean over the points labelled with the part; (0,1,0) / identity when none
+//               networks.py:127-138
+//   dR       =  from_3d(pooled) (y-axis -> frame)  or  Gram-Schmidt on the columns of pooled
+//               part_dof_utils.py:137-141, rotations.py:356-387
+//   R        =  R_prev * dR                          part_dof_utils.py:124-134
+// Only head p on cloud (b,p) is evaluated (the reference computes all P x P and keeps the diagonal,
+// networks.py:200-203).  The reference runs ~60 tiny ATen kernels for this.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void normalize3(const float v[3], float out[3]) {  // rotations.py:302-314
+    const float mag = sqrtf((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
+    if (mag > 1e-8f) {
+        const float d = fmaxf(mag, 1e-8f);
+        out[0] = v[0] / d; out[1] = v[1] / d; out[2] = v[2] / d;
+    } else {
+        out[0] = 1.f; out[1] = 0.f; out[2] = 0.f;
+    }
+}
+__device__ __forceinline__ void cross3(const float u[3], const float v[3], float out[3]) {
+    out[0] = u[1] * v[2] - u[2] * v[1];
+    out[1] = u[2] * v[0] - u[0] * v[2];
+    out[2] = u[0] * v[1] - u[1] * v[0];
+}
+
+__global__ __launch_bounds__(PF_THREADS) void rot_pool_compose_kernel(int p, int n, int sym, const float *__restrict__ raw,
+                                                                      const int *__restrict__ labels,
+                                                                      const float *__restrict__ prev_rot,
+                                                                      float *__restrict__ rot, float *__restrict__ delta) {
+    __shared__ double smem[10 * 4];
+    const int q = blockIdx.x;            // = b * P + part: cloud q, head `part`
+    const int bi = q / p, pi = q % p;
+    const int R = sym ? 3 : 6;
+    const float *src = raw + ((size_t)q * p + pi) * R * n;
+    const int *lab = labels + (size_t)bi * n;
+    double acc[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) acc[i] = 0.0;
+    for (int e = threadIdx.x; e < n; e += PF_THREADS) {
+        if (lab[e] != pi) continue;
+        acc[9] += 1.0;
+        if (sym) {
+            const float v[3] = {src[e], src[n + e], src[2 * (size_t)n + e]};
+            float u[3];
+            normalize3(v, u);
+            acc[0] += u[0]; acc[1] += u[1]; acc[2] += u[2];
+        } else {
+            const float a[3] = {src[e], src[n + e], src[2 * (size_t)n + e]};
+            const float c[3] = {src[3 * (size_t)n + e], src[4 * (size_t)n + e], src[5 * (size_t)n + e]};
+            float x[3], zr[3], z[3], y[3];
+            normalize3(a, x);
+            cross3(x, c, zr);
+            normalize3(zr, z);
+            cross3(z, x, y);
+            // row-major 3x3 with columns x, y, z
+            acc[0] += x[0]; acc[1] += y[0]; acc[2] += z[0];
+            acc[3] += x[1]; acc[4] += y[1]; acc[5] += z[1];
+            acc[6] += x[2]; acc[7] += y[2]; acc[8] += z[2];
+        }
+    }
+    block_reduce_sum<10>(acc, smem);
+    if (threadIdx.x != 0) return;
+    const float cnt = (float)acc[9];
+    float dR[9];  // row-major
+    if (sym) {
+        float v[3];
+        if (cnt > 0.f) { v[0] = (float)acc[0] / fmaxf(cnt, 1.f); v[1] = (float)acc[1] / fmaxf(cnt, 1.f); v[2] = (float)acc[2] / fmaxf(cnt, 1.f); }
+        else { v[0] = 0.f; v[1] = 1.f; v[2] = 0.f; }
+        float y[3], zr[3], z[3], x[3];
+        const float ex[3] = {1.f, 0.f, 0.f};
+        normalize3(v, y);
+        cross3(ex, y, zr);
+        normalize3(zr, z);
+        cross3(y, z, x);
+        for (int i = 0; i < 3; ++i) { dR[i * 3 + 0] = x[i]; dR[i * 3 + 1] = y[i]; dR[i * 3 + 2] = z[i]; }
+    } else {
+        float m[9];
+        for (int i = 0; i < 9; ++i) m[i] = cnt > 0.f ? (float)acc[i] / fmaxf(cnt, 1.f) : (i % 4 == 0 ? 1.f : 0.f);
+        // Gram-Schmidt on the columns (rotations.py:356-372)
+        float a1[3] = {m[0], m[3], m[6]}, a2[3] = {m[1], m[4], m[7]}, a3[3] = {m[2], m[5], m[8]};
+        float u2[3], u3[3];
+        auto dot = [](const float *u, const float *v) { return (u[0] * v[0] + u[1] * v[1]) + u[2] * v[2]; };
+        const float k12 = dot(a1, a2) / fmaxf(dot(a1, a1), 1e-8f);
+        for (int i = 0; i < 3; ++i) u2[i] = a2[i] - k12 * a1[i];
+        const float k13 = dot(a1, a3) / fmaxf(dot(a1, a1), 1e-8f);
+        const float k23 = dot(u2, a3) / fmaxf(dot(u2, u2), 1e-8f);
+        for (int i = 0; i < 3; ++i) u3[i] = (a3[i] - k13 * a1[i]) - k23 * u2[i];
+        float c1[3], c2[3], c3[3];
+        normalize3(a1, c1); normalize3(u2, c2); normalize3(u3, c3);
+        for (int i = 0; i < 3; ++i) { dR[i * 3 + 0] = c1[i]; dR[i * 3 + 1] = c2[i]; dR[i * 3 + 2] = c3[i]; }
+    }
+    const float *Rp = prev_rot + (size_t)q * 9;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            float v = 0.f;
+            for (int k = 0; k < 3; ++k) v += Rp[i * 3 + k] * dR[k * 3 + j];
+            rot[(size_t)q * 9 + i * 3 + j] = v;
+        }
+    if (delta != nullptr)
+        for (int i = 0; i < 9; ++i) delta[(size_t)q * 9 + i] = dR[i];
+}
+
 }  // namespace
+
+extern "C" int captra_rot_pool_compose(int b, int p, int n, int sym, const float *raw, const int *labels,
+                                       const float *prev_rot, float *rot, float *delta, captra_stream_t stream) {
+    if (b < 0 || p < 1 || n < 0) return -1;
+    if (b == 0) return 0;
+    CAPTRA_LAUNCH("rot_pool_compose", rot_pool_compose_kernel, dim3(b * p), dim3(PF_THREADS), 0, (hipStream_t)stream, p, n, sym,
+                  raw, labels, prev_rot, rot, delta);
+    return captra_last_error();
+}
 
 extern "C" int captra_part_fit_st(int b, int p, int n, int sym, const int *labels, const float *src,
                                   const float *tgt, int tgt_per_part, const float *rot, const float *given_scale,

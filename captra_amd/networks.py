@@ -122,6 +122,11 @@ class RotationRegressionBackbone(nn.Module):
         self.cfg = cfg
         self._default = None
 
+    def raw_point_rtvec(self, cam, cam_n3=None, geom=None):
+        """cam (B,3,N) -> (B,P,R,N): backbone + the rotation heads' raw outputs (fused read-out path:
+        captra_rot_pool_compose does the per-point normalisation, the masked mean and the pose algebra)."""
+        return self.pose_pred.raw(self.encoder(cam, input_n3=cam_n3, geom=geom))
+
     def forward(self, cam, cam_labels, cam_n3=None, geom=None):
         """cam (B,3,N), cam_labels (B,N) -> {'rtvec' (B,P,D) masked mean, 'point_rtvec' (B,P,D,N)}."""
         feat = self.encoder(cam, input_n3=cam_n3, geom=geom)
@@ -174,6 +179,18 @@ class PartCanonNet(nn.Module):
         else:
             cam_cn, cam_n3 = _canonicalize(input["points"], input["points_mean"], canon_pose, num_parts=P)
             geom = None
+        if (eval_rnpcs and test_mode and not self.return_point_rotation and not self.training and cam_cn.is_cuda
+                and fused.USE_ROT_READOUT):
+            # tracking fast path: one launch for per-point normalisation + masked mean + frame + R_prev * dR
+            raw = self.regress_net.raw_point_rtvec(cam_cn, cam_n3=cam_n3, geom=geom)       # (B*P,P,R,N)
+            labels_i32 = input["pred_labels"].int().contiguous()
+            rotation = fused.rot_pool_compose(raw, labels_i32, part_pose["rotation"].float().contiguous(), self.sym)
+            npcs = input["pred_nocs"].reshape(B, P, 3, -1).float().contiguous()
+            cam_points = (input["points"] + input["points_mean"]).float().contiguous()        # (B,3,N)
+            scale, trans, valid = part_fit_st_cn(labels_i32, npcs, cam_points, rotation, self.sym)
+            return {"part": {"rotation": rotation,
+                             "scale": torch.where(valid, scale, part_pose["scale"]),
+                             "translation": torch.where(valid[..., None, None], trans, part_pose["translation"])}}
         seg_rep = cam_seg.unsqueeze(1).expand(-1, P, -1).reshape(B * P, -1)
         pred = self.regress_net(cam_cn, seg_rep, cam_n3=cam_n3, geom=geom)
 

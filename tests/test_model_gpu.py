@@ -526,3 +526,40 @@ def test_track_cli_matches_trainer_and_writes_result_pickles(device, tmp_path):
         for key in ("rotation", "translation", "scale"):
             np.testing.assert_array_equal(np.asarray(saved["pred"]["poses"][i][key]).reshape(-1),
                                           pred["poses"][i][key][0].cpu().numpy().reshape(-1))
+
+
+@pytest.mark.parametrize("sym,P", [(True, 1), (False, 1), (False, 4), (True, 3)])
+def test_rot_pool_compose_vs_reference_algebra(device, sym, P):
+    """The one-launch rotation read-out equals the reference's op sequence (per-point normalise / ortho6d, masked mean
+    with default, from_3d / Gram-Schmidt, diagonal pick, R_prev @ dR) evaluated with the package's torch mirrors of
+    rotations.py / part_dof_utils.py; a part without points takes the default; degenerate per-point vectors are included."""
+    from captra_amd import fused
+    from captra_amd.pose_utils.part_dof_utils import convert_pred_rtvec_to_matrix
+    from captra_amd.pose_utils.rotations import compute_rotation_matrix_from_ortho6d, normalize_vector
+    rng = np.random.default_rng(17 + P + int(sym))
+    B, N, R = 3, 1000, (3 if sym else 6)
+    raw = rng.standard_normal((B * P, P, R, N)).astype(np.float32)
+    raw[0, 0, :, :5] = 0.0                                      # |v| = 0: the (1,0,0) fallback of normalize_vector
+    labels = rng.integers(0, P + 1, (B, N)).astype(np.int32)    # label P = background
+    if P > 1:
+        labels[1][labels[1] == P - 1] = P                       # trajectory 1: last part has no points
+    prev = np.stack([clouds._rot_y(0.3 * i) @ clouds._rot_x(0.1 * i) for i in range(B * P)]).reshape(B, P, 3, 3).astype(np.float32)
+    rot, delta = fused.rot_pool_compose(_dev(raw, device), _dev(labels, device), _dev(prev, device), sym, want_delta=True)
+    # reference sequence on the CPU
+    t = torch.from_numpy(raw).transpose(-1, -2)                 # (Q,P,N,R)
+    if sym:
+        per_point = normalize_vector(t.reshape(-1, 3)).reshape(t.shape).transpose(-1, -2)
+    else:
+        per_point = compute_rotation_matrix_from_ortho6d(t.reshape(-1, 6)).reshape(t.shape[:-1] + (9,)).transpose(-1, -2)
+    lab = torch.from_numpy(labels).long().unsqueeze(1).expand(-1, P, -1).reshape(B * P, -1)
+    mask = (lab.unsqueeze(1) == torch.arange(P).view(1, P, 1)).float().unsqueeze(-2)
+    valid = (mask.sum(dim=(-1, -2)) > 0).float().unsqueeze(-1)
+    pooled = (per_point * mask).sum(-1) / torch.clamp_min(mask.sum(-1), 1.0)
+    default = (torch.tensor((0.0, 1.0, 0.0)) if sym else torch.eye(3).reshape(-1)).reshape(1, 1, -1)
+    pooled = valid * pooled + (1.0 - valid) * default
+    d_all = convert_pred_rtvec_to_matrix(pooled, sym).reshape(B, P, P, 3, 3)
+    idx = torch.arange(P)
+    d_ref = d_all[:, idx, idx]
+    r_ref = torch.matmul(torch.from_numpy(prev), d_ref)
+    np.testing.assert_allclose(delta.cpu().numpy(), d_ref.numpy(), atol=2e-6, rtol=0)
+    np.testing.assert_allclose(rot.cpu().numpy(), r_ref.numpy(), atol=2e-6, rtol=0)
