@@ -356,6 +356,7 @@ struct SwParams {
     const float *w1, *b1, *w2, *b2, *w3, *b3;
     float *out;
     int out_ctotal, co_off;
+    const float *v1;           // PRE kernels: (B,C1,N) = b1 + W1[feature rows] * feat per source point, else null
     unsigned long long *prof;  // debug: per-phase wave-cycle totals of a sample of waves (sa_wave_kernel), else null
 };
 
@@ -430,11 +431,55 @@ __device__ __forceinline__ void sw_layer1_gather(const SwParams &p, int b, int i
     for (int t = 0; t < NT; ++t) sw_mid_epilogue<NOUT>(acc[t], t, hout);
 }
 
+// First layer with a PRE-TRANSFORMED feature part.  The k-ascending chain of layer 1 runs over the feature rows
+// first and the three relative-xyz rows last (pointnet_utils.py:234-240: cat([features, xyz])), and its first CF
+// steps -- bias + sum_k W[k] feat_j[k] -- depend on the source point j only, not on the centre.  They are computed
+// ONCE per source point by the dense kernel (v1 (B,C1,N) = captra_pointwise_mlp(feat, W1 rows 0..CF-1, b1, no
+// activation): the very same partial fmaf chain), and here a wave just gathers them as its accumulator init and
+// continues the chain with the two k-steps of the xyz rows: bit-identical to the full gather-GEMM at 1/80 of its MFMAs.
+template <int CF, int C1, int NOUT, typename Next>
+__device__ __forceinline__ void sw_layer1_pre(const SwParams &p, int b, int id, const float (&ctr)[3], float (&hout)[NOUT],
+                                              int lane, Next next) {
+    using S = SwShape<CF + 3, C1>;
+    constexpr int NT = S::NT;
+    static_assert(NT <= 4, "unsupported first-layer shape");
+    const int half = lane >> 5;
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)p.w1, 0, S::KP * S::LDW * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)(p.v1 + (size_t)b * C1 * p.n), 0, C1 * p.n * 4, 0x00020000);
+    const int voff_w = (half * S::LDW + (lane & 31)) * 4;
+    const int voff_v = (4 * half * p.n + id) * 4;
+    const int row_bytes = p.n * 4;
+    float at[2][NT], bt[2];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            at[jj][t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, voff_w, ((CF + 2 * jj) * S::LDW + 32 * t) * 4, 0));
+        const int a = 2 * jj + half;
+        bt[jj] = a < 3 ? p.xyz_cn[((size_t)b * 3 + a) * p.n + id] - ctr[a] : 0.f;
+    }
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)   // accumulator register r of this lane = row 32t + 8(r>>2) + (r&3) + 4*half, column = its neighbour
+            acc[t][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rv, voff_v, (32 * t + 8 * (r >> 2) + (r & 3)) * row_bytes, 0));
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(at[jj][t], bt[jj], acc[t], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    next();
+#pragma unroll
+    for (int t = 0; t < NT; ++t) sw_mid_epilogue<NOUT>(acc[t], t, hout);
+}
+
 // live registers peak in layer 2 at about (C1 + C2)/2 activations + 64: beyond the 256 a wave gets at two
 // waves per SIMD, run one wave per SIMD with the whole 512-register file instead of spilling
 constexpr int sw_waves_per_simd(int c1, int c2) { return (c1 + c2) / 2 + 80 > 230 ? 1 : 2; }
 
-template <int CF, int C1, int C2, int C3>
+template <int CF, int C1, int C2, int C3, bool PRE = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, sw_waves_per_simd(C1, C2) == 1 ? 1 : 8)))
 void sa_wave_kernel(SwParams p) {
     constexpr int CIN1 = CF + 3;
@@ -492,7 +537,10 @@ void sa_wave_kernel(SwParams p) {
             }
             sw_layer_reg<CIN1, C1, SW_EPI_MID, 0>(p.w1, bias_lds, x1, h1, s, red, wave, lane, next2);
         } else {
-            sw_layer1_gather<CF, C1>(p, b, id, ctr, bias_lds, h1, lane, [&]() { sw_first_set<C1, C2>(s[0], p.w2, lane); });
+            if constexpr (PRE)
+                sw_layer1_pre<CF, C1>(p, b, id, ctr, h1, lane, [&]() { sw_first_set<C1, C2>(s[0], p.w2, lane); });
+            else
+                sw_layer1_gather<CF, C1>(p, b, id, ctr, bias_lds, h1, lane, [&]() { sw_first_set<C1, C2>(s[0], p.w2, lane); });
         }
         SW_TICK(1)
         sw_layer_reg<C1, C2, SW_EPI_MID, START2>(p.w2, bias_lds + SF_MAXC, h1, h2, s, red, wave, lane, next3);
@@ -717,7 +765,7 @@ extern "C" int captra_sa_scale_fused(int b, int n, int m, int k, int cfeat, int 
         // PointNet2Msg config); any other shape takes the generic LDS kernel below
         SwParams q;
         q.b = b; q.n = n; q.m = m; q.k = k; q.feat = feat; q.xyz_cn = xyz_cn; q.new_xyz = new_xyz; q.idx = idx;
-        q.w1 = w1; q.b1 = b1; q.w2 = w2; q.b2 = b2; q.w3 = w3; q.b3 = b3; q.out = out; q.out_ctotal = out_ctotal; q.co_off = co_off; q.prof = g_sa_prof;
+        q.w1 = w1; q.b1 = b1; q.w2 = w2; q.b2 = b2; q.w3 = w3; q.b3 = b3; q.out = out; q.out_ctotal = out_ctotal; q.co_off = co_off; q.v1 = nullptr; q.prof = g_sa_prof;
         const long long Lw = (long long)m * k;
         dim3 gridw((unsigned)((Lw + SF_POS - 1) / SF_POS), b);
         // small-input scales: persistent workgroups with the weights resident in LDS (mode 2 = streaming kernel for all)
@@ -795,4 +843,31 @@ extern "C" int captra_sa_scale_fused(int b, int n, int m, int k, int cfeat, int 
         CAPTRA_LAUNCH("sa_scale_fused", (sa_fused_kernel<1, false>), grid, dim3(256), lds32, (hipStream_t)stream, p);
     }
     return captra_last_error();
+}
+
+// SA scale with a pre-transformed first layer (see sw_layer1_pre and include/captra_hip.h): v1 (B,c1,N) replaces feat.
+extern "C" int captra_sa_scale_pre(int b, int n, int m, int k, int cfeat, int c1, int c2, int c3, const float *v1,
+                                   const float *xyz_cn, const float *new_xyz, const int *idx, const float *w1,
+                                   const float *w2, const float *b2, const float *w3, const float *b3, float *out,
+                                   int out_ctotal, int co_off, captra_stream_t stream) {
+    if (b < 0 || n < 1 || m < 0 || k < 1 || cfeat < 1 || c1 < 1 || c2 < 1 || c3 < 1 || v1 == nullptr) return -1;
+    if (out_ctotal < co_off + c3 || co_off < 0) return -1;
+    if (k % 32 != 0 || 128 % k != 0) return -2;
+    if ((long long)c1 * n * 4 >= (1ll << 31)) return -2;
+    SwParams q;
+    q.b = b; q.n = n; q.m = m; q.k = k; q.feat = nullptr; q.xyz_cn = xyz_cn; q.new_xyz = new_xyz; q.idx = idx;
+    q.w1 = w1; q.b1 = b2 /* unused by the PRE kernels: any valid packed bias */; q.w2 = w2; q.b2 = b2; q.w3 = w3; q.b3 = b3;
+    q.out = out; q.out_ctotal = out_ctotal; q.co_off = co_off; q.v1 = v1; q.prof = nullptr;
+    const long long Lw = (long long)m * k;
+    dim3 gridw((unsigned)((Lw + SF_POS - 1) / SF_POS), b);
+#define SWP_CASE(CF_, C1_, C2_, C3_)                                                                                       \
+    if (cfeat == CF_ && c1 == C1_ && c2 == C2_ && c3 == C3_) {                                                             \
+        if (b == 0 || m == 0) return 0;                                                                                    \
+        CAPTRA_LAUNCH("sa_scale_fused", (sa_wave_kernel<CF_, C1_, C2_, C3_, true>), gridw, dim3(256), 0, (hipStream_t)stream, q); \
+        return captra_last_error();                                                                                        \
+    }
+    SWP_CASE(320, 128, 128, 256)
+    SWP_CASE(320, 128, 196, 256)
+#undef SWP_CASE
+    return -2;
 }

@@ -88,6 +88,39 @@ def pointwise_mlp(x, lin: PackedLinear, act: int = ACT_RELU, out=None):
     return out
 
 
+USE_SA_PRE = True        # SA scales with many feature channels: first layer's feature part once per source point
+_SA_PRE_SHAPES = {(320, 128, 128, 256), (320, 128, 196, 256)}   # csrc/sa_fused.hip SWP_CASE list
+
+
+def sa_scale_pre_supported(cfeat, layers, k) -> bool:
+    return (USE_SA_PRE and USE_SA_FUSED and len(layers) == 3 and k % 32 == 0 and 128 % k == 0
+            and (cfeat, layers[0].cout, layers[1].cout, layers[2].cout) in _SA_PRE_SHAPES)
+
+
+def sa_first_layer_pre(feat, lin: PackedLinear):
+    """v1 (B,c1,N) = b1 + W1[feature rows] feat: the part of an SA scale's first layer that depends on the source
+    point only (the chain's first cfeat steps; the packed buffer's leading rows ARE the feature rows)."""
+    view = PackedLinear.__new__(PackedLinear)
+    view.wt, view.bias, view.cin, view.cout = lin.wt, lin.bias, feat.shape[1], lin.cout
+    assert lin.cin == feat.shape[1] + 3
+    return pointwise_mlp(feat, view, ACT_NONE)
+
+
+def sa_scale_pre(v1, xyz_cn, new_xyz_n3, idx, layers, out, co_off, cfeat):
+    """One SA scale from the pre-transformed first layer (captra_sa_scale_pre)."""
+    l1, l2, l3 = layers
+    L.require_device(v1, xyz_cn, new_xyz_n3, idx, out)
+    B, _, N = xyz_cn.shape
+    _, M, K = idx.shape
+    with torch.cuda.device(xyz_cn.device):
+        L.call("captra_sa_scale_pre", B, N, M, K, cfeat, l1.cout, l2.cout, l3.cout, L.ptr(v1), L.ptr(xyz_cn),
+               L.ptr(new_xyz_n3), L.ptr(idx), L.ptr(l1.wt), L.ptr(l2.wt), L.ptr(l2.bias), L.ptr(l3.wt), L.ptr(l3.bias),
+               L.ptr(out), out.shape[1], co_off)
+    _work("sa_scale_fused", flops=2.0 * B * M * K * (3 * l1.cout + l1.cout * l2.cout + l2.cout * l3.cout),
+          nbytes=4.0 * B * (l1.cout * N + 3 * N + M * K + 3 * M + l3.cout * M))
+    return out
+
+
 USE_ROT_READOUT = True   # tracking: rotation read-out (normalise, masked mean, frame, compose) as one launch
 
 

@@ -179,6 +179,11 @@ class PointNetSetAbstractionMsg(_FoldCache, nn.Module):
         feat = points.contiguous() if points is not None else None
         off = 0
         for layers, idx in zip(folded, idx_list):
+            if feat is not None and fused.sa_scale_pre_supported(feat.shape[1], layers, idx.shape[2]):
+                v1 = fused.sa_first_layer_pre(feat, layers[0])      # (B,c1,N): once per source point, not per neighbour
+                fused.sa_scale_pre(v1, xyz_cn, new_xyz_n3, idx, layers, out, off, feat.shape[1])
+                off += layers[-1].cout
+                continue
             if fused.sa_scale_fusable(idx.shape[2], layers):
                 fused.sa_scale_fused(feat, xyz_cn, new_xyz_n3, idx, layers, out, off)
                 off += layers[-1].cout

@@ -152,6 +152,17 @@ int captra_sa_scale_fused(int b, int n, int m, int k, int cfeat, int c1, int c2,
                           const float *b1, const float *w2, const float *b2, const float *w3, const float *b3,
                           float *out, int out_ctotal, int co_off, captra_stream_t stream);
 
+/* SA scale with a pre-transformed first layer.  Layer 1's k-ascending chain runs over the cfeat feature rows first and the
+ * three relative-xyz rows last (pointnet_utils.py:234-240), and its first cfeat steps depend on the SOURCE point only:
+ *   v1 (B,c1,N) = captra_pointwise_mlp(feat (B,cfeat,N), w1 rows 0..cfeat-1, b1, CAPTRA_ACT_NONE)      (once per source point)
+ * The kernel gathers v1[:, idx] as the accumulator start and continues the chain with the xyz rows of w1 (same packed
+ * buffer), then layers 2, 3 and the max as captra_sa_scale_fused.  Bit-identical to captra_sa_scale_fused at ~60 % of its
+ * flops for the SA2 scales.  Instantiated for (cfeat,c1,c2,c3) = (320,128,128,256), (320,128,196,256); -2 otherwise. */
+int captra_sa_scale_pre(int b, int n, int m, int k, int cfeat, int c1, int c2, int c3, const float *v1,
+                        const float *xyz_cn, const float *new_xyz, const int *idx, const float *w1, const float *w2,
+                        const float *b2, const float *w3, const float *b3, float *out, int out_ctotal, int co_off,
+                        captra_stream_t stream);
+
 /* Three dense layers in one launch: y (B,c3,l) = act3(W3 relu(W2 relu(W1 x + b1) + b2) + b3), x (B,c0,l); packed
  * weights (captra_pack_weights).  Replaces the FP1 shared MLP + conv1/bn1/ReLU tail of PointNet2Msg
  * (pointnet_utils.py:296-298, backbones.py:66-68) without the two intermediate (B,128,l) tensors.  Instantiated

@@ -107,6 +107,36 @@ def test_sa_scale_fused_bit_exact(device, cfeat, chans, n, m, k, mode):
         _lib.lib().captra_sa_fused_set_mode(ctypes.c_int(0))
 
 
+@pytest.mark.parametrize("chans,n,m,k", [((128, 128, 256), 512, 128, 64), ((128, 196, 256), 512, 128, 128),
+                                         ((128, 196, 256), 200, 5, 64), ((128, 128, 256), 333, 37, 32)])
+def test_sa_scale_pre_bit_exact(device, chans, n, m, k):
+    """First layer's feature part computed once per source point (captra_pointwise_mlp on the feature rows) + the
+    scale kernel continuing the chain with the xyz rows == the oracle's gather -> 3 layers -> max, bit for bit."""
+    from captra_amd import fused
+    cfeat = 320
+    rng = np.random.default_rng(sum(chans) + n + k)
+    B = 2
+    xyz_cn = (rng.random((B, 3, n), dtype=np.float32) - 0.5)
+    feat = rng.standard_normal((B, cfeat, n)).astype(np.float32)
+    new_xyz = (rng.random((B, m, 3), dtype=np.float32) - 0.5)
+    idx = rng.integers(0, n, (B, m, k)).astype(np.int32)
+    dims = (cfeat + 3,) + chans
+    layers = [((rng.standard_normal((dims[i], dims[i + 1])) / np.sqrt(dims[i])).astype(np.float32),
+               rng.standard_normal(dims[i + 1]).astype(np.float32)) for i in range(3)]
+    packed = [fused.pack(_dev(w, device), _dev(b, device)) for w, b in layers]
+    assert fused.sa_scale_pre_supported(cfeat, packed, k)
+    out = torch.full((B, chans[2] + 9, m), -1.0, device=device)
+    v1 = fused.sa_first_layer_pre(_dev(feat, device), packed[0])
+    fused.sa_scale_pre(v1, _dev(xyz_cn, device), _dev(new_xyz, device), _dev(idx, device), packed, out, 4, cfeat)
+    x = O.sa_group(feat, xyz_cn, new_xyz, idx)
+    for w, b in layers:
+        x = O.pointwise_mlp(x, w, b, 1)
+    ref = O.max_over_k(x)
+    got = out.cpu().numpy()
+    np.testing.assert_array_equal(got[:, 4:4 + chans[2]], ref)
+    assert (got[:, :4] == -1).all() and (got[:, 4 + chans[2]:] == -1).all()
+
+
 def _sa_scale_fused_case(device, cfeat, chans, n, m, k):
     from captra_amd import fused
     rng = np.random.default_rng(cfeat + sum(chans) + k)
@@ -177,6 +207,14 @@ def test_backbone_layer_by_layer_kernels_equal_fused_scale(device):
         finally:
             fused.USE_SA_FUSED = True
             fused.USE_MLP_CHAIN = True
+        fused.USE_SA_PRE = False                      # full gather-GEMM first layer instead of the pre-transformed one
+        try:
+            c = net(cloud_cn).cpu().numpy()
+        finally:
+            fused.USE_SA_PRE = True
+    np.testing.assert_array_equal(a, c)
+    with torch.no_grad():
+        pass
     np.testing.assert_array_equal(a, b)
 
 

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--layered", action="store_true")
     ap.add_argument("--wn", type=int, default=0)
+    ap.add_argument("--pre", action="store_true", help="pre-transformed first layer (captra_sa_scale_pre) where supported; time includes the v1 launch")
     ap.add_argument("--mode", type=int, default=0, help="0 = register-resident kernels where instantiated, 1 = generic LDS kernel")
     ap.add_argument("--phases", action="store_true", help="debug: in-kernel s_memtime phase breakdown (PROF kernels)")
     ap.add_argument("--ablate", type=int, default=0, help="debug: phases to skip (1 gather, 2 mid epilogues, 4 last epilogue, 8/16/32 layer 1/2/3)")
@@ -50,12 +51,15 @@ def main():
                 y = fused.sa_group_mlp(feat, xyz, new_xyz, idx, layers[0])
                 y = fused.pointwise_mlp(y, layers[1], fused.ACT_RELU)
                 fused.mlp_max(y, layers[2], out, 0)
+            elif a.pre and feat is not None and fused.sa_scale_pre_supported(cfeat, layers, k):
+                v1 = fused.sa_first_layer_pre(feat, layers[0])
+                fused.sa_scale_pre(v1, xyz, new_xyz, idx, layers, out, 0, cfeat)
             else:
                 fused.sa_scale_fused(feat, xyz, new_xyz, idx, layers, out, 0)
 
         if not a.layered:
             _lib.lib().captra_sa_fused_set_mode(ctypes.c_int(1))
-            run()
+            fused.sa_scale_fused(feat, xyz, new_xyz, idx, layers, out, 0)
             ref = out.clone()
             _lib.lib().captra_sa_fused_set_mode(ctypes.c_int(a.mode))
             out.zero_()
