@@ -480,7 +480,7 @@ __device__ __forceinline__ void sw_layer1_pre(const SwParams &p, int b, int id, 
 constexpr int sw_waves_per_simd(int c1, int c2) { return (c1 + c2) / 2 + 80 > 230 ? 1 : 2; }
 
 template <int CF, int C1, int C2, int C3, bool PRE = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, sw_waves_per_simd(C1, C2) == 1 ? 1 : 8)))
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, (!PRE && sw_waves_per_simd(C1, C2) == 1) ? 1 : 8)))
 void sa_wave_kernel(SwParams p) {
     constexpr int CIN1 = CF + 3;
     constexpr bool SMALL1 = CIN1 <= 8;
