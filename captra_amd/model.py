@@ -68,6 +68,11 @@ class EvalTrackModel(BaseModel):
         # single-part objects: RotationNet canonicalises with the very pose CoordNet used, so both nets see
         # the same cloud and FPS / ball query / 3-NN run once per frame instead of twice
         self.share_geometry = True
+        # replay one captured hipGraph per frame instead of launching the ~140 kernels of a step one by one
+        # (captra_amd/graph.py); opt-in: `--hipgraph` of captra_amd.track / cfg['hipgraph'].  Same kernels, same bits.
+        self.use_graph = bool(cfg.get("hipgraph", False))
+        self._graph = None
+        self._graph_key = None
 
     # ---- host -> device ------------------------------------------------------------------------
     def _gt_part(self, frame):
@@ -130,6 +135,22 @@ class EvalTrackModel(BaseModel):
             input["shared_geometry"] = (self.npcs_net.last_canon, self.npcs_net.backbone.last_geom)
         return npcs_pred, self.net(input, test_mode=True)["part"]
 
+    def _graph_usable(self, input) -> bool:
+        return (self.use_graph and not self.training and input["points"].is_cuda
+                and not (self.track_cfg["gt_label"] or self.track_cfg["nocs2d_label"]))
+
+    def _graph_step(self, input, last_pose):
+        """One frame through the captured graph (captured on first use for this batch shape); outputs are cloned out
+        of the graph's static buffers."""
+        from .graph import TrackStepGraph
+        key = (tuple(input["points"].shape), str(input["points"].device))
+        if self._graph is None or self._graph_key != key:
+            self._graph = TrackStepGraph(self, input["points"], input["points_mean"], last_pose)
+            self._graph_key = key
+        pose = self._graph.replay(input["points"], input["points_mean"], last_pose)
+        npcs = {k: v.clone() for k, v in self._graph.npcs_pred.items() if torch.is_tensor(v)}
+        return npcs, {k: v.clone() for k, v in pose.items()}
+
     def forward(self, save=False):
         if self.nocs_otf:
             raise NotImplementedError("nocs_otf (on-the-fly depth crop, reference model.py:425-452) is a "
@@ -147,7 +168,10 @@ class EvalTrackModel(BaseModel):
                 # draw it too so that seeded runs consume the generator identically
                 add_noise_to_part_dof(self.feed_dict[i - 1]["gt_part"], self.pose_perturb_cfg)
                 last_pose = {k: v.clone() for k, v in pred_poses[-1].items()}
-                cur_npcs, pose = self.track_step(input, self.npcs_feed_dict[i], last_pose)
+                if self._graph_usable(input):
+                    cur_npcs, pose = self._graph_step(input, last_pose)
+                else:
+                    cur_npcs, pose = self.track_step(input, self.npcs_feed_dict[i], last_pose)
                 npcs_pred.append(cur_npcs)
                 pred_poses.append(pose)
         self.pred_dict = {"poses": pred_poses, "npcs_pred": npcs_pred}

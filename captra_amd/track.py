@@ -79,6 +79,8 @@ def parse_args(argv=None):
     parser.add_argument("--random_init", action="store_true", default=False,
                         help="no checkpoints: keep the freshly constructed (random) weights -- throughput runs only")
     parser.add_argument("--seed", type=int, default=0)
+    parser.add_argument("--hipgraph", action="store_true", default=False,
+                        help="replay one captured hipGraph per frame (same kernels, no per-launch host overhead)")
     return parser.parse_args(argv)
 
 
@@ -116,10 +118,11 @@ def main(argv=None) -> dict:
     if args.nocs_otf:
         raise SystemExit("--nocs_otf True (on-the-fly depth crop, reference model.py:425-452) is not part of this build: "
                          "feed pre-cropped trajectories (captra_amd/trajectory_io.py)")
-    data_args = {k: getattr(args, k) for k in ("data", "num_traj", "num_frames", "random_init", "seed")}
+    data_args = {k: getattr(args, k) for k in ("data", "num_traj", "num_frames", "random_init", "seed", "hipgraph")}
     for k in data_args:
         delattr(args, k)
     cfg = get_config(args, save=False)
+    cfg["hipgraph"] = data_args["hipgraph"]
     args = argparse.Namespace(**vars(args), **data_args)
 
     log_dir = pjoin(cfg["experiment_dir"], "log")

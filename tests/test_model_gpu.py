@@ -546,7 +546,7 @@ def test_track_cli_matches_trainer_and_writes_result_pickles(device, tmp_path):
     torch.manual_seed(0)
     np.random.seed(0)
     res = track.main(["--obj_category", "1", "--experiment_dir", str(rot_dir), "--coord_exp/dir", str(coord_dir),
-                      "--batch_size", "2", "--data", str(data_dir), "--save",
+                      "--batch_size", "2", "--data", str(data_dir), "--save", "--hipgraph",
                       "--pose_perturb/r", "0", "--pose_perturb/t", "0", "--pose_perturb/s", "0"])
     assert res["frames"] == 8 and any(k.startswith("avg_pred/") for k in res["loss"]), res
     out = sorted((rot_dir / "results" / "data").glob("*.pkl"))
