@@ -39,6 +39,7 @@ _SIGNATURES = {
     "captra_mlp_max": [_INT, _INT, _INT, _INT, _INT, _P, _P, _P, _P, _INT, _INT, _P],
     "captra_sa_scale_fused": [_INT] * 8 + [_P] * 11 + [_INT, _INT, _P],
     "captra_three_nn_weights": [_INT, _INT, _INT, _P, _P, _P, _P, _P],
+    "captra_fps_gather": [_INT, _INT, _INT, _P, _P, _P, _P, _P],
     "captra_sa_scale_pre": [_INT] * 8 + [_P] * 9 + [_P, _INT, _INT, _P],
     "captra_rot_pool_compose": [_INT, _INT, _INT, _INT, _P, _P, _P, _P, _P, _P],
     "captra_mlp_chain3": [_INT, _INT, _INT, _INT, _INT, _LL, _P, _P, _P, _P, _P, _P, _P, _INT, _P, _P],

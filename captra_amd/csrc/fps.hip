@@ -148,6 +148,131 @@ __global__ __launch_bounds__(NWAVES * 64) void fps_kernel(int n, int m,
     }
 }
 
+// u32 max reductions whose DPP move folds into the max (v_max_u32_dpp): 0 is the identity, so lanes without a valid
+// source (bound_ctrl) or in masked-off rows simply contribute 0
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned dpp_max_u32(unsigned v) {
+    const unsigned o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, true);
+    return max(v, o);
+}
+__device__ __forceinline__ unsigned row_max_u32_fold(unsigned v) {
+    v = dpp_max_u32<0xB1, 0xF>(v);
+    v = dpp_max_u32<0x4E, 0xF>(v);
+    v = dpp_max_u32<0x141, 0xF>(v);
+    v = dpp_max_u32<0x140, 0xF>(v);
+    return v;
+}
+__device__ __forceinline__ unsigned wave_max_u32_fold(unsigned v) {
+    v = row_max_u32_fold(v);
+    v = dpp_max_u32<0x142, 0xA>(v);  // row_bcast15 -> rows 1,3
+    v = dpp_max_u32<0x143, 0xC>(v);  // row_bcast31 -> rows 2,3
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// Second generation of the register-resident kernel (the default): BLOCKED ownership -- lane l of wave w holds the PPT
+// consecutive points starting at (64w + l) * PPT -- so that "lowest index among equal maxima" is "lowest wave, then
+// lowest lane, then lowest slot": after one DPP max reduction the winner is picked with a ballot + find-first-set +
+// v_readlane instead of a second 6-step reduction (and likewise across waves).  Distances are computed two points
+// per instruction (v_pk_add_f32 / v_pk_mul_f32: same IEEE single operations, unfused), the running minimum and the
+// argmax run on the non-negative floats' bit patterns (v_min_u32 / v_max3_u32: no NaN-canonicalising extras).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int NWAVES, int PPT>
+__global__ __launch_bounds__(NWAVES * 64) void fps_kernel_blocked(int n, int m, const float *__restrict__ xyz_all,
+                                                                  float *__restrict__ temp_all, int *__restrict__ idx_all,
+                                                                  float *__restrict__ new_n3, float *__restrict__ new_cn) {
+    static_assert(PPT % 2 == 0, "two points per packed instruction");
+    constexpr int H = PPT / 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint2 *slots = reinterpret_cast<uint2 *>(smem_raw);                  // [2][16] ping-pong
+    float *xs = reinterpret_cast<float *>(smem_raw + 2 * 16 * sizeof(uint2));
+    float *ys = xs + n;
+    float *zs = ys + n;
+    const int b = blockIdx.x;
+    const float *xyz = xyz_all + (size_t)b * n * 3;
+    float *temp = temp_all != nullptr ? temp_all + (size_t)b * n : nullptr;  // null: start from 1e10, nothing written back
+    int *idx = idx_all + (size_t)b * m;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int base = tid * PPT;
+    // optional gather of the sampled coordinates (pointnet_utils.py:222-223 index_points(xyz, fps_idx)): both layouts
+    auto emit = [&](int j, float x, float y, float z) {
+        if (new_n3 != nullptr) {
+            float *d = new_n3 + ((size_t)b * m + j) * 3;
+            d[0] = x; d[1] = y; d[2] = z;
+        }
+        if (new_cn != nullptr) {
+            float *d = new_cn + (size_t)b * 3 * m + j;
+            d[0] = x; d[m] = y; d[2 * (size_t)m] = z;
+        }
+    };
+
+    f32x2 px[H], py[H], pz[H];
+    unsigned dmin[PPT];   // running min distance, as bits (>= 0: bit order == value order)
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+        const int k = base + i;
+        float x = 0.f, y = 0.f, z = 0.f;
+        unsigned d0 = 0u;                      // slots beyond n: distance 0 forever, highest indices -> never preferred
+        if (k < n) {
+            x = xyz[(size_t)k * 3 + 0]; y = xyz[(size_t)k * 3 + 1]; z = xyz[(size_t)k * 3 + 2];
+            d0 = __float_as_uint(temp != nullptr ? temp[k] : 1e10f);
+            xs[k] = x; ys[k] = y; zs[k] = z;
+        }
+        px[i / 2][i & 1] = x; py[i / 2][i & 1] = y; pz[i / 2][i & 1] = z;
+        dmin[i] = d0;
+    }
+    if (tid == 0) idx[0] = 0;
+    __syncthreads();
+
+    int old = 0;
+    for (int j = 1; j < m; ++j) {
+        const float ox = xs[old], oy = ys[old], oz = zs[old];
+        if (tid == 0) emit(j - 1, ox, oy, oz);
+        const f32x2 o2x = {ox, ox}, o2y = {oy, oy}, o2z = {oz, oz};
+        unsigned best = 0u;
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            const f32x2 dx = px[h] - o2x, dy = py[h] - o2y, dz = pz[h] - o2z;
+            const f32x2 d = (dx * dx + dy * dy) + dz * dz;
+            const unsigned b0 = __float_as_uint(d[0]), b1 = __float_as_uint(d[1]);
+            dmin[2 * h] = b0 < dmin[2 * h] ? b0 : dmin[2 * h];
+            dmin[2 * h + 1] = b1 < dmin[2 * h + 1] ? b1 : dmin[2 * h + 1];
+            best = max(best, max(dmin[2 * h], dmin[2 * h + 1]));
+        }
+        int li = PPT - 1;                       // lowest slot of this lane holding `best`
+#pragma unroll
+        for (int i = PPT - 2; i >= 0; --i) li = dmin[i] == best ? i : li;
+        const unsigned wmax = wave_max_u32_fold(best);
+        const unsigned long long hit = __ballot(best == wmax);
+        const int wl = __ffsll((long long)hit) - 1;            // lowest lane = lowest indices of the wave
+        const unsigned widx = (unsigned)__builtin_amdgcn_readlane(base + li, wl);
+        unsigned sel;
+        if (NWAVES == 1) {
+            sel = widx;
+        } else {
+            uint2 *slot = slots + (j & 1) * 16;
+            if (lane == 0) slot[wave] = make_uint2(wmax, widx);
+            __syncthreads();
+            const uint2 kv = slot[lane & (NWAVES - 1)];
+            const unsigned gmax = row_max_u32_fold(kv.x);
+            const unsigned long long hit2 = __ballot(kv.x == gmax);
+            const int gl = __ffsll((long long)hit2) - 1;       // lowest lane = lowest wave = lowest indices
+            sel = (unsigned)__builtin_amdgcn_readlane((int)kv.y, gl);
+        }
+        old = (int)sel;
+        if (tid == 0) idx[j] = old;
+    }
+    if (tid == 0) emit(m - 1, xs[old], ys[old], zs[old]);
+    if (temp != nullptr) {
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) {
+            const int k = base + i;
+            if (k < n) temp[k] = __uint_as_float(dmin[i]);
+        }
+    }
+}
+
 // Fallback for clouds too large for the register-resident kernel: running min in global memory,
 // same selection rule.  1024 threads, strided ownership.
 __global__ __launch_bounds__(1024) void fps_kernel_big(int n, int m, const float *__restrict__ xyz_all,
@@ -187,10 +312,26 @@ __global__ __launch_bounds__(1024) void fps_kernel_big(int n, int m, const float
     }
 }
 
+static int g_fps_variant = 0;  // 0 = blocked / ballot / packed-math kernel where it applies, 1 = first-generation kernel
+
 template <int NWAVES, int PPT>
-int launch_fps(int b, int n, int m, const float *xyz, float *temp, int *idx, hipStream_t s) {
+int launch_fps(int b, int n, int m, const float *xyz, float *temp, int *idx, hipStream_t s, float *new_n3 = nullptr,
+               float *new_cn = nullptr, bool need_blocked = false) {
     size_t slots = 2 * 16 * sizeof(uint2);
     size_t lds_xyz = (size_t)n * 3 * sizeof(float);
+    if constexpr (PPT % 2 == 0) {
+        if (g_fps_variant == 0 && slots + lds_xyz <= 150 * 1024) {
+            auto kern2 = fps_kernel_blocked<NWAVES, PPT>;
+            static bool attr2_set = false;
+            if (!attr2_set) {
+                hipFuncSetAttribute(reinterpret_cast<const void *>(kern2), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+                attr2_set = true;
+            }
+            CAPTRA_LAUNCH("fps", kern2, dim3(b), dim3(NWAVES * 64), slots + lds_xyz, s, n, m, xyz, temp, idx, new_n3, new_cn);
+            return captra_last_error();
+        }
+    }
+    if (need_blocked) return -2;  // the fused sample + gather entry exists on the blocked kernel only
     if (slots + lds_xyz <= 150 * 1024) {
         auto kern = fps_kernel<NWAVES, PPT, true>;
         static bool attr_set = false;
@@ -213,6 +354,7 @@ int launch_fps(int b, int n, int m, const float *xyz, float *temp, int *idx, hip
 // (0 = heuristic).  Not part of the stable ABI.
 static int g_fps_waves = 0;
 extern "C" void captra_fps_set_waves(int w) { g_fps_waves = w; }
+extern "C" void captra_fps_set_variant(int v) { g_fps_variant = v; }
 
 extern "C" int captra_furthest_point_sampling(int b, int n, int m, const float *xyz, float *temp,
                                               int *idx, captra_stream_t stream) {
@@ -222,9 +364,10 @@ extern "C" int captra_furthest_point_sampling(int b, int n, int m, const float *
     hipStream_t s = (hipStream_t)stream;
     int waves = g_fps_waves;
     if (waves == 0) {
-        // heuristic: ~4 points per lane, at most 16 waves
+        // heuristic: ~8 points per lane (blocked kernel) / ~4 (first generation), at most 16 waves
+        const int per_lane = g_fps_variant == 0 ? 8 : 4;
         waves = 1;
-        while (waves < 16 && waves * 64 * 4 < n) waves *= 2;
+        while (waves < 16 && waves * 64 * per_lane < n) waves *= 2;
     }
     int ppt = (n + waves * 64 - 1) / (waves * 64);
 #define FPS_CASE(W, P) \
@@ -237,4 +380,23 @@ extern "C" int captra_furthest_point_sampling(int b, int n, int m, const float *
 #undef FPS_CASE
     CAPTRA_LAUNCH("fps", fps_kernel_big, dim3(b), dim3(1024), 0, s, n, m, xyz, temp, idx);
     return captra_last_error();
+}
+
+// FPS + gather of the sampled coordinates in one launch (see include/captra_hip.h).  -2 when the cloud does not fit the
+// register-resident kernel (use captra_furthest_point_sampling + captra_gather_points then).
+extern "C" int captra_fps_gather(int b, int n, int m, const float *xyz, int *idx, float *new_xyz_n3, float *new_xyz_cn,
+                                 captra_stream_t stream) {
+    if (b < 0 || n < 1 || m < 1) return -1;
+    if (b == 0) return 0;
+    if (g_fps_variant != 0) return -2;
+    hipStream_t s = (hipStream_t)stream;
+    int waves = 1;
+    while (waves < 16 && waves * 64 * 8 < n) waves *= 2;
+    const int ppt = (n + waves * 64 - 1) / (waves * 64);
+#define FPSG_CASE(W, P) \
+    if (waves == W && ppt <= P) return launch_fps<W, P>(b, n, m, xyz, nullptr, idx, s, new_xyz_n3, new_xyz_cn, true);
+    FPSG_CASE(1, 2) FPSG_CASE(1, 4) FPSG_CASE(1, 8)
+    FPSG_CASE(2, 8) FPSG_CASE(4, 8) FPSG_CASE(8, 8) FPSG_CASE(16, 8) FPSG_CASE(16, 16) FPSG_CASE(16, 32)
+#undef FPSG_CASE
+    return -2;
 }

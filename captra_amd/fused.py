@@ -88,6 +88,21 @@ def pointwise_mlp(x, lin: PackedLinear, act: int = ACT_RELU, out=None):
     return out
 
 
+def fps_gather(xyz_n3, m: int):
+    """xyz (B,N,3) -> (idx (B,m) int32, new_xyz (B,m,3), new_xyz (B,3,m)): sampling and the gather of the sampled
+    coordinates in one launch; None when the cloud is too large for that kernel (caller samples and gathers separately)."""
+    L.require_device(xyz_n3)
+    B, N, _ = xyz_n3.shape
+    if N * 12 + 256 > 150 * 1024:     # the register-resident kernel mirrors the cloud in LDS (csrc/fps.hip launch_fps)
+        return None
+    idx = torch.empty(B, m, dtype=torch.int32, device=xyz_n3.device)
+    n3 = torch.empty(B, m, 3, dtype=torch.float32, device=xyz_n3.device)
+    cn = torch.empty(B, 3, m, dtype=torch.float32, device=xyz_n3.device)
+    with torch.cuda.device(xyz_n3.device):
+        L.call("captra_fps_gather", B, N, m, L.ptr(xyz_n3), L.ptr(idx), L.ptr(n3), L.ptr(cn))
+    return idx, n3, cn
+
+
 USE_SA_PRE = True        # SA scales with many feature channels: first layer's feature part once per source point
 _SA_PRE_SHAPES = {(320, 128, 128, 256), (320, 128, 196, 256)}   # csrc/sa_fused.hip SWP_CASE list
 

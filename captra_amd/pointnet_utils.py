@@ -158,9 +158,14 @@ class PointNetSetAbstractionMsg(_FoldCache, nn.Module):
         if xyz_n3 is None:
             xyz_n3 = xyz.transpose(1, 2).contiguous()
         if geom is None:
-            fps_idx = futils.furthest_point_sample(xyz_n3, self.npoint)                      # (B,S) int32
-            new_xyz_n3 = torch.gather(xyz_n3, 1, fps_idx.long().unsqueeze(-1).expand(-1, -1, 3))  # (B,S,3)
-            geom = {"new_xyz_n3": new_xyz_n3, "new_xyz": new_xyz_n3.transpose(1, 2).contiguous(), "idx_list": None}
+            sampled = fused.fps_gather(xyz_n3.contiguous(), self.npoint) if self._can_fuse(xyz) else None
+            if sampled is not None:                                                          # one launch
+                _, new_xyz_n3, new_xyz_cn = sampled
+                geom = {"new_xyz_n3": new_xyz_n3, "new_xyz": new_xyz_cn, "idx_list": None}
+            else:
+                fps_idx = futils.furthest_point_sample(xyz_n3, self.npoint)                  # (B,S) int32
+                new_xyz_n3 = torch.gather(xyz_n3, 1, fps_idx.long().unsqueeze(-1).expand(-1, -1, 3))  # (B,S,3)
+                geom = {"new_xyz_n3": new_xyz_n3, "new_xyz": new_xyz_n3.transpose(1, 2).contiguous(), "idx_list": None}
         new_xyz_n3, new_xyz = geom["new_xyz_n3"], geom["new_xyz"]
         self.last_new_xyz_n3 = new_xyz_n3
         self.last_geom = geom

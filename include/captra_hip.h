@@ -152,6 +152,13 @@ int captra_sa_scale_fused(int b, int n, int m, int k, int cfeat, int c1, int c2,
                           const float *b1, const float *w2, const float *b2, const float *w3, const float *b3,
                           float *out, int out_ctotal, int co_off, captra_stream_t stream);
 
+/* Furthest point sampling + index_points in one launch (pointnet_utils.py:222-223: new_xyz = index_points(xyz,
+ * farthest_point_sample(xyz, S))): xyz (B,N,3) -> idx (B,M) i32, new_xyz_n3 (B,M,3), new_xyz_cn (B,3,M) (either output
+ * pointer may be NULL).  Same selection rule as captra_furthest_point_sampling with temp = 1e10.  Returns -2 when the
+ * cloud does not fit the register-resident kernel (N > ~32k): sample and gather separately then. */
+int captra_fps_gather(int b, int n, int m, const float *xyz, int *idx, float *new_xyz_n3, float *new_xyz_cn,
+                      captra_stream_t stream);
+
 /* SA scale with a pre-transformed first layer.  Layer 1's k-ascending chain runs over the cfeat feature rows first and the
  * three relative-xyz rows last (pointnet_utils.py:234-240), and its first cfeat steps depend on the SOURCE point only:
  *   v1 (B,c1,N) = captra_pointwise_mlp(feat (B,cfeat,N), w1 rows 0..cfeat-1, b1, CAPTRA_ACT_NONE)      (once per source point)

@@ -53,18 +53,53 @@ def test_fps_all_points_identical(pn, device):
     assert (got == 0).all()  # every distance is 0: the lowest index wins every round
 
 
+@pytest.mark.parametrize("variant", [0, 1])
 @pytest.mark.parametrize("waves", [1, 2, 4, 8, 16])
-def test_fps_every_wave_configuration(pn, device, waves):
+def test_fps_every_wave_configuration(pn, device, waves, variant):
+    """Every workgroup shape of both register-resident kernels (variant 0: blocked ownership + ballot pick + packed
+    math, the default; variant 1: strided ownership + two DPP reductions) on clean and duplicated clouds."""
     import ctypes
     from captra_amd import _lib
-    xyz = _nocs_batch(range(2))
+    xyz = np.concatenate([_nocs_batch(range(2)), _nocs_batch(range(1), dup=True)])
     ref = O.furthest_point_sample(xyz, 128)
     _lib.lib().captra_fps_set_waves(ctypes.c_int(waves))
+    _lib.lib().captra_fps_set_variant(ctypes.c_int(variant))
     try:
         got = pn.furthest_point_sample(_dev(xyz, device), 128).cpu().numpy()
     finally:
         _lib.lib().captra_fps_set_waves(ctypes.c_int(0))
+        _lib.lib().captra_fps_set_variant(ctypes.c_int(0))
     np.testing.assert_array_equal(got, ref)
+
+
+@pytest.mark.parametrize("n,m", [(4096, 512), (512, 128), (1000, 300), (130, 130), (3, 2)])
+def test_fps_first_generation_kernel(pn, device, n, m):
+    """The strided-ownership kernel stays selectable (captra_fps_set_variant): same indices."""
+    import ctypes
+    from captra_amd import _lib
+    rng = np.random.default_rng(n + m)
+    xyz = (rng.random((2, n, 3), dtype=np.float32) - 0.5).astype(np.float32)
+    _lib.lib().captra_fps_set_variant(ctypes.c_int(1))
+    try:
+        got = pn.furthest_point_sample(_dev(xyz, device), m).cpu().numpy()
+    finally:
+        _lib.lib().captra_fps_set_variant(ctypes.c_int(0))
+    np.testing.assert_array_equal(got, O.furthest_point_sample(xyz, m))
+
+
+@pytest.mark.parametrize("n,m", [(4096, 512), (512, 128), (1000, 300), (77, 77), (3, 2), (12000, 40)])
+def test_fps_gather_one_launch(device, n, m):
+    """captra_fps_gather: indices of furthest_point_sample + the sampled coordinates in both layouts."""
+    from captra_amd import fused
+    rng = np.random.default_rng(n * 3 + m)
+    xyz = (rng.random((2, n, 3), dtype=np.float32) - 0.5).astype(np.float32)
+    idx, n3, cn = fused.fps_gather(_dev(xyz, device), m)
+    ref = O.furthest_point_sample(xyz, m)
+    np.testing.assert_array_equal(idx.cpu().numpy(), ref)
+    picked = np.take_along_axis(xyz, ref[..., None].astype(np.int64).repeat(3, -1), axis=1)
+    np.testing.assert_array_equal(n3.cpu().numpy(), picked)
+    np.testing.assert_array_equal(cn.cpu().numpy(), picked.transpose(0, 2, 1))
+    assert fused.fps_gather(_dev(np.zeros((1, 20000, 3), np.float32), device), 4) is None   # too large: caller falls back
 
 
 def test_fps_big_cloud_fallback(pn, device):
