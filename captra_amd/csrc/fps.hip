@@ -177,7 +177,7 @@ __device__ __forceinline__ unsigned wave_max_u32_fold(unsigned v) {
 // argmax run on the non-negative floats' bit patterns (v_min_u32 / v_max3_u32: no NaN-canonicalising extras).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <int NWAVES, int PPT>
+template <int NWAVES, int PPT, bool XYZ_LDS>
 __global__ __launch_bounds__(NWAVES * 64) void fps_kernel_blocked(int n, int m, const float *__restrict__ xyz_all,
                                                                   float *__restrict__ temp_all, int *__restrict__ idx_all,
                                                                   float *__restrict__ new_n3, float *__restrict__ new_cn) {
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(NWAVES * 64) void fps_kernel_blocked(int n, int m, 
         if (k < n) {
             x = xyz[(size_t)k * 3 + 0]; y = xyz[(size_t)k * 3 + 1]; z = xyz[(size_t)k * 3 + 2];
             d0 = __float_as_uint(temp != nullptr ? temp[k] : 1e10f);
-            xs[k] = x; ys[k] = y; zs[k] = z;
+            if (XYZ_LDS) { xs[k] = x; ys[k] = y; zs[k] = z; }
         }
         px[i / 2][i & 1] = x; py[i / 2][i & 1] = y; pz[i / 2][i & 1] = z;
         dmin[i] = d0;
@@ -227,7 +227,10 @@ __global__ __launch_bounds__(NWAVES * 64) void fps_kernel_blocked(int n, int m, 
 
     int old = 0;
     for (int j = 1; j < m; ++j) {
-        const float ox = xs[old], oy = ys[old], oz = zs[old];
+        // the last pick's coordinates: broadcast read of the LDS mirror, or (clouds beyond the LDS budget) of global memory
+        const float ox = XYZ_LDS ? xs[old] : xyz[(size_t)old * 3 + 0];
+        const float oy = XYZ_LDS ? ys[old] : xyz[(size_t)old * 3 + 1];
+        const float oz = XYZ_LDS ? zs[old] : xyz[(size_t)old * 3 + 2];
         if (tid == 0) emit(j - 1, ox, oy, oz);
         const f32x2 o2x = {ox, ox}, o2y = {oy, oy}, o2z = {oz, oz};
         unsigned best = 0u;
@@ -263,7 +266,7 @@ __global__ __launch_bounds__(NWAVES * 64) void fps_kernel_blocked(int n, int m, 
         old = (int)sel;
         if (tid == 0) idx[j] = old;
     }
-    if (tid == 0) emit(m - 1, xs[old], ys[old], zs[old]);
+    if (tid == 0) emit(m - 1, xyz[(size_t)old * 3 + 0], xyz[(size_t)old * 3 + 1], xyz[(size_t)old * 3 + 2]);
     if (temp != nullptr) {
 #pragma unroll
         for (int i = 0; i < PPT; ++i) {
@@ -321,13 +324,18 @@ int launch_fps(int b, int n, int m, const float *xyz, float *temp, int *idx, hip
     size_t lds_xyz = (size_t)n * 3 * sizeof(float);
     if constexpr (PPT % 2 == 0) {
         if (g_fps_variant == 0 && slots + lds_xyz <= 150 * 1024) {
-            auto kern2 = fps_kernel_blocked<NWAVES, PPT>;
+            auto kern2 = fps_kernel_blocked<NWAVES, PPT, true>;
             static bool attr2_set = false;
             if (!attr2_set) {
                 hipFuncSetAttribute(reinterpret_cast<const void *>(kern2), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
                 attr2_set = true;
             }
             CAPTRA_LAUNCH("fps", kern2, dim3(b), dim3(NWAVES * 64), slots + lds_xyz, s, n, m, xyz, temp, idx, new_n3, new_cn);
+            return captra_last_error();
+        }
+        if (g_fps_variant == 0) {  // cloud larger than the LDS mirror: same kernel, winner coordinates from global memory
+            CAPTRA_LAUNCH("fps", (fps_kernel_blocked<NWAVES, PPT, false>), dim3(b), dim3(NWAVES * 64), slots, s, n, m, xyz, temp, idx,
+                          new_n3, new_cn);
             return captra_last_error();
         }
     }

@@ -93,7 +93,7 @@ def fps_gather(xyz_n3, m: int):
     coordinates in one launch; None when the cloud is too large for that kernel (caller samples and gathers separately)."""
     L.require_device(xyz_n3)
     B, N, _ = xyz_n3.shape
-    if N * 12 + 256 > 150 * 1024:     # the register-resident kernel mirrors the cloud in LDS (csrc/fps.hip launch_fps)
+    if N > 16 * 64 * 32:              # beyond 32 points per lane x 16 waves the cloud no longer fits the register file
         return None
     idx = torch.empty(B, m, dtype=torch.int32, device=xyz_n3.device)
     n3 = torch.empty(B, m, 3, dtype=torch.float32, device=xyz_n3.device)

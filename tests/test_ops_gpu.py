@@ -87,7 +87,7 @@ def test_fps_first_generation_kernel(pn, device, n, m):
     np.testing.assert_array_equal(got, O.furthest_point_sample(xyz, m))
 
 
-@pytest.mark.parametrize("n,m", [(4096, 512), (512, 128), (1000, 300), (77, 77), (3, 2), (12000, 40)])
+@pytest.mark.parametrize("n,m", [(4096, 512), (512, 128), (1000, 300), (77, 77), (3, 2), (12000, 40), (20480, 64), (32768, 8)])
 def test_fps_gather_one_launch(device, n, m):
     """captra_fps_gather: indices of furthest_point_sample + the sampled coordinates in both layouts."""
     from captra_amd import fused
@@ -99,7 +99,7 @@ def test_fps_gather_one_launch(device, n, m):
     picked = np.take_along_axis(xyz, ref[..., None].astype(np.int64).repeat(3, -1), axis=1)
     np.testing.assert_array_equal(n3.cpu().numpy(), picked)
     np.testing.assert_array_equal(cn.cpu().numpy(), picked.transpose(0, 2, 1))
-    assert fused.fps_gather(_dev(np.zeros((1, 20000, 3), np.float32), device), 4) is None   # too large: caller falls back
+    assert fused.fps_gather(_dev(np.zeros((1, 40000, 3), np.float32), device), 4) is None   # too large: caller falls back
 
 
 def test_fps_big_cloud_fallback(pn, device):
