@@ -48,8 +48,6 @@ struct SaParams {
     const float *w1, *b1, *w2, *b2, *w3, *b3;  // packed: w (ceil32(cin), ceil128(cout)), b (ceil128(cout)), zero padded
     float *out;            // (B,out_ctotal,M)
     int out_ctotal, co_off;
-    int ablate;            // debug/profiling only: bit mask of phases to skip (0 in production)
-    unsigned long long *prof;  // debug/profiling only: per-phase wave-cycle totals (PROF kernels), else null
 };
 
 // Issue the loads of a layer's FIRST register set (16 values per lane) -- called one phase ahead of the
@@ -98,8 +96,7 @@ __device__ __forceinline__ void sa_prefetch_first(float (&pre)[16], const float 
 template <bool LAST, int WN, int TM, bool SMALL>
 __device__ __forceinline__ void sa_layer(int cin, int cout, const float *__restrict__ wt, const float *bias_lds,
                                          const float *Hin, float *Hout, float *red, int red_slot, bool col_ok,
-                                         float (&pre)[16], const float *__restrict__ next_wt, int next_cin, int next_cout,
-                                         bool ablate_epi) {
+                                         float (&pre)[16], const float *__restrict__ next_wt, int next_cin, int next_cout) {
     constexpr int SF_T = 32 * WN;
     constexpr int SF_SLOTS = SF_POS / 32;
     constexpr int KS = 16 / TM;
@@ -175,7 +172,6 @@ __device__ __forceinline__ void sa_layer(int cin, int cout, const float *__restr
 #undef SA_LOAD_SET
 #undef SA_MFMA_SET
     sa_prefetch_first<WN>(pre, next_wt, next_cin, next_cout);
-    if (ablate_epi) return;
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
         const int rbase = tm * SF_BM + wm * 32 + 4 * (lane >> 5);
@@ -206,13 +202,13 @@ __device__ __forceinline__ void sa_layer(int cin, int cout, const float *__restr
 template <bool LAST, int WN>
 __device__ __forceinline__ void sa_layer_any(int cin, int cout, const float *wt, const float *bias_lds, const float *Hin,
                                              float *Hout, float *red, int red_slot, bool col_ok, float (&pre)[16],
-                                             const float *next_wt, int next_cin, int next_cout, bool ablate_epi) {
+                                             const float *next_wt, int next_cin, int next_cout) {
     if (cout > SF_BM) {
-        sa_layer<LAST, WN, 2, false>(cin, cout, wt, bias_lds, Hin, Hout, red, red_slot, col_ok, pre, next_wt, next_cin, next_cout, ablate_epi);
+        sa_layer<LAST, WN, 2, false>(cin, cout, wt, bias_lds, Hin, Hout, red, red_slot, col_ok, pre, next_wt, next_cin, next_cout);
     } else if (cin <= 8) {
-        sa_layer<LAST, WN, 1, true>(cin, cout, wt, bias_lds, Hin, Hout, red, red_slot, col_ok, pre, next_wt, next_cin, next_cout, ablate_epi);
+        sa_layer<LAST, WN, 1, true>(cin, cout, wt, bias_lds, Hin, Hout, red, red_slot, col_ok, pre, next_wt, next_cin, next_cout);
     } else {
-        sa_layer<LAST, WN, 1, false>(cin, cout, wt, bias_lds, Hin, Hout, red, red_slot, col_ok, pre, next_wt, next_cin, next_cout, ablate_epi);
+        sa_layer<LAST, WN, 1, false>(cin, cout, wt, bias_lds, Hin, Hout, red, red_slot, col_ok, pre, next_wt, next_cin, next_cout);
     }
 }
 
@@ -226,15 +222,7 @@ __device__ __forceinline__ void zero_pad_rows(float *buf, int c) {
     for (int e = threadIdx.x; e < n; e += 256 * WN) buf[(size_t)c * SF_T + e] = 0.f;
 }
 
-// PROF: every wave accumulates s_memtime deltas per phase (gather, barrier, layer 1, barrier, layer 2, barrier,
-// layer 3, barrier; slot 8 = whole kernel, slot 9 = waves) into p.prof -- a measurement build of the same code.
-#define SA_TICK(slot)                                                     \
-    if (PROF) {                                                           \
-        const unsigned long long t_now = __builtin_amdgcn_s_memtime();    \
-        t_acc[slot] += t_now - t_last;                                    \
-        t_last = t_now;                                                   \
-    }
-template <int WN, bool PROF>
+template <int WN>
 __global__ __launch_bounds__(256 * WN) __attribute__((amdgpu_waves_per_eu(4, 8))) void sa_fused_kernel(SaParams p) {
     constexpr int SF_T = 32 * WN;
     constexpr int SF_THREADS = 256 * WN;
@@ -257,9 +245,6 @@ __global__ __launch_bounds__(256 * WN) __attribute__((amdgpu_waves_per_eu(4, 8))
     const int gcol = tid % SF_T;   // gather: this thread's position within the sub-tile
     const int grow = tid / SF_T;   // ... and its first row (8 row groups)
 
-    unsigned long long t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long t_last = PROF ? __builtin_amdgcn_s_memtime() : 0ull;
-    const unsigned long long t_begin = t_last;
     float pre[16];  // the next layer's first weight set, in flight across epilogues / barriers / the gather
     sa_prefetch_first<WN>(pre, p.w1, cin1, p.c1);
     for (int e = tid; e < 3 * SF_MAXC; e += SF_THREADS) {
@@ -272,7 +257,6 @@ __global__ __launch_bounds__(256 * WN) __attribute__((amdgpu_waves_per_eu(4, 8))
 
     for (int sub = 0; sub < SF_SUBS; ++sub) {
         const long long base = pos0 + (long long)sub * SF_T;
-        if (PROF) t_last = __builtin_amdgcn_s_memtime();
         // ---- gather X1 = [feat rows | xyz rows - centre] for the 64 positions of this sub-tile --------
         {
             long long pos = base + gcol;
@@ -282,7 +266,6 @@ __global__ __launch_bounds__(256 * WN) __attribute__((amdgpu_waves_per_eu(4, 8))
             const float *fb = p.feat + (size_t)b * p.cfeat * p.n + id;
             float *xcol = RA + gcol;
             int kg = grow;
-            if (p.ablate & 1) kg = 1 << 30;                 // ablation: no feature gather
             for (; kg + 56 < p.cfeat; kg += 64) {       // 8 independent loads in flight per lane
                 float v[8];
 #pragma unroll
@@ -297,23 +280,15 @@ __global__ __launch_bounds__(256 * WN) __attribute__((amdgpu_waves_per_eu(4, 8))
             }
             zero_pad_rows<WN>(RA, cin1);
         }
-        SA_TICK(0)
         __syncthreads();  // X1 complete (and the previous sub-tile's layer 3 is done with region A)
-        SA_TICK(1)
-        if (!(p.ablate & 8)) sa_layer_any<false, WN>(cin1, p.c1, p.w1, bias_lds, RA, RB, red, 0, true, pre, p.w2, p.c1, p.c2, p.ablate & 2);
-        SA_TICK(2)
+        sa_layer_any<false, WN>(cin1, p.c1, p.w1, bias_lds, RA, RB, red, 0, true, pre, p.w2, p.c1, p.c2);
         __syncthreads();  // H1 complete, X1 dead
-        SA_TICK(3)
-        if (!(p.ablate & 16)) sa_layer_any<false, WN>(p.c1, p.c2, p.w2, bias_lds + SF_MAXC, RB, RA, red, 0, true, pre, p.w3, p.c2, p.c3, p.ablate & 2);
+        sa_layer_any<false, WN>(p.c1, p.c2, p.w2, bias_lds + SF_MAXC, RB, RA, red, 0, true, pre, p.w3, p.c2, p.c3);
         zero_pad_rows<WN>(RA, p.c2);
-        SA_TICK(4)
         __syncthreads();  // H2 complete
-        SA_TICK(5)
         const bool col_ok = (base + wn * 32 + (lane & 31)) < L;
-        if (!(p.ablate & 32)) sa_layer_any<true, WN>(p.c2, p.c3, p.w3, bias_lds + 2 * SF_MAXC, RA, nullptr, red, sub * WN, col_ok, pre, p.w1, cin1, p.c1, p.ablate & 4);
-        SA_TICK(6)
+        sa_layer_any<true, WN>(p.c2, p.c3, p.w3, bias_lds + 2 * SF_MAXC, RA, nullptr, red, sub * WN, col_ok, pre, p.w1, cin1, p.c1);
         __syncthreads();  // region A free for the next gather, red visible
-        SA_TICK(7)
     }
     // combine the 32-position maxima of each group of K positions
     const int tiles_per_group = p.k / 32;
@@ -327,13 +302,7 @@ __global__ __launch_bounds__(256 * WN) __attribute__((amdgpu_waves_per_eu(4, 8))
             p.out[((size_t)b * p.out_ctotal + p.co_off + row) * p.m + centre] = v;
         }
     }
-    if (PROF && p.prof != nullptr && lane == 0 && (blockIdx.x + blockIdx.y) % 61 == 0) {  // a sample of the blocks
-        for (int i = 0; i < 8; ++i) atomicAdd(p.prof + i, t_acc[i]);
-        atomicAdd(p.prof + 8, __builtin_amdgcn_s_memtime() - t_begin);
-        atomicAdd(p.prof + 9, 1ull);
-    }
 }
-#undef SA_TICK
 
 // =====================================================================================================
 // Register-resident variant: sa_wave_kernel<CF, C1, C2, C3>  (channel counts are template constants)
@@ -735,13 +704,11 @@ __global__ __launch_bounds__(SL_WAVES * 64) __attribute__((amdgpu_waves_per_eu(4
 
 // experiment knob (not part of the ABI): force the sub-tile width, 0 = heuristic
 static int g_sa_wn = 0;
-static int g_sa_ablate = 0;
 extern "C" void captra_sa_fused_set_wn(int wn) { g_sa_wn = wn; }
-extern "C" void captra_sa_fused_set_ablate(int mask) { g_sa_ablate = mask; }
 static int g_sa_mode = 0;  // 0 = heuristic (register-resident kernels where instantiated), 1 = always the generic LDS kernel,
                            // 2 = register-resident kernels with streamed weights only (no LDS-weight variant)
 extern "C" void captra_sa_fused_set_mode(int mode) { g_sa_mode = mode; }
-static unsigned long long *g_sa_prof = nullptr;  // device buffer of 10 counters; non-null selects the PROF kernels
+static unsigned long long *g_sa_prof = nullptr;  // device buffer of 10 counters: sa_wave_kernel's opt-in phase timers
 extern "C" void captra_sa_fused_set_prof(unsigned long long *dev_counters) { g_sa_prof = dev_counters; }
 
 // One SA scale, fused (see include/captra_hip.h).
@@ -759,8 +726,8 @@ extern "C" int captra_sa_scale_fused(int b, int n, int m, int k, int cfeat, int 
     p.n = n; p.m = m; p.k = k; p.cfeat = cfeat; p.c1 = c1; p.c2 = c2; p.c3 = c3;
     p.feat = feat; p.xyz_cn = xyz_cn; p.new_xyz = new_xyz; p.idx = idx;
     p.w1 = w1; p.b1 = b1; p.w2 = w2; p.b2 = b2; p.w3 = w3; p.b3 = b3;
-    p.out = out; p.out_ctotal = out_ctotal; p.co_off = co_off; p.ablate = g_sa_ablate; p.prof = g_sa_prof;
-    if (g_sa_mode != 1 && g_sa_ablate == 0) {
+    p.out = out; p.out_ctotal = out_ctotal; p.co_off = co_off; 
+    if (g_sa_mode != 1) {
         // register-resident kernels for the channel shapes of the CAPTRA backbone (network/models/pointnet_utils.py
         // PointNet2Msg config); any other shape takes the generic LDS kernel below
         SwParams q;
@@ -825,22 +792,14 @@ extern "C" int captra_sa_scale_fused(int b, int n, int m, int k, int cfeat, int 
     if ((wn == 2 ? lds64 : lds32) > 160 * 1024) return -2;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(sa_fused_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void *>(sa_fused_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void *>(sa_fused_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void *>(sa_fused_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(sa_fused_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(sa_fused_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    if (p.prof != nullptr) {
-        if (wn == 2) {
-            CAPTRA_LAUNCH("sa_scale_fused", (sa_fused_kernel<2, true>), grid, dim3(512), lds64, (hipStream_t)stream, p);
-        } else {
-            CAPTRA_LAUNCH("sa_scale_fused", (sa_fused_kernel<1, true>), grid, dim3(256), lds32, (hipStream_t)stream, p);
-        }
-    } else if (wn == 2) {
-        CAPTRA_LAUNCH("sa_scale_fused", (sa_fused_kernel<2, false>), grid, dim3(512), lds64, (hipStream_t)stream, p);
+    if (wn == 2) {
+        CAPTRA_LAUNCH("sa_scale_fused", sa_fused_kernel<2>, grid, dim3(512), lds64, (hipStream_t)stream, p);
     } else {
-        CAPTRA_LAUNCH("sa_scale_fused", (sa_fused_kernel<1, false>), grid, dim3(256), lds32, (hipStream_t)stream, p);
+        CAPTRA_LAUNCH("sa_scale_fused", sa_fused_kernel<1>, grid, dim3(256), lds32, (hipStream_t)stream, p);
     }
     return captra_last_error();
 }

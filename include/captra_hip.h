@@ -238,6 +238,16 @@ void captra_prof_reset(void);
 int captra_prof_read(const char *name, double *total_ms, long long *launches);
 int captra_prof_names(char *buf, int buflen);
 
+/* ---- 4. Experiment switches (process-wide, NOT part of the stable ABI; used by tests/ and tools/ to cross-check variants
+ *         that compute the same bits).  Defaults (0 / 1 for captra_pw_set_direct) select the production kernels. ---- */
+void captra_fps_set_waves(int waves);       /* FPS: waves per cloud (0 = heuristic) */
+void captra_fps_set_variant(int v);         /* FPS: 0 = blocked ownership + ballot pick (default), 1 = first-generation kernel */
+void captra_sa_fused_set_mode(int mode);    /* SA scale: 0 = register-resident kernels where instantiated, 1 = generic LDS kernel
+                                               for every shape, 2 = register-resident with streamed weights only */
+void captra_sa_fused_set_wn(int wn);        /* generic LDS kernel: sub-tile width 32*wn (0 = heuristic) */
+void captra_sa_fused_set_prof(unsigned long long *dev_counters); /* sa_wave_kernel: 10 device counters of phase timers, or NULL */
+void captra_pw_set_direct(int on);          /* dense layers: 1 = direct-operand kernel (default), 0 = LDS-staged kernel */
+
 #ifdef __cplusplus
 }
 #endif

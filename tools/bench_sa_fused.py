@@ -26,13 +26,11 @@ def main():
     ap.add_argument("--wn", type=int, default=0)
     ap.add_argument("--pre", action="store_true", help="pre-transformed first layer (captra_sa_scale_pre) where supported; time includes the v1 launch")
     ap.add_argument("--mode", type=int, default=0, help="0 = register-resident kernels where instantiated, 1 = generic LDS kernel")
-    ap.add_argument("--phases", action="store_true", help="debug: in-kernel s_memtime phase breakdown (PROF kernels)")
-    ap.add_argument("--ablate", type=int, default=0, help="debug: phases to skip (1 gather, 2 mid epilogues, 4 last epilogue, 8/16/32 layer 1/2/3)")
+    ap.add_argument("--phases", action="store_true", help="debug: in-kernel s_memtime phase breakdown of sa_wave_kernel")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     import ctypes
     _lib.lib().captra_sa_fused_set_wn(ctypes.c_int(a.wn))
-    _lib.lib().captra_sa_fused_set_ablate(ctypes.c_int(a.ablate))
     B = a.clouds
     names = list(SHAPES) if a.which == "all" else [a.which]
     for name in names:
@@ -75,13 +73,13 @@ def main():
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(); run(); e1.record()
             torch.cuda.synchronize()
-            print(f"  PROF kernel took {e0.elapsed_time(e1) * 1e3:.1f} us")
+            print(f"  timed launch took {e0.elapsed_time(e1) * 1e3:.1f} us")
             _lib.lib().captra_sa_fused_set_prof(ctypes.c_void_p(0))
             c = cnt.tolist()
             waves = max(c[9], 1)
-            labels = ["gather", "bar", "L1", "bar", "L2", "bar", "L3", "bar"] if a.mode == 1 else ["start", "L1", "L2", "L3", "end-barrier"]
-            tot = c[8] / waves if a.mode == 1 else sum(c[:len(labels)]) / waves
-            if a.mode != 1 and c[6]:
+            labels = ["start", "L1", "L2", "L3", "end-barrier"]     # sa_wave_kernel's timers (streamed-weight scales)
+            tot = sum(c[:len(labels)]) / waves
+            if c[6]:
                 print(f"  wave life: {c[5] / waves:.0f} shader cycles in {c[6] / waves / 100:.1f} us (s_memrealtime) -> shader clock {c[5] / c[6] * 0.1:.3f} GHz")
             print(f"  {name}: per-wave cycles, kernel {tot:.0f}: " + "  ".join(f"{l} {c[i] / waves:.0f}" for i, l in enumerate(labels)))
         _lib.prof_reset(); _lib.prof_enable(True)
