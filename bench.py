@@ -40,13 +40,21 @@ PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 pea
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec
 
 
-def build_workload(batch: int, device, frames: int = 8, category: str = "1"):
+WORKLOADS = {  # name: (obj_category, obj_config, synthetic trajectory kind, description)
+    "bottle": ("1", "obj_info_nocs.yml", "nocs", "NOCS-REAL275-shaped rigid category 'bottle' (1 part, symmetric)"),
+    "camera": ("3", "obj_info_nocs.yml", "nocs", "NOCS-REAL275-shaped rigid category 'camera' (1 part, non-symmetric)"),
+    "drawers": ("drawers", "obj_info_sapien.yml", "arti", "SAPIEN-shaped articulated category 'drawers' (4 parts)"),
+}
+
+
+def build_workload(batch: int, device, frames: int = 8, category: str = "bottle"):
     from captra_amd.configs import make_config
     from captra_amd.trainer import Trainer
     from tests import clouds
     from tests.weights import make_state_dict
 
-    cfg = make_config(category, experiment_dir="/tmp/captra_bench")
+    obj_category, obj_config, kind, _ = WORKLOADS[category]
+    cfg = make_config(obj_category, obj_config, experiment_dir="/tmp/captra_bench")
     cfg["device"] = device
     trainer = Trainer(cfg)
     shapes = {k: tuple(v.shape) for k, v in trainer.model.state_dict().items()}
@@ -54,7 +62,7 @@ def build_workload(batch: int, device, frames: int = 8, category: str = "1"):
     trainer.model.load_state_dict(sd)
     model = trainer.model.eval()
     # distinct clouds per trajectory (8 base objects tiled), `frames` frames cycled by the loop
-    base = clouds.make_trajectory("nocs", min(batch, 8), frames, seed=0)
+    base = clouds.make_trajectory(kind, min(batch, 8), frames, seed=0)
     reps = (batch + len(base[0]["points"]) - 1) // len(base[0]["points"])
 
     def tile(t):
@@ -204,6 +212,8 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     ap.add_argument("--no-graph", action="store_true", help="launch the step eagerly instead of replaying a hipGraph")
+    ap.add_argument("--category", default="bottle", choices=sorted(WORKLOADS),
+                    help="bottle = BASELINE.json configs[1] (the metric's configuration); camera / drawers: the other object classes")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -222,7 +232,7 @@ def main():
     from captra_amd import _lib, fused
     from captra_amd.parallel import PoseExchange
 
-    cfg, sd, model, data = build_workload(args.batch, device)
+    cfg, sd, model, data = build_workload(args.batch, device, category=args.category)
     B, P = args.batch, cfg["num_parts"]
     exchange = PoseExchange(B, P, device, world, rank)
     nframes = len(model.feed_dict)
@@ -298,10 +308,10 @@ def main():
         "metric": "tracked frames/sec (4096-pt clouds)", "value": round(frames / elapsed, 2), "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "NOCS-REAL275-shaped rigid category 'bottle' (1 part, symmetric), 4096 pts/frame, "
-                               f"batch={B} trajectories per GPU, fp32 (BASELINE.json configs[1])",
+        "config": {"workload": f"{WORKLOADS[args.category][3]}, 4096 pts/frame, batch={B} trajectories per GPU, fp32"
+                               + (" (BASELINE.json configs[1])" if args.category == "bottle" else " (BASELINE.json configs[3]: drawers)" if args.category == "drawers" else ""),
                    "points": 4096, "trajectories_per_gpu": B, "parallelism": f"dp{world} (trajectory-sharded, RCCL all-gather of poses)",
-                   "weights": "random-init default_rng(7), real architecture (3.94 M params)",
+                   "weights": f"random-init default_rng(7), real architecture ({sum(v.numel() for v in sd.values()) / 1e6:.2f} M params incl. BN statistics)",
                    "launch": "hipGraph replay of the step" if graph is not None else "eager launches"},
     }
     if timing:
@@ -341,7 +351,7 @@ def main():
         out["kernel_ms_per_step"]["_sum_captra_kernels"] = round(total_ms / args.steps, 3)
     if world == 1 and timing:
         out["hbm_ops"] = hbm_ops_roofline(B, device)
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and args.category == "bottle":
         out["cpu_baseline"] = cpu_baseline(cfg, sd, args.cpu_budget)
         out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
     print(json.dumps(out))

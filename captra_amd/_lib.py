@@ -41,7 +41,7 @@ _SIGNATURES = {
     "captra_three_nn_weights": [_INT, _INT, _INT, _P, _P, _P, _P, _P],
     "captra_fps_gather": [_INT, _INT, _INT, _P, _P, _P, _P, _P],
     "captra_sa_scale_pre": [_INT] * 8 + [_P] * 9 + [_P, _INT, _INT, _P],
-    "captra_rot_pool_compose": [_INT, _INT, _INT, _INT, _P, _P, _P, _P, _P, _P],
+    "captra_rot_pool_compose": [_INT, _INT, _INT, _INT, _INT, _P, _P, _P, _P, _P, _P],
     "captra_mlp_chain3": [_INT, _INT, _INT, _INT, _INT, _LL, _P, _P, _P, _P, _P, _P, _P, _INT, _P, _P],
     "captra_interp_concat": [_INT, _INT, _INT, _INT, _INT, _P, _P, _P, _P, _P, _P],
     "captra_fp_interpolate_concat": [_INT, _INT, _INT, _INT, _INT, _P, _P, _P, _P, _P, _P, _P, _P],

@@ -150,6 +150,16 @@ class RotationRegressor(nn.Module):
             return self.rtvec_head[0](feat).unsqueeze(1)
         return torch.stack([head(feat) for head in self.rtvec_head], dim=1)
 
+    def raw_diag(self, feat):
+        """feat (B*P,in_dim,N), clouds ordered (trajectory, part) -> (B*P,R,N): head p evaluated on the clouds of part p
+        only.  The tracking read-out keeps exactly these entries of the P x P evaluation (networks.py:200-203)."""
+        P = self.num_parts
+        if P == 1:
+            return self.rtvec_head[0](feat)
+        Q, C, N = feat.shape
+        per_part = feat.view(Q // P, P, C, N)
+        return torch.stack([self.rtvec_head[p](per_part[:, p].contiguous()) for p in range(P)], dim=1).reshape(Q, -1, N)
+
     def forward(self, feat):
         """feat (B,in_dim,N) -> (B,P,3,N) unit vectors or (B,P,9,N) row-major rotation matrices."""
         raw = self.raw(feat)                                                         # (B,P,R,N)

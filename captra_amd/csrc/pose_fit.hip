@@ -303,7 +303,7 @@ __device__ __forceinline__ void cross3(const float u[3], const float v[3], float
     out[2] = u[0] * v[1] - u[1] * v[0];
 }
 
-__global__ __launch_bounds__(PF_THREADS) void rot_pool_compose_kernel(int p, int n, int sym, const float *__restrict__ raw,
+__global__ __launch_bounds__(PF_THREADS) void rot_pool_compose_kernel(int p, int n, int sym, int diag, const float *__restrict__ raw,
                                                                       const int *__restrict__ labels,
                                                                       const float *__restrict__ prev_rot,
                                                                       float *__restrict__ rot, float *__restrict__ delta) {
@@ -311,7 +311,8 @@ __global__ __launch_bounds__(PF_THREADS) void rot_pool_compose_kernel(int p, int
     const int q = blockIdx.x;            // = b * P + part: cloud q, head `part`
     const int bi = q / p, pi = q % p;
     const int R = sym ? 3 : 6;
-    const float *src = raw + ((size_t)q * p + pi) * R * n;
+    // diag: raw holds only head `part` on cloud (b, part) -- (B*P, R, N); else all P heads per cloud -- (B*P, P, R, N)
+    const float *src = raw + (diag ? (size_t)q : (size_t)q * p + pi) * R * n;
     const int *lab = labels + (size_t)bi * n;
     double acc[10];
 #pragma unroll
@@ -382,12 +383,12 @@ __global__ __launch_bounds__(PF_THREADS) void rot_pool_compose_kernel(int p, int
 
 }  // namespace
 
-extern "C" int captra_rot_pool_compose(int b, int p, int n, int sym, const float *raw, const int *labels,
+extern "C" int captra_rot_pool_compose(int b, int p, int n, int sym, int diag_only, const float *raw, const int *labels,
                                        const float *prev_rot, float *rot, float *delta, captra_stream_t stream) {
     if (b < 0 || p < 1 || n < 0) return -1;
     if (b == 0) return 0;
     CAPTRA_LAUNCH("rot_pool_compose", rot_pool_compose_kernel, dim3(b * p), dim3(PF_THREADS), 0, (hipStream_t)stream, p, n, sym,
-                  raw, labels, prev_rot, rot, delta);
+                  diag_only, raw, labels, prev_rot, rot, delta);
     return captra_last_error();
 }
 

@@ -140,18 +140,21 @@ USE_ROT_READOUT = True   # tracking: rotation read-out (normalise, masked mean, 
 
 
 def rot_pool_compose(raw, labels_i32, prev_rot, sym: bool, want_delta: bool = False):
-    """raw (B*P,P,R,N) rotation-head outputs, labels (B,N) int32, prev_rot (B,P,3,3) -> rotation (B,P,3,3)
-    = prev_rot @ dR (captra_rot_pool_compose); with want_delta also dR."""
+    """raw: rotation-head outputs, (B*P,P,R,N) (every head on every cloud) or (B*P,R,N) (head p on cloud (b,p) only);
+    labels (B,N) int32, prev_rot (B,P,3,3) -> rotation (B,P,3,3) = prev_rot @ dR (captra_rot_pool_compose);
+    with want_delta also dR."""
     L.require_device(raw, labels_i32, prev_rot)
-    Q, P, R, N = raw.shape
-    B = Q // P
-    assert Q == B * P and R == (3 if sym else 6) and labels_i32.shape == (B, N) and labels_i32.dtype == torch.int32
+    B, P = prev_rot.shape[:2]
+    diag = raw.dim() == 3
+    R, N = raw.shape[-2:]
+    assert raw.shape[0] == B * P and (diag or raw.shape[1] == P) and R == (3 if sym else 6)
+    assert labels_i32.shape == (B, N) and labels_i32.dtype == torch.int32
     assert prev_rot.shape == (B, P, 3, 3) and raw.is_contiguous() and prev_rot.is_contiguous() and labels_i32.is_contiguous()
     rot = torch.empty(B, P, 3, 3, dtype=torch.float32, device=raw.device)
     delta = torch.empty_like(rot) if want_delta else None
     with torch.cuda.device(raw.device):
-        L.call("captra_rot_pool_compose", B, P, N, 1 if sym else 0, L.ptr(raw), L.ptr(labels_i32), L.ptr(prev_rot),
-               L.ptr(rot), L.ptr(delta))
+        L.call("captra_rot_pool_compose", B, P, N, 1 if sym else 0, 1 if diag else 0, L.ptr(raw), L.ptr(labels_i32),
+               L.ptr(prev_rot), L.ptr(rot), L.ptr(delta))
     return (rot, delta) if want_delta else rot
 
 

@@ -123,9 +123,9 @@ class RotationRegressionBackbone(nn.Module):
         self._default = None
 
     def raw_point_rtvec(self, cam, cam_n3=None, geom=None):
-        """cam (B,3,N) -> (B,P,R,N): backbone + the rotation heads' raw outputs (fused read-out path:
+        """cam (B*P,3,N) -> (B*P,R,N): backbone + rotation head p on the clouds of part p (fused read-out path:
         captra_rot_pool_compose does the per-point normalisation, the masked mean and the pose algebra)."""
-        return self.pose_pred.raw(self.encoder(cam, input_n3=cam_n3, geom=geom))
+        return self.pose_pred.raw_diag(self.encoder(cam, input_n3=cam_n3, geom=geom))
 
     def forward(self, cam, cam_labels, cam_n3=None, geom=None):
         """cam (B,3,N), cam_labels (B,N) -> {'rtvec' (B,P,D) masked mean, 'point_rtvec' (B,P,D,N)}."""
@@ -182,7 +182,7 @@ class PartCanonNet(nn.Module):
         if (eval_rnpcs and test_mode and not self.return_point_rotation and not self.training and cam_cn.is_cuda
                 and fused.USE_ROT_READOUT):
             # tracking fast path: one launch for per-point normalisation + masked mean + frame + R_prev * dR
-            raw = self.regress_net.raw_point_rtvec(cam_cn, cam_n3=cam_n3, geom=geom)       # (B*P,P,R,N)
+            raw = self.regress_net.raw_point_rtvec(cam_cn, cam_n3=cam_n3, geom=geom)       # (B*P,R,N), head p on cloud (b,p)
             labels_i32 = input["pred_labels"].int().contiguous()
             rotation = fused.rot_pool_compose(raw, labels_i32, part_pose["rotation"].float().contiguous(), self.sym)
             npcs = input["pred_nocs"].reshape(B, P, 3, -1).float().contiguous()

@@ -213,12 +213,14 @@ int captra_part_fit_st(int b, int p, int n, int sym, const int *labels, const fl
                        float *scale, float *trans, int *valid, captra_stream_t stream);
 
 /* Rotation read-out of one tracking step (blocks.py:147-156, networks.py:127-138 and 200-203,
- * part_dof_utils.py:124-141, rotations.py:302-387) in one launch: raw (B*P, P, R, N) = the P rotation heads' raw outputs
- * on each of the B*P canonicalised clouds (R = 3 symmetric: y-axis; R = 6: ortho6d), labels (B,N) i32, prev_rot (B,P,3,3)
+ * part_dof_utils.py:124-141, rotations.py:302-387) in one launch.  raw = the rotation heads' raw outputs on the B*P
+ * canonicalised clouds (R = 3 symmetric: y-axis; R = 6: ortho6d): (B*P, P, R, N) with all P heads per cloud as the
+ * reference evaluates them (diag_only = 0), or (B*P, R, N) holding only head p on cloud (b,p) -- the only entries the
+ * read-out consumes (diag_only = 1).  labels (B,N) i32, prev_rot (B,P,3,3)
  *   -> rot (B,P,3,3) = prev_rot * dR, where dR = frame of the masked-mean per-point prediction of head p on cloud (b,p)
  *      ((0,1,0) / identity when no point carries label p); delta (B,P,3,3) receives dR when non-NULL. */
-int captra_rot_pool_compose(int b, int p, int n, int sym, const float *raw, const int *labels, const float *prev_rot,
-                            float *rot, float *delta, captra_stream_t stream);
+int captra_rot_pool_compose(int b, int p, int n, int sym, int diag_only, const float *raw, const int *labels,
+                            const float *prev_rot, float *rot, float *delta, captra_stream_t stream);
 
 /* Batched 3x3 orthogonal Procrustes: R = U diag(1,1,det(U V^T)) V^T with U S V^T = tgt^T src
  * (rotate_pts_batch procrustes.py:25-56).  src, tgt (nb,N,3) -> rot (nb,3,3).  One-sided Jacobi. */

@@ -583,6 +583,10 @@ def test_rot_pool_compose_vs_reference_algebra(device, sym, P):
         labels[1][labels[1] == P - 1] = P                       # trajectory 1: last part has no points
     prev = np.stack([clouds._rot_y(0.3 * i) @ clouds._rot_x(0.1 * i) for i in range(B * P)]).reshape(B, P, 3, 3).astype(np.float32)
     rot, delta = fused.rot_pool_compose(_dev(raw, device), _dev(labels, device), _dev(prev, device), sym, want_delta=True)
+    # the diagonal-only layout (head p on cloud (b,p)) gives the same read-out
+    diag = np.ascontiguousarray(raw.reshape(B, P, P, R, N)[:, np.arange(P), np.arange(P)].reshape(B * P, R, N))
+    rot_d, delta_d = fused.rot_pool_compose(_dev(diag, device), _dev(labels, device), _dev(prev, device), sym, want_delta=True)
+    assert torch.equal(rot, rot_d) and torch.equal(delta, delta_d)
     # reference sequence on the CPU
     t = torch.from_numpy(raw).transpose(-1, -2)                 # (Q,P,N,R)
     if sym:
