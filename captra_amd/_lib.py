@@ -39,6 +39,8 @@ _SIGNATURES = {
     "captra_mlp_max": [_INT, _INT, _INT, _INT, _INT, _P, _P, _P, _P, _INT, _INT, _P],
     "captra_sa_scale_fused": [_INT] * 8 + [_P] * 11 + [_INT, _INT, _P],
     "captra_three_nn_weights": [_INT, _INT, _INT, _P, _P, _P, _P, _P],
+    "captra_pointwise_mlp_gn": [_INT, _INT, _INT, _LL, _P, _P, _P, _P, _INT, _P, _P, _INT, _P],
+    "captra_gn_finalize": [_INT, _INT, _INT, _INT, _LL, _F, _P, _P, _P, _P, _P],
     "captra_fps_gather": [_INT, _INT, _INT, _P, _P, _P, _P, _P],
     "captra_sa_scale_pre": [_INT] * 8 + [_P] * 9 + [_P, _INT, _INT, _P],
     "captra_rot_pool_compose": [_INT, _INT, _INT, _INT, _INT, _P, _P, _P, _P, _P, _P],

@@ -56,11 +56,13 @@ def get_point_mlp(in_dim, out_dim, dims, acti="none", dropout=True, last_bn=Fals
 
 def run_point_mlp(seq: nn.Sequential, x: torch.Tensor, cache: dict) -> torch.Tensor:
     """Evaluate a get_point_mlp / MLPConv1d Sequential on (B,C,N) through the fused kernels:
-    Conv(+BatchNorm)(+ReLU | Sigmoid) groups become one MFMA launch; GroupNorm(+ReLU) stays a
-    separate normalisation step after an activation-free conv."""
+    Conv(+BatchNorm)(+ReLU | Sigmoid) groups become one MFMA launch.  Conv -> GroupNorm -> ReLU chains (the rotation
+    heads) run without a normalisation pass: the conv's epilogue emits the group statistics and the next conv applies
+    relu(a*x + b) while loading its operand (fused.USE_GN_FUSED); otherwise GroupNorm(+ReLU) is one separate kernel."""
     mods = list(seq)
     i = 0
     x = x.contiguous()
+    pending = None      # GroupNorm coefficients (B,C,2) of the layer that produced x, not applied yet (fused GN chain)
     while i < len(mods):
         conv = mods[i]
         assert isinstance(conv, nn.Conv1d), type(conv)
@@ -83,6 +85,22 @@ def run_point_mlp(seq: nn.Sequential, x: torch.Tensor, cache: dict) -> torch.Ten
         if key not in cache:
             cache[key] = fold_conv_bn(conv, bn, x.device)
         lin = cache[key]
+        n_pos = x.numel() // (x.shape[0] * x.shape[1])
+        if gn is not None and act == fused.ACT_RELU and fused.gn_chain_supported(x, lin.cout) and j < len(mods):
+            # Conv -> GroupNorm -> ReLU with a consumer behind it: the conv emits the statistics, the consumer normalises
+            x, stats = fused.pointwise_mlp_gn(x, lin, pending, fused.ACT_NONE, want_stats=True)
+            pending = fused.gn_finalize(stats, gn.num_groups, gn.weight, gn.bias, gn.eps, n_pos)
+            i = j
+            continue
+        if pending is not None:
+            if gn is None and not sigmoid_tail:
+                x = fused.pointwise_mlp_gn(x, lin, pending, act)
+                pending = None
+                i = j
+                continue
+            # a consumer the fused kernels do not cover: materialise the pending normalisation first
+            x = torch.relu(x * pending[:, :, 0:1] + pending[:, :, 1:2])
+            pending = None
         if gn is not None:
             x = fused.pointwise_mlp(x, lin, fused.ACT_NONE)
             cpg = x.shape[1] // gn.num_groups
@@ -97,6 +115,8 @@ def run_point_mlp(seq: nn.Sequential, x: torch.Tensor, cache: dict) -> torch.Ten
             if sigmoid_tail:
                 x = torch.sigmoid(x)
         i = j
+    if pending is not None:          # (cannot happen for the heads of this network: their last conv has no norm)
+        x = torch.relu(x * pending[:, :, 0:1] + pending[:, :, 1:2])
     return x
 
 

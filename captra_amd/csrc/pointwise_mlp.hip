@@ -56,6 +56,10 @@ struct PwParams {
     const int *idx;       // (B,M,K)
     // EPI_MAXK
     int y_ctotal, co_off; // y is (B,y_ctotal,M), this layer writes channels [co_off, co_off+cout)
+    // GroupNorm fusion of the direct kernel (captra_pointwise_mlp_gn)
+    const float *ab_in;   // (B,cin,2) or null: the input is relu(a*x + b) per (cloud, input channel)
+    float *stats_out;     // (B,cout,T,2) or null: per output row and 64-column tile, (sum, sum of squares) of y
+    int stats_t;          // T
 };
 
 template <int CTRL>
@@ -312,10 +316,29 @@ int launch_pw(int b, const PwParams &p, hipStream_t s, const char *name) {
 // A wave owns a (TM*32) x (TN*32) tile with TM*TN independent accumulators; the four waves of a
 // workgroup (WGM x WGN) share operand rows through L1.  Same k-ascending fmaf chain -> same bits.
 // ---------------------------------------------------------------------------------------------
-template <int TM, int TN, int WGM, int WGN>
+// AFF: the layer's input is the previous layer's raw output under that layer's GroupNorm + ReLU, applied on the fly
+//      to every B operand as relu(a*x + b) with per-(cloud, channel) coefficients (captra_gn_finalize);
+// ST:  the epilogue also reduces this layer's raw output to per-row, per-64-column-tile (sum, sum of squares)
+//      partials -- fixed DPP order, no atomics -- from which captra_gn_finalize derives the next coefficients.
+// Together they remove the separate GroupNorm pass (one read and one write of the activation tensor per layer).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add_f32(float v) {  // 0 is the identity: lanes without a source / masked rows add 0
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, true));
+}
+// sum over each half-wave (32 lanes): valid in lanes 16..31 (lower half) and 48..63 (upper half)
+__device__ __forceinline__ float half_wave_sum(float v) {
+    v = dpp_add_f32<0xB1, 0xF>(v);
+    v = dpp_add_f32<0x4E, 0xF>(v);
+    v = dpp_add_f32<0x141, 0xF>(v);
+    v = dpp_add_f32<0x140, 0xF>(v);   // every lane of a row of 16 holds the row sum
+    v = dpp_add_f32<0x142, 0xA>(v);   // row_bcast15: rows 1 and 3 add rows 0 and 2
+    return v;
+}
+
+template <int TM, int TN, int WGM, int WGN, bool AFF = false, bool ST = false>
 __global__ __launch_bounds__(256) void pw_direct_kernel(PwParams p) {
     static_assert(WGM * WGN == 4, "4 waves");
-    constexpr int KS = 8;  // k-steps per register set
+    constexpr int KS = AFF ? 4 : 8;  // k-steps per register set (shorter sets pay for the coefficient registers of AFF)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -354,29 +377,41 @@ __global__ __launch_bounds__(256) void pw_direct_kernel(PwParams p) {
     }
 
     float a0[TM][KS], a1[TM][KS], b0[TN][KS], b1[TN][KS];
+    float2 g0[AFF ? KS : 1], g1[AFF ? KS : 1];  // GroupNorm coefficients (a, b) of the set's k rows
+    const __amdgpu_buffer_rsrc_t gsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(AFF ? p.ab_in + (size_t)b * p.cin * 2 : p.wt), 0, AFF ? p.cin * 8 : 0, 0x00020000);
+    const int gvoff = (lane >> 5) * 8;
     const int nsets = (p.cin + 2 * KS - 1) / (2 * KS);
-#define PW_LOAD_SET(A, Bv, si)                                                                                           \
+#define PW_LOAD_SET(A, Bv, G, si)                                                                                        \
     _Pragma("unroll") for (int j = 0; j < KS; ++j) {                                                                    \
         _Pragma("unroll") for (int tm = 0; tm < TM; ++tm) A[tm][j] = __builtin_bit_cast(                                 \
             float, __builtin_amdgcn_raw_buffer_load_b32(wsrc, wvoff[tm], ((si) * KS + j) * wstep, 0));                   \
         _Pragma("unroll") for (int tn = 0; tn < TN; ++tn) Bv[tn][j] = __builtin_bit_cast(                                \
             float, __builtin_amdgcn_raw_buffer_load_b32(xsrc, xvoff[tn] + ((si) * KS + j) * xstep, 0, 0));               \
+        if (AFF) G[j] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(gsrc, gvoff + ((si) * KS + j) * 16, 0, 0)); \
     }                                                                                                                    \
     __builtin_amdgcn_sched_barrier(0);
-#define PW_MFMA_SET(A, Bv)                                                                                               \
+#define PW_MFMA_SET(A, Bv, G)                                                                                            \
+    if (AFF) {                                                                                                           \
+        _Pragma("unroll") for (int j = 0; j < KS; ++j)                                                                  \
+            _Pragma("unroll") for (int tn = 0; tn < TN; ++tn) {                                                         \
+                const float t = __builtin_fmaf(G[j].x, Bv[tn][j], G[j].y);                                               \
+                Bv[tn][j] = t > 0.f ? t : 0.f;                                                                           \
+            }                                                                                                            \
+    }                                                                                                                    \
     _Pragma("unroll") for (int j = 0; j < KS; ++j)                                                                      \
         _Pragma("unroll") for (int tm = 0; tm < TM; ++tm)                                                               \
             _Pragma("unroll") for (int tn = 0; tn < TN; ++tn)                                                           \
                 acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[tm][j], Bv[tn][j], acc[tm][tn], 0, 0, 0);           \
     __builtin_amdgcn_sched_barrier(0);
-    PW_LOAD_SET(a0, b0, 0)
+    PW_LOAD_SET(a0, b0, g0, 0)
     for (int c = 0; c + 1 < nsets; c += 2) {
-        PW_LOAD_SET(a1, b1, c + 1)
-        PW_MFMA_SET(a0, b0)
-        PW_LOAD_SET(a0, b0, (c + 2 < nsets ? c + 2 : nsets - 1))
-        PW_MFMA_SET(a1, b1)
+        PW_LOAD_SET(a1, b1, g1, c + 1)
+        PW_MFMA_SET(a0, b0, g0)
+        PW_LOAD_SET(a0, b0, g0, (c + 2 < nsets ? c + 2 : nsets - 1))
+        PW_MFMA_SET(a1, b1, g1)
     }
-    if (nsets & 1) { PW_MFMA_SET(a0, b0) }
+    if (nsets & 1) { PW_MFMA_SET(a0, b0, g0) }
 #undef PW_LOAD_SET
 #undef PW_MFMA_SET
 
@@ -395,6 +430,67 @@ __global__ __launch_bounds__(256) void pw_direct_kernel(PwParams p) {
                 }
             }
         }
+    }
+    if (ST) {
+        // (sum, sum of squares) of the RAW outputs (act is none on this path) of every row over this wave's TN*32 columns
+        const int tcol = (int)(pos0 / (TN * 32));
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            const int row0 = co0 + tm * 32 + 4 * (lane >> 5);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float sm = 0.f, sq = 0.f;
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    const float v = (pos0 + tn * 32 + (lane & 31) < p.L) ? acc[tm][tn][r] : 0.f;
+                    sm += v;
+                    sq += v * v;
+                }
+                sm = half_wave_sum(sm);
+                sq = half_wave_sum(sq);
+                const int row = row0 + (r & 3) + 8 * (r >> 2);
+                if ((lane & 31) == 16 && row < p.cout) {
+                    float *d = p.stats_out + (((size_t)b * p.cout + row) * p.stats_t + tcol) * 2;
+                    d[0] = sm;
+                    d[1] = sq;
+                }
+            }
+        }
+    }
+}
+
+// One wave per (cloud, group): fixed-order double-precision sum of the partials -> mean, rstd -> per-channel (a, b) with
+// GroupNorm(x) = a*x + b  (a = gamma*rstd, b = beta - mean*a).
+__global__ __launch_bounds__(256) void gn_finalize_kernel(int nb, int c, int cpg, int t, long long n, float eps,
+                                                          const float *__restrict__ stats, const float *__restrict__ gamma,
+                                                          const float *__restrict__ beta, float *__restrict__ ab) {
+    const int lane = threadIdx.x & 63;
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int groups = c / cpg;
+    if (e >= nb * groups) return;  // wave-uniform
+    const int bi = e / groups, g = e % groups;
+    // the group's partials are contiguous: cpg channels x t tiles x (sum, sumsq)
+    const float2 *s2 = reinterpret_cast<const float2 *>(stats + ((size_t)bi * c + (size_t)g * cpg) * t * 2);
+    double sm = 0.0, sq = 0.0;
+    for (int i = lane; i < cpg * t; i += 64) {
+        const float2 v = s2[i];
+        sm += (double)v.x;
+        sq += (double)v.y;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        sm += __shfl_xor(sm, off, 64);
+        sq += __shfl_xor(sq, off, 64);
+    }
+    const double cnt = (double)cpg * (double)n;
+    const double mean = sm / cnt;
+    double var = sq / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double rstd = 1.0 / sqrt(var + (double)eps);
+    for (int ch = g * cpg + lane; ch < (g + 1) * cpg; ch += 64) {
+        const double a = (double)gamma[ch] * rstd;
+        ab[((size_t)bi * c + ch) * 2 + 0] = (float)a;
+        ab[((size_t)bi * c + ch) * 2 + 1] = (float)((double)beta[ch] - mean * a);
     }
 }
 
@@ -460,6 +556,59 @@ extern "C" int captra_pointwise_mlp(int b, int cin, int cout, long long l, const
     const bool vec = (l % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
     if (vec) return launch_pw<PRO_PLAIN, EPI_STORE, true>(b, p, (hipStream_t)stream, "pointwise_mlp");
     return launch_pw<PRO_PLAIN, EPI_STORE, false>(b, p, (hipStream_t)stream, "pointwise_mlp");
+}
+
+// Dense layer inside a Conv -> GroupNorm -> ReLU chain (see include/captra_hip.h).
+extern "C" int captra_pointwise_mlp_gn(int b, int cin, int cout, long long l, const float *x, const float *wt_packed,
+                                       const float *bias_packed, const float *ab_in, int act, float *y, float *stats_out,
+                                       int stats_t, captra_stream_t stream) {
+    if (b < 0 || cin < 1 || cout < 1 || l < 0 || act < 0 || act > 2) return -1;
+    if (stats_out != nullptr && act != ACT_NONE) return -1;           // statistics are those of the raw output
+    if ((long long)cin * l * 4 >= (1ll << 31)) return -2;
+    if (b == 0 || l == 0) return 0;
+    PwParams p = {};
+    p.cin = cin; p.cout = cout; p.ldw = (cout + 127) / 128 * 128; p.L = l; p.x = x; p.wt = wt_packed; p.bias = bias_packed;
+    p.y = y; p.act = act; p.ab_in = ab_in; p.stats_out = stats_out; p.stats_t = stats_t;
+    hipStream_t s = (hipStream_t)stream;
+    if (cout > 64) {
+        if (stats_out != nullptr && stats_t != (int)((l + 127) / 128) * 2) return -1;
+        dim3 grid((unsigned)((l + 127) / 128), (cout + 127) / 128, b);
+        if (ab_in != nullptr && stats_out != nullptr) {
+            CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<2, 2, 2, 2, true, true>), grid, dim3(256), 0, s, p);
+        } else if (stats_out != nullptr) {
+            CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<2, 2, 2, 2, false, true>), grid, dim3(256), 0, s, p);
+        } else if (ab_in != nullptr) {
+            CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<2, 2, 2, 2, true, false>), grid, dim3(256), 0, s, p);
+        } else {
+            CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<2, 2, 2, 2>), grid, dim3(256), 0, s, p);
+        }
+        return captra_last_error();
+    }
+    if (stats_out != nullptr) return -2;   // statistics only from the 64x64 wave-tile configuration
+    dim3 grid((unsigned)((l + 255) / 256), 1, b);
+    if (cout > 32) {
+        if (ab_in != nullptr) {
+            CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<2, 2, 1, 4, true, false>), grid, dim3(256), 0, s, p);
+        } else {
+            CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<2, 2, 1, 4>), grid, dim3(256), 0, s, p);
+        }
+    } else if (ab_in != nullptr) {
+        CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<1, 2, 1, 4, true, false>), grid, dim3(256), 0, s, p);
+    } else {
+        CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<1, 2, 1, 4>), grid, dim3(256), 0, s, p);
+    }
+    return captra_last_error();
+}
+
+extern "C" int captra_gn_finalize(int b, int c, int channels_per_group, int stats_t, long long n, float eps,
+                                  const float *stats, const float *gamma, const float *beta, float *ab,
+                                  captra_stream_t stream) {
+    if (b < 0 || c < 1 || channels_per_group < 1 || c % channels_per_group != 0 || stats_t < 1 || n < 1) return -1;
+    if (b == 0) return 0;
+    const int total = b * (c / channels_per_group);
+    CAPTRA_LAUNCH("gn_finalize", gn_finalize_kernel, dim3((total + 3) / 4), dim3(256), 0, (hipStream_t)stream, b, c,
+                  channels_per_group, stats_t, n, eps, stats, gamma, beta, ab);
+    return captra_last_error();
 }
 
 extern "C" int captra_sa_group_mlp(int b, int n, int m, int k, int cfeat, int cout, const float *feat,

@@ -158,6 +158,44 @@ def rot_pool_compose(raw, labels_i32, prev_rot, sym: bool, want_delta: bool = Fa
     return (rot, delta) if want_delta else rot
 
 
+USE_GN_FUSED = True      # Conv -> GroupNorm -> ReLU chains: statistics in the conv's epilogue, normalisation in the next conv's load
+
+
+def gn_chain_supported(x, cout: int) -> bool:
+    """A conv whose output is group-normalised can emit the statistics itself when it runs in the 64x64 wave-tile
+    configuration of the direct kernel (csrc/pointwise_mlp.hip captra_pointwise_mlp_gn)."""
+    B, cin = x.shape[0], x.shape[1]
+    l = x.numel() // max(B * cin, 1)
+    return USE_GN_FUSED and cout > 64 and cin * l * 4 < (1 << 31)
+
+
+def pointwise_mlp_gn(x, lin: PackedLinear, ab_in=None, act: int = ACT_NONE, want_stats: bool = False):
+    """Dense layer of a Conv -> GroupNorm -> ReLU chain: x (B,cin,L) raw output of the previous layer with its GroupNorm
+    coefficients ab_in (B,cin,2) (or a plain input, ab_in None) -> y (B,cout,L) [, stats (B,cout,T,2)]."""
+    L.require_device(x, lin.wt, lin.bias, ab_in)
+    B, cin = x.shape[0], x.shape[1]
+    assert lin.cin == cin and x.is_contiguous()
+    l = x.numel() // max(B * cin, 1)
+    y = torch.empty((B, lin.cout) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+    t = 2 * ((l + 127) // 128)
+    stats = torch.empty(B, lin.cout, t, 2, dtype=torch.float32, device=x.device) if want_stats else None
+    with torch.cuda.device(x.device):
+        L.call("captra_pointwise_mlp_gn", B, cin, lin.cout, l, L.ptr(x), L.ptr(lin.wt), L.ptr(lin.bias), L.ptr(ab_in), act,
+               L.ptr(y), L.ptr(stats), t)
+    _work("pointwise_mlp", flops=2.0 * B * cin * lin.cout * l, nbytes=4.0 * B * l * (cin + lin.cout))
+    return (y, stats) if want_stats else y
+
+
+def gn_finalize(stats, num_groups: int, gamma, beta, eps: float, n: int):
+    """stats (B,C,T,2) partial (sum, sum of squares) -> ab (B,C,2) with GroupNorm(x) = a*x + b."""
+    L.require_device(stats, gamma, beta)
+    B, C, T, _ = stats.shape
+    ab = torch.empty(B, C, 2, dtype=torch.float32, device=stats.device)
+    with torch.cuda.device(stats.device):
+        L.call("captra_gn_finalize", B, C, C // num_groups, T, n, float(eps), L.ptr(stats), L.ptr(gamma), L.ptr(beta), L.ptr(ab))
+    return ab
+
+
 USE_MLP_CHAIN = True     # three dense layers in one launch where the shape is instantiated (else layer by layer)
 _CHAIN3_SHAPES = {(134, 128, 128, 128), (131, 128, 128, 128)}   # csrc/mlp_chain.hip CHAIN_CASE list
 

@@ -605,3 +605,32 @@ def test_rot_pool_compose_vs_reference_algebra(device, sym, P):
     r_ref = torch.matmul(torch.from_numpy(prev), d_ref)
     np.testing.assert_allclose(delta.cpu().numpy(), d_ref.numpy(), atol=2e-6, rtol=0)
     np.testing.assert_allclose(rot.cpu().numpy(), r_ref.numpy(), atol=2e-6, rtol=0)
+
+
+@pytest.mark.parametrize("n", [4096, 1000])
+def test_group_norm_chain_fused_vs_separate_and_torch(device, n):
+    """Rotation-head MLP (Conv -> GroupNorm(C/2 groups) -> ReLU x3 -> Conv): statistics emitted by the conv epilogue and
+    the normalisation applied in the next conv's operand load == the separate GroupNorm kernel == torch, to rounding."""
+    from captra_amd import fused
+    from captra_amd.blocks import MLPConv1d
+    torch.manual_seed(3)
+    head = MLPConv1d(128, [512, 512, 256, 3], bn=True, gn=True, last_activation="none").eval()
+    with torch.no_grad():
+        for m in head.modules():
+            if isinstance(m, torch.nn.GroupNorm):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.uniform_(-0.3, 0.3)
+    x = torch.randn(3, 128, n)
+    with torch.no_grad():
+        ref = head(x)                                   # CPU: plain torch modules
+        head_gpu = head.to(device)
+        got = head_gpu(x.to(device)).cpu()
+        fused.USE_GN_FUSED = False
+        try:
+            head_gpu._cache = {}
+            sep = head_gpu(x.to(device)).cpu()
+        finally:
+            fused.USE_GN_FUSED = True
+    scale = float(ref.abs().max())
+    np.testing.assert_allclose(got.numpy(), sep.numpy(), atol=2e-5 * scale, rtol=0)
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), atol=1e-4 * scale, rtol=0)
