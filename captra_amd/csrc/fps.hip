@@ -185,7 +185,8 @@ __global__ __launch_bounds__(NWAVES * 64) void fps_kernel_blocked(int n, int m, 
     constexpr int H = PPT / 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint2 *slots = reinterpret_cast<uint2 *>(smem_raw);                  // [2][16] ping-pong
-    float *xs = reinterpret_cast<float *>(smem_raw + 2 * 16 * sizeof(uint2));
+    float4 *slotc = reinterpret_cast<float4 *>(smem_raw + 2 * 16 * sizeof(uint2));  // !XYZ_LDS: the candidates' coordinates
+    float *xs = reinterpret_cast<float *>(smem_raw + 2 * 16 * sizeof(uint2) + (XYZ_LDS ? 0 : 2 * 16 * sizeof(float4)));
     float *ys = xs + n;
     float *zs = ys + n;
     const int b = blockIdx.x;
@@ -226,11 +227,14 @@ __global__ __launch_bounds__(NWAVES * 64) void fps_kernel_blocked(int n, int m, 
     __syncthreads();
 
     int old = 0;
+    // clouds beyond the LDS budget: the winner's coordinates travel with its (distance, index) through the wave slots
+    // (picked out of the owner lane's registers with a uniform slot switch + v_readlane), so a round reads no memory at all
+    float nx = xyz[0], ny = xyz[1], nz = xyz[2];
     for (int j = 1; j < m; ++j) {
-        // the last pick's coordinates: broadcast read of the LDS mirror, or (clouds beyond the LDS budget) of global memory
-        const float ox = XYZ_LDS ? xs[old] : xyz[(size_t)old * 3 + 0];
-        const float oy = XYZ_LDS ? ys[old] : xyz[(size_t)old * 3 + 1];
-        const float oz = XYZ_LDS ? zs[old] : xyz[(size_t)old * 3 + 2];
+        // the last pick's coordinates: broadcast read of the LDS mirror, or the values carried over from the last round
+        const float ox = XYZ_LDS ? xs[old] : nx;
+        const float oy = XYZ_LDS ? ys[old] : ny;
+        const float oz = XYZ_LDS ? zs[old] : nz;
         if (tid == 0) emit(j - 1, ox, oy, oz);
         const f32x2 o2x = {ox, ox}, o2y = {oy, oy}, o2z = {oz, oz};
         unsigned best = 0u;
@@ -250,18 +254,41 @@ __global__ __launch_bounds__(NWAVES * 64) void fps_kernel_blocked(int n, int m, 
         const unsigned long long hit = __ballot(best == wmax);
         const int wl = __ffsll((long long)hit) - 1;            // lowest lane = lowest indices of the wave
         const unsigned widx = (unsigned)__builtin_amdgcn_readlane(base + li, wl);
+        float wx = 0.f, wy = 0.f, wz = 0.f;
+        if (!XYZ_LDS) {
+            const int ls = __builtin_amdgcn_readlane(li, wl);  // the winner lane's slot: wave-uniform
+#pragma unroll
+            for (int i = 0; i < PPT; ++i)
+                if (ls == i) {                                  // uniform branch: exactly one case runs
+                    wx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__float_as_int(px[i / 2][i & 1]), wl));
+                    wy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__float_as_int(py[i / 2][i & 1]), wl));
+                    wz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__float_as_int(pz[i / 2][i & 1]), wl));
+                }
+        }
         unsigned sel;
         if (NWAVES == 1) {
             sel = widx;
+            nx = wx; ny = wy; nz = wz;
         } else {
             uint2 *slot = slots + (j & 1) * 16;
-            if (lane == 0) slot[wave] = make_uint2(wmax, widx);
+            float4 *sc = slotc + (j & 1) * 16;
+            if (lane == 0) {
+                slot[wave] = make_uint2(wmax, widx);
+                if (!XYZ_LDS) sc[wave] = make_float4(wx, wy, wz, 0.f);
+            }
             __syncthreads();
             const uint2 kv = slot[lane & (NWAVES - 1)];
+            float4 kc = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!XYZ_LDS) kc = sc[lane & (NWAVES - 1)];
             const unsigned gmax = row_max_u32_fold(kv.x);
             const unsigned long long hit2 = __ballot(kv.x == gmax);
             const int gl = __ffsll((long long)hit2) - 1;       // lowest lane = lowest wave = lowest indices
             sel = (unsigned)__builtin_amdgcn_readlane((int)kv.y, gl);
+            if (!XYZ_LDS) {
+                nx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__float_as_int(kc.x), gl));
+                ny = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__float_as_int(kc.y), gl));
+                nz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__float_as_int(kc.z), gl));
+            }
         }
         old = (int)sel;
         if (tid == 0) idx[j] = old;
@@ -334,8 +361,8 @@ int launch_fps(int b, int n, int m, const float *xyz, float *temp, int *idx, hip
             return captra_last_error();
         }
         if (g_fps_variant == 0) {  // cloud larger than the LDS mirror: same kernel, winner coordinates from global memory
-            CAPTRA_LAUNCH("fps", (fps_kernel_blocked<NWAVES, PPT, false>), dim3(b), dim3(NWAVES * 64), slots, s, n, m, xyz, temp, idx,
-                          new_n3, new_cn);
+            CAPTRA_LAUNCH("fps", (fps_kernel_blocked<NWAVES, PPT, false>), dim3(b), dim3(NWAVES * 64),
+                          slots + 2 * 16 * sizeof(float4), s, n, m, xyz, temp, idx, new_n3, new_cn);
             return captra_last_error();
         }
     }
@@ -384,7 +411,8 @@ extern "C" int captra_furthest_point_sampling(int b, int n, int m, const float *
     FPS_CASE(2, 1) FPS_CASE(2, 2) FPS_CASE(2, 4) FPS_CASE(2, 8) FPS_CASE(2, 16)
     FPS_CASE(4, 1) FPS_CASE(4, 2) FPS_CASE(4, 4) FPS_CASE(4, 8) FPS_CASE(4, 16)
     FPS_CASE(8, 1) FPS_CASE(8, 2) FPS_CASE(8, 4) FPS_CASE(8, 8) FPS_CASE(8, 16)
-    FPS_CASE(16, 1) FPS_CASE(16, 2) FPS_CASE(16, 4) FPS_CASE(16, 8) FPS_CASE(16, 16) FPS_CASE(16, 32)
+    FPS_CASE(16, 1) FPS_CASE(16, 2) FPS_CASE(16, 4) FPS_CASE(16, 8) FPS_CASE(16, 12) FPS_CASE(16, 16) FPS_CASE(16, 20)
+    FPS_CASE(16, 24) FPS_CASE(16, 32)
 #undef FPS_CASE
     CAPTRA_LAUNCH("fps", fps_kernel_big, dim3(b), dim3(1024), 0, s, n, m, xyz, temp, idx);
     return captra_last_error();
@@ -404,7 +432,8 @@ extern "C" int captra_fps_gather(int b, int n, int m, const float *xyz, int *idx
 #define FPSG_CASE(W, P) \
     if (waves == W && ppt <= P) return launch_fps<W, P>(b, n, m, xyz, nullptr, idx, s, new_xyz_n3, new_xyz_cn, true);
     FPSG_CASE(1, 2) FPSG_CASE(1, 4) FPSG_CASE(1, 8)
-    FPSG_CASE(2, 8) FPSG_CASE(4, 8) FPSG_CASE(8, 8) FPSG_CASE(16, 8) FPSG_CASE(16, 16) FPSG_CASE(16, 32)
+    FPSG_CASE(2, 8) FPSG_CASE(4, 8) FPSG_CASE(8, 8) FPSG_CASE(16, 8) FPSG_CASE(16, 12) FPSG_CASE(16, 16) FPSG_CASE(16, 20)
+    FPSG_CASE(16, 24) FPSG_CASE(16, 32)
 #undef FPSG_CASE
     return -2;
 }
