@@ -17,8 +17,8 @@
 
 namespace {
 
-constexpr int BQ_WAVES = 4;         // waves per workgroup
-constexpr int BQ_CPW = 8;           // centres per wave
+constexpr int BQ_WAVES = 8;         // waves per workgroup
+constexpr int BQ_CPW = 2;           // centres per wave
 constexpr int BQ_TILE = 8192;       // points staged per LDS tile (96 KiB)
 constexpr int BQ_MAXR = 4;
 
