@@ -47,7 +47,10 @@ __global__ __launch_bounds__(GP_THREADS) void group_points_kernel(int c, int n, 
             for (int ch = 0; ch < ccv; ++ch) {
                 const float *row = rows + (size_t)ch * n;
                 float4 v = make_float4(row[id.x], row[id.y], row[id.z], row[id.w]);
-                *reinterpret_cast<float4 *>(out_b + (size_t)ch * npos + p) = v;
+                // written once, never re-read by this kernel: streaming (non-temporal) store keeps L2 for idx / rows
+                typedef float f32x4 __attribute__((ext_vector_type(4)));
+                const f32x4 vv = {v.x, v.y, v.z, v.w};
+                __builtin_nontemporal_store(vv, reinterpret_cast<f32x4 *>(out_b + (size_t)ch * npos + p));
             }
         }
     } else {
