@@ -36,6 +36,7 @@ if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
+PEAK_BF16_MFMA_TFLOPS = 2500.0 # MI355X_MICROARCH.md: dense bf16 MFMA peak (only for --mlp-dtype bf16 runs)
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak (= fp32 vector peak)
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec
 
@@ -212,6 +213,9 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     ap.add_argument("--no-graph", action="store_true", help="launch the step eagerly instead of replaying a hipGraph")
+    ap.add_argument("--mlp-dtype", default="fp32", choices=["fp32", "bf16"],
+                    help="fp32 = the metric's configuration (exact); bf16 = bf16 MFMA operands / fp32 accumulation for the shared "
+                         "MLPs (BASELINE.json configs[2]'s arithmetic) -- reported with dtype \"bf16\", not the headline")
     ap.add_argument("--category", default="bottle", choices=sorted(WORKLOADS),
                     help="bottle = BASELINE.json configs[1] (the metric's configuration); camera / drawers: the other object classes")
     args = ap.parse_args()
@@ -232,6 +236,7 @@ def main():
     from captra_amd import _lib, fused
     from captra_amd.parallel import PoseExchange
 
+    fused.MLP_DTYPE = args.mlp_dtype
     cfg, sd, model, data = build_workload(args.batch, device, category=args.category)
     B, P = args.batch, cfg["num_parts"]
     exchange = PoseExchange(B, P, device, world, rank)
@@ -307,9 +312,11 @@ def main():
     out = {
         "metric": "tracked frames/sec (4096-pt clouds)", "value": round(frames / elapsed, 2), "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{WORKLOADS[args.category][3]}, 4096 pts/frame, batch={B} trajectories per GPU, fp32"
-                               + (" (BASELINE.json configs[1])" if args.category == "bottle" else " (BASELINE.json configs[3]: drawers)" if args.category == "drawers" else ""),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.mlp_dtype == "fp32" else "bf16",
+        "data": "synthetic",
+        "config": {"workload": f"{WORKLOADS[args.category][3]}, 4096 pts/frame, batch={B} trajectories per GPU, "
+                               + ("fp32" if args.mlp_dtype == "fp32" else "bf16 MFMA operands / fp32 accumulation in the shared MLPs (BASELINE.json configs[2]'s arithmetic; NOT the metric's configuration)")
+                               + (" (BASELINE.json configs[1])" if args.category == "bottle" and args.mlp_dtype == "fp32" else " (BASELINE.json configs[3]: drawers)" if args.category == "drawers" else ""),
                    "points": 4096, "trajectories_per_gpu": B, "parallelism": f"dp{world} (trajectory-sharded, RCCL all-gather of poses)",
                    "weights": f"random-init default_rng(7), real architecture ({sum(v.numel() for v in sd.values()) / 1e6:.2f} M params incl. BN statistics)",
                    "launch": "hipGraph replay of the step" if graph is not None else "eager launches"},
@@ -330,13 +337,15 @@ def main():
         dominant = max(fams, key=lambda k: fams[k]["ms_total"]) if fams else None
         if mlp_ms > 0:
             ach = mlp_flops / (mlp_ms * 1e-3) / 1e12
-            out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-                               "kernel": "fp32 MFMA 32x32x2 shared-MLP kernels: sa_wave_kernel / sa_wave_lds_kernel (dominant) + mlp_chain3_kernel + pw_direct_kernel + pw_mlp_kernel",
+            peak = PEAK_F32_MFMA_TFLOPS if args.mlp_dtype == "fp32" else PEAK_BF16_MFMA_TFLOPS
+            out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                               "frac": round(ach / peak, 4), "traffic": None,
+                               "kernel": ("fp32 MFMA 32x32x2 shared-MLP kernels: sa_wave_kernel / sa_wave_lds_kernel (dominant) + mlp_chain3_kernel + pw_direct_kernel + pw_mlp_kernel"
+                                          if args.mlp_dtype == "fp32" else "bf16 MFMA 32x32x16 shared-MLP kernels: sa_wave_bf16_kernel + pw_bf16_kernel"),
                                "avg_launch_us": round(1e3 * mlp_ms / max(mlp_launches, 1), 2),
                                "flops_per_launch": round(mlp_flops / max(mlp_launches, 1)),
                                "share_of_kernel_time": round(mlp_ms / max(total_ms, 1e-9), 3), "dominant_family": dominant}
-            traffic, src = pmc_traffic(["sa_wave_kernel", "sa_wave_lds_kernel", "sa_fused_kernel", "mlp_chain3_kernel", "pw_direct_kernel", "pw_mlp_kernel"])
+            traffic, src = (None, None) if args.mlp_dtype != "fp32" else pmc_traffic(["sa_wave_kernel", "sa_wave_lds_kernel", "sa_fused_kernel", "mlp_chain3_kernel", "pw_direct_kernel", "pw_mlp_kernel"])
             if traffic is not None:
                 out["roofline"]["traffic"] = round(traffic)
                 out["roofline"]["traffic_source"] = f"profiles/{src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch)"

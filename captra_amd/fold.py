@@ -15,7 +15,7 @@ class PackedLinear:
     """A layer's weights in the layout the MFMA kernels stage (include/captra_hip.h "packed weights"):
     W'^T zero-padded to (ceil32(cin), ceil128(cout)), bias zero-padded to ceil128(cout)."""
 
-    __slots__ = ("wt", "bias", "cin", "cout")
+    __slots__ = ("wt", "bias", "cin", "cout", "_bf16")
 
     def __init__(self, wt_dense: torch.Tensor, bias_dense: torch.Tensor):
         cin, cout = wt_dense.shape
@@ -25,6 +25,25 @@ class PackedLinear:
         bias = torch.zeros(cp, dtype=torch.float32, device=wt_dense.device)
         bias[:cout] = bias_dense
         self.wt, self.bias, self.cin, self.cout = wt.contiguous(), bias.contiguous(), cin, cout
+        self._bf16 = {}
+
+    def bf16(self, row0: int = 0, rows: int | None = None) -> torch.Tensor:
+        """bf16 image of input rows [row0, row0+rows) of this layer for the bf16 kernels (include/captra_hip.h:
+        Wb [ceil32(cout)][ceil32(rows)], untransposed, zero padded), built once per (row0, rows) on the device."""
+        from . import _lib as L
+        rows = self.cin - row0 if rows is None else rows
+        key = (row0, rows)
+        cache = getattr(self, "_bf16", None)
+        if cache is None:
+            cache = self._bf16 = {}
+        if key not in cache:
+            dense = self.wt[row0:row0 + rows, :self.cout].contiguous()
+            kb, cp = (rows + 31) // 32 * 32, (self.cout + 31) // 32 * 32
+            wb = torch.empty(cp, kb, dtype=torch.bfloat16, device=self.wt.device)
+            with torch.cuda.device(self.wt.device):
+                L.call("captra_pack_weights_bf16", rows, self.cout, L.ptr(dense), L.ptr(wb))
+            cache[key] = wb
+        return cache[key]
 
 
 def fold_conv_bn(conv, bn=None, device=None) -> PackedLinear:

@@ -72,8 +72,11 @@ def pack(wt_dense, bias_dense) -> PackedLinear:
     return PackedLinear(wt_dense.float(), bias_dense.float())
 
 
+MLP_DTYPE = "fp32"       # "bf16": bf16 operands / fp32 accumulation for the shared MLPs (BASELINE.json configs[2]); opt-in
+
+
 def pointwise_mlp(x, lin: PackedLinear, act: int = ACT_RELU, out=None):
-    """x (B,cin,*), packed layer -> (B,cout,*) = act(W x + b) (exact-fp32 MFMA)."""
+    """x (B,cin,*), packed layer -> (B,cout,*) = act(W x + b) (exact-fp32 MFMA; bf16 operands when MLP_DTYPE is "bf16")."""
     wt, bias = lin.wt, lin.bias
     L.require_device(x, wt, bias)
     B, cin = x.shape[0], x.shape[1]
@@ -82,6 +85,11 @@ def pointwise_mlp(x, lin: PackedLinear, act: int = ACT_RELU, out=None):
     l = x.numel() // max(B * cin, 1)
     if out is None:
         out = torch.empty((B, cout) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+    if MLP_DTYPE == "bf16":
+        with torch.cuda.device(x.device):
+            L.call("captra_pointwise_mlp_bf16", B, cin, cout, l, L.ptr(x), L.ptr(lin.bf16(0, cin)), L.ptr(bias), act, L.ptr(out))
+        _work("pointwise_mlp", flops=2.0 * B * cin * cout * l, nbytes=4.0 * B * l * (cin + cout))
+        return out
     with torch.cuda.device(x.device):
         L.call("captra_pointwise_mlp", B, cin, cout, l, L.ptr(x), L.ptr(wt), L.ptr(bias), act, L.ptr(out))
     _work("pointwise_mlp", flops=2.0 * B * cin * cout * l, nbytes=4.0 * B * l * (cin + cout))
@@ -112,11 +120,43 @@ def sa_scale_pre_supported(cfeat, layers, k) -> bool:
             and (cfeat, layers[0].cout, layers[1].cout, layers[2].cout) in _SA_PRE_SHAPES)
 
 
+_SA_BF16_SHAPES = {(0, 32, 32, 64), (0, 64, 64, 128), (0, 64, 96, 128), (3, 32, 32, 64), (3, 64, 64, 128), (3, 64, 96, 128),
+                   (320, 128, 128, 256), (320, 128, 196, 256)}      # csrc/bf16_mlp.hip BS_CASE list
+
+
+def sa_scale_bf16_supported(cfeat, layers, k) -> bool:
+    return (MLP_DTYPE == "bf16" and len(layers) == 3 and k % 32 == 0 and 128 % k == 0
+            and (cfeat, layers[0].cout, layers[1].cout, layers[2].cout) in _SA_BF16_SHAPES)
+
+
+def sa_scale_bf16(feat, xyz_cn, new_xyz_n3, idx, layers, out, co_off):
+    """One SA scale with bf16 MFMA operands (captra_sa_scale_bf16); wide inputs go through the pre-transformed first layer."""
+    l1, l2, l3 = layers
+    B, _, N = xyz_cn.shape
+    _, M, K = idx.shape
+    cfeat = 0 if feat is None else feat.shape[1]
+    pre = cfeat + 3 > 8
+    if pre:
+        src = sa_first_layer_pre(feat, l1)                      # (B,c1,N) fp32 through the bf16 dense kernel
+        w1 = l1.bf16(cfeat, 3)                                   # the three xyz rows
+    else:
+        src = feat
+        w1 = l1.bf16(0, cfeat + 3)
+    L.require_device(src, xyz_cn, new_xyz_n3, idx, out)
+    with torch.cuda.device(xyz_cn.device):
+        L.call("captra_sa_scale_bf16", B, N, M, K, cfeat, l1.cout, l2.cout, l3.cout, 1 if pre else 0, L.ptr(src), L.ptr(xyz_cn),
+               L.ptr(new_xyz_n3), L.ptr(idx), L.ptr(w1), L.ptr(l1.bias), L.ptr(l2.bf16()), L.ptr(l2.bias), L.ptr(l3.bf16()),
+               L.ptr(l3.bias), L.ptr(out), out.shape[1], co_off)
+    _work("sa_scale_fused", flops=2.0 * B * M * K * ((3 if pre else cfeat + 3) * l1.cout + l1.cout * l2.cout + l2.cout * l3.cout),
+          nbytes=4.0 * B * ((l1.cout if pre else cfeat) * N + 3 * N + M * K + 3 * M + l3.cout * M))
+    return out
+
+
 def sa_first_layer_pre(feat, lin: PackedLinear):
     """v1 (B,c1,N) = b1 + W1[feature rows] feat: the part of an SA scale's first layer that depends on the source
     point only (the chain's first cfeat steps; the packed buffer's leading rows ARE the feature rows)."""
     view = PackedLinear.__new__(PackedLinear)
-    view.wt, view.bias, view.cin, view.cout = lin.wt, lin.bias, feat.shape[1], lin.cout
+    view.wt, view.bias, view.cin, view.cout, view._bf16 = lin.wt, lin.bias, feat.shape[1], lin.cout, lin._bf16
     assert lin.cin == feat.shape[1] + 3
     return pointwise_mlp(feat, view, ACT_NONE)
 
@@ -163,10 +203,10 @@ USE_GN_FUSED = True      # Conv -> GroupNorm -> ReLU chains: statistics in the c
 
 def gn_chain_supported(x, cout: int) -> bool:
     """A conv whose output is group-normalised can emit the statistics itself when it runs in the 64x64 wave-tile
-    configuration of the direct kernel (csrc/pointwise_mlp.hip captra_pointwise_mlp_gn)."""
+    configuration of the direct kernel (csrc/pointwise_mlp.hip captra_pointwise_mlp_gn; fp32 path only)."""
     B, cin = x.shape[0], x.shape[1]
     l = x.numel() // max(B * cin, 1)
-    return USE_GN_FUSED and cout > 64 and cin * l * 4 < (1 << 31)
+    return USE_GN_FUSED and MLP_DTYPE == "fp32" and cout > 64 and cin * l * 4 < (1 << 31)
 
 
 def pointwise_mlp_gn(x, lin: PackedLinear, ab_in=None, act: int = ACT_NONE, want_stats: bool = False):
@@ -208,7 +248,7 @@ def mlp_chain3(x, layers, act3: int = ACT_RELU):
     assert x.shape[1] == shape[0] and layers[1].cin == shape[1] and layers[2].cin == shape[2], (x.shape, shape)
     B = x.shape[0]
     l = x.numel() // max(B * shape[0], 1)
-    if not (USE_MLP_CHAIN and shape in _CHAIN3_SHAPES and shape[0] * l * 4 < (1 << 31)):
+    if not (USE_MLP_CHAIN and MLP_DTYPE == "fp32" and shape in _CHAIN3_SHAPES and shape[0] * l * 4 < (1 << 31)):
         y = pointwise_mlp(x, layers[0], ACT_RELU)
         y = pointwise_mlp(y, layers[1], ACT_RELU)
         return pointwise_mlp(y, layers[2], act3)
@@ -248,6 +288,9 @@ def mlp_max(x, lin: PackedLinear, out, co_off: int):
     B, cin, M, K = x.shape
     cout = lin.cout
     assert lin.cin == cin
+    if MLP_DTYPE == "bf16":     # bf16 dense layer, then the (exact) max: only SA3's 128-point layer takes this route
+        out[:, co_off:co_off + cout, :] = pointwise_mlp(x, lin, ACT_RELU).max(dim=3)[0]
+        return out
     with torch.cuda.device(x.device):
         L.call("captra_mlp_max", B, cin, cout, M, K, L.ptr(x), L.ptr(wt), L.ptr(bias), L.ptr(out), out.shape[1], co_off)
     _work("mlp_max", flops=2.0 * B * cin * cout * M * K, nbytes=4.0 * B * (cin * M * K + cout * M))

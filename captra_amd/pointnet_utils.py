@@ -184,6 +184,10 @@ class PointNetSetAbstractionMsg(_FoldCache, nn.Module):
         feat = points.contiguous() if points is not None else None
         off = 0
         for layers, idx in zip(folded, idx_list):
+            if fused.sa_scale_bf16_supported(0 if feat is None else feat.shape[1], layers, idx.shape[2]):
+                fused.sa_scale_bf16(feat, xyz_cn, new_xyz_n3, idx, layers, out, off)
+                off += layers[-1].cout
+                continue
             if feat is not None and fused.sa_scale_pre_supported(feat.shape[1], layers, idx.shape[2]):
                 v1 = fused.sa_first_layer_pre(feat, layers[0])      # (B,c1,N): once per source point, not per neighbour
                 fused.sa_scale_pre(v1, xyz_cn, new_xyz_n3, idx, layers, out, off, feat.shape[1])

@@ -79,6 +79,8 @@ def parse_args(argv=None):
     parser.add_argument("--random_init", action="store_true", default=False,
                         help="no checkpoints: keep the freshly constructed (random) weights -- throughput runs only")
     parser.add_argument("--seed", type=int, default=0)
+    parser.add_argument("--mlp_dtype", default="fp32", choices=["fp32", "bf16"],
+                        help="bf16: bf16 MFMA operands / fp32 accumulation in the shared MLPs (opt-in; default exact fp32)")
     parser.add_argument("--hipgraph", action="store_true", default=False,
                         help="replay one captured hipGraph per frame (same kernels, no per-launch host overhead)")
     return parser.parse_args(argv)
@@ -118,11 +120,13 @@ def main(argv=None) -> dict:
     if args.nocs_otf:
         raise SystemExit("--nocs_otf True (on-the-fly depth crop, reference model.py:425-452) is not part of this build: "
                          "feed pre-cropped trajectories (captra_amd/trajectory_io.py)")
-    data_args = {k: getattr(args, k) for k in ("data", "num_traj", "num_frames", "random_init", "seed", "hipgraph")}
+    data_args = {k: getattr(args, k) for k in ("data", "num_traj", "num_frames", "random_init", "seed", "hipgraph", "mlp_dtype")}
     for k in data_args:
         delattr(args, k)
     cfg = get_config(args, save=False)
     cfg["hipgraph"] = data_args["hipgraph"]
+    from . import fused
+    fused.MLP_DTYPE = data_args["mlp_dtype"]
     args = argparse.Namespace(**vars(args), **data_args)
 
     log_dir = pjoin(cfg["experiment_dir"], "log")

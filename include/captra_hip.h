@@ -167,6 +167,23 @@ int captra_pointwise_mlp_gn(int b, int cin, int cout, long long l, const float *
 int captra_gn_finalize(int b, int c, int channels_per_group, int stats_t, long long n, float eps, const float *stats,
                        const float *gamma, const float *beta, float *ab, captra_stream_t stream);
 
+/* bf16-operand / fp32-accumulate variants of the shared-MLP kernels (BASELINE.json configs[2]; opt-in, the default path is
+ * exact fp32): y = act(b + sum_k bf16(w[k]) * bf16(x[k])), weights rounded (RNE) once by captra_pack_weights_bf16 into
+ * wb [ceil32(cout)][ceil32(cin)] bf16 (UNtransposed, k contiguous, zero padded) from dense wt (cin,cout) fp32; every layer's
+ * input is rounded when it becomes an MFMA operand; bias (the fp32 packed bias of captra_pack_weights) and accumulation
+ * in fp32; tensors in memory stay fp32.
+ *   captra_pointwise_mlp_bf16: as captra_pointwise_mlp.
+ *   captra_sa_scale_bf16: one SA scale, register-resident.  pre = 0: feat_or_v1 = feat (B,cfeat,N) (cfeat + 3 <= 8), w1 packs
+ *     all cfeat+3 input rows; pre = 1: feat_or_v1 = v1 (B,c1,N) fp32 = b1 + W1[feature rows] feat (captra_pointwise_mlp_bf16),
+ *     w1 packs the three xyz rows only (cin = 3), b1 unused.  Instantiated for the CAPTRA backbone shapes; -2 otherwise. */
+int captra_pack_weights_bf16(int cin, int cout, const float *wt, unsigned short *wb, captra_stream_t stream);
+int captra_pointwise_mlp_bf16(int b, int cin, int cout, long long l, const float *x, const unsigned short *wb,
+                              const float *bias_packed, int act, float *y, captra_stream_t stream);
+int captra_sa_scale_bf16(int b, int n, int m, int k, int cfeat, int c1, int c2, int c3, int pre, const float *feat_or_v1,
+                         const float *xyz_cn, const float *new_xyz, const int *idx, const unsigned short *w1, const float *b1,
+                         const unsigned short *w2, const float *b2, const unsigned short *w3, const float *b3, float *out,
+                         int out_ctotal, int co_off, captra_stream_t stream);
+
 /* Furthest point sampling + index_points in one launch (pointnet_utils.py:222-223: new_xyz = index_points(xyz,
  * farthest_point_sample(xyz, S))): xyz (B,N,3) -> idx (B,M) i32, new_xyz_n3 (B,M,3), new_xyz_cn (B,3,M) (either output
  * pointer may be NULL).  Same selection rule as captra_furthest_point_sampling with temp = 1e10.  Returns -2 when the

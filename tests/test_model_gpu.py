@@ -634,3 +634,99 @@ def test_group_norm_chain_fused_vs_separate_and_torch(device, n):
     scale = float(ref.abs().max())
     np.testing.assert_allclose(got.numpy(), sep.numpy(), atol=2e-5 * scale, rtol=0)
     np.testing.assert_allclose(got.numpy(), ref.numpy(), atol=1e-4 * scale, rtol=0)
+
+
+# ------------------------------------------------------------------------------- bf16 operand mode (configs[2])
+def _bf16_round(a):
+    """Round-to-nearest-even fp32 -> bf16 -> fp32 (numpy)."""
+    u = np.ascontiguousarray(a, np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(np.float32).reshape(np.shape(a))
+
+
+def _bf16_layer(x, w, b, act):
+    """act(b + sum_k bf16(w[k]) bf16(x[k])) with wide accumulation: the contract of the bf16 kernels up to fp32 summation order."""
+    y = np.einsum("kc,bk...->bc...", _bf16_round(w).astype(np.float64), _bf16_round(x).astype(np.float64)) + b.reshape((1, -1) + (1,) * (x.ndim - 2))
+    y = y.astype(np.float32)
+    return np.maximum(y, 0) if act == 1 else y
+
+
+@pytest.mark.parametrize("cin,cout,l", [(128, 512, 4096), (515, 256, 128), (134, 128, 1000), (256, 3, 4096), (320, 128, 512), (7, 40, 77)])
+def test_bf16_dense_layer(device, cin, cout, l):
+    from captra_amd import fused
+    rng = np.random.default_rng(cin + cout + l)
+    x = rng.standard_normal((2, cin, l)).astype(np.float32)
+    w = (rng.standard_normal((cin, cout)) / np.sqrt(cin)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    fused.MLP_DTYPE = "bf16"
+    try:
+        got = fused.pointwise_mlp(_dev(x, device), fused.pack(_dev(w, device), _dev(b, device)), 1).cpu().numpy()
+    finally:
+        fused.MLP_DTYPE = "fp32"
+    ref = _bf16_layer(x, w, b, 1)
+    np.testing.assert_allclose(got, ref, atol=2e-5 * max(1.0, float(np.abs(ref).max())), rtol=0)
+
+
+@pytest.mark.parametrize("cfeat,chans,n,m,k", [(3, (64, 96, 128), 4096, 512, 128), (0, (32, 32, 64), 700, 41, 32),
+                                                (320, (128, 196, 256), 512, 128, 128), (320, (128, 128, 256), 200, 5, 64)])
+def test_bf16_sa_scale(device, cfeat, chans, n, m, k):
+    """bf16-operand SA scale against the same layer contract evaluated layer by layer in numpy; an occasional element whose
+    fp32 pre-activation sits on a bf16 rounding boundary may round the other way (accumulation order), hence the two bounds."""
+    from captra_amd import fused
+    rng = np.random.default_rng(cfeat + sum(chans) + k)
+    B = 2
+    xyz_cn = (rng.random((B, 3, n), dtype=np.float32) - 0.5)
+    feat = rng.standard_normal((B, cfeat, n)).astype(np.float32) if cfeat else None
+    new_xyz = (rng.random((B, m, 3), dtype=np.float32) - 0.5)
+    idx = rng.integers(0, n, (B, m, k)).astype(np.int32)
+    dims = (cfeat + 3,) + chans
+    layers = [((rng.standard_normal((dims[i], dims[i + 1])) / np.sqrt(dims[i])).astype(np.float32),
+               rng.standard_normal(dims[i + 1]).astype(np.float32)) for i in range(3)]
+    packed = [fused.pack(_dev(w, device), _dev(b, device)) for w, b in layers]
+    out = torch.zeros(B, chans[2], m, device=device)
+    fused.MLP_DTYPE = "bf16"
+    try:
+        assert fused.sa_scale_bf16_supported(cfeat, packed, k)
+        fused.sa_scale_bf16(None if feat is None else _dev(feat, device), _dev(xyz_cn, device), _dev(new_xyz, device),
+                            _dev(idx, device), packed, out, 0)
+    finally:
+        fused.MLP_DTYPE = "fp32"
+    x = O.sa_group(feat, xyz_cn, new_xyz, idx)
+    for w, b in layers:
+        x = _bf16_layer(x, w, b, 1)
+    ref = x.max(axis=-1)
+    got = out.cpu().numpy()
+    scale = float(np.abs(ref).max())
+    err = np.abs(got - ref)
+    assert err.max() <= 3e-2 * scale, err.max() / scale          # a flipped bf16 rounding upstream: <= 2^-8 relative per flip
+    assert np.mean(err) <= 2e-4 * scale, np.mean(err) / scale    # typical elements agree to accumulation-order noise
+
+
+def test_bf16_mode_track_step_close_to_fp32(device):
+    """The whole tracking step with bf16 MFMA operands in the shared MLPs (fused.MLP_DTYPE, BASELINE.json configs[2]) stays
+    close to the exact-fp32 step on the same inputs: NOCS coordinates within bf16-level error, (almost) no label flips."""
+    from captra_amd import fused
+    from captra_amd.configs import make_config
+    from captra_amd.trainer import Trainer
+    cfg = make_config("1", experiment_dir="/tmp/captra_bf16_test")
+    cfg["device"] = device
+    trainer = Trainer(cfg)
+    sd = make_state_dict({k: tuple(v.shape) for k, v in trainer.model.state_dict().items()}, seed=7)
+    trainer.model.load_state_dict(sd)
+    data = clouds.make_trajectory("nocs", 4, 3, seed=0)
+    model = trainer.model.to(device).eval()
+    model.set_data(data)
+    pose = {k: v.clone() for k, v in model.feed_dict[0]["gt_part"].items()}
+    outs = {}
+    for dt in ("fp32", "bf16"):
+        fused.MLP_DTYPE = dt
+        try:
+            with torch.no_grad():
+                npcs, _ = model.track_step(dict(model.feed_dict[1]), dict(model.npcs_feed_dict[1]), {k: v.clone() for k, v in pose.items()})
+        finally:
+            fused.MLP_DTYPE = "fp32"
+        outs[dt] = (npcs["nocs"].cpu().numpy(), npcs["seg"].cpu().numpy())
+    d = np.abs(outs["fp32"][0] - outs["bf16"][0])
+    assert np.isfinite(outs["bf16"][0]).all() and d.mean() < 5e-3 and d.max() < 5e-2, (d.mean(), d.max())
+    flips = (outs["fp32"][1].argmax(1) != outs["bf16"][1].argmax(1)).mean()
+    assert flips < 0.01, flips
