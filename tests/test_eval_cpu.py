@@ -1,0 +1,53 @@
+"""CPU: the evaluation tables (captra_amd/pose_utils/bbox_utils.py, captra_amd/eval.py) against golden G10, produced by
+the reference's own pose_utils/bbox_utils.py::eval_single_part_iou and misc/eval/eval.py::get_joint_state
+(tests/golden/make_golden_eval.py)."""
+import pickle
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from captra_amd.pose_utils.bbox_utils import bbox_from_corners, eval_single_part_iou, iou_3d, nocs_iou_3d
+from tests.golden.make_golden_eval import make_inputs
+
+G = np.load(Path(__file__).resolve().parent / "golden" / "g10_eval.npz")
+
+
+@pytest.mark.parametrize("tag,P,sym,nocs", [("rigid_sym", 1, True, True), ("rigid", 1, False, True), ("arti", 4, False, False)])
+def test_part_iou_vs_reference(tag, P, sym, nocs):
+    gc, pc, gt, pred = make_inputs(11 + P + int(sym), P)
+    got = eval_single_part_iou(gc, pc, gt, pred, nocs=nocs, sym=sym)
+    for name in ("npcs_iou", "iou", "gt_bbox_iou"):
+        np.testing.assert_allclose(got[name], G[f"{tag}_{name}"], atol=1e-6, rtol=0, err_msg=name)
+
+
+def test_iou_properties():
+    box = bbox_from_corners(np.array([[-0.2, -0.1, -0.3], [0.2, 0.1, 0.3]], np.float32))
+    assert abs(nocs_iou_3d(box, box) - 1.0) < 1e-6 and nocs_iou_3d(box, box + 10.0) == 0.0
+    assert iou_3d(box, box) == 1.0 and iou_3d(box, box + 0.7) == 0.0      # disjoint, still resolved by the 50^3 grid
+    assert iou_3d(box, box + 100.0) == 1.0   # the reference's grid artefact: no sample inside either box -> "both empty" -> 1
+    shifted = iou_3d(box, box + np.array([0.2, 0.0, 0.0], np.float32))
+    assert 0.0 < shifted < 1.0
+
+
+def test_joint_state_and_eval_cli(tmp_path):
+    """get_joint_state against the reference's values, then the whole `python -m captra_amd.eval` pass over a result pickle
+    in the layout `captra_amd.track --save` writes."""
+    from captra_amd import eval as ev
+    gc, pc, gt, pred = make_inputs(11 + 4, 4)
+    info = {"tree": [3, 3, 3, -1], "type": "prismatic", "main_axis": [2, 2, 2]}
+    np.testing.assert_allclose(ev.get_joint_state(info, gt), G["arti_joint_state_gt"], atol=1e-6)
+    np.testing.assert_allclose(ev.get_joint_state(info, pred), G["arti_joint_state_pred"], atol=1e-6)
+    data_dir = tmp_path / "results" / "data"
+    data_dir.mkdir(parents=True)
+    frames = [gt, pred, pred]
+    with open(data_dir / "inst0_track0.pkl", "wb") as f:
+        pickle.dump({"pred": {"poses": frames, "corners": [None, pc, pc]}, "gt": {"poses": [gt, gt, gt], "corners": gc},
+                     "frame_nums": [["0"], ["1"], ["2"]]}, f)
+    avg = ev.main(["--obj_category", "drawers", "--obj_config", "obj_info_sapien.yml", "--experiment_dir", str(tmp_path)])
+    np.testing.assert_allclose([avg[f"iou_{p}"] for p in range(4)], G["arti_iou"], atol=1e-6)
+    np.testing.assert_allclose([avg[f"rdiff_{p}"] for p in range(4)], G["rot_diff_deg"], atol=1e-3)
+    np.testing.assert_allclose([avg[f"theta_diff_{j}"] for j in range(3)],
+                               np.abs(G["arti_joint_state_pred"] - G["arti_joint_state_gt"]), atol=1e-6)
+    assert (tmp_path / "results" / "err.csv").exists() and (tmp_path / "results" / "err.pkl").exists()
