@@ -91,6 +91,10 @@ class EvalTrackModel(BaseModel):
                 out["npcs"] = frame["nocs"].float().to(self.device)
         if "labels" in frame:
             out["labels"] = frame["labels"].long().to(self.device)
+        pre = frame["meta"].get("pre_fetched")
+        if pre is not None:      # nocs_otf: the frame's depth image and instance mask live on the device
+            out["pre_fetched"] = {"depth": torch.as_tensor(pre["depth"]).to(self.device).int(),
+                                  "mask": torch.as_tensor(pre["mask"]).to(self.device).bool()}
         return out
 
     def _convert_npcs_frame(self, frame):
@@ -151,10 +155,31 @@ class EvalTrackModel(BaseModel):
         npcs = {k: v.clone() for k, v in self._graph.npcs_pred.items() if torch.is_tensor(v)}
         return npcs, {k: v.clone() for k, v in pose.items()}
 
+    def _recrop(self, i, input, last_pose):
+        """nocs_otf (reference model.py:425-452): re-crop frame i around the pose predicted for frame i-1 -- on the device
+        (captra_amd/nocs_otf.py).  The frame must carry its depth image and instance mask (meta['pre_fetched'])."""
+        from .nocs_otf import full_data_from_depth
+        pre = input.get("pre_fetched")
+        if pre is None:
+            raise ValueError("nocs_otf=True needs the frame's depth and mask tensors (meta['pre_fetched']): reading depth.png / "
+                             "mask.png from disk (cv2) is outside this build")
+        npcs = self.npcs_feed_dict[i]
+        B, _, N = input["points"].shape
+        centers = last_pose["translation"][:, self.root].reshape(B, 3).double().cpu().numpy()
+        scales = last_pose["scale"][:, self.root].reshape(B).double().cpu().numpy()
+        gt = {k: v[:, self.root].double().cpu().numpy() for k, v in input["gt_part"].items()}
+        pts, lab, nocs = [], [], []
+        for b in range(B):
+            full = full_data_from_depth(pre["depth"][b], pre["mask"][b], centers[b], self.radius * float(scales[b]),
+                                        {k: gt[k][b] for k in gt}, N)
+            pts.append((full["points"].float() - npcs["points_mean"][b].reshape(1, 3)).t())
+            lab.append(full["labels"])
+            nocs.append(full["nocs"].float().t())
+        input["points"] = torch.stack(pts).contiguous()
+        input["labels"] = torch.stack(lab).contiguous()
+        npcs["points"], npcs["labels"], npcs["nocs"] = input["points"], input["labels"], torch.stack(nocs).contiguous()
+
     def forward(self, save=False):
-        if self.nocs_otf:
-            raise NotImplementedError("nocs_otf (on-the-fly depth crop, reference model.py:425-452) is a "
-                                      "'next' row of SURVEY.md §8(f); feed pre-cropped clouds instead")
         pred_poses = [self._initial_pose()]
         npcs_pred = [None]
         frame_nums = []
@@ -168,6 +193,8 @@ class EvalTrackModel(BaseModel):
                 # draw it too so that seeded runs consume the generator identically
                 add_noise_to_part_dof(self.feed_dict[i - 1]["gt_part"], self.pose_perturb_cfg)
                 last_pose = {k: v.clone() for k, v in pred_poses[-1].items()}
+                if self.nocs_otf:
+                    self._recrop(i, input, last_pose)
                 if self._graph_usable(input):
                     cur_npcs, pose = self._graph_step(input, last_pose)
                 else:

@@ -8,8 +8,9 @@ result pickles of model.py:482-509.
 
 Data: `--data DIR` reads pre-cropped trajectories (`captra_amd/trajectory_io.py`: one .npz per trajectory);
 `--data synthetic[:nocs|:arti]` generates the seeded S-nocs / S-arti trajectories of SURVEY.md §8d (needs this
-repository's tests/ package).  The reference's dataset classes / on-the-fly depth crop are out of scope
-(§8f row 1): `--nocs_otf True` is rejected.
+repository's tests/ package).  `--nocs_otf True` re-crops every frame around the predicted pose on the device
+(captra_amd/nocs_otf.py); the trajectory files then carry the frames' depth images and masks.  The reference's dataset
+classes and image decoding (cv2) are outside this build.
 """
 from __future__ import annotations
 
@@ -117,9 +118,6 @@ def iter_batches(args, cfg):
 
 def main(argv=None) -> dict:
     args = parse_args(argv)
-    if args.nocs_otf:
-        raise SystemExit("--nocs_otf True (on-the-fly depth crop, reference model.py:425-452) is not part of this build: "
-                         "feed pre-cropped trajectories (captra_amd/trajectory_io.py)")
     data_args = {k: getattr(args, k) for k in ("data", "num_traj", "num_frames", "random_init", "seed", "hipgraph", "mlp_dtype")}
     for k in data_args:
         delattr(args, k)

@@ -12,6 +12,8 @@ per trajectory -- the arrays a dataset item holds after cropping to N points:
     rotation     (T,P,3,3) f32, translation (T,P,3,1) f32, scale (T,P) f32   ground-truth nocs2camera per part
     nocs_corners (P,2,3) f32
     paths        (T,) str      "…/<instance>/<track>/<frame>.<ext>" (drives the result file names, model.py:497-509)
+    depth, mask  (T,H,W) uint16 mm / bool, optional: the frames' depth images and instance masks for `--nocs_otf True`
+                               (the reference's meta['pre_fetched'], dataset.py:157-194)
 
 `stack_trajectories` batches B trajectories of equal length into the (B, …) frame dicts `set_data` takes.
 """
@@ -37,6 +39,9 @@ def save_trajectory_npz(path: str, frames: list, b: int = 0) -> None:
         "nocs_corners": frames[0]["meta"]["nocs_corners"][b].cpu().numpy().astype(np.float32),
         "paths": np.array([f["meta"]["path"][b] for f in frames]),
     }
+    if all("pre_fetched" in f["meta"] for f in frames):
+        out["depth"] = np.stack([np.asarray(f["meta"]["pre_fetched"]["depth"][b]) for f in frames]).astype(np.uint16)
+        out["mask"] = np.stack([np.asarray(f["meta"]["pre_fetched"]["mask"][b]) for f in frames]).astype(bool)
     np.savez(path, **out)
 
 
@@ -46,6 +51,9 @@ def load_trajectory_npz(path: str) -> dict:
         if missing:
             raise ValueError(f"{path}: not a trajectory file, missing {missing}")
         traj = {k: z[k] for k in _KEYS}
+        for k in ("depth", "mask"):
+            if k in z.files:
+                traj[k] = z[k]
     T = traj["points"].shape[0]
     if not all(traj[k].shape[0] == T for k in ("points_mean", "labels", "nocs", "rotation", "translation", "scale", "paths")):
         raise ValueError(f"{path}: inconsistent frame counts")
@@ -64,9 +72,10 @@ def stack_trajectories(trajs: list) -> list:
             return torch.from_numpy(np.stack([t[key][i] for t in trajs])).to(dtype)
         poses = [{"rotation": cat("rotation")[:, p].contiguous(), "translation": cat("translation")[:, p].contiguous(),
                   "scale": cat("scale")[:, p].contiguous()} for p in range(P)]
-        frames.append({
-            "points": cat("points"), "labels": cat("labels", torch.int64), "nocs": cat("nocs"),
-            "meta": {"path": [str(t["paths"][i]) for t in trajs], "nocs2camera": poses, "points_mean": cat("points_mean"),
-                     "nocs_corners": torch.from_numpy(np.stack([t["nocs_corners"] for t in trajs])).float()},
-        })
+        meta = {"path": [str(t["paths"][i]) for t in trajs], "nocs2camera": poses, "points_mean": cat("points_mean"),
+                "nocs_corners": torch.from_numpy(np.stack([t["nocs_corners"] for t in trajs])).float()}
+        if all("depth" in t and "mask" in t for t in trajs):
+            meta["pre_fetched"] = {"depth": torch.from_numpy(np.stack([t["depth"][i].astype(np.int32) for t in trajs])),
+                                   "mask": torch.from_numpy(np.stack([t["mask"][i] for t in trajs]))}
+        frames.append({"points": cat("points"), "labels": cat("labels", torch.int64), "nocs": cat("nocs"), "meta": meta})
     return frames

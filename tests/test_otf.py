@@ -1,0 +1,78 @@
+"""On-the-fly ball crop + resample (captra_amd/nocs_otf.py) against golden G11, produced by the reference's own
+crop_ball_from_depth_image + base_generate_data (tests/golden/make_golden_otf.py).  The CPU test injects the oracle FPS;
+the GPU test runs the product path (device tensors, captra_fps_gather)."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from captra_amd import nocs_otf
+from tests.golden.make_golden_otf import CASES, make_frame
+
+G = np.load(Path(__file__).resolve().parent / "golden" / "g11_otf.npz")
+
+
+def _oracle_fps(points_f32: torch.Tensor, num: int) -> torch.Tensor:
+    from oracle import ops as O
+    return torch.from_numpy(O.furthest_point_sample(points_f32.cpu().numpy()[None], num)[0].astype(np.int64)).to(points_f32.device)
+
+
+def _check(tag, seed, radius, n, device, fps_fn):
+    depth, mask, center, pose = make_frame(seed)
+    np.testing.assert_array_equal(nocs_otf.proj_corners(depth.shape[0], depth.shape[1], center, radius), G[f"{tag}_corners"])
+    np.random.seed(100 + seed)
+    kw = {} if fps_fn is None else {"fps_fn": fps_fn}
+    full = nocs_otf.full_data_from_depth(torch.from_numpy(depth.astype(np.int32)).to(device), torch.from_numpy(mask).to(device),
+                                         center, radius, pose, n, **kw)
+    assert full["points"].shape == (n, 3) and full["points"].dtype == torch.float64
+    if str(device) == "cpu":
+        np.testing.assert_array_equal(full["points"].cpu().numpy(), G[f"{tag}_points"])  # same pixels, same float64 arithmetic
+    else:   # the device's float64 3x3 product may contract into FMAs: last-bit differences, same pixels selected
+        np.testing.assert_allclose(full["points"].cpu().numpy(), G[f"{tag}_points"], atol=1e-15, rtol=0)
+    np.testing.assert_array_equal(full["labels"].cpu().numpy(), G[f"{tag}_labels"])
+    np.testing.assert_allclose(full["nocs"].cpu().numpy(), G[f"{tag}_nocs"], atol=1e-12, rtol=0)
+
+
+@pytest.mark.parametrize("tag,seed,radius,n", CASES)
+def test_crop_and_resample_vs_reference_cpu(tag, seed, radius, n):
+    _check(tag, seed, radius, n, "cpu", _oracle_fps)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,seed,radius,n", CASES)
+def test_crop_and_resample_vs_reference_gpu(device, tag, seed, radius, n):
+    _check(tag, seed, radius, n, device, None)
+
+
+@pytest.mark.gpu
+def test_track_loop_with_on_the_fly_crop(device):
+    """EvalTrackModel with nocs_otf=True: every frame's cloud is re-cropped on the device around the previous pose; with
+    init_frame/gt the first re-crop is centred on the ground-truth pose of frame 0, so it equals a direct call."""
+    from captra_amd.configs import make_config
+    from captra_amd.trainer import Trainer
+    from tests import clouds
+    from tests.weights import make_state_dict
+    cfg = make_config("1", experiment_dir="/tmp/captra_otf_test", nocs_otf=True, **{"init_frame/gt": True})
+    cfg["device"] = device
+    trainer = Trainer(cfg)
+    sd = make_state_dict({k: tuple(v.shape) for k, v in trainer.model.state_dict().items()}, seed=7)
+    trainer.model.load_state_dict(sd)
+    frames = clouds.make_trajectory("nocs", 2, 3, seed=0)
+    depth, mask, center, pose = make_frame(1)
+    for f in frames:                                        # same synthetic depth frame for every trajectory and time step
+        f["meta"]["pre_fetched"] = {"depth": torch.from_numpy(np.stack([depth.astype(np.int32)] * 2)), "mask": torch.from_numpy(np.stack([mask] * 2))}
+        for p in f["meta"]["nocs2camera"]:
+            p["rotation"] = torch.from_numpy(np.stack([pose["rotation"]] * 2)).float()
+            p["translation"] = torch.from_numpy(np.stack([pose["translation"]] * 2)).float()
+            p["scale"] = torch.full((2,), float(pose["scale"]))
+    np.random.seed(5)
+    pred, _ = trainer.test(frames)
+    assert len(pred["poses"]) == 3 and all(torch.isfinite(v).all() for p in pred["poses"] for v in p.values())
+    model = trainer.model
+    np.random.seed(5)
+    c0 = pose["translation"].reshape(3).astype(np.float32).astype(np.float64)
+    ref = nocs_otf.full_data_from_depth(torch.from_numpy(depth.astype(np.int32)).to(device), torch.from_numpy(mask).to(device), c0,
+                                        cfg["data_radius"] * float(np.float32(pose["scale"])), pose, 4096)
+    got = model.feed_dict[1]["points"][0].t().double() + model.npcs_feed_dict[1]["points_mean"][0].reshape(1, 3).double()
+    np.testing.assert_allclose(got.cpu().numpy(), ref["points"].cpu().numpy(), atol=2e-7)
