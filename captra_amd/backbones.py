@@ -49,7 +49,7 @@ class PointNet2Msg(_FoldCache, nn.Module):
         self.device = cfg["device"]
         self._folded = None
 
-    def forward(self, input, input_n3=None, geom=None):
+    def forward(self, input, input_n3=None, geom=None, finish=None):
         """input (B,3(+C),N); `input_n3` optionally the (B,N,3) copy of input[:, :3]; `geom` optionally
         the `last_geom` of another PointNet2Msg that ran on the SAME cloud (FPS picks, ball-query lists
         and 3-NN weights depend on coordinates only): those kernels are then skipped."""
@@ -72,8 +72,9 @@ class PointNet2Msg(_FoldCache, nn.Module):
         if fuse and self._folded is None:
             self._folded = fold_conv_bn(self.conv1, self.bn1, l0_xyz.device)
         # fused path: conv1 + bn1 + ReLU rides at the end of FP1's MLP (one launch for the three layers)
+        # `finish` (fused path): the caller evaluates FP1's layers + conv1 itself, fused with its own heads
         l0_points = self.fp1(l0_xyz, l1_xyz, skip0, l1_points, xyz1_n3=input_n3, xyz2_n3=l1_n3, nn=geom.get("fp1"),
-                             tail=self._folded if fuse else None)
+                             tail=self._folded if fuse else None, finish=finish if fuse else None)
         self.last_geom = {"sa1": self.sa1.last_geom, "sa2": self.sa2.last_geom, "fp2": self.fp2.last_nn, "fp1": self.fp1.last_nn}
         if fuse:
             return l0_points

@@ -111,7 +111,74 @@ __global__ __launch_bounds__(256) void mlp_chain3_kernel(ChainParams p) {
     sw_layer_reg<C2, C3, SW_EPI_STORE, START3>(p.w3, bias_lds + 512, h2, none, s, nullptr, wave, lane, [&](float (&)[16]) {}, st);
 }
 
+// CoordNet's tail in one launch: FP1 shared MLP + conv1 (-> feat, never stored) + the segmentation head (one conv) + the
+// NOCS head (conv + BN + ReLU, conv, sigmoid - 0.5): six layers, two stored outputs (reference networks.py:29-32, 44-46,
+// blocks.py:118-135).  Same building blocks as above; feat stays in registers as the B operand of both heads.
+struct TailParams {
+    long long L;
+    const float *x;                                  // (B,C0,L)
+    const float *w[6], *b[6];                        // fp1a, fp1b, conv1, seg, nocs hidden, nocs out (packed)
+    float *seg, *nocs;                               // (B,SEG,L), (B,NOCS,L)
+    int nocs_act;
+};
+
+template <int C0, int SEG, int NOCS>
+__global__ __launch_bounds__(256) void coord_tail_kernel(TailParams p) {
+    constexpr int C = 128;
+    using SH = SwShape<C, C>;
+    using SS = SwShape<C, SEG>;
+    __shared__ __attribute__((aligned(16))) float bias_lds[6 * 256];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.y;
+    const long long pos = ((long long)blockIdx.x * 4 + wave) * 32;
+    for (int e = tid; e < 6 * 256; e += 256) {
+        const int l = e / 256, c = e % 256;
+        bias_lds[e] = c < 128 ? p.b[l][c] : 0.f;     // packed biases: ceil128(cout) >= 128 floats each
+    }
+    __syncthreads();
+    if (pos >= p.L) return;
+    const bool col_ok = pos + (lane & 31) < p.L;
+    float s[2][16];
+    float h1[SH::KST], h2[SH::KST], h3[SH::KST], h4[SH::KST], none[1];
+    ChainParams cp;
+    cp.c0 = C0; cp.L = p.L; cp.x = p.x; cp.w1 = p.w[0];
+    chain_layer1<C0, C>(cp, p.x + (size_t)b * C0 * p.L, pos, col_ok, bias_lds, h1, lane, [&]() { sw_first_set<C, C>(s[0], p.w[1], lane); });
+    constexpr int P2 = 0, P3 = (P2 + SH::STEPS) & 1, P4 = (P3 + SH::STEPS) & 1, P5 = (P4 + SS::STEPS) & 1, P6 = (P5 + SH::STEPS) & 1;
+    sw_layer_reg<C, C, SW_EPI_MID, P2>(p.w[1], bias_lds + 256, h1, h2, s, nullptr, wave, lane, [&](float (&d)[16]) { sw_first_set<C, C>(d, p.w[2], lane); });
+    sw_layer_reg<C, C, SW_EPI_MID, P3>(p.w[2], bias_lds + 512, h2, h3, s, nullptr, wave, lane, [&](float (&d)[16]) { sw_first_set<C, SEG>(d, p.w[3], lane); });
+    SwStore st;
+    st.ld = p.L; st.col_ok = col_ok;
+    st.y = p.seg + (size_t)b * SEG * p.L + pos; st.act = ACT_NONE;
+    sw_layer_reg<C, SEG, SW_EPI_STORE, P4>(p.w[3], bias_lds + 768, h3, none, s, nullptr, wave, lane, [&](float (&d)[16]) { sw_first_set<C, C>(d, p.w[4], lane); }, st);
+    sw_layer_reg<C, C, SW_EPI_MID, P5>(p.w[4], bias_lds + 1024, h3, h4, s, nullptr, wave, lane, [&](float (&d)[16]) { sw_first_set<C, NOCS>(d, p.w[5], lane); });
+    st.y = p.nocs + (size_t)b * NOCS * p.L + pos; st.act = p.nocs_act;
+    sw_layer_reg<C, NOCS, SW_EPI_STORE, P6>(p.w[5], bias_lds + 1280, h4, none, s, nullptr, wave, lane, [&](float (&)[16]) {}, st);
+}
+
 }  // namespace
+
+extern "C" int captra_coord_tail(int b, int c0, int seg_dim, int nocs_dim, long long l, const float *x, const float *const *w,
+                                 const float *const *bias, int nocs_act, float *seg, float *nocs, captra_stream_t stream) {
+    if (b < 0 || c0 < 1 || seg_dim < 1 || nocs_dim < 1 || l < 0 || nocs_act < 0 || nocs_act > 2) return -1;
+    if ((long long)c0 * l * 4 >= (1ll << 31)) return -2;
+    TailParams p;
+    p.L = l; p.x = x; p.seg = seg; p.nocs = nocs; p.nocs_act = nocs_act;
+    for (int i = 0; i < 6; ++i) { p.w[i] = w[i]; p.b[i] = bias[i]; }
+    dim3 grid((unsigned)((l + 127) / 128), b);
+#define TAIL_CASE(C0_, S_, N_)                                                                                     \
+    if (c0 == C0_ && seg_dim == S_ && nocs_dim == N_) {                                                            \
+        if (b == 0 || l == 0) return 0;                                                                            \
+        CAPTRA_LAUNCH("coord_tail", (coord_tail_kernel<C0_, S_, N_>), grid, dim3(256), 0, (hipStream_t)stream, p);  \
+        return captra_last_error();                                                                                \
+    }
+    TAIL_CASE(134, 2, 3)    // rigid categories: 1 part + background, 3 NOCS channels
+    TAIL_CASE(134, 4, 12)   // drawers: 4 parts
+    TAIL_CASE(134, 3, 9)    // glasses: 3 parts
+    TAIL_CASE(134, 2, 6)    // scissors / laptop: 2 parts
+#undef TAIL_CASE
+    return -2;
+}
 
 // y = act3(W3 relu(W2 relu(W1 x + b1) + b2) + b3), see include/captra_hip.h.  Returns -2 for channel shapes that are
 // not instantiated (the caller then runs the three layers with captra_pointwise_mlp: same bits).

@@ -263,6 +263,35 @@ def mlp_chain3(x, layers, act3: int = ACT_RELU):
     return out
 
 
+USE_COORD_TAIL = True
+_COORD_TAIL_SHAPES = {(134, 2, 3), (134, 4, 12), (134, 3, 9), (134, 2, 6)}   # csrc/mlp_chain.hip TAIL_CASE list
+
+
+def coord_tail_supported(x, layers) -> bool:
+    """layers = [fp1a, fp1b, conv1, seg, nocs hidden, nocs out] (PackedLinear)."""
+    if not (USE_COORD_TAIL and MLP_DTYPE == "fp32" and len(layers) == 6):
+        return False
+    l = x.numel() // max(x.shape[0] * x.shape[1], 1)
+    widths_ok = all(lin.cout == 128 for lin in (layers[0], layers[1], layers[2], layers[4])) and all(lin.cin == 128 for lin in layers[1:])
+    return widths_ok and (x.shape[1], layers[3].cout, layers[5].cout) in _COORD_TAIL_SHAPES and x.shape[1] * l * 4 < (1 << 31)
+
+
+def coord_tail(x, layers, nocs_act: int = ACT_SIGMOID_M05):
+    """x (B,c0,N) -> (seg logits (B,S,N), nocs (B,3P,N)): FP1 MLP + conv1 + both CoordNet heads in one launch."""
+    import ctypes
+    L.require_device(x, *(t for lin in layers for t in (lin.wt, lin.bias)))
+    B, c0 = x.shape[:2]
+    l = x.numel() // max(B * c0, 1)
+    seg = torch.empty((B, layers[3].cout) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+    nocs = torch.empty((B, layers[5].cout) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+    wp = (ctypes.c_void_p * 6)(*[lin.wt.data_ptr() for lin in layers])
+    bp = (ctypes.c_void_p * 6)(*[lin.bias.data_ptr() for lin in layers])
+    with torch.cuda.device(x.device):
+        L.call("captra_coord_tail", B, c0, layers[3].cout, layers[5].cout, l, L.ptr(x), wp, bp, nocs_act, L.ptr(seg), L.ptr(nocs))
+    _work("mlp_chain3", flops=2.0 * B * l * sum(lin.cin * lin.cout for lin in layers), nbytes=4.0 * B * l * (c0 + layers[3].cout + layers[5].cout))
+    return seg, nocs
+
+
 def sa_group_mlp(feat, xyz_cn, new_xyz_n3, idx, lin: PackedLinear):
     """First SA layer with group + centre-subtract + concat fused into the load -> (B,cout,M,K)."""
     wt, bias = lin.wt, lin.bias

@@ -15,6 +15,7 @@ import torch.nn.functional as F
 from . import fused
 from .backbones import PointNet2Msg
 from .blocks import RotationRegressor, get_point_mlp, run_point_mlp
+from .fold import fold_conv_bn
 from .pose_utils.part_dof_utils import convert_pred_rtvec_to_matrix, merge_reenact_canon_part_pose
 from .pose_utils.pose_fit import part_fit_st_cn
 from .pose_utils.procrustes import (rot_around_yaxis_to_3d, scale_pts_mask, transform_pts_2d_mask,
@@ -54,6 +55,19 @@ class CoordNet(nn.Module):
         self._cache = {}
         return super()._apply(fn, *a, **k)
 
+    def _head_layers(self, device):
+        """[seg conv, nocs hidden conv+BN, nocs out conv] folded, when the heads have the shape the one-launch tail covers
+        (seg head = one conv; NOCS head = conv-BN-ReLU, conv, sigmoid); None otherwise."""
+        key = "tail_layers"
+        if key not in self._cache:
+            seg, nocs = list(self.seg_head), [m for m in self.nocs_head if not isinstance(m, nn.Dropout)]
+            ok = (len(seg) == 1 and isinstance(seg[0], nn.Conv1d) and len(nocs) == 5 and isinstance(nocs[0], nn.Conv1d)
+                  and isinstance(nocs[1], nn.BatchNorm1d) and isinstance(nocs[2], nn.ReLU) and isinstance(nocs[3], nn.Conv1d)
+                  and isinstance(nocs[4], nn.Sigmoid))
+            self._cache[key] = ([fold_conv_bn(seg[0], None, device), fold_conv_bn(nocs[0], nocs[1], device),
+                                 fold_conv_bn(nocs[3], None, device)] if ok else None)
+        return self._cache[key]
+
     def _heads(self, feat):
         if (not self.training) and feat.is_cuda:
             return run_point_mlp(self.seg_head, feat, self._cache), run_point_mlp(self.nocs_head, feat, self._cache)
@@ -65,9 +79,23 @@ class CoordNet(nn.Module):
         canon_pose = input["canon_pose"]
         cam_cn, cam_n3 = _canonicalize(input["points"], input["points_mean"], canon_pose)
         self.last_canon = (cam_cn, cam_n3)
-        feat = self.backbone(cam_cn, input_n3=cam_n3)
-        seg_logits, nocs = self._heads(feat)
-        pred = {"seg": F.softmax(seg_logits, dim=1), "nocs": nocs - 0.5, "points": cam_cn}
+        fused_tail = None
+        if (not self.training) and cam_cn.is_cuda:
+            head_layers = self._head_layers(cam_cn.device)
+            if head_layers is not None:
+                def fused_tail(x, layers):
+                    all_layers = list(layers) + head_layers
+                    if fused.coord_tail_supported(x, all_layers):
+                        return fused.coord_tail(x, all_layers)            # (seg logits, sigmoid(nocs) - 0.5)
+                    seg_logits, nocs = self._heads(fused.mlp_chain3(x, layers, fused.ACT_RELU))
+                    return seg_logits, nocs - 0.5
+        out = self.backbone(cam_cn, input_n3=cam_n3, finish=fused_tail)
+        if fused_tail is not None:
+            seg_logits, nocs_m05 = out
+        else:
+            seg_logits, nocs = self._heads(out)
+            nocs_m05 = nocs - 0.5
+        pred = {"seg": F.softmax(seg_logits, dim=1), "nocs": nocs_m05, "points": cam_cn}
         if "gt_part" in input:
             pred["part"] = self._fit_with_gt_rotation(input, pred, test)
         return pred

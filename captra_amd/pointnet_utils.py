@@ -246,12 +246,14 @@ class PointNetFeaturePropagation(_FoldCache, nn.Module):
             self._folded = [fold_conv_bn(c, b, device) for c, b in zip(self.mlp_convs, self.mlp_bns)]
         return self._folded
 
-    def forward(self, xyz1, xyz2, points1, points2, xyz1_n3=None, xyz2_n3=None, nn=None, tail=None):
+    def forward(self, xyz1, xyz2, points1, points2, xyz1_n3=None, xyz2_n3=None, nn=None, tail=None, finish=None):
         """xyz1 (B,3,N) dense, xyz2 (B,3,S) sparse, points1 (B,D1,N) or None, points2 (B,D2,S)
         -> (B,D',N).  `nn` = (idx, weight) of fused.three_nn_weights on the same coordinates, when
         another network already computed them; what was used is left in `self.last_nn`.
         `tail` (fused path only) = a folded conv+BN+ReLU layer the caller applies to the result anyway
-        (the backbone's conv1): it is appended to this module's MLP so that the chain runs as one launch."""
+        (the backbone's conv1): it is appended to this module's MLP so that the chain runs as one launch.
+        `finish(new_points, layers)` (fused path only), when given, replaces the evaluation of those layers: the caller
+        runs them together with whatever consumes their output (CoordNet's heads) and gets back what it returns."""
         self.last_nn = None
         B, _, N = xyz1.shape
         S = xyz2.shape[2]
@@ -281,6 +283,8 @@ class PointNetFeaturePropagation(_FoldCache, nn.Module):
         if fuse:
             new_points = new_points.contiguous()
             layers = list(self._fold(xyz1.device)) + ([tail] if tail is not None else [])
+            if finish is not None:
+                return finish(new_points, layers)
             if len(layers) == 3:
                 return fused.mlp_chain3(new_points, layers, fused.ACT_RELU)
             for lin in layers:

@@ -211,6 +211,15 @@ int captra_mlp_chain3(int b, int c0, int c1, int c2, int c3, long long l, const 
                       const float *b1, const float *w2, const float *b2, const float *w3, const float *b3, int act3,
                       float *y, captra_stream_t stream);
 
+/* CoordNet's tail in one launch (networks.py:29-32, 44-46; backbones.py:66-68): x (B,c0,l) = FP1's concatenated input ->
+ * FP1 shared MLP (2 layers) -> conv1+bn1+ReLU -> feat (128 channels, never stored) -> seg (B,seg_dim,l) = segmentation head
+ * (one conv, raw logits) and nocs (B,nocs_dim,l) = NOCS head (conv+BN+ReLU, conv, nocs_act: CAPTRA_ACT_SIGMOID_M05 gives
+ * sigmoid - 0.5).  w / bias: HOST arrays of the six layers' packed device pointers in that order (fp1a, fp1b, conv1, seg,
+ * nocs hidden, nocs out); hidden widths 128.  Instantiated for c0 = 134 and (seg_dim, nocs_dim) in {(2,3), (4,12), (3,9), (2,6)};
+ * -2 otherwise.  Every output equals the corresponding chain of captra_pointwise_mlp calls bit for bit (sigmoid: same expf). */
+int captra_coord_tail(int b, int c0, int seg_dim, int nocs_dim, long long l, const float *x, const float *const *w,
+                      const float *const *bias, int nocs_act, float *seg, float *nocs, captra_stream_t stream);
+
 /* Feature propagation input (pointnet_utils.py:280-294, CUDA semantics: weights from sqrt(d2), SURVEY.md
  * §2.2), in two halves so that networks looking at the same cloud share the geometric one:
  *   captra_three_nn_weights: unknown (B,N,3), known (B,S,3) -> idx (B,N,3) i32, weight (B,N,3) f32 with

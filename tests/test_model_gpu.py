@@ -730,3 +730,24 @@ def test_bf16_mode_track_step_close_to_fp32(device):
     assert np.isfinite(outs["bf16"][0]).all() and d.mean() < 5e-3 and d.max() < 5e-2, (d.mean(), d.max())
     flips = (outs["fp32"][1].argmax(1) != outs["bf16"][1].argmax(1)).mean()
     assert flips < 0.01, flips
+
+
+def test_coord_tail_one_launch_equals_layer_by_layer(device):
+    """CoordNet's FP1 + conv1 + seg / NOCS heads as one launch == the same layers through captra_pointwise_mlp (bit-exact
+    for the logits; the NOCS sigmoid uses the same expf) and the reference-structured torch path to 1e-5."""
+    from captra_amd import fused
+    rng = np.random.default_rng(77)
+    B, c0, l = 2, 134, 1000
+    x = rng.standard_normal((B, c0, l)).astype(np.float32)
+    dims = [(c0, 128), (128, 128), (128, 128), (128, 2), (128, 128), (128, 3)]
+    layers = [((rng.standard_normal(d) / np.sqrt(d[0])).astype(np.float32), rng.standard_normal(d[1]).astype(np.float32)) for d in dims]
+    packed = [fused.pack(_dev(w, device), _dev(b, device)) for w, b in layers]
+    assert fused.coord_tail_supported(_dev(x, device), packed)
+    seg, nocs = fused.coord_tail(_dev(x, device), packed)
+    feat = x
+    for w, b in layers[:3]:
+        feat = O.pointwise_mlp(feat, w, b, 1)
+    np.testing.assert_array_equal(seg.cpu().numpy(), O.pointwise_mlp(feat, layers[3][0], layers[3][1], 0))
+    hid = O.pointwise_mlp(feat, layers[4][0], layers[4][1], 1)
+    raw = O.pointwise_mlp(hid, layers[5][0], layers[5][1], 0)
+    np.testing.assert_allclose(nocs.cpu().numpy(), 1.0 / (1.0 + np.exp(-raw.astype(np.float64))) - 0.5, atol=2e-7, rtol=0)
