@@ -459,6 +459,91 @@ __global__ __launch_bounds__(256) void pw_direct_kernel(PwParams p) {
     }
 }
 
+// Dense layer + ReLU + max over groups of K consecutive positions (K in {32, 64, 128}; SA3's last layer over its 128 points,
+// reference pointnet_utils.py:336-343), direct-operand form: a workgroup = 4 waves x 32 positions x one 32-row output
+// tile, both operands prefetched 16 k-steps ahead (one accumulator chain per wave, so the sets are deep), ReLU and the
+// 32-lane max on the bit patterns (v_max_i32_dpp), the 4 waves' maxima combined through LDS.
+__global__ __launch_bounds__(256) void pw_direct_max_kernel(PwParams p) {
+    constexpr int KS = 16;
+    __shared__ float red[32 * 4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.z;
+    const int co0 = blockIdx.y * 32;
+    const long long blk0 = (long long)blockIdx.x * 128;
+    const long long pos0 = blk0 + wave * 32;
+    const int kp = (p.cin + 31) / 32 * 32;
+    const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc((void *)p.wt, 0, kp * p.ldw * 4, 0x00020000);
+    const float *xb = p.x + (size_t)b * p.cin * p.L;
+    const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc((void *)xb, 0, (int)((long long)p.cin * p.L * 4), 0x00020000);
+    const int wstep = 2 * p.ldw * 4, xstep = (int)(2 * p.L * 4);
+    const int wvoff = (((lane >> 5) * p.ldw) + co0 + (lane & 31)) * 4;
+    long long col = pos0 + (lane & 31);
+    const bool col_ok = col < p.L;
+    if (!col_ok) col = p.L - 1;
+    const int xvoff = (int)(((long long)(lane >> 5) * p.L + col) * 4);
+    f32x16 acc;
+    {
+        const float *bp = p.bias + co0 + 4 * (lane >> 5);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = bp[(r & 3) + 8 * (r >> 2)];
+    }
+    float a0[KS], a1[KS], b0[KS], b1[KS];
+    const int nsets = (p.cin + 2 * KS - 1) / (2 * KS);
+#define PM_LOAD(A, Bv, si)                                                                                              \
+    _Pragma("unroll") for (int j = 0; j < KS; ++j) {                                                                    \
+        A[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wsrc, wvoff, ((si) * KS + j) * wstep, 0)); \
+        Bv[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xsrc, xvoff + ((si) * KS + j) * xstep, 0, 0)); \
+    }                                                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);
+#define PM_MFMA(A, Bv)                                                                                                  \
+    _Pragma("unroll") for (int j = 0; j < KS; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[j], Bv[j], acc, 0, 0, 0);  \
+    __builtin_amdgcn_sched_barrier(0);
+    PM_LOAD(a0, b0, 0)
+    for (int c = 0; c + 1 < nsets; c += 2) {
+        PM_LOAD(a1, b1, c + 1)
+        PM_MFMA(a0, b0)
+        PM_LOAD(a0, b0, (c + 2 < nsets ? c + 2 : nsets - 1))
+        PM_MFMA(a1, b1)
+    }
+    if (nsets & 1) { PM_MFMA(a0, b0) }
+#undef PM_LOAD
+#undef PM_MFMA
+    int v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int xbits = __float_as_int(acc[r]);
+        v[r] = (xbits > 0 && col_ok) ? xbits : 0;       // ReLU on the bit pattern; columns beyond L contribute 0
+    }
+#define PM_STEP(CTRL)                                                                                   \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                   \
+        const int o = __builtin_amdgcn_update_dpp(0, v[r], CTRL, 0xF, 0xF, true);                       \
+        v[r] = o > v[r] ? o : v[r];                                                                     \
+    }
+    PM_STEP(0xB1) PM_STEP(0x4E) PM_STEP(0x141) PM_STEP(0x140)
+#undef PM_STEP
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int o = __builtin_amdgcn_update_dpp(v[r], v[r], 0x142, 0xA, 0xF, false);  // row_bcast15 into rows 1, 3
+        v[r] = o > v[r] ? o : v[r];
+    }
+    if ((lane & 31) == 16) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 4 + wave] = __int_as_float(v[r]);
+    }
+    __syncthreads();
+    const int tiles_per_group = p.k / 32, groups = 128 / p.k;
+    for (int e = tid; e < 32 * groups; e += 256) {
+        const int row = e / groups, gi = e % groups;
+        const long long g = blk0 / p.k + gi;
+        if (g < p.m && co0 + row < p.cout) {
+            float mx = red[row * 4 + gi * tiles_per_group];
+            for (int t = 1; t < tiles_per_group; ++t) mx = fmaxf(mx, red[row * 4 + gi * tiles_per_group + t]);
+            p.y[((size_t)b * p.y_ctotal + p.co_off + co0 + row) * p.m + g] = mx;
+        }
+    }
+}
+
 // One wave per (cloud, group): fixed-order double-precision sum of the partials -> mean, rstd -> per-channel (a, b) with
 // GroupNorm(x) = a*x + b  (a = gamma*rstd, b = beta - mean*a).
 __global__ __launch_bounds__(256) void gn_finalize_kernel(int nb, int c, int cpg, int t, long long n, float eps,
@@ -633,6 +718,11 @@ extern "C" int captra_mlp_max(int b, int cin, int cout, int m, int k, const floa
     p.cin = cin; p.cout = cout; p.ldw = (cout + 127) / 128 * 128; p.L = (long long)m * k; p.x = x; p.wt = wt_packed;
     p.bias = bias_packed; p.y = y; p.act = ACT_RELU;
     p.m = m; p.k = k; p.y_ctotal = y_ctotal; p.co_off = co_off;
+    if (g_pw_direct && (long long)cin * p.L * 4 < (1ll << 31)) {
+        dim3 grid((unsigned)((p.L + 127) / 128), (cout + 31) / 32, b);
+        CAPTRA_LAUNCH("mlp_max", pw_direct_max_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+        return captra_last_error();
+    }
     const bool vec = ((reinterpret_cast<uintptr_t>(x) & 15) == 0);  // L = m*k is a multiple of 32
     if (vec) return launch_pw<PRO_PLAIN, EPI_MAXK, true>(b, p, (hipStream_t)stream, "mlp_max");
     return launch_pw<PRO_PLAIN, EPI_MAXK, false>(b, p, (hipStream_t)stream, "mlp_max");
