@@ -330,7 +330,7 @@ def main():
         total_ms = sum(v["ms_total"] for v in fams.values())
         # the fp32-MFMA shared-MLP kernels: the fused SA scale (sa_fused.hip) and the layer kernel template
         # (pointwise_mlp.hip: pointwise_mlp / sa_group_mlp / mlp_max entry points)
-        mlp = ["sa_scale_fused", "pointwise_mlp", "mlp_chain3", "sa_group_mlp", "mlp_max"]
+        mlp = ["sa_scale_fused", "pointwise_mlp", "mlp_chain3", "coord_tail", "sa_group_mlp", "mlp_max"]
         mlp_ms = sum(fams[k]["ms_total"] for k in mlp if k in fams)
         mlp_launches = sum(fams[k]["launches"] for k in mlp if k in fams)
         mlp_flops = sum(fused.WORK["flops"].get(k, 0.0) for k in mlp)
@@ -340,12 +340,12 @@ def main():
             peak = PEAK_F32_MFMA_TFLOPS if args.mlp_dtype == "fp32" else PEAK_BF16_MFMA_TFLOPS
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                                "frac": round(ach / peak, 4), "traffic": None,
-                               "kernel": ("fp32 MFMA 32x32x2 shared-MLP kernels: sa_wave_kernel / sa_wave_lds_kernel (dominant) + mlp_chain3_kernel + pw_direct_kernel + pw_mlp_kernel"
+                               "kernel": ("fp32 MFMA 32x32x2 shared-MLP kernels: sa_wave_kernel / sa_wave_lds_kernel (dominant) + mlp_chain3_kernel + coord_tail_kernel + pw_direct_kernel + pw_direct_max_kernel"
                                           if args.mlp_dtype == "fp32" else "bf16 MFMA 32x32x16 shared-MLP kernels: sa_wave_bf16_kernel + pw_bf16_kernel"),
                                "avg_launch_us": round(1e3 * mlp_ms / max(mlp_launches, 1), 2),
                                "flops_per_launch": round(mlp_flops / max(mlp_launches, 1)),
                                "share_of_kernel_time": round(mlp_ms / max(total_ms, 1e-9), 3), "dominant_family": dominant}
-            traffic, src = (None, None) if args.mlp_dtype != "fp32" else pmc_traffic(["sa_wave_kernel", "sa_wave_lds_kernel", "sa_fused_kernel", "mlp_chain3_kernel", "pw_direct_kernel", "pw_mlp_kernel"])
+            traffic, src = (None, None) if args.mlp_dtype != "fp32" else pmc_traffic(["sa_wave_kernel", "sa_wave_lds_kernel", "sa_fused_kernel", "mlp_chain3_kernel", "coord_tail_kernel", "pw_direct_kernel", "pw_direct_max_kernel", "pw_mlp_kernel"])
             if traffic is not None:
                 out["roofline"]["traffic"] = round(traffic)
                 out["roofline"]["traffic_source"] = f"profiles/{src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch)"

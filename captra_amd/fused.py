@@ -288,7 +288,7 @@ def coord_tail(x, layers, nocs_act: int = ACT_SIGMOID_M05):
     bp = (ctypes.c_void_p * 6)(*[lin.bias.data_ptr() for lin in layers])
     with torch.cuda.device(x.device):
         L.call("captra_coord_tail", B, c0, layers[3].cout, layers[5].cout, l, L.ptr(x), wp, bp, nocs_act, L.ptr(seg), L.ptr(nocs))
-    _work("mlp_chain3", flops=2.0 * B * l * sum(lin.cin * lin.cout for lin in layers), nbytes=4.0 * B * l * (c0 + layers[3].cout + layers[5].cout))
+    _work("coord_tail", flops=2.0 * B * l * sum(lin.cin * lin.cout for lin in layers), nbytes=4.0 * B * l * (c0 + layers[3].cout + layers[5].cout))
     return seg, nocs
 
 
