@@ -75,18 +75,24 @@ __global__ __launch_bounds__(NW_THREADS) void three_nn_weights_kernel(int n, int
             (comp == 0 ? xs : (comp == 1 ? ys : zs))[pp] = v;
         }
         __syncthreads();
-        for (int k = 0; k < tn; ++k) {
-            const float d = dist2_unfused(ux, uy, uz, xs[k], ys[k], zs[k]);
-            const int kk = t0 + k;
-            if (d < b1) {
-                b3 = b2; i3 = i2;
-                b2 = b1; i2 = i1;
-                b1 = d;  i1 = kk;
-            } else if (d < b2) {
-                b3 = b2; i3 = i2;
-                b2 = d;  i2 = kk;
-            } else if (d < b3) {
-                b3 = d;  i3 = kk;
+        // branch-free insertion into the sorted triple (strict '<': an equal distance keeps the earlier index), four known
+        // points per 16-byte LDS read; the tail of a tile that is not a multiple of 4 is read as +inf padding below
+        const int tn4 = (tn + 3) & ~3;
+        for (int e = tn + tid; e < tn4; e += NW_THREADS) { xs[e] = INFINITY; ys[e] = INFINITY; zs[e] = INFINITY; }
+        if (tn4 != tn) __syncthreads();
+        for (int k = 0; k < tn4; k += 4) {
+            const float4 kx = *reinterpret_cast<const float4 *>(xs + k);
+            const float4 ky = *reinterpret_cast<const float4 *>(ys + k);
+            const float4 kz = *reinterpret_cast<const float4 *>(zs + k);
+            const float qx[4] = {kx.x, kx.y, kx.z, kx.w}, qy[4] = {ky.x, ky.y, ky.z, ky.w}, qz[4] = {kz.x, kz.y, kz.z, kz.w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float d = dist2_unfused(ux, uy, uz, qx[u], qy[u], qz[u]);   // padding: inf - never inserted (NaN-free: inf*inf)
+                const int kk = t0 + k + u;
+                const bool c1 = d < b1, c2 = d < b2, c3 = d < b3;
+                b3 = c2 ? b2 : (c3 ? d : b3);  i3 = c2 ? i2 : (c3 ? kk : i3);
+                b2 = c1 ? b1 : (c2 ? d : b2);  i2 = c1 ? i1 : (c2 ? kk : i2);
+                b1 = c1 ? d : b1;              i1 = c1 ? kk : i1;
             }
         }
     }
