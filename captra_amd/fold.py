@@ -27,6 +27,14 @@ class PackedLinear:
         self.wt, self.bias, self.cin, self.cout = wt.contiguous(), bias.contiguous(), cin, cout
         self._bf16 = {}
 
+    def leading_rows(self, rows: int) -> "PackedLinear":
+        """The layer restricted to its first `rows` input channels, sharing this layer's buffers (the packed image's leading
+        rows ARE those channels; the kernels never read past ceil32(cin) rows)."""
+        assert 1 <= rows <= self.cin
+        view = PackedLinear.__new__(PackedLinear)
+        view.wt, view.bias, view.cin, view.cout, view._bf16 = self.wt, self.bias, rows, self.cout, self._bf16
+        return view
+
     def bf16(self, row0: int = 0, rows: int | None = None) -> torch.Tensor:
         """bf16 image of input rows [row0, row0+rows) of this layer for the bf16 kernels (include/captra_hip.h:
         Wb [ceil32(cout)][ceil32(rows)], untransposed, zero padded), built once per (row0, rows) on the device."""

@@ -155,10 +155,8 @@ def sa_scale_bf16(feat, xyz_cn, new_xyz_n3, idx, layers, out, co_off):
 def sa_first_layer_pre(feat, lin: PackedLinear):
     """v1 (B,c1,N) = b1 + W1[feature rows] feat: the part of an SA scale's first layer that depends on the source
     point only (the chain's first cfeat steps; the packed buffer's leading rows ARE the feature rows)."""
-    view = PackedLinear.__new__(PackedLinear)
-    view.wt, view.bias, view.cin, view.cout, view._bf16 = lin.wt, lin.bias, feat.shape[1], lin.cout, lin._bf16
     assert lin.cin == feat.shape[1] + 3
-    return pointwise_mlp(feat, view, ACT_NONE)
+    return pointwise_mlp(feat, lin.leading_rows(feat.shape[1]), ACT_NONE)
 
 
 def sa_scale_pre(v1, xyz_cn, new_xyz_n3, idx, layers, out, co_off, cfeat):
