@@ -360,6 +360,13 @@ def main():
         out["kernel_ms_per_step"]["_sum_captra_kernels"] = round(total_ms / args.steps, 3)
     if world == 1 and timing:
         out["hbm_ops"] = hbm_ops_roofline(B, device)
+        bq_ms = out.get("kernel_ms_per_step", {}).get("ball_query")
+        if bq_ms:
+            # what the timed step spends on the same job: the ball-query launches only -- grouping happens inside the SA
+            # kernels' operand loads and moves none of the 4*C*M*K bytes
+            eq = out["hbm_ops"]["bytes_per_frame"] * B / (bq_ms * 1e-3) / 1e9
+            out["hbm_ops"]["product_path"] = {"ms_per_step": bq_ms, "equivalent_GB/s": round(eq, 1), "equivalent_frac": round(eq / PEAK_HBM_GBS, 3),
+                                              "note": "materialised-op bytes of one step / time the step spends in ball query (group is fused into the MFMA kernels)"}
     if world == 1 and not args.no_cpu_baseline and args.category == "bottle":
         out["cpu_baseline"] = cpu_baseline(cfg, sd, args.cpu_budget)
         out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
