@@ -87,6 +87,9 @@ def lib():
         l.captra_prof_read.restype = _INT
         l.captra_prof_names.argtypes = [C.c_char_p, _INT]
         l.captra_prof_names.restype = _INT
+        if hasattr(l, "captra_pointwise_mlp_gn_tiles"):
+            l.captra_pointwise_mlp_gn_tiles.argtypes = [_INT, _INT, _LL]
+            l.captra_pointwise_mlp_gn_tiles.restype = _INT
         _lib = l
     return _lib
 

@@ -655,6 +655,22 @@ extern "C" int captra_pointwise_mlp_gn(int b, int cin, int cout, long long l, co
     p.cin = cin; p.cout = cout; p.ldw = (cout + 127) / 128 * 128; p.L = l; p.x = x; p.wt = wt_packed; p.bias = bias_packed;
     p.y = y; p.act = act; p.ab_in = ab_in; p.stats_out = stats_out; p.stats_t = stats_t;
     hipStream_t s = (hipStream_t)stream;
+    const long long waves22 = ((l + 63) / 64) * ((cout + 63) / 64) * b;
+    if (cout > 64 && waves22 < 2048) {
+        // few positions (single-trajectory latency): 32x32 wave tiles, statistics per 32-column tile
+        if (stats_out != nullptr && stats_t != (int)((l + 63) / 64) * 2) return -1;
+        dim3 grid((unsigned)((l + 63) / 64), (cout + 63) / 64, b);
+        if (ab_in != nullptr && stats_out != nullptr) {
+            CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<1, 1, 2, 2, true, true>), grid, dim3(256), 0, s, p);
+        } else if (stats_out != nullptr) {
+            CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<1, 1, 2, 2, false, true>), grid, dim3(256), 0, s, p);
+        } else if (ab_in != nullptr) {
+            CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<1, 1, 2, 2, true, false>), grid, dim3(256), 0, s, p);
+        } else {
+            CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<1, 1, 2, 2>), grid, dim3(256), 0, s, p);
+        }
+        return captra_last_error();
+    }
     if (cout > 64) {
         if (stats_out != nullptr && stats_t != (int)((l + 127) / 128) * 2) return -1;
         dim3 grid((unsigned)((l + 127) / 128), (cout + 127) / 128, b);
@@ -683,6 +699,11 @@ extern "C" int captra_pointwise_mlp_gn(int b, int cin, int cout, long long l, co
         CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<1, 2, 1, 4>), grid, dim3(256), 0, s, p);
     }
     return captra_last_error();
+}
+
+extern "C" int captra_pointwise_mlp_gn_tiles(int b, int cout, long long l) {
+    const long long waves22 = ((l + 63) / 64) * ((cout + 63) / 64) * b;
+    return (cout > 64 && waves22 < 2048) ? (int)((l + 63) / 64) * 2 : (int)((l + 127) / 128) * 2;
 }
 
 extern "C" int captra_gn_finalize(int b, int c, int channels_per_group, int stats_t, long long n, float eps,

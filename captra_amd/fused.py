@@ -215,7 +215,7 @@ def pointwise_mlp_gn(x, lin: PackedLinear, ab_in=None, act: int = ACT_NONE, want
     assert lin.cin == cin and x.is_contiguous()
     l = x.numel() // max(B * cin, 1)
     y = torch.empty((B, lin.cout) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
-    t = 2 * ((l + 127) // 128)
+    t = L.lib().captra_pointwise_mlp_gn_tiles(B, lin.cout, l)      # 64- or 32-position statistics tiles, by launch shape
     stats = torch.empty(B, lin.cout, t, 2, dtype=torch.float32, device=x.device) if want_stats else None
     with torch.cuda.device(x.device):
         L.call("captra_pointwise_mlp_gn", B, cin, lin.cout, l, L.ptr(x), L.ptr(lin.wt), L.ptr(lin.bias), L.ptr(ab_in), act,

@@ -157,13 +157,15 @@ int captra_sa_scale_fused(int b, int n, int m, int k, int cfeat, int c1, int c2,
  *   ab_in     (B,cin,2) or NULL: the input tensor is the previous layer's RAW output; every element is read as
  *             relu(a*x + b) with that layer's per-(cloud, channel) GroupNorm coefficients;
  *   stats_out (B,cout,stats_t,2) or NULL: per output channel and 64-position tile, (sum, sum of squares) of this layer's
- *             raw output (act must be CAPTRA_ACT_NONE), stats_t = 2*ceil(l/128); needs cout > 64 (-2 otherwise).
+ *             raw output (act must be CAPTRA_ACT_NONE); needs cout > 64 (-2 otherwise); stats_t = 2*ceil(l/128), or
+ *             2*ceil(l/64) (32-position tiles) when ceil(l/64)*ceil(cout/64)*b < 2048 -- captra_pointwise_mlp_gn_tiles().
  * captra_gn_finalize reduces the partials (fixed order, double precision) to ab (B,c,2): a = gamma*rstd, b = beta - mean*a,
  * mean / biased variance over the group's channels_per_group channels x n positions (torch.nn.GroupNorm semantics).
  * Same convolution bits as captra_pointwise_mlp; the normalisation differs from a two-pass GroupNorm by rounding only. */
 int captra_pointwise_mlp_gn(int b, int cin, int cout, long long l, const float *x, const float *wt_packed,
                             const float *bias_packed, const float *ab_in, int act, float *y, float *stats_out,
                             int stats_t, captra_stream_t stream);
+int captra_pointwise_mlp_gn_tiles(int b, int cout, long long l);   /* the stats_t captra_pointwise_mlp_gn expects for this shape */
 int captra_gn_finalize(int b, int c, int channels_per_group, int stats_t, long long n, float eps, const float *stats,
                        const float *gamma, const float *beta, float *ab, captra_stream_t stream);
 
