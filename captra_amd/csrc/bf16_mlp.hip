@@ -328,7 +328,11 @@ extern "C" int captra_pointwise_mlp_bf16(int b, int cin, int cout, long long l, 
     p.cin = cin; p.cout = cout; p.kb = (cin + 31) / 32 * 32; p.L = l; p.x = x; p.wb = wb; p.bias = bias_packed; p.y = y; p.act = act;
     hipStream_t s = (hipStream_t)stream;
     const long long waves22 = ((l + 63) / 64) * ((cout + 63) / 64) * b;
-    if (cout > 64 && waves22 >= 2048) {
+    if (cout >= 256 && cin >= 256 && waves22 >= 8192) {
+        // wide layers: 128 x 64 wave tiles -- every converted B operand feeds four MFMAs, halving the loads per MFMA
+        dim3 grid((unsigned)((l + 255) / 256), (cout + 127) / 128, b);
+        CAPTRA_LAUNCH("pointwise_mlp", (pw_bf16_kernel<4, 2, 1, 4>), grid, dim3(256), 0, s, p);
+    } else if (cout > 64 && waves22 >= 2048) {
         dim3 grid((unsigned)((l + 127) / 128), (cout + 127) / 128, b);
         CAPTRA_LAUNCH("pointwise_mlp", (pw_bf16_kernel<2, 2, 2, 2>), grid, dim3(256), 0, s, p);
     } else if (cout > 32) {

@@ -20,8 +20,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--mlp-dtype", default="fp32", choices=["fp32", "bf16"])
     a = ap.parse_args()
     dev = torch.device("cuda:0")
+    fused.MLP_DTYPE = a.mlp_dtype
     cfg, sd, model, _ = bench.build_workload(a.batch, dev)
     pose = {k: v.clone() for k, v in model.feed_dict[0]["gt_part"].items()}
     records = OrderedDict()
