@@ -3,9 +3,10 @@
 // Replaces ball_query_kernel_fast (reference ball_query_gpu.cu:9-45), which runs one THREAD per
 // centre streaming the whole cloud from global memory with a 12-byte stride and a divergent
 // early exit.  Here:
-//   * the cloud is staged once per workgroup into LDS as SoA (x[], y[], z[]) with coalesced
-//     global reads, and reused by CENTRES_PER_BLOCK centres;
-//   * one WAVE owns a centre: 64 consecutive points are tested per step, the hit mask comes
+//   * the cloud is staged once per workgroup into LDS as three coordinate planes and reused by
+//     BQ_WAVES * BQ_CPW centres; four 64-point chunks are interleaved per lane so that one
+//     ds_read_b128 per plane feeds 256 distance tests, computed with packed fp32 instructions;
+//   * one WAVE owns a centre: chunks of 64 consecutive points are tested in order, the hit mask comes
 //     from the compare itself (wave64 ballot), the output slot of each hit is
 //     cnt + popcount(mask below my lane) — an ordered compaction that reproduces the
 //     reference's "first nsample hits in index order" bit for bit — and the early exit is
@@ -28,13 +29,21 @@ struct BqParams {
     int *idx[BQ_MAXR];
 };
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__host__ __device__ constexpr int bq_pad(int v) { return (v + 255) & ~255; }
+
 template <int NR>
 __global__ __launch_bounds__(BQ_WAVES * 64) void ball_query_kernel(int n, int m,
                                                                    const float *__restrict__ new_xyz_all,
                                                                    const float *__restrict__ xyz_all,
                                                                    BqParams prm) {
+    // three planes (x, y, z); inside a plane the 64-point chunks are interleaved four by four:
+    // element ((chunk / 4) * 64 + lane) * 4 + chunk % 4, so a lane fetches its coordinate of four
+    // consecutive chunks with ONE ds_read_b128 and the distances of 256 points cost 16 packed-fp32
+    // instructions per wave.  Slots past the end of the cloud hold +inf and never hit.
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tile_cap = n < BQ_TILE ? n : BQ_TILE;
+    const int tile_cap = bq_pad(n < BQ_TILE ? n : BQ_TILE);
     float *xs = lds;
     float *ys = xs + tile_cap;
     float *zs = ys + tile_cap;
@@ -60,13 +69,17 @@ __global__ __launch_bounds__(BQ_WAVES * 64) void ball_query_kernel(int n, int m,
 
     for (int t0 = 0; t0 < n; t0 += BQ_TILE) {
         const int tn = (n - t0) < BQ_TILE ? (n - t0) : BQ_TILE;
+        const int tn_pad = bq_pad(tn);
         if (t0 > 0) __syncthreads();
-        // coalesced AoS read -> SoA LDS
-        for (int e = tid; e < tn * 3; e += BQ_WAVES * 64) {
-            float v = xyz[(size_t)t0 * 3 + e];
-            int p = e / 3, comp = e - p * 3;
-            float *dst = comp == 0 ? xs : (comp == 1 ? ys : zs);
-            dst[p] = v;
+        for (int p = tid; p < tn_pad; p += BQ_WAVES * 64) {
+            const bool inb = p < tn;
+            const float *q = xyz + (size_t)(t0 + (inb ? p : 0)) * 3;
+            const float inf = __builtin_inff();
+            const int chunk = p >> 6;
+            const int a = (((chunk >> 2) << 6) + (p & 63)) * 4 + (chunk & 3);
+            xs[a] = inb ? q[0] : inf;
+            ys[a] = inb ? q[1] : inf;
+            zs[a] = inb ? q[2] : inf;
         }
         __syncthreads();
 
@@ -81,28 +94,34 @@ __global__ __launch_bounds__(BQ_WAVES * 64) void ball_query_kernel(int n, int m,
             const float cx = new_xyz[(size_t)c * 3 + 0];
             const float cy = new_xyz[(size_t)c * 3 + 1];
             const float cz = new_xyz[(size_t)c * 3 + 2];
-            for (int k0 = 0; k0 < tn; k0 += 64) {
-                const int kl = k0 + lane;
-                const bool inb = kl < tn;
-                const int ks = inb ? kl : 0;
-                const float d2 = dist2_unfused(cx, cy, cz, xs[ks], ys[ks], zs[ks]);
-                bool any_open = false;
+            const f32x4 cx4 = {cx, cx, cx, cx}, cy4 = {cy, cy, cy, cy}, cz4 = {cz, cz, cz, cz};
+            for (int g = 0; g < (tn_pad >> 8) && open; ++g) {
+                const f32x4 dx = cx4 - reinterpret_cast<const f32x4 *>(xs)[g * 64 + lane];
+                const f32x4 dy = cy4 - reinterpret_cast<const f32x4 *>(ys)[g * 64 + lane];
+                const f32x4 dz = cz4 - reinterpret_cast<const f32x4 *>(zs)[g * 64 + lane];
+                const f32x4 d2 = (dx * dx + dy * dy) + dz * dz;  // unfused: the build runs with -ffp-contract=off
 #pragma unroll
-                for (int r = 0; r < NR; ++r) {
-                    if (cnt[ci][r] < prm.ns[r]) {
-                        const bool hit = inb && (d2 < prm.r2[r]);
-                        const unsigned long long mask = __ballot(hit);
-                        if (mask) {
-                            const int pos = cnt[ci][r] + __popcll(mask & lt_mask);
-                            if (cnt[ci][r] == 0) first[ci][r] = t0 + k0 + (__ffsll((long long)mask) - 1);
-                            if (hit && pos < prm.ns[r])
-                                prm.idx[r][((size_t)b * m + c) * prm.ns[r] + pos] = t0 + kl;
-                            cnt[ci][r] += __popcll(mask);
+                for (int h = 0; h < 4; ++h) {
+                    if (!open) break;
+                    const int k0 = t0 + g * 256 + h * 64;
+                    bool any_open = false;
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) {
+                        if (cnt[ci][r] < prm.ns[r]) {
+                            const bool hit = d2[h] < prm.r2[r];
+                            const unsigned long long mask = __ballot(hit);
+                            if (mask) {
+                                const int pos = cnt[ci][r] + __popcll(mask & lt_mask);
+                                if (cnt[ci][r] == 0) first[ci][r] = k0 + (__ffsll((long long)mask) - 1);
+                                if (hit && pos < prm.ns[r])
+                                    prm.idx[r][((size_t)b * m + c) * prm.ns[r] + pos] = k0 + lane;
+                                cnt[ci][r] += __popcll(mask);
+                            }
+                            any_open = any_open || (cnt[ci][r] < prm.ns[r]);
                         }
-                        any_open = any_open || (cnt[ci][r] < prm.ns[r]);
                     }
+                    open = any_open;
                 }
-                if (!any_open) break;
             }
         }
     }
@@ -138,8 +157,8 @@ int launch_ball_query(int b, int n, int m, int nr, const float *radius, const in
         prm.ns[r] = nsample[r];
         prm.idx[r] = idx[r];
     }
-    const int tile_cap = n < BQ_TILE ? n : BQ_TILE;
-    size_t shmem = (size_t)(tile_cap > 0 ? tile_cap : 1) * 3 * sizeof(float);
+    const int tile_cap = bq_pad(n < BQ_TILE ? n : BQ_TILE);
+    size_t shmem = (size_t)(tile_cap > 0 ? tile_cap : 256) * 3 * sizeof(float);
     dim3 grid((m + BQ_WAVES * BQ_CPW - 1) / (BQ_WAVES * BQ_CPW), b);
     dim3 block(BQ_WAVES * 64);
 #define BQ_LAUNCH(NR)                                                                            \
