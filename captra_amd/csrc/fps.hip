@@ -178,20 +178,23 @@ __device__ __forceinline__ unsigned wave_max_u32_fold(unsigned v) {
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 template <int NWAVES, int PPT, bool XYZ_LDS>
-__global__ __launch_bounds__(NWAVES * 64) void fps_kernel_blocked(int n, int m, const float *__restrict__ xyz_all,
+__global__ __launch_bounds__(NWAVES * 64) void fps_kernel_blocked(int n_stride, int m, const float *__restrict__ xyz_all,
                                                                   float *__restrict__ temp_all, int *__restrict__ idx_all,
-                                                                  float *__restrict__ new_n3, float *__restrict__ new_cn) {
+                                                                  float *__restrict__ new_n3, float *__restrict__ new_cn,
+                                                                  const int *__restrict__ n_per_cloud) {
     static_assert(PPT % 2 == 0, "two points per packed instruction");
     constexpr int H = PPT / 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint2 *slots = reinterpret_cast<uint2 *>(smem_raw);                  // [2][16] ping-pong
     float4 *slotc = reinterpret_cast<float4 *>(smem_raw + 2 * 16 * sizeof(uint2));  // !XYZ_LDS: the candidates' coordinates
     float *xs = reinterpret_cast<float *>(smem_raw + 2 * 16 * sizeof(uint2) + (XYZ_LDS ? 0 : 2 * 16 * sizeof(float4)));
-    float *ys = xs + n;
-    float *zs = ys + n;
+    float *ys = xs + n_stride;
+    float *zs = ys + n_stride;
     const int b = blockIdx.x;
-    const float *xyz = xyz_all + (size_t)b * n * 3;
-    float *temp = temp_all != nullptr ? temp_all + (size_t)b * n : nullptr;  // null: start from 1e10, nothing written back
+    // ragged batches: clouds padded to n_stride points, cloud b has n_per_cloud[b] of them (slots beyond n never win)
+    const int n = n_per_cloud != nullptr ? n_per_cloud[b] : n_stride;
+    const float *xyz = xyz_all + (size_t)b * n_stride * 3;
+    float *temp = temp_all != nullptr ? temp_all + (size_t)b * n_stride : nullptr;  // null: start from 1e10, nothing written back
     int *idx = idx_all + (size_t)b * m;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -346,7 +349,7 @@ static int g_fps_variant = 0;  // 0 = blocked / ballot / packed-math kernel wher
 
 template <int NWAVES, int PPT>
 int launch_fps(int b, int n, int m, const float *xyz, float *temp, int *idx, hipStream_t s, float *new_n3 = nullptr,
-               float *new_cn = nullptr, bool need_blocked = false) {
+               float *new_cn = nullptr, bool need_blocked = false, const int *ns = nullptr) {
     size_t slots = 2 * 16 * sizeof(uint2);
     size_t lds_xyz = (size_t)n * 3 * sizeof(float);
     if constexpr (PPT % 2 == 0) {
@@ -357,16 +360,16 @@ int launch_fps(int b, int n, int m, const float *xyz, float *temp, int *idx, hip
                 hipFuncSetAttribute(reinterpret_cast<const void *>(kern2), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
                 attr2_set = true;
             }
-            CAPTRA_LAUNCH("fps", kern2, dim3(b), dim3(NWAVES * 64), slots + lds_xyz, s, n, m, xyz, temp, idx, new_n3, new_cn);
+            CAPTRA_LAUNCH("fps", kern2, dim3(b), dim3(NWAVES * 64), slots + lds_xyz, s, n, m, xyz, temp, idx, new_n3, new_cn, ns);
             return captra_last_error();
         }
         if (g_fps_variant == 0) {  // cloud larger than the LDS mirror: same kernel, winner coordinates from global memory
             CAPTRA_LAUNCH("fps", (fps_kernel_blocked<NWAVES, PPT, false>), dim3(b), dim3(NWAVES * 64),
-                          slots + 2 * 16 * sizeof(float4), s, n, m, xyz, temp, idx, new_n3, new_cn);
+                          slots + 2 * 16 * sizeof(float4), s, n, m, xyz, temp, idx, new_n3, new_cn, ns);
             return captra_last_error();
         }
     }
-    if (need_blocked) return -2;  // the fused sample + gather entry exists on the blocked kernel only
+    if (need_blocked || ns != nullptr) return -2;  // the fused sample + gather entry exists on the blocked kernel only
     if (slots + lds_xyz <= 150 * 1024) {
         auto kern = fps_kernel<NWAVES, PPT, true>;
         static bool attr_set = false;
@@ -385,6 +388,12 @@ int launch_fps(int b, int n, int m, const float *xyz, float *temp, int *idx, hip
 
 }  // namespace
 
+// fps_pruned.hip: exact spatially-pruned kernel for 8k-20k point clouds (-2 beyond its capacity)
+int captra_fps_pruned_launch(int b, int n_stride, const int *n_per_cloud, int m, const float *xyz, float *temp, int *idx,
+                             float *new_n3, float *new_cn, hipStream_t s);
+static int g_fps_pruned_min = 8192;   // clouds of at least this many points take the pruned kernel (0 = never)
+extern "C" void captra_fps_set_pruned_min(int n) { g_fps_pruned_min = n; }
+
 // Tunable from the host for experiments: waves per cloud for the register-resident kernel
 // (0 = heuristic).  Not part of the stable ABI.
 static int g_fps_waves = 0;
@@ -397,6 +406,10 @@ extern "C" int captra_furthest_point_sampling(int b, int n, int m, const float *
     if (b == 0 || m == 0) return 0;
     if (n == 0) return -1;
     hipStream_t s = (hipStream_t)stream;
+    if (g_fps_variant == 0 && g_fps_waves == 0 && g_fps_pruned_min > 0 && n >= g_fps_pruned_min && m > 1) {
+        const int rc = captra_fps_pruned_launch(b, n, nullptr, m, xyz, temp, idx, nullptr, nullptr, s);
+        if (rc != -2) return rc;
+    }
     int waves = g_fps_waves;
     if (waves == 0) {
         // heuristic: ~8 points per lane (blocked kernel) / ~4 (first generation), at most 16 waves
@@ -420,20 +433,34 @@ extern "C" int captra_furthest_point_sampling(int b, int n, int m, const float *
 
 // FPS + gather of the sampled coordinates in one launch (see include/captra_hip.h).  -2 when the cloud does not fit the
 // register-resident kernel (use captra_furthest_point_sampling + captra_gather_points then).
-extern "C" int captra_fps_gather(int b, int n, int m, const float *xyz, int *idx, float *new_xyz_n3, float *new_xyz_cn,
-                                 captra_stream_t stream) {
+static int fps_gather_dispatch(int b, int n, const int *ns, int m, const float *xyz, int *idx, float *new_xyz_n3,
+                               float *new_xyz_cn, hipStream_t s) {
     if (b < 0 || n < 1 || m < 1) return -1;
     if (b == 0) return 0;
     if (g_fps_variant != 0) return -2;
-    hipStream_t s = (hipStream_t)stream;
+    if (g_fps_pruned_min > 0 && n >= g_fps_pruned_min && m > 1) {
+        const int rc = captra_fps_pruned_launch(b, n, ns, m, xyz, nullptr, idx, new_xyz_n3, new_xyz_cn, s);
+        if (rc != -2) return rc;
+    }
     int waves = 1;
     while (waves < 16 && waves * 64 * 8 < n) waves *= 2;
     const int ppt = (n + waves * 64 - 1) / (waves * 64);
 #define FPSG_CASE(W, P) \
-    if (waves == W && ppt <= P) return launch_fps<W, P>(b, n, m, xyz, nullptr, idx, s, new_xyz_n3, new_xyz_cn, true);
+    if (waves == W && ppt <= P) return launch_fps<W, P>(b, n, m, xyz, nullptr, idx, s, new_xyz_n3, new_xyz_cn, true, ns);
     FPSG_CASE(1, 2) FPSG_CASE(1, 4) FPSG_CASE(1, 8)
     FPSG_CASE(2, 8) FPSG_CASE(4, 8) FPSG_CASE(8, 8) FPSG_CASE(16, 8) FPSG_CASE(16, 12) FPSG_CASE(16, 16) FPSG_CASE(16, 20)
     FPSG_CASE(16, 24) FPSG_CASE(16, 32)
 #undef FPSG_CASE
     return -2;
+}
+
+extern "C" int captra_fps_gather(int b, int n, int m, const float *xyz, int *idx, float *new_xyz_n3, float *new_xyz_cn,
+                                 captra_stream_t stream) {
+    return fps_gather_dispatch(b, n, nullptr, m, xyz, idx, new_xyz_n3, new_xyz_cn, (hipStream_t)stream);
+}
+
+// Ragged batch: clouds padded to n_stride points each, cloud i samples from its first n_per_cloud[i] (device array).
+extern "C" int captra_fps_gather_ragged(int b, int n_stride, const int *n_per_cloud, int m, const float *xyz, int *idx,
+                                        float *new_xyz_n3, float *new_xyz_cn, captra_stream_t stream) {
+    return fps_gather_dispatch(b, n_stride, n_per_cloud, m, xyz, idx, new_xyz_n3, new_xyz_cn, (hipStream_t)stream);
 }

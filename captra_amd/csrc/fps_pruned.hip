@@ -1,0 +1,349 @@
+// Furthest point sampling of LARGE clouds (8k - 20k points) with exact spatial pruning, for gfx950.
+//
+// The register-resident kernel of fps.hip updates every running minimum in every round: at 16384 -
+// 20480 points (the on-the-fly re-crop of real NOCS tracking samples 4096 of up to 20480 candidates,
+// reference data_utils.py:138-157; BASELINE.json configs[4] samples 2048 of 16384) that is ~1.5 us of
+// pure VALU work per round on the one CU a cloud can use.  But a new sample s can only lower the
+// running minimum of points closer to it than their current minimum, i.e. (after the first few
+// rounds) of a small neighbourhood.  This kernel
+//   1. sorts the cloud by a 12-bit Morton cell (one LDS counting sort, in the workgroup),
+//   2. cuts the sorted sequence into BUCKETS of 64 consecutive points — one point per lane, bucket k
+//      owned by wave k % NW (interleaved, so that the buckets a sample touches spread over the waves)
+//      — and keeps per bucket its bounding box, the largest running minimum `bmax`, the sorted
+//      position of the point holding it and that point's coordinates (lane i of a few VGPRs = bucket i
+//      of the wave),
+//   3. per round tests all buckets of a wave at once: lb = squared distance from s to the bucket's box,
+//      computed with the SAME unfused fp32 operations and association as the point distances, so by
+//      monotonicity of rounding lb <= d(s, p) for every point p of the bucket; lb >= bmax  =>  no
+//      running minimum of the bucket changes and the bucket is skipped.  The buckets that fail the test
+//      are updated one by one (uniform branch into the slot's registers).
+// The selection is then a reduction over bucket maxima.  Picks are IDENTICAL to the plain kernel's:
+// same arithmetic for every distance that can matter, and "lowest original index among equal maxima"
+// is resolved exactly (the original index of a sorted position is kept in LDS and consulted whenever
+// a maximum is attained more than once — always the case in duplicate-padded clouds).
+#include "common.h"
+#include <type_traits>
+
+namespace {
+
+constexpr int FP_NW = 8;            // waves per workgroup: 2 per SIMD, 256 VGPRs each (4 per point + bucket metadata)
+constexpr int FP_T = FP_NW * 64;
+constexpr int FP_BINS = 4096;       // 16 x 16 x 16 Morton cells
+constexpr int FP_BPT = FP_BINS / FP_T;
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned fp_dpp_max(unsigned v) {   // 0 is the identity: invalid sources contribute 0
+    const unsigned o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, true);
+    return max(v, o);
+}
+__device__ __forceinline__ unsigned fp_row_max(unsigned v) {
+    v = fp_dpp_max<0xB1, 0xF>(v);
+    v = fp_dpp_max<0x4E, 0xF>(v);
+    v = fp_dpp_max<0x141, 0xF>(v);
+    v = fp_dpp_max<0x140, 0xF>(v);
+    return v;
+}
+__device__ __forceinline__ unsigned fp_wave_max(unsigned v) {
+    v = fp_row_max(v);
+    v = fp_dpp_max<0x142, 0xA>(v);
+    v = fp_dpp_max<0x143, 0xC>(v);
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ unsigned fp_wave_min(unsigned v) { return ~fp_wave_max(~v); }
+__device__ __forceinline__ float fp_wave_minf(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ float fp_wave_maxf(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ float fp_readlane(float v, int l) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+__device__ __forceinline__ unsigned fp_spread4(unsigned v) {   // 4 bits -> every third bit
+    return (v & 1u) | ((v & 2u) << 2) | ((v & 4u) << 4) | ((v & 8u) << 6);
+}
+
+// A floats per lane held in REGISTERS yet indexed at run time by a wave-uniform slot number: an ext-vector value, which
+// the backend addresses through the GPR index mode (s_set_gpr_idx_on + v_mov) instead of spilling an alloca.  (Legal
+// widths are 8 / 16 / 32; 8-wide vectors are expanded into a compare / select chain instead — measured 0.3 us slower
+// per round — so slots beyond 32 live in LDS, see below.)
+template <int A>
+struct RegVec {
+    typedef float VA __attribute__((ext_vector_type(A)));
+    VA a;
+    __device__ __forceinline__ float get(int s) const { return a[s]; }
+    __device__ __forceinline__ void set(int s, float v) { a[s] = v; }
+};
+
+// SLOTS = A + B buckets per wave: the first A in registers, B more in LDS (x, y, z and the running minimum of a bucket
+// as four rows of 64 floats); capacity = FP_NW * SLOTS * 64 points.
+template <int A, int B>
+__global__ __launch_bounds__(FP_T) void fps_pruned_kernel(int n_stride, const int *__restrict__ n_per_cloud, int m,
+                                                          const float *__restrict__ xyz_all, float *__restrict__ temp_all,
+                                                          int *__restrict__ idx_all, float *__restrict__ new_n3,
+                                                          float *__restrict__ new_cn, unsigned long long *stats) {
+    constexpr int SLOTS = A + B;
+    constexpr int CAP = FP_NW * SLOTS * 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    static_assert(SLOTS <= 64, "one metadata lane per bucket");
+    uint2 *slots = reinterpret_cast<uint2 *>(smem_raw);                                   // [2][16] (bmax, sorted pos)
+    float4 *slotc = reinterpret_cast<float4 *>(smem_raw + 2 * 16 * sizeof(uint2));       // [2][16] the candidates' coordinates
+    float *red = reinterpret_cast<float *>(smem_raw + 2 * 16 * (sizeof(uint2) + sizeof(float4)));   // [6][16] bbox partials
+    unsigned short *oidx = reinterpret_cast<unsigned short *>(red + 6 * 16);             // [CAP] original index of a sorted position (< 65535)
+    unsigned char *scratch = reinterpret_cast<unsigned char *>(oidx + CAP);
+    unsigned *hist = reinterpret_cast<unsigned *>(scratch);                               // [FP_BINS] (sort phase)
+    unsigned *wsum = hist + FP_BINS;                                                      // [16]
+    float *ovf = reinterpret_cast<float *>(scratch);                                      // [NW][B][4][64] (after the sort; reuses hist)
+
+    const int b = blockIdx.x;
+    const int n = n_per_cloud != nullptr ? n_per_cloud[b] : n_stride;
+    if (n < 1 || n > n_stride) return;   // workgroup-uniform: nothing to sample from
+    const float *xyz = xyz_all + (size_t)b * n_stride * 3;
+    float *temp = temp_all != nullptr ? temp_all + (size_t)b * n_stride : nullptr;
+    int *idx = idx_all + (size_t)b * m;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    auto emit = [&](int j, float x, float y, float z) {
+        if (new_n3 != nullptr) {
+            float *d = new_n3 + ((size_t)b * m + j) * 3;
+            d[0] = x; d[1] = y; d[2] = z;
+        }
+        if (new_cn != nullptr) {
+            float *d = new_cn + (size_t)b * 3 * m + j;
+            d[0] = x; d[m] = y; d[2 * (size_t)m] = z;
+        }
+    };
+
+    // ---- 1. bounding box of the cloud
+    float lx = __builtin_inff(), ly = lx, lz = lx, hx = -lx, hy = -lx, hz = -lx;
+    for (int k = tid; k < n; k += FP_T) {
+        const float x = xyz[(size_t)k * 3 + 0], y = xyz[(size_t)k * 3 + 1], z = xyz[(size_t)k * 3 + 2];
+        lx = fminf(lx, x); ly = fminf(ly, y); lz = fminf(lz, z);
+        hx = fmaxf(hx, x); hy = fmaxf(hy, y); hz = fmaxf(hz, z);
+    }
+    lx = fp_wave_minf(lx); ly = fp_wave_minf(ly); lz = fp_wave_minf(lz);
+    hx = fp_wave_maxf(hx); hy = fp_wave_maxf(hy); hz = fp_wave_maxf(hz);
+    if (lane == 0) {
+        red[0 * 16 + wave] = lx; red[1 * 16 + wave] = ly; red[2 * 16 + wave] = lz;
+        red[3 * 16 + wave] = hx; red[4 * 16 + wave] = hy; red[5 * 16 + wave] = hz;
+    }
+    for (int e = tid; e < FP_BINS; e += FP_T) hist[e] = 0u;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < FP_NW; ++w) {
+        lx = fminf(lx, red[0 * 16 + w]); ly = fminf(ly, red[1 * 16 + w]); lz = fminf(lz, red[2 * 16 + w]);
+        hx = fmaxf(hx, red[3 * 16 + w]); hy = fmaxf(hy, red[4 * 16 + w]); hz = fmaxf(hz, red[5 * 16 + w]);
+    }
+    const float sx = 16.f / fmaxf(hx - lx, 1e-30f), sy = 16.f / fmaxf(hy - ly, 1e-30f), sz = 16.f / fmaxf(hz - lz, 1e-30f);
+
+    // ---- 2. counting sort by Morton cell: dst[i] = sorted position of this thread's i-th point
+    unsigned dst[SLOTS];
+#pragma unroll
+    for (int i = 0; i < SLOTS; ++i) {
+        const int k = tid + i * FP_T;
+        dst[i] = 0xFFFFFFFFu;
+        if (k < n) {
+            const float x = xyz[(size_t)k * 3 + 0], y = xyz[(size_t)k * 3 + 1], z = xyz[(size_t)k * 3 + 2];
+            const int cx = min(15, max(0, (int)((x - lx) * sx))), cy = min(15, max(0, (int)((y - ly) * sy))),
+                      cz = min(15, max(0, (int)((z - lz) * sz)));
+            const unsigned key = fp_spread4((unsigned)cx) | (fp_spread4((unsigned)cy) << 1) | (fp_spread4((unsigned)cz) << 2);
+            const unsigned rank = atomicAdd(&hist[key], 1u);
+            dst[i] = (key << 20) | rank;           // rank < 2^20
+        }
+    }
+    __syncthreads();
+    {   // exclusive scan of the 4096 bins: FP_BPT bins per thread, wave scan, wave totals through LDS
+        unsigned c[FP_BPT], tsum = 0u;
+#pragma unroll
+        for (int e = 0; e < FP_BPT; ++e) { c[e] = hist[tid * FP_BPT + e]; tsum += c[e]; }
+        unsigned incl = tsum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        unsigned run = incl - tsum;
+#pragma unroll
+        for (int w = 0; w < FP_NW; ++w) run += (w < wave) ? wsum[w] : 0u;
+#pragma unroll
+        for (int e = 0; e < FP_BPT; ++e) { hist[tid * FP_BPT + e] = run; run += c[e]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < SLOTS; ++i) {
+        const int k = tid + i * FP_T;
+        if (k < n) {
+            dst[i] = hist[dst[i] >> 20] + (dst[i] & 0xFFFFFu);
+            oidx[dst[i]] = (unsigned short)k;
+        }
+    }
+    for (int q = n + tid; q < CAP; q += FP_T) oidx[q] = 0xFFFFu;   // sentinels: never preferred
+    __syncthreads();   // hist is dead from here on: its memory holds the LDS-resident slots
+
+    // ---- 3. ownership: sorted position q -> wave (q / 64) % NW, slot (q / 64) / NW, lane q % 64.  Each lane fetches
+    // its points through the permutation (a one-time 12-byte gather per point, served by L2).
+    RegVec<A> px, py, pz, dmin;   // dmin: running minimum as a float (>= 0: value order == bit order)
+    float *ovf_w = ovf + (size_t)wave * B * 256 + lane;
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+        const int q = ((s * FP_NW + wave) << 6) + lane;
+        // slots past the end of the cloud: a copy of the last sorted point (so bounding boxes need no masking) whose
+        // distance is 0 forever and whose original index is the sentinel — never selected
+        const unsigned k = oidx[q < n ? q : n - 1];
+        const float x = xyz[(size_t)k * 3 + 0], y = xyz[(size_t)k * 3 + 1], z = xyz[(size_t)k * 3 + 2];
+        const float d0 = q < n ? (temp != nullptr ? temp[k] : 1e10f) : 0.f;
+        if (s < A) {
+            px.set(s, x); py.set(s, y); pz.set(s, z); dmin.set(s, d0);
+        } else {
+            float *o = ovf_w + (s - A) * 256;
+            o[0] = x; o[64] = y; o[128] = z; o[192] = d0;
+        }
+    }
+
+    // ---- 4. bucket metadata: lane i of these registers describes bucket (slot) i of this wave
+    float blx = __builtin_inff(), bly = blx, blz = blx, bhx = -blx, bhy = -blx, bhz = -blx;   // lanes >= SLOTS: empty box
+    unsigned bmax = 0u, bq = 0u;
+    float bwx = 0.f, bwy = 0.f, bwz = 0.f;
+    // Update bucket s (wave-uniform, run time) against the sample (sx, sy, sz): the lane's point of that bucket is read
+    // out of the register vectors by index, so ONE copy of this code serves every slot (an unrolled per-slot version
+    // is ~90 KB of instructions and lost more to instruction fetch than the pruning saved).
+    unsigned n_upd = 0, n_ref = 0;   // experiment counters (captra_fps_set_stats)
+    auto update = [&](int s, float sx_, float sy_, float sz_, bool first) __attribute__((always_inline)) {
+        ++n_upd;
+        float x, y, z, dm;
+        float *o = ovf_w + (s - A) * 256;
+        if (B == 0 || s < A) { x = px.get(s); y = py.get(s); z = pz.get(s); dm = dmin.get(s); }
+        else { x = o[0]; y = o[64]; z = o[128]; dm = o[192]; }
+        const float dx = x - sx_, dy = y - sy_, dz = z - sz_;
+        const unsigned d = __float_as_uint((dx * dx + dy * dy) + dz * dz);
+        const unsigned dold = __float_as_uint(dm);
+        const unsigned dnew = d < dold ? d : dold;
+        if (B == 0 || s < A) dmin.set(s, __uint_as_float(dnew));
+        else o[192] = __uint_as_float(dnew);
+        if (first) {   // the bucket's bounding box (once)
+            const float a0 = fp_wave_minf(x), a1 = fp_wave_minf(y), a2 = fp_wave_minf(z);
+            const float b0 = fp_wave_maxf(x), b1 = fp_wave_maxf(y), b2 = fp_wave_maxf(z);
+            if (lane == s) { blx = a0; bly = a1; blz = a2; bhx = b0; bhy = b1; bhz = b2; }
+        } else {
+            // the bucket's maximum (and who holds it) can only change if a point AT the maximum was lowered
+            const unsigned bm_old = (unsigned)__builtin_amdgcn_readlane((int)bmax, s);
+            if (__ballot(dnew != dold && dold == bm_old) == 0ull) return;
+        }
+        ++n_ref;
+        const unsigned bm = fp_wave_max(dnew);
+        const unsigned long long hit = __ballot(dnew == bm);
+        int wl = __ffsll((long long)hit) - 1;
+        const int q0 = (s * FP_NW + wave) << 6;
+        if (hit & (hit - 1)) {   // the maximum is attained more than once: lowest ORIGINAL index wins
+            const unsigned oi = (dnew == bm) ? (unsigned)oidx[q0 + lane] : 0xFFFFFFFFu;
+            const unsigned best = fp_wave_min(oi);
+            wl = __ffsll((long long)__ballot(oi == best)) - 1;
+        }
+        const float wx = fp_readlane(x, wl), wy = fp_readlane(y, wl), wz = fp_readlane(z, wl);
+        if (lane == s) { bmax = bm; bq = (unsigned)(q0 + wl); bwx = wx; bwy = wy; bwz = wz; }
+    };
+    // initial maxima: an "update" against a sample at infinity leaves every running minimum as it is
+    const int slots_used = (n + FP_T - 1) / FP_T;   // buckets beyond the cloud keep bmax = 0 and an empty box: never touched
+    for (int s = 0; s < slots_used; ++s) update(s, __builtin_inff(), __builtin_inff(), __builtin_inff(), true);
+
+    // ---- 5. the selection rounds
+    if (tid == 0) idx[0] = 0;
+    float ox = xyz[0], oy = xyz[1], oz = xyz[2];
+    for (int j = 1; j < m; ++j) {
+        if (tid == 0) emit(j - 1, ox, oy, oz);
+        // which buckets can change?  same operations as the point distance: fl(p - o), squares, (x + y) + z
+        {
+            const float ddx = fmaxf(fmaxf(blx - ox, ox - bhx), 0.f), ddy = fmaxf(fmaxf(bly - oy, oy - bhy), 0.f),
+                        ddz = fmaxf(fmaxf(blz - oz, oz - bhz), 0.f);
+            const float lb = (ddx * ddx + ddy * ddy) + ddz * ddz;
+            unsigned long long need = __ballot(lane < SLOTS && __float_as_uint(lb) < bmax);
+            while (need) {
+                const int s = __ffsll((long long)need) - 1;
+                need &= need - 1;
+                update(s, ox, oy, oz, false);
+            }
+        }
+        // the wave's candidate
+        const unsigned wm = fp_wave_max(bmax);
+        const unsigned long long hitb = __ballot(bmax == wm);
+        int li = __ffsll((long long)hitb) - 1;
+        if (hitb & (hitb - 1)) {
+            const unsigned oi = (bmax == wm) ? (unsigned)oidx[bq] : 0xFFFFFFFFu;
+            const unsigned best = fp_wave_min(oi);
+            li = __ffsll((long long)__ballot(oi == best)) - 1;
+        }
+        uint2 *slot = slots + (j & 1) * 16;
+        float4 *sc = slotc + (j & 1) * 16;
+        if (lane == li) {
+            slot[wave] = make_uint2(bmax, bq);
+            sc[wave] = make_float4(bwx, bwy, bwz, 0.f);
+        }
+        __syncthreads();
+        const uint2 kv = slot[lane & (FP_NW - 1)];
+        const float4 kc = sc[lane & (FP_NW - 1)];
+        const unsigned gmax = fp_row_max(kv.x);
+        const unsigned long long hit2 = __ballot(kv.x == gmax) & ((1ull << FP_NW) - 1);
+        int gl = __ffsll((long long)hit2) - 1;
+        if (hit2 & (hit2 - 1)) {
+            const unsigned oi = (lane < FP_NW && kv.x == gmax) ? (unsigned)oidx[kv.y] : 0xFFFFFFFFu;
+            const unsigned best = fp_wave_min(oi);
+            gl = __ffsll((long long)__ballot(oi == best)) - 1;
+        }
+        const unsigned sel = (unsigned)__builtin_amdgcn_readlane((int)kv.y, gl);
+        ox = fp_readlane(kc.x, gl); oy = fp_readlane(kc.y, gl); oz = fp_readlane(kc.z, gl);
+        if (tid == 0) idx[j] = (int)sel;   // sorted position for now: the LDS look-up of the original index would sit on wave 0's critical path
+    }
+    if (tid == 0) emit(m - 1, ox, oy, oz);
+    __syncthreads();   // (same-workgroup global writes of thread 0 are visible after the barrier)
+    for (int j = 1 + tid; j < m; j += FP_T) idx[j] = (int)oidx[idx[j]];
+    if (stats != nullptr && lane == 0) {   // per wave: bucket updates, maximum refreshes (both include the SLOTS initial ones)
+        atomicAdd(stats + 0, (unsigned long long)n_upd);
+        atomicAdd(stats + 1, (unsigned long long)n_ref);
+    }
+    if (temp != nullptr) {
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) {
+            const int q = ((s * FP_NW + wave) << 6) + lane;
+            if (q < n) temp[oidx[q]] = s < A ? dmin.get(s) : ovf_w[(s - A) * 256 + 192];
+        }
+    }
+}
+
+unsigned long long *g_fps_stats = nullptr;
+
+template <int A, int B>
+int launch_pruned(int b, int n_stride, const int *ns, int m, const float *xyz, float *temp, int *idx, float *new_n3,
+                  float *new_cn, hipStream_t s) {
+    constexpr int CAP = FP_NW * (A + B) * 64;
+    const size_t sort_bytes = (size_t)(FP_BINS + 16) * sizeof(unsigned), ovf_bytes = (size_t)FP_NW * B * 256 * sizeof(float);
+    const size_t shmem = 2 * 16 * (sizeof(uint2) + sizeof(float4)) + 6 * 16 * sizeof(float) + (size_t)CAP * 2 +
+                         (sort_bytes > ovf_bytes ? sort_bytes : ovf_bytes);
+    auto kern = fps_pruned_kernel<A, B>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        attr_set = true;
+    }
+    CAPTRA_LAUNCH("fps", kern, dim3(b), dim3(FP_T), shmem, s, n_stride, ns, m, xyz, temp, idx, new_n3, new_cn, g_fps_stats);
+    return captra_last_error();
+}
+
+}  // namespace
+
+// experiment hook: device pointer to two u64 counters (bucket updates, maximum refreshes) accumulated by every wave
+extern "C" void captra_fps_set_stats(unsigned long long *dev_counters) { g_fps_stats = dev_counters; }
+
+// Internal entry used by fps.hip's dispatchers: -2 when the cloud exceeds the kernel's capacity (20480 points).
+int captra_fps_pruned_launch(int b, int n_stride, const int *n_per_cloud, int m, const float *xyz, float *temp, int *idx,
+                             float *new_n3, float *new_cn, hipStream_t s) {
+    // 32 register slots whatever the cloud size up to 16384 points (unused slots are never touched), 8 more in LDS beyond
+    if (n_stride <= FP_NW * 64 * 32) return launch_pruned<32, 0>(b, n_stride, n_per_cloud, m, xyz, temp, idx, new_n3, new_cn, s);
+    if (n_stride <= FP_NW * 64 * 40) return launch_pruned<32, 8>(b, n_stride, n_per_cloud, m, xyz, temp, idx, new_n3, new_cn, s);
+    return -2;
+}

@@ -96,9 +96,10 @@ def pointwise_mlp(x, lin: PackedLinear, act: int = ACT_RELU, out=None):
     return out
 
 
-def fps_gather(xyz_n3, m: int):
+def fps_gather(xyz_n3, m: int, n_per_cloud=None):
     """xyz (B,N,3) -> (idx (B,m) int32, new_xyz (B,m,3), new_xyz (B,3,m)): sampling and the gather of the sampled
-    coordinates in one launch; None when the cloud is too large for that kernel (caller samples and gathers separately)."""
+    coordinates in one launch; None when the cloud is too large for that kernel (caller samples and gathers separately).
+    n_per_cloud (B,) int32 device tensor: ragged batch, cloud i samples from its first n_per_cloud[i] points."""
     L.require_device(xyz_n3)
     B, N, _ = xyz_n3.shape
     if N > 16 * 64 * 32:              # beyond 32 points per lane x 16 waves the cloud no longer fits the register file
@@ -107,7 +108,12 @@ def fps_gather(xyz_n3, m: int):
     n3 = torch.empty(B, m, 3, dtype=torch.float32, device=xyz_n3.device)
     cn = torch.empty(B, 3, m, dtype=torch.float32, device=xyz_n3.device)
     with torch.cuda.device(xyz_n3.device):
-        L.call("captra_fps_gather", B, N, m, L.ptr(xyz_n3), L.ptr(idx), L.ptr(n3), L.ptr(cn))
+        if n_per_cloud is None:
+            L.call("captra_fps_gather", B, N, m, L.ptr(xyz_n3), L.ptr(idx), L.ptr(n3), L.ptr(cn))
+        else:
+            assert n_per_cloud.dtype == torch.int32 and n_per_cloud.numel() == B and n_per_cloud.is_contiguous()
+            L.require_device(n_per_cloud)
+            L.call("captra_fps_gather_ragged", B, N, L.ptr(n_per_cloud), m, L.ptr(xyz_n3), L.ptr(idx), L.ptr(n3), L.ptr(cn))
     return idx, n3, cn
 
 

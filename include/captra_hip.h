@@ -193,6 +193,15 @@ int captra_sa_scale_bf16(int b, int n, int m, int k, int cfeat, int c1, int c2, 
 int captra_fps_gather(int b, int n, int m, const float *xyz, int *idx, float *new_xyz_n3, float *new_xyz_cn,
                       captra_stream_t stream);
 
+/* Ragged batch of the same operation: the clouds are padded to n_stride points each (xyz (B,n_stride,3)) and cloud i
+ * samples m of its FIRST n_per_cloud[i] points (device array of B ints, 1 <= n_per_cloud[i] <= n_stride; NULL = all
+ * n_stride).  This is the re-sampling step of the on-the-fly ball crop (reference datasets/data_utils.py:138-157:
+ * farthest_point_sample of up to 5 x num_points candidates, a different count per tracked instance), batched over the
+ * trajectories of a step.  Clouds of 8192-20480 points take the spatially pruned kernel (csrc/fps_pruned.hip), picks
+ * identical to captra_furthest_point_sampling. */
+int captra_fps_gather_ragged(int b, int n_stride, const int *n_per_cloud, int m, const float *xyz, int *idx,
+                             float *new_xyz_n3, float *new_xyz_cn, captra_stream_t stream);
+
 /* SA scale with a pre-transformed first layer.  Layer 1's k-ascending chain runs over the cfeat feature rows first and the
  * three relative-xyz rows last (pointnet_utils.py:234-240), and its first cfeat steps depend on the SOURCE point only:
  *   v1 (B,c1,N) = captra_pointwise_mlp(feat (B,cfeat,N), w1 rows 0..cfeat-1, b1, CAPTRA_ACT_NONE)      (once per source point)
@@ -286,6 +295,8 @@ int captra_prof_names(char *buf, int buflen);
 /* ---- 4. Experiment switches (process-wide, NOT part of the stable ABI; used by tests/ and tools/ to cross-check variants
  *         that compute the same bits).  Defaults (0 / 1 for captra_pw_set_direct) select the production kernels. ---- */
 void captra_fps_set_waves(int waves);       /* FPS: waves per cloud (0 = heuristic) */
+void captra_fps_set_pruned_min(int n);     /* FPS: clouds of >= n points take the pruned kernel (default 8192; 0 = never) */
+void captra_fps_set_stats(unsigned long long *dev_counters); /* pruned FPS: accumulate {bucket updates, refreshes} (NULL = off) */
 void captra_fps_set_variant(int v);         /* FPS: 0 = blocked ownership + ballot pick (default), 1 = first-generation kernel */
 void captra_sa_fused_set_mode(int mode);    /* SA scale: 0 = register-resident kernels where instantiated, 1 = generic LDS kernel
                                                for every shape, 2 = register-resident with streamed weights only */

@@ -102,6 +102,73 @@ def test_fps_gather_one_launch(device, n, m):
     assert fused.fps_gather(_dev(np.zeros((1, 40000, 3), np.float32), device), 4) is None   # too large: caller falls back
 
 
+def _surface_cloud(seed, n):
+    """Points on a noisy cylinder + clutter (the shape of a depth crop), float32."""
+    rng = np.random.default_rng(seed)
+    th, h = rng.random(n) * 2 * np.pi, rng.random(n) - 0.5
+    pts = np.stack([0.2 * np.cos(th), h, 0.2 * np.sin(th)], -1) + rng.normal(0, 0.004, (n, 3))
+    pts[: n // 5] = rng.random((n // 5, 3)) - 0.5
+    return rng.permutation(pts).astype(np.float32)
+
+
+@pytest.mark.parametrize("n,m", [(8192, 700), (12288, 300), (16384, 2048), (20480, 4096), (9001, 513)])
+def test_fps_pruned_kernel_same_picks(pn, device, n, m):
+    """Clouds of 8k-20k points take the spatially pruned kernel (csrc/fps_pruned.hip): picks, sampled coordinates and
+    the running-minimum array it hands back are those of the plain kernel and of the oracle, on a surface-like cloud
+    and on a uniform one."""
+    import ctypes
+    from captra_amd import _lib, fused
+    xyz = np.stack([_surface_cloud(n + m, n), clouds.s_uni(n, n)])
+    ref = O.furthest_point_sample(xyz, m)
+    x = _dev(xyz, device)
+    got = pn.furthest_point_sample(x, m).cpu().numpy()
+    np.testing.assert_array_equal(got, ref)
+    idx, n3, cn = fused.fps_gather(x, m)
+    np.testing.assert_array_equal(idx.cpu().numpy(), ref)
+    picked = np.take_along_axis(xyz, ref[..., None].astype(np.int64).repeat(3, -1), axis=1)
+    np.testing.assert_array_equal(n3.cpu().numpy(), picked)
+    np.testing.assert_array_equal(cn.cpu().numpy(), picked.transpose(0, 2, 1))
+    # the drop-in op's temp array (in: 1e10, out: final running minima) against the unpruned kernel
+    temp_p = torch.full((2, n), 1e10, device=device)
+    out_p = torch.zeros(2, m, dtype=torch.int32, device=device)
+    _lib.call("captra_furthest_point_sampling", 2, n, m, x.data_ptr(), temp_p.data_ptr(), out_p.data_ptr())
+    _lib.lib().captra_fps_set_pruned_min(ctypes.c_int(0))
+    try:
+        temp_u = torch.full((2, n), 1e10, device=device)
+        out_u = torch.zeros(2, m, dtype=torch.int32, device=device)
+        _lib.call("captra_furthest_point_sampling", 2, n, m, x.data_ptr(), temp_u.data_ptr(), out_u.data_ptr())
+    finally:
+        _lib.lib().captra_fps_set_pruned_min(ctypes.c_int(8192))
+    assert torch.equal(out_p, out_u) and torch.equal(temp_p, temp_u)
+
+
+def test_fps_pruned_duplicate_padded_cloud(device):
+    """The on-the-fly crop doubles a short candidate list until it holds num_points (nocs_data_process.py:105-106):
+    every point then exists twice or four times, every maximum is attained several times, and once all distinct points
+    are taken the sampler keeps returning index 0.  The pruned kernel resolves those ties by ORIGINAL index."""
+    from captra_amd import fused
+    base = _surface_cloud(5, 2500)
+    xyz = np.concatenate([base] * 4)[None]                     # 10000 points, 2500 distinct
+    ref = O.furthest_point_sample(xyz, 4096)
+    idx, _, _ = fused.fps_gather(_dev(xyz, device), 4096)
+    np.testing.assert_array_equal(idx.cpu().numpy(), ref)
+    assert (ref[0, 2500:] == 0).all() and len(set(ref[0, :2500])) == 2500
+
+
+def test_fps_gather_ragged_batch(device):
+    """captra_fps_gather_ragged: clouds padded to a common stride, each sampling from its own prefix — equal to sampling
+    every cloud on its own (pruned kernel at 20480 stride, register kernel at 3000)."""
+    from captra_amd import fused
+    for stride, counts, m in [(20480, [20480, 8300, 4096, 13001], 4096), (3000, [3000, 1500, 64, 2999], 64)]:
+        full = np.stack([_surface_cloud(40 + i, stride) for i in range(len(counts))])
+        ns = torch.tensor(counts, dtype=torch.int32, device=device)
+        idx, n3, cn = fused.fps_gather(_dev(full, device), m, n_per_cloud=ns)
+        for i, c in enumerate(counts):
+            ref = O.furthest_point_sample(full[i:i + 1, :c], m)[0]
+            np.testing.assert_array_equal(idx[i].cpu().numpy(), ref)
+            np.testing.assert_array_equal(n3[i].cpu().numpy(), full[i, ref])
+
+
 def test_fps_big_cloud_fallback(pn, device):
     xyz = clouds.s_uni(0, 40000)[None]
     got = pn.furthest_point_sample(_dev(xyz, device), 64).cpu().numpy()
