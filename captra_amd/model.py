@@ -158,7 +158,7 @@ class EvalTrackModel(BaseModel):
     def _recrop(self, i, input, last_pose):
         """nocs_otf (reference model.py:425-452): re-crop frame i around the pose predicted for frame i-1 -- on the device
         (captra_amd/nocs_otf.py).  The frame must carry its depth image and instance mask (meta['pre_fetched'])."""
-        from .nocs_otf import full_data_from_depth
+        from .nocs_otf import full_data_batch
         pre = input.get("pre_fetched")
         if pre is None:
             raise ValueError("nocs_otf=True needs the frame's depth and mask tensors (meta['pre_fetched']): reading depth.png / "
@@ -169,9 +169,9 @@ class EvalTrackModel(BaseModel):
         scales = last_pose["scale"][:, self.root].reshape(B).double().cpu().numpy()
         gt = {k: v[:, self.root].double().cpu().numpy() for k, v in input["gt_part"].items()}
         pts, lab, nocs = [], [], []
-        for b in range(B):
-            full = full_data_from_depth(pre["depth"][b], pre["mask"][b], centers[b], self.radius * float(scales[b]),
-                                        {k: gt[k][b] for k in gt}, N)
+        fulls = full_data_batch([(pre["depth"][b], pre["mask"][b], centers[b], self.radius * float(scales[b]),
+                                  {k: gt[k][b] for k in gt}) for b in range(B)], N)     # one sampling launch for the step
+        for b, full in enumerate(fulls):
             pts.append((full["points"].float() - npcs["points_mean"][b].reshape(1, 3)).t())
             lab.append(full["labels"])
             nocs.append(full["nocs"].float().t())

@@ -47,10 +47,12 @@ def _device_fps(points_f32: torch.Tensor, num: int) -> torch.Tensor:
     return res[0].reshape(-1).long()
 
 
-def crop_ball_from_depth(depth: torch.Tensor, mask: torch.Tensor, center, radius: float, num_points: int,
-                         intrinsics=NOCS_REAL_INTRINSICS, fps_fn=_device_fps, _depth_retry: int = 0):
-    """depth (H,W) integer millimetres, mask (H,W) bool (the tracked instance), both on the compute device
-    -> (points (num_points,3) float64 camera frame, obj_mask (num_points,) bool).  nocs_data_process.py:92-109, 151-163."""
+def crop_candidates(depth: torch.Tensor, mask: torch.Tensor, center, radius: float, num_points: int,
+                    intrinsics=NOCS_REAL_INTRINSICS, _depth_retry: int = 0):
+    """Everything of the crop BEFORE the furthest-point sampling (nocs_data_process.py:92-109, 151-163;
+    data_utils.py:146-152): -> (pts (n,3) float64 back-projected pixels, raw_mask (n,) bool, idx (c,) long = the ball
+    members, list-doubled up to num_points, perm (5*num_points,) long or None = the thinning of an over-long list).
+    The cloud handed to the sampler is pts[idx] (or pts[idx][perm]) as float32."""
     H, W = depth.shape
     dev = depth.device
     box = proj_corners(H, W, center, radius, intrinsics)
@@ -80,24 +82,31 @@ def crop_ball_from_depth(depth: torch.Tensor, mask: torch.Tensor, center, radius
     if idx.numel() == 0:
         if _depth_retry > 20:
             raise RuntimeError("crop_ball_from_depth: no valid depth pixel anywhere near the predicted centre")
-        return crop_ball_from_depth(depth, mask, center, float(radius) * 1.2, num_points, intrinsics, fps_fn, _depth_retry + 1)
+        return crop_candidates(depth, mask, center, float(radius) * 1.2, num_points, intrinsics, _depth_retry + 1)
     while idx.numel() < num_points:
         idx = torch.cat([idx, idx])
-    cand = pts[idx]
+    perm = None
     if idx.numel() > 5 * num_points:                                # data_utils.py:146-152
         perm = torch.from_numpy(np.random.permutation(idx.numel())[:5 * num_points]).to(dev)
-        picked = perm[fps_fn(cand[perm].float(), num_points)]
-    else:
-        picked = fps_fn(cand.float(), num_points)
-    idx = idx[picked]
+    return pts, raw_mask, idx, perm
+
+
+def _candidate_cloud(pts, idx, perm) -> torch.Tensor:
+    cand = pts[idx]
+    return (cand[perm] if perm is not None else cand).float()
+
+
+def crop_ball_from_depth(depth: torch.Tensor, mask: torch.Tensor, center, radius: float, num_points: int,
+                         intrinsics=NOCS_REAL_INTRINSICS, fps_fn=_device_fps):
+    """depth (H,W) integer millimetres, mask (H,W) bool (the tracked instance), both on the compute device
+    -> (points (num_points,3) float64 camera frame, obj_mask (num_points,) bool).  nocs_data_process.py:92-109, 151-163."""
+    pts, raw_mask, idx, perm = crop_candidates(depth, mask, center, radius, num_points, intrinsics)
+    picked = fps_fn(_candidate_cloud(pts, idx, perm), num_points)
+    idx = idx[perm[picked] if perm is not None else picked]
     return pts[idx], raw_mask[idx]
 
 
-def full_data_from_depth(depth, mask, center, radius, gt_pose: dict, num_points: int, intrinsics=NOCS_REAL_INTRINSICS,
-                         fps_fn=_device_fps) -> dict:
-    """-> {'points' (N,3), 'labels' (N,) (0 = object, 1 = background), 'nocs' (N,3)} float64 / int64 device tensors;
-    gt_pose {'rotation' (3,3), 'translation' (3,1), 'scale' ()} of the instance (nocs_data_process.py:43-50, 227-236)."""
-    pts, obj = crop_ball_from_depth(depth, mask, center, radius, num_points, intrinsics, fps_fn)
+def _full_data(pts, obj, gt_pose: dict) -> dict:
     dev = pts.device
     rot = torch.as_tensor(np.asarray(gt_pose["rotation"], np.float64).reshape(3, 3), device=dev)
     trans = torch.as_tensor(np.asarray(gt_pose["translation"], np.float64).reshape(1, 3), device=dev)
@@ -105,3 +114,35 @@ def full_data_from_depth(depth, mask, center, radius, gt_pose: dict, num_points:
     nocs = torch.zeros_like(pts)
     nocs[obj] = ((pts[obj] - trans) / scale) @ rot
     return {"points": pts, "labels": 1 - obj.long(), "nocs": nocs}
+
+
+def full_data_from_depth(depth, mask, center, radius, gt_pose: dict, num_points: int, intrinsics=NOCS_REAL_INTRINSICS,
+                         fps_fn=_device_fps) -> dict:
+    """-> {'points' (N,3), 'labels' (N,) (0 = object, 1 = background), 'nocs' (N,3)} float64 / int64 device tensors;
+    gt_pose {'rotation' (3,3), 'translation' (3,1), 'scale' ()} of the instance (nocs_data_process.py:43-50, 227-236)."""
+    pts, obj = crop_ball_from_depth(depth, mask, center, radius, num_points, intrinsics, fps_fn)
+    return _full_data(pts, obj, gt_pose)
+
+
+def full_data_batch(frames, num_points: int, intrinsics=NOCS_REAL_INTRINSICS) -> list:
+    """The re-crop of ALL trajectories of a tracking step with ONE furthest-point-sampling launch.
+    frames: list of (depth, mask, center, radius, gt_pose) -> list of full_data_from_depth's dicts, identical to calling it
+    once per trajectory in list order (the thinning permutations are drawn in that order; the sampler draws nothing).
+    The candidate clouds (num_points .. 5 x num_points points each, a different count per instance) are packed into one
+    padded batch and sampled by captra_fps_gather_ragged — one workgroup per trajectory side by side instead of one
+    launch after the other, which is what made the re-crop the slowest stage of real NOCS tracking."""
+    from . import fused
+    cands = [crop_candidates(d, m, c, r, num_points, intrinsics) for d, m, c, r, _ in frames]
+    clouds = [_candidate_cloud(p, i, pm) for p, _, i, pm in cands]
+    counts = [int(c.shape[0]) for c in clouds]
+    dev = clouds[0].device
+    padded = torch.zeros(len(clouds), max(counts), 3, dtype=torch.float32, device=dev)
+    for b, c in enumerate(clouds):
+        padded[b, :counts[b]] = c
+    res = fused.fps_gather(padded, num_points, n_per_cloud=torch.tensor(counts, dtype=torch.int32, device=dev))
+    out = []
+    for b, ((pts, raw_mask, idx, perm), frame) in enumerate(zip(cands, frames)):
+        picked = res[0][b].long() if res is not None else _device_fps(clouds[b], num_points)
+        sel = idx[perm[picked] if perm is not None else picked]
+        out.append(_full_data(pts[sel], raw_mask[sel], frame[4]))
+    return out

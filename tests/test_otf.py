@@ -76,3 +76,24 @@ def test_track_loop_with_on_the_fly_crop(device):
                                         cfg["data_radius"] * float(np.float32(pose["scale"])), pose, 4096)
     got = model.feed_dict[1]["points"][0].t().double() + model.npcs_feed_dict[1]["points_mean"][0].reshape(1, 3).double()
     np.testing.assert_allclose(got.cpu().numpy(), ref["points"].cpu().numpy(), atol=2e-7)
+
+
+@pytest.mark.gpu
+def test_batched_recrop_equals_one_call_per_trajectory(device):
+    """full_data_batch (one ragged furthest-point-sampling launch for all trajectories of a step) == full_data_from_depth
+    called once per trajectory, including the order in which the thinning permutations are drawn."""
+    items = []
+    for tag, seed, radius, n in CASES:
+        if n != CASES[0][3]:
+            continue
+        depth, mask, center, pose = make_frame(seed)
+        items.append((torch.from_numpy(depth.astype(np.int32)).to(device), torch.from_numpy(mask).to(device), center, radius, pose))
+    items = items + [items[0]]
+    n = CASES[0][3]
+    np.random.seed(11)
+    one_by_one = [nocs_otf.full_data_from_depth(d, m, c, r, p, n) for d, m, c, r, p in items]
+    np.random.seed(11)
+    batched = nocs_otf.full_data_batch(items, n)
+    for a, b in zip(one_by_one, batched):
+        for k in ("points", "labels", "nocs"):
+            assert torch.equal(a[k], b[k])

@@ -1,0 +1,62 @@
+"""On-the-fly re-crop of real NOCS tracking (`--nocs_otf True`): time of the crop + resample stage for a step of B
+trajectories, one sampling launch per trajectory (the reference's structure) vs one ragged launch for the step, with
+and without the spatially pruned sampler.
+
+Usage: python tools/bench_otf.py [--batch 32]
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+from captra_amd import _lib, nocs_otf  # noqa: E402
+from tests.golden.make_golden_otf import make_frame  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--radius", type=float, default=0.30)
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    items = []
+    for b in range(args.batch):
+        depth, mask, center, pose = make_frame(1 + b % 3)
+        items.append((torch.from_numpy(depth.astype(np.int32)).to(dev), torch.from_numpy(mask).to(dev), center, args.radius, pose))
+    np.random.seed(0)
+    counts = [int(nocs_otf._candidate_cloud(*[x for j, x in enumerate(nocs_otf.crop_candidates(d, m, c, r, 4096)) if j != 1]).shape[0])
+              for d, m, c, r, _ in items[:3]]
+    print(f"candidate points per crop (first 3 frames): {counts}")
+
+    def timed(fn, label):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.iters):
+            fn()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / args.iters * 1e3
+        print(f"{label:70s} {ms:8.2f} ms / step of {args.batch} trajectories  ({ms / args.batch:6.3f} ms per frame)", flush=True)
+
+    for pruned in (8192, 0):
+        _lib.lib().captra_fps_set_pruned_min(ctypes.c_int(pruned))
+        tag = "pruned sampler" if pruned else "plain register-resident sampler"
+        timed(lambda: [nocs_otf.full_data_from_depth(d, m, c, r, p, 4096) for d, m, c, r, p in items], f"one launch per trajectory, {tag}")
+        timed(lambda: nocs_otf.full_data_batch(items, 4096), f"one ragged launch per step, {tag}")
+    _lib.lib().captra_fps_set_pruned_min(ctypes.c_int(8192))
+    timed(lambda: [nocs_otf.crop_candidates(d, m, c, r, 4096) for d, m, c, r, _ in items], "candidate extraction alone (torch ops, host syncs)")
+
+
+if __name__ == "__main__":
+    main()
