@@ -1,0 +1,101 @@
+// Ball crop of a depth frame around a predicted centre, for gfx950 — the candidate extraction of the on-the-fly re-crop
+// of NOCS tracking (reference datasets/nocs_data/nocs_data_process.py:92-109, 151-163 `crop_ball_from_depth_image` /
+// `crop_ball_from_pts`; nocs_utils.py:5-33 `backproject`): inside the image-space box of the ball, back-project every
+// pixel with a valid depth, keep those within `radius` of the centre, IN ROW-MAJOR PIXEL ORDER (the order decides which
+// point furthest-point sampling starts from).  The reference does this in numpy on the host per tracked instance; the
+// torch restatement in captra_amd/nocs_otf.py costs ~0.35 ms and two host syncs per instance.  Here one workgroup per
+// instance walks its box 1024 pixels at a time and compacts the members in order (wave ballot + LDS wave offsets).
+//
+// Arithmetic is float64 like numpy's, written out operation by operation (no FMA contraction: the build runs with
+// -ffp-contract=off):  ray = Kinv (col, H - row, 1);  p = ray * z / ray_z;  p = (p_x, p_y, -p_z) * 0.001;
+// member  <=>  sqrt(((p - c)_x^2 + (p - c)_y^2) + (p - c)_z^2) <= radius.
+#include "common.h"
+
+#include <math.h>
+
+namespace {
+
+constexpr int CB_T = 1024;
+
+__global__ __launch_bounds__(CB_T) void crop_ball_kernel(int h, int w, int cap, const int *__restrict__ depth_all,
+                                                         const unsigned char *__restrict__ mask_all,
+                                                         const int *__restrict__ box_all, const double *__restrict__ center_all,
+                                                         const double *__restrict__ radius_all, const double *__restrict__ kinv,
+                                                         double *__restrict__ pts_all, unsigned char *__restrict__ obj_all,
+                                                         int *__restrict__ pix_all, int *__restrict__ counts) {
+    __shared__ int wave_tot[2][16];
+    const int b = blockIdx.x;
+    const int *depth = depth_all + (size_t)b * h * w;
+    const unsigned char *mask = mask_all + (size_t)b * h * w;
+    const int r0 = box_all[b * 4 + 0], c0 = box_all[b * 4 + 1], r1 = box_all[b * 4 + 2], c1 = box_all[b * 4 + 3];
+    const double cx = center_all[b * 3 + 0], cy = center_all[b * 3 + 1], cz = center_all[b * 3 + 2];
+    const double rad = radius_all[b];
+    double k[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) k[i] = kinv[i];
+    double *pts = pts_all + (size_t)b * cap * 3;
+    unsigned char *obj = obj_all + (size_t)b * cap;
+    int *pix = pix_all + (size_t)b * cap;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bw = c1 - c0 + 1, bh = r1 - r0 + 1;
+    const long long total = (bw > 0 && bh > 0) ? (long long)bw * bh : 0;
+    int base = 0, valid = 0, it = 0;
+    for (long long t0 = 0; t0 < total; t0 += CB_T, ++it) {
+        const long long t = t0 + tid;
+        bool member = false, has_depth = false;
+        double px = 0., py = 0., pz = 0.;
+        int row = 0, col = 0;
+        if (t < total) {
+            row = r0 + (int)(t / bw);
+            col = c0 + (int)(t % bw);
+            const int d = depth[(size_t)row * w + col];
+            if (d > 0) {
+                has_depth = true;
+                const double u = (double)col, v = (double)(h - row);
+                const double rx = (k[0] * u + k[1] * v) + k[2];
+                const double ry = (k[3] * u + k[4] * v) + k[5];
+                const double rz = (k[6] * u + k[7] * v) + k[8];
+                const double z = (double)(float)d;                 // depth[idxs].astype(np.float32)
+                px = (rx * z / rz) * 0.001;
+                py = (ry * z / rz) * 0.001;
+                pz = -(rz * z / rz) * 0.001;
+                const double dx = px - cx, dy = py - cy, dz = pz - cz;
+                member = sqrt((dx * dx + dy * dy) + dz * dz) <= rad;
+            }
+        }
+        const unsigned long long m = __ballot(member), v = __ballot(has_depth);
+        if (lane == 0) wave_tot[it & 1][wave] = __popcll(m) | (__popcll(v) << 8);
+        __syncthreads();
+        int before = 0, all = 0, allv = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int e = wave_tot[it & 1][i];
+            before += i < wave ? (e & 0xFF) : 0;
+            all += e & 0xFF;
+            allv += e >> 8;
+        }
+        if (member) {
+            const int pos = base + before + __popcll(m & ((1ull << lane) - 1ull));
+            if (pos < cap) {
+                pts[(size_t)pos * 3 + 0] = px; pts[(size_t)pos * 3 + 1] = py; pts[(size_t)pos * 3 + 2] = pz;
+                obj[pos] = mask[(size_t)row * w + col];
+                pix[pos] = row * w + col;
+            }
+        }
+        base += all;
+        valid += allv;
+    }
+    if (tid == 0) { counts[b * 2 + 0] = base; counts[b * 2 + 1] = valid; }
+}
+
+}  // namespace
+
+extern "C" int captra_crop_ball(int b, int h, int w, int cap, const int *depth, const unsigned char *mask, const int *box,
+                                const double *center, const double *radius, const double *kinv, double *pts,
+                                unsigned char *obj, int *pix, int *counts, captra_stream_t stream) {
+    if (b < 0 || h < 1 || w < 1 || cap < 1) return -1;
+    if (b == 0) return 0;
+    CAPTRA_LAUNCH("crop_ball", crop_ball_kernel, dim3(b), dim3(CB_T), 0, (hipStream_t)stream, h, w, cap, depth, mask, box,
+                  center, radius, kinv, pts, obj, pix, counts);
+    return captra_last_error();
+}

@@ -124,13 +124,12 @@ def full_data_from_depth(depth, mask, center, radius, gt_pose: dict, num_points:
     return _full_data(pts, obj, gt_pose)
 
 
-def full_data_batch(frames, num_points: int, intrinsics=NOCS_REAL_INTRINSICS) -> list:
-    """The re-crop of ALL trajectories of a tracking step with ONE furthest-point-sampling launch.
-    frames: list of (depth, mask, center, radius, gt_pose) -> list of full_data_from_depth's dicts, identical to calling it
-    once per trajectory in list order (the thinning permutations are drawn in that order; the sampler draws nothing).
-    The candidate clouds (num_points .. 5 x num_points points each, a different count per instance) are packed into one
-    padded batch and sampled by captra_fps_gather_ragged — one workgroup per trajectory side by side instead of one
-    launch after the other, which is what made the re-crop the slowest stage of real NOCS tracking."""
+CROP_CAP = 65536          # ball members kept per instance by the crop kernel (more: that instance takes the torch path)
+
+
+def _full_data_batch_torch(frames, num_points: int, intrinsics) -> list:
+    """full_data_batch with the candidate extraction in torch ops, one instance after the other (the restatement the crop
+    kernel is tested against); the sampling is already one ragged launch."""
     from . import fused
     cands = [crop_candidates(d, m, c, r, num_points, intrinsics) for d, m, c, r, _ in frames]
     clouds = [_candidate_cloud(p, i, pm) for p, _, i, pm in cands]
@@ -145,4 +144,75 @@ def full_data_batch(frames, num_points: int, intrinsics=NOCS_REAL_INTRINSICS) ->
         picked = res[0][b].long() if res is not None else _device_fps(clouds[b], num_points)
         sel = idx[perm[picked] if perm is not None else picked]
         out.append(_full_data(pts[sel], raw_mask[sel], frame[4]))
+    return out
+
+
+def full_data_batch(frames, num_points: int, intrinsics=NOCS_REAL_INTRINSICS, use_kernel: bool = True) -> list:
+    """The re-crop of ALL trajectories of a tracking step: one crop launch (captra_crop_ball, a workgroup per instance),
+    one host round trip for the member counts, one furthest-point-sampling launch (captra_fps_gather_ragged).
+    frames: list of (depth, mask, center, radius, gt_pose) -> list of full_data_from_depth's dicts, as if it had been
+    called once per trajectory in list order (the thinning permutations are drawn in that order; nothing else draws).
+    Instances on a rare path — fewer than 10 ball members (radius growth), more than CROP_CAP — take the torch path."""
+    from . import _lib as L, fused
+    dev = frames[0][0].device
+    if not use_kernel or dev.type != "cuda":
+        return _full_data_batch_torch(frames, num_points, intrinsics)
+    B = len(frames)
+    depth = torch.stack([f[0] for f in frames]).to(torch.int32).contiguous()
+    mask = torch.stack([f[1] for f in frames]).to(torch.uint8).contiguous()
+    _, H, W = depth.shape
+    centers = np.stack([np.asarray(f[2], np.float64).reshape(3) for f in frames])
+    radii = np.array([max(float(f[3]), 0.05) for f in frames], np.float64)
+    boxes = np.stack([proj_corners(H, W, centers[b], frames[b][3], intrinsics).reshape(4) for b in range(B)]).astype(np.int32)
+    kinv = np.linalg.inv(np.asarray(intrinsics, np.float64)).reshape(9)
+    host = torch.from_numpy(np.concatenate([centers.reshape(-1), radii, kinv])).to(dev)         # one H2D for the doubles
+    box_d = torch.from_numpy(boxes).to(dev)
+    pts = torch.empty(B, CROP_CAP, 3, dtype=torch.float64, device=dev)
+    obj = torch.empty(B, CROP_CAP, dtype=torch.uint8, device=dev)
+    pix = torch.empty(B, CROP_CAP, dtype=torch.int32, device=dev)
+    counts = torch.empty(B, 2, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        L.call("captra_crop_ball", B, H, W, CROP_CAP, L.ptr(depth), L.ptr(mask), L.ptr(box_d), host.data_ptr(),
+               host.data_ptr() + 8 * 3 * B, host.data_ptr() + 8 * 4 * B, L.ptr(pts), L.ptr(obj), L.ptr(pix), L.ptr(counts))
+    n_members = counts[:, 0].cpu().numpy()                                                       # the one sync of the stage
+
+    # host: the candidate list of every instance as indices into its member table (list doubling = index modulo count,
+    # thinning = a prefix of numpy's permutation), in trajectory order because the permutations consume numpy's generator
+    members, slow = [None] * B, {}
+    for b in range(B):
+        c = int(n_members[b])
+        if c < 10 or c > CROP_CAP:
+            slow[b] = crop_candidates(frames[b][0], frames[b][1], frames[b][2], frames[b][3], num_points, intrinsics)
+            continue
+        length = c
+        while length < num_points:
+            length *= 2
+        j = np.random.permutation(length)[:5 * num_points] if length > 5 * num_points else np.arange(length)
+        members[b] = (j % c).astype(np.int64)
+    fast = [b for b in range(B) if members[b] is not None]
+    out = [None] * B
+    if fast:
+        lens = [len(members[b]) for b in fast]
+        table = np.zeros((len(fast), max(lens)), np.int64)
+        for i, b in enumerate(fast):
+            table[i, :lens[i]] = members[b]
+        table_d = torch.from_numpy(table).to(dev)
+        fidx = torch.tensor(fast, device=dev)
+        pts_f, obj_f = pts[fidx], obj[fidx]
+        cand = torch.gather(pts_f, 1, table_d.unsqueeze(-1).expand(-1, -1, 3)).float()
+        res = fused.fps_gather(cand, num_points, n_per_cloud=torch.tensor(lens, dtype=torch.int32, device=dev))
+        sel = torch.gather(table_d, 1, res[0].long())                                             # (F, N) member numbers
+        P = torch.gather(pts_f, 1, sel.unsqueeze(-1).expand(-1, -1, 3))                            # (F, N, 3) float64
+        O = torch.gather(obj_f, 1, sel).bool()
+        rot = torch.from_numpy(np.stack([np.asarray(frames[b][4]["rotation"], np.float64).reshape(3, 3) for b in fast])).to(dev)
+        trans = torch.from_numpy(np.stack([np.asarray(frames[b][4]["translation"], np.float64).reshape(1, 3) for b in fast])).to(dev)
+        scale = torch.from_numpy(np.array([float(np.asarray(frames[b][4]["scale"], np.float64).reshape(-1)[0]) for b in fast])).to(dev)
+        nocs = torch.where(O.unsqueeze(-1), torch.bmm((P - trans) / scale.reshape(-1, 1, 1), rot), torch.zeros_like(P))
+        labels = 1 - O.long()
+        for i, b in enumerate(fast):
+            out[b] = {"points": P[i], "labels": labels[i], "nocs": nocs[i]}
+    for b, (p_all, raw_mask, idx, perm) in slow.items():
+        picked = _device_fps(_candidate_cloud(p_all, idx, perm), num_points)
+        sel_b = idx[perm[picked] if perm is not None else picked]
+        out[b] = _full_data(p_all[sel_b], raw_mask[sel_b], frames[b][4])
     return out

@@ -193,6 +193,16 @@ int captra_sa_scale_bf16(int b, int n, int m, int k, int cfeat, int c1, int c2, 
 int captra_fps_gather(int b, int n, int m, const float *xyz, int *idx, float *new_xyz_n3, float *new_xyz_cn,
                       captra_stream_t stream);
 
+/* Candidate extraction of the on-the-fly ball crop (reference nocs_data_process.py:92-109, 151-163; nocs_utils.py:5-33), one
+ * workgroup per tracked instance: inside the inclusive image box box[i] = {row_min, col_min, row_max, col_max} back-project the
+ * pixels with depth > 0 (float64: ray = kinv (col, h - row, 1); p = ray * z / ray_z; (p_x, p_y, -p_z) * 0.001) and keep those with
+ * |p - center[i]| <= radius[i], in row-major pixel order: pts (B,cap,3) float64, obj (B,cap) = the instance mask at those pixels,
+ * pix (B,cap) = row * w + col, counts (B,2) = {members found (may exceed cap: only the first cap are stored), pixels with
+ * depth > 0 in the box}.  depth (B,h,w) int32 millimetres, mask (B,h,w) bytes, kinv 9 doubles (row-major inverse intrinsics). */
+int captra_crop_ball(int b, int h, int w, int cap, const int *depth, const unsigned char *mask, const int *box,
+                     const double *center, const double *radius, const double *kinv, double *pts, unsigned char *obj,
+                     int *pix, int *counts, captra_stream_t stream);
+
 /* Ragged batch of the same operation: the clouds are padded to n_stride points each (xyz (B,n_stride,3)) and cloud i
  * samples m of its FIRST n_per_cloud[i] points (device array of B ints, 1 <= n_per_cloud[i] <= n_stride; NULL = all
  * n_stride).  This is the re-sampling step of the on-the-fly ball crop (reference datasets/data_utils.py:138-157:

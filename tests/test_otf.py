@@ -78,22 +78,56 @@ def test_track_loop_with_on_the_fly_crop(device):
     np.testing.assert_allclose(got.cpu().numpy(), ref["points"].cpu().numpy(), atol=2e-7)
 
 
-@pytest.mark.gpu
-def test_batched_recrop_equals_one_call_per_trajectory(device):
-    """full_data_batch (one ragged furthest-point-sampling launch for all trajectories of a step) == full_data_from_depth
-    called once per trajectory, including the order in which the thinning permutations are drawn."""
+def _items(device, cases):
     items = []
-    for tag, seed, radius, n in CASES:
-        if n != CASES[0][3]:
-            continue
+    for tag, seed, radius, n in cases:
         depth, mask, center, pose = make_frame(seed)
         items.append((torch.from_numpy(depth.astype(np.int32)).to(device), torch.from_numpy(mask).to(device), center, radius, pose))
-    items = items + [items[0]]
+    return items
+
+
+def _same(a, b):
+    np.testing.assert_allclose(a["points"].cpu().numpy(), b["points"].cpu().numpy(), atol=1e-15, rtol=0)
+    np.testing.assert_array_equal(a["labels"].cpu().numpy(), b["labels"].cpu().numpy())
+    np.testing.assert_allclose(a["nocs"].cpu().numpy(), b["nocs"].cpu().numpy(), atol=1e-12, rtol=0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("use_kernel", [False, True])
+def test_batched_recrop_equals_one_call_per_trajectory(device, use_kernel):
+    """full_data_batch (one crop launch + one ragged furthest-point-sampling launch for all trajectories of a step) ==
+    full_data_from_depth called once per trajectory, including the order in which the thinning permutations are drawn.
+    use_kernel=False keeps the candidate extraction in torch ops (bit-identical); the crop kernel writes the float64
+    back-projection out operation by operation (last-bit differences against torch's matmul, same pixels)."""
     n = CASES[0][3]
+    items = _items(device, [c for c in CASES if c[3] == n])
+    items = items + [items[0]]
     np.random.seed(11)
     one_by_one = [nocs_otf.full_data_from_depth(d, m, c, r, p, n) for d, m, c, r, p in items]
     np.random.seed(11)
-    batched = nocs_otf.full_data_batch(items, n)
+    batched = nocs_otf.full_data_batch(items, n, use_kernel=use_kernel)
     for a, b in zip(one_by_one, batched):
-        for k in ("points", "labels", "nocs"):
-            assert torch.equal(a[k], b[k])
+        if use_kernel:
+            _same(a, b)
+        else:
+            for k in ("points", "labels", "nocs"):
+                assert torch.equal(a[k], b[k])
+
+
+@pytest.mark.gpu
+def test_batched_recrop_rare_paths_and_golden(device):
+    """A batch mixing a normal crop with one whose ball holds fewer than 10 pixels at first (radius growth: that instance
+    takes the torch path) and one thinned by the permutation; each equals its own single call, and the sparse case equals
+    golden G11 (the reference's own output)."""
+    tag, seed, radius, n = CASES[2]
+    depth, mask, center, pose = make_frame(seed)
+    d, m = torch.from_numpy(depth.astype(np.int32)).to(device), torch.from_numpy(mask).to(device)
+    items = [(d, m, center, radius, pose), (d, m, center, 0.004, pose), (d, m, center, 0.3, pose)]
+    np.random.seed(100 + seed)
+    singles = [nocs_otf.full_data_from_depth(*it, n) for it in items]
+    np.random.seed(100 + seed)
+    batched = nocs_otf.full_data_batch(items, n)
+    for a, b in zip(singles, batched):
+        _same(a, b)
+    np.testing.assert_allclose(batched[0]["points"].cpu().numpy(), G[f"{tag}_points"], atol=1e-15, rtol=0)
+    np.testing.assert_array_equal(batched[0]["labels"].cpu().numpy(), G[f"{tag}_labels"])

@@ -47,13 +47,14 @@ def main():
             fn()
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / args.iters * 1e3
-        print(f"{label:70s} {ms:8.2f} ms / step of {args.batch} trajectories  ({ms / args.batch:6.3f} ms per frame)", flush=True)
+        print(f"{label:98s} {ms:8.2f} ms / step of {args.batch} trajectories  ({ms / args.batch:6.3f} ms per frame)", flush=True)
 
     for pruned in (8192, 0):
         _lib.lib().captra_fps_set_pruned_min(ctypes.c_int(pruned))
         tag = "pruned sampler" if pruned else "plain register-resident sampler"
         timed(lambda: [nocs_otf.full_data_from_depth(d, m, c, r, p, 4096) for d, m, c, r, p in items], f"one launch per trajectory, {tag}")
-        timed(lambda: nocs_otf.full_data_batch(items, 4096), f"one ragged launch per step, {tag}")
+        timed(lambda: nocs_otf.full_data_batch(items, 4096, use_kernel=False), f"one ragged sampling launch per step, torch candidate extraction, {tag}")
+        timed(lambda: nocs_otf.full_data_batch(items, 4096), f"crop kernel + one ragged sampling launch per step, {tag}")
     _lib.lib().captra_fps_set_pruned_min(ctypes.c_int(8192))
     timed(lambda: [nocs_otf.crop_candidates(d, m, c, r, 4096) for d, m, c, r, _ in items], "candidate extraction alone (torch ops, host syncs)")
 
