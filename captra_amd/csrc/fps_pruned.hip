@@ -26,10 +26,7 @@
 
 namespace {
 
-constexpr int FP_NW = 8;            // waves per workgroup: 2 per SIMD, 256 VGPRs each (4 per point + bucket metadata)
-constexpr int FP_T = FP_NW * 64;
 constexpr int FP_BINS = 4096;       // 16 x 16 x 16 Morton cells
-constexpr int FP_BPT = FP_BINS / FP_T;
 
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ unsigned fp_dpp_max(unsigned v) {   // 0 is the identity: invalid sources contribute 0
@@ -81,12 +78,13 @@ struct RegVec {
 
 // SLOTS = A + B buckets per wave: the first A in registers, B more in LDS (x, y, z and the running minimum of a bucket
 // as four rows of 64 floats); capacity = FP_NW * SLOTS * 64 points.
-template <int A, int B>
-__global__ __launch_bounds__(FP_T) void fps_pruned_kernel(int n_stride, const int *__restrict__ n_per_cloud, int m,
+template <int FP_NW, int A, int B, bool STATS>
+__global__ __launch_bounds__(FP_NW * 64) void fps_pruned_kernel(int n_stride, const int *__restrict__ n_per_cloud, int m,
                                                           const float *__restrict__ xyz_all, float *__restrict__ temp_all,
                                                           int *__restrict__ idx_all, float *__restrict__ new_n3,
                                                           float *__restrict__ new_cn, unsigned long long *stats) {
     constexpr int SLOTS = A + B;
+    constexpr int FP_T = FP_NW * 64, FP_BPT = FP_BINS / FP_T;
     constexpr int CAP = FP_NW * SLOTS * 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     static_assert(SLOTS <= 64, "one metadata lane per bucket");
@@ -255,7 +253,9 @@ __global__ __launch_bounds__(FP_T) void fps_pruned_kernel(int n_stride, const in
     // ---- 5. the selection rounds
     if (tid == 0) idx[0] = 0;
     float ox = xyz[0], oy = xyz[1], oz = xyz[2];
+    unsigned long long tph[4] = {0ull, 0ull, 0ull, 0ull};   // phase cycles (stats only)
     for (int j = 1; j < m; ++j) {
+        const unsigned long long t0 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
         if (tid == 0) emit(j - 1, ox, oy, oz);
         // which buckets can change?  same operations as the point distance: fl(p - o), squares, (x + y) + z
         {
@@ -269,6 +269,7 @@ __global__ __launch_bounds__(FP_T) void fps_pruned_kernel(int n_stride, const in
                 update(s, ox, oy, oz, false);
             }
         }
+        const unsigned long long t1 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
         // the wave's candidate
         const unsigned wm = fp_wave_max(bmax);
         const unsigned long long hitb = __ballot(bmax == wm);
@@ -284,7 +285,9 @@ __global__ __launch_bounds__(FP_T) void fps_pruned_kernel(int n_stride, const in
             slot[wave] = make_uint2(bmax, bq);
             sc[wave] = make_float4(bwx, bwy, bwz, 0.f);
         }
+        const unsigned long long t2 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
         __syncthreads();
+        const unsigned long long t3 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
         const uint2 kv = slot[lane & (FP_NW - 1)];
         const float4 kc = sc[lane & (FP_NW - 1)];
         const unsigned gmax = fp_row_max(kv.x);
@@ -298,13 +301,18 @@ __global__ __launch_bounds__(FP_T) void fps_pruned_kernel(int n_stride, const in
         const unsigned sel = (unsigned)__builtin_amdgcn_readlane((int)kv.y, gl);
         ox = fp_readlane(kc.x, gl); oy = fp_readlane(kc.y, gl); oz = fp_readlane(kc.z, gl);
         if (tid == 0) idx[j] = (int)sel;   // sorted position for now: the LDS look-up of the original index would sit on wave 0's critical path
+        if (STATS) {
+            const unsigned long long t4 = __builtin_amdgcn_s_memtime();
+            tph[0] += t1 - t0; tph[1] += t2 - t1; tph[2] += t3 - t2; tph[3] += t4 - t3;
+        }
     }
     if (tid == 0) emit(m - 1, ox, oy, oz);
     __syncthreads();   // (same-workgroup global writes of thread 0 are visible after the barrier)
     for (int j = 1 + tid; j < m; j += FP_T) idx[j] = (int)oidx[idx[j]];
-    if (stats != nullptr && lane == 0) {   // per wave: bucket updates, maximum refreshes (both include the SLOTS initial ones)
+    if (STATS && stats != nullptr && lane == 0) {   // per wave: bucket updates, maximum refreshes (both include the SLOTS initial ones)
         atomicAdd(stats + 0, (unsigned long long)n_upd);
         atomicAdd(stats + 1, (unsigned long long)n_ref);
+        for (int i = 0; i < 4; ++i) atomicAdd(stats + 2 + i, tph[i]);   // test + updates | candidate | barrier wait | exchange
     }
     if (temp != nullptr) {
 #pragma unroll
@@ -317,33 +325,44 @@ __global__ __launch_bounds__(FP_T) void fps_pruned_kernel(int n_stride, const in
 
 unsigned long long *g_fps_stats = nullptr;
 
-template <int A, int B>
+template <int FP_NW, int A, int B>
 int launch_pruned(int b, int n_stride, const int *ns, int m, const float *xyz, float *temp, int *idx, float *new_n3,
                   float *new_cn, hipStream_t s) {
     constexpr int CAP = FP_NW * (A + B) * 64;
     const size_t sort_bytes = (size_t)(FP_BINS + 16) * sizeof(unsigned), ovf_bytes = (size_t)FP_NW * B * 256 * sizeof(float);
     const size_t shmem = 2 * 16 * (sizeof(uint2) + sizeof(float4)) + 6 * 16 * sizeof(float) + (size_t)CAP * 2 +
                          (sort_bytes > ovf_bytes ? sort_bytes : ovf_bytes);
-    auto kern = fps_pruned_kernel<A, B>;
+    constexpr int FP_T = FP_NW * 64;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(fps_pruned_kernel<FP_NW, A, B, false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(fps_pruned_kernel<FP_NW, A, B, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         attr_set = true;
     }
-    CAPTRA_LAUNCH("fps", kern, dim3(b), dim3(FP_T), shmem, s, n_stride, ns, m, xyz, temp, idx, new_n3, new_cn, g_fps_stats);
+    if (g_fps_stats != nullptr) {   // instrumented build of the same kernel (counters + s_memtime per phase)
+        CAPTRA_LAUNCH("fps", (fps_pruned_kernel<FP_NW, A, B, true>), dim3(b), dim3(FP_T), shmem, s, n_stride, ns, m, xyz, temp,
+                      idx, new_n3, new_cn, g_fps_stats);
+    } else {
+        CAPTRA_LAUNCH("fps", (fps_pruned_kernel<FP_NW, A, B, false>), dim3(b), dim3(FP_T), shmem, s, n_stride, ns, m, xyz, temp,
+                      idx, new_n3, new_cn, g_fps_stats);
+    }
     return captra_last_error();
 }
 
 }  // namespace
 
-// experiment hook: device pointer to two u64 counters (bucket updates, maximum refreshes) accumulated by every wave
+// experiment hook: device pointer to six u64 counters accumulated by every wave: bucket updates, maximum refreshes,
+// and s_memtime cycles of the four phases of a round (test + updates, wave candidate, barrier wait, exchange)
 extern "C" void captra_fps_set_stats(unsigned long long *dev_counters) { g_fps_stats = dev_counters; }
 
 // Internal entry used by fps.hip's dispatchers: -2 when the cloud exceeds the kernel's capacity (20480 points).
 int captra_fps_pruned_launch(int b, int n_stride, const int *n_per_cloud, int m, const float *xyz, float *temp, int *idx,
                              float *new_n3, float *new_cn, hipStream_t s) {
+    // 8 waves (2 per SIMD, 256 VGPRs each); 16 waves x 16 slots measured no faster (exchange and barrier cost more)
     // 32 register slots whatever the cloud size up to 16384 points (unused slots are never touched), 8 more in LDS beyond
-    if (n_stride <= FP_NW * 64 * 32) return launch_pruned<32, 0>(b, n_stride, n_per_cloud, m, xyz, temp, idx, new_n3, new_cn, s);
-    if (n_stride <= FP_NW * 64 * 40) return launch_pruned<32, 8>(b, n_stride, n_per_cloud, m, xyz, temp, idx, new_n3, new_cn, s);
+    if (n_stride <= 8 * 64 * 32) return launch_pruned<8, 32, 0>(b, n_stride, n_per_cloud, m, xyz, temp, idx, new_n3, new_cn, s);
+    if (n_stride <= 8 * 64 * 40) return launch_pruned<8, 32, 8>(b, n_stride, n_per_cloud, m, xyz, temp, idx, new_n3, new_cn, s);
     return -2;
 }

@@ -306,7 +306,7 @@ int captra_prof_names(char *buf, int buflen);
  *         that compute the same bits).  Defaults (0 / 1 for captra_pw_set_direct) select the production kernels. ---- */
 void captra_fps_set_waves(int waves);       /* FPS: waves per cloud (0 = heuristic) */
 void captra_fps_set_pruned_min(int n);     /* FPS: clouds of >= n points take the pruned kernel (default 8192; 0 = never) */
-void captra_fps_set_stats(unsigned long long *dev_counters); /* pruned FPS: accumulate {bucket updates, refreshes} (NULL = off) */
+void captra_fps_set_stats(unsigned long long *dev_counters); /* pruned FPS: accumulate 6 counters {bucket updates, refreshes, cycles of 4 phases} (NULL = off) */
 void captra_fps_set_variant(int v);         /* FPS: 0 = blocked ownership + ballot pick (default), 1 = first-generation kernel */
 void captra_sa_fused_set_mode(int mode);    /* SA scale: 0 = register-resident kernels where instantiated, 1 = generic LDS kernel
                                                for every shape, 2 = register-resident with streamed weights only */
