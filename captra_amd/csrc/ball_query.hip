@@ -18,7 +18,7 @@
 
 namespace {
 
-constexpr int BQ_WAVES = 8;         // waves per workgroup
+constexpr int BQ_WAVES = 16;        // waves per workgroup (two workgroups per CU hold the full 32 wave slots; M = 512 -> 16 per cloud)
 constexpr int BQ_CPW = 2;           // centres per wave
 constexpr int BQ_TILE = 8192;       // points staged per LDS tile (96 KiB)
 constexpr int BQ_MAXR = 4;
