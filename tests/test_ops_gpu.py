@@ -350,3 +350,43 @@ def test_cpu_tensor_is_rejected_loudly(pn):
 def test_bad_k_raises(pn, device):
     with pytest.raises(RuntimeError):
         pn.knn(201, torch.zeros(1, 4, 3, device=device), torch.zeros(1, 4, 3, device=device))
+
+
+# ----------------------------------------------------------------------------- degenerate sizes
+def test_empty_batches_and_zero_sized_outputs_are_no_ops(device):
+    """b = 0, m = 0 or c = 0 through the C ABI: return 0, touch nothing (the reference's launchers would launch a grid of
+    zero blocks and print a HIP error)."""
+    from captra_amd import _lib
+    one = torch.zeros(16, device=device)
+    canary = torch.full((16,), 7, dtype=torch.int32, device=device)
+    p, q = one.data_ptr(), canary.data_ptr()
+    _lib.call("captra_furthest_point_sampling", 0, 10, 4, p, p, q)
+    _lib.call("captra_furthest_point_sampling", 2, 10, 0, p, p, q)
+    _lib.call("captra_ball_query", 0, 10, 4, 0.1, 4, p, p, q)
+    _lib.call("captra_ball_query", 1, 10, 0, 0.1, 4, p, p, q)
+    _lib.call("captra_group_points", 0, 3, 10, 4, 4, p, q, p)
+    _lib.call("captra_group_points", 1, 0, 10, 4, 4, p, q, p)
+    _lib.call("captra_gather_points", 0, 3, 10, 4, p, q, p)
+    _lib.call("captra_fps_gather", 0, 10, 4, p, q, p, p)
+    torch.cuda.synchronize()
+    assert (canary == 7).all() and (one == 0).all()
+
+
+def test_query_and_group_module(pn, device):
+    """pointnet2_utils.QueryAndGroup / GroupAll (reference pointnet2_utils.py:274-330): ball query + grouping + centre
+    subtraction + concatenation, features first and relative xyz last."""
+    rng = np.random.default_rng(8)
+    xyz = (rng.random((2, 300, 3), dtype=np.float32) - 0.5).astype(np.float32)
+    new_xyz = xyz[:, :40].copy()
+    feat = rng.standard_normal((2, 5, 300)).astype(np.float32)
+    idx = O.ball_query(0.2, 16, xyz, new_xyz)
+    gx = O.grouping_operation(np.ascontiguousarray(xyz.transpose(0, 2, 1)), idx) - new_xyz.transpose(0, 2, 1)[..., None]
+    gf = O.grouping_operation(feat, idx)
+    qg = pn.QueryAndGroup(0.2, 16, use_xyz=True)
+    np.testing.assert_array_equal(qg(_dev(xyz, device), _dev(new_xyz, device), _dev(feat, device)).cpu().numpy(),
+                                  np.concatenate([gf, gx], 1))
+    np.testing.assert_array_equal(qg(_dev(xyz, device), _dev(new_xyz, device)).cpu().numpy(), gx)
+    np.testing.assert_array_equal(pn.QueryAndGroup(0.2, 16, use_xyz=False)(_dev(xyz, device), _dev(new_xyz, device),
+                                                                           _dev(feat, device)).cpu().numpy(), gf)
+    ga = pn.GroupAll(use_xyz=True)(_dev(xyz, device), None, _dev(feat, device)).cpu().numpy()
+    np.testing.assert_array_equal(ga, np.concatenate([xyz.transpose(0, 2, 1), feat], 1)[:, :, None])
