@@ -62,9 +62,9 @@ def get_config(args, save: bool = True) -> dict:
     return cfg
 
 
-def make_config(obj_category="1", obj_config="obj_info_nocs.yml", **overrides) -> dict:
+def make_config(obj_category="1", obj_config="obj_info_nocs.yml", config="config_track.yml", **overrides) -> dict:
     """Programmatic equivalent of get_config for tests / bench: no argparse, no directories."""
-    cfg = copy.deepcopy(_load(pjoin("all_config", "config_track.yml")))
+    cfg = copy.deepcopy(_load(pjoin("all_config", config)))
     cfg["obj_category"] = str(obj_category)
     cfg["obj_config"] = obj_config
     for key, item in overrides.items():

@@ -65,3 +65,27 @@ class PoseExchange:
             self.handle.wait()
             self.handle = None
         return self.gathered
+
+
+def allreduce_gradients(params, world: int, bucket_bytes: int = 32 << 20) -> None:
+    """Data-parallel training step: average the gradients of `params` over the ranks, in flat buckets
+    of ~bucket_bytes so that the 3.9 M parameters of a CAPTRA net (15.8 MB fp32) travel as ONE ring all-reduce over xGMI —
+    per-tensor collectives would pay the ring's latency 190 times.  No-op for world == 1."""
+    if world == 1:
+        return
+    import torch.distributed as dist
+    grads = [p.grad for p in params if p.grad is not None]
+    start = 0
+    while start < len(grads):
+        end, size = start, 0
+        while end < len(grads) and (size == 0 or size + grads[end].numel() * grads[end].element_size() <= bucket_bytes):
+            size += grads[end].numel() * grads[end].element_size()
+            end += 1
+        flat = torch.cat([g.reshape(-1) for g in grads[start:end]])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat /= world
+        offset = 0
+        for g in grads[start:end]:
+            g.copy_(flat[offset:offset + g.numel()].view_as(g))
+            offset += g.numel()
+        start = end

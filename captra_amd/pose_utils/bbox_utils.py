@@ -89,3 +89,23 @@ def eval_single_part_iou(gt_corners, pred_corners, gt_pose: dict, pred_pose: dic
     return {"npcs_iou": part_iou([gt_box], pred_box, nocs),
             "iou": part_iou(gt_posed, pose_box(pred_pose, pred_box), nocs),
             "gt_bbox_iou": part_iou(gt_posed, pose_box(pred_pose, gt_box), nocs)}
+
+
+# ---- tensor versions used by the training losses (reference bbox_utils.py:64-72, 88-92) ------------------------------
+def tensor_bbox_from_corners(corners, device=None):
+    """(..., 2, 3) [min; max] -> (..., 8, 3) corner points (same order as bbox_from_corners), torch."""
+    import torch
+    c = corners if isinstance(corners, torch.Tensor) else torch.as_tensor(np.asarray(corners)).float()
+    if device is not None:
+        c = c.to(device)
+    pts = [torch.stack([c[..., (i % 4) // 2, 0], c[..., i // 4, 1], c[..., i % 2, 2]], dim=-1) for i in range(8)]
+    return torch.stack(pts, dim=-2)
+
+
+def yaxis_from_corners(corners, device=None):
+    """Symmetric objects are compared along their axis only: the two corners with x and z zeroed, (..., 2, 3)."""
+    import torch
+    c = corners if isinstance(corners, torch.Tensor) else torch.as_tensor(np.asarray(corners)).float()
+    if device is not None:
+        c = c.to(device)
+    return c * torch.tensor((0.0, 1.0, 0.0), device=c.device).reshape((1,) * (c.dim() - 1) + (3,))

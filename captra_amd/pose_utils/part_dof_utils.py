@@ -3,7 +3,8 @@
 Mirrors the used subset of the reference's pose_utils/part_dof_utils.py:
 `part_model_batch_to_part` (l.70-75), `add_noise_to_part_dof` (l.78-98),
 `merge_reenact_canon_part_pose` (l.124-134), `convert_pred_rtvec_to_matrix` (l.137-141),
-`eval_part_full` (l.54-67, the 5°5cm accuracy gate).
+`eval_part_full` (l.54-67, the 5°5cm accuracy gate), and for the training step `pose_with_part` (l.101-117),
+`compute_parts_delta_pose` (l.144-159).
 A part pose is a dict {'rotation' (B,P,3,3), 'translation' (B,P,3,1), 'scale' (B,P)}.
 """
 from __future__ import annotations
@@ -57,6 +58,29 @@ def merge_reenact_canon_part_pose(part_dof: dict, delta: dict) -> dict:
         pose["translation"] = part_dof["translation"] + part_dof["scale"][..., None, None] * torch.matmul(
             part_dof["rotation"], delta["trans"].unsqueeze(-1))
     return pose
+
+
+def pose_with_part(model: dict, src: torch.Tensor) -> torch.Tensor:
+    """Canonical points (B,P,K,3) posed by each part's (s, R, t): s * (src R^T) + t^T."""
+    est = torch.matmul(src, model["rotation"].transpose(-1, -2)) * model["scale"][..., None, None]
+    return est + model["translation"].transpose(-1, -2)
+
+
+def compute_parts_delta_pose(init: dict, final: dict, canon: dict) -> dict:
+    """The pose update that takes `init` to `final`, expressed in the frame of `canon` (the supervision target of the
+    per-point rotation loss): init / final (B,P,…), canon (B,…) or (B,P,…)."""
+    if canon["scale"].dim() < final["scale"].dim():
+        canon = {k: v.unsqueeze(1) for k, v in canon.items()}
+    s0, sf, sc = init["scale"], final["scale"], canon["scale"]
+    t0, tf, tc = init["translation"], final["translation"], canon["translation"]
+    r0, rf, rc = init["rotation"], final["rotation"], canon["rotation"]
+    s_delta = sf / s0
+    r_delta = torch.matmul(torch.matmul(rc.transpose(-1, -2), rf), torch.matmul(r0.transpose(-1, -2), rc))
+    t = tf - tc
+    if (t0 - tc).max() > 1e-7:
+        t = t - s_delta[..., None, None] * torch.matmul(torch.matmul(rf, r0.transpose(-1, -2)), t0 - tc)
+    t_delta = torch.matmul(rc.transpose(-1, -2), t) / sc[..., None, None]
+    return {"scale": s_delta, "rotation": r_delta, "translation": t_delta}
 
 
 def convert_pred_rtvec_to_matrix(pred: torch.Tensor, sym: bool) -> torch.Tensor:

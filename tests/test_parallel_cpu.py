@@ -88,3 +88,38 @@ def test_trajectory_npz_roundtrip(tmp_path):
         for p0, p1 in zip(f0["meta"]["nocs2camera"], f1["meta"]["nocs2camera"]):
             for k in ("rotation", "translation", "scale"):
                 np.testing.assert_array_equal(p0[k].numpy(), p1[k].numpy())
+
+
+def _grad_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from captra_amd.parallel import allreduce_gradients
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        shapes = [(7, 3), (5,), (2, 2, 2), (1,), (300,)]
+        params = [torch.nn.Parameter(torch.zeros(s)) for s in shapes] + [torch.nn.Parameter(torch.zeros(3))]   # last: no grad
+        for i, (p, s) in enumerate(zip(params, shapes)):
+            p.grad = torch.full(s, float(rank + 1)) * (i + 1) + torch.arange(p.numel(), dtype=torch.float32).reshape(s)
+        allreduce_gradients(params, world, bucket_bytes=64)          # tiny buckets: several collectives, ragged packing
+        for i, (p, s) in enumerate(zip(params, shapes)):
+            exp = torch.full(s, sum(r + 1 for r in range(world)) / world) * (i + 1) + torch.arange(p.numel(), dtype=torch.float32).reshape(s)
+            assert torch.allclose(p.grad, exp), (i, p.grad, exp)
+        assert params[-1].grad is None
+        ret[rank] = True
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradient_allreduce_gloo_world2():
+    """The data-parallel training step's gradient exchange (bucketed flat all-reduce + average) on 2 CPU ranks."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+    assert all(p.exitcode == 0 for p in procs) and dict(ret) == {0: True, 1: True}
