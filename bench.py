@@ -22,6 +22,7 @@ cores of rank 0 at N=1 on a bounded sample of the same workload at batch 1.
 from __future__ import annotations
 
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -159,14 +160,37 @@ def hbm_ops_roofline(batch: int, device, reps: int = 5):
             for c in chans:
                 nbytes["group_points"] += B * (4.0 * c * n + 4.0 * m * k + 4.0 * c * m * k)
 
-    def run():
+    def run(multi=False):
+        done = set()
         for (n, m, r, k, new_xyz, xyz_l, idx, feats, outs, chans) in work:
-            pc.ball_query_wrapper(B, n, m, r, k, new_xyz, xyz_l, idx)
+            if not multi:
+                pc.ball_query_wrapper(B, n, m, r, k, new_xyz, xyz_l, idx)
+            elif n not in done:      # one scan per level for all its radii (captra_ball_query_multi, what the host mirror calls)
+                done.add(n)
+                lvl = [w for w in work if w[0] == n]
+                radii = (ctypes.c_float * len(lvl))(*[w[2] for w in lvl])
+                ks = (ctypes.c_int * len(lvl))(*[w[3] for w in lvl])
+                ptrs = (ctypes.c_void_p * len(lvl))(*[w[6].data_ptr() for w in lvl])
+                _lib.call("captra_ball_query_multi", B, n, m, len(lvl), ctypes.cast(radii, ctypes.c_void_p), ctypes.cast(ks, ctypes.c_void_p),
+                          new_xyz.data_ptr(), xyz_l.data_ptr(), ctypes.cast(ptrs, ctypes.c_void_p))
             for c in chans:
                 pc.group_points_wrapper(B, c, n, m, k, feats[c], idx, outs[c])
 
     run()
     torch.cuda.synchronize()
+    ref_idx = [w[6].clone() for w in work]
+    for w in work:
+        w[6].zero_()
+    run(multi=True)
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, w[6]) for a, w in zip(ref_idx, work)), "multi-radius ball query differs from the single-radius op"
+    _lib.prof_reset()
+    _lib.prof_enable(True)
+    for _ in range(reps):
+        run(multi=True)
+    torch.cuda.synchronize()
+    _lib.prof_enable(False)
+    ms_multi = {k: _lib.prof_read(k)[0] / reps for k in nbytes}
     _lib.prof_reset()
     _lib.prof_enable(True)
     for _ in range(reps):
@@ -179,6 +203,9 @@ def hbm_ops_roofline(batch: int, device, reps: int = 5):
            "achieved": round(tot_b / (tot_ms * 1e-3) / 1e9, 1), "frac": round(tot_b / (tot_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
            "bytes_per_frame": round(tot_b / B), "us_per_frame": round(1e3 * tot_ms / B, 2),
            "ops": {k: {"GB/s": round(nbytes[k] / (ms[k] * 1e-3) / 1e9, 1), "ms": round(ms[k], 3)} for k in nbytes},
+           "multi_radius": {"frac": round(tot_b / (sum(ms_multi.values()) * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                            "ball_query_ms": round(ms_multi["ball_query"], 3), "group_points_ms": round(ms_multi["group_points"], 3),
+                            "note": "same job with captra_ball_query_multi: one scan per level serves all its radii (identical lists)"},
            "note": "drop-in captra_ball_query + captra_group_points on the SA1/SA2 shapes of one frame (both nets), materialised-op bytes; "
                    "not part of the timed step (the fused SA kernels never materialise the grouped tensor)"}
     return out
