@@ -57,6 +57,15 @@ def main():
         timed(lambda: nocs_otf.full_data_batch(items, 4096), f"crop kernel + one ragged sampling launch per step, {tag}")
     _lib.lib().captra_fps_set_pruned_min(ctypes.c_int(8192))
     timed(lambda: [nocs_otf.crop_candidates(d, m, c, r, 4096) for d, m, c, r, _ in items], "candidate extraction alone (torch ops, host syncs)")
+    _lib.prof_reset()
+    _lib.prof_enable(True)
+    for _ in range(args.iters):
+        nocs_otf.full_data_batch(items, 4096)
+    torch.cuda.synchronize()
+    _lib.prof_enable(False)
+    for name in ("crop_ball", "fps"):
+        ms, n = _lib.prof_read(name)
+        print(f"  kernel {name:10s} {ms / max(n, 1):7.3f} ms per launch ({n} launches; HIP events on the launch stream)")
 
 
 if __name__ == "__main__":
