@@ -153,6 +153,14 @@ def test_fps_pruned_duplicate_padded_cloud(device):
     idx, _, _ = fused.fps_gather(_dev(xyz, device), 4096)
     np.testing.assert_array_equal(idx.cpu().numpy(), ref)
     assert (ref[0, 2500:] == 0).all() and len(set(ref[0, :2500])) == 2500
+    # degenerate: every point the same (zero-extent bounding box, one Morton cell, every distance 0) -> index 0 forever
+    same = np.tile(np.array([[0.3, -0.2, 0.9]], np.float32), (1, 8193, 1))
+    idx, n3, _ = fused.fps_gather(_dev(same, device), 40)
+    assert (idx.cpu().numpy() == 0).all() and np.array_equal(n3.cpu().numpy(), same[:, :40])
+    # two distinct points among thousands of copies of one of them, and a point count that is not a multiple of 64
+    mixed = same.copy()
+    mixed[0, 5000] = (0.4, -0.2, 0.9)
+    np.testing.assert_array_equal(fused.fps_gather(_dev(mixed, device), 5)[0].cpu().numpy(), O.furthest_point_sample(mixed, 5))
 
 
 def test_fps_gather_ragged_batch(device):
