@@ -44,9 +44,16 @@ PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec
 
 WORKLOADS = {  # name: (obj_category, obj_config, synthetic trajectory kind, description)
     "bottle": ("1", "obj_info_nocs.yml", "nocs", "NOCS-REAL275-shaped rigid category 'bottle' (1 part, symmetric)"),
+    "bowl": ("2", "obj_info_nocs.yml", "nocs", "NOCS-REAL275-shaped rigid category 'bowl' (1 part, symmetric)"),
     "camera": ("3", "obj_info_nocs.yml", "nocs", "NOCS-REAL275-shaped rigid category 'camera' (1 part, non-symmetric)"),
+    "can": ("4", "obj_info_nocs.yml", "nocs", "NOCS-REAL275-shaped rigid category 'can' (1 part, symmetric)"),
+    "laptop": ("5", "obj_info_nocs.yml", "nocs", "NOCS-REAL275-shaped rigid category 'laptop' (1 part, non-symmetric)"),
+    "mug": ("6", "obj_info_nocs.yml", "nocs", "NOCS-REAL275-shaped rigid category 'mug' (1 part, non-symmetric)"),
     "drawers": ("drawers", "obj_info_sapien.yml", "arti", "SAPIEN-shaped articulated category 'drawers' (4 parts)"),
 }
+
+
+MIX6 = ["bottle", "bowl", "camera", "can", "laptop", "mug"]
 
 
 def build_workload(batch: int, device, frames: int = 8, category: str = "bottle"):
@@ -243,9 +250,13 @@ def main():
     ap.add_argument("--mlp-dtype", default="fp32", choices=["fp32", "bf16"],
                     help="fp32 = the metric's configuration (exact); bf16 = bf16 MFMA operands / fp32 accumulation for the shared "
                          "MLPs (BASELINE.json configs[2]'s arithmetic) -- reported with dtype \"bf16\", not the headline")
-    ap.add_argument("--category", default="bottle", choices=sorted(WORKLOADS),
-                    help="bottle = BASELINE.json configs[1] (the metric's configuration); camera / drawers: the other object classes")
+    ap.add_argument("--category", default="bottle", choices=sorted(WORKLOADS) + ["mix6"],
+                    help="bottle = BASELINE.json configs[1] (the metric's configuration); the other object classes; mix6 = "
+                         "BASELINE.json configs[2]'s serving mix: rank r tracks NOCS category 1 + r mod 6 with that category's weights")
     args = ap.parse_args()
+    if args.category == "mix6":
+        args.category = MIX6[int(os.environ.get("RANK", "0")) % 6]
+        args.mix6 = True
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -343,7 +354,8 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"{WORKLOADS[args.category][3]}, 4096 pts/frame, batch={B} trajectories per GPU, "
                                + ("fp32" if args.mlp_dtype == "fp32" else "bf16 MFMA operands / fp32 accumulation in the shared MLPs (BASELINE.json configs[2]'s arithmetic; NOT the metric's configuration)")
-                               + (" (BASELINE.json configs[1])" if args.category == "bottle" and args.mlp_dtype == "fp32" else " (BASELINE.json configs[3]: drawers)" if args.category == "drawers" else ""),
+                               + (" (BASELINE.json configs[2]'s mix: rank r serves NOCS category 1 + r mod 6; rank 0's workload named here)" if getattr(args, "mix6", False)
+                                  else " (BASELINE.json configs[1])" if args.category == "bottle" and args.mlp_dtype == "fp32" else " (BASELINE.json configs[3]: drawers)" if args.category == "drawers" else ""),
                    "points": 4096, "trajectories_per_gpu": B, "parallelism": f"dp{world} (trajectory-sharded, RCCL all-gather of poses)",
                    "weights": f"random-init default_rng(7), real architecture ({sum(v.numel() for v in sd.values()) / 1e6:.2f} M params incl. BN statistics)",
                    "launch": "hipGraph replay of the step" if graph is not None else "eager launches"},
