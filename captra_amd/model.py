@@ -168,16 +168,12 @@ class EvalTrackModel(BaseModel):
         centers = last_pose["translation"][:, self.root].reshape(B, 3).double().cpu().numpy()
         scales = last_pose["scale"][:, self.root].reshape(B).double().cpu().numpy()
         gt = {k: v[:, self.root].double().cpu().numpy() for k, v in input["gt_part"].items()}
-        pts, lab, nocs = [], [], []
-        fulls = full_data_batch([(pre["depth"][b], pre["mask"][b], centers[b], self.radius * float(scales[b]),
-                                  {k: gt[k][b] for k in gt}) for b in range(B)], N)     # one sampling launch for the step
-        for b, full in enumerate(fulls):
-            pts.append((full["points"].float() - npcs["points_mean"][b].reshape(1, 3)).t())
-            lab.append(full["labels"])
-            nocs.append(full["nocs"].float().t())
-        input["points"] = torch.stack(pts).contiguous()
-        input["labels"] = torch.stack(lab).contiguous()
-        npcs["points"], npcs["labels"], npcs["nocs"] = input["points"], input["labels"], torch.stack(nocs).contiguous()
+        full = full_data_batch([(pre["depth"][b], pre["mask"][b], centers[b], self.radius * float(scales[b]),
+                                 {k: gt[k][b] for k in gt}) for b in range(B)], N, stacked=True)   # one crop + one sampling launch
+        input["points"] = (full["points"].float() - npcs["points_mean"].reshape(B, 1, 3)).transpose(1, 2).contiguous()
+        input["labels"] = full["labels"].contiguous()
+        npcs["points"], npcs["labels"] = input["points"], input["labels"]
+        npcs["nocs"] = full["nocs"].float().transpose(1, 2).contiguous()
 
     def forward(self, save=False):
         pred_poses = [self._initial_pose()]

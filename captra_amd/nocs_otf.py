@@ -147,16 +147,23 @@ def _full_data_batch_torch(frames, num_points: int, intrinsics) -> list:
     return out
 
 
-def full_data_batch(frames, num_points: int, intrinsics=NOCS_REAL_INTRINSICS, use_kernel: bool = True) -> list:
+def stack_full_data(items: list) -> dict:
+    """list of per-instance dicts -> {'points' (B,N,3), 'labels' (B,N), 'nocs' (B,N,3)}."""
+    return {k: torch.stack([it[k] for it in items]) for k in ("points", "labels", "nocs")}
+
+
+def full_data_batch(frames, num_points: int, intrinsics=NOCS_REAL_INTRINSICS, use_kernel: bool = True, stacked: bool = False):
     """The re-crop of ALL trajectories of a tracking step: one crop launch (captra_crop_ball, a workgroup per instance),
     one host round trip for the member counts, one furthest-point-sampling launch (captra_fps_gather_ragged).
     frames: list of (depth, mask, center, radius, gt_pose) -> list of full_data_from_depth's dicts, as if it had been
     called once per trajectory in list order (the thinning permutations are drawn in that order; nothing else draws).
-    Instances on a rare path — fewer than 10 ball members (radius growth), more than CROP_CAP — take the torch path."""
+    Instances on a rare path — fewer than 10 ball members (radius growth), more than CROP_CAP — take the torch path.
+    stacked=True returns one dict of (B, …) tensors instead of the list (no per-instance slicing when nothing was rare)."""
     from . import _lib as L, fused
     dev = frames[0][0].device
     if not use_kernel or dev.type != "cuda":
-        return _full_data_batch_torch(frames, num_points, intrinsics)
+        res = _full_data_batch_torch(frames, num_points, intrinsics)
+        return stack_full_data(res) if stacked else res
     B = len(frames)
     depth = torch.stack([f[0] for f in frames]).to(torch.int32).contiguous()
     mask = torch.stack([f[1] for f in frames]).to(torch.uint8).contiguous()
@@ -178,7 +185,7 @@ def full_data_batch(frames, num_points: int, intrinsics=NOCS_REAL_INTRINSICS, us
 
     # host: the candidate list of every instance as indices into its member table (list doubling = index modulo count,
     # thinning = a prefix of numpy's permutation), in trajectory order because the permutations consume numpy's generator
-    members, slow = [None] * B, {}
+    lengths, perms, slow = [0] * B, {}, {}
     for b in range(B):
         c = int(n_members[b])
         if c < 10 or c > CROP_CAP:
@@ -187,18 +194,26 @@ def full_data_batch(frames, num_points: int, intrinsics=NOCS_REAL_INTRINSICS, us
         length = c
         while length < num_points:
             length *= 2
-        j = np.random.permutation(length)[:5 * num_points] if length > 5 * num_points else np.arange(length)
-        members[b] = (j % c).astype(np.int64)
-    fast = [b for b in range(B) if members[b] is not None]
+        if length > 5 * num_points:
+            perms[b] = np.random.permutation(length)[:5 * num_points]
+            length = 5 * num_points
+        lengths[b] = length
+    fast = [b for b in range(B) if lengths[b] > 0]
     out = [None] * B
     if fast:
-        lens = [len(members[b]) for b in fast]
-        table = np.zeros((len(fast), max(lens)), np.int64)
+        lens = [lengths[b] for b in fast]
+        cnt_f = counts[fast, 0].long() if len(fast) < B else counts[:, 0].long()
+        # candidate j of an instance = member (j mod count): computed on the device (no table upload); only a thinned
+        # list needs its permutation prefix from the host
+        table_d = torch.arange(max(lens), device=dev).unsqueeze(0) % cnt_f.unsqueeze(1)
         for i, b in enumerate(fast):
-            table[i, :lens[i]] = members[b]
-        table_d = torch.from_numpy(table).to(dev)
-        fidx = torch.tensor(fast, device=dev)
-        pts_f, obj_f = pts[fidx], obj[fidx]
+            if b in perms:
+                table_d[i, :lens[i]] = torch.from_numpy(perms[b]).to(dev) % cnt_f[i]
+        if len(fast) == B:
+            pts_f, obj_f = pts, obj
+        else:
+            fidx = torch.tensor(fast, device=dev)
+            pts_f, obj_f = pts[fidx], obj[fidx]
         cand = torch.gather(pts_f, 1, table_d.unsqueeze(-1).expand(-1, -1, 3)).float()
         res = fused.fps_gather(cand, num_points, n_per_cloud=torch.tensor(lens, dtype=torch.int32, device=dev))
         sel = torch.gather(table_d, 1, res[0].long())                                             # (F, N) member numbers
@@ -209,10 +224,12 @@ def full_data_batch(frames, num_points: int, intrinsics=NOCS_REAL_INTRINSICS, us
         scale = torch.from_numpy(np.array([float(np.asarray(frames[b][4]["scale"], np.float64).reshape(-1)[0]) for b in fast])).to(dev)
         nocs = torch.where(O.unsqueeze(-1), torch.bmm((P - trans) / scale.reshape(-1, 1, 1), rot), torch.zeros_like(P))
         labels = 1 - O.long()
+        if stacked and len(fast) == B:
+            return {"points": P, "labels": labels, "nocs": nocs}
         for i, b in enumerate(fast):
             out[b] = {"points": P[i], "labels": labels[i], "nocs": nocs[i]}
     for b, (p_all, raw_mask, idx, perm) in slow.items():
         picked = _device_fps(_candidate_cloud(p_all, idx, perm), num_points)
         sel_b = idx[perm[picked] if perm is not None else picked]
         out[b] = _full_data(p_all[sel_b], raw_mask[sel_b], frames[b][4])
-    return out
+    return stack_full_data(out) if stacked else out

@@ -68,5 +68,42 @@ def main():
         print(f"  kernel {name:10s} {ms / max(n, 1):7.3f} ms per launch ({n} launches; HIP events on the launch stream)")
 
 
+def track_loop(batch: int, frames: int = 6):
+    """The whole tracking loop with nocs_otf on (EvalTrackModel.forward: re-crop + hipGraph step per frame) vs off."""
+    from captra_amd.configs import make_config
+    from captra_amd.trainer import Trainer
+    from tests import clouds
+    from tests.weights import make_state_dict
+    dev = torch.device("cuda:0")
+    for otf in (False, True):
+        cfg = make_config("1", experiment_dir="/tmp/captra_otf_bench", nocs_otf=otf, **{"init_frame/gt": True})
+        cfg["device"] = dev
+        trainer = Trainer(cfg)
+        trainer.model.load_state_dict(make_state_dict({k: tuple(v.shape) for k, v in trainer.model.state_dict().items()}, seed=7))
+        trainer.model.use_graph = True
+        data = clouds.make_trajectory("nocs", batch, frames, seed=0)
+        depth, mask, center, pose = make_frame(1)
+        for f in data:
+            f["meta"]["pre_fetched"] = {"depth": torch.from_numpy(np.stack([depth.astype(np.int32)] * batch)).to(dev),
+                                        "mask": torch.from_numpy(np.stack([mask] * batch)).to(dev)}
+            for p in f["meta"]["nocs2camera"]:
+                p["rotation"] = torch.from_numpy(np.stack([pose["rotation"]] * batch)).float()
+                p["translation"] = torch.from_numpy(np.stack([pose["translation"]] * batch)).float()
+                p["scale"] = torch.full((batch,), float(pose["scale"]))
+        np.random.seed(0)
+        best = None
+        for rep in range(3):
+            trainer.model.eval()
+            trainer.model.set_data(data)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            trainer.model.test(save=False, no_eval=True)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / (frames - 1)
+            best = dt if best is None or dt < best else best
+        print(f"EvalTrackModel loop, nocs_otf={otf}: {best * 1e3:7.2f} ms per step of {batch} trajectories = {batch / best:7.0f} frames/s", flush=True)
+
+
 if __name__ == "__main__":
     main()
+    track_loop(32)
