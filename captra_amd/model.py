@@ -24,7 +24,7 @@ import torch
 import torch.nn as nn
 
 from .networks import CoordNet, PartCanonNet
-from .pose_utils.part_dof_utils import add_noise_to_part_dof, eval_part_full, part_model_batch_to_part
+from .pose_utils.part_dof_utils import add_noise_to_part_dof, consume_noise_draws, eval_part_full, part_model_batch_to_part
 from .utils import Timer, add_dict, cvt_torch, divide_dict, ensure_dirs, get_ith_from_batch
 
 
@@ -187,7 +187,7 @@ class EvalTrackModel(BaseModel):
                     continue
                 # the reference draws (and discards) a perturbed pose every frame (model.py:414);
                 # draw it too so that seeded runs consume the generator identically
-                add_noise_to_part_dof(self.feed_dict[i - 1]["gt_part"], self.pose_perturb_cfg)
+                consume_noise_draws(self.feed_dict[i - 1]["gt_part"], self.pose_perturb_cfg)
                 last_pose = {k: v.clone() for k, v in pred_poses[-1].items()}
                 if self.nocs_otf:
                     self._recrop(i, input, last_pose)

@@ -47,6 +47,21 @@ def add_noise_to_part_dof(part: dict, cfg: dict) -> dict:
     return out
 
 
+def consume_noise_draws(part: dict, cfg: dict) -> None:
+    """The random draws of add_noise_to_part_dof on a pose of this shape, and nothing else: the track loop's reference draws a
+    perturbed pose every frame and never uses it (model.py:414-420); seeded runs must consume the generator identically,
+    but the pose algebra and its five host-to-device copies per frame need not happen."""
+    rand = torch.randn if cfg["type"] == "normal" else torch.rand
+    if cfg["type"] not in ("normal", "uniform"):
+        raise ValueError(cfg["type"])
+    bp = tuple(part["scale"].shape)
+    rand(bp)                # rotation angle            (noisy_rot_matrix)
+    torch.randn(bp + (4,))  # jitter quaternion         (generate_random_quaternion: always normal)
+    rand(bp)                # scale
+    rand(bp)                # translation norm
+    rand(bp + (3,))         # translation direction
+
+
 def merge_reenact_canon_part_pose(part_dof: dict, delta: dict) -> dict:
     """Apply a canonical-frame delta to a pose: R = R_prev ΔR (and s, t when present)."""
     pose = {k: v.clone() for k, v in part_dof.items()}
