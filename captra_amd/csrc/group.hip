@@ -8,6 +8,10 @@
 // reads each idx quad ONCE, gathers the cc rows from LDS and writes 16-byte coalesced stores.
 #include "common.h"
 
+// scatter_reduce.hip: CSR inversion of an index list + per-source-point sums (-2: shape outside that path)
+int captra_scatter_reduce(bool interp, int b, int c, int n_src, long long npos, const float *grad_out, const float *weight,
+                          const int *idx, float *grad_points, hipStream_t s);
+
 namespace {
 
 constexpr int GP_THREADS = 256;
@@ -148,6 +152,10 @@ int launch_group_grad(int b, int c, int n, long long npos, const float *grad_out
                       float *grad_points, hipStream_t s) {
     if (b < 0 || c < 0 || n < 0 || npos < 0) return -1;
     if (b == 0 || c == 0 || npos == 0) return 0;
+    if (c >= 8) {   // many channels share one index list: invert it once, then sum per source point (scatter_reduce.hip)
+        const int rc = captra_scatter_reduce(false, b, c, n, npos, grad_out, nullptr, idx, grad_points, s);
+        if (rc != -2) return rc;
+    }
     dim3 grid((unsigned)((npos + GP_THREADS - 1) / GP_THREADS), c < 64 ? c : 64, b);
     CAPTRA_LAUNCH("group_points_grad", group_points_grad_kernel, grid, dim3(GP_THREADS), 0, s, c, n, npos,
                   grad_out, idx, grad_points);

@@ -15,6 +15,10 @@
 
 #include <math.h>
 
+// scatter_reduce.hip
+int captra_scatter_reduce(bool interp, int b, int c, int n_src, long long npos, const float *grad_out, const float *weight,
+                          const int *idx, float *grad_points, hipStream_t s);
+
 namespace {
 
 constexpr int NN_THREADS = 256;
@@ -240,6 +244,10 @@ extern "C" int captra_three_interpolate_grad(int b, int c, int n, int m, const f
                                              captra_stream_t stream) {
     if (b < 0 || c < 0 || m < 0 || n < 0) return -1;
     if (b == 0 || c == 0 || n == 0) return 0;
+    if (c >= 8) {   // positions (n, j) grouped by the known point they read: per-point sums instead of 3 float atomics per (channel, n)
+        const int rc = captra_scatter_reduce(true, b, c, m, 3ll * n, grad_out, weight, idx, grad_points, (hipStream_t)stream);
+        if (rc != -2) return rc;
+    }
     dim3 grid((n + TI_THREADS - 1) / TI_THREADS, c < 64 ? c : 64, b);
     CAPTRA_LAUNCH("three_interpolate_grad", three_interpolate_grad_kernel, grid, dim3(TI_THREADS), 0,
                   (hipStream_t)stream, c, n, m, grad_out, idx, weight, grad_points);

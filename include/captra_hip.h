@@ -51,7 +51,9 @@ int captra_group_points(int b, int c, int n, int npoints, int nsample, const flo
                         const int *idx, float *out, captra_stream_t stream);
 
 /* Replaces group_points_grad_wrapper (group_points.cpp:11-22, kernel group_points_gpu.cu:8-25).
- * grad_out (B,C,npoints,nsample), idx -> grad_points (B,C,N) += scatter (caller pre-zeroes). */
+ * grad_out (B,C,npoints,nsample), idx -> grad_points (B,C,N) += scatter (caller pre-zeroes).  For C >= 8 and N <= 16384 the
+ * index list is inverted once (CSR, stream-ordered scratch from hipMallocAsync) and every source point sums its own list in
+ * ascending position order: no float atomics, bit-reproducible; otherwise atomicAdd like the reference. */
 int captra_group_points_grad(int b, int c, int n, int npoints, int nsample, const float *grad_out,
                              const int *idx, float *grad_points, captra_stream_t stream);
 
