@@ -55,8 +55,6 @@ __global__ __launch_bounds__(BQ_WAVES * 64) void ball_query_kernel(int n, int m,
     const float *xyz = xyz_all + (size_t)b * n * 3;
     const float *new_xyz = new_xyz_all + (size_t)b * m * 3;
     const int c_base = (blockIdx.x * BQ_WAVES + wave) * BQ_CPW;
-    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-
     int cnt[BQ_CPW][NR];
     int first[BQ_CPW][NR];
 #pragma unroll
@@ -111,10 +109,13 @@ __global__ __launch_bounds__(BQ_WAVES * 64) void ball_query_kernel(int n, int m,
                             const bool hit = d2[h] < prm.r2[r];
                             const unsigned long long mask = __ballot(hit);
                             if (mask) {
-                                const int pos = cnt[ci][r] + __popcll(mask & lt_mask);
+                                // rank of this lane among the hits = hits in lower lanes (v_mbcnt), written through a
+                                // uniform row pointer + unsigned 32-bit slot (scalar base + VGPR offset addressing)
+                                const unsigned pos = (unsigned)cnt[ci][r] +
+                                                     __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
                                 if (cnt[ci][r] == 0) first[ci][r] = k0 + (__ffsll((long long)mask) - 1);
-                                if (hit && pos < prm.ns[r])
-                                    prm.idx[r][((size_t)b * m + c) * prm.ns[r] + pos] = k0 + lane;
+                                int *row = prm.idx[r] + ((size_t)b * m + c) * prm.ns[r];
+                                if (hit && pos < (unsigned)prm.ns[r]) row[pos] = k0 + lane;
                                 cnt[ci][r] += __popcll(mask);
                             }
                             any_open = any_open || (cnt[ci][r] < prm.ns[r]);
