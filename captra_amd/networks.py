@@ -223,8 +223,9 @@ class PartCanonNet(nn.Module):
         pred = self.regress_net(cam_cn, seg_rep, cam_n3=cam_n3, geom=geom)
 
         out = {"rotation": convert_pred_rtvec_to_matrix(pred["rtvec"], self.sym)}       # (B*P,P,3,3)
-        if self.return_point_rotation or not test_mode:
-            # per-point rotations are only consumed by training losses; skipped while tracking
+        if self.return_point_rotation or not test_mode or self.type == "rot":
+            # per-point rotations are only consumed by the RotationNet experiment's losses (training and its evaluation
+            # pass); skipped while tracking
             out["point_rotation"] = convert_pred_rtvec_to_matrix(pred["point_rtvec"].transpose(-1, -2), self.sym)
         diag = torch.arange(P, device=out["rotation"].device)
         for key in list(out.keys()):                                                     # head p on cloud p

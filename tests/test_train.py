@@ -132,3 +132,23 @@ def test_train_cli_one_epoch(device, tmp_path, monkeypatch):
     cfg = make_config("1", config="config_coordnet.yml", experiment_dir=exp)
     cfg["device"] = device
     assert Trainer(cfg).resume() == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", [c[0] for c in CASES])
+def test_trainer_test_pass_vs_reference_gpu(device, tag):
+    """`Trainer.test(data)` of the training experiments (eval-mode networks = the fused inference kernels, predicted labels,
+    the experiment's loss dict) against the reference's on the same seeded batch."""
+    trainer, data = _trainer(tag, device)
+    torch.manual_seed(TORCH_SEED + 1)
+    np.random.seed(TORCH_SEED + 1)
+    _, loss_dict = trainer.test(data)
+    keys = sorted(k.split("/", 2)[2] for k in G.files if k.startswith(f"{tag}/test_loss/"))
+    assert sorted(loss_dict) == keys
+    for k in keys:
+        got = float(loss_dict[k].detach()) if torch.is_tensor(loss_dict[k]) else float(loss_dict[k])
+        ref = float(G[f"{tag}/test_loss/{k}"])
+        if "deg" in k and "cm" in k:
+            assert abs(got - ref) < 1e-6, k              # hit rates: the same poses fall on the same side of 5 deg / 5 cm
+        else:
+            np.testing.assert_allclose(got, ref, rtol=2e-4, atol=5e-3 if "rdiff" in k else 2e-5, err_msg=k)
