@@ -231,11 +231,19 @@ class EvalTrackModel(BaseModel):
             with open(pjoin(save_path, f"{instance}_{track_num}.pkl"), "wb") as f:
                 pickle.dump(get_ith_from_batch(save_dict, i, to_single=False), f)
 
-    def compute_loss(self, per_instance=False):
-        """Pose-error part of the reference's compute_loss (model.py:511-593): rdiff / tdiff / sdiff /
-        5deg5cm per part, averaged over frames 1..T-1, for the prediction and for its initialisation."""
+    def compute_loss(self, test=False, per_instance=False, eval_iou=False, test_prefix=None):
+        """The reference's compute_loss (model.py:511-593): per-part rdiff / tdiff / sdiff / 5deg5cm averaged over frames
+        1..T-1 for the prediction and for its initialisation (= the previous frame's prediction), the segmentation and
+        NOCS losses of CoordinateNet's maps when the frames carry labels / NOCS, and with `eval_iou` the three box IoUs
+        (canonical boxes, posed predicted box, ground-truth box under the predicted pose; host-side numpy as in the
+        reference).  Keys as in the reference, including its quirk of storing the per-frame NOCS losses under
+        'frame_seg'."""
+        from .loss import choose_coord_by_label, compute_miou_loss, compute_nocs_loss
+        from .pose_utils.bbox_utils import eval_single_part_iou
         avg_pred, avg_init, all_pred, all_init = {}, {}, {}, {}
+        avg_iou, all_iou, seg_losses, all_seg, nocs_losses, all_nocs = {}, {}, [], {}, [], {}
         poses = self.pred_dict["poses"]
+        gt_corners = self.feed_dict[0]["meta"]["nocs_corners"].float().cpu().numpy()               # (B,P,2,3)
         for i, pose in enumerate(poses):
             diff, per = eval_part_full(self.feed_dict[i]["gt_part"], pose, per_instance=per_instance, yaxis_only=self.sym)
             all_pred[i] = deepcopy(diff)
@@ -247,13 +255,53 @@ class EvalTrackModel(BaseModel):
             init_diff, _ = eval_part_full(self.feed_dict[i]["gt_part"], poses[i - 1], per_instance=False, yaxis_only=self.sym)
             add_dict(avg_init, init_diff)
             all_init[i] = deepcopy(init_diff)
+            npcs_pred, npcs_feed = self.pred_dict["npcs_pred"][i], self.npcs_feed_dict[i]
+            if npcs_pred is None:
+                continue
+            if "labels" in npcs_feed:
+                all_seg[i] = compute_miou_loss(npcs_pred["seg"], npcs_feed["labels"].long(), per_instance=False)
+                seg_losses.append(all_seg[i])
+            pred_labels = torch.max(npcs_pred["seg"], dim=-2)[1]
+            if "nocs" in npcs_feed:
+                all_nocs[i] = compute_nocs_loss(npcs_pred["nocs"], npcs_feed["nocs"], labels=pred_labels, confidence=None,
+                                                loss="l2", self_supervise=False, per_instance=False)
+                nocs_losses.append(all_nocs[i])
+            if eval_iou:
+                pred_nocs = choose_coord_by_label(npcs_pred["nocs"].transpose(-1, -2), pred_labels).cpu().numpy()   # (B,N,3)
+                lab = pred_labels.cpu().numpy()
+                gt_np = {k: v.cpu().numpy() for k, v in self.feed_dict[i]["gt_part"].items()}
+                pr_np = {k: v.cpu().numpy() for k, v in pose.items()}
+                per_b = []
+                for b in range(len(lab)):
+                    corners = np.zeros((self.num_parts, 2, 3), np.float32)
+                    for p in range(self.num_parts):                       # symmetric extent of the part's predicted NOCS
+                        sel = lab[b] == p
+                        if sel.any():
+                            size = np.abs(pred_nocs[b][sel]).max(axis=0)
+                            corners[p] = np.stack([-size, size])
+                    per_b.append(eval_single_part_iou(gt_corners[b], corners, {k: v[b] for k, v in gt_np.items()},
+                                                      {k: v[b] for k, v in pr_np.items()}, nocs=self.nocs_otf, sym=self.sym))
+                iou = {name: {p: float(np.mean([x[name][p] for x in per_b])) for p in range(self.num_parts)}
+                       for name in ("npcs_iou", "iou", "gt_bbox_iou")}
+                add_dict(avg_iou, iou)
+                if per_instance:
+                    self.record_per_diff(self.feed_dict[i], {name: {p: np.array([x[name][p] for x in per_b]) for p in range(self.num_parts)}
+                                                              for name in ("npcs_iou", "iou", "gt_bbox_iou")})
+                all_iou[i] = deepcopy(iou)
         n = max(len(poses) - 1, 1)
-        self.loss_dict = {"avg_pred": divide_dict(avg_pred, n), "avg_init": divide_dict(avg_init, n),
-                          "frame_pred": all_pred, "frame_init": all_init}
+        loss_dict = {"avg_pred": divide_dict(avg_pred, n), "avg_init": divide_dict(avg_init, n),
+                     "frame_pred": all_pred, "frame_init": all_init}
+        if seg_losses:
+            loss_dict.update({"avg_seg": torch.mean(torch.stack(seg_losses)), "frame_seg": all_seg})
+        if nocs_losses:
+            loss_dict.update({"avg_nocs": torch.mean(torch.stack(nocs_losses)), "frame_seg": all_nocs})
+        if eval_iou:
+            loss_dict.update({"avg_iou": divide_dict(avg_iou, n), "frame_iou": all_iou})
+        self.loss_dict = loss_dict
 
     def test(self, save=False, no_eval=False, epoch=0):
         self.forward(save=save)
         if no_eval:
             self.loss_dict = {}
         else:
-            self.compute_loss(per_instance=save)
+            self.compute_loss(test=True, per_instance=save, eval_iou=True, test_prefix="test")

@@ -63,9 +63,13 @@ def get_ith_from_batch(data, i, to_single=True):
 
 
 def add_dict(total: dict, new: dict) -> None:
+    """total += new, key by key, recursing into nested dicts (reference utils.py:46-70)."""
     for k, v in new.items():
-        total[k] = total[k] + v if k in total else v
+        if isinstance(v, dict):
+            add_dict(total.setdefault(k, {}), v)
+        else:
+            total[k] = total[k] + v if k in total else v
 
 
 def divide_dict(d: dict, n: float) -> dict:
-    return {k: v / n for k, v in d.items()}
+    return {k: divide_dict(v, n) if isinstance(v, dict) else v / n for k, v in d.items()}
