@@ -67,3 +67,37 @@ def test_discarded_noise_draws_consume_the_generator_like_the_real_ones():
         torch.manual_seed(3)
         consume_noise_draws(part, cfg)
         assert torch.equal(a, torch.rand(4)), kind
+
+
+def test_config_dicts_agree_with_the_reference():
+    """captra_amd.configs against the dicts the reference's get_config builds (tests/golden/make_golden_cfg.py) for the three
+    experiment types and rigid / articulated categories: every key this package's configuration carries that the reference
+    also has holds the same value (nested dicts: ours is a sub-dict of theirs — the reference tables also carry dataset
+    bookkeeping and the hyper-parameters of modules outside the path)."""
+    import json
+    from pathlib import Path
+    from captra_amd.configs import make_config
+    ref_all = json.load(open(Path(__file__).resolve().parent / "golden" / "cfg_reference.json"))
+
+    def sub(mine, ref, where):
+        if isinstance(mine, dict) and isinstance(ref, dict):
+            for k, v in mine.items():
+                if k in ref:
+                    sub(v, ref[k], f"{where}/{k}")
+        else:
+            assert mine == ref, (where, mine, ref)
+
+    must_have = ("num_parts", "num_joints", "obj_tree", "obj_sym", "num_points", "data_radius", "network", "pose_perturb",
+                 "batch_size", "pointnet", "obj_info", "obj_category")
+    for key, ref in ref_all.items():
+        config, cat, objcfg = key.split("|")
+        mine = make_config(cat, objcfg, config=config)
+        mine = json.loads(json.dumps({k: v for k, v in mine.items() if k not in ("device", "obj")}, default=str))
+        assert all(k in mine and k in ref for k in must_have), key
+        if config != "config_track.yml":
+            assert all(k in mine for k in ("loss_weight", "pose_loss_type", "optimizer", "learning_rate", "weight_decay", "lr_policy",
+                                           "lr_step_size", "lr_gamma", "lr_clip", "momentum_original", "momentum_decay",
+                                           "momentum_step_size", "momentum_min", "weight_init", "total_epoch", "freq")), key
+        sub({k: v for k, v in mine.items() if k not in ("experiment_dir", "num_expr", "root_dset")}, ref, key)
+        for level in ("sa1", "sa2", "sa3", "fp3", "fp2", "fp1"):
+            assert mine["pointnet"]["camera"][level] == ref["pointnet"]["camera"][level], (key, level)
