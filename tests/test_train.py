@@ -152,3 +152,14 @@ def test_trainer_test_pass_vs_reference_gpu(device, tag):
             assert abs(got - ref) < 1e-6, k              # hit rates: the same poses fall on the same side of 5 deg / 5 cm
         else:
             np.testing.assert_allclose(got, ref, rtol=2e-4, atol=5e-3 if "rdiff" in k else 2e-5, err_msg=k)
+
+
+@pytest.mark.parametrize("tag", [c[0] for c in CASES])
+def test_training_model_state_dict_keys_and_shapes(tag):
+    """Checkpoints of the training experiments are interchangeable with the reference's: same state-dict keys and tensor
+    shapes (captured from the reference's Trainer(cfg).model)."""
+    import json
+    ref = json.load(open(Path(__file__).resolve().parent / "golden" / "state_dict_keys_train.json"))[tag]
+    trainer, _ = _trainer(tag, "cpu")
+    mine = {k: list(v.shape) for k, v in trainer.model.state_dict().items()}
+    assert mine == ref
