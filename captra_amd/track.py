@@ -25,6 +25,7 @@ from os.path import join as pjoin
 import torch
 
 from .configs.config import get_config
+from .parse_args import HARNESS_ONLY, add_args as _add_reference_args, boolean_string  # noqa: F401
 from .trainer import Trainer
 from .trajectory_io import load_trajectory_npz, stack_trajectories
 from .utils import add_dict, ensure_dirs
@@ -38,38 +39,9 @@ def _is_number(v) -> bool:
         return False
 
 
-def boolean_string(s: str) -> bool:
-    if s not in ("True", "False"):
-        raise ValueError("Not a valid boolean string")
-    return s == "True"
-
-
 def add_args(parser: argparse.ArgumentParser) -> argparse.ArgumentParser:
-    """The inference-relevant subset of the reference's flags (parse_args.py:5-69), same names and defaults."""
-    parser.add_argument("--config", type=str, default="config_track.yml")
-    parser.add_argument("--obj_config", type=str, default=None)
-    parser.add_argument("--obj_category", type=str, default=None)
-    parser.add_argument("--experiment_dir", type=str, default=None)
-    parser.add_argument("--resume_epoch", type=int, default=-1)
-    parser.add_argument("--coord_exp/dir", type=str, default=None)
-    parser.add_argument("--coord_exp/resume_epoch", type=int, default=None)
-    parser.add_argument("--batch_size", type=int, default=None)
-    parser.add_argument("--cuda_id", type=int, default=None)
-    parser.add_argument("--num_points", type=int, default=None)
-    parser.add_argument("--network/type", type=str, default=None)
-    parser.add_argument("--network/nocs_head_dims", type=int, default=None)
-    parser.add_argument("--network/backbone_out_dim", type=int, default=None)
-    parser.add_argument("--save", action="store_true", default=False)
-    parser.add_argument("--no_eval", action="store_true", default=False)
-    parser.add_argument("--init_frame/gt", type=boolean_string, default=None)
-    parser.add_argument("--pose_perturb/type", type=str, default=None)
-    parser.add_argument("--pose_perturb/r", type=float, default=None)
-    parser.add_argument("--pose_perturb/s", type=float, default=None)
-    parser.add_argument("--pose_perturb/t", type=float, default=None)
-    parser.add_argument("--nocs_otf", type=boolean_string, default=None)
-    parser.add_argument("--track_cfg/gt_label", type=boolean_string, default=None)
-    parser.add_argument("--track_cfg/nocs2d_label", type=boolean_string, default=None)
-    return parser
+    """The reference's flags (parse_args.py:5-69; captra_amd/parse_args.py), tracking configuration by default."""
+    return _add_reference_args(parser, default_config="config_track.yml")
 
 
 def parse_args(argv=None):

@@ -22,20 +22,15 @@ from os.path import join as pjoin
 import torch
 
 from .configs.config import get_config
+from .parse_args import add_args as _add_reference_args
 from .trainer import Trainer
 from .trajectory_io import load_trajectory_npz, stack_trajectories
 from .utils import add_dict
 
 
 def add_args(parser):
-    parser.add_argument("--config", type=str, default="config_coordnet.yml")
-    parser.add_argument("--obj_config", type=str, default=None)
-    parser.add_argument("--obj_category", type=str, default=None)
-    parser.add_argument("--experiment_dir", type=str, default=None)
-    parser.add_argument("--batch_size", type=int, default=None)
-    parser.add_argument("--total_epoch", type=int, default=None)
-    parser.add_argument("--learning_rate", type=float, default=None)
-    parser.add_argument("--cuda_id", type=int, default=None)
+    """The reference's flags (captra_amd/parse_args.py) + the data source of this harness."""
+    _add_reference_args(parser, default_config="config_coordnet.yml")
     parser.add_argument("--data", type=str, default="synthetic")
     parser.add_argument("--samples", type=int, default=48, help="synthetic data: samples per epoch and rank")
     return parser

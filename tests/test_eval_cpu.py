@@ -101,3 +101,29 @@ def test_config_dicts_agree_with_the_reference():
         sub({k: v for k, v in mine.items() if k not in ("experiment_dir", "num_expr", "root_dset")}, ref, key)
         for level in ("sa1", "sa2", "sa3", "fp3", "fp2", "fp1"):
             assert mine["pointnet"]["camera"][level] == ref["pointnet"]["camera"][level], (key, level)
+
+
+def test_harness_flags_are_the_references():
+    """track / train accept every flag of the reference's network/parse_args.py (names captured in the list below from
+    parse_args.py:5-69) and turn `a/b` flags into cfg['a']['b'] overrides."""
+    import argparse
+    from captra_amd import parse_args as pa, track, train
+    reference_flags = """config obj_config obj_category experiment_dir resume_epoch coord_exp/dir coord_exp/resume_epoch batch_size cuda_id
+        total_epoch optimizer weight_decay learning_rate lr_policy lr_gamma lr_step_size lr_clip num_workers num_points data_radius
+        dataset_length freq/save pointnet_cfg/camera network/type network/nocs_head_dims network/backbone_out_dim network/pwm_num save
+        eval_train no_eval init_frame/gt loss_weight/rloss loss_weight/tloss loss_weight/sloss loss_weight/corner_loss
+        loss_weight/nocs_loss loss_weight/nocs_dist_loss loss_weight/nocs_pwm_loss loss_weight/seg_loss pose_loss_type/r pose_loss_type/s
+        pose_loss_type/t pose_loss_type/point pose_perturb/type pose_perturb/r pose_perturb/s pose_perturb/t nocs_otf
+        track_cfg/gt_label track_cfg/nocs2d_label track_cfg/nocs2d_path""".split()
+    for mod in (track, train):
+        parser = mod.add_args(argparse.ArgumentParser())
+        have = {a.dest for a in parser._actions}
+        assert set(reference_flags) <= have, sorted(set(reference_flags) - have)
+    from captra_amd.configs.config import get_config
+    import tempfile
+    ns = pa.add_args(argparse.ArgumentParser(), "config_rotnet.yml").parse_args(
+        ["--obj_category", "3", "--experiment_dir", tempfile.mkdtemp(), "--loss_weight/rloss", "7.5", "--pose_loss_type/r", "l1",
+         "--lr_step_size", "5", "--track_cfg/gt_label", "True", "--freq/save", "3"])
+    cfg = get_config(ns, save=False)
+    assert cfg["loss_weight"]["rloss"] == 7.5 and cfg["pose_loss_type"]["r"] == "l1" and cfg["lr_step_size"] == 5
+    assert cfg["track_cfg"]["gt_label"] is True and cfg["freq"]["save"] == 3 and cfg["loss_weight"]["corner_loss"] == 1.0
