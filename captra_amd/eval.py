@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from .configs.config import get_config
-from .pose_utils.bbox_utils import eval_single_part_iou
+from .pose_utils.bbox_utils import eval_instance_part_iou
 from .pose_utils.metrics import rot_diff_degree
 from .pose_utils.part_dof_utils import eval_part_full
 
@@ -45,7 +45,7 @@ def eval_data(name: str, data: dict, obj_info: dict) -> dict:
         pred = {k: torch.as_tensor(np.asarray(v)) for k, v in data["pred"]["poses"][i].items()}
         _, per = eval_part_full(gt, pred, per_instance=True, yaxis_only=sym)
         row = {k: float(np.asarray(v)) for k, v in per.items()}
-        iou = eval_single_part_iou(gt_corners, np.asarray(data["pred"]["corners"][i]), {k: v.numpy() for k, v in gt.items()},
+        iou = eval_instance_part_iou(gt_corners, np.asarray(data["pred"]["corners"][i]), {k: v.numpy() for k, v in gt.items()},
                                    {k: v.numpy() for k, v in pred.items()}, nocs=rigid, sym=sym)
         row.update({f"iou_{j}": float(v) for j, v in enumerate(iou["iou"])})
         if not rigid:

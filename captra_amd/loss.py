@@ -93,6 +93,16 @@ def compute_miou_loss(pred, labels, per_instance=False):
     return (loss, miou) if per_instance else loss
 
 
+def compute_hard_miou_loss(pred, gt, num_parts, per_instance=False):
+    """IoU of two hard labelings (B,N) with classes 0..num_parts-1, as 1 - mean IoU (reference l.137-148)."""
+    a = torch.eye(num_parts, device=gt.device)[gt]
+    b = torch.eye(num_parts, device=pred.device)[pred]
+    inter = torch.sum(a * b, dim=-2)
+    miou = inter / (torch.sum(a + b, dim=-2) - inter + EPS)
+    loss = 1.0 - torch.mean(miou)
+    return (loss, miou) if per_instance else loss
+
+
 def rot_trace_loss(rot1, rot2, metric="l1"):
     """'frob': squared Frobenius norm of R1 - R2; 'l1' / 'l2': |trace(R1 R2^T) - 3| or its square."""
     if metric == "frob":

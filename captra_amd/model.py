@@ -239,11 +239,11 @@ class EvalTrackModel(BaseModel):
         reference).  Keys as in the reference, including its quirk of storing the per-frame NOCS losses under
         'frame_seg'."""
         from .loss import choose_coord_by_label, compute_miou_loss, compute_nocs_loss
-        from .pose_utils.bbox_utils import eval_single_part_iou
+        from .pose_utils.bbox_utils import eval_single_part_iou, get_pred_nocs_corners
         avg_pred, avg_init, all_pred, all_init = {}, {}, {}, {}
         avg_iou, all_iou, seg_losses, all_seg, nocs_losses, all_nocs = {}, {}, [], {}, [], {}
         poses = self.pred_dict["poses"]
-        gt_corners = self.feed_dict[0]["meta"]["nocs_corners"].float().cpu().numpy()               # (B,P,2,3)
+        gt_corners = self.feed_dict[0]["meta"]["nocs_corners"].float().cpu()                       # (B,P,2,3)
         for i, pose in enumerate(poses):
             diff, per = eval_part_full(self.feed_dict[i]["gt_part"], pose, per_instance=per_instance, yaxis_only=self.sym)
             all_pred[i] = deepcopy(diff)
@@ -267,26 +267,14 @@ class EvalTrackModel(BaseModel):
                                                 loss="l2", self_supervise=False, per_instance=False)
                 nocs_losses.append(all_nocs[i])
             if eval_iou:
-                pred_nocs = choose_coord_by_label(npcs_pred["nocs"].transpose(-1, -2), pred_labels).cpu().numpy()   # (B,N,3)
-                lab = pred_labels.cpu().numpy()
-                gt_np = {k: v.cpu().numpy() for k, v in self.feed_dict[i]["gt_part"].items()}
-                pr_np = {k: v.cpu().numpy() for k, v in pose.items()}
-                per_b = []
-                for b in range(len(lab)):
-                    corners = np.zeros((self.num_parts, 2, 3), np.float32)
-                    for p in range(self.num_parts):                       # symmetric extent of the part's predicted NOCS
-                        sel = lab[b] == p
-                        if sel.any():
-                            size = np.abs(pred_nocs[b][sel]).max(axis=0)
-                            corners[p] = np.stack([-size, size])
-                    per_b.append(eval_single_part_iou(gt_corners[b], corners, {k: v[b] for k, v in gt_np.items()},
-                                                      {k: v[b] for k, v in pr_np.items()}, nocs=self.nocs_otf, sym=self.sym))
-                iou = {name: {p: float(np.mean([x[name][p] for x in per_b])) for p in range(self.num_parts)}
-                       for name in ("npcs_iou", "iou", "gt_bbox_iou")}
+                pred_nocs = choose_coord_by_label(npcs_pred["nocs"].transpose(-1, -2), pred_labels)                 # (B,N,3)
+                pred_corners = torch.from_numpy(get_pred_nocs_corners(pred_labels, pred_nocs, self.num_parts)).float()
+                iou, per_iou = eval_single_part_iou(gt_corners, pred_corners, self.feed_dict[i]["gt_part"], pose,
+                                                    separate="both", nocs=self.nocs_otf, sym=self.sym)
+                iou = {name: {p: float(v) for p, v in d.items()} for name, d in iou.items()}
                 add_dict(avg_iou, iou)
                 if per_instance:
-                    self.record_per_diff(self.feed_dict[i], {name: {p: np.array([x[name][p] for x in per_b]) for p in range(self.num_parts)}
-                                                              for name in ("npcs_iou", "iou", "gt_bbox_iou")})
+                    self.record_per_diff(self.feed_dict[i], per_iou)
                 all_iou[i] = deepcopy(iou)
         n = max(len(poses) - 1, 1)
         loss_dict = {"avg_pred": divide_dict(avg_pred, n), "avg_init": divide_dict(avg_init, n),

@@ -33,6 +33,14 @@ from .pointnet_lib import pointnet2_utils as futils
 # ---------------------------------------------------------------------------------------------
 # functions (same names / argument order as the reference)
 # ---------------------------------------------------------------------------------------------
+def square_distance(src, dst):
+    """(B,N,C), (B,M,C) -> (B,N,M) squared distances in the expanded form |a|^2 + |b|^2 - 2ab (reference l.56-78; plain
+    torch, any device: the reference's CPU path builds its neighbour searches on it — the HIP operators use the direct form)."""
+    dist = -2.0 * torch.matmul(src, dst.transpose(1, 2))
+    dist = dist + torch.sum(src ** 2, dim=-1).unsqueeze(-1)
+    return dist + torch.sum(dst ** 2, dim=-1).unsqueeze(1)
+
+
 def knn_point(k, pos2, pos1):
     """k nearest of pos1 (B,N,3) for every query pos2 (B,M,3) -> (L2 distances (B,M,k), idx long)."""
     val, idx = futils.knn(k, pos2, pos1)

@@ -74,7 +74,7 @@ def part_iou(gt_boxes: list, pred_box: np.ndarray, nocs: bool) -> np.ndarray:
     return np.array([max(fn(g[p], pred_box[p]) for g in gt_boxes) for p in range(pred_box.shape[0])], np.float64)
 
 
-def eval_single_part_iou(gt_corners, pred_corners, gt_pose: dict, pred_pose: dict, nocs: bool = False, sym: bool = False) -> dict:
+def eval_instance_part_iou(gt_corners, pred_corners, gt_pose: dict, pred_pose: dict, nocs: bool = False, sym: bool = False) -> dict:
     """One frame of one instance: corners (P,2,3), poses {'rotation' (P,3,3), 'translation' (P,3,1), 'scale' (P,)}
     -> {'npcs_iou', 'iou', 'gt_bbox_iou'}: (P,) each -- canonical-space boxes, posed predicted box vs posed ground truth,
     and the ground-truth box under the predicted pose vs under the ground-truth pose (reference l.160-198)."""
@@ -109,3 +109,56 @@ def yaxis_from_corners(corners, device=None):
     if device is not None:
         c = c.to(device)
     return c * torch.tensor((0.0, 1.0, 0.0), device=c.device).reshape((1,) * (c.dim() - 1) + (3,))
+
+
+# ---- the reference's batch-level names (bbox_utils.py:75-85, 95-104, 107-125, 128-158, 160-198) --------------------------
+def np_bbox_from_corners(corners):
+    """(..., 2, 3) -> (..., 8, 3) torch tensor (the reference returns a CPU float tensor here despite the name)."""
+    import torch
+    return torch.from_numpy(bbox_from_corners(np.asarray(corners, dtype=np.float32)))
+
+
+def get_posed_bbox_from_part(part_model: dict, corners):
+    """Part poses (B,P,...) tensors + canonical corners (B,P,2,3) -> posed box points (B,P,8,3) numpy array."""
+    from .part_dof_utils import pose_with_part
+    return pose_with_part(part_model, tensor_bbox_from_corners(corners.detach(), corners.device)).detach().cpu().numpy()
+
+
+def get_pred_nocs_corners(pred_seg, nocs_pred, num_parts: int) -> np.ndarray:
+    """Predicted labels (B,N), the points' own-part NOCS (B,N,3) -> (B,P,2,3): per part the symmetric extent
+    [-max|x|, +max|x|] of its points (zeros for an empty part)."""
+    lab = pred_seg.detach().cpu().numpy() if hasattr(pred_seg, "detach") else np.asarray(pred_seg)
+    nocs = nocs_pred.detach().cpu().numpy() if hasattr(nocs_pred, "detach") else np.asarray(nocs_pred)
+    out = np.zeros((len(lab), num_parts, 2, 3), np.float64)
+    for b in range(len(lab)):
+        for p in range(num_parts):
+            sel = lab[b] == p
+            if sel.any():
+                size = np.abs(nocs[b][sel]).max(axis=0)
+                out[b, p] = np.stack([-size, size])
+    return out
+
+
+def calc_part_iou_list(gt_bbox_list, pred_bbox, separate="both", nocs=False):
+    """Best IoU of every predicted part box against the candidate ground-truth boxes: boxes (B,P,8,3) ->
+    ({part: batch mean}, {part: (B,) values}); separate=True / False picks one of the two like the reference."""
+    to_np = lambda x: x if isinstance(x, np.ndarray) else x.detach().cpu().numpy()
+    gts, pred = [to_np(g) for g in gt_bbox_list], to_np(pred_bbox)
+    per = {p: np.array([part_iou([g[b] for g in gts], pred[b], nocs)[p] for b in range(pred.shape[0])]) for p in range(pred.shape[1])}
+    mean = {p: np.mean(v) for p, v in per.items()}
+    return per if separate is True else mean if separate is False else (mean, per)
+
+
+def eval_single_part_iou(gt_corners, pred_corners, gt_pose: dict, pred_pose: dict, separate=False, nocs: bool = False, sym: bool = False):
+    """Batch-level box IoUs, the reference's signature: corners (B,P,2,3) tensors, poses dicts of (B,P,...) tensors ->
+    {'npcs_iou', 'iou', 'gt_bbox_iou'} of {part: value}: batch means (separate=True), per-instance arrays (False) or both."""
+    import torch
+    gc = gt_corners.detach().cpu().numpy()
+    pc = pred_corners.detach().cpu().numpy() if isinstance(pred_corners, torch.Tensor) else np.asarray(pred_corners)
+    g = {k: v.detach().cpu().numpy() for k, v in gt_pose.items()}
+    q = {k: v.detach().cpu().numpy() for k, v in pred_pose.items()}
+    rows = [eval_instance_part_iou(gc[b], pc[b], {k: v[b] for k, v in g.items()}, {k: v[b] for k, v in q.items()}, nocs=nocs, sym=sym)
+            for b in range(len(gc))]
+    per = {name: {p: np.array([r[name][p] for r in rows]) for p in range(gc.shape[1])} for name in ("npcs_iou", "iou", "gt_bbox_iou")}
+    mean = {name: {p: np.mean(v) for p, v in d.items()} for name, d in per.items()}
+    return mean if separate is True else per if separate is False else (mean, per)

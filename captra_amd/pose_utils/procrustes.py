@@ -102,3 +102,38 @@ def transform_pts_mask(source, target, mask, weights, given_scale=None, rotation
     translation = translate_pts_mask(scale.reshape(scale.shape + (1, 1)) * torch.matmul(rotation, source.transpose(-1, -2)),
                                      target.transpose(-1, -2), weights)
     return rotation, scale, translation
+
+
+# ---- unmasked (every point counts) variants of the same API (reference l.59-66, 78-107, 231-243) ----------------------------
+def scale_pts_batch(source, target):
+    """(..., N, 3) x2 -> (...): least-squares scale of source onto target."""
+    return torch.sum(source * target, dim=(-1, -2)) / (torch.sum(source * source, dim=(-1, -2)) + EPS)
+
+
+def translate_pts_batch(source, target):
+    """(..., 3, N) x2 -> (..., 3, 1): mean of target - source."""
+    return torch.mean(target - source, dim=-1, keepdim=True)
+
+
+def transform_pts_2d_batch(source, target):
+    """(..., N, 2) x2 -> (in-plane rotation (..., 2, 2), translation (..., 2, 1)); (None, None) never occurs here: the
+    closed-form 2x2 solve has no failure path (degenerate inputs give the identity)."""
+    rotation = rotate_pts_2d_batch(source - source.mean(-2, keepdim=True), target - target.mean(-2, keepdim=True))
+    return rotation, translate_pts_batch(torch.matmul(rotation, source.transpose(-1, -2)), target.transpose(-1, -2))
+
+
+def transform_pts_batch(source, target, given_scale=None, rotation=None, sym=False):
+    """source, target (..., N, 3) -> (R (..., 3, 3), s (...), t (..., 3, 1)) with target ~ s R source + t; `rotation` given
+    skips the 3x3 Procrustes; `sym` refines it by an in-plane rotation about y fitted on the (x, z) coordinates."""
+    src_c = source - source.mean(-2, keepdim=True)
+    tgt_c = target - target.mean(-2, keepdim=True)
+    if rotation is None:
+        rotation = rotate_pts_batch(src_c, tgt_c)
+    if sym:
+        canon_target = torch.matmul(target, rotation)
+        rot_2d, _ = transform_pts_2d_batch(source[..., [0, 2]], canon_target[..., [0, 2]])
+        rotation = torch.matmul(rotation, rot_around_yaxis_to_3d(rot_2d))
+    scale = given_scale if given_scale is not None else scale_pts_batch(torch.matmul(src_c, rotation.transpose(-1, -2)), tgt_c)
+    translation = translate_pts_batch(scale[..., None, None] * torch.matmul(rotation, source.transpose(-1, -2)),
+                                      target.transpose(-1, -2))
+    return rotation, scale, translation

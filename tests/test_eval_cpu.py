@@ -1,5 +1,5 @@
 """CPU: the evaluation tables (captra_amd/pose_utils/bbox_utils.py, captra_amd/eval.py) against golden G10, produced by
-the reference's own pose_utils/bbox_utils.py::eval_single_part_iou and misc/eval/eval.py::get_joint_state
+the reference's own pose_utils/bbox_utils.py::eval_instance_part_iou and misc/eval/eval.py::get_joint_state
 (tests/golden/make_golden_eval.py)."""
 import pickle
 from pathlib import Path
@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from captra_amd.pose_utils.bbox_utils import bbox_from_corners, eval_single_part_iou, iou_3d, nocs_iou_3d
+from captra_amd.pose_utils.bbox_utils import bbox_from_corners, eval_instance_part_iou, iou_3d, nocs_iou_3d
 from tests.golden.make_golden_eval import make_inputs
 
 G = np.load(Path(__file__).resolve().parent / "golden" / "g10_eval.npz")
@@ -17,7 +17,7 @@ G = np.load(Path(__file__).resolve().parent / "golden" / "g10_eval.npz")
 @pytest.mark.parametrize("tag,P,sym,nocs", [("rigid_sym", 1, True, True), ("rigid", 1, False, True), ("arti", 4, False, False)])
 def test_part_iou_vs_reference(tag, P, sym, nocs):
     gc, pc, gt, pred = make_inputs(11 + P + int(sym), P)
-    got = eval_single_part_iou(gc, pc, gt, pred, nocs=nocs, sym=sym)
+    got = eval_instance_part_iou(gc, pc, gt, pred, nocs=nocs, sym=sym)
     for name in ("npcs_iou", "iou", "gt_bbox_iou"):
         np.testing.assert_allclose(got[name], G[f"{tag}_{name}"], atol=1e-6, rtol=0, err_msg=name)
 
@@ -127,3 +127,38 @@ def test_harness_flags_are_the_references():
     cfg = get_config(ns, save=False)
     assert cfg["loss_weight"]["rloss"] == 7.5 and cfg["pose_loss_type"]["r"] == "l1" and cfg["lr_step_size"] == 5
     assert cfg["track_cfg"]["gt_label"] is True and cfg["freq"]["save"] == 3 and cfg["loss_weight"]["corner_loss"] == 1.0
+
+
+def test_small_public_functions_vs_reference_g14():
+    """The remaining public helpers of the reference's path modules against golden G14 (tests/golden/make_golden_api.py):
+    the unmasked Procrustes family given a rotation (the free 3x3 solve runs the HIP kernel: GPU test), square_distance,
+    compute_hard_miou_loss, get_pred_nocs_corners, get_posed_bbox_from_part, calc_part_iou_list."""
+    import torch
+    from pathlib import Path
+    from captra_amd import loss as LS, pointnet_utils as PU
+    from captra_amd.pose_utils import bbox_utils as BU, procrustes as P
+    from tests.golden.make_golden_api import inputs
+    g = np.load(Path(__file__).resolve().parent / "golden" / "g14_api.npz")
+    d = inputs()
+    t = torch.from_numpy
+    src, tgt = t(d["src"]), t(d["tgt"])
+    close = lambda a, k, tol=1e-5: np.testing.assert_allclose(np.asarray(a), g[k], atol=tol, rtol=1e-5, err_msg=k)
+    close(P.scale_pts_batch(src, tgt), "scale_pts_batch")
+    close(P.translate_pts_batch(src.transpose(-1, -2), tgt.transpose(-1, -2)), "translate_pts_batch")
+    r2, t2 = P.transform_pts_2d_batch(src[..., [0, 2]], tgt[..., [0, 2]])
+    close(r2, "t2d_rot"), close(t2, "t2d_trans")
+    for tag, kw in (("given", {"rotation": t(d["given_rot"])}), ("given_sym", {"rotation": t(d["given_rot"]), "sym": True}),
+                    ("given_scale", {"rotation": t(d["given_rot"]), "given_scale": torch.full((2, 3), 1.3)})):
+        r, s, tr = P.transform_pts_batch(src, tgt, **kw)
+        close(r, f"tpb_{tag}_rot"), close(s, f"tpb_{tag}_scale"), close(tr, f"tpb_{tag}_trans")
+    close(PU.square_distance(src[:, 0], tgt[:, 1]), "square_distance", 1e-4)
+    loss, miou = LS.compute_hard_miou_loss(t(d["labels_a"]), t(d["labels_b"]), 3, per_instance=True)
+    close(loss, "hard_miou_loss"), close(miou, "hard_miou")
+    close(BU.get_pred_nocs_corners(t(d["labels_a"]), t(d["nocs"]), 3), "pred_corners")
+    pose = {k: t(v) for k, v in d["pose"].items()}
+    pose2 = {k: t(v) for k, v in d["pose2"].items()}
+    box1, box2 = BU.get_posed_bbox_from_part(pose, t(d["corners"])), BU.get_posed_bbox_from_part(pose2, t(d["corners"]))
+    close(box1, "posed_bbox")
+    mean, per = BU.calc_part_iou_list([box1], box2, separate="both", nocs=False)
+    close([mean[p] for p in range(3)], "iou_mean", 2e-3), close(np.stack([per[p] for p in range(3)]), "iou_per", 2e-3)
+    close([BU.calc_part_iou_list([box1], box2, separate=False, nocs=True)[p] for p in range(3)], "iou_mean_nocs")

@@ -839,3 +839,16 @@ def test_track_loss_dict_vs_reference(device, tag, cat, objcfg, kind):
             # drawers), pooled over a handful of points per part there -> 2e-3 relative; IoU: occupancy on a 50^3 grid
             atol = 5e-3 if "rdiff" in k else 2e-3 if "iou" in k else 1e-4
             np.testing.assert_allclose(got[k], ref[k], rtol=2e-3 if "rdiff" in k else 2e-4, atol=atol, err_msg=k)
+
+
+def test_transform_pts_batch_free_rotation_vs_reference(device):
+    """transform_pts_batch with no rotation given: the 3x3 Procrustes runs captra_procrustes_rot3 (on-device Jacobi SVD) where
+    the reference calls torch.svd on the CPU — same rotation, scale and translation (golden G14)."""
+    from captra_amd.pose_utils import procrustes as P
+    from tests.golden.make_golden_api import inputs
+    g = np.load(G / "g14_api.npz")
+    d = inputs()
+    r, s, t = P.transform_pts_batch(_dev(d["src"], device), _dev(d["tgt"], device))
+    np.testing.assert_allclose(r.cpu().numpy(), g["tpb_free_rot"], atol=2e-5)
+    np.testing.assert_allclose(s.cpu().numpy(), g["tpb_free_scale"], atol=2e-5)
+    np.testing.assert_allclose(t.cpu().numpy(), g["tpb_free_trans"], atol=2e-5)
