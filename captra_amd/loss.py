@@ -104,7 +104,12 @@ def compute_hard_miou_loss(pred, gt, num_parts, per_instance=False):
 
 
 def rot_trace_loss(rot1, rot2, metric="l1"):
-    """'frob': squared Frobenius norm of R1 - R2; 'l1' / 'l2': |trace(R1 R2^T) - 3| or its square."""
+    """'frob': squared Frobenius norm of R1 - R2; 'l1' / 'l2': |trace(R1 R2^T) - 3| or its square; 'exp_l1' / 'exp_l2':
+    difference of the rotation vectors."""
+    if metric in ("exp_l1", "exp_l2"):
+        from .pose_utils.rotations import matrix_to_rotvec
+        diff = matrix_to_rotvec(rot1) - matrix_to_rotvec(rot2)
+        return torch.abs(diff) if metric == "exp_l1" else diff ** 2
     if metric == "frob":
         d = rot1 - rot2
         prod = torch.matmul(d, d.transpose(-1, -2))
@@ -113,7 +118,7 @@ def rot_trace_loss(rot1, rot2, metric="l1"):
         prod = torch.matmul(rot1, rot2.transpose(-1, -2))
         tr = prod[..., 0, 0] + prod[..., 1, 1] + prod[..., 2, 2]
         return torch.abs(tr - 3) if metric == "l1" else (tr - 3.0) ** 2
-    raise ValueError(f"unsupported metric {metric} (the exponential-map metrics are not used by any shipped config)")
+    raise ValueError(f"unsupported metric {metric}")
 
 
 def rot_yaxis_loss(rot1, rot2, metric="l2"):

@@ -112,3 +112,53 @@ def noisy_rot_matrix(matrix: torch.Tensor, rad: float, type: str = "normal") -> 
         raise ValueError(type)
     q = matrix_to_unit_quaternion(matrix)
     return unit_quaternion_to_matrix(jitter_quaternion(q, theta.to(matrix.device).unsqueeze(-1)))
+
+
+# ---- axis-angle / rotation-vector conversions (reference rotations.py:109-155): used by the exponential-map metrics -----
+def axis_theta_to_quater(axis: torch.Tensor, theta: torch.Tensor) -> torch.Tensor:
+    """unit axis (…,3), angle (…) -> unit quaternion (w, x, y, z)."""
+    half = theta / 2.0
+    return normalize(torch.cat([torch.cos(half).unsqueeze(-1), axis * torch.sin(half).unsqueeze(-1)], dim=-1))
+
+
+def quater_to_axis_theta(quater: torch.Tensor):
+    """quaternion (…,4) -> (axis (…,3), angle (…) in [0, 2 pi]); the axis of a null rotation is the zero vector."""
+    q = normalize(quater)
+    cosa = q[..., 0]
+    sina = torch.sqrt(1 - cosa ** 2).unsqueeze(-1)
+    axis = q[..., 1:] / torch.max(sina, (sina < 1e-8).float())
+    return axis, 2 * torch.acos(torch.clamp(cosa, min=-1, max=1))
+
+
+def axis_theta_to_matrix(axis: torch.Tensor, theta: torch.Tensor) -> torch.Tensor:
+    return unit_quaternion_to_matrix(axis_theta_to_quater(axis, theta))
+
+
+def matrix_to_axis_theta(matrix: torch.Tensor):
+    return quater_to_axis_theta(matrix_to_unit_quaternion(matrix))
+
+
+def matrix_to_rotvec(matrix: torch.Tensor) -> torch.Tensor:
+    """Rotation vector with the reference's angle convention: theta mod 2 pi, plus 2 pi."""
+    import math
+    axis, theta = matrix_to_axis_theta(matrix)
+    return axis * (theta % (2 * math.pi) + 2 * math.pi).unsqueeze(-1)
+
+
+def rotvec_to_axis_theta(rotvec: torch.Tensor):
+    theta = torch.norm(rotvec, dim=-1, keepdim=True)
+    return rotvec / torch.max(theta, (theta < 1e-8).float()), theta.squeeze(-1)
+
+
+def rotvec_to_matrix(rotvec: torch.Tensor) -> torch.Tensor:
+    return axis_theta_to_matrix(*rotvec_to_axis_theta(rotvec))
+
+
+def rot_diff_rad(rot1, rot2, yaxis_only=False):      # also exported here, where the reference keeps them (rotations.py:345+)
+    from .metrics import rot_diff_rad as _impl
+    return _impl(rot1, rot2, yaxis_only=yaxis_only)
+
+
+def rot_diff_degree(rot1, rot2, yaxis_only=False):
+    from .metrics import rot_diff_degree as _impl
+    return _impl(rot1, rot2, yaxis_only=yaxis_only)

@@ -73,6 +73,13 @@ def main():
     out["iou_per"] = np.stack([per[p] for p in range(3)])
     mean_n = BU.calc_part_iou_list([box1], box2, separate=False, nocs=True)
     out["iou_mean_nocs"] = np.array([mean_n[p] for p in range(3)])
+    import rotations as RT
+    rots = RT.unit_quaternion_to_matrix(RT.normalize(torch.from_numpy(np.random.default_rng(5).standard_normal((6, 4)).astype(np.float32))))
+    out["rotvec"] = RT.matrix_to_rotvec(rots).numpy()
+    out["rotvec_back"] = RT.rotvec_to_matrix(RT.matrix_to_rotvec(rots)).numpy()
+    for m in ("frob", "l1", "l2", "exp_l1", "exp_l2"):
+        out[f"rot_trace_{m}"] = LS.rot_trace_loss(rots[:3], rots[3:], metric=m).numpy()
+    out["rot_yaxis_l2"] = LS.rot_yaxis_loss(rots[:3], rots[3:]).numpy()
     np.savez_compressed(HERE / "g14_api.npz", **out)
     print("wrote", HERE / "g14_api.npz", {k: v.shape for k, v in out.items()})
 

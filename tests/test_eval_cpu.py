@@ -162,3 +162,9 @@ def test_small_public_functions_vs_reference_g14():
     mean, per = BU.calc_part_iou_list([box1], box2, separate="both", nocs=False)
     close([mean[p] for p in range(3)], "iou_mean", 2e-3), close(np.stack([per[p] for p in range(3)]), "iou_per", 2e-3)
     close([BU.calc_part_iou_list([box1], box2, separate=False, nocs=True)[p] for p in range(3)], "iou_mean_nocs")
+    from captra_amd.pose_utils import rotations as RT
+    rots = RT.unit_quaternion_to_matrix(RT.normalize(torch.from_numpy(np.random.default_rng(5).standard_normal((6, 4)).astype(np.float32))))
+    close(RT.matrix_to_rotvec(rots), "rotvec"), close(RT.rotvec_to_matrix(RT.matrix_to_rotvec(rots)), "rotvec_back")
+    for m in ("frob", "l1", "l2", "exp_l1", "exp_l2"):
+        close(LS.rot_trace_loss(rots[:3], rots[3:], metric=m), f"rot_trace_{m}", 2e-5)
+    close(LS.rot_yaxis_loss(rots[:3], rots[3:]), "rot_yaxis_l2")
