@@ -14,8 +14,12 @@ the next step (frame i needs pose i-1, reference model.py:408-478).  Trajectorie
 GPUs with no data-path dependency; the per-frame pose records are all-gathered with RCCL so that
 every rank holds the full result ("weak" scaling: 32 trajectories per GPU).
 
+CoordNet and RotationNet run side by side on two streams (two branches of the replayed hipGraph; `--no-overlap` puts them
+back one after the other).
+
 Prints ONE JSON line on rank 0 (see the keys below).  `roofline` describes the dominant kernel
-family of the step, measured with HIP events on the launch stream inside the timed region;
+family of the step, measured with HIP events on the launch stream over the same steps launched eagerly right after the
+timed region, networks one after the other (a launch's duration is then the kernel's own);
 `cpu_baseline` is the CPU oracle (oracle/, a port of the reference's CPU path) timed on the host
 cores of rank 0 at N=1 on a bounded sample of the same workload at batch 1.
 """
@@ -247,6 +251,9 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     ap.add_argument("--no-graph", action="store_true", help="launch the step eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="run CoordinateNet and RotationNet one after the other instead of side by side on two streams (what the "
+                         "per-kernel timing pass and the rocprofv3 recipes use: isolated kernel durations)")
     ap.add_argument("--mlp-dtype", default="fp32", choices=["fp32", "bf16"],
                     help="fp32 = the metric's configuration (exact); bf16 = bf16 MFMA operands / fp32 accumulation for the shared "
                          "MLPs (BASELINE.json configs[2]'s arithmetic) -- reported with dtype \"bf16\", not the headline")
@@ -281,6 +288,7 @@ def main():
     nframes = len(model.feed_dict)
     pose = {k: v.clone() for k, v in model.feed_dict[0]["gt_part"].items()}
 
+    model.overlap_nets = not args.no_overlap
     use_graph = not args.no_graph
     graph = None
     if use_graph:
@@ -327,6 +335,7 @@ def main():
         # the timed region replayed a hipGraph; the per-kernel HIP events come from the same steps
         # launched eagerly right after it (same kernels, same shapes, same stream)
         p2 = {k: v.clone() for k, v in pose.items()}
+        model.overlap_nets = False   # kernels one at a time: a launch's duration is the kernel's own, not its share of a busy chip
         _lib.prof_reset()
         _lib.prof_enable(True)
         fused.work_reset(True)
@@ -358,7 +367,8 @@ def main():
                                   else " (BASELINE.json configs[1])" if args.category == "bottle" and args.mlp_dtype == "fp32" else " (BASELINE.json configs[3]: drawers)" if args.category == "drawers" else ""),
                    "points": 4096, "trajectories_per_gpu": B, "parallelism": f"dp{world} (trajectory-sharded, RCCL all-gather of poses)",
                    "weights": f"random-init default_rng(7), real architecture ({sum(v.numel() for v in sd.values()) / 1e6:.2f} M params incl. BN statistics)",
-                   "launch": "hipGraph replay of the step" if graph is not None else "eager launches"},
+                   "launch": ("hipGraph replay of the step" if graph is not None else "eager launches")
+                             + (", CoordinateNet and RotationNet on two streams (two branches of the graph)" if not args.no_overlap and P == 1 else "")},
     }
     if timing:
         fams = {}

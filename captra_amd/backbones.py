@@ -49,6 +49,23 @@ class PointNet2Msg(_FoldCache, nn.Module):
         self.device = cfg["device"]
         self._folded = None
 
+    def precompute_geometry(self, xyz_n3):
+        """Everything that depends on the coordinates only, in the layout `forward(geom=...)` takes: the two samplings, the
+        ball-query lists of both levels, the 3-NN weights of FP1 / FP2.  Lets a caller run the MLP work of two networks
+        that share a cloud on two streams (EvalTrackModel at small batch).  None when the fused samplers do not apply."""
+        if self.training or not xyz_n3.is_cuda or self.sa1.knn or self.sa2.knn:
+            return None
+        first = fused.fps_gather(xyz_n3.contiguous(), self.sa1.npoint)
+        if first is None:
+            return None
+        _, n1_n3, n1_cn = first
+        _, n2_n3, n2_cn = fused.fps_gather(n1_n3, self.sa2.npoint)
+        g1 = {"new_xyz_n3": n1_n3, "new_xyz": n1_cn,
+              "idx_list": fused.ball_query_multi(self.sa1.radius_list, self.sa1.nsample_list, xyz_n3, n1_n3)}
+        g2 = {"new_xyz_n3": n2_n3, "new_xyz": n2_cn,
+              "idx_list": fused.ball_query_multi(self.sa2.radius_list, self.sa2.nsample_list, n1_n3, n2_n3)}
+        return {"sa1": g1, "sa2": g2, "fp1": fused.three_nn_weights(xyz_n3, n1_n3), "fp2": fused.three_nn_weights(n1_n3, n2_n3)}
+
     def forward(self, input, input_n3=None, geom=None, finish=None):
         """input (B,3(+C),N); `input_n3` optionally the (B,N,3) copy of input[:, :3]; `geom` optionally
         the `last_geom` of another PointNet2Msg that ran on the SAME cloud (FPS picks, ball-query lists

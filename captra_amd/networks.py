@@ -77,7 +77,8 @@ class CoordNet(nn.Module):
         """input: {'points' (B,3,N), 'points_mean' (B,3,1), 'canon_pose' {rotation (B,3,3),
         translation (B,3,1), scale (B,)}, [...]} -> {'seg' (B,P+e,N) softmax, 'nocs' (B,3P,N), 'points'}."""
         canon_pose = input["canon_pose"]
-        cam_cn, cam_n3 = _canonicalize(input["points"], input["points_mean"], canon_pose)
+        # `_canon` / `_geom`: the canonicalised cloud and its geometry, when the caller already computed them
+        cam_cn, cam_n3 = input["_canon"] if "_canon" in input else _canonicalize(input["points"], input["points_mean"], canon_pose)
         self.last_canon = (cam_cn, cam_n3)
         fused_tail = None
         if (not self.training) and cam_cn.is_cuda:
@@ -89,7 +90,7 @@ class CoordNet(nn.Module):
                         return fused.coord_tail(x, all_layers)            # (seg logits, sigmoid(nocs) - 0.5)
                     seg_logits, nocs = self._heads(fused.mlp_chain3(x, layers, fused.ACT_RELU))
                     return seg_logits, nocs - 0.5
-        out = self.backbone(cam_cn, input_n3=cam_n3, finish=fused_tail)
+        out = self.backbone(cam_cn, input_n3=cam_n3, geom=input.get("_geom"), finish=fused_tail)
         if fused_tail is not None:
             seg_logits, nocs_m05 = out
         else:
@@ -202,15 +203,20 @@ class PartCanonNet(nn.Module):
         # `shared` = (canonicalised cloud, backbone geometry) of CoordNet, valid when this net's clouds are
         # the same clouds (one part: the part's previous pose IS the CoordNet's canonical pose)
         shared = input.get("shared_geometry") if P == 1 else None
-        if shared is not None:
+        fast = (eval_rnpcs and test_mode and not self.return_point_rotation and not self.training and input["points"].is_cuda
+                and fused.USE_ROT_READOUT)
+        if fast and input.get("_raw") is not None:
+            cam_cn, cam_n3, geom = input["points"], None, None      # the heads already ran (side stream): nothing to canonicalise
+        elif shared is not None:
             (cam_cn, cam_n3), geom = shared
         else:
             cam_cn, cam_n3 = _canonicalize(input["points"], input["points_mean"], canon_pose, num_parts=P)
             geom = None
-        if (eval_rnpcs and test_mode and not self.return_point_rotation and not self.training and cam_cn.is_cuda
-                and fused.USE_ROT_READOUT):
+        if fast:
             # tracking fast path: one launch for per-point normalisation + masked mean + frame + R_prev * dR
-            raw = self.regress_net.raw_point_rtvec(cam_cn, cam_n3=cam_n3, geom=geom)       # (B*P,R,N), head p on cloud (b,p)
+            raw = input.get("_raw")                                                       # computed ahead on a side stream?
+            if raw is None:
+                raw = self.regress_net.raw_point_rtvec(cam_cn, cam_n3=cam_n3, geom=geom)   # (B*P,R,N), head p on cloud (b,p)
             labels_i32 = input["pred_labels"].int().contiguous()
             rotation = fused.rot_pool_compose(raw, labels_i32, part_pose["rotation"].float().contiguous(), self.sym)
             npcs = input["pred_nocs"].reshape(B, P, 3, -1).float().contiguous()

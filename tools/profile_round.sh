@@ -7,13 +7,20 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timing"
-BENCH_EAGER="python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-graph"
+# --no-overlap: the two networks one after the other, so that a dispatch's duration is the kernel's own (bench.py's roofline
+# figures are measured the same way); the default bench line runs them side by side on two streams
+BENCH="python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-overlap"
+BENCH_EAGER="python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-graph --no-overlap"
+BENCH_OVERLAP="python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timing"
 cd /tmp
 # 1. kernel trace + stats of the bench command (hipGraph replay path)
 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_trace -o bench -- $BENCH > $OUT/${TAG}_trace.log 2>&1
 DB=$(ls $OUT/${TAG}_trace/*.db 2>/dev/null | head -1)
 [ -n "$DB" ] && python $ROOT/tools/rocpd_summary.py $DB --step-trace 1 > $OUT/${TAG}_bench_kernel_trace_stats.txt 2>&1
+# 1b. the default command (networks side by side): kernel trace only
+rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_trace_overlap -o bench -- $BENCH_OVERLAP > $OUT/${TAG}_trace_overlap.log 2>&1
+DB2=$(ls $OUT/${TAG}_trace_overlap/*.db 2>/dev/null | head -1)
+[ -n "$DB2" ] && python $ROOT/tools/rocpd_summary.py $DB2 > $OUT/${TAG}_bench_overlap_kernel_trace_stats.txt 2>&1
 # 2. PMC passes (separate runs, counters only; eager launches so every dispatch is a kernel node the tool sees)
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_fetch -o p -- $BENCH_EAGER > $OUT/${TAG}_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_write -o p -- $BENCH_EAGER > $OUT/${TAG}_write.log 2>&1
