@@ -208,9 +208,10 @@ class EvalTrackModel(BaseModel):
                              "mask.png from disk (cv2) is outside this build")
         npcs = self.npcs_feed_dict[i]
         B, _, N = input["points"].shape
-        centers = last_pose["translation"][:, self.root].reshape(B, 3).double().cpu().numpy()
-        scales = last_pose["scale"][:, self.root].reshape(B).double().cpu().numpy()
-        gt = {k: v[:, self.root].double().cpu().numpy() for k, v in input["gt_part"].items()}
+        from .nocs_otf import to_host
+        centers = to_host(last_pose["translation"][:, self.root].reshape(B, 3).double())
+        scales = to_host(last_pose["scale"][:, self.root].reshape(B).double())
+        gt = {k: to_host(v[:, self.root].double().contiguous()) for k, v in input["gt_part"].items()}
         full = full_data_batch([(pre["depth"][b], pre["mask"][b], centers[b], self.radius * float(scales[b]),
                                  {k: gt[k][b] for k in gt}) for b in range(B)], N, stacked=True)   # one crop + one sampling launch
         input["points"] = (full["points"].float() - npcs["points_mean"].reshape(B, 1, 3)).transpose(1, 2).contiguous()

@@ -18,6 +18,30 @@ from __future__ import annotations
 import numpy as np
 import torch
 
+def to_host(t: torch.Tensor) -> np.ndarray:
+    """Device -> host through pinned memory and an event on the CURRENT stream.  A plain `.cpu()` lands in pageable memory,
+    which the runtime serves with a staged copy that waits for the whole device — with two lanes of trajectories on two
+    streams that wait is what kept one lane's sampler from running under the other lane's networks."""
+    if not t.is_cuda:
+        return t.numpy()
+    buf = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    buf.copy_(t, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(t.device))
+    ev.synchronize()
+    return buf.numpy()
+
+
+def to_device(a, dev, dtype=None) -> torch.Tensor:
+    """Host array -> device through pinned memory, asynchronously on the current stream (same reason as to_host)."""
+    t = torch.as_tensor(np.ascontiguousarray(a)) if not isinstance(a, torch.Tensor) else a
+    if dtype is not None:
+        t = t.to(dtype)
+    if torch.device(dev).type != "cuda":
+        return t.to(dev)
+    return t.pin_memory().to(dev, non_blocking=True)
+
+
 NOCS_REAL_INTRINSICS = np.array([[591.0125, 0.0, 322.525], [0.0, 590.16775, 244.11084], [0.0, 0.0, 1.0]])   # nocs_data_process.py:20
 
 
@@ -172,8 +196,8 @@ def full_data_batch(frames, num_points: int, intrinsics=NOCS_REAL_INTRINSICS, us
     radii = np.array([max(float(f[3]), 0.05) for f in frames], np.float64)
     boxes = np.stack([proj_corners(H, W, centers[b], frames[b][3], intrinsics).reshape(4) for b in range(B)]).astype(np.int32)
     kinv = np.linalg.inv(np.asarray(intrinsics, np.float64)).reshape(9)
-    host = torch.from_numpy(np.concatenate([centers.reshape(-1), radii, kinv])).to(dev)         # one H2D for the doubles
-    box_d = torch.from_numpy(boxes).to(dev)
+    host = to_device(np.concatenate([centers.reshape(-1), radii, kinv]), dev)                   # one H2D for the doubles
+    box_d = to_device(boxes, dev)
     pts = torch.empty(B, CROP_CAP, 3, dtype=torch.float64, device=dev)
     obj = torch.empty(B, CROP_CAP, dtype=torch.uint8, device=dev)
     pix = torch.empty(B, CROP_CAP, dtype=torch.int32, device=dev)
@@ -181,7 +205,7 @@ def full_data_batch(frames, num_points: int, intrinsics=NOCS_REAL_INTRINSICS, us
     with torch.cuda.device(dev):
         L.call("captra_crop_ball", B, H, W, CROP_CAP, L.ptr(depth), L.ptr(mask), L.ptr(box_d), host.data_ptr(),
                host.data_ptr() + 8 * 3 * B, host.data_ptr() + 8 * 4 * B, L.ptr(pts), L.ptr(obj), L.ptr(pix), L.ptr(counts))
-    n_members = counts[:, 0].cpu().numpy()                                                       # the one sync of the stage
+    n_members = to_host(counts[:, 0].contiguous())                                               # the one sync of the stage
 
     # host: the candidate list of every instance as indices into its member table (list doubling = index modulo count,
     # thinning = a prefix of numpy's permutation), in trajectory order because the permutations consume numpy's generator
@@ -208,20 +232,20 @@ def full_data_batch(frames, num_points: int, intrinsics=NOCS_REAL_INTRINSICS, us
         table_d = torch.arange(max(lens), device=dev).unsqueeze(0) % cnt_f.unsqueeze(1)
         for i, b in enumerate(fast):
             if b in perms:
-                table_d[i, :lens[i]] = torch.from_numpy(perms[b]).to(dev) % cnt_f[i]
+                table_d[i, :lens[i]] = to_device(perms[b], dev) % cnt_f[i]
         if len(fast) == B:
             pts_f, obj_f = pts, obj
         else:
-            fidx = torch.tensor(fast, device=dev)
+            fidx = to_device(np.asarray(fast, np.int64), dev)
             pts_f, obj_f = pts[fidx], obj[fidx]
         cand = torch.gather(pts_f, 1, table_d.unsqueeze(-1).expand(-1, -1, 3)).float()
-        res = fused.fps_gather(cand, num_points, n_per_cloud=torch.tensor(lens, dtype=torch.int32, device=dev))
+        res = fused.fps_gather(cand, num_points, n_per_cloud=to_device(np.asarray(lens, np.int32), dev))
         sel = torch.gather(table_d, 1, res[0].long())                                             # (F, N) member numbers
         P = torch.gather(pts_f, 1, sel.unsqueeze(-1).expand(-1, -1, 3))                            # (F, N, 3) float64
         O = torch.gather(obj_f, 1, sel).bool()
-        rot = torch.from_numpy(np.stack([np.asarray(frames[b][4]["rotation"], np.float64).reshape(3, 3) for b in fast])).to(dev)
-        trans = torch.from_numpy(np.stack([np.asarray(frames[b][4]["translation"], np.float64).reshape(1, 3) for b in fast])).to(dev)
-        scale = torch.from_numpy(np.array([float(np.asarray(frames[b][4]["scale"], np.float64).reshape(-1)[0]) for b in fast])).to(dev)
+        rot = to_device(np.stack([np.asarray(frames[b][4]["rotation"], np.float64).reshape(3, 3) for b in fast]), dev)
+        trans = to_device(np.stack([np.asarray(frames[b][4]["translation"], np.float64).reshape(1, 3) for b in fast]), dev)
+        scale = to_device(np.array([float(np.asarray(frames[b][4]["scale"], np.float64).reshape(-1)[0]) for b in fast]), dev)
         nocs = torch.where(O.unsqueeze(-1), torch.bmm((P - trans) / scale.reshape(-1, 1, 1), rot), torch.zeros_like(P))
         labels = 1 - O.long()
         if stacked and len(fast) == B:
