@@ -49,7 +49,7 @@ class PointNet2Msg(_FoldCache, nn.Module):
         self.device = cfg["device"]
         self._folded = None
 
-    def precompute_geometry(self, xyz_n3):
+    def precompute_geometry(self, xyz_n3, level1_only=False):
         """Everything that depends on the coordinates only, in the layout `forward(geom=...)` takes: the two samplings, the
         ball-query lists of both levels, the 3-NN weights of FP1 / FP2.  Lets a caller run the MLP work of two networks
         that share a cloud on two streams (EvalTrackModel at small batch).  None when the fused samplers do not apply."""
@@ -59,12 +59,22 @@ class PointNet2Msg(_FoldCache, nn.Module):
         if first is None:
             return None
         _, n1_n3, n1_cn = first
-        _, n2_n3, n2_cn = fused.fps_gather(n1_n3, self.sa2.npoint)
         g1 = {"new_xyz_n3": n1_n3, "new_xyz": n1_cn,
               "idx_list": fused.ball_query_multi(self.sa1.radius_list, self.sa1.nsample_list, xyz_n3, n1_n3)}
-        g2 = {"new_xyz_n3": n2_n3, "new_xyz": n2_cn,
-              "idx_list": fused.ball_query_multi(self.sa2.radius_list, self.sa2.nsample_list, n1_n3, n2_n3)}
-        return {"sa1": g1, "sa2": g2, "fp1": fused.three_nn_weights(xyz_n3, n1_n3), "fp2": fused.three_nn_weights(n1_n3, n2_n3)}
+        geom = {"sa1": g1}
+        if level1_only:
+            return geom
+        return self.precompute_geometry_rest(geom, xyz_n3)
+
+    def precompute_geometry_rest(self, geom, xyz_n3):
+        """Level 2 and the interpolation weights, given level 1 (`precompute_geometry(..., level1_only=True)`)."""
+        n1_n3 = geom["sa1"]["new_xyz_n3"]
+        _, n2_n3, n2_cn = fused.fps_gather(n1_n3, self.sa2.npoint)
+        geom["sa2"] = {"new_xyz_n3": n2_n3, "new_xyz": n2_cn,
+                       "idx_list": fused.ball_query_multi(self.sa2.radius_list, self.sa2.nsample_list, n1_n3, n2_n3)}
+        geom["fp1"] = fused.three_nn_weights(xyz_n3, n1_n3)
+        geom["fp2"] = fused.three_nn_weights(n1_n3, n2_n3)
+        return geom
 
     def forward(self, input, input_n3=None, geom=None, finish=None):
         """input (B,3(+C),N); `input_n3` optionally the (B,N,3) copy of input[:, :3]; `geom` optionally
@@ -78,6 +88,8 @@ class PointNet2Msg(_FoldCache, nn.Module):
             input_n3 = l0_xyz.transpose(1, 2).contiguous()
         l1_xyz, l1_points = self.sa1(l0_xyz, l0_points, xyz_n3=input_n3, geom=geom.get("sa1"))
         l1_n3 = self.sa1.last_new_xyz_n3
+        if geom.get("_ready") is not None:            # the rest of the geometry is being computed on another stream
+            torch.cuda.current_stream(l0_xyz.device).wait_event(geom["_ready"])
         l2_xyz, l2_points = self.sa2(l1_xyz, l1_points, xyz_n3=l1_n3, geom=geom.get("sa2"))
         l2_n3 = self.sa2.last_new_xyz_n3
         l3_xyz, l3_points = self.sa3(l2_xyz, l2_points)

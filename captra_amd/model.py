@@ -160,7 +160,8 @@ class EvalTrackModel(BaseModel):
         from .networks import _canonicalize
         P = self.num_parts
         cam = _canonicalize(npcs_input["points"], npcs_input["points_mean"], npcs_input["canon_pose"])
-        geom = self.npcs_net.backbone.precompute_geometry(cam[1])
+        small = len(input["points"]) <= 2      # one or two trajectories: every kernel is latency-bound, overlap all that can be (no gain from 4 up)
+        geom = self.npcs_net.backbone.precompute_geometry(cam[1], level1_only=small)
         if geom is None:
             return None
         npcs_input["_canon"], npcs_input["_geom"] = cam, geom
