@@ -368,7 +368,8 @@ def main():
                    "points": 4096, "trajectories_per_gpu": B, "parallelism": f"dp{world} (trajectory-sharded, RCCL all-gather of poses)",
                    "weights": f"random-init default_rng(7), real architecture ({sum(v.numel() for v in sd.values()) / 1e6:.2f} M params incl. BN statistics)",
                    "launch": ("hipGraph replay of the step" if graph is not None else "eager launches")
-                             + (", CoordinateNet and RotationNet on two streams (two branches of the graph)" if not args.no_overlap and P == 1 else "")},
+                             + (", CoordinateNet and RotationNet side by side on two streams" + (" (two branches of the graph)" if graph is not None else "")
+                                if not args.no_overlap else "")},
     }
     if timing:
         fams = {}

@@ -153,7 +153,7 @@ class EvalTrackModel(BaseModel):
         launch ramps / tails.  1.37 -> 1.18 ms per frame at one trajectory, 6.56 -> 6.40 ms per step at 32."""
         from . import fused
         return (self.overlap_nets
-                and not self.training and input["points"].is_cuda and fused.USE_ROT_READOUT and fused.MLP_DTYPE == "fp32"
+                and not self.training and input["points"].is_cuda and fused.USE_ROT_READOUT
                 and not (self.track_cfg["gt_label"] or self.track_cfg["nocs2d_label"]) and not self.net.return_point_rotation)
 
     def _fork_rotation_net(self, input, npcs_input, last_pose):
