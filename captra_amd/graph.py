@@ -22,7 +22,6 @@ class TrackStepGraph:
         self.points_mean = points_mean.clone()
         self.pose = {k: v.clone() for k, v in pose.items()}
         self.labels = None if labels is None else labels.clone()
-        self.graph = torch.cuda.CUDAGraph()
         stream = torch.cuda.Stream(device=dev)
         stream.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(stream), torch.no_grad():
@@ -30,6 +29,19 @@ class TrackStepGraph:
                 self._step()
         torch.cuda.current_stream(dev).wait_stream(stream)
         torch.cuda.synchronize(dev)
+        try:
+            self._capture()
+        except RuntimeError:
+            # the step forks CoordinateNet / RotationNet onto two streams (model.overlap_nets); should a runtime refuse
+            # to capture the fork, capture the one-stream step instead
+            if not getattr(model, "overlap_nets", False):
+                raise
+            model.overlap_nets = False
+            torch.cuda.synchronize(dev)
+            self._capture()
+
+    def _capture(self):
+        self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph), torch.no_grad():
             self.npcs_pred, self.out_pose = self._step()
 
