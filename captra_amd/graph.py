@@ -42,7 +42,8 @@ class TrackStepGraph:
 
     def _capture(self):
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph), torch.no_grad():
+        # thread_local: other host threads (RCCL's watchdog under torch.distributed) may touch the runtime while this thread captures
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"), torch.no_grad():
             self.npcs_pred, self.out_pose = self._step()
 
     def _step(self):
