@@ -245,12 +245,16 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=20, help="untimed steps before the timed region (SURVEY.md 8d: at least 20)")
     ap.add_argument("--batch", type=int, default=32, help="trajectories per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     ap.add_argument("--no-graph", action="store_true", help="launch the step eagerly instead of replaying a hipGraph")
+    ap.add_argument("--lanes", type=int, default=0,
+                    help="sub-batches of the rank's trajectories, each replaying its own captured step on its own stream, free-running "
+                         "(captra_amd.graph.TrackLanes); 1 = one graph for the whole batch; 0 = 2 from 32 trajectories per GPU on "
+                         "(measured: +2.8 %% at 32 and 64, -1 %% at 8 and 16)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="run CoordinateNet and RotationNet one after the other instead of side by side on two streams (what the "
                          "per-kernel timing pass and the rocprofv3 recipes use: isolated kernel durations)")
@@ -284,23 +288,35 @@ def main():
     fused.MLP_DTYPE = args.mlp_dtype
     cfg, sd, model, data = build_workload(args.batch, device, category=args.category)
     B, P = args.batch, cfg["num_parts"]
+    if args.lanes == 0:
+        args.lanes = 2 if B >= 32 and B % 2 == 0 else 1
+    if args.no_overlap or args.no_graph:
+        args.lanes = 1
     exchange = PoseExchange(B, P, device, world, rank)
     nframes = len(model.feed_dict)
     pose = {k: v.clone() for k, v in model.feed_dict[0]["gt_part"].items()}
 
     model.overlap_nets = not args.no_overlap
     use_graph = not args.no_graph
-    graph = None
+    graph = lanes = None
     if use_graph:
-        from captra_amd.graph import TrackStepGraph
+        from captra_amd.graph import TrackLanes, TrackStepGraph
         f1 = model.feed_dict[1]
-        graph = TrackStepGraph(model, f1["points"], f1["points_mean"], pose)
+        if args.lanes > 1 and B % args.lanes == 0:
+            graph = lanes = TrackLanes(model, f1["points"], f1["points_mean"], pose, lanes=args.lanes)
+        else:
+            graph = TrackStepGraph(model, f1["points"], f1["points_mean"], pose)
 
     def step(i, pose, timing_pass=False):
         f = 1 + i % (nframes - 1)
         if graph is not None and not timing_pass:
             fd = model.feed_dict[f]
-            new_pose = graph.replay(fd["points"], fd["points_mean"], pose)
+            if lanes is not None:
+                # every lane hands its pose over to itself and runs ahead; this stream only waits (on the GPU) for the
+                # frame's records and feeds them to the exchange
+                new_pose = lanes.gather(lanes.step(fd["points"], fd["points_mean"]))
+            else:
+                new_pose = graph.replay(fd["points"], fd["points_mean"], pose)
         else:
             with torch.no_grad():
                 _, new_pose = model.track_step(model.feed_dict[f], model.npcs_feed_dict[f], pose)
@@ -367,7 +383,8 @@ def main():
                                   else " (BASELINE.json configs[1])" if args.category == "bottle" and args.mlp_dtype == "fp32" else " (BASELINE.json configs[3]: drawers)" if args.category == "drawers" else ""),
                    "points": 4096, "trajectories_per_gpu": B, "parallelism": f"dp{world} (trajectory-sharded, RCCL all-gather of poses)",
                    "weights": f"random-init default_rng(7), real architecture ({sum(v.numel() for v in sd.values()) / 1e6:.2f} M params incl. BN statistics)",
-                   "launch": ("hipGraph replay of the step" if graph is not None else "eager launches")
+                   "launch": (f"{args.lanes} free-running lanes of {B // args.lanes} trajectories, each a hipGraph replay of the step on its own stream" if lanes is not None
+                              else "hipGraph replay of the step" if graph is not None else "eager launches")
                              + (", CoordinateNet and RotationNet side by side on two streams" + (" (two branches of the graph)" if graph is not None else "")
                                 if not args.no_overlap else "")},
     }

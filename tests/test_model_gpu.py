@@ -307,6 +307,37 @@ def test_hipgraph_replay_equals_eager(device, tag):
             np.testing.assert_array_equal(pe[k].cpu().numpy(), pg[k].cpu().numpy(), err_msg=f"frame {i} {k}")
 
 
+@pytest.mark.parametrize("tag", ["bottle", "drawers"])
+def test_free_running_lanes_equal_eager(device, tag):
+    """TrackLanes: the batch as two sub-batches, each replaying its own captured step on its own stream and handing its pose
+    over to itself — every frame's gathered record equals the eager whole-batch step bit for bit (ring of 2: slots reused)."""
+    from captra_amd.graph import TrackLanes
+    trainer, cfg, sd, data = _trainer(tag, device)
+    model = trainer.model.eval()
+    model.track_cfg["gt_label"] = False
+    model.set_data(data)
+    pose0 = {k: v.clone() for k, v in model.feed_dict[0]["gt_part"].items()}
+    lanes = TrackLanes(model, model.feed_dict[1]["points"], model.feed_dict[1]["points_mean"], pose0, lanes=2, ring=2)
+    eager, pe = [], pose0
+    for rep in range(2):                      # the second pass restarts the trajectories through set_pose
+        got = []
+        for i in range(1, len(data)):
+            f = model.feed_dict[i]
+            got.append({k: v.clone() for k, v in lanes.gather(lanes.step(f["points"], f["points_mean"])).items()})
+        if rep == 0:
+            for i in range(1, len(data)):
+                with torch.no_grad():
+                    _, pe = model.track_step(model.feed_dict[i], model.npcs_feed_dict[i], pe)
+                eager.append(pe)
+        for i, (a, b) in enumerate(zip(eager, got)):
+            for k in a:
+                np.testing.assert_array_equal(a[k].cpu().numpy(), b[k].cpu().numpy(), err_msg=f"pass {rep} frame {i + 1} {k}")
+        torch.cuda.synchronize()
+        lanes.set_pose(pose0)
+    with pytest.raises(ValueError):
+        TrackLanes(model, model.feed_dict[1]["points"], model.feed_dict[1]["points_mean"], pose0, lanes=3)
+
+
 @pytest.mark.parametrize("sym", [False, True])
 def test_part_fit_st_vs_oracle_and_golden(device, sym):
     from captra_amd.pose_utils.pose_fit import part_fit_st_cn, part_fit_st_no_ransac

@@ -11,7 +11,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
 os.environ.setdefault("MASTER_PORT", "29533")
 import bench  # noqa: E402
-from captra_amd.graph import TrackStepGraph  # noqa: E402
+from captra_amd.graph import TrackLanes, TrackStepGraph  # noqa: E402
 from captra_amd.parallel import PoseExchange  # noqa: E402
 
 device = torch.device("cuda", 0)
@@ -32,4 +32,14 @@ for i in range(5):
 torch.cuda.synchronize()
 assert all(torch.isfinite(v).all() for v in pose.values())
 print("ok: captured with overlap_nets =", model.overlap_nets)
+# bench.py's default from 32 trajectories per GPU on: two free-running lanes, the all-gather fed from the ring records
+from captra_amd.parallel import pack_pose  # noqa: E402
+lanes = TrackLanes(model, f1["points"], f1["points_mean"], {k: v.clone() for k, v in model.feed_dict[0]["gt_part"].items()}, lanes=2)
+for i in range(12):
+    rec = lanes.gather(lanes.step(f1["points"], f1["points_mean"]))
+    dist.all_gather_into_tensor(ex.gathered, ex.local.copy_(pack_pose(rec)))
+dist.barrier()
+torch.cuda.synchronize()
+assert torch.isfinite(ex.gathered).all()
+print("ok: free-running lanes + all-gather")
 dist.destroy_process_group()
