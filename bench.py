@@ -15,7 +15,10 @@ GPUs with no data-path dependency; the per-frame pose records are all-gathered w
 every rank holds the full result ("weak" scaling: 32 trajectories per GPU).
 
 CoordNet and RotationNet run side by side on two streams (two branches of the replayed hipGraph; `--no-overlap` puts them
-back one after the other).
+back one after the other), and from 32 trajectories per GPU on the rank's trajectories run as two free-running lanes of half the
+batch each (`--lanes`, captra_amd.graph.TrackLanes: every lane replays its own captured step on its own stream and hands its pose
+over to itself; the frame's poses reach the exchange through a ring of records).  A step still passes every trajectory of the rank
+through one frame, and the timed region ends with a device-wide synchronize + barrier.
 
 Prints ONE JSON line on rank 0 (see the keys below).  `roofline` describes the dominant kernel
 family of the step, measured with HIP events on the launch stream over the same steps launched eagerly right after the
