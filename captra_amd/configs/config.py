@@ -5,7 +5,6 @@ from __future__ import annotations
 import copy
 import os
 from os.path import join as pjoin
-from types import SimpleNamespace
 
 import torch
 import yaml

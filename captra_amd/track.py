@@ -17,7 +17,6 @@ from __future__ import annotations
 import argparse
 import glob
 import logging
-import os
 import sys
 import time
 from os.path import join as pjoin
