@@ -78,7 +78,10 @@ class TrackLanes:
     write their slices of and `gather` hands out on the caller's stream (GPU-side event waits, the lanes do not stop).
     Measured: 2 lanes +3.5 % frames/s at B = 32; joining the lanes every frame instead gives the gain back (-0.5 %)."""
 
-    def __init__(self, model, points: torch.Tensor, points_mean: torch.Tensor, pose: dict, lanes: int = 2, ring: int = 4):
+    def __init__(self, model, points: torch.Tensor, points_mean: torch.Tensor, pose: dict, lanes: int = 2, ring: int = 4,
+                 keep_npcs: bool = False):
+        """keep_npcs: also keep CoordinateNet's per-point outputs of every frame in the ring (`gather(slot, npcs=True)`; the
+        track loop's pred_dict['npcs_pred'], model.py:476-478)."""
         B = points.shape[0]
         if lanes < 1 or B % lanes:
             raise ValueError(f"{B} trajectories do not split into {lanes} lanes")
@@ -89,6 +92,10 @@ class TrackLanes:
                        for s in self.slices]
         self.streams = [torch.cuda.Stream(device=dev) for _ in range(lanes)]
         self.ring = [{k: torch.empty_like(v) for k, v in pose.items()} for _ in range(ring)]
+        self.npcs_ring = None
+        if keep_npcs:
+            first = {k: v for k, v in self.graphs[0].npcs_pred.items() if torch.is_tensor(v)}
+            self.npcs_ring = [{k: v.new_empty((B,) + tuple(v.shape[1:])) for k, v in first.items()} for _ in range(ring)]
         self.written = [[torch.cuda.Event() for _ in range(lanes)] for _ in range(ring)]
         self.consumed = [None] * ring          # recorded on the consumer's stream when the slot was handed out and read
         self.frame = 0
@@ -122,17 +129,21 @@ class TrackLanes:
                 for k in out:
                     self.ring[slot][k][s].copy_(out[k])
                     g.pose[k].copy_(out[k])    # hand-over inside the lane
+                if self.npcs_ring is not None:
+                    for k, dst in self.npcs_ring[slot].items():
+                        dst[s].copy_(g.npcs_pred[k])
                 self.written[slot][l].record(st)
         return slot
 
-    def gather(self, slot: int) -> dict:
-        """The frame's poses of all B trajectories, valid on the current stream (which waits for the lanes' writes on the
-        GPU; the host does not block).  The dict is a ring record: it is overwritten `ring` frames later."""
+    def gather(self, slot: int, npcs: bool = False):
+        """The frame's poses of all B trajectories (npcs=True: and CoordinateNet's outputs), valid on the current stream
+        (which waits for the lanes' writes on the GPU; the host does not block).  The dicts are ring records: they are
+        overwritten `ring` frames later."""
         cur = torch.cuda.current_stream()
         for ev in self.written[slot]:
             cur.wait_event(ev)
         self._pending = (slot, cur)
-        return self.ring[slot]
+        return (self.ring[slot], self.npcs_ring[slot]) if npcs else self.ring[slot]
 
     def _mark_consumed(self):
         if self._pending is not None:

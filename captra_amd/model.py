@@ -199,6 +199,22 @@ class EvalTrackModel(BaseModel):
         npcs = {k: v.clone() for k, v in self._graph.npcs_pred.items() if torch.is_tensor(v)}
         return npcs, {k: v.clone() for k, v in pose.items()}
 
+    def _lanes_usable(self, input) -> bool:
+        """From 32 trajectories on the captured step runs as two free-running lanes (graph.TrackLanes; +2.8 % frames/s,
+        -1 % at 8 and 16).  Not with the on-the-fly re-crop: it reads the previous pose on the host every frame."""
+        B = input["points"].shape[0]
+        return self._graph_usable(input) and not self.nocs_otf and B >= 32 and B % 2 == 0
+
+    def _lanes_for(self, input, pose):
+        from .graph import TrackLanes
+        key = ("lanes", tuple(input["points"].shape), str(input["points"].device))
+        if self._graph is None or self._graph_key != key:
+            self._graph = TrackLanes(self, input["points"], input["points_mean"], pose, lanes=2, keep_npcs=True)
+            self._graph_key = key
+        else:
+            self._graph.set_pose(pose)
+        return self._graph
+
     def _recrop(self, i, input, last_pose):
         """nocs_otf (reference model.py:425-452): re-crop frame i around the pose predicted for frame i-1 -- on the device
         (captra_amd/nocs_otf.py).  The frame must carry its depth image and instance mask (meta['pre_fetched'])."""
@@ -225,10 +241,20 @@ class EvalTrackModel(BaseModel):
         npcs_pred = [None]
         frame_nums = []
         self.timer.tick()
+        lanes = None
         with torch.no_grad():
+            if len(self.feed_dict) > 1 and self._lanes_usable(self.feed_dict[1]):
+                lanes = self._lanes_for(self.feed_dict[1], pred_poses[0])
             for i, input in enumerate(self.feed_dict):
                 frame_nums.append([p.split(".")[-2].split("/")[-1] for p in input["meta"]["path"]])
                 if i == 0:
+                    continue
+                if lanes is not None:
+                    # the lanes hand their poses over themselves; this stream only copies the frame's records out
+                    consume_noise_draws(self.feed_dict[i - 1]["gt_part"], self.pose_perturb_cfg)
+                    pose, cur_npcs = lanes.gather(lanes.step(input["points"], input["points_mean"], sync_inputs=(i == 1)), npcs=True)
+                    npcs_pred.append({k: v.clone() for k, v in cur_npcs.items()})
+                    pred_poses.append({k: v.clone() for k, v in pose.items()})
                     continue
                 # the reference draws (and discards) a perturbed pose every frame (model.py:414);
                 # draw it too so that seeded runs consume the generator identically

@@ -338,6 +338,34 @@ def test_free_running_lanes_equal_eager(device, tag):
         TrackLanes(model, model.feed_dict[1]["points"], model.feed_dict[1]["points_mean"], pose0, lanes=3)
 
 
+def test_track_loop_with_graph_and_lanes_equals_eager(device):
+    """Trainer.test with cfg['hipgraph']: 2 trajectories replay one captured step, 32 run as two free-running lanes
+    (EvalTrackModel._lanes_usable) — poses and CoordinateNet maps of every frame equal the eager loop's, twice in a row
+    (the second call restarts the lanes through set_pose)."""
+    from captra_amd.graph import TrackLanes, TrackStepGraph
+    trainer, cfg, sd, _ = _trainer("bottle", device)
+    model = trainer.model
+    for B, kind in ((2, TrackStepGraph), (32, TrackLanes)):
+        data = clouds.make_trajectory("nocs", B, 4, seed=5)
+        runs = []
+        for use_graph in (False, True, True):
+            model.use_graph = use_graph
+            torch.manual_seed(11)
+            pred, _ = trainer.test(data, save=False, no_eval=True)
+            runs.append(([{k: v.cpu().numpy() for k, v in p.items()} for p in pred["poses"]],
+                         [None if n is None else {k: v.cpu().numpy() for k, v in n.items()} for n in pred["npcs_pred"]]))
+        assert isinstance(model._graph, kind)
+        for poses, npcs in runs[1:]:
+            for i, (a, b) in enumerate(zip(runs[0][0], poses)):
+                for k in a:
+                    np.testing.assert_array_equal(a[k], b[k], err_msg=f"B={B} frame {i} {k}")
+            for i, (a, b) in enumerate(zip(runs[0][1], npcs)):
+                if a is not None:
+                    for k in b:
+                        np.testing.assert_array_equal(a[k], b[k], err_msg=f"B={B} frame {i} npcs {k}")
+    model.use_graph = False
+
+
 @pytest.mark.parametrize("sym", [False, True])
 def test_part_fit_st_vs_oracle_and_golden(device, sym):
     from captra_amd.pose_utils.pose_fit import part_fit_st_cn, part_fit_st_no_ransac
