@@ -63,33 +63,38 @@ WORKLOADS = {  # name: (obj_category, obj_config, synthetic trajectory kind, des
 MIX6 = ["bottle", "bowl", "camera", "can", "laptop", "mug"]
 
 
-def build_workload(batch: int, device, frames: int = 8, category: str = "bottle"):
+def csrc_fingerprint() -> str:
+    """sha1 (16 hex) over the kernel sources (captra_amd/csrc/*.hip, *.h, *.cpp) and the build recipe: the identity of the
+    code a committed counter file was profiled on (there is no .git on the GPU box to ask)."""
+    import hashlib
+    h = hashlib.sha1()
+    csrc = ROOT / "captra_amd" / "csrc"
+    for p in sorted(list(csrc.glob("*.hip")) + list(csrc.glob("*.h")) + list(csrc.glob("*.cpp")) + [ROOT / "captra_amd" / "build.py"]):
+        h.update(p.name.encode())
+        h.update(p.read_bytes())
+    return h.hexdigest()[:16]
+
+
+def build_workload(batch: int, device, frames: int = 8, category: str = "bottle", traj_seed: int = 0, mlp_dtype: str = "fp32"):
+    """`batch` DISTINCT synthetic trajectories (clouds seeded per trajectory; `traj_seed` = the rank, so that no two ranks
+    track the same objects) with physical-regime seeded weights (tests/weights.make_physical_state_dict: the random SA / FP
+    stack of make_state_dict + a planted coordinate pass-through, so the loop tracks -- positive scales, small rotations --
+    and `pose_match` can be asked of the timed trajectories themselves)."""
     from captra_amd.configs import make_config
     from captra_amd.trainer import Trainer
     from tests import clouds
-    from tests.weights import make_state_dict
+    from tests.weights import make_physical_state_dict
 
     obj_category, obj_config, kind, _ = WORKLOADS[category]
     cfg = make_config(obj_category, obj_config, experiment_dir="/tmp/captra_bench")
     cfg["device"] = device
+    cfg["mlp_dtype"] = mlp_dtype
     trainer = Trainer(cfg)
     shapes = {k: tuple(v.shape) for k, v in trainer.model.state_dict().items()}
-    sd = make_state_dict(shapes, seed=7)
+    sd = make_physical_state_dict(shapes, 7, cfg["num_parts"], bool(cfg["obj_sym"]), kind)
     trainer.model.load_state_dict(sd)
     model = trainer.model.eval()
-    # distinct clouds per trajectory (8 base objects tiled), `frames` frames cycled by the loop
-    base = clouds.make_trajectory(kind, min(batch, 8), frames, seed=0)
-    reps = (batch + len(base[0]["points"]) - 1) // len(base[0]["points"])
-
-    def tile(t):
-        return t.repeat((reps,) + (1,) * (t.dim() - 1))[:batch].contiguous()
-
-    data = []
-    for f in base:
-        meta = {"path": (f["meta"]["path"] * reps)[:batch],
-                "nocs2camera": [{k: tile(v) for k, v in part.items()} for part in f["meta"]["nocs2camera"]],
-                "points_mean": tile(f["meta"]["points_mean"]), "nocs_corners": tile(f["meta"]["nocs_corners"])}
-        data.append({"points": tile(f["points"]), "labels": tile(f["labels"]), "nocs": tile(f["nocs"]), "meta": meta})
+    data = clouds.make_trajectory(kind, batch, frames, seed=10 + traj_seed)     # cloud b of this rank: seed (10 + rank) * 100 + b
     model.set_data(data)           # host -> HBM once, before any timed region
     return cfg, sd, model, data
 
@@ -152,8 +157,7 @@ def hbm_ops_roofline(batch: int, device, reps: int = 5):
     from captra_amd import pointnet2_cuda as pc
     from tests import clouds
     B = batch
-    pts = torch.from_numpy(np.stack([clouds.s_nocs(1000 + i)[0] for i in range(min(B, 8))])).to(device)
-    pts = pts.repeat((B + pts.shape[0] - 1) // pts.shape[0], 1, 1)[:B].contiguous()        # (B,N,3)
+    pts = torch.from_numpy(np.stack([clouds.s_nocs(1000 + i)[0] for i in range(B)])).to(device).contiguous()   # (B,N,3), B distinct clouds
     gen = torch.Generator(device="cpu").manual_seed(3)
     levels = [  # (N, M, [(radius, K)], feature channel counts grouped per frame: rot net xyz, coord net xyz + C0)
         (4096, 512, [(0.05, 32), (0.1, 64), (0.2, 128)], [3, 3, 3]),
@@ -228,30 +232,84 @@ def hbm_ops_roofline(batch: int, device, reps: int = 5):
 def pmc_traffic(kernel_prefixes):
     """HBM bytes per launch of the MFMA family from the newest committed PMC summary (profiles/*_bench_pmc.json,
     written by tools/profile_round.sh from separate rocprofv3 --pmc passes): 2 x FETCH_SIZE (gfx950 correction,
-    MI355X_MICROARCH.md) + WRITE_SIZE, KiB -> bytes, averaged over the family's launches."""
+    MI355X_MICROARCH.md) + WRITE_SIZE, KiB -> bytes, averaged over the family's launches.  The file carries the fingerprint
+    of the kernel sources it was profiled on (`csrc_sha16`, tools/pmc_summary.py); a file taken on other sources is NOT
+    used: -> (None, name, reason)."""
     import glob
     files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_bench_pmc.json")))
     if not files:
-        return None, None
+        return None, None, "no profiles/*_bench_pmc.json"
     with open(files[-1]) as fh:
         data = json.load(fh)
+    name = os.path.basename(files[-1])
+    stamp, now = data.get("csrc_sha16"), csrc_fingerprint()
+    if stamp != now:
+        return None, name, (f"{name} was profiled on kernel sources {stamp or '(unstamped)'}, this tree is {now}: re-run "
+                            "tools/profile_round.sh")
     tot, n = 0.0, 0
-    for name, c in data.get("kernels", {}).items():
-        if name.startswith(tuple(kernel_prefixes)) and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+    for kname, c in data.get("kernels", {}).items():
+        if kname.startswith(tuple(kernel_prefixes)) and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
             k = min(c["FETCH_SIZE"]["dispatches"], c["WRITE_SIZE"]["dispatches"])
             tot += k * 1024.0 * (2.0 * c["FETCH_SIZE"]["mean"] + c["WRITE_SIZE"]["mean"])
             n += k
-    return (tot / n if n else None), os.path.basename(files[-1])
+    return (tot / n if n else None), name, None
+
+
+def pose_match(cfg, sd, frame_cpu, prev_pose, new_pose, which=(0, 1)):
+    """Accuracy of the timed trajectories themselves (outside the timed region): the LAST step of the run, for trajectories
+    `which` of this rank, redone by the CPU oracle (oracle/model.py track_step: C geometry + torch-CPU shared MLPs) from the
+    same previous pose -> max |dR|, |dt|, |ds| and 5 deg / 5 cm agreement (eval_part_model, part_dof_utils.py:54-67)."""
+    from captra_amd.pose_utils.part_dof_utils import eval_part_model
+    from oracle import model as OM
+    idx = list(which)
+    prev = {k: v[idx].float().cpu().numpy() for k, v in prev_pose.items()}
+    ours = {k: v[idx].float().cpu() for k, v in new_pose.items()}
+    torch.set_num_threads(min(16, os.cpu_count() or 8))
+    ref, _ = OM.track_step(sd, cfg, frame_cpu["points"][idx].numpy(), frame_cpu["meta"]["points_mean"][idx].numpy(), prev, "torch")
+    ref = {k: torch.from_numpy(np.asarray(v)) for k, v in ref.items()}
+    d = eval_part_model(ref, ours, yaxis_only=bool(cfg["obj_sym"]))
+    hit = torch.logical_and(d["rdiff"] <= 5.0, d["tdiff"] <= 0.05).float().mean()
+    return {"vs": "oracle/model.py track_step (CPU) on the last timed frame, same previous pose", "trajectories": idx,
+            "max_abs_dR": float((ref["rotation"] - ours["rotation"]).abs().max()),
+            "max_abs_dt": float((ref["translation"] - ours["translation"]).abs().max()),
+            "max_abs_ds": float((ref["scale"] - ours["scale"]).abs().max()),
+            "rdiff_deg_max": float(d["rdiff"].max()), "tdiff_m_max": float(d["tdiff"].max()),
+            "agree_5deg5cm": float(hit), "within_1e-4": bool(max(float((ref[k] - ours[k]).abs().max()) for k in ref) <= 1e-4)}
+
+
+def _free_port() -> int:
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_spawn(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) of this very command under
+    torch.distributed.run on 127.0.0.1 and return its exit code.  Refuses when the node has fewer than N GPUs (unless
+    CAPTRA_BENCH_SHARE_GPU=1, the functional test mode in which ranks share devices over gloo)."""
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n and os.environ.get("CAPTRA_BENCH_SHARE_GPU") != "1":
+        raise SystemExit(f"bench.py --gpus {n}: this node has {have} GPU(s); one rank per GPU is the only measured configuration")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd).returncode
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=20, help="untimed steps before the timed region (SURVEY.md 8d: at least 20)")
+    ap.add_argument("--warmup", type=int, default=20, help="untimed steps before the timed region; at least 20 are run whatever the flag (SURVEY.md 8d)")
+    ap.add_argument("--min-warmup", type=int, default=20, help=argparse.SUPPRESS)   # profiling recipes only (short traces)
+    ap.add_argument("--repeats", type=int, default=10,
+                    help="the timed block of exactly --steps steps (barrier + synchronize on both sides) is run this many times back to "
+                         "back; `value` / `ms_per_step` come from the MEDIAN block, min / max are reported beside it")
     ap.add_argument("--batch", type=int, default=32, help="trajectories per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--no-pose-match", action="store_true", help="skip the CPU-oracle check of the timed trajectories' last step")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     ap.add_argument("--no-graph", action="store_true", help="launch the step eagerly instead of replaying a hipGraph")
     ap.add_argument("--lanes", type=int, default=0,
@@ -268,28 +326,40 @@ def main():
                     help="bottle = BASELINE.json configs[1] (the metric's configuration); the other object classes; mix6 = "
                          "BASELINE.json configs[2]'s serving mix: rank r tracks NOCS category 1 + r mod 6 with that category's weights")
     args = ap.parse_args()
-    if args.category == "mix6":
-        args.category = MIX6[int(os.environ.get("RANK", "0")) % 6]
-        args.mix6 = True
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_spawn(args.gpus))        # one rank per GPU, rendezvous on 127.0.0.1
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} launched with WORLD_SIZE={world}: the launcher must start exactly --gpus ranks")
+    if args.category == "mix6":
+        args.category = MIX6[rank % 6]
+        args.mix6 = True
+    share = os.environ.get("CAPTRA_BENCH_SHARE_GPU") == "1"
+    ndev = torch.cuda.device_count()
+    if world > ndev and not share:
+        raise SystemExit(f"bench.py: {world} ranks but {ndev} GPU(s) on this node")
+    dev_index = local_rank % ndev if share else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     dist = None
+    backend = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=device)   # RCCL on ROCm
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+        backend = "gloo" if share else "nccl"        # "nccl" IS RCCL on ROCm; gloo only in the shared-GPU functional test mode
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)
+        else:
+            dist.init_process_group(backend="gloo")
 
     from captra_amd import _lib, fused
     from captra_amd.parallel import PoseExchange
 
-    fused.MLP_DTYPE = args.mlp_dtype
-    cfg, sd, model, data = build_workload(args.batch, device, category=args.category)
+    cfg, sd, model, data = build_workload(args.batch, device, category=args.category, traj_seed=rank, mlp_dtype=args.mlp_dtype)
     B, P = args.batch, cfg["num_parts"]
     if args.lanes == 0:
         args.lanes = 2 if B >= 32 and B % 2 == 0 else 1
@@ -310,8 +380,11 @@ def main():
         else:
             graph = TrackStepGraph(model, f1["points"], f1["points_mean"], pose)
 
+    def frame_of(i):
+        return 1 + i % (nframes - 1)
+
     def step(i, pose, timing_pass=False):
-        f = 1 + i % (nframes - 1)
+        f = frame_of(i)
         if graph is not None and not timing_pass:
             fd = model.feed_dict[f]
             if lanes is not None:
@@ -326,7 +399,8 @@ def main():
         exchange.all_gather(new_pose)          # every rank ends the step holding all poses
         return new_pose
 
-    for i in range(args.warmup):
+    warm = max(args.warmup, args.min_warmup)
+    for i in range(warm):
         pose = step(i, pose)
 
     def sync():
@@ -337,43 +411,70 @@ def main():
 
     timing = not args.no_kernel_timing
     eager_timing = timing and graph is None       # events can bracket kernels only when they are launched eagerly
-    sync()
-    if eager_timing:
-        _lib.prof_reset()
-        _lib.prof_enable(True)
-        fused.work_reset(True)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        pose = step(args.warmup + i, pose)
-    sync()
-    elapsed = time.perf_counter() - t0
-    if eager_timing:
-        _lib.prof_enable(False)
-        fused.WORK["on"] = False
-    elif timing:
-        # the timed region replayed a hipGraph; the per-kernel HIP events come from the same steps
-        # launched eagerly right after it (same kernels, same shapes, same stream)
-        p2 = {k: v.clone() for k, v in pose.items()}
+    done = warm
+    blocks = []                                   # seconds per timed block of exactly args.steps steps, this rank
+    for r in range(max(args.repeats, 1)):
+        sync()
+        if eager_timing and r == 0:
+            _lib.prof_reset()
+            _lib.prof_enable(True)
+            fused.work_reset(True)
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            pose = step(done + i, pose)
+        sync()
+        blocks.append(time.perf_counter() - t0)
+        done += args.steps
+        if eager_timing and r == 0:
+            _lib.prof_enable(False)
+            fused.WORK["on"] = False
+    # the last step once more, keeping its input and output pose, for pose_match (outside every timed block)
+    if lanes is not None:
+        prev_pose = {k: v.clone() for k, v in pose.items()}
+        last_pose = {k: v.clone() for k, v in step(done, pose).items()}
+    else:
+        prev_pose = {k: v.clone() for k, v in pose.items()}
+        last_pose = {k: v.clone() for k, v in step(done, prev_pose).items()}
+    last_frame = frame_of(done)
+    torch.cuda.synchronize()
+    timed_steps = args.steps
+    if timing and not eager_timing:
+        # the timed blocks replayed a hipGraph; the per-kernel HIP events come from the same steps
+        # launched eagerly right after them (same kernels, same shapes, same stream)
+        p2 = {k: v.clone() for k, v in last_pose.items()}
         model.overlap_nets = False   # kernels one at a time: a launch's duration is the kernel's own, not its share of a busy chip
         _lib.prof_reset()
         _lib.prof_enable(True)
         fused.work_reset(True)
-        for i in range(args.steps):
-            p2 = step(args.warmup + i, p2, timing_pass=True)
+        for i in range(timed_steps):
+            p2 = step(done + 1 + i, p2, timing_pass=True)
         torch.cuda.synchronize()
         _lib.prof_enable(False)
         fused.WORK["on"] = False
+    rccl_world = 1
+    per_rank_ms = [[1e3 * b / args.steps for b in blocks]]
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    assert all(torch.isfinite(v).all() for v in pose.values()), "non-finite pose"
+        # the world size as the collective library sees it: an actual all-gather of one word per rank
+        mine = torch.tensor([rank], dtype=torch.int64, device=device)
+        seen = torch.empty(world, dtype=torch.int64, device=device)
+        dist.all_gather_into_tensor(seen, mine)
+        rccl_world = int(seen.unique().numel())
+        assert rccl_world == dist.get_world_size() == world, (rccl_world, dist.get_world_size(), world)
+        mat = torch.tensor(blocks, dtype=torch.float64, device=device)
+        allb = torch.empty(world, len(blocks), dtype=torch.float64, device=device)
+        dist.all_gather_into_tensor(allb, mat)
+        per_rank_ms = (1e3 * allb / args.steps).tolist()
+        blocks = allb.max(dim=0)[0].tolist()              # a block takes as long as its slowest rank
+    assert all(torch.isfinite(v).all() for v in last_pose.values()), "non-finite pose"
 
     if rank != 0:
         if dist is not None:
+            dist.barrier()
             dist.destroy_process_group()
         return
 
+    order = sorted(blocks)
+    elapsed = order[(len(order) - 1) // 2]                # median block (lower median for an even count)
     frames = B * world * args.steps
     out = {
         "metric": "tracked frames/sec (4096-pt clouds)", "value": round(frames / elapsed, 2), "unit": "frames/s",
@@ -384,12 +485,22 @@ def main():
                                + ("fp32" if args.mlp_dtype == "fp32" else "bf16 MFMA operands / fp32 accumulation in the shared MLPs (BASELINE.json configs[2]'s arithmetic; NOT the metric's configuration)")
                                + (" (BASELINE.json configs[2]'s mix: rank r serves NOCS category 1 + r mod 6; rank 0's workload named here)" if getattr(args, "mix6", False)
                                   else " (BASELINE.json configs[1])" if args.category == "bottle" and args.mlp_dtype == "fp32" else " (BASELINE.json configs[3]: drawers)" if args.category == "drawers" else ""),
-                   "points": 4096, "trajectories_per_gpu": B, "parallelism": f"dp{world} (trajectory-sharded, RCCL all-gather of poses)",
-                   "weights": f"random-init default_rng(7), real architecture ({sum(v.numel() for v in sd.values()) / 1e6:.2f} M params incl. BN statistics)",
+                   "points": 4096, "trajectories_per_gpu": B, "distinct_clouds_per_gpu": B,
+                   "parallelism": f"dp{world} (trajectory-sharded, RCCL all-gather of poses)",
+                   "weights": f"seeded default_rng(7) on the real architecture ({sum(v.numel() for v in sd.values()) / 1e6:.2f} M params incl. BN statistics), "
+                              "physical-regime plants (tests/weights.make_physical_state_dict)",
                    "launch": (f"{args.lanes} free-running lanes of {B // args.lanes} trajectories, each a hipGraph replay of the step on its own stream" if lanes is not None
                               else "hipGraph replay of the step" if graph is not None else "eager launches")
                              + (", CoordinateNet and RotationNet side by side on two streams" + (" (two branches of the graph)" if graph is not None else "")
                                 if not args.no_overlap else "")},
+        "timed_blocks": {"n": len(blocks), "steps_each": args.steps, "ms_per_step_median": round(1e3 * elapsed / args.steps, 3),
+                         "ms_per_step_min": round(1e3 * order[0] / args.steps, 3), "ms_per_step_max": round(1e3 * order[-1] / args.steps, 3),
+                         "value_from": "median block; every block = exactly `steps` steps between barrier + device synchronize, max over ranks",
+                         "warmup_steps_run": warm},
+        "rccl_world_size": rccl_world,
+        "collective_backend": ("none (single rank)" if world == 1 else "nccl (RCCL)" if backend == "nccl" else
+                               "gloo -- CAPTRA_BENCH_SHARE_GPU functional test mode: ranks share GPUs, NOT a scaling measurement"),
+        "per_rank_ms_per_step": [[round(x, 3) for x in row] for row in per_rank_ms],
     }
     if timing:
         fams = {}
@@ -410,15 +521,20 @@ def main():
             peak = PEAK_F32_MFMA_TFLOPS if args.mlp_dtype == "fp32" else PEAK_BF16_MFMA_TFLOPS
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                                "frac": round(ach / peak, 4), "traffic": None,
-                               "kernel": ("fp32 MFMA 32x32x2 shared-MLP kernels: sa_wave_kernel / sa_wave_lds_kernel (dominant) + mlp_chain3_kernel + coord_tail_kernel + pw_direct_kernel + pw_direct_max_kernel"
+                               "kernel": ("fp32 MFMA shared-MLP kernels: sa_wave_kernel / sa_wave_lds_kernel (dominant) + mlp_chain3_kernel + coord_tail_kernel + pw_direct_kernel + pw_direct_max_kernel"
                                           if args.mlp_dtype == "fp32" else "bf16 MFMA 32x32x16 shared-MLP kernels: sa_wave_bf16_kernel + pw_bf16_kernel"),
                                "avg_launch_us": round(1e3 * mlp_ms / max(mlp_launches, 1), 2),
                                "flops_per_launch": round(mlp_flops / max(mlp_launches, 1)),
                                "share_of_kernel_time": round(mlp_ms / max(total_ms, 1e-9), 3), "dominant_family": dominant}
-            traffic, src = (None, None) if args.mlp_dtype != "fp32" else pmc_traffic(["sa_wave_kernel", "sa_wave_lds_kernel", "sa_fused_kernel", "mlp_chain3_kernel", "coord_tail_kernel", "pw_direct_kernel", "pw_direct_max_kernel", "pw_mlp_kernel"])
+            traffic, src, why = (None, None, "fp32 counter files only") if args.mlp_dtype != "fp32" else pmc_traffic(
+                ["sa_wave_kernel", "sa_wave_lds_kernel", "sa_fused_kernel", "mlp_chain3_kernel", "coord_tail_kernel", "pw_direct_kernel", "pw_direct_max_kernel", "pw_mlp_kernel"])
             if traffic is not None:
                 out["roofline"]["traffic"] = round(traffic)
-                out["roofline"]["traffic_source"] = f"profiles/{src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch)"
+                out["roofline"]["traffic_source"] = (f"profiles/{src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch; "
+                                                     f"profiled on kernel sources {csrc_fingerprint()} = this tree)")
+            else:
+                out["roofline"]["traffic_source"] = f"null: {why}"
+                print(f"bench.py: roofline.traffic dropped -- {why}", file=sys.stderr)
         if "ball_query" in fams:
             bq = fams["ball_query"]
             nbytes = fused.WORK["bytes"].get("ball_query", 0.0)
@@ -426,8 +542,8 @@ def main():
             out["roofline_ball_query"] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                           "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None,
                                           "avg_launch_us": round(1e3 * bq["ms_total"] / bq["launches"], 2)}
-        out["kernel_ms_per_step"] = {k: round(v["ms_total"] / args.steps, 3) for k, v in sorted(fams.items(), key=lambda kv: -kv[1]["ms_total"])}
-        out["kernel_ms_per_step"]["_sum_captra_kernels"] = round(total_ms / args.steps, 3)
+        out["kernel_ms_per_step"] = {k: round(v["ms_total"] / timed_steps, 3) for k, v in sorted(fams.items(), key=lambda kv: -kv[1]["ms_total"])}
+        out["kernel_ms_per_step"]["_sum_captra_kernels"] = round(total_ms / timed_steps, 3)
     if world == 1 and timing:
         out["hbm_ops"] = hbm_ops_roofline(B, device)
         bq_ms = out.get("kernel_ms_per_step", {}).get("ball_query")
@@ -437,11 +553,18 @@ def main():
             eq = out["hbm_ops"]["bytes_per_frame"] * B / (bq_ms * 1e-3) / 1e9
             out["hbm_ops"]["product_path"] = {"ms_per_step": bq_ms, "equivalent_GB/s": round(eq, 1), "equivalent_frac": round(eq / PEAK_HBM_GBS, 3),
                                               "note": "materialised-op bytes of one step / time the step spends in ball query (group is fused into the MFMA kernels)"}
+    if not args.no_pose_match and args.mlp_dtype == "fp32":
+        out["pose_match"] = pose_match(cfg, sd, data[last_frame], prev_pose, last_pose)
     if world == 1 and not args.no_cpu_baseline and args.category == "bottle":
         out["cpu_baseline"] = cpu_baseline(cfg, sd, args.cpu_budget)
+        out["cpu_baseline"]["reference_cpu_path_in_authoring_container"] = {
+            "value": 3.08, "unit": "frames/s", "cores": 8,
+            "note": "BASELINE.md section 2: the reference's own CPU fallback path (EvalTrackModel.test, bottle, B=1, 4096 pts), timed in the "
+                    "authoring container -- the reference's Python cannot travel to the GPU box, so this is a recorded number, not re-measured here"}
         out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
-    print(json.dumps(out))
+    print(json.dumps(out), flush=True)
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -134,16 +134,23 @@ class MLPConv1d(nn.Module):
         self.out_channel = last
         self._cache = {}
 
-    def train(self, mode=True):
+    def _drop_cache(self):
+        if self._cache:
+            from .fold import bump_weights_version
+            bump_weights_version()
         self._cache = {}
+
+    def train(self, mode=True):
+        if mode != self.training:       # eval() while already in eval mode keeps the folded weights (see _FoldCache.train)
+            self._drop_cache()
         return super().train(mode)
 
     def _load_from_state_dict(self, *a, **k):
-        self._cache = {}
+        self._drop_cache()
         return super()._load_from_state_dict(*a, **k)
 
     def _apply(self, fn, *a, **k):
-        self._cache = {}
+        self._drop_cache()
         return super()._apply(fn, *a, **k)
 
     def forward(self, input):

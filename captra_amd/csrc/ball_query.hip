@@ -165,12 +165,10 @@ int launch_ball_query(int b, int n, int m, int nr, const float *radius, const in
 #define BQ_LAUNCH(NR)                                                                            \
     {                                                                                            \
         auto kern = ball_query_kernel<NR>;                                                       \
-        static bool attr_set = false;                                                            \
-        if (!attr_set) {                                                                         \
+        static CaptraDeviceOnce once;                                                            \
+        if (once.first_use())                                                                    \
             hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                            \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, BQ_TILE * 12);       \
-            attr_set = true;                                                                     \
-        }                                                                                        \
         CAPTRA_LAUNCH("ball_query", kern, grid, block, shmem, s, n, m, new_xyz, xyz, prm);       \
     }
     switch (nr) {

@@ -25,6 +25,25 @@ struct CaptraProfScope {
 
 static inline int captra_last_error() { return (int)hipGetLastError(); }
 
+// ---- per-device one-shot (kernel function attributes) ---------------------------------------------
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per DEVICE: a process that launches on a second GPU must set it
+// there too.  captra_first_use_on_device(flags) is true the first time it is called for the current device with this
+// flag word (one bit per device ordinal, atomic; two threads racing both set the attribute, which is idempotent).
+#include <atomic>
+struct CaptraDeviceOnce {
+    std::atomic<unsigned long long> seen[2] = {{0ull}, {0ull}};   // device ordinals 0..127
+    bool first_use() {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 128) return true;   // unknown device: always (re)set
+        const unsigned long long bit = 1ull << (dev & 63);
+        return (seen[dev >> 6].fetch_or(bit, std::memory_order_relaxed) & bit) == 0ull;
+    }
+};
+
+// debug / experiment knobs (captra_*_set_*): thread-local so that one host thread's A/B switch never changes what
+// another thread (another GPU's stream in the same process) launches; the reference boundary has no global state.
+#define CAPTRA_KNOB thread_local
+
 // ---- device helpers ---------------------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 

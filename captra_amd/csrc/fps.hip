@@ -345,7 +345,7 @@ __global__ __launch_bounds__(1024) void fps_kernel_big(int n, int m, const float
     }
 }
 
-static int g_fps_variant = 0;  // 0 = blocked / ballot / packed-math kernel where it applies, 1 = first-generation kernel
+static CAPTRA_KNOB int g_fps_variant = 0;  // 0 = blocked / ballot / packed-math kernel where it applies, 1 = first-generation kernel
 
 template <int NWAVES, int PPT>
 int launch_fps(int b, int n, int m, const float *xyz, float *temp, int *idx, hipStream_t s, float *new_n3 = nullptr,
@@ -355,11 +355,9 @@ int launch_fps(int b, int n, int m, const float *xyz, float *temp, int *idx, hip
     if constexpr (PPT % 2 == 0) {
         if (g_fps_variant == 0 && slots + lds_xyz <= 150 * 1024) {
             auto kern2 = fps_kernel_blocked<NWAVES, PPT, true>;
-            static bool attr2_set = false;
-            if (!attr2_set) {
+            static CaptraDeviceOnce once2;
+            if (once2.first_use())
                 hipFuncSetAttribute(reinterpret_cast<const void *>(kern2), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-                attr2_set = true;
-            }
             CAPTRA_LAUNCH("fps", kern2, dim3(b), dim3(NWAVES * 64), slots + lds_xyz, s, n, m, xyz, temp, idx, new_n3, new_cn, ns);
             return captra_last_error();
         }
@@ -372,12 +370,10 @@ int launch_fps(int b, int n, int m, const float *xyz, float *temp, int *idx, hip
     if (need_blocked || ns != nullptr) return -2;  // the fused sample + gather entry exists on the blocked kernel only
     if (slots + lds_xyz <= 150 * 1024) {
         auto kern = fps_kernel<NWAVES, PPT, true>;
-        static bool attr_set = false;
-        if (!attr_set) {
+        static CaptraDeviceOnce once;
+        if (once.first_use())
             hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-            attr_set = true;
-        }
         CAPTRA_LAUNCH("fps", kern, dim3(b), dim3(NWAVES * 64), slots + lds_xyz, s, n, m, xyz, temp, idx);
     } else {
         CAPTRA_LAUNCH("fps", (fps_kernel<NWAVES, PPT, false>), dim3(b), dim3(NWAVES * 64), slots, s, n, m,
@@ -391,12 +387,12 @@ int launch_fps(int b, int n, int m, const float *xyz, float *temp, int *idx, hip
 // fps_pruned.hip: exact spatially-pruned kernel for 8k-20k point clouds (-2 beyond its capacity)
 int captra_fps_pruned_launch(int b, int n_stride, const int *n_per_cloud, int m, const float *xyz, float *temp, int *idx,
                              float *new_n3, float *new_cn, hipStream_t s);
-static int g_fps_pruned_min = 8192;   // clouds of at least this many points take the pruned kernel (0 = never)
+static CAPTRA_KNOB int g_fps_pruned_min = 8192;   // clouds of at least this many points take the pruned kernel (0 = never)
 extern "C" void captra_fps_set_pruned_min(int n) { g_fps_pruned_min = n; }
 
 // Tunable from the host for experiments: waves per cloud for the register-resident kernel
 // (0 = heuristic).  Not part of the stable ABI.
-static int g_fps_waves = 0;
+static CAPTRA_KNOB int g_fps_waves = 0;
 extern "C" void captra_fps_set_waves(int w) { g_fps_waves = w; }
 extern "C" void captra_fps_set_variant(int v) { g_fps_variant = v; }
 

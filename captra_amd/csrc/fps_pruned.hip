@@ -333,13 +333,12 @@ int launch_pruned(int b, int n_stride, const int *ns, int m, const float *xyz, f
     const size_t shmem = 2 * 16 * (sizeof(uint2) + sizeof(float4)) + 6 * 16 * sizeof(float) + (size_t)CAP * 2 +
                          (sort_bytes > ovf_bytes ? sort_bytes : ovf_bytes);
     constexpr int FP_T = FP_NW * 64;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static CaptraDeviceOnce once;
+    if (once.first_use()) {
         hipFuncSetAttribute(reinterpret_cast<const void *>(fps_pruned_kernel<FP_NW, A, B, false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         hipFuncSetAttribute(reinterpret_cast<const void *>(fps_pruned_kernel<FP_NW, A, B, true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        attr_set = true;
     }
     if (g_fps_stats != nullptr) {   // instrumented build of the same kernel (counters + s_memtime per phase)
         CAPTRA_LAUNCH("fps", (fps_pruned_kernel<FP_NW, A, B, true>), dim3(b), dim3(FP_T), shmem, s, n_stride, ns, m, xyz, temp,

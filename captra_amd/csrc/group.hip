@@ -10,7 +10,8 @@
 
 // scatter_reduce.hip: CSR inversion of an index list + per-source-point sums (-2: shape outside that path)
 int captra_scatter_reduce(bool interp, int b, int c, int n_src, long long npos, const float *grad_out, const float *weight,
-                          const int *idx, float *grad_points, hipStream_t s);
+                          const int *idx, float *grad_points, void *workspace, size_t workspace_bytes, hipStream_t s);
+size_t captra_scatter_ws_bytes(int b, int c, int n_src, long long npos);
 
 namespace {
 
@@ -130,13 +131,12 @@ int launch_group(int b, int c, int n, long long npos, const float *points, const
     size_t shmem = (size_t)cc * row_bytes;
     const bool vec = (npos % 4 == 0) && ((reinterpret_cast<uintptr_t>(idx) & 15) == 0) &&
                      ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static CaptraDeviceOnce once;
+    if (once.first_use()) {
         hipFuncSetAttribute(reinterpret_cast<const void *>(group_points_kernel<4>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, GP_LDS_BYTES);
         hipFuncSetAttribute(reinterpret_cast<const void *>(group_points_kernel<1>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, GP_LDS_BYTES);
-        attr_set = true;
     }
     if (vec) {
         CAPTRA_LAUNCH("group_points", group_points_kernel<4>, grid, dim3(GP_THREADS), shmem, s, c, n, npos, cc, ppb,
@@ -148,12 +148,15 @@ int launch_group(int b, int c, int n, long long npos, const float *points, const
     return captra_last_error();
 }
 
+// workspace == nullptr: the reference's algorithm (float atomics, group_points_gpu.cu:8-25), which needs no scratch.
+// With the caller's scratch (captra_group_points_grad_ws_bytes): the index list, shared by every channel, is inverted once
+// and every source point sums its own list in ascending position order (scatter_reduce.hip) -- no atomics, bit-reproducible.
 int launch_group_grad(int b, int c, int n, long long npos, const float *grad_out, const int *idx,
-                      float *grad_points, hipStream_t s) {
+                      float *grad_points, void *workspace, size_t workspace_bytes, hipStream_t s) {
     if (b < 0 || c < 0 || n < 0 || npos < 0) return -1;
     if (b == 0 || c == 0 || npos == 0) return 0;
-    if (c >= 8) {   // many channels share one index list: invert it once, then sum per source point (scatter_reduce.hip)
-        const int rc = captra_scatter_reduce(false, b, c, n, npos, grad_out, nullptr, idx, grad_points, s);
+    if (workspace != nullptr) {
+        const int rc = captra_scatter_reduce(false, b, c, n, npos, grad_out, nullptr, idx, grad_points, workspace, workspace_bytes, s);
         if (rc != -2) return rc;
     }
     dim3 grid((unsigned)((npos + GP_THREADS - 1) / GP_THREADS), c < 64 ? c : 64, b);
@@ -172,7 +175,18 @@ extern "C" int captra_group_points(int b, int c, int n, int npoints, int nsample
 extern "C" int captra_group_points_grad(int b, int c, int n, int npoints, int nsample,
                                         const float *grad_out, const int *idx, float *grad_points,
                                         captra_stream_t stream) {
-    return launch_group_grad(b, c, n, (long long)npoints * nsample, grad_out, idx, grad_points,
+    return launch_group_grad(b, c, n, (long long)npoints * nsample, grad_out, idx, grad_points, nullptr, 0,
+                             (hipStream_t)stream);
+}
+
+extern "C" size_t captra_group_points_grad_ws_bytes(int b, int c, int n, int npoints, int nsample) {
+    return captra_scatter_ws_bytes(b, c, n, (long long)npoints * nsample);
+}
+
+extern "C" int captra_group_points_grad_ws(int b, int c, int n, int npoints, int nsample, const float *grad_out,
+                                           const int *idx, float *grad_points, void *workspace, size_t workspace_bytes,
+                                           captra_stream_t stream) {
+    return launch_group_grad(b, c, n, (long long)npoints * nsample, grad_out, idx, grad_points, workspace, workspace_bytes,
                              (hipStream_t)stream);
 }
 
@@ -184,5 +198,5 @@ extern "C" int captra_gather_points(int b, int c, int n, int npoints, const floa
 
 extern "C" int captra_gather_points_grad(int b, int c, int n, int npoints, const float *grad_out,
                                          const int *idx, float *grad_points, captra_stream_t stream) {
-    return launch_group_grad(b, c, n, (long long)npoints, grad_out, idx, grad_points, (hipStream_t)stream);
+    return launch_group_grad(b, c, n, (long long)npoints, grad_out, idx, grad_points, nullptr, 0, (hipStream_t)stream);
 }

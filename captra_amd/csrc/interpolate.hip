@@ -17,7 +17,8 @@
 
 // scatter_reduce.hip
 int captra_scatter_reduce(bool interp, int b, int c, int n_src, long long npos, const float *grad_out, const float *weight,
-                          const int *idx, float *grad_points, hipStream_t s);
+                          const int *idx, float *grad_points, void *workspace, size_t workspace_bytes, hipStream_t s);
+size_t captra_scatter_ws_bytes(int b, int c, int n_src, long long npos);
 
 namespace {
 
@@ -227,29 +228,45 @@ extern "C" int captra_three_interpolate(int b, int c, int m, int n, const float 
     int cc = (int)(TI_LDS_BYTES / row_bytes);
     if (cc > c) cc = c;
     if (cc > 32) cc = 32;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static CaptraDeviceOnce once;
+    if (once.first_use())
         hipFuncSetAttribute(reinterpret_cast<const void *>(three_interpolate_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, TI_LDS_BYTES);
-        attr_set = true;
-    }
     dim3 grid((n + TI_POS_PER_BLOCK - 1) / TI_POS_PER_BLOCK, (c + cc - 1) / cc, b);
     CAPTRA_LAUNCH("three_interpolate", three_interpolate_kernel, grid, dim3(TI_THREADS), (size_t)cc * row_bytes, s,
                   c, m, n, cc, points, idx, weight, out);
     return captra_last_error();
 }
 
-extern "C" int captra_three_interpolate_grad(int b, int c, int n, int m, const float *grad_out,
-                                             const int *idx, const float *weight, float *grad_points,
-                                             captra_stream_t stream) {
+// workspace == nullptr: float atomics like interpolate_gpu.cu:192-214 (no scratch).  With the caller's scratch the positions
+// (n, j) are grouped by the known point they read and summed per point in ascending order (scatter_reduce.hip).
+static int launch_interp_grad(int b, int c, int n, int m, const float *grad_out, const int *idx, const float *weight,
+                              float *grad_points, void *workspace, size_t workspace_bytes, captra_stream_t stream) {
     if (b < 0 || c < 0 || m < 0 || n < 0) return -1;
     if (b == 0 || c == 0 || n == 0) return 0;
-    if (c >= 8) {   // positions (n, j) grouped by the known point they read: per-point sums instead of 3 float atomics per (channel, n)
-        const int rc = captra_scatter_reduce(true, b, c, m, 3ll * n, grad_out, weight, idx, grad_points, (hipStream_t)stream);
+    if (workspace != nullptr) {
+        const int rc = captra_scatter_reduce(true, b, c, m, 3ll * n, grad_out, weight, idx, grad_points, workspace, workspace_bytes,
+                                             (hipStream_t)stream);
         if (rc != -2) return rc;
     }
     dim3 grid((n + TI_THREADS - 1) / TI_THREADS, c < 64 ? c : 64, b);
     CAPTRA_LAUNCH("three_interpolate_grad", three_interpolate_grad_kernel, grid, dim3(TI_THREADS), 0,
                   (hipStream_t)stream, c, n, m, grad_out, idx, weight, grad_points);
     return captra_last_error();
+}
+
+extern "C" int captra_three_interpolate_grad(int b, int c, int n, int m, const float *grad_out,
+                                             const int *idx, const float *weight, float *grad_points,
+                                             captra_stream_t stream) {
+    return launch_interp_grad(b, c, n, m, grad_out, idx, weight, grad_points, nullptr, 0, stream);
+}
+
+extern "C" size_t captra_three_interpolate_grad_ws_bytes(int b, int c, int n, int m) {
+    return captra_scatter_ws_bytes(b, c, m, 3ll * n);
+}
+
+extern "C" int captra_three_interpolate_grad_ws(int b, int c, int n, int m, const float *grad_out, const int *idx,
+                                                const float *weight, float *grad_points, void *workspace,
+                                                size_t workspace_bytes, captra_stream_t stream) {
+    return launch_interp_grad(b, c, n, m, grad_out, idx, weight, grad_points, workspace, workspace_bytes, stream);
 }

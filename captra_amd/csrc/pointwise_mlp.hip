@@ -579,7 +579,7 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(int nb, int c, int cpg
     }
 }
 
-static int g_pw_direct = 1;  // experiment knob: 0 = LDS-staged kernel for dense layers too
+static CAPTRA_KNOB int g_pw_direct = 1;  // experiment knob: 0 = LDS-staged kernel for dense layers too
 
 int launch_pw_direct(int b, const PwParams &p, hipStream_t s) {
     if ((long long)p.cin * p.L * 4 >= (1ll << 31)) return -3;  // buffer offsets are 32-bit: fall back

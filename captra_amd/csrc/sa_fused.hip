@@ -703,9 +703,9 @@ __global__ __launch_bounds__(SL_WAVES * 64) __attribute__((amdgpu_waves_per_eu(4
 }  // namespace
 
 // experiment knob (not part of the ABI): force the sub-tile width, 0 = heuristic
-static int g_sa_wn = 0;
+static CAPTRA_KNOB int g_sa_wn = 0;
 extern "C" void captra_sa_fused_set_wn(int wn) { g_sa_wn = wn; }
-static int g_sa_mode = 0;  // 0 = heuristic (register-resident kernels where instantiated), 1 = always the generic LDS kernel,
+static CAPTRA_KNOB int g_sa_mode = 0;  // 0 = heuristic (register-resident kernels where instantiated), 1 = always the generic LDS kernel,
                            // 2 = register-resident kernels with streamed weights only (no LDS-weight variant)
 extern "C" void captra_sa_fused_set_mode(int mode) { g_sa_mode = mode; }
 static unsigned long long *g_sa_prof = nullptr;  // device buffer of 10 counters: sa_wave_kernel's opt-in phase timers
@@ -740,15 +740,19 @@ extern "C" int captra_sa_scale_fused(int b, int n, int m, int k, int cfeat, int 
     if (g_sa_mode != 2 && cfeat == CF_ && c1 == C1_ && c2 == C2_ && c3 == C3_ && SL_POS % k == 0) {                    \
         auto kern = sa_wave_lds_kernel<CF_, C1_, C2_, C3_>;                                                            \
         constexpr int lds_bytes = sl_lds_floats<CF_, C1_, C2_, C3_>() * 4;                                             \
-        static int resident = 0;                                                                                       \
+        static std::atomic<int> resident_of[128];              /* per device: the attribute and the occupancy are */    \
+        int dev = 0;                                                                                                   \
+        (void)hipGetDevice(&dev);                                                                                      \
+        std::atomic<int> &resident_slot = resident_of[dev & 127];                                                      \
+        int resident = resident_slot.load(std::memory_order_relaxed);                                                  \
         if (resident == 0) {                                                                                           \
-            int per_cu = 0, dev = 0;                                                                                   \
+            int per_cu = 0;                                                                                            \
             hipDeviceProp_t prop;                                                                                      \
-            (void)hipGetDevice(&dev);                                                                                  \
             (void)hipGetDeviceProperties(&prop, dev);                                                                  \
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); \
             (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, SL_WAVES * 64, lds_bytes);                \
             resident = (per_cu > 0 ? per_cu : 1) * (prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);    \
+            resident_slot.store(resident, std::memory_order_relaxed);                                                  \
         }                                                                                                              \
         const long long tiles = ((Lw + SL_POS - 1) / SL_POS) * b;                                                      \
         q.b = b;                                                                                                       \
@@ -790,11 +794,10 @@ extern "C" int captra_sa_scale_fused(int b, int n, int m, int k, int cfeat, int 
     int wn = (2 * lds64 <= 160 * 1024) ? 2 : 1;
     if (g_sa_wn == 1 || g_sa_wn == 2) wn = g_sa_wn;
     if ((wn == 2 ? lds64 : lds32) > 160 * 1024) return -2;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static CaptraDeviceOnce once;
+    if (once.first_use()) {
         hipFuncSetAttribute(reinterpret_cast<const void *>(sa_fused_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipFuncSetAttribute(reinterpret_cast<const void *>(sa_fused_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
     }
     if (wn == 2) {
         CAPTRA_LAUNCH("sa_scale_fused", sa_fused_kernel<2>, grid, dim3(512), lds64, (hipStream_t)stream, p);

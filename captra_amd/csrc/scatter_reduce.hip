@@ -140,34 +140,36 @@ __global__ __launch_bounds__(1024) void scatter_reduce_lds_kernel(int c, int n_s
 
 // -> 0 on success, -2 when the shape is outside the CSR path (caller falls back to its atomic kernel).
 // idx: (B, npos) entries in [0, n_src); grad_out rows have row_len = npos (group) or npos / 3 (interpolation).
+// Scratch of the CSR path in bytes (0: the shape is outside it): B x (n_src + 1) row starts + B x npos ordered positions, int32.
+size_t captra_scatter_ws_bytes(int b, int c, int n_src, long long npos) {
+    if (c < 8 || b < 1 || n_src > CSR_MAX_SRC || npos > (1ll << 30) || n_src < 1 || npos < 1) return 0;
+    return (size_t)b * ((size_t)n_src + 1 + (size_t)npos) * sizeof(int);
+}
+
+// The caller owns the scratch (include/captra_hip.h: "the caller owns every buffer, scratch included"): `ws` must hold
+// captra_scatter_ws_bytes(...) bytes; nothing is allocated here.
 int captra_scatter_reduce(bool interp, int b, int c, int n_src, long long npos, const float *grad_out, const float *weight,
-                          const int *idx, float *grad_points, hipStream_t s) {
-    if (n_src > CSR_MAX_SRC || npos > (1ll << 30) || n_src < 1) return -2;
-    int *ws = nullptr;
-    const size_t words = (size_t)b * ((size_t)n_src + 1 + (size_t)npos);
-    if (hipMallocAsync(reinterpret_cast<void **>(&ws), words * sizeof(int), s) != hipSuccess) {
-        (void)hipGetLastError();
-        return -2;
-    }
+                          const int *idx, float *grad_points, void *workspace, size_t workspace_bytes, hipStream_t s) {
+    const size_t need = captra_scatter_ws_bytes(b, c, n_src, npos);
+    if (need == 0) return -2;
+    if (workspace == nullptr || workspace_bytes < need) return (int)hipErrorInvalidValue;
+    int *ws = static_cast<int *>(workspace);
     int *start = ws, *order = ws + (size_t)b * (n_src + 1);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static CaptraDeviceOnce once;
+    if (once.first_use())
         hipFuncSetAttribute(reinterpret_cast<const void *>(build_csr_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             CSR_MAX_SRC * (int)sizeof(int));
-        attr_set = true;
-    }
     CAPTRA_LAUNCH("scatter_csr", build_csr_kernel, dim3(b), dim3(CSR_T), (size_t)n_src * sizeof(int), s, n_src, (int)npos, idx,
                   start, order);
     dim3 grid((n_src + 255) / 256, (c + SR_CH - 1) / SR_CH, b);
     const int row_len = interp ? (int)(npos / 3) : (int)npos;
     if (row_len <= 16384 && c >= 8) {
-        static bool lds_attr = false;
-        if (!lds_attr) {
+        static CaptraDeviceOnce once_lds;
+        if (once_lds.first_use()) {
             hipFuncSetAttribute(reinterpret_cast<const void *>(scatter_reduce_lds_kernel<true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * (int)sizeof(float));
             hipFuncSetAttribute(reinterpret_cast<const void *>(scatter_reduce_lds_kernel<false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * (int)sizeof(float));
-            lds_attr = true;
         }
         int cpb = 1;
         while ((long long)((c + cpb - 1) / cpb) * b > 1024 && cpb < 16) cpb *= 2;   // ~2-4 workgroups per CU
@@ -186,7 +188,5 @@ int captra_scatter_reduce(bool interp, int b, int c, int n_src, long long npos, 
         CAPTRA_LAUNCH("scatter_reduce", scatter_reduce_kernel<false>, grid, dim3(256), 0, s, c, n_src, (int)npos, row_len, grad_out,
                       weight, start, order, grad_points);
     }
-    const int err = captra_last_error();
-    (void)hipFreeAsync(ws, s);
-    return err;
+    return captra_last_error();
 }

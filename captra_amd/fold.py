@@ -10,6 +10,39 @@ from __future__ import annotations
 
 import torch
 
+# Bumped whenever a module drops its folded weights (mode change, load_state_dict, .to()).  Anything that baked raw device
+# pointers of folded tensors into a captured hipGraph compares the value it was captured at (captra_amd/graph.py, model.py).
+_WEIGHTS_VERSION = [0]
+
+
+def weights_version() -> int:
+    return _WEIGHTS_VERSION[0]
+
+
+def bump_weights_version() -> None:
+    _WEIGHTS_VERSION[0] += 1
+
+
+def collect_folded(module) -> list:
+    """Every PackedLinear currently cached under `module` (the `_folded` / `_cache` attributes of the fused modules):
+    holding this list keeps the device buffers a captured graph points at alive."""
+    found = []
+
+    def walk(obj):
+        if isinstance(obj, PackedLinear):
+            found.append(obj)
+        elif isinstance(obj, (list, tuple)):
+            for o in obj:
+                walk(o)
+        elif isinstance(obj, dict):
+            for o in obj.values():
+                walk(o)
+
+    for m in module.modules():
+        walk(getattr(m, "_folded", None))
+        walk(getattr(m, "_cache", None))
+    return found
+
 
 class PackedLinear:
     """A layer's weights in the layout the MFMA kernels stage (include/captra_hip.h "packed weights"):

@@ -5,7 +5,9 @@ contiguity, and launches on torch's current stream.  No CPU fallback.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
+import threading
 
 import torch
 
@@ -72,11 +74,41 @@ def pack(wt_dense, bias_dense) -> PackedLinear:
     return PackedLinear(wt_dense.float(), bias_dense.float())
 
 
-MLP_DTYPE = "fp32"       # "bf16": bf16 operands / fp32 accumulation for the shared MLPs (BASELINE.json configs[2]); opt-in
+# Arithmetic of the shared MLPs: "fp32" (exact, the metric's configuration) or "bf16" (bf16 MFMA operands / fp32 accumulation,
+# BASELINE.json configs[2]; opt-in).  NOT process-global: a per-thread setting, normally entered by the model that owns it
+# (EvalTrackModel(cfg['mlp_dtype']) wraps its step in `use_mlp_dtype`), so two models / two host threads never see each
+# other's mode.
+MLP_DTYPES = ("fp32", "bf16")
+_TLS = threading.local()
+
+
+def mlp_dtype() -> str:
+    return getattr(_TLS, "mlp_dtype", "fp32")
+
+
+def set_mlp_dtype(dtype: str) -> None:
+    """Default of the calling thread (tools / ad-hoc scripts); models use `use_mlp_dtype`."""
+    if dtype not in MLP_DTYPES:
+        raise ValueError(f"mlp dtype {dtype!r}: expected one of {MLP_DTYPES}")
+    _TLS.mlp_dtype = dtype
+
+
+@contextlib.contextmanager
+def use_mlp_dtype(dtype):
+    """`with use_mlp_dtype("bf16"): ...` -- the shared-MLP launches of this thread inside the block; None = leave as is."""
+    if dtype is None:
+        yield
+        return
+    prev = mlp_dtype()
+    set_mlp_dtype(dtype)
+    try:
+        yield
+    finally:
+        _TLS.mlp_dtype = prev
 
 
 def pointwise_mlp(x, lin: PackedLinear, act: int = ACT_RELU, out=None):
-    """x (B,cin,*), packed layer -> (B,cout,*) = act(W x + b) (exact-fp32 MFMA; bf16 operands when MLP_DTYPE is "bf16")."""
+    """x (B,cin,*), packed layer -> (B,cout,*) = act(W x + b) (exact-fp32 MFMA; bf16 operands inside `use_mlp_dtype("bf16")`)."""
     wt, bias = lin.wt, lin.bias
     L.require_device(x, wt, bias)
     B, cin = x.shape[0], x.shape[1]
@@ -85,7 +117,7 @@ def pointwise_mlp(x, lin: PackedLinear, act: int = ACT_RELU, out=None):
     l = x.numel() // max(B * cin, 1)
     if out is None:
         out = torch.empty((B, cout) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
-    if MLP_DTYPE == "bf16":
+    if mlp_dtype() == "bf16":
         with torch.cuda.device(x.device):
             L.call("captra_pointwise_mlp_bf16", B, cin, cout, l, L.ptr(x), L.ptr(lin.bf16(0, cin)), L.ptr(bias), act, L.ptr(out))
         _work("pointwise_mlp", flops=2.0 * B * cin * cout * l, nbytes=4.0 * B * l * (cin + cout))
@@ -131,7 +163,7 @@ _SA_BF16_SHAPES = {(0, 32, 32, 64), (0, 64, 64, 128), (0, 64, 96, 128), (3, 32, 
 
 
 def sa_scale_bf16_supported(cfeat, layers, k) -> bool:
-    return (MLP_DTYPE == "bf16" and len(layers) == 3 and k % 32 == 0 and 128 % k == 0
+    return (mlp_dtype() == "bf16" and len(layers) == 3 and k % 32 == 0 and 128 % k == 0
             and (cfeat, layers[0].cout, layers[1].cout, layers[2].cout) in _SA_BF16_SHAPES)
 
 
@@ -210,7 +242,7 @@ def gn_chain_supported(x, cout: int) -> bool:
     configuration of the direct kernel (csrc/pointwise_mlp.hip captra_pointwise_mlp_gn; fp32 path only)."""
     B, cin = x.shape[0], x.shape[1]
     l = x.numel() // max(B * cin, 1)
-    return USE_GN_FUSED and MLP_DTYPE == "fp32" and cout > 64 and cin * l * 4 < (1 << 31)
+    return USE_GN_FUSED and mlp_dtype() == "fp32" and cout > 64 and cin * l * 4 < (1 << 31)
 
 
 def pointwise_mlp_gn(x, lin: PackedLinear, ab_in=None, act: int = ACT_NONE, want_stats: bool = False):
@@ -252,7 +284,7 @@ def mlp_chain3(x, layers, act3: int = ACT_RELU):
     assert x.shape[1] == shape[0] and layers[1].cin == shape[1] and layers[2].cin == shape[2], (x.shape, shape)
     B = x.shape[0]
     l = x.numel() // max(B * shape[0], 1)
-    if not (USE_MLP_CHAIN and MLP_DTYPE == "fp32" and shape in _CHAIN3_SHAPES and shape[0] * l * 4 < (1 << 31)):
+    if not (USE_MLP_CHAIN and mlp_dtype() == "fp32" and shape in _CHAIN3_SHAPES and shape[0] * l * 4 < (1 << 31)):
         y = pointwise_mlp(x, layers[0], ACT_RELU)
         y = pointwise_mlp(y, layers[1], ACT_RELU)
         return pointwise_mlp(y, layers[2], act3)
@@ -273,7 +305,7 @@ _COORD_TAIL_SHAPES = {(134, 2, 3), (134, 4, 12), (134, 3, 9), (134, 2, 6)}   # c
 
 def coord_tail_supported(x, layers) -> bool:
     """layers = [fp1a, fp1b, conv1, seg, nocs hidden, nocs out] (PackedLinear)."""
-    if not (USE_COORD_TAIL and MLP_DTYPE == "fp32" and len(layers) == 6):
+    if not (USE_COORD_TAIL and mlp_dtype() == "fp32" and len(layers) == 6):
         return False
     l = x.numel() // max(x.shape[0] * x.shape[1], 1)
     widths_ok = all(lin.cout == 128 for lin in (layers[0], layers[1], layers[2], layers[4])) and all(lin.cin == 128 for lin in layers[1:])
@@ -321,7 +353,7 @@ def mlp_max(x, lin: PackedLinear, out, co_off: int):
     B, cin, M, K = x.shape
     cout = lin.cout
     assert lin.cin == cin
-    if MLP_DTYPE == "bf16":     # bf16 dense layer, then the (exact) max: only SA3's 128-point layer takes this route
+    if mlp_dtype() == "bf16":     # bf16 dense layer, then the (exact) max: only SA3's 128-point layer takes this route
         out[:, co_off:co_off + cout, :] = pointwise_mlp(x, lin, ACT_RELU).max(dim=3)[0]
         return out
     with torch.cuda.device(x.device):

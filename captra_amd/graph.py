@@ -29,6 +29,11 @@ class TrackStepGraph:
                 self._step()
         torch.cuda.current_stream(dev).wait_stream(stream)
         torch.cuda.synchronize(dev)
+        # the captured kernels read the folded weights through raw device pointers: own them (a module that drops its
+        # cache must not hand the memory back to the allocator under the graph) and remember the version they belong to
+        from .fold import collect_folded, weights_version
+        self.weights = collect_folded(model)
+        self.weights_version = weights_version()
         try:
             self._capture()
         except RuntimeError:
@@ -54,9 +59,18 @@ class TrackStepGraph:
             npcs_input["labels"] = self.labels
         return self.model.track_step(input, npcs_input, self.pose)
 
+    def stale(self) -> bool:
+        """True when some module re-folded (or dropped) its weights after this graph was captured: the replay would still
+        compute with the weights it owns, i.e. the OLD parameters."""
+        from .fold import weights_version
+        return weights_version() != self.weights_version
+
     def replay(self, points, points_mean, pose, labels=None):
         """Copies the inputs into the captured buffers, replays, returns the (static) output pose dict —
         clone it if it must survive the next replay."""
+        if self.stale():
+            raise RuntimeError("the model's weights changed after this hipGraph was captured (train()/load_state_dict()/.to()); "
+                               "capture a new TrackStepGraph")
         self.points.copy_(points)
         self.points_mean.copy_(points_mean)
         if pose is not self.pose:          # (a lane of TrackLanes hands its pose over in place)
@@ -101,6 +115,9 @@ class TrackLanes:
         self.frame = 0
         self._pending = None                   # (slot, stream) handed out by the last gather, not yet marked consumed
         self.set_pose(pose)
+
+    def stale(self) -> bool:
+        return any(g.stale() for g in self.graphs)
 
     def set_pose(self, pose: dict) -> None:
         """(Re)start the trajectories from `pose` (B-major dict) — the initial pose of the track loop (model.py:394)."""

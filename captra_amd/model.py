@@ -28,6 +28,16 @@ from .pose_utils.part_dof_utils import add_noise_to_part_dof, consume_noise_draw
 from .utils import Timer, add_dict, cvt_torch, divide_dict, ensure_dirs, get_ith_from_batch
 
 
+def write_result_pickles(experiment_dir: str, records) -> None:
+    """records: [(file name, per-trajectory result dict)] -> <experiment_dir>/results/data/<instance>_<track>.pkl
+    (reference model.py:503-509)."""
+    save_path = pjoin(experiment_dir, "results", "data")
+    ensure_dirs([save_path])
+    for name, rec in records:
+        with open(pjoin(save_path, name), "wb") as f:
+            pickle.dump(rec, f)
+
+
 class BaseModel(nn.Module):
     def __init__(self, cfg):
         super().__init__()
@@ -72,6 +82,15 @@ class EvalTrackModel(BaseModel):
         # replay one captured hipGraph per frame instead of launching the ~140 kernels of a step one by one
         # (captra_amd/graph.py); opt-in: `--hipgraph` of captra_amd.track / cfg['hipgraph'].  Same kernels, same bits.
         self.use_graph = bool(cfg.get("hipgraph", False))
+        # arithmetic of the shared MLPs for THIS model (None = whatever the calling thread has set, default exact fp32);
+        # "bf16" = BASELINE.json configs[2].  Entered around every step (fused.use_mlp_dtype): no process-wide switch.
+        self.mlp_dtype = cfg.get("mlp_dtype")
+        # multi-GPU harness hooks (captra_amd/track.py): `frame_hook(i, pose)` is called with every frame's pose (B,P,...)
+        # as soon as it is enqueued -- the per-frame all-gather of pose records starts there and runs under the next
+        # frame's kernels; `result_sink(list of (file name, per-trajectory result dict))` receives what `_save` would
+        # write (rank 0 writes the pickles of every rank's trajectories).  Both None = the single-process behaviour.
+        self.frame_hook = None
+        self.result_sink = None
         self._graph = None
         self._graph_key = None
 
@@ -125,6 +144,11 @@ class EvalTrackModel(BaseModel):
 
     def track_step(self, input, npcs_input, last_pose):
         """One frame for all B trajectories: CoordNet -> labels -> RotationNet -> pose fit."""
+        from . import fused
+        with fused.use_mlp_dtype(self.mlp_dtype):
+            return self._track_step(input, npcs_input, last_pose)
+
+    def _track_step(self, input, npcs_input, last_pose):
         npcs_input["canon_pose"] = {k: last_pose[k][:, self.root].clone() for k in ("rotation", "translation", "scale")}
         npcs_input["init_part"] = last_pose
         for k in ("_canon", "_geom"):
@@ -192,7 +216,7 @@ class EvalTrackModel(BaseModel):
         of the graph's static buffers."""
         from .graph import TrackStepGraph
         key = (tuple(input["points"].shape), str(input["points"].device))
-        if self._graph is None or self._graph_key != key:
+        if self._graph is None or self._graph_key != key or self._graph.stale():
             self._graph = TrackStepGraph(self, input["points"], input["points_mean"], last_pose)
             self._graph_key = key
         pose = self._graph.replay(input["points"], input["points_mean"], last_pose)
@@ -208,7 +232,7 @@ class EvalTrackModel(BaseModel):
     def _lanes_for(self, input, pose):
         from .graph import TrackLanes
         key = ("lanes", tuple(input["points"].shape), str(input["points"].device))
-        if self._graph is None or self._graph_key != key:
+        if self._graph is None or self._graph_key != key or self._graph.stale():
             self._graph = TrackLanes(self, input["points"], input["points_mean"], pose, lanes=2, keep_npcs=True)
             self._graph_key = key
         else:
@@ -238,6 +262,8 @@ class EvalTrackModel(BaseModel):
 
     def forward(self, save=False):
         pred_poses = [self._initial_pose()]
+        if self.frame_hook is not None:
+            self.frame_hook(0, pred_poses[0])
         npcs_pred = [None]
         frame_nums = []
         self.timer.tick()
@@ -255,6 +281,8 @@ class EvalTrackModel(BaseModel):
                     pose, cur_npcs = lanes.gather(lanes.step(input["points"], input["points_mean"], sync_inputs=(i == 1)), npcs=True)
                     npcs_pred.append({k: v.clone() for k, v in cur_npcs.items()})
                     pred_poses.append({k: v.clone() for k, v in pose.items()})
+                    if self.frame_hook is not None:
+                        self.frame_hook(i, pred_poses[-1])
                     continue
                 # the reference draws (and discards) a perturbed pose every frame (model.py:414);
                 # draw it too so that seeded runs consume the generator identically
@@ -268,39 +296,38 @@ class EvalTrackModel(BaseModel):
                     cur_npcs, pose = self.track_step(input, self.npcs_feed_dict[i], last_pose)
                 npcs_pred.append(cur_npcs)
                 pred_poses.append(pose)
+                if self.frame_hook is not None:
+                    self.frame_hook(i, pose)
         self.pred_dict = {"poses": pred_poses, "npcs_pred": npcs_pred}
         if save:
             self._save(frame_nums)
 
     def _save(self, frame_nums):
         """Per-trajectory pickle {'pred': {'poses','corners'}, 'gt': {'poses','corners'}, 'frame_nums'}
-        (reference model.py:482-509).  Predicted NOCS corners = per-part min/max of the predicted
-        coordinates of the points labelled with that part."""
+        (reference model.py:482-509).  Predicted NOCS corners = `get_pred_nocs_corners` of the points' own-part predicted
+        coordinates: per part the symmetric extent [-max|x|, +max|x|] (model.py:489-493) -- the same boxes compute_loss
+        evaluates, so the offline IoU tables (captra_amd/eval.py) agree with the in-loop avg_iou."""
+        from .loss import choose_coord_by_label
+        from .pose_utils.bbox_utils import get_pred_nocs_corners
         gt_corners = self.feed_dict[0]["meta"]["nocs_corners"].cpu().numpy()
         corner_list = [None]
         for i in range(1, len(self.pred_dict["poses"])):
             pred = self.pred_dict["npcs_pred"][i]
-            labels = torch.argmax(pred["seg"], dim=-2)
-            nocs = pred["nocs"].reshape(len(labels), self.num_parts, 3, -1)
-            corners = np.zeros((len(labels), self.num_parts, 2, 3), np.float32)
-            for p in range(self.num_parts):
-                m = (labels == p).unsqueeze(1)
-                lo = torch.where(m, nocs[:, p], torch.full_like(nocs[:, p], float("inf"))).min(dim=-1)[0]
-                hi = torch.where(m, nocs[:, p], torch.full_like(nocs[:, p], float("-inf"))).max(dim=-1)[0]
-                empty = ~m.any(dim=-1)
-                corners[:, p, 0] = torch.where(empty, torch.zeros_like(lo), lo).cpu().numpy()
-                corners[:, p, 1] = torch.where(empty, torch.zeros_like(hi), hi).cpu().numpy()
-            corner_list.append(corners)
+            pred_labels = torch.max(pred["seg"], dim=-2)[1]                                        # (B,N)
+            pred_nocs = choose_coord_by_label(pred["nocs"].transpose(-1, -2), pred_labels)         # (B,N,3)
+            corner_list.append(get_pred_nocs_corners(pred_labels, pred_nocs, self.num_parts))
         to_np = lambda pose: {k: v.detach().cpu().numpy() for k, v in pose.items()}
         save_dict = {"pred": {"poses": [to_np(p) for p in self.pred_dict["poses"]], "corners": corner_list},
                      "gt": {"poses": [to_np(f["gt_part"]) for f in self.feed_dict], "corners": gt_corners},
                      "frame_nums": frame_nums}
-        save_path = pjoin(self.cfg["experiment_dir"], "results", "data")
-        ensure_dirs([save_path])
+        records = []
         for i, path in enumerate(self.feed_dict[0]["meta"]["path"]):
             instance, track_num = path.split(".")[-2].split("/")[-3:-1]
-            with open(pjoin(save_path, f"{instance}_{track_num}.pkl"), "wb") as f:
-                pickle.dump(get_ith_from_batch(save_dict, i, to_single=False), f)
+            records.append((f"{instance}_{track_num}.pkl", get_ith_from_batch(save_dict, i, to_single=False)))
+        if self.result_sink is not None:
+            self.result_sink(records)
+        else:
+            write_result_pickles(self.cfg["experiment_dir"], records)
 
     def compute_loss(self, test=False, per_instance=False, eval_iou=False, test_prefix=None):
         """The reference's compute_loss (model.py:511-593): per-part rdiff / tdiff / sdiff / 5deg5cm averaged over frames

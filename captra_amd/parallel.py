@@ -51,6 +51,10 @@ class PoseExchange:
 
     def all_gather(self, pose: dict, valid: torch.Tensor | None = None, async_op: bool = False) -> torch.Tensor:
         self.local.copy_(pack_pose(pose, valid))
+        return self.all_gather_packed(async_op)
+
+    def all_gather_packed(self, async_op: bool = False) -> torch.Tensor:
+        """All-gather whatever `self.local` holds (records packed by the caller, e.g. a short batch padded with invalid ones)."""
         if self.world == 1:
             self.gathered.copy_(self.local)
             return self.gathered

@@ -58,7 +58,10 @@ def group_points_grad_wrapper(b, c, n, npoints, nsample, grad_out, idx, grad_poi
     _chk(grad_out, torch.float32, "grad_out"); _chk(idx, torch.int32, "idx"); _chk(grad_points, torch.float32, "grad_points")
     _need(grad_out, b * c * npoints * nsample, "grad_out"); _need(idx, b * npoints * nsample, "idx"); _need(grad_points, b * c * n, "grad_points")
     with torch.cuda.device(grad_out.device):
-        L.call("captra_group_points_grad", b, c, n, npoints, nsample, L.ptr(grad_out), L.ptr(idx), L.ptr(grad_points))
+        # scratch for the atomic-free path is the caller's (include/captra_hip.h): allocated here with torch, 0 bytes = atomics
+        need = int(L.lib().captra_group_points_grad_ws_bytes(b, c, n, npoints, nsample))
+        ws = torch.empty(need, dtype=torch.uint8, device=grad_out.device) if need else None
+        L.call("captra_group_points_grad_ws", b, c, n, npoints, nsample, L.ptr(grad_out), L.ptr(idx), L.ptr(grad_points), L.ptr(ws), need)
     return 1
 
 
@@ -122,4 +125,6 @@ def three_interpolate_grad_wrapper(b, c, n, m, grad_out, idx, weight, grad_point
     _chk(weight, torch.float32, "weight"); _chk(grad_points, torch.float32, "grad_points")
     _need(grad_out, b * c * n, "grad_out"); _need(idx, b * n * 3, "idx"); _need(weight, b * n * 3, "weight"); _need(grad_points, b * c * m, "grad_points")
     with torch.cuda.device(grad_out.device):
-        L.call("captra_three_interpolate_grad", b, c, n, m, L.ptr(grad_out), L.ptr(idx), L.ptr(weight), L.ptr(grad_points))
+        need = int(L.lib().captra_three_interpolate_grad_ws_bytes(b, c, n, m))
+        ws = torch.empty(need, dtype=torch.uint8, device=grad_out.device) if need else None
+        L.call("captra_three_interpolate_grad_ws", b, c, n, m, L.ptr(grad_out), L.ptr(idx), L.ptr(weight), L.ptr(grad_points), L.ptr(ws), need)

@@ -209,3 +209,32 @@ class GroupAll(nn.Module):
             return grouped_xyz
         grouped = features.unsqueeze(2)
         return torch.cat([grouped_xyz, grouped], dim=1) if self.use_xyz else grouped
+
+
+class KNNAndGroup(nn.Module):
+    """k-nearest-neighbour grouping (reference pointnet2_utils.py:335-386): `idx` (B,M,K) given or the `nsample` nearest
+    points of every centre; grouped coordinates relative to the centre; **xyz first**, features last (unlike QueryAndGroup).
+    The reference's own neighbour search here is a call with the wrong arity (`knn(xyz, new_xyz, radius, nsample)` against
+    `KNN.forward(k, unknown, known)`, l.361 vs l.80 -- it can only run with `idx` passed in); this module runs the search it
+    evidently means: the `nsample` nearest points of `xyz` for every `new_xyz` (captra_knn)."""
+
+    def __init__(self, radius: float, nsample: int, use_xyz: bool = True):
+        super().__init__()
+        self.radius, self.nsample, self.use_xyz = radius, nsample, use_xyz
+
+    def forward(self, xyz: torch.Tensor, new_xyz: torch.Tensor = None, idx: torch.Tensor = None,
+                features: torch.Tensor = None) -> torch.Tensor:
+        """xyz (B,N,3), new_xyz (B,M,3) (default: xyz), idx (B,M,K) int32 or None, features (B,C,N) or None
+        -> (B,3+C,M,K) (use_xyz) or (B,C,M,K)."""
+        if new_xyz is None:
+            new_xyz = xyz
+        if idx is None:
+            _, idx = knn(self.nsample, new_xyz, xyz)
+        idx = idx.detach().int()
+        grouped_xyz = grouping_operation(xyz.transpose(1, 2).contiguous(), idx)           # (B,3,M,K)
+        grouped_xyz = grouped_xyz - new_xyz.transpose(1, 2).unsqueeze(-1)
+        if features is None:
+            assert self.use_xyz, "Cannot have not features and not use xyz as a feature!"
+            return grouped_xyz
+        grouped = grouping_operation(features, idx)
+        return torch.cat([grouped_xyz, grouped], dim=1) if self.use_xyz else grouped

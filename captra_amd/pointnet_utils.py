@@ -103,10 +103,16 @@ class _FoldCache:
     """Mixin: folded (conv+BN) weights, rebuilt lazily after load_state_dict()/train()/to()."""
 
     def _invalidate(self):
+        if getattr(self, "_folded", None) is not None:
+            from .fold import bump_weights_version
+            bump_weights_version()
         self._folded = None
 
     def train(self, mode: bool = True):
-        self._invalidate()
+        # eval() on a model already in eval mode (every Trainer.test call) keeps the folded weights: BatchNorm statistics
+        # only move in training mode, and a captured hipGraph may hold these tensors' addresses
+        if mode != self.training:
+            self._invalidate()
         return super().train(mode)
 
     def _apply(self, fn, *a, **k):

@@ -38,6 +38,14 @@ class BaseModel(nn.Module):
         self.pwm_num = None if not self.sym else cfg["network"]["pwm_num"]
         self.cfg = cfg
         self.feed_dict, self.pred_dict, self.loss_dict = {}, {}, {}
+        self.per_diff_dict = {}
+
+    def record_per_diff(self, data, per_diff):
+        """Per-instance error tables keyed '<instance>_<track>_<frame>' (reference model.py:42-49)."""
+        from .utils import get_ith_from_batch
+        for i, path in enumerate(data["meta"]["path"]):
+            instance, track_num, frame_i = path.split(".")[-2].split("/")[-3:]
+            self.per_diff_dict.setdefault(f"{instance}_{track_num}_{frame_i}", {}).update(get_ith_from_batch(per_diff, i))
 
     def prepare_poses(self, data):
         """Ground-truth part poses and their perturbed copy = the pose the networks canonicalise with (model.py:49-58)."""
@@ -144,7 +152,10 @@ class RotationModel(BaseModel):
     def compute_loss(self, test_mode=False, per_instance=False):
         feed, pred = self.feed_dict, self.pred_dict
         loss_dict = {}
-        self._pose_terms(feed["gt_part"], pred["part"], feed["state"]["part"], loss_dict, per_instance=per_instance)
+        per, init_per = self._pose_terms(feed["gt_part"], pred["part"], feed["state"]["part"], loss_dict, per_instance=per_instance)
+        if per_instance:      # test(save=True): the per-instance table the harness dumps as CSV (reference model.py:264-266)
+            per.update({f"init_{k}": v for k, v in init_per.items()})
+            self.record_per_diff(feed, {"test": per})
         loss_dict["corner_loss"] = compute_point_pose_loss(feed["gt_part"], pred["part"], self._gt_box(feed["meta"]),
                                                            metric=self.pose_loss_type["point"])[0]
         if "point_rotation" in pred:

@@ -131,7 +131,10 @@ class Trainer(nn.Module):
             ckpt.update(state["model"])
             self.log_string("Resume from epoch %d" % self.epoch)
             if self.optimizer is not None and state.get("optimizer"):
-                self.optimizer.load_state_dict(state["optimizer"])
+                try:      # a checkpoint whose parameter groups do not match (added / missing parameters) keeps the
+                    self.optimizer.load_state_dict(state["optimizer"])   # weights and drops the optimiser state (trainer.py:181-186)
+                except (ValueError, KeyError):
+                    self.log_string("Optimizer state of the checkpoint does not match this model: discarded")
                 self.scheduler = get_scheduler(self.optimizer, self.cfg, self.epoch)
         self.model.load_state_dict(ckpt, strict=False)
         return self.epoch

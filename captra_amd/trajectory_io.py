@@ -79,3 +79,29 @@ def stack_trajectories(trajs: list) -> list:
                                    "mask": torch.from_numpy(np.stack([t["mask"][i] for t in trajs]))}
         frames.append({"points": cat("points"), "labels": cat("labels", torch.int64), "nocs": cat("nocs"), "meta": meta})
     return frames
+
+
+def concat_frame_batches(batches: list) -> list:
+    """[list over T of frame dicts with batch b_k] (equal T, N, P) -> one list over T with batch sum(b_k): the batch
+    dimension of every tensor concatenated, path lists chained.  Used by the harness to build a batch out of
+    independently generated / loaded trajectories, so that a trajectory's content does not depend on which rank or
+    batch it lands in."""
+    if len(batches) == 1:
+        return batches[0]
+    T = len(batches[0])
+    if any(len(b) != T for b in batches):
+        raise ValueError("trajectories of one batch must share the frame count")
+    out = []
+    for i in range(T):
+        frames = [b[i] for b in batches]
+        P = len(frames[0]["meta"]["nocs2camera"])
+        meta = {"path": [p for f in frames for p in f["meta"]["path"]],
+                "nocs2camera": [{k: torch.cat([f["meta"]["nocs2camera"][p][k] for f in frames]) for k in frames[0]["meta"]["nocs2camera"][p]}
+                                for p in range(P)],
+                "points_mean": torch.cat([f["meta"]["points_mean"] for f in frames]),
+                "nocs_corners": torch.cat([f["meta"]["nocs_corners"] for f in frames])}
+        if all("pre_fetched" in f["meta"] for f in frames):
+            meta["pre_fetched"] = {k: torch.cat([torch.as_tensor(f["meta"]["pre_fetched"][k]) for f in frames]) for k in ("depth", "mask")}
+        out.append({"points": torch.cat([f["points"] for f in frames]), "labels": torch.cat([f["labels"] for f in frames]),
+                    "nocs": torch.cat([f["nocs"] for f in frames]), "meta": meta})
+    return out

@@ -19,6 +19,8 @@
 #ifndef CAPTRA_HIP_H
 #define CAPTRA_HIP_H
 
+#include <stddef.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -51,11 +53,17 @@ int captra_group_points(int b, int c, int n, int npoints, int nsample, const flo
                         const int *idx, float *out, captra_stream_t stream);
 
 /* Replaces group_points_grad_wrapper (group_points.cpp:11-22, kernel group_points_gpu.cu:8-25).
- * grad_out (B,C,npoints,nsample), idx -> grad_points (B,C,N) += scatter (caller pre-zeroes).  For C >= 8 and N <= 16384 the
- * index list is inverted once (CSR, stream-ordered scratch from hipMallocAsync) and every source point sums its own list in
- * ascending position order: no float atomics, bit-reproducible; otherwise atomicAdd like the reference. */
+ * grad_out (B,C,npoints,nsample), idx -> grad_points (B,C,N) += scatter (caller pre-zeroes): atomicAdd like the reference
+ * (this signature has no scratch argument, and the library never allocates). */
 int captra_group_points_grad(int b, int c, int n, int npoints, int nsample, const float *grad_out,
                              const int *idx, float *grad_points, captra_stream_t stream);
+/* The same operator with caller-owned scratch: captra_group_points_grad_ws_bytes() bytes (0 = shape outside the path: C < 8 or
+ * N > 16384; pass workspace NULL then).  The index list, shared by every channel, is inverted once into a CSR structure in the
+ * scratch and every source point sums its own list in ascending position order: no float atomics, bit-reproducible gradients
+ * (csrc/scatter_reduce.hip).  What captra_amd.pointnet2_cuda.group_points_grad_wrapper calls. */
+size_t captra_group_points_grad_ws_bytes(int b, int c, int n, int npoints, int nsample);
+int captra_group_points_grad_ws(int b, int c, int n, int npoints, int nsample, const float *grad_out, const int *idx,
+                                float *grad_points, void *workspace, size_t workspace_bytes, captra_stream_t stream);
 
 /* Replaces gather_points_wrapper (sampling.cpp:11-21, kernel sampling_gpu.cu:8-24).
  * points (B,C,N), idx (B,npoints) -> out (B,C,npoints). */
@@ -86,6 +94,10 @@ int captra_three_interpolate(int b, int c, int m, int n, const float *points, co
  * grad_out (B,C,N), idx, weight (B,N,3) -> grad_points (B,C,M) += scatter (caller pre-zeroes). */
 int captra_three_interpolate_grad(int b, int c, int n, int m, const float *grad_out, const int *idx,
                                   const float *weight, float *grad_points, captra_stream_t stream);
+/* The same with caller-owned scratch (atomic-free per-known-point sums; see captra_group_points_grad_ws). */
+size_t captra_three_interpolate_grad_ws_bytes(int b, int c, int n, int m);
+int captra_three_interpolate_grad_ws(int b, int c, int n, int m, const float *grad_out, const int *idx, const float *weight,
+                                     float *grad_points, void *workspace, size_t workspace_bytes, captra_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Section 2 — fused operators of the tracking path (no single reference kernel; each replaces
@@ -304,8 +316,10 @@ void captra_prof_reset(void);
 int captra_prof_read(const char *name, double *total_ms, long long *launches);
 int captra_prof_names(char *buf, int buflen);
 
-/* ---- 4. Experiment switches (process-wide, NOT part of the stable ABI; used by tests/ and tools/ to cross-check variants
- *         that compute the same bits).  Defaults (0 / 1 for captra_pw_set_direct) select the production kernels. ---- */
+/* ---- 4. Experiment switches (NOT part of the stable ABI; used by tests/ and tools/ to cross-check variants that compute the
+ *         same bits).  Each switch is THREAD-LOCAL: it affects launches made by the calling host thread only, so the
+ *         operators above keep the reference boundary's "no global state" property for every other thread / GPU of the
+ *         process.  Defaults (0 / 1 for captra_pw_set_direct) select the production kernels. ---- */
 void captra_fps_set_waves(int waves);       /* FPS: waves per cloud (0 = heuristic) */
 void captra_fps_set_pruned_min(int n);     /* FPS: clouds of >= n points take the pruned kernel (default 8192; 0 = never) */
 void captra_fps_set_stats(unsigned long long *dev_counters); /* pruned FPS: accumulate 6 counters {bucket updates, refreshes, cycles of 4 phases} (NULL = off) */

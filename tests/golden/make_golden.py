@@ -108,6 +108,32 @@ def ref_cfg(ref, category, obj_config, **over):
     return cfg
 
 
+# CUDA-kernel semantics of the two neighbour searches, patched into the reference's CPU path for the NETWORK goldens
+# (see the module docstring, items 2 and 3; used by make_golden_track_physical.py as well)
+def three_nn_cuda_semantics(a, b):
+    diff = a[:, :, None, :] - b[:, None, :, :]
+    sq = diff * diff
+    d2 = (sq[..., 0] + sq[..., 1]) + sq[..., 2]
+    d, i = d2.sort(dim=-1, stable=True)
+    return torch.sqrt(d[:, :, :3]), i[:, :, :3]
+
+
+def query_ball_point_cuda_semantics(radius, nsample, xyz, new_xyz):
+    B, N, _ = xyz.shape
+    r2 = torch.tensor(radius, dtype=torch.float32) * torch.tensor(radius, dtype=torch.float32)
+    out = []
+    for b in range(B):
+        diff = new_xyz[b, :, None, :] - xyz[b, None, :, :]
+        sq = diff * diff
+        d2 = (sq[..., 0] + sq[..., 1]) + sq[..., 2]                      # (S,N)
+        cand = torch.where(d2 < r2, torch.arange(N).view(1, N), torch.full((1, 1), N))
+        first_k = cand.sort(dim=-1)[0][:, :nsample]
+        first = first_k[:, :1].clone()
+        first[first == N] = 0
+        out.append(torch.where(first_k == N, first.expand_as(first_k), first_k))
+    return torch.stack(out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -170,34 +196,12 @@ def main():
         d, i = orig_three_nn(a, b)
         return torch.sqrt(torch.clamp_min(d, 0)), i
 
-    def three_nn_cuda_semantics(a, b):
-        diff = a[:, :, None, :] - b[:, None, :, :]
-        sq = diff * diff
-        d2 = (sq[..., 0] + sq[..., 1]) + sq[..., 2]
-        d, i = d2.sort(dim=-1, stable=True)
-        return torch.sqrt(d[:, :, :3]), i[:, :, :3]
-
     pu.three_nn = three_nn_cuda_semantics
 
     # Same for the ball query of the NETWORK goldens: direct-form distance and strict '<'
     # (ball_query_gpu.cu:33-34).  The reference's CPU query_ball_point (expanded form, '>') flips
     # about one ball per cloud at the sphere boundary (see ambiguous_rows); the raw-op golden G2
     # above is the unpatched CPU output.
-    def query_ball_point_cuda_semantics(radius, nsample, xyz, new_xyz):
-        B, N, _ = xyz.shape
-        r2 = torch.tensor(radius, dtype=torch.float32) * torch.tensor(radius, dtype=torch.float32)
-        out = []
-        for b in range(B):
-            diff = new_xyz[b, :, None, :] - xyz[b, None, :, :]
-            sq = diff * diff
-            d2 = (sq[..., 0] + sq[..., 1]) + sq[..., 2]                      # (S,N)
-            cand = torch.where(d2 < r2, torch.arange(N).view(1, N), torch.full((1, 1), N))
-            first_k = cand.sort(dim=-1)[0][:, :nsample]
-            first = first_k[:, :1].clone()
-            first[first == N] = 0
-            out.append(torch.where(first_k == N, first.expand_as(first_k), first_k))
-        return torch.stack(out)
-
     pu.query_ball_point = query_ball_point_cuda_semantics
 
     # ---------------------------------------------------------------- G5 / G6 SA modules, backbone

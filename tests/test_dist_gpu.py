@@ -1,0 +1,65 @@
+"""The N > 1 path on real kernels.  A gpurun box has ONE GPU, so these tests start two ranks that share it over gloo
+(CAPTRA_DIST_BACKEND=gloo / CAPTRA_BENCH_SHARE_GPU=1 -- functional modes, never a measurement): everything but the
+collective library is the product path an 8-GPU node runs (sharding, per-frame pose all-gather, rank-0 result files,
+bench.py's self-spawn, per-rank timing, world-size report)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from tests.test_parallel_cpu import _compare_track_worlds, _run_track_world
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_track_harness_two_ranks_equal_single_process_bit_for_bit(device, tmp_path):
+    """`python -m captra_amd.track` as 2 ranks (3 + 2 trajectories, the second round is short on rank 0 and EMPTY on rank 1)
+    against the single-process run: the five result pickles are identical bit for bit (the poses in the 2-rank files are
+    the all-gathered per-frame records), frames and trajectory-weighted errors agree."""
+    env = {"CAPTRA_DIST_BACKEND": "gloo"}
+    _run_track_world(tmp_path, 1, "g1", env)
+    out = _run_track_world(tmp_path, 2, "g2", env)
+    assert "rank 0 of 2" in out
+    _compare_track_worlds(tmp_path, ["g1", "g2"])
+    _run_track_world(tmp_path, 2, "g2graph", env, extra_args=("--hipgraph",))
+    _compare_track_worlds(tmp_path, ["g1", "g2graph"])
+
+
+def _bench(args, env_extra=None, timeout=900):
+    env = dict(os.environ, **(env_extra or {}))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], env=env, cwd=ROOT, capture_output=True, text=True,
+                          timeout=timeout)
+
+
+def test_bench_gpus_n_without_a_launcher_spawns_n_ranks(device):
+    """`python bench.py --gpus 2` with WORLD_SIZE unset starts two ranks itself (torch.distributed.run on 127.0.0.1), never
+    a silent single-GPU run: the line reports n_gpus 2, the world size seen by an actual all-gather, and one row of block
+    times per rank.  (Two ranks share this box's GPU over gloo here: functional test mode, flagged in the line.)"""
+    res = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--min-warmup", "1", "--repeats", "2", "--batch", "4",
+                  "--no-cpu-baseline", "--no-kernel-timing"], {"CAPTRA_BENCH_SHARE_GPU": "1"})
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    line = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1, res.stdout          # rank 0 prints ONE JSON line
+    out = json.loads(line[0])
+    assert out["n_gpus"] == 2 and out["rccl_world_size"] == 2 and len(out["per_rank_ms_per_step"]) == 2
+    assert out["timed_blocks"]["n"] == 2 and out["config"]["trajectories_per_gpu"] == 4
+    assert "gloo" in out["collective_backend"]
+    assert out["value"] > 0 and abs(out["value"] - 2 * 4 * 2 / (out["ms_per_step"] * 2 / 1e3)) / out["value"] < 1e-2
+    assert out["pose_match"]["within_1e-4"] and out["pose_match"]["agree_5deg5cm"] == 1.0
+
+
+def test_bench_refuses_more_ranks_than_gpus(device):
+    """More ranks than GPUs is refused loudly (exit code != 0, message), both for the self-spawn and under a launcher."""
+    n = torch.cuda.device_count() + 1
+    res = _bench(["--gpus", str(n), "--steps", "1"])
+    assert res.returncode != 0 and "GPU(s)" in (res.stdout + res.stderr)
+    env = {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], env=dict(os.environ, **env),
+                         cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert res.returncode != 0 and "WORLD_SIZE=1" in (res.stdout + res.stderr)

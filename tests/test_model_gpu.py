@@ -366,6 +366,74 @@ def test_track_loop_with_graph_and_lanes_equals_eager(device):
     model.use_graph = False
 
 
+def test_captured_graph_owns_its_weights_and_is_recaptured_when_they_change(device):
+    """a captured step reads the folded weights through raw device pointers.  (a) Trainer.test() calls
+    model.eval() every time -- on a model already in eval mode that must NOT drop the folded tensors (same tensor objects
+    before and after), and the graph holds references to them in any case; (b) after load_state_dict() the graph is stale:
+    the loop recaptures and the poses are the NEW weights' (equal to an eager run), a direct replay of the old graph raises."""
+    from captra_amd.fold import collect_folded
+    from captra_amd.graph import TrackStepGraph
+    trainer, cfg, sd, _ = _trainer("bottle", device)
+    model = trainer.model
+    model.use_graph = True
+    data = clouds.make_trajectory("nocs", 2, 3, seed=5)
+    torch.manual_seed(3)
+    first, _ = trainer.test(data, save=False, no_eval=True)
+    g = model._graph
+    assert isinstance(g, TrackStepGraph) and len(g.weights) > 40 and not g.stale()
+    ptrs = sorted(w.wt.data_ptr() for w in collect_folded(model))
+    filler = [torch.full((1 << 20,), float("nan"), device=device) for _ in range(8)]      # would land in freed weight blocks
+    torch.manual_seed(3)
+    second, _ = trainer.test(data, save=False, no_eval=True)                              # model.eval() again, same graph
+    assert model._graph is g and sorted(w.wt.data_ptr() for w in collect_folded(model)) == ptrs
+    for a, b in zip(first["poses"], second["poses"]):
+        for k in a:
+            np.testing.assert_array_equal(a[k].cpu().numpy(), b[k].cpu().numpy())
+    del filler
+    # new weights: stale graph, recapture, results of the new weights
+    sd2 = make_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=8)
+    model.load_state_dict(sd2)
+    assert g.stale()
+    with pytest.raises(RuntimeError):
+        g.replay(model.feed_dict[1]["points"], model.feed_dict[1]["points_mean"], first["poses"][0])
+    torch.manual_seed(3)
+    third, _ = trainer.test(data, save=False, no_eval=True)
+    assert model._graph is not g and not model._graph.stale()
+    model.use_graph = False
+    torch.manual_seed(3)
+    eager, _ = trainer.test(data, save=False, no_eval=True)
+    changed = False
+    for a, b, c in zip(third["poses"][1:], eager["poses"][1:], first["poses"][1:]):
+        for k in a:
+            np.testing.assert_array_equal(a[k].cpu().numpy(), b[k].cpu().numpy())
+            changed |= not np.array_equal(a[k].cpu().numpy(), c[k].cpu().numpy())
+    assert changed
+
+
+def test_saved_result_corners_are_the_reference_symmetric_extent(device, tmp_path):
+    """pred['corners'] of the result pickles = get_pred_nocs_corners of the own-part predicted NOCS
+    ([-max|x|, +max|x|], reference model.py:489-493), i.e. the boxes compute_loss evaluates -- not a [min, max] box."""
+    import pickle
+    from captra_amd.loss import choose_coord_by_label
+    from captra_amd.pose_utils.bbox_utils import get_pred_nocs_corners
+    trainer, cfg, sd, data = _trainer("drawers", device)
+    cfg["experiment_dir"] = trainer.model.cfg["experiment_dir"] = str(tmp_path)
+    pred, _ = trainer.test(data, save=True, no_eval=True)
+    files = sorted((tmp_path / "results" / "data").glob("*.pkl"))
+    assert len(files) == 2
+    for b, path in enumerate(files):
+        with open(path, "rb") as fh:
+            rec = pickle.load(fh)
+        assert rec["pred"]["corners"][0] is None
+        for i in range(1, len(data)):
+            n = pred["npcs_pred"][i]
+            labels = torch.max(n["seg"], dim=-2)[1]
+            want = get_pred_nocs_corners(labels, choose_coord_by_label(n["nocs"].transpose(-1, -2), labels), cfg["num_parts"])[b]
+            got = np.asarray(rec["pred"]["corners"][i])
+            np.testing.assert_array_equal(got, want)
+            np.testing.assert_array_equal(got[:, 0], -got[:, 1])            # symmetric about the origin
+
+
 @pytest.mark.parametrize("sym", [False, True])
 def test_part_fit_st_vs_oracle_and_golden(device, sym):
     from captra_amd.pose_utils.pose_fit import part_fit_st_cn, part_fit_st_no_ransac
@@ -507,33 +575,65 @@ def _trainer(tag, device):
     return trainer, cfg, sd, clouds.make_trajectory(kind, 2, frames, seed=0)
 
 
-@pytest.mark.parametrize("tag", ["bottle", "camera", "drawers"])
-def test_track_loop_vs_golden(device, tag):
-    trainer, cfg, sd, data = _trainer(tag, device)
-    g7, g9 = np.load(G / "g7_step.npz"), np.load(G / "g9_track.npz")
-    torch.manual_seed(1234)
+def _trainer_physical(tag, device, **cfg_over):
+    """The G9p fixture (tests/golden/make_golden_track_physical.py): physical-regime weights, seed-7 trajectories."""
+    from captra_amd.configs import make_config
+    from captra_amd.trainer import Trainer
+    from tests.weights import make_physical_state_dict
+    cat, objcfg, kind, frames, batch, wseed, tseed = clouds.PHYSICAL_SETUPS[tag]
+    cfg = make_config(cat, objcfg, experiment_dir="/tmp/captra_test_exp")
+    cfg.update(cfg_over)
+    trainer = Trainer(cfg)
+    shapes = {k: tuple(v.shape) for k, v in trainer.model.state_dict().items()}
+    sd = make_physical_state_dict(shapes, wseed, cfg["num_parts"], bool(cfg["obj_sym"]), kind)
+    trainer.model.load_state_dict(sd)
+    return trainer, cfg, sd, clouds.make_trajectory(kind, batch, frames, seed=7), tseed
+
+
+@pytest.mark.parametrize("hipgraph", [False, True])
+@pytest.mark.parametrize("tag", ["bottle", "camera", "laptop", "drawers"])
+def test_track_loop_vs_golden(device, tag, hipgraph):
+    """FREE-RUNNING Trainer.test against the reference's own EvalTrackModel loop (golden G9p): every pose of every frame
+    of every trajectory within the 1e-4 contract -- predicted labels, no teacher forcing, no loosened frames; eager
+    launches and the captured-hipGraph loop alike."""
+    trainer, cfg, sd, data, tseed = _trainer_physical(tag, device, hipgraph=hipgraph)
+    trainer.model.use_graph = hipgraph
+    g = np.load(G / "g9p_track.npz")
+    torch.manual_seed(tseed)
     pred_dict, loss_dict = trainer.test(data, save=False, no_eval=False)
     poses = pred_dict["poses"]
     assert len(poses) == len(data)
-    # initial (noisy) pose: same seed, same draw order as the reference
+    for key in ("rotation", "translation", "scale"):      # initial (noisy) pose: same seed, same draw order as the reference
+        np.testing.assert_allclose(poses[0][key].cpu().numpy(), g[f"{tag}_0_{key}"], atol=1e-6, rtol=0)
+    for i in range(1, len(poses)):
+        for key in ("rotation", "scale", "translation"):
+            np.testing.assert_allclose(poses[i][key].cpu().numpy(), g[f"{tag}_{i}_{key}"], atol=TOL, rtol=0,
+                                       err_msg=f"{tag} frame {i} {key}")
+        lab = torch.argmax(pred_dict["npcs_pred"][i]["seg"], dim=-2)
+        counts = [[int((lab[b] == p).sum()) for p in range(cfg["num_parts"])] for b in range(lab.shape[0])]
+        np.testing.assert_array_equal(np.asarray(counts), g[f"{tag}_label_counts"][i - 1], err_msg=f"{tag} frame {i} label counts")
+    assert "avg_pred" in loss_dict and any(k.startswith("5deg5cm") for k in loss_dict["avg_pred"])
+
+
+@pytest.mark.parametrize("tag", ["bottle", "camera", "drawers"])
+def test_track_first_frame_vs_golden_random_weights(device, tag):
+    """Purely random weights (goldens G7 / G9): the seeded initial pose, CoordinateNet's maps and the pose of frame 1.
+    (Under random weights the reference's own loop leaves the physical regime after a frame or two -- negative scales on
+    the drawers -- and amplifies rounding noise, so the FREE-RUNNING comparison lives on the physical-regime fixture above;
+    every later frame of this fixture is held to 1e-4 teacher-forced below.)"""
+    trainer, cfg, sd, data = _trainer(tag, device)
+    g7, g9 = np.load(G / "g7_step.npz"), np.load(G / "g9_track.npz")
+    torch.manual_seed(1234)
+    pred_dict, _ = trainer.test(data[:2], save=False, no_eval=True)
+    poses = pred_dict["poses"]
     for key in ("rotation", "translation", "scale"):
         np.testing.assert_allclose(poses[0][key].cpu().numpy(), g9[f"{tag}_0_{key}"], atol=1e-6, rtol=0)
-    # CoordNet outputs of frame 1
     n1 = pred_dict["npcs_pred"][1]
     np.testing.assert_array_equal(torch.argmax(n1["seg"], dim=-2).cpu().numpy(), g7[f"{tag}_labels"].astype(np.int64))
     np.testing.assert_allclose(n1["nocs"].cpu().numpy(), g7[f"{tag}_nocs"], atol=TOL, rtol=0)
     np.testing.assert_allclose(n1["seg"].cpu().numpy(), g7[f"{tag}_seg"], atol=1e-3, rtol=0)
-    # free-running trajectory against the reference's
-    # (free-running errors compound through the pose hand-over; with random weights the drawers
-    # poses leave the physical regime after frame 1 — negative scales — and amplify rounding noise,
-    # so later frames of that fixture are only sanity-bounded here; every frame is checked at 1e-4
-    # in the teacher-forced test below)
-    for i in range(1, len(poses)):
-        loose = tag == "drawers" and i >= 2
-        for key in ("rotation", "scale", "translation"):
-            np.testing.assert_allclose(poses[i][key].cpu().numpy(), g9[f"{tag}_{i}_{key}"], atol=5e-2 if loose else 5 * TOL,
-                                       rtol=5e-2 if loose else 5e-4, err_msg=f"{tag} frame {i} {key}")
-    assert "avg_pred" in loss_dict and any(k.startswith("5deg5cm") for k in loss_dict["avg_pred"])
+    for key in ("rotation", "scale", "translation"):
+        np.testing.assert_allclose(poses[1][key].cpu().numpy(), g9[f"{tag}_1_{key}"], atol=TOL, rtol=1e-4, err_msg=f"{tag} frame 1 {key}")
 
 
 @pytest.mark.parametrize("tag", ["bottle", "camera", "drawers"])
@@ -717,11 +817,11 @@ def test_bf16_dense_layer(device, cin, cout, l):
     x = rng.standard_normal((2, cin, l)).astype(np.float32)
     w = (rng.standard_normal((cin, cout)) / np.sqrt(cin)).astype(np.float32)
     b = rng.standard_normal(cout).astype(np.float32)
-    fused.MLP_DTYPE = "bf16"
+    fused.set_mlp_dtype("bf16")
     try:
         got = fused.pointwise_mlp(_dev(x, device), fused.pack(_dev(w, device), _dev(b, device)), 1).cpu().numpy()
     finally:
-        fused.MLP_DTYPE = "fp32"
+        fused.set_mlp_dtype("fp32")
     ref = _bf16_layer(x, w, b, 1)
     np.testing.assert_allclose(got, ref, atol=2e-5 * max(1.0, float(np.abs(ref).max())), rtol=0)
 
@@ -743,13 +843,13 @@ def test_bf16_sa_scale(device, cfeat, chans, n, m, k):
                rng.standard_normal(dims[i + 1]).astype(np.float32)) for i in range(3)]
     packed = [fused.pack(_dev(w, device), _dev(b, device)) for w, b in layers]
     out = torch.zeros(B, chans[2], m, device=device)
-    fused.MLP_DTYPE = "bf16"
+    fused.set_mlp_dtype("bf16")
     try:
         assert fused.sa_scale_bf16_supported(cfeat, packed, k)
         fused.sa_scale_bf16(None if feat is None else _dev(feat, device), _dev(xyz_cn, device), _dev(new_xyz, device),
                             _dev(idx, device), packed, out, 0)
     finally:
-        fused.MLP_DTYPE = "fp32"
+        fused.set_mlp_dtype("fp32")
     x = O.sa_group(feat, xyz_cn, new_xyz, idx)
     for w, b in layers:
         x = _bf16_layer(x, w, b, 1)
@@ -762,7 +862,7 @@ def test_bf16_sa_scale(device, cfeat, chans, n, m, k):
 
 
 def test_bf16_mode_track_step_close_to_fp32(device):
-    """The whole tracking step with bf16 MFMA operands in the shared MLPs (fused.MLP_DTYPE, BASELINE.json configs[2]) stays
+    """The whole tracking step with bf16 MFMA operands in the shared MLPs (fused.use_mlp_dtype / cfg['mlp_dtype'], BASELINE.json configs[2]) stays
     close to the exact-fp32 step on the same inputs: NOCS coordinates within bf16-level error, (almost) no label flips."""
     from captra_amd import fused
     from captra_amd.configs import make_config
@@ -778,12 +878,12 @@ def test_bf16_mode_track_step_close_to_fp32(device):
     pose = {k: v.clone() for k, v in model.feed_dict[0]["gt_part"].items()}
     outs = {}
     for dt in ("fp32", "bf16"):
-        fused.MLP_DTYPE = dt
+        fused.set_mlp_dtype(dt)
         try:
             with torch.no_grad():
                 npcs, _ = model.track_step(dict(model.feed_dict[1]), dict(model.npcs_feed_dict[1]), {k: v.clone() for k, v in pose.items()})
         finally:
-            fused.MLP_DTYPE = "fp32"
+            fused.set_mlp_dtype("fp32")
         outs[dt] = (npcs["nocs"].cpu().numpy(), npcs["seg"].cpu().numpy())
     d = np.abs(outs["fp32"][0] - outs["bf16"][0])
     assert np.isfinite(outs["bf16"][0]).all() and d.mean() < 5e-3 and d.max() < 5e-2, (d.mean(), d.max())

@@ -398,3 +398,87 @@ def test_query_and_group_module(pn, device):
                                                                            _dev(feat, device)).cpu().numpy(), gf)
     ga = pn.GroupAll(use_xyz=True)(_dev(xyz, device), None, _dev(feat, device)).cpu().numpy()
     np.testing.assert_array_equal(ga, np.concatenate([xyz.transpose(0, 2, 1), feat], 1)[:, :, None])
+
+
+def test_knn_and_group_module(pn, device):
+    """pointnet2_utils.KNNAndGroup (reference pointnet2_utils.py:335-386): k-NN lists (or the caller's idx) + grouping +
+    centre subtraction; relative xyz FIRST, features last."""
+    rng = np.random.default_rng(18)
+    xyz = (rng.random((2, 300, 3), dtype=np.float32) - 0.5).astype(np.float32)
+    new_xyz = xyz[:, :40].copy()
+    feat = rng.standard_normal((2, 5, 300)).astype(np.float32)
+    _, idx = O.knn(16, new_xyz, xyz)
+    gx = O.grouping_operation(np.ascontiguousarray(xyz.transpose(0, 2, 1)), idx) - new_xyz.transpose(0, 2, 1)[..., None]
+    gf = O.grouping_operation(feat, idx)
+    kg = pn.KNNAndGroup(0.2, 16, use_xyz=True)
+    np.testing.assert_array_equal(kg(_dev(xyz, device), _dev(new_xyz, device), None, _dev(feat, device)).cpu().numpy(),
+                                  np.concatenate([gx, gf], 1))
+    np.testing.assert_array_equal(kg(_dev(xyz, device), _dev(new_xyz, device), _dev(idx, device), _dev(feat, device)).cpu().numpy(),
+                                  np.concatenate([gx, gf], 1))
+    np.testing.assert_array_equal(kg(_dev(xyz, device), _dev(new_xyz, device)).cpu().numpy(), gx)
+    np.testing.assert_array_equal(pn.KNNAndGroup(0.2, 16, use_xyz=False)(_dev(xyz, device), _dev(new_xyz, device), None,
+                                                                         _dev(feat, device)).cpu().numpy(), gf)
+    # new_xyz defaults to xyz (every point its own centre)
+    _, idx_self = O.knn(4, xyz, xyz)
+    gself = O.grouping_operation(np.ascontiguousarray(xyz.transpose(0, 2, 1)), idx_self) - xyz.transpose(0, 2, 1)[..., None]
+    np.testing.assert_array_equal(pn.KNNAndGroup(0.2, 4)(_dev(xyz, device)).cpu().numpy(), gself)
+
+
+# --------------------------------------------------- backward operators at the shapes of the training step (CSR path)
+@pytest.mark.parametrize("c,n,m,k", [(320, 512, 128, 128), (320, 512, 128, 64), (8, 4096, 512, 32), (131, 700, 33, 16)])
+def test_group_points_grad_csr_path_vs_float64(pn, device, c, n, m, k):
+    """group_points backward where many channels share the index list (C >= 8: the caller-scratch CSR path of
+    captra_group_points_grad_ws): every source point sums its list in ascending position order, which is the order of the
+    oracle's serial loop -> the SAME bits; and within 1e-6 (relative to the row's scale) of a float64 scatter."""
+    from captra_amd import _lib
+    rng = np.random.default_rng(c + k)
+    idx = np.stack([clouds_ball_idx(rng, n, m, k) for _ in range(2)])
+    g = rng.standard_normal((2, c, m, k)).astype(np.float32)
+    assert int(_lib.lib().captra_group_points_grad_ws_bytes(2, c, n, m, k)) == 2 * (n + 1 + m * k) * 4
+    feat = torch.zeros(2, c, n, device=device, requires_grad=True)
+    pn.grouping_operation(feat, _dev(idx, device)).backward(_dev(g, device))
+    got = feat.grad.cpu().numpy()
+    np.testing.assert_array_equal(got, O.grouping_operation_grad(g, idx, n))
+    ref64 = np.zeros((2, c, n), np.float64)
+    for b in range(2):
+        np.add.at(ref64[b].T, idx[b].reshape(-1), g[b].reshape(c, -1).T.astype(np.float64))
+    scale = np.abs(ref64).max(axis=-1, keepdims=True) + 1e-30
+    assert float((np.abs(got - ref64) / scale).max()) <= 1e-6
+    # the reference-signature entry (no scratch argument): float atomics, same sums to rounding
+    grad_atomic = torch.zeros(2, c, n, device=device)
+    _lib.call("captra_group_points_grad", 2, c, n, m, k, _dev(g, device).data_ptr(), _dev(idx, device).data_ptr(), grad_atomic.data_ptr())
+    assert float((np.abs(grad_atomic.cpu().numpy() - ref64) / scale).max()) <= 2e-6
+
+
+def clouds_ball_idx(rng, n, m, k):
+    """Index lists shaped like a ball query's: a few distinct neighbours per centre, padded with the first."""
+    idx = np.empty((m, k), np.int32)
+    for j in range(m):
+        cnt = int(rng.integers(1, k + 1))
+        hits = np.sort(rng.choice(n, size=min(cnt, n), replace=False)).astype(np.int32)
+        idx[j, :len(hits)] = hits
+        idx[j, len(hits):] = hits[0]
+    return idx
+
+
+@pytest.mark.parametrize("c,m,n", [(128, 512, 4096), (256, 128, 512), (9, 50, 333)])
+def test_three_interpolate_grad_csr_path_vs_float64(pn, device, c, m, n):
+    """three_interpolate backward at FP1 / FP2's shapes (captra_three_interpolate_grad_ws): per-known-point sums in
+    ascending (n, j) order = the oracle's loop order -> the same bits; within 1e-6 of float64."""
+    rng = np.random.default_rng(c + m)
+    unknown = (rng.random((2, n, 3), dtype=np.float32) - 0.5).astype(np.float32)
+    known = (rng.random((2, m, 3), dtype=np.float32) - 0.5).astype(np.float32)
+    d2, idx = O.three_nn(unknown, known)
+    recip = 1.0 / (np.sqrt(d2) + 1e-8)
+    w = (recip / recip.sum(-1, keepdims=True)).astype(np.float32)
+    g = rng.standard_normal((2, c, n)).astype(np.float32)
+    feat = torch.zeros(2, c, m, device=device, requires_grad=True)
+    pn.three_interpolate(feat, _dev(idx, device), _dev(w, device)).backward(_dev(g, device))
+    got = feat.grad.cpu().numpy()
+    np.testing.assert_array_equal(got, O.three_interpolate_grad(g, idx, w, m))
+    ref64 = np.zeros((2, c, m), np.float64)
+    for b in range(2):
+        for j in range(3):
+            np.add.at(ref64[b].T, idx[b, :, j], (g[b].astype(np.float64) * w[b, :, j].astype(np.float64)).T)
+    scale = np.abs(ref64).max(axis=-1, keepdims=True) + 1e-30
+    assert float((np.abs(got - ref64) / scale).max()) <= 1e-6

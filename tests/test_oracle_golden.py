@@ -184,6 +184,43 @@ def test_g7_single_step_and_g9_trajectory(tag):
         np.testing.assert_allclose(pose["translation"], g9[f"{tag}_{i}_translation"], atol=TOL, rtol=1e-4)
 
 
+def _physical_setup(tag):
+    """The G9p fixture: physical-regime weights (tests/weights.make_physical_state_dict) on the seed-7 trajectories."""
+    from tests.weights import make_physical_state_dict
+    cat, objcfg, kind, frames, batch, wseed, tseed = clouds.PHYSICAL_SETUPS[tag]
+    cfg = _cfg(cat, objcfg)
+    from captra_amd.model import EvalTrackModel   # only to enumerate parameter names/shapes
+    shapes = {k: tuple(v.shape) for k, v in EvalTrackModel(cfg).state_dict().items()}
+    sd = make_physical_state_dict(shapes, wseed, cfg["num_parts"], bool(cfg["obj_sym"]), kind)
+    data = clouds.make_trajectory(kind, batch, frames, seed=7)
+    from captra_amd.pose_utils.part_dof_utils import add_noise_to_part_dof, part_model_batch_to_part
+    torch.manual_seed(tseed)
+    gt = part_model_batch_to_part(data[0]["meta"]["nocs2camera"], cfg["num_parts"], "cpu")
+    pp = cfg["pose_perturb"]
+    init = add_noise_to_part_dof(gt, {"type": pp["type"], "scale": pp["s"], "translation": pp["t"],
+                                      "rotation": float(np.deg2rad(pp["r"]))})
+    return cfg, sd, data, {k: v.numpy() for k, v in init.items()}
+
+
+@pytest.mark.parametrize("tag", ["bottle", "camera", "laptop", "drawers"])
+def test_g9p_free_running_trajectory_every_frame_1e4(tag):
+    """G9p: the reference's own EvalTrackModel loop under physical-regime weights.  The oracle runs FREE (each frame from
+    its own previous pose, labels from its own segmentation) and every pose of every frame stays within the 1e-4
+    contract of the reference's -- no teacher forcing, no loosened frames."""
+    cfg, sd, data, init = _physical_setup(tag)
+    g = np.load(G / "g9p_track.npz")
+    for key in ("rotation", "translation", "scale"):
+        np.testing.assert_allclose(init[key], g[f"{tag}_0_{key}"], atol=1e-6, rtol=0)
+    poses, aux = OM.track(sd, cfg, data, init, "torch")
+    for i in range(1, len(data)):
+        for key in ("rotation", "scale", "translation"):
+            np.testing.assert_allclose(poses[i][key], g[f"{tag}_{i}_{key}"], atol=TOL, rtol=0, err_msg=f"{tag} frame {i} {key}")
+        assert poses[i]["scale"].min() > 0.05          # physical regime
+    counts = np.asarray([[[int((aux[i]["labels"][b] == p).sum()) for p in range(cfg["num_parts"])] for b in range(len(init["scale"]))]
+                         for i in range(1, len(data))])
+    np.testing.assert_array_equal(counts, g[f"{tag}_label_counts"])
+
+
 def test_g8_pose_fit_and_procrustes():
     g = np.load(G / "g8_pose_fit.npz")
     rng = np.random.default_rng(88)

@@ -54,7 +54,10 @@ def main():
         print(f"{kern:92s} " + " ".join(cells))
     if json_out:
         with open(json_out, "w") as fh:
-            json.dump({"unit_note": "mean per dispatch; FETCH_SIZE / WRITE_SIZE in KiB as rocprofv3 reports them (gfx950: double FETCH_SIZE)",
+            import os
+            sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+            from bench import csrc_fingerprint      # identity of the kernel sources these counters were collected on
+            json.dump({"csrc_sha16": csrc_fingerprint(), "unit_note": "mean per dispatch; FETCH_SIZE / WRITE_SIZE in KiB as rocprofv3 reports them (gfx950: double FETCH_SIZE)",
                        "kernels": {k: {c: {"mean": v[0] / v[1], "dispatches": v[1]} for c, v in cs.items() if v[1]} for k, cs in table.items()}},
                       fh, indent=1)
     print("\n# values are the MEAN PER DISPATCH (summed over XCDs/SEs).  FETCH_SIZE/WRITE_SIZE are in KiB as rocprofv3 reports them;")

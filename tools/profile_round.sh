@@ -9,9 +9,10 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 # --no-overlap: the two networks one after the other, so that a dispatch's duration is the kernel's own (bench.py's roofline
 # figures are measured the same way); the default bench line runs them side by side on two streams
-BENCH="python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-overlap --lanes 1"
-BENCH_EAGER="python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-graph --no-overlap"
-BENCH_OVERLAP="python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timing"
+QUICK="--repeats 1 --min-warmup 2 --no-pose-match --no-cpu-baseline --no-kernel-timing"
+BENCH="python $ROOT/bench.py --steps 5 --warmup 2 $QUICK --no-overlap --lanes 1"
+BENCH_EAGER="python $ROOT/bench.py --steps 2 --warmup 1 $QUICK --no-graph --no-overlap"
+BENCH_OVERLAP="python $ROOT/bench.py --steps 5 --warmup 2 $QUICK"
 cd /tmp
 # 1. kernel trace + stats of the bench command (hipGraph replay path)
 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_trace -o bench -- $BENCH > $OUT/${TAG}_trace.log 2>&1

@@ -23,7 +23,7 @@ def main():
     ap.add_argument("--mlp-dtype", default="fp32", choices=["fp32", "bf16"])
     a = ap.parse_args()
     dev = torch.device("cuda:0")
-    fused.MLP_DTYPE = a.mlp_dtype
+    fused.set_mlp_dtype(a.mlp_dtype)
     cfg, sd, model, _ = bench.build_workload(a.batch, dev)
     pose = {k: v.clone() for k, v in model.feed_dict[0]["gt_part"].items()}
     records = OrderedDict()
