@@ -461,8 +461,9 @@ def main():
         rccl_world = int(seen.unique().numel())
         assert rccl_world == dist.get_world_size() == world, (rccl_world, dist.get_world_size(), world)
         mat = torch.tensor(blocks, dtype=torch.float64, device=device)
-        allb = torch.empty(world, len(blocks), dtype=torch.float64, device=device)
+        allb = torch.empty(world * len(blocks), dtype=torch.float64, device=device)
         dist.all_gather_into_tensor(allb, mat)
+        allb = allb.view(world, len(blocks))
         per_rank_ms = (1e3 * allb / args.steps).tolist()
         blocks = allb.max(dim=0)[0].tolist()              # a block takes as long as its slowest rank
     assert all(torch.isfinite(v).all() for v in last_pose.values()), "non-finite pose"

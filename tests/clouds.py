@@ -145,8 +145,8 @@ def make_trajectory(kind: str, batch: int, frames: int, seed: int = 0):
 # G9p fixture (tests/golden/make_golden_track_physical.py): tag -> (obj_category, obj_config, kind, frames, batch,
 # weight seed, torch seed); trajectories from make_trajectory(kind, batch, frames, seed=7)
 PHYSICAL_SETUPS = {
-    "bottle": ("1", "obj_info_nocs.yml", "nocs", 6, 2, 21, 4321),
-    "camera": ("3", "obj_info_nocs.yml", "nocs", 5, 2, 22, 4322),
-    "laptop": ("5", "obj_info_nocs.yml", "nocs", 5, 2, 23, 4323),
-    "drawers": ("drawers", "obj_info_sapien.yml", "arti", 5, 2, 24, 4324),
+    "bottle": ("1", "obj_info_nocs.yml", "nocs", 9, 2, 21, 4321),
+    "camera": ("3", "obj_info_nocs.yml", "nocs", 7, 2, 22, 4322),
+    "laptop": ("5", "obj_info_nocs.yml", "nocs", 7, 2, 23, 4323),
+    "drawers": ("drawers", "obj_info_sapien.yml", "arti", 7, 2, 24, 4324),
 }

@@ -373,7 +373,8 @@ def test_captured_graph_owns_its_weights_and_is_recaptured_when_they_change(devi
     the loop recaptures and the poses are the NEW weights' (equal to an eager run), a direct replay of the old graph raises."""
     from captra_amd.fold import collect_folded
     from captra_amd.graph import TrackStepGraph
-    trainer, cfg, sd, _ = _trainer("bottle", device)
+    from tests.weights import make_physical_state_dict
+    trainer, cfg, sd, _, _ = _trainer_physical("bottle", device)
     model = trainer.model
     model.use_graph = True
     data = clouds.make_trajectory("nocs", 2, 3, seed=5)
@@ -391,7 +392,7 @@ def test_captured_graph_owns_its_weights_and_is_recaptured_when_they_change(devi
             np.testing.assert_array_equal(a[k].cpu().numpy(), b[k].cpu().numpy())
     del filler
     # new weights: stale graph, recapture, results of the new weights
-    sd2 = make_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=8)
+    sd2 = make_physical_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, 8, 1, True, "nocs")
     model.load_state_dict(sd2)
     assert g.stale()
     with pytest.raises(RuntimeError):
