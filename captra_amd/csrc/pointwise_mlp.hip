@@ -60,6 +60,7 @@ struct PwParams {
     const float *ab_in;   // (B,cin,2) or null: the input is relu(a*x + b) per (cloud, input channel)
     float *stats_out;     // (B,cout,T,2) or null: per output row and 64-column tile, (sum, sum of squares) of y
     int stats_t;          // T
+    int y_pm;             // direct kernel only: 1 = y is POINT-major (B,L,cout), cout % 4 == 0 (captra_pointwise_mlp_pm)
 };
 
 template <int CTRL>
@@ -421,7 +422,16 @@ __global__ __launch_bounds__(256) void pw_direct_kernel(PwParams p) {
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
             const long long col = pos0 + tn * 32 + (lane & 31);
-            if (col < p.L) {
+            if (col < p.L && p.y_pm) {
+                // point-major output: registers 4q..4q+3 are four consecutive channels of this lane's position
+                float *yp = p.y + ((size_t)b * p.L + col) * p.cout + row0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (row0 + 8 * q + 3 < p.cout)
+                        *reinterpret_cast<float4 *>(yp + 8 * q) =
+                            make_float4(apply_act(acc[tm][tn][4 * q + 0], p.act), apply_act(acc[tm][tn][4 * q + 1], p.act),
+                                        apply_act(acc[tm][tn][4 * q + 2], p.act), apply_act(acc[tm][tn][4 * q + 3], p.act));
+            } else if (col < p.L) {
                 float *yp = p.y + ((size_t)b * p.cout + row0) * p.L + col;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -613,9 +623,35 @@ __global__ void pack_weights_kernel(int cin, int cout, int kp, int cp, const flo
     if (e < cp) bias_packed[e] = e < cout ? bias[e] : 0.f;
 }
 
+// fragment order of a packed layer (include/captra_hip.h: captra_pack_weights_frag)
+__global__ void pack_weights_frag_kernel(int cin, int ldw, int kq, int total, const float *__restrict__ wt_packed,
+                                         float *__restrict__ wfrag) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int i = e & 3, lane = (e >> 2) & 63, tq = e >> 8;
+    const int q = tq % kq, t = tq / kq;
+    const int row = 2 * (4 * q + i) + (lane >> 5), col = 32 * t + (lane & 31);
+    wfrag[e] = (row < cin && col < ldw) ? wt_packed[(size_t)row * ldw + col] : 0.f;
+}
+
 }  // namespace
 
 extern "C" void captra_pw_set_direct(int on) { g_pw_direct = on; }
+
+extern "C" long long captra_pack_weights_frag_floats(int cin, int cout) {
+    if (cin < 1 || cout < 1) return 0;
+    const int kst = (cin + 1) / 2, kq = (kst + 3) / 4, nt = (cout + 31) / 32;
+    return (long long)nt * kq * 256;
+}
+
+extern "C" int captra_pack_weights_frag(int cin, int cout, const float *wt_packed, float *wfrag, captra_stream_t stream) {
+    if (cin < 1 || cout < 1) return -1;
+    const int kst = (cin + 1) / 2, kq = (kst + 3) / 4, nt = (cout + 31) / 32;
+    const int total = nt * kq * 256, ldw = (cout + 127) / 128 * 128;
+    CAPTRA_LAUNCH("pack_weights", pack_weights_frag_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, cin, ldw,
+                  kq, total, wt_packed, wfrag);
+    return captra_last_error();
+}
 
 extern "C" int captra_pack_weights(int cin, int cout, const float *wt, const float *bias, float *wt_packed,
                                    float *bias_packed, captra_stream_t stream) {
@@ -641,6 +677,20 @@ extern "C" int captra_pointwise_mlp(int b, int cin, int cout, long long l, const
     const bool vec = (l % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
     if (vec) return launch_pw<PRO_PLAIN, EPI_STORE, true>(b, p, (hipStream_t)stream, "pointwise_mlp");
     return launch_pw<PRO_PLAIN, EPI_STORE, false>(b, p, (hipStream_t)stream, "pointwise_mlp");
+}
+
+// The same layer with a POINT-major result y (B,L,cout): what a consumer that gathers whole points reads with 16-byte loads
+// (the SA2 scales' pre-transformed first layer, csrc/sa_pipe.hip).  Direct-operand kernel only: -2 outside its range.
+extern "C" int captra_pointwise_mlp_pm(int b, int cin, int cout, long long l, const float *x, const float *wt_packed,
+                                       const float *bias_packed, int act, float *y, captra_stream_t stream) {
+    if (b < 0 || cin < 1 || cout < 1 || l < 0 || act < 0 || act > 2) return -1;
+    if (cout % 4 != 0 || (reinterpret_cast<uintptr_t>(y) & 15) != 0) return -2;
+    if (b == 0 || l == 0) return 0;
+    PwParams p = {};
+    p.cin = cin; p.cout = cout; p.ldw = (cout + 127) / 128 * 128; p.L = l; p.x = x; p.wt = wt_packed; p.bias = bias_packed;
+    p.y = y; p.act = act; p.y_pm = 1;
+    const int err = launch_pw_direct(b, p, (hipStream_t)stream);
+    return err == -3 ? -2 : err;
 }
 
 // Dense layer inside a Conv -> GroupNorm -> ReLU chain (see include/captra_hip.h).

@@ -710,6 +710,7 @@ static CAPTRA_KNOB int g_sa_mode = 0;  // 0 = heuristic (register-resident kerne
 extern "C" void captra_sa_fused_set_mode(int mode) { g_sa_mode = mode; }
 static unsigned long long *g_sa_prof = nullptr;  // device buffer of 10 counters: sa_wave_kernel's opt-in phase timers
 extern "C" void captra_sa_fused_set_prof(unsigned long long *dev_counters) { g_sa_prof = dev_counters; }
+unsigned long long *captra_sa_prof_ptr() { return g_sa_prof; }
 
 // One SA scale, fused (see include/captra_hip.h).
 extern "C" int captra_sa_scale_fused(int b, int n, int m, int k, int cfeat, int c1, int c2, int c3,
@@ -819,7 +820,7 @@ extern "C" int captra_sa_scale_pre(int b, int n, int m, int k, int cfeat, int c1
     SwParams q;
     q.b = b; q.n = n; q.m = m; q.k = k; q.feat = nullptr; q.xyz_cn = xyz_cn; q.new_xyz = new_xyz; q.idx = idx;
     q.w1 = w1; q.b1 = b2 /* unused by the PRE kernels: any valid packed bias */; q.w2 = w2; q.b2 = b2; q.w3 = w3; q.b3 = b3;
-    q.out = out; q.out_ctotal = out_ctotal; q.co_off = co_off; q.v1 = v1; q.prof = nullptr;
+    q.out = out; q.out_ctotal = out_ctotal; q.co_off = co_off; q.v1 = v1; q.prof = g_sa_prof;
     const long long Lw = (long long)m * k;
     dim3 gridw((unsigned)((Lw + SF_POS - 1) / SF_POS), b);
 #define SWP_CASE(CF_, C1_, C2_, C3_)                                                                                       \

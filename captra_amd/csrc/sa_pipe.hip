@@ -1,0 +1,467 @@
+// sa_wave_pipe_kernel<CF, C1, C2, C3>: the register-resident SA2 scale (sa_fused.hip: sa_wave_kernel<..., PRE>) rebuilt
+// around ONE wave per SIMD and its whole 512-register file, for gfx950.
+//
+// What the counters said about sa_wave_kernel<320,128,196,256,true> (profiles/r02a_*; tools/bench_sa_fused.py --phases):
+// it already ran at one wave per SIMD (198 VGPR + 64 AGPR under the latency-first scheduler), so nothing covered
+//   * the first layer's gather (64 four-byte gathers per lane from the channel-major v1, up to 64 cache lines per
+//     instruction): 15 % of a wave's life,
+//   * the epilogues between output-tile passes (ReLU + permlane swap; ReLU + five DPP max steps + LDS): ~9 %,
+//   * late weight sets (one 16-register set = 1024 MFMA cycles of lead against an L2 hit under load): ~7 %.
+// Here the same k-ascending fmaf chains (bit-identical results) are scheduled so that the matrix pipe always has work:
+//   1. persistent workgroups walk tiles; the NEXT tile's neighbour ids, centre and accumulator start values are fetched
+//      while the current tile's layers 2 / 3 run (the gather costs registers, not time).  v1 is read POINT-major
+//      (B,N,C1; written that way by captra_pointwise_mlp_pm): the four accumulator rows a lane needs are one 16-byte
+//      load, a wave-tile touches 128 cache lines instead of up to 4096;
+//   2. every pass's epilogue is deferred by one pass and issued in parts behind the next pass's MFMA blocks (two
+//      accumulator pairs alternate), only a layer's last pass is exposed;
+//   3. weight sets stream two sets (2048 MFMA cycles) ahead through a ring of three;
+//   4. a workgroup keeps the maxima of CH consecutive tiles in LDS and writes each output row's CH..2CH consecutive
+//      centres at once (the old kernel's 4-byte stores strided along M hit one 32-byte sector each: 8x write traffic).
+// Replaces nothing of the reference one-to-one: it is the body of PointNetSetAbstractionMsg.forward's loop over radii
+// (pointnet_utils.py:228-248) for the SA2 shapes, as sa_wave_kernel is.
+#include "wave_mlp.h"
+
+namespace {
+
+constexpr int SP_POS = 128;   // positions per workgroup tile: 4 waves x 32 neighbours
+constexpr int SP_MAXCH = 8;   // tiles whose maxima a workgroup stages before it writes them out
+
+struct SpParams {
+    int b, n, m, k;
+    const float *v1pm;      // (B,N,C1) point-major: b1 + W1[feature rows] feat per source point
+    const float *xyz_cn;    // (B,3,N)
+    const float *new_xyz;   // (B,M,3)
+    const int *idx;         // (B,M,K)
+    const float *w1;        // packed first-layer weights (rows CF..CF+2 = the relative-xyz rows are used)
+    const float *w2, *b2, *w3, *b3;   // w2, w3: FRAGMENT-ordered images (captra_pack_weights_frag); b2, b3: packed biases
+    float *out;             // (B,out_ctotal,M)
+    int out_ctotal, co_off;
+    int tiles_per_cloud;    // M*K / 128
+    int chunk;              // tiles per staged output chunk (1..SP_MAXCH), divides tiles_per_cloud
+    long long chunks;       // B * tiles_per_cloud / chunk
+    unsigned long long *prof;  // debug: per-phase wave-cycle totals of a sample of workgroups (captra_sa_fused_set_prof), or null
+};
+
+#define SP_TICK(slot)                                                           \
+    if (p.prof != nullptr) {                                                    \
+        const unsigned long long t_now = __builtin_amdgcn_s_memtime();          \
+        if (lane == 0 && sampled) atomicAdd(p.prof + (slot), t_now - t_last);   \
+        t_last = t_now;                                                         \
+    }
+
+// ---- deferred epilogues, one part at a time -------------------------------------------------------------------------
+// MID: unit u = (tile tm = u >> 2, register quad q = u & 3); MAX: unit u = (tile tm = u >> 4, register r = u & 15).
+// Part c of NPARTS takes the units with u * NPARTS / UNITS == c, so the work spreads evenly over a pass's k-step sets.
+template <int NOUT>
+__device__ __forceinline__ void sp_mid_unit(const f32x16 &acc, int t, int q, float (&hout)[NOUT]) {
+#if defined(SP_EXP) && (SP_EXP & 4)
+    {   // EXPERIMENT: no ReLU / swap (wrong results, same data flow)
+        const int k0 = 16 * t + 4 * q;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (k0 + i < NOUT) hout[k0 + i] = acc[4 * q + i];
+        return;
+    }
+#endif
+    float a[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = acc[4 * q + i] > 0.f ? acc[4 * q + i] : 0.f;
+    const auto p01 = __builtin_amdgcn_permlane32_swap(__float_as_uint(a[0]), __float_as_uint(a[1]), false, false);
+    const auto p23 = __builtin_amdgcn_permlane32_swap(__float_as_uint(a[2]), __float_as_uint(a[3]), false, false);
+    const int k0 = 16 * t + 4 * q;
+    if (k0 + 0 < NOUT) hout[k0 + 0] = __uint_as_float(p01[0]);
+    if (k0 + 1 < NOUT) hout[k0 + 1] = __uint_as_float(p23[0]);
+    if (k0 + 2 < NOUT) hout[k0 + 2] = __uint_as_float(p01[1]);
+    if (k0 + 3 < NOUT) hout[k0 + 3] = __uint_as_float(p23[1]);
+}
+
+// ---- max over the 32 positions of a tile: a transpose-reduce butterfly ---------------------------------------------------
+// The old epilogue reduced each of a tile's 16 accumulator registers on its own (ReLU + five DPP max steps + a one-lane LDS
+// store under an exec mask: ~8 instructions and an exec switch per register, ~130 per tile).  Here neighbouring REGISTERS
+// are merged while neighbouring LANES are reduced: stage k pairs lane l with lane l ^ 2^k and registers (2i, 2i+1); a lane
+// with bit k clear keeps register 2i and takes the partner's 2i, a lane with bit k set keeps 2i+1.  After four stages ONE
+// register holds, in lane l, the maximum over its row of 16 lanes of accumulator register (l & 15): 16 + 8 + 4 + 2 max
+// steps instead of 80, one ReLU instead of 16 (max on the raw bit patterns: if any input is positive the signed-integer
+// maximum is the largest positive float, otherwise the result is negative and the ReLU makes it 0 -- what ReLU-then-max
+// gives), and ONE 64-lane ds_write_b32 per tile.  The two rows of 16 of each half-wave are combined by the final cross-wave
+// pass, which reads 2 x 4 slots per output row instead of 4.  51 VALU + 1 DS per tile.
+__device__ __forceinline__ int sp_imax(int a, int b) { return a > b ? a : b; }
+
+template <int CTRL, int BANK_MASK>
+__device__ __forceinline__ int sp_dpp(int old, int src) {
+    return __builtin_amdgcn_update_dpp(old, src, CTRL, 0xF, BANK_MASK, false);
+}
+
+struct SpMaxState {
+    int w[8];   // after stage A (lane bit 0)
+    int u[2];   // after stages B, C (lane bits 1, 2)
+};
+
+// stage A: 16 raw accumulator registers -> 8
+__device__ __forceinline__ void sp_max_stage_a(const f32x16 &acc, SpMaxState &st, int lane) {
+    const bool b0 = lane & 1;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int x0 = __float_as_int(acc[2 * i]), x1 = __float_as_int(acc[2 * i + 1]);
+        const int own = b0 ? x1 : x0, oth = b0 ? x0 : x1;
+        st.w[i] = sp_imax(own, sp_dpp<0xB1, 0xF>(own, oth));           // quad_perm [1,0,3,2]: lane ^ 1
+    }
+}
+
+// stages B and C: 8 -> 4 -> 2
+__device__ __forceinline__ void sp_max_stage_bc(SpMaxState &st, int lane) {
+    const bool b1 = lane & 2, b2 = lane & 4;
+    int v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int own = b1 ? st.w[2 * j + 1] : st.w[2 * j], oth = b1 ? st.w[2 * j] : st.w[2 * j + 1];
+        v[j] = sp_imax(own, sp_dpp<0x4E, 0xF>(own, oth));               // quad_perm [2,3,0,1]: lane ^ 2
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int own = b2 ? v[2 * m + 1] : v[2 * m], oth = b2 ? v[2 * m] : v[2 * m + 1];
+        // lane ^ 4: banks 0, 2 (lanes 0-3, 8-11 of a row) read four lanes up, banks 1, 3 four lanes down
+        const int p = sp_dpp<0x104, 0x5>(own, oth);                      // row_shl:4 into banks 0, 2; the others keep `own`
+        const int q = sp_dpp<0x114, 0xA>(p, oth);                        // row_shr:4 into banks 1, 3
+        st.u[m] = sp_imax(own, q);
+    }
+}
+
+// stage D + ReLU + store: lane l of a row of 16 ends with accumulator register (l & 15) = output row
+// 32 t + 8 (r >> 2) + (r & 3) + 4 (l >> 5), maximum over the row's 16 positions -> red8[row][2 wave + row-of-16 in the half]
+__device__ __forceinline__ void sp_max_stage_d(const SpMaxState &st, int t, float *red8_lane) {
+    // red8_lane = red8 + (lane's row within a tile) * 8 + 2 * wave + ((lane >> 4) & 1), computed once per kernel
+    const int lane = (int)(threadIdx.x & 63);
+    const bool b3 = lane & 8;
+    const int own = b3 ? st.u[1] : st.u[0], oth = b3 ? st.u[0] : st.u[1];
+    int z = sp_imax(own, sp_dpp<0x128, 0xF>(own, oth));                  // row_ror:8: lane ^ 8 within the row
+    z = z > 0 ? z : 0;                                                   // ReLU on the bit pattern
+    red8_lane[32 * t * (SP_MAXCH * 8)] = __int_as_float(z);
+}
+
+template <int COUT, bool LAST, int NPARTS, int NOUT>
+__device__ __forceinline__ void sp_epi_part(const f32x16 (&acc)[2], int ps, int c, float (&hout)[NOUT], float *red8_lane,
+                                            SpMaxState (&mst)[2], int lane) {
+    constexpr int NT = (COUT + 31) / 32;
+    if constexpr (LAST) {
+        // six units per pass: (tile 0: A, BC, D) (tile 1: A, BC, D), spread over the NPARTS steps of the next pass
+#pragma unroll
+        for (int u = 0; u < 6; ++u)
+            if (u * NPARTS / 6 == c && 2 * ps + u / 3 < NT) {
+                const int tm = u / 3;
+#if defined(SP_EXP) && (SP_EXP & 4)
+                if (u % 3 == 2) red8_lane[32 * (2 * ps + tm) * (SP_MAXCH * 8)] = acc[tm][0] + acc[tm][5] + acc[tm][10] + acc[tm][15];   // EXPERIMENT: no max
+                continue;
+#endif
+                if (u % 3 == 0) sp_max_stage_a(acc[tm], mst[tm], lane);
+                else if (u % 3 == 1) sp_max_stage_bc(mst[tm], lane);
+                else sp_max_stage_d(mst[tm], 2 * ps + tm, red8_lane);
+            }
+    } else {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (u * NPARTS / 8 == c && 2 * ps + (u >> 2) < NT) sp_mid_unit<NOUT>(acc[u >> 2], 2 * ps + (u >> 2), u & 3, hout);
+    }
+}
+
+// Weight sets from the FRAGMENT-ordered image (captra_pack_weights_frag): element ((t*KQ + q)*64 + lane)*4 + i =
+// W'^T[2(4q+i) + (lane>>5)][32t + (lane&31)], so ONE 16-byte load per lane holds the A operands of four consecutive
+// k-steps of output tile t.  A set (8 k-steps x 2 tiles) is 4 loads instead of 16: with one dword load per MFMA the four
+// waves of a CU kept its vector-memory address unit (one 64-lane instruction per ~16 cycles) exactly as busy as its matrix
+// pipes (one MFMA per SIMD per 64 cycles) -- measured 19 % of a tile's cycles (tools/exp_sw.sh, SW_EXP=2).
+template <int CIN, int COUT>
+struct SpFrag {
+    static constexpr int KST = (CIN + 1) / 2, KQ = (KST + 3) / 4, NT = (COUT + 31) / 32;
+    static constexpr int FLOATS = NT * KQ * 256;
+};
+
+template <int CIN, int COUT>
+__device__ __forceinline__ void sp_load_set(float (&dst)[16], const __amdgpu_buffer_rsrc_t rsrc, int lane, int ps, int c) {
+    using S = SwShape<CIN, COUT>;
+    using F = SpFrag<CIN, COUT>;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int qq = 0; qq < SW_KS / 4; ++qq) {
+            const int q = c * (SW_KS / 4) + qq, t = 2 * ps + tm;
+            if (q < F::KQ && t < S::NT) {
+                // (bit_cast of the WHOLE vector: hipcc 7.2 lowers `bit_cast<float>(v[i])` on this builtin's result to a single
+                // buffer_load_dword and leaves the other three elements undefined)
+                const float4 v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, (t * F::KQ + q) * 1024, 0));
+                dst[tm * SW_KS + qq * 4 + 0] = v.x; dst[tm * SW_KS + qq * 4 + 1] = v.y;
+                dst[tm * SW_KS + qq * 4 + 2] = v.z; dst[tm * SW_KS + qq * 4 + 3] = v.w;
+            }
+        }
+}
+
+template <int CIN, int COUT>
+__device__ __forceinline__ void sp_first_set(float (&dst)[16], const float *wfrag, int lane) {
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)wfrag, 0, SpFrag<CIN, COUT>::FLOATS * 4, 0x00020000);
+    sp_load_set<CIN, COUT>(dst, rsrc, lane, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// One layer: hin[] (B operands) -> hout[] (LAST = false) or per-wave maxima in red (LAST = true).  Weight sets in the ring
+// s[3]: the set of step g is s[(START + g) % 3]; this layer's first set must already be on its way (previous phase), the
+// following layer's first set is requested through `next(s[(START + STEPS) % 3])` two steps before the end.  `side(g)` runs
+// once per step before the MFMA block (the kernel hangs the next tile's prefetch on it).
+template <int CIN, int COUT, bool LAST, int START, int NIN, int NOUT, typename Next, typename Side>
+__device__ __forceinline__ void sp_layer(const float *wt, const float *bias_lds, const float (&hin)[NIN], float (&hout)[NOUT],
+                                         float (&s)[3][16], float *red8_lane, int lane, Next next, Side side) {
+    using S = SwShape<CIN, COUT>;
+    static_assert(NIN >= S::KST, "input operand array too small");
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)wt, 0, SpFrag<CIN, COUT>::FLOATS * 4, 0x00020000);
+    f32x16 acc[2][2];
+    SpMaxState mst[2];
+    static_assert(!LAST || S::NSETS >= 6 || S::NPASS == 1, "the deferred max needs its six units in distinct steps, in order");
+#pragma unroll
+    for (int g = 0; g < S::STEPS; ++g) {
+        const int ps = g / S::NSETS, c = g % S::NSETS, pb = ps & 1;
+        if (c == 0) {
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+                if (2 * ps + tm < S::NT) sw_bias_init(acc[pb][tm], bias_lds, 2 * ps + tm, lane);
+        }
+        if (g == 0 && S::STEPS > 1) sp_load_set<CIN, COUT>(s[(START + 1) % 3], rsrc, lane, 1 / S::NSETS, 1 % S::NSETS);
+        if (g + 2 < S::STEPS) sp_load_set<CIN, COUT>(s[(START + g + 2) % 3], rsrc, lane, (g + 2) / S::NSETS, (g + 2) % S::NSETS);
+        if (g + 2 == S::STEPS || (S::STEPS == 1 && g == 0)) next(s[(START + S::STEPS) % 3]);
+        side(g);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < SW_KS; ++j)
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm) {
+                const int kk = c * SW_KS + j;
+                if (kk < S::KST && 2 * ps + tm < S::NT)
+                    acc[pb][tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(s[(START + g) % 3][tm * SW_KS + j], hin[kk], acc[pb][tm], 0, 0, 0);
+            }
+#if defined(SP_EXP) && (SP_EXP & 1)
+        __builtin_amdgcn_sched_barrier(0);
+        if (c == S::NSETS - 1 && ps + 1 < S::NPASS) {     // EXPERIMENT: epilogue right after its pass (not deferred)
+#pragma unroll
+            for (int cc = 0; cc < S::NSETS; ++cc) sp_epi_part<COUT, LAST, S::NSETS>(acc[pb], ps, cc, hout, red8_lane, mst, lane);
+        }
+#else
+        // the previous pass's epilogue, one part per step: issued behind this step's MFMAs, it runs while they execute
+        if (ps > 0) {
+            sp_epi_part<COUT, LAST, S::NSETS>(acc[pb ^ 1], ps - 1, c, hout, red8_lane, mst, lane);
+#if !(defined(SP_EXP) && (SP_EXP & 8))
+            // one MFMA, then a few of the part's VALU instructions, sixteen times: each of them issues while an MFMA executes
+            // (left to itself the scheduler puts the whole part behind the block, where only the last MFMA covers it)
+#pragma unroll
+            for (int i = 0; i < 2 * SW_KS; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);   // VALU
+            }
+#endif
+        }
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    constexpr int LP = S::NPASS - 1;
+#pragma unroll
+    for (int c = 0; c < S::NSETS; ++c) sp_epi_part<COUT, LAST, S::NSETS>(acc[LP & 1], LP, c, hout, red8_lane, mst, lane);
+}
+
+template <int CF, int C1, int C2, int C3>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void sa_wave_pipe_kernel(SpParams p) {
+    using S1 = SwShape<CF + 3, C1>;
+    using S2 = SwShape<C1, C2>;
+    using S3 = SwShape<C2, C3>;
+    constexpr int NT1 = S1::NT;
+    static_assert(NT1 <= 4 && C1 % 32 == 0, "first-layer width");
+    __shared__ __attribute__((aligned(16))) float bias_lds[2 * 256];       // packed b2, b3 (zero padded)
+    // maxima of a CHUNK of tiles: [chunk parity][row][tile of the chunk][2 * wave + row-of-16].  The four waves of a
+    // workgroup meet once per chunk, not once per tile (a per-tile barrier cost ~3 k cycles of waiting for the slowest
+    // wave); two buffers, so the next chunk's first tile may write while this chunk is still being read out.
+    extern __shared__ __attribute__((aligned(16))) float red[];              // 2 * pad32c(C3) * SP_MAXCH * 8 floats
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long long L = (long long)p.m * p.k;
+    const int groups = SP_POS / p.k, tiles_per_group = p.k / 32;            // centres per tile, waves per centre
+    const int cpc = p.chunk * groups;                                        // centres per chunk
+
+    for (int e = tid; e < 2 * 256; e += 256) {
+        const int c = e & 255;
+        bias_lds[e] = e < 256 ? (c < pad128c(C2) ? p.b2[c] : 0.f) : (c < pad128c(C3) ? p.b3[c] : 0.f);
+    }
+    // first layer's xyz rows of W1 (A operands of its two k-steps): the same for every tile
+    float at[2][NT1];
+    {
+        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)p.w1, 0, S1::KP * S1::LDW * 4, 0x00020000);
+        const int voff_w = (half * S1::LDW + (lane & 31)) * 4;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int t = 0; t < NT1; ++t)
+                at[jj][t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, voff_w, ((CF + 2 * jj) * S1::LDW + 32 * t) * 4, 0));
+    }
+    __syncthreads();
+
+    // a tile's per-lane inputs: neighbour id, relative xyz operands, accumulator start values (gathered v1 rows)
+    int id = 0;
+    float bt[2] = {0.f, 0.f};
+    float4 g4[NT1][4];
+    auto tile_of = [&](int chunk_id, int j, int &tb, int &pos0) {     // 32-bit: tiles < 2^31 / 128 (checked by the launcher)
+        const int tile = chunk_id * p.chunk + j;
+        tb = tile / p.tiles_per_cloud;
+        pos0 = (tile - tb * p.tiles_per_cloud) * SP_POS;
+    };
+    auto load_id = [&](int tb, int pos0) { return p.idx[(size_t)tb * L + pos0 + wave * 32 + (lane & 31)]; };
+    auto load_rest = [&](int tb, int pos0, int id_, float (&bt_)[2], float4 (&g_)[NT1][4]) {
+        const float *cp = p.new_xyz + ((size_t)tb * p.m + (int)((pos0 + wave * 32) / p.k)) * 3;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int a = 2 * jj + half;
+            bt_[jj] = a < 3 ? p.xyz_cn[((size_t)tb * 3 + a) * p.n + id_] - cp[a] : 0.f;
+        }
+        const float4 *vp = reinterpret_cast<const float4 *>(p.v1pm + ((size_t)tb * p.n + id_) * C1 + 4 * half);
+#pragma unroll
+        for (int t = 0; t < NT1; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) g_[t][q] = vp[8 * t + 2 * q];       // rows 32t + 8q + 4 half + (0..3)
+    };
+
+    // this lane's slot in red for the butterfly's final register: accumulator register (lane & 15) of a tile
+    const int red_lane_off = (8 * ((lane & 15) >> 2) + (lane & 3) + 4 * half) * (SP_MAXCH * 8) + 2 * wave + ((lane >> 4) & 1);
+    constexpr int RED_BUF = pad32c(C3) * SP_MAXCH * 8;
+    const bool sampled = blockIdx.x % 16 == 0;
+    unsigned long long t_last = p.prof != nullptr ? __builtin_amdgcn_s_memtime() : 0ull;
+    float s[3][16];
+    constexpr int START3 = S2::STEPS % 3;                     // ring slot of layer 3's first set (layer 2 starts in slot 0)
+    constexpr int NEXT2 = (START3 + S3::STEPS) % 3;            // slot in which layer 3 leaves the NEXT tile's first layer-2 set
+    int chunk_id = blockIdx.x;
+    const int nchunks = (int)p.chunks;
+    int par = 0;
+    if (chunk_id < nchunks) {
+        sp_first_set<C1, C2>(s[NEXT2], p.w2, lane);
+        int tb, pos0;
+        tile_of(chunk_id, 0, tb, pos0);
+        id = load_id(tb, pos0);
+        load_rest(tb, pos0, id, bt, g4);
+    }
+    for (; chunk_id < nchunks; chunk_id += gridDim.x) {
+        int cb, cpos0;
+        tile_of(chunk_id, 0, cb, cpos0);
+        for (int j = 0; j < p.chunk; ++j) {
+            // ---- what comes after this tile (wave-uniform) ----
+            const bool last_in_chunk = j + 1 == p.chunk;
+            const int nchunk = last_in_chunk ? chunk_id + (int)gridDim.x : chunk_id;
+            const bool has_next = nchunk < nchunks;
+            int nb = 0, npos0 = 0;
+            if (has_next) tile_of(nchunk, last_in_chunk ? 0 : j + 1, nb, npos0);
+            int id_n = 0;
+
+            float h1[S2::KST], h2[S3::KST], none[1];
+            SP_TICK(0)
+            // layer 2's first weight set was requested two steps before the previous tile ended: move it to slot 0
+            if (NEXT2 != 0) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) s[0][i] = s[NEXT2][i];
+            }
+            // ---- layer 1: the chain continues from the gathered start values with the two relative-xyz k-steps ----
+            {
+                f32x16 acc[NT1];
+#pragma unroll
+                for (int t = 0; t < NT1; ++t)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        acc[t][4 * q + 0] = g4[t][q].x; acc[t][4 * q + 1] = g4[t][q].y;
+                        acc[t][4 * q + 2] = g4[t][q].z; acc[t][4 * q + 3] = g4[t][q].w;
+                    }
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int t = 0; t < NT1; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(at[jj][t], bt[jj], acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < NT1; ++t) sw_mid_epilogue<S2::KST>(acc[t], t, h1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            SP_TICK(1)
+            // ---- layer 2; its second step asks for the next tile's neighbour ids ----
+            sp_layer<C1, C2, false, 0>(p.w2, bias_lds, h1, h2, s, red + par * RED_BUF + red_lane_off + j * 8, lane,
+                                       [&](float (&dst)[16]) { sp_first_set<C2, C3>(dst, p.w3, lane); },
+                                       [&](int g) { if (g == 1 && has_next) id_n = load_id(nb, npos0); });
+            SP_TICK(2)
+            // ---- layer 3 + max over the 32 neighbours; its third step gathers the next tile's start values ----
+            sp_layer<C2, C3, true, START3>(p.w3, bias_lds + 256, h2, none, s, red + par * RED_BUF + red_lane_off + j * 8, lane,
+                                           [&](float (&dst)[16]) { sp_first_set<C1, C2>(dst, p.w2, lane); },
+#if defined(SP_EXP) && (SP_EXP & 2)
+                                           [&](int) {});
+            if (has_next) load_rest(nb, npos0, id_n, bt, g4);   // EXPERIMENT: gather after layer 3 (exposed)
+#else
+                                           [&](int g) { if (g == 2 && has_next) load_rest(nb, npos0, id_n, bt, g4); });
+#endif
+            id = id_n;
+            SP_TICK(3)
+            if (p.prof != nullptr && lane == 0 && sampled) atomicAdd(p.prof + 9, 1ull);
+        }
+        __syncthreads();                             // every wave's maxima of the chunk's tiles are in red[par]
+        const int centre0 = cpos0 / p.k;             // first centre of the chunk (a chunk never straddles clouds)
+        const float *rb = red + par * RED_BUF;
+        for (int e = tid; e < C3 * cpc; e += 256) {
+            const int row = e / cpc, ci = e % cpc;   // consecutive threads = consecutive centres of one output row
+            const float *rp = rb + (row * SP_MAXCH + ci / groups) * 8 + (ci % groups) * 2 * tiles_per_group;
+            float v = rp[0];                         // 2 slots (rows of 16 lanes) per wave of the centre
+            for (int tt = 1; tt < 2 * tiles_per_group; ++tt) v = fmaxf(v, rp[tt]);
+            p.out[((size_t)cb * p.out_ctotal + p.co_off + row) * p.m + centre0 + ci] = v;
+        }
+        par ^= 1;
+        SP_TICK(4)
+        // (this buffer is written again two chunks from now, after the next chunk's barrier: every thread has left by then)
+    }
+}
+
+}  // namespace
+
+extern unsigned long long *captra_sa_prof_ptr();   // sa_fused.hip: the debug counters set by captra_sa_fused_set_prof
+
+// SA scale with a pre-transformed, POINT-major first layer (see include/captra_hip.h): v1pm (B,N,c1).
+// -2: shape not instantiated / not tileable (the caller takes captra_sa_scale_pre).
+extern "C" int captra_sa_scale_pre_pm(int b, int n, int m, int k, int cfeat, int c1, int c2, int c3, const float *v1pm,
+                                      const float *xyz_cn, const float *new_xyz, const int *idx, const float *w1,
+                                      const float *w2, const float *b2, const float *w3, const float *b3, float *out,
+                                      int out_ctotal, int co_off, captra_stream_t stream) {
+    if (b < 0 || n < 1 || m < 0 || k < 1 || cfeat < 1 || c1 < 1 || c2 < 1 || c3 < 1 || v1pm == nullptr) return -1;
+    if (out_ctotal < co_off + c3 || co_off < 0) return -1;
+    if (k % 32 != 0 || 128 % k != 0) return -2;
+    const long long L = (long long)m * k;
+    if (L % SP_POS != 0 || (long long)c1 * n * 4 >= (1ll << 31) || (long long)b * L >= (1ll << 31)) return -2;
+    if (b == 0 || m == 0) return 0;
+    SpParams q;
+    q.b = b; q.n = n; q.m = m; q.k = k; q.v1pm = v1pm; q.xyz_cn = xyz_cn; q.new_xyz = new_xyz; q.idx = idx;
+    q.w1 = w1; q.w2 = w2; q.b2 = b2; q.w3 = w3; q.b3 = b3; q.out = out; q.out_ctotal = out_ctotal; q.co_off = co_off;
+    q.tiles_per_cloud = (int)(L / SP_POS);
+    q.prof = captra_sa_prof_ptr();
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    static std::atomic<int> cus_of[128];
+    cus = cus_of[dev & 127].load(std::memory_order_relaxed);
+    if (cus == 0) {
+        hipDeviceProp_t prop;
+        cus = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+        cus_of[dev & 127].store(cus, std::memory_order_relaxed);
+    }
+    // one workgroup (4 waves, one per SIMD) per CU; chunks of up to SP_MAXCH consecutive tiles as long as that still gives
+    // every CU work (small batches keep single-tile chunks: latency first)
+    const long long tiles = (long long)b * q.tiles_per_cloud;
+    int ch = SP_MAXCH;
+    while (ch > 1 && (q.tiles_per_cloud % ch != 0 || tiles / ch < cus)) ch >>= 1;
+    q.chunk = ch;
+    q.chunks = tiles / ch;
+    const unsigned grid = (unsigned)(q.chunks < cus ? q.chunks : cus);
+#define SPP_CASE(CF_, C1_, C2_, C3_)                                                                                  \
+    if (cfeat == CF_ && c1 == C1_ && c2 == C2_ && c3 == C3_) {                                                        \
+        auto kern = sa_wave_pipe_kernel<CF_, C1_, C2_, C3_>;                                                          \
+        constexpr int lds_bytes = 2 * pad32c(C3_) * SP_MAXCH * 8 * 4;                                                 \
+        static CaptraDeviceOnce once;                                                                                 \
+        if (once.first_use())                                                                                         \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); \
+        CAPTRA_LAUNCH("sa_scale_fused", kern, dim3(grid), dim3(256), lds_bytes, (hipStream_t)stream, q);               \
+        return captra_last_error();                                                                                   \
+    }
+    SPP_CASE(320, 128, 128, 256)
+    SPP_CASE(320, 128, 196, 256)
+#undef SPP_CASE
+    return -2;
+}

@@ -55,8 +55,13 @@ __device__ __forceinline__ void sw_load_set(float (&dst)[16], const __amdgpu_buf
 #pragma unroll
         for (int j = 0; j < SW_KS; ++j) {
             const int kk = c * SW_KS + j, t = 2 * ps + tm;
-            if (kk < S::KST && t < S::NT)
+            if (kk < S::KST && t < S::NT) {
+#if defined(SW_EXP) && (SW_EXP & 2)
+                dst[tm * SW_KS + j] = __int_as_float(0x3c000000 + voff + kk + t);   // EXPERIMENT: no weight loads (wrong results)
+#else
                 dst[tm * SW_KS + j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, ((2 * kk) * S::LDW + 32 * t) * 4, 0));
+#endif
+            }
         }
 }
 
@@ -80,6 +85,16 @@ __device__ __forceinline__ void sw_bias_init(f32x16 &acc, const float *bias_lds,
 // ReLU, then turn output tile t (rows 32t..32t+31) into B operands hout[16t..16t+15] (k-step = row pair)
 template <int NOUT>
 __device__ __forceinline__ void sw_mid_epilogue(const f32x16 &acc, int t, float (&hout)[NOUT]) {
+#if defined(SW_EXP) && (SW_EXP & 1)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {      // EXPERIMENT: no ReLU / swap (wrong results, same data flow)
+        const int k0 = 16 * t + 4 * q;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (k0 + i < NOUT) hout[k0 + i] = acc[4 * q + i];
+    }
+    return;
+#endif
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         float a[4];
@@ -116,6 +131,16 @@ __device__ __forceinline__ void sw_last_epilogue(const f32x16 &acc, int t, float
         const int x = __float_as_int(acc[r]);
         v[r] = x > 0 ? x : 0;  // ReLU on the bit pattern: negative floats (and -0) are negative integers
     }
+#if defined(SW_EXP) && (SW_EXP & 1)
+    if ((lane & 31) == 16) {           // EXPERIMENT: no wave-wide max (wrong results)
+        float *rp = red + (32 * t + 4 * (lane >> 5)) * RED_STRIDE + wave;
+        int acc_or = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_or |= v[r];
+        rp[0] = __int_as_float(acc_or);
+    }
+    return;
+#endif
 #pragma unroll
     for (int r = 0; r < 16; ++r) v[r] = dpp_max_i32<0xB1, 0xF>(v[r]);   // quad_perm [1,0,3,2]
 #pragma unroll

@@ -68,6 +68,19 @@ class PackedLinear:
         view.wt, view.bias, view.cin, view.cout, view._bf16 = self.wt, self.bias, rows, self.cout, self._bf16
         return view
 
+    def frag(self) -> torch.Tensor:
+        """MFMA-fragment-ordered image of the layer (include/captra_hip.h: captra_pack_weights_frag) for the kernels that
+        stream weights with 16-byte loads; built once on the device, cached with the layer."""
+        from . import _lib as L
+        cache = self._bf16
+        if "frag" not in cache:
+            n = int(L.lib().captra_pack_weights_frag_floats(self.cin, self.cout))
+            wf = torch.empty(n, dtype=torch.float32, device=self.wt.device)
+            with torch.cuda.device(self.wt.device):
+                L.call("captra_pack_weights_frag", self.cin, self.cout, L.ptr(self.wt), L.ptr(wf))
+            cache["frag"] = wf
+        return cache["frag"]
+
     def bf16(self, row0: int = 0, rows: int | None = None) -> torch.Tensor:
         """bf16 image of input rows [row0, row0+rows) of this layer for the bf16 kernels (include/captra_hip.h:
         Wb [ceil32(cout)][ceil32(rows)], untransposed, zero padded), built once per (row0, rows) on the device."""

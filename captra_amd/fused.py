@@ -197,6 +197,42 @@ def sa_first_layer_pre(feat, lin: PackedLinear):
     return pointwise_mlp(feat, lin.leading_rows(feat.shape[1]), ACT_NONE)
 
 
+USE_SA_PIPE = True       # SA2 scales on the pipelined kernel (csrc/sa_pipe.hip); False = sa_wave_kernel<..., PRE> (A/B, tests)
+
+
+def sa_scale_pipe_supported(cfeat, layers, m: int, k: int) -> bool:
+    return USE_SA_PIPE and sa_scale_pre_supported(cfeat, layers, k) and (m * k) % 128 == 0
+
+
+def sa_first_layer_pre_pm(feat, lin: PackedLinear):
+    """v1 POINT-major (B,N,c1) = b1 + W1[feature rows] feat (captra_pointwise_mlp_pm): what the pipelined SA kernel gathers
+    with 16-byte loads."""
+    assert lin.cin == feat.shape[1] + 3
+    lead = lin.leading_rows(feat.shape[1])
+    L.require_device(feat, lead.wt, lead.bias)
+    B, cin, N = feat.shape
+    out = torch.empty(B, N, lead.cout, dtype=torch.float32, device=feat.device)
+    with torch.cuda.device(feat.device):
+        L.call("captra_pointwise_mlp_pm", B, cin, lead.cout, N, L.ptr(feat), L.ptr(lead.wt), L.ptr(lead.bias), ACT_NONE, L.ptr(out))
+    _work("pointwise_mlp", flops=2.0 * B * cin * lead.cout * N, nbytes=4.0 * B * N * (cin + lead.cout))
+    return out
+
+
+def sa_scale_pre_pm(v1pm, xyz_cn, new_xyz_n3, idx, layers, out, co_off, cfeat):
+    """One SA scale from the point-major pre-transformed first layer (captra_sa_scale_pre_pm)."""
+    l1, l2, l3 = layers
+    L.require_device(v1pm, xyz_cn, new_xyz_n3, idx, out)
+    B, _, N = xyz_cn.shape
+    _, M, K = idx.shape
+    with torch.cuda.device(xyz_cn.device):
+        L.call("captra_sa_scale_pre_pm", B, N, M, K, cfeat, l1.cout, l2.cout, l3.cout, L.ptr(v1pm), L.ptr(xyz_cn),
+               L.ptr(new_xyz_n3), L.ptr(idx), L.ptr(l1.wt), L.ptr(l2.frag()), L.ptr(l2.bias), L.ptr(l3.frag()), L.ptr(l3.bias),
+               L.ptr(out), out.shape[1], co_off)
+    _work("sa_scale_fused", flops=2.0 * B * M * K * (3 * l1.cout + l1.cout * l2.cout + l2.cout * l3.cout),
+          nbytes=4.0 * B * (l1.cout * N + 3 * N + M * K + 3 * M + l3.cout * M))
+    return out
+
+
 def sa_scale_pre(v1, xyz_cn, new_xyz_n3, idx, layers, out, co_off, cfeat):
     """One SA scale from the pre-transformed first layer (captra_sa_scale_pre)."""
     l1, l2, l3 = layers

@@ -237,6 +237,29 @@ int captra_sa_scale_pre(int b, int n, int m, int k, int cfeat, int c1, int c2, i
                         const float *b2, const float *w3, const float *b3, float *out, int out_ctotal, int co_off,
                         captra_stream_t stream);
 
+/* The same scale on the pipelined kernel (csrc/sa_pipe.hip: persistent one-wave-per-SIMD workgroups, next tile's gather
+ * under the current tile's MFMAs, deferred epilogues, weight sets two ahead, staged output rows): v1pm is the POINT-major
+ * (B,N,c1) result of captra_pointwise_mlp_pm.  Same k-ascending chains: bit-identical to captra_sa_scale_pre /
+ * captra_sa_scale_fused.  w1 is the PACKED first layer (its relative-xyz rows are used), w2 / w3 are the FRAGMENT-ordered
+ * images of layers 2 / 3 (captra_pack_weights_frag), b2 / b3 their packed biases.  -2 when the shape is not instantiated or
+ * m*k is not a multiple of 128 (take captra_sa_scale_pre). */
+int captra_sa_scale_pre_pm(int b, int n, int m, int k, int cfeat, int c1, int c2, int c3, const float *v1pm,
+                           const float *xyz_cn, const float *new_xyz, const int *idx, const float *w1, const float *w2,
+                           const float *b2, const float *w3, const float *b3, float *out, int out_ctotal, int co_off,
+                           captra_stream_t stream);
+
+/* MFMA-fragment order of a packed layer for kernels that stream weights with 16-byte loads (csrc/sa_pipe.hip): with
+ * KQ = ceil(ceil(cin/2)/4) and NT = ceil(cout/32), element ((t*KQ + q)*64 + lane)*4 + i of wfrag (NT*KQ*256 floats =
+ * captra_pack_weights_frag_floats) = W'^T[2(4q+i) + (lane>>5)][32t + (lane&31)] of the packed image (zero beyond cin): one
+ * 16-byte load per lane = the A operands of four consecutive k-steps of output tile t. */
+long long captra_pack_weights_frag_floats(int cin, int cout);
+int captra_pack_weights_frag(int cin, int cout, const float *wt_packed, float *wfrag, captra_stream_t stream);
+
+/* captra_pointwise_mlp with a POINT-major result y (B,l,cout) (cout % 4 == 0, y 16-byte aligned; -2 otherwise or when the
+ * layer is outside the direct-operand kernel's 32-bit offset range). */
+int captra_pointwise_mlp_pm(int b, int cin, int cout, long long l, const float *x, const float *wt_packed,
+                            const float *bias_packed, int act, float *y, captra_stream_t stream);
+
 /* Three dense layers in one launch: y (B,c3,l) = act3(W3 relu(W2 relu(W1 x + b1) + b2) + b3), x (B,c0,l); packed
  * weights (captra_pack_weights).  Replaces the FP1 shared MLP + conv1/bn1/ReLU tail of PointNet2Msg
  * (pointnet_utils.py:296-298, backbones.py:66-68) without the two intermediate (B,128,l) tensors.  Instantiated

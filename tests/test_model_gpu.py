@@ -137,6 +137,45 @@ def test_sa_scale_pre_bit_exact(device, chans, n, m, k):
     assert (got[:, :4] == -1).all() and (got[:, 4 + chans[2]:] == -1).all()
 
 
+@pytest.mark.parametrize("chans,n,m,k,B", [((128, 128, 256), 512, 128, 64, 2), ((128, 196, 256), 512, 128, 128, 2),
+                                           ((128, 196, 256), 512, 128, 128, 5), ((128, 128, 256), 512, 128, 64, 33),
+                                           ((128, 196, 256), 200, 6, 64, 3), ((128, 128, 256), 333, 36, 32, 2),
+                                           ((128, 196, 256), 700, 1, 128, 1)])
+def test_sa_scale_pipe_bit_exact(device, chans, n, m, k, B):
+    """The pipelined SA2 kernel (csrc/sa_pipe.hip: persistent workgroups, next tile's gather prefetched, deferred epilogues,
+    weight ring of three, staged output rows) on the point-major pre-transformed first layer == the oracle's gather -> 3
+    layers -> max, bit for bit: single- and multi-tile chunks, several tiles per workgroup, batches that do not fill the
+    chip, channel offsets in the output; and the point-major dense layer == the channel-major one, transposed."""
+    from captra_amd import fused
+    cfeat = 320
+    rng = np.random.default_rng(sum(chans) + n + k + B)
+    xyz_cn = (rng.random((B, 3, n), dtype=np.float32) - 0.5)
+    feat = rng.standard_normal((B, cfeat, n)).astype(np.float32)
+    new_xyz = (rng.random((B, m, 3), dtype=np.float32) - 0.5)
+    idx = rng.integers(0, n, (B, m, k)).astype(np.int32)
+    dims = (cfeat + 3,) + chans
+    layers = [((rng.standard_normal((dims[i], dims[i + 1])) / np.sqrt(dims[i])).astype(np.float32),
+               rng.standard_normal(dims[i + 1]).astype(np.float32)) for i in range(3)]
+    packed = [fused.pack(_dev(w, device), _dev(b, device)) for w, b in layers]
+    assert fused.sa_scale_pipe_supported(cfeat, packed, m, k)
+    v1pm = fused.sa_first_layer_pre_pm(_dev(feat, device), packed[0])
+    v1 = fused.sa_first_layer_pre(_dev(feat, device), packed[0])
+    assert torch.equal(v1pm, v1.transpose(1, 2))
+    out = torch.full((B, chans[2] + 9, m), -1.0, device=device)
+    fused.sa_scale_pre_pm(v1pm, _dev(xyz_cn, device), _dev(new_xyz, device), _dev(idx, device), packed, out, 4, cfeat)
+    x = O.sa_group(feat, xyz_cn, new_xyz, idx)
+    for w, b in layers:
+        x = O.pointwise_mlp(x, w, b, 1)
+    ref = O.max_over_k(x)
+    got = out.cpu().numpy()
+    np.testing.assert_array_equal(got[:, 4:4 + chans[2]], ref)
+    assert (got[:, :4] == -1).all() and (got[:, 4 + chans[2]:] == -1).all()
+    # and against the previous-generation kernel on the same inputs
+    out2 = torch.full_like(out, -1.0)
+    fused.sa_scale_pre(v1, _dev(xyz_cn, device), _dev(new_xyz, device), _dev(idx, device), packed, out2, 4, cfeat)
+    assert torch.equal(out, out2)
+
+
 def _sa_scale_fused_case(device, cfeat, chans, n, m, k):
     from captra_amd import fused
     rng = np.random.default_rng(cfeat + sum(chans) + k)

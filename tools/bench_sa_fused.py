@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--layered", action="store_true")
     ap.add_argument("--wn", type=int, default=0)
     ap.add_argument("--pre", action="store_true", help="pre-transformed first layer (captra_sa_scale_pre) where supported; time includes the v1 launch")
+    ap.add_argument("--pipe", action="store_true", help="pipelined SA2 kernel (captra_sa_scale_pre_pm); time includes the point-major v1 launch")
+    ap.add_argument("--zeros", action="store_true", help="all-zero features / weights: same instruction stream at lower power (DVFS probe)")
     ap.add_argument("--mode", type=int, default=0, help="0 = register-resident kernels where instantiated, 1 = generic LDS kernel")
     ap.add_argument("--phases", action="store_true", help="debug: in-kernel s_memtime phase breakdown of sa_wave_kernel")
     a = ap.parse_args()
@@ -43,12 +45,21 @@ def main():
         dims = (cfeat + 3,) + ch
         layers = [fused.pack((torch.randn(dims[i], dims[i + 1], generator=g) / dims[i] ** 0.5).to(dev), torch.randn(dims[i + 1], generator=g).to(dev)) for i in range(3)]
         out = torch.empty(B, ch[2], m, device=dev)
+        if a.zeros:
+            xyz.zero_(); new_xyz.zero_()
+            if feat is not None:
+                feat.zero_()
+            for lin in layers:
+                lin.wt.zero_(); lin.bias.zero_()
 
         def run():
             if a.layered:
                 y = fused.sa_group_mlp(feat, xyz, new_xyz, idx, layers[0])
                 y = fused.pointwise_mlp(y, layers[1], fused.ACT_RELU)
                 fused.mlp_max(y, layers[2], out, 0)
+            elif a.pipe and feat is not None and fused.sa_scale_pipe_supported(cfeat, layers, m, k):
+                v1 = fused.sa_first_layer_pre_pm(feat, layers[0])
+                fused.sa_scale_pre_pm(v1, xyz, new_xyz, idx, layers, out, 0, cfeat)
             elif a.pre and feat is not None and fused.sa_scale_pre_supported(cfeat, layers, k):
                 v1 = fused.sa_first_layer_pre(feat, layers[0])
                 fused.sa_scale_pre(v1, xyz, new_xyz, idx, layers, out, 0, cfeat)
@@ -77,7 +88,8 @@ def main():
             _lib.lib().captra_sa_fused_set_prof(ctypes.c_void_p(0))
             c = cnt.tolist()
             waves = max(c[9], 1)
-            labels = ["start", "L1", "L2", "L3", "end-barrier"]     # sa_wave_kernel's timers (streamed-weight scales)
+            labels = (["between", "L1", "L2", "L3", "combine"] if a.pipe else      # sa_wave_pipe_kernel: per tile
+                      ["start", "L1", "L2", "L3", "end-barrier"])                 # sa_wave_kernel's timers (streamed-weight scales)
             tot = sum(c[:len(labels)]) / waves
             if c[6]:
                 print(f"  wave life: {c[5] / waves:.0f} shader cycles in {c[6] / waves / 100:.1f} us (s_memrealtime) -> shader clock {c[5] / c[6] * 0.1:.3f} GHz")
