@@ -44,7 +44,7 @@ _SIGNATURES = {
     "captra_pointwise_mlp_gn": [_INT, _INT, _INT, _LL, _P, _P, _P, _P, _INT, _P, _P, _INT, _P],
     "captra_gn_finalize": [_INT, _INT, _INT, _INT, _LL, _F, _P, _P, _P, _P, _P],
     "captra_pack_weights_bf16": [_INT, _INT, _P, _P, _P],
-    "captra_pack_weights_frag": [_INT, _INT, _P, _P, _P],
+    "captra_pack_weights_frag": [_INT, _INT, _P, _P],
     "captra_pointwise_mlp_bf16": [_INT, _INT, _INT, _LL, _P, _P, _P, _INT, _P, _P],
     "captra_sa_scale_bf16": [_INT] * 9 + [_P] * 11 + [_INT, _INT, _P],
     "captra_coord_tail": [_INT, _INT, _INT, _INT, _LL, _P, _P, _P, _INT, _P, _P, _P],
@@ -98,9 +98,9 @@ def lib():
             if hasattr(l, name):
                 getattr(l, name).argtypes = args
                 getattr(l, name).restype = C.c_size_t
-        if hasattr(l, "captra_pack_weights_frag_floats"):
-            l.captra_pack_weights_frag_floats.argtypes = [_INT, _INT]
-            l.captra_pack_weights_frag_floats.restype = _LL
+        if hasattr(l, "captra_packed_weight_floats"):
+            l.captra_packed_weight_floats.argtypes = [_INT, _INT]
+            l.captra_packed_weight_floats.restype = _LL
         if hasattr(l, "captra_pointwise_mlp_gn_tiles"):
             l.captra_pointwise_mlp_gn_tiles.argtypes = [_INT, _INT, _LL]
             l.captra_pointwise_mlp_gn_tiles.restype = _INT

@@ -349,15 +349,23 @@ __global__ __launch_bounds__(256) void pw_direct_kernel(PwParams p) {
     const long long pos0 = ((long long)blockIdx.x * WGN + wn) * TN * 32;
     if (co0 >= p.cout) return;  // wave-uniform; no barriers in this kernel
 
+    // A operands from the FRAGMENT image of the packed buffer (behind its row-major image): one 16-byte load per lane holds
+    // four consecutive k-steps of an output tile -- a quarter of the vector-memory instructions of dword loads, which at one
+    // load per MFMA kept the CU's address unit as busy as its four matrix pipes
     const int kp = (p.cin + 31) / 32 * 32;
-    const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc((void *)p.wt, 0, kp * p.ldw * 4, 0x00020000);
+    const int kq = ((p.cin + 1) / 2 + 3) / 4;                  // quads of k-steps per output tile
+    const int ntile = (p.cout + 31) / 32;
+    const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(p.wt + (size_t)kp * p.ldw), 0, ntile * kq * 1024, 0x00020000);
     const float *xb = p.x + (size_t)b * p.cin * p.L;
     const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc((void *)xb, 0, (int)((long long)p.cin * p.L * 4), 0x00020000);
-    const int wstep = 2 * p.ldw * 4;          // bytes per k-step in W
     const int xstep = (int)(2 * p.L * 4);     // bytes per k-step in X
     int wvoff[TM], xvoff[TN];
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm) wvoff[tm] = (((lane >> 5) * p.ldw) + co0 + tm * 32 + (lane & 31)) * 4;
+    for (int tm = 0; tm < TM; ++tm) {
+        int tile = co0 / 32 + tm;
+        if (tile >= ntile) tile = ntile - 1;                    // rows beyond cout: any valid tile (their results are not stored)
+        wvoff[tm] = tile * kq * 1024 + lane * 16;
+    }
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
         long long col = pos0 + tn * 32 + (lane & 31);
@@ -384,9 +392,12 @@ __global__ __launch_bounds__(256) void pw_direct_kernel(PwParams p) {
     const int gvoff = (lane >> 5) * 8;
     const int nsets = (p.cin + 2 * KS - 1) / (2 * KS);
 #define PW_LOAD_SET(A, Bv, G, si)                                                                                        \
+    _Pragma("unroll") for (int jq = 0; jq < KS / 4; ++jq)                                                               \
+        _Pragma("unroll") for (int tm = 0; tm < TM; ++tm) {                                                             \
+            const float4 w4 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wsrc, wvoff[tm], ((si) * (KS / 4) + jq) * 1024, 0)); \
+            A[tm][4 * jq + 0] = w4.x; A[tm][4 * jq + 1] = w4.y; A[tm][4 * jq + 2] = w4.z; A[tm][4 * jq + 3] = w4.w;       \
+        }                                                                                                                \
     _Pragma("unroll") for (int j = 0; j < KS; ++j) {                                                                    \
-        _Pragma("unroll") for (int tm = 0; tm < TM; ++tm) A[tm][j] = __builtin_bit_cast(                                 \
-            float, __builtin_amdgcn_raw_buffer_load_b32(wsrc, wvoff[tm], ((si) * KS + j) * wstep, 0));                   \
         _Pragma("unroll") for (int tn = 0; tn < TN; ++tn) Bv[tn][j] = __builtin_bit_cast(                                \
             float, __builtin_amdgcn_raw_buffer_load_b32(xsrc, xvoff[tn] + ((si) * KS + j) * xstep, 0, 0));               \
         if (AFF) G[j] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(gsrc, gvoff + ((si) * KS + j) * 16, 0, 0)); \
@@ -638,18 +649,20 @@ __global__ void pack_weights_frag_kernel(int cin, int ldw, int kq, int total, co
 
 extern "C" void captra_pw_set_direct(int on) { g_pw_direct = on; }
 
-extern "C" long long captra_pack_weights_frag_floats(int cin, int cout) {
+extern "C" long long captra_packed_weight_floats(int cin, int cout) {
     if (cin < 1 || cout < 1) return 0;
-    const int kst = (cin + 1) / 2, kq = (kst + 3) / 4, nt = (cout + 31) / 32;
-    return (long long)nt * kq * 256;
+    const long long kp = (cin + 31) / 32 * 32, cp = (cout + 127) / 128 * 128;
+    const long long kst = (cin + 1) / 2, kq = (kst + 3) / 4, nt = (cout + 31) / 32;
+    return kp * cp + nt * kq * 256;
 }
 
-extern "C" int captra_pack_weights_frag(int cin, int cout, const float *wt_packed, float *wfrag, captra_stream_t stream) {
+extern "C" int captra_pack_weights_frag(int cin, int cout, float *wt_packed, captra_stream_t stream) {
     if (cin < 1 || cout < 1) return -1;
+    const int kp = (cin + 31) / 32 * 32, ldw = (cout + 127) / 128 * 128;
     const int kst = (cin + 1) / 2, kq = (kst + 3) / 4, nt = (cout + 31) / 32;
-    const int total = nt * kq * 256, ldw = (cout + 127) / 128 * 128;
+    const int total = nt * kq * 256;
     CAPTRA_LAUNCH("pack_weights", pack_weights_frag_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, cin, ldw,
-                  kq, total, wt_packed, wfrag);
+                  kq, total, wt_packed, wt_packed + (size_t)kp * ldw);
     return captra_last_error();
 }
 
@@ -660,7 +673,8 @@ extern "C" int captra_pack_weights(int cin, int cout, const float *wt, const flo
     const int n = kp * cp;
     CAPTRA_LAUNCH("pack_weights", pack_weights_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, cin,
                   cout, kp, cp, wt, bias, wt_packed, bias_packed);
-    return captra_last_error();
+    const int err = captra_last_error();
+    return err != 0 ? err : captra_pack_weights_frag(cin, cout, wt_packed, stream);   // the fragment-ordered image behind it
 }
 
 extern "C" int captra_pointwise_mlp(int b, int cin, int cout, long long l, const float *x, const float *wt_packed,

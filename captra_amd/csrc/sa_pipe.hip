@@ -33,7 +33,7 @@ struct SpParams {
     const float *new_xyz;   // (B,M,3)
     const int *idx;         // (B,M,K)
     const float *w1;        // packed first-layer weights (rows CF..CF+2 = the relative-xyz rows are used)
-    const float *w2, *b2, *w3, *b3;   // w2, w3: FRAGMENT-ordered images (captra_pack_weights_frag); b2, b3: packed biases
+    const float *w2, *b2, *w3, *b3;   // packed (row-major + fragment images); layers 2 / 3 stream the fragment image
     float *out;             // (B,out_ctotal,M)
     int out_ctotal, co_off;
     int tiles_per_cloud;    // M*K / 128
@@ -164,42 +164,10 @@ __device__ __forceinline__ void sp_epi_part(const f32x16 (&acc)[2], int ps, int 
     }
 }
 
-// Weight sets from the FRAGMENT-ordered image (captra_pack_weights_frag): element ((t*KQ + q)*64 + lane)*4 + i =
-// W'^T[2(4q+i) + (lane>>5)][32t + (lane&31)], so ONE 16-byte load per lane holds the A operands of four consecutive
-// k-steps of output tile t.  A set (8 k-steps x 2 tiles) is 4 loads instead of 16: with one dword load per MFMA the four
-// waves of a CU kept its vector-memory address unit (one 64-lane instruction per ~16 cycles) exactly as busy as its matrix
-// pipes (one MFMA per SIMD per 64 cycles) -- measured 19 % of a tile's cycles (tools/exp_sw.sh, SW_EXP=2).
-template <int CIN, int COUT>
-struct SpFrag {
-    static constexpr int KST = (CIN + 1) / 2, KQ = (KST + 3) / 4, NT = (COUT + 31) / 32;
-    static constexpr int FLOATS = NT * KQ * 256;
-};
-
-template <int CIN, int COUT>
-__device__ __forceinline__ void sp_load_set(float (&dst)[16], const __amdgpu_buffer_rsrc_t rsrc, int lane, int ps, int c) {
-    using S = SwShape<CIN, COUT>;
-    using F = SpFrag<CIN, COUT>;
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-        for (int qq = 0; qq < SW_KS / 4; ++qq) {
-            const int q = c * (SW_KS / 4) + qq, t = 2 * ps + tm;
-            if (q < F::KQ && t < S::NT) {
-                // (bit_cast of the WHOLE vector: hipcc 7.2 lowers `bit_cast<float>(v[i])` on this builtin's result to a single
-                // buffer_load_dword and leaves the other three elements undefined)
-                const float4 v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, (t * F::KQ + q) * 1024, 0));
-                dst[tm * SW_KS + qq * 4 + 0] = v.x; dst[tm * SW_KS + qq * 4 + 1] = v.y;
-                dst[tm * SW_KS + qq * 4 + 2] = v.z; dst[tm * SW_KS + qq * 4 + 3] = v.w;
-            }
-        }
-}
-
-template <int CIN, int COUT>
-__device__ __forceinline__ void sp_first_set(float (&dst)[16], const float *wfrag, int lane) {
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)wfrag, 0, SpFrag<CIN, COUT>::FLOATS * 4, 0x00020000);
-    sp_load_set<CIN, COUT>(dst, rsrc, lane, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-}
+// Weight sets: the fragment image of the packed buffer (wave_mlp.h: sw_load_set / sw_first_set), 4 loads per set instead of
+// 16.  With one dword load per MFMA the four waves of a CU kept its vector-memory address unit (one 64-lane instruction per
+// ~16 cycles) exactly as busy as its matrix pipes (one MFMA per SIMD per 64 cycles): 19 % of a tile's cycles went into
+// waiting for weights that were in L2 all along (tools/exp_sw.sh, SW_EXP=2).
 
 // One layer: hin[] (B operands) -> hout[] (LAST = false) or per-wave maxima in red (LAST = true).  Weight sets in the ring
 // s[3]: the set of step g is s[(START + g) % 3]; this layer's first set must already be on its way (previous phase), the
@@ -210,7 +178,8 @@ __device__ __forceinline__ void sp_layer(const float *wt, const float *bias_lds,
                                          float (&s)[3][16], float *red8_lane, int lane, Next next, Side side) {
     using S = SwShape<CIN, COUT>;
     static_assert(NIN >= S::KST, "input operand array too small");
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)wt, 0, SpFrag<CIN, COUT>::FLOATS * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc = sw_frag_rsrc<CIN, COUT>(wt);
+    const int voff = lane * 16;
     f32x16 acc[2][2];
     SpMaxState mst[2];
     static_assert(!LAST || S::NSETS >= 6 || S::NPASS == 1, "the deferred max needs its six units in distinct steps, in order");
@@ -222,8 +191,8 @@ __device__ __forceinline__ void sp_layer(const float *wt, const float *bias_lds,
             for (int tm = 0; tm < 2; ++tm)
                 if (2 * ps + tm < S::NT) sw_bias_init(acc[pb][tm], bias_lds, 2 * ps + tm, lane);
         }
-        if (g == 0 && S::STEPS > 1) sp_load_set<CIN, COUT>(s[(START + 1) % 3], rsrc, lane, 1 / S::NSETS, 1 % S::NSETS);
-        if (g + 2 < S::STEPS) sp_load_set<CIN, COUT>(s[(START + g + 2) % 3], rsrc, lane, (g + 2) / S::NSETS, (g + 2) % S::NSETS);
+        if (g == 0 && S::STEPS > 1) sw_load_set<CIN, COUT>(s[(START + 1) % 3], rsrc, voff, 1 / S::NSETS, 1 % S::NSETS);
+        if (g + 2 < S::STEPS) sw_load_set<CIN, COUT>(s[(START + g + 2) % 3], rsrc, voff, (g + 2) / S::NSETS, (g + 2) % S::NSETS);
         if (g + 2 == S::STEPS || (S::STEPS == 1 && g == 0)) next(s[(START + S::STEPS) % 3]);
         side(g);
         __builtin_amdgcn_sched_barrier(0);
@@ -334,7 +303,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int nchunks = (int)p.chunks;
     int par = 0;
     if (chunk_id < nchunks) {
-        sp_first_set<C1, C2>(s[NEXT2], p.w2, lane);
+        sw_first_set<C1, C2>(s[NEXT2], p.w2, lane);
         int tb, pos0;
         tile_of(chunk_id, 0, tb, pos0);
         id = load_id(tb, pos0);
@@ -380,12 +349,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             SP_TICK(1)
             // ---- layer 2; its second step asks for the next tile's neighbour ids ----
             sp_layer<C1, C2, false, 0>(p.w2, bias_lds, h1, h2, s, red + par * RED_BUF + red_lane_off + j * 8, lane,
-                                       [&](float (&dst)[16]) { sp_first_set<C2, C3>(dst, p.w3, lane); },
+                                       [&](float (&dst)[16]) { sw_first_set<C2, C3>(dst, p.w3, lane); },
                                        [&](int g) { if (g == 1 && has_next) id_n = load_id(nb, npos0); });
             SP_TICK(2)
             // ---- layer 3 + max over the 32 neighbours; its third step gathers the next tile's start values ----
             sp_layer<C2, C3, true, START3>(p.w3, bias_lds + 256, h2, none, s, red + par * RED_BUF + red_lane_off + j * 8, lane,
-                                           [&](float (&dst)[16]) { sp_first_set<C1, C2>(dst, p.w2, lane); },
+                                           [&](float (&dst)[16]) { sw_first_set<C1, C2>(dst, p.w2, lane); },
 #if defined(SP_EXP) && (SP_EXP & 2)
                                            [&](int) {});
             if (has_next) load_rest(nb, npos0, id_n, bt, g4);   // EXPERIMENT: gather after layer 3 (exposed)

@@ -4,8 +4,9 @@
 // A wave owns 32 positions and carries them through consecutive 1x1-conv layers.  The MFMA accumulator layout
 // (register r of lane l = row 8(r>>2)+(r&3)+4(l>>5), column l&31) becomes the next layer's B operand (lane-half h
 // of k-step j = row 2j+h) with one v_permlane32_swap per register pair (sw_mid_epilogue), so activations never
-// leave the vector registers.  Weights are the packed W'^T of captra_pack_weights (ceil32(cin) x ceil128(cout),
-// zero padded) streamed with buffer loads (scalar k offset) one 16-register set ahead of the MFMAs (sw_layer_reg).
+// leave the vector registers.  Weights are streamed from the FRAGMENT image of the packed buffer (include/captra_hip.h
+// "PACKED WEIGHTS": behind the row-major image; one 16-byte load per lane = four consecutive k-steps of an output tile)
+// one 16-register set ahead of the MFMAs (sw_layer_reg).
 // Accumulators start from the bias and K ascends within one wave: the k-ascending fmaf chain of the oracle.
 #pragma once
 #include "common.h"
@@ -46,30 +47,46 @@ struct SwShape {
     static constexpr int LDW = pad128c(COUT), KP = pad32c(CIN);
 };
 
-// loads of set `c` of pass `ps` into dst[tm*8 + j]
+// the fragment image of a packed layer: element ((t*KQ + q)*64 + lane)*4 + i = W'^T[2(4q+i) + (lane>>5)][32t + (lane&31)]
+template <int CIN, int COUT>
+struct SwFrag {
+    static constexpr int KST = (CIN + 1) / 2, KQ = (KST + 3) / 4, NT = (COUT + 31) / 32;
+    static constexpr int BYTES = NT * KQ * 1024;
+    static constexpr int OFFSET = pad32c(CIN) * pad128c(COUT);     // floats of the row-major image in front of it
+};
+
+template <int CIN, int COUT>
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t sw_frag_rsrc(const float *wt_packed) {
+    return __builtin_amdgcn_make_buffer_rsrc((void *)(wt_packed + SwFrag<CIN, COUT>::OFFSET), 0, SwFrag<CIN, COUT>::BYTES, 0x00020000);
+}
+
+// loads of set `c` of pass `ps` into dst[tm*8 + j]: two 16-byte loads per tile (8 k-steps).
+// (bit_cast of the WHOLE vector: hipcc 7.2 lowers `bit_cast<float>(v[i])` on this builtin's result to a single
+// buffer_load_dword and leaves the other three elements undefined)
 template <int CIN, int COUT>
 __device__ __forceinline__ void sw_load_set(float (&dst)[16], const __amdgpu_buffer_rsrc_t rsrc, int voff, int ps, int c) {
     using S = SwShape<CIN, COUT>;
+    using F = SwFrag<CIN, COUT>;
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-        for (int j = 0; j < SW_KS; ++j) {
-            const int kk = c * SW_KS + j, t = 2 * ps + tm;
-            if (kk < S::KST && t < S::NT) {
+        for (int qq = 0; qq < SW_KS / 4; ++qq) {
+            const int q = c * (SW_KS / 4) + qq, t = 2 * ps + tm;
+            if (q < F::KQ && t < S::NT) {
 #if defined(SW_EXP) && (SW_EXP & 2)
-                dst[tm * SW_KS + j] = __int_as_float(0x3c000000 + voff + kk + t);   // EXPERIMENT: no weight loads (wrong results)
+                const float4 v = make_float4(__int_as_float(0x3c000000 + voff + q), __int_as_float(0x3c100000 + voff + t), 0.5f, 0.25f);  // EXPERIMENT: no weight loads
 #else
-                dst[tm * SW_KS + j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, ((2 * kk) * S::LDW + 32 * t) * 4, 0));
+                const float4 v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, (t * F::KQ + q) * 1024, 0));
 #endif
+                dst[tm * SW_KS + qq * 4 + 0] = v.x; dst[tm * SW_KS + qq * 4 + 1] = v.y;
+                dst[tm * SW_KS + qq * 4 + 2] = v.z; dst[tm * SW_KS + qq * 4 + 3] = v.w;
             }
         }
 }
 
 template <int CIN, int COUT>
 __device__ __forceinline__ void sw_first_set(float (&dst)[16], const float *wt, int lane) {
-    using S = SwShape<CIN, COUT>;
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)wt, 0, S::KP * S::LDW * 4, 0x00020000);
-    sw_load_set<CIN, COUT>(dst, rsrc, ((lane >> 5) * S::LDW + (lane & 31)) * 4, 0, 0);
+    sw_load_set<CIN, COUT>(dst, sw_frag_rsrc<CIN, COUT>(wt), lane * 16, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -191,8 +208,8 @@ __device__ __forceinline__ void sw_layer_reg(const float *wt, const float *bias_
                                              float (&s)[2][16], float *red, int wave, int lane, Next next, const SwStore &st = SwStore()) {
     using S = SwShape<CIN, COUT>;
     static_assert(NIN >= S::KST, "input operand array too small");
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)wt, 0, S::KP * S::LDW * 4, 0x00020000);
-    const int voff = ((lane >> 5) * S::LDW + (lane & 31)) * 4;
+    const __amdgpu_buffer_rsrc_t rsrc = sw_frag_rsrc<CIN, COUT>(wt);
+    const int voff = lane * 16;
     f32x16 acc[2];
 #pragma unroll
     for (int g = 0; g < S::STEPS; ++g) {

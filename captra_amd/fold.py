@@ -45,41 +45,38 @@ def collect_folded(module) -> list:
 
 
 class PackedLinear:
-    """A layer's weights in the layout the MFMA kernels stage (include/captra_hip.h "packed weights"):
-    W'^T zero-padded to (ceil32(cin), ceil128(cout)), bias zero-padded to ceil128(cout)."""
+    """A layer's weights in the layout the MFMA kernels take (include/captra_hip.h "PACKED WEIGHTS"): ONE buffer `wt` holding
+    W'^T row-major, zero-padded to (ceil32(cin), ceil128(cout)), followed by the same numbers in MFMA-fragment order (the
+    image the streaming kernels read with 16-byte loads); bias zero-padded to ceil128(cout).  `wt2d` is the row-major
+    part as a (KP, CP) view."""
 
-    __slots__ = ("wt", "bias", "cin", "cout", "_bf16")
+    __slots__ = ("wt", "wt2d", "bias", "cin", "cout", "_bf16")
 
     def __init__(self, wt_dense: torch.Tensor, bias_dense: torch.Tensor):
         cin, cout = wt_dense.shape
         kp, cp = (cin + 31) // 32 * 32, (cout + 127) // 128 * 128
-        wt = torch.zeros(kp, cp, dtype=torch.float32, device=wt_dense.device)
-        wt[:cin, :cout] = wt_dense
-        bias = torch.zeros(cp, dtype=torch.float32, device=wt_dense.device)
+        kq, nt = ((cin + 1) // 2 + 3) // 4, (cout + 31) // 32
+        dev = wt_dense.device
+        buf = torch.zeros(kp * cp + nt * kq * 256, dtype=torch.float32, device=dev)
+        wt2d = buf[:kp * cp].view(kp, cp)
+        wt2d[:cin, :cout] = wt_dense
+        bias = torch.zeros(cp, dtype=torch.float32, device=dev)
         bias[:cout] = bias_dense
-        self.wt, self.bias, self.cin, self.cout = wt.contiguous(), bias.contiguous(), cin, cout
+        self.wt, self.wt2d, self.bias, self.cin, self.cout = buf, wt2d, bias.contiguous(), cin, cout
         self._bf16 = {}
+        if dev.type == "cuda":       # (a CPU-side PackedLinear only exists in host-logic tests: no kernel will read it)
+            from . import _lib as L
+            with torch.cuda.device(dev):
+                L.call("captra_pack_weights_frag", cin, cout, L.ptr(buf))
 
     def leading_rows(self, rows: int) -> "PackedLinear":
-        """The layer restricted to its first `rows` input channels, sharing this layer's buffers (the packed image's leading
-        rows ARE those channels; the kernels never read past ceil32(cin) rows)."""
+        """The layer restricted to its first `rows` input channels (same bias): its own packed buffer (the fragment image
+        depends on the row count), built once and cached with the layer."""
         assert 1 <= rows <= self.cin
-        view = PackedLinear.__new__(PackedLinear)
-        view.wt, view.bias, view.cin, view.cout, view._bf16 = self.wt, self.bias, rows, self.cout, self._bf16
-        return view
-
-    def frag(self) -> torch.Tensor:
-        """MFMA-fragment-ordered image of the layer (include/captra_hip.h: captra_pack_weights_frag) for the kernels that
-        stream weights with 16-byte loads; built once on the device, cached with the layer."""
-        from . import _lib as L
-        cache = self._bf16
-        if "frag" not in cache:
-            n = int(L.lib().captra_pack_weights_frag_floats(self.cin, self.cout))
-            wf = torch.empty(n, dtype=torch.float32, device=self.wt.device)
-            with torch.cuda.device(self.wt.device):
-                L.call("captra_pack_weights_frag", self.cin, self.cout, L.ptr(self.wt), L.ptr(wf))
-            cache["frag"] = wf
-        return cache["frag"]
+        key = ("lead", rows)
+        if key not in self._bf16:
+            self._bf16[key] = PackedLinear(self.wt2d[:rows, :self.cout].contiguous(), self.bias[:self.cout].contiguous())
+        return self._bf16[key]
 
     def bf16(self, row0: int = 0, rows: int | None = None) -> torch.Tensor:
         """bf16 image of input rows [row0, row0+rows) of this layer for the bf16 kernels (include/captra_hip.h:
@@ -87,11 +84,9 @@ class PackedLinear:
         from . import _lib as L
         rows = self.cin - row0 if rows is None else rows
         key = (row0, rows)
-        cache = getattr(self, "_bf16", None)
-        if cache is None:
-            cache = self._bf16 = {}
+        cache = self._bf16
         if key not in cache:
-            dense = self.wt[row0:row0 + rows, :self.cout].contiguous()
+            dense = self.wt2d[row0:row0 + rows, :self.cout].contiguous()
             kb, cp = (rows + 31) // 32 * 32, (self.cout + 31) // 32 * 32
             wb = torch.empty(cp, kb, dtype=torch.bfloat16, device=self.wt.device)
             with torch.cuda.device(self.wt.device):

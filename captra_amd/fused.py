@@ -226,7 +226,7 @@ def sa_scale_pre_pm(v1pm, xyz_cn, new_xyz_n3, idx, layers, out, co_off, cfeat):
     _, M, K = idx.shape
     with torch.cuda.device(xyz_cn.device):
         L.call("captra_sa_scale_pre_pm", B, N, M, K, cfeat, l1.cout, l2.cout, l3.cout, L.ptr(v1pm), L.ptr(xyz_cn),
-               L.ptr(new_xyz_n3), L.ptr(idx), L.ptr(l1.wt), L.ptr(l2.frag()), L.ptr(l2.bias), L.ptr(l3.frag()), L.ptr(l3.bias),
+               L.ptr(new_xyz_n3), L.ptr(idx), L.ptr(l1.wt), L.ptr(l2.wt), L.ptr(l2.bias), L.ptr(l3.wt), L.ptr(l3.bias),
                L.ptr(out), out.shape[1], co_off)
     _work("sa_scale_fused", flops=2.0 * B * M * K * (3 * l1.cout + l1.cout * l2.cout + l2.cout * l3.cout),
           nbytes=4.0 * B * (l1.cout * N + 3 * N + M * K + 3 * M + l3.cout * M))

@@ -121,13 +121,21 @@ int captra_ball_query_multi(int b, int n, int m, int nr, const float *radius, co
                             const float *new_xyz, const float *xyz, int *const *idx,
                             captra_stream_t stream);
 
-/* PACKED WEIGHTS.  The shared-MLP kernels take a layer's weights as W^T (cin rows, cout columns) with
- * BatchNorm folded in, zero-padded to (ceil32(cin), ceil128(cout)) row-major, and the bias zero-padded
- * to ceil128(cout), so that every tile they stage is in bounds and needs no predicate.
- * captra_pack_weights builds that image on device from dense wt (cin,cout) / bias (cout);
- * wt_packed has ceil32(cin)*ceil128(cout) floats, bias_packed ceil128(cout). */
+/* PACKED WEIGHTS.  The shared-MLP kernels take a layer's weights W^T (cin rows, cout columns; BatchNorm folded in) as ONE
+ * buffer of captra_packed_weight_floats(cin, cout) floats holding two images of the same numbers:
+ *   [0, KP*CP)   row-major, zero-padded to KP = ceil32(cin) rows x CP = ceil128(cout) columns: every tile a kernel stages is
+ *                in bounds and needs no predicate;
+ *   [KP*CP, ..)  MFMA-FRAGMENT order for the kernels that stream weights straight into matrix-operand registers: with
+ *                KQ = ceil(ceil(cin/2)/4), NT = ceil(cout/32), element ((t*KQ + q)*64 + lane)*4 + i =
+ *                W^T[2(4q+i) + (lane>>5)][32t + (lane&31)] (zero beyond cin / cout): one 16-byte load per lane = the A
+ *                operands (v_mfma_f32_32x32x2_f32) of four consecutive k-steps of output tile t.  (One dword load per
+ *                MFMA kept a CU's vector-memory address unit as busy as its matrix pipes: DESIGN.md section 3.2.)
+ * and the bias zero-padded to ceil128(cout).  captra_pack_weights builds both images on device from dense wt (cin,cout) /
+ * bias (cout); captra_pack_weights_frag (re)builds the fragment image of a buffer whose row-major image is in place. */
+long long captra_packed_weight_floats(int cin, int cout);
 int captra_pack_weights(int cin, int cout, const float *wt, const float *bias, float *wt_packed,
                         float *bias_packed, captra_stream_t stream);
+int captra_pack_weights_frag(int cin, int cout, float *wt_packed, captra_stream_t stream);
 
 /* One shared-MLP layer, y = act(W x + bias), as an exact-fp32 MFMA GEMM over positions
  * (Conv2d/Conv1d 1x1 + folded BatchNorm + ReLU, pointnet_utils.py:242-245, 296-298).
@@ -240,20 +248,12 @@ int captra_sa_scale_pre(int b, int n, int m, int k, int cfeat, int c1, int c2, i
 /* The same scale on the pipelined kernel (csrc/sa_pipe.hip: persistent one-wave-per-SIMD workgroups, next tile's gather
  * under the current tile's MFMAs, deferred epilogues, weight sets two ahead, staged output rows): v1pm is the POINT-major
  * (B,N,c1) result of captra_pointwise_mlp_pm.  Same k-ascending chains: bit-identical to captra_sa_scale_pre /
- * captra_sa_scale_fused.  w1 is the PACKED first layer (its relative-xyz rows are used), w2 / w3 are the FRAGMENT-ordered
- * images of layers 2 / 3 (captra_pack_weights_frag), b2 / b3 their packed biases.  -2 when the shape is not instantiated or
- * m*k is not a multiple of 128 (take captra_sa_scale_pre). */
+ * captra_sa_scale_fused.  w1, w2, w3 PACKED (both images, see PACKED WEIGHTS): the kernel streams the fragment images of
+ * layers 2 / 3.  -2 when the shape is not instantiated or m*k is not a multiple of 128 (take captra_sa_scale_pre). */
 int captra_sa_scale_pre_pm(int b, int n, int m, int k, int cfeat, int c1, int c2, int c3, const float *v1pm,
                            const float *xyz_cn, const float *new_xyz, const int *idx, const float *w1, const float *w2,
                            const float *b2, const float *w3, const float *b3, float *out, int out_ctotal, int co_off,
                            captra_stream_t stream);
-
-/* MFMA-fragment order of a packed layer for kernels that stream weights with 16-byte loads (csrc/sa_pipe.hip): with
- * KQ = ceil(ceil(cin/2)/4) and NT = ceil(cout/32), element ((t*KQ + q)*64 + lane)*4 + i of wfrag (NT*KQ*256 floats =
- * captra_pack_weights_frag_floats) = W'^T[2(4q+i) + (lane>>5)][32t + (lane&31)] of the packed image (zero beyond cin): one
- * 16-byte load per lane = the A operands of four consecutive k-steps of output tile t. */
-long long captra_pack_weights_frag_floats(int cin, int cout);
-int captra_pack_weights_frag(int cin, int cout, const float *wt_packed, float *wfrag, captra_stream_t stream);
 
 /* captra_pointwise_mlp with a POINT-major result y (B,l,cout) (cout % 4 == 0, y 16-byte aligned; -2 otherwise or when the
  * layer is outside the direct-operand kernel's 32-bit offset range). */
