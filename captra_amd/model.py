@@ -91,6 +91,10 @@ class EvalTrackModel(BaseModel):
         # write (rank 0 writes the pickles of every rank's trajectories).  Both None = the single-process behaviour.
         self.frame_hook = None
         self.result_sink = None
+        # nocs_otf at batch >= 32 as two lanes half a frame apart (_forward_otf_lanes).  Opt-in (cfg['otf_lanes']): bit-identical
+        # results, 10.5 -> 9.3-9.8 ms per 32-trajectory step when the lanes' streams land on separate hardware queues
+        # (GPU_MAX_HW_QUEUES=8), 12 ms when they do not -- see DESIGN.md section 5
+        self.otf_lanes = bool(cfg.get("otf_lanes", False))
         self._graph = None
         self._graph_key = None
 
@@ -115,6 +119,10 @@ class EvalTrackModel(BaseModel):
         if pre is not None:      # nocs_otf: the frame's depth image and instance mask live on the device
             out["pre_fetched"] = {"depth": torch.as_tensor(pre["depth"]).to(self.device).int(),
                                   "mask": torch.as_tensor(pre["mask"]).to(self.device).bool()}
+            # the re-crop derives ground-truth NOCS from the root part's ground-truth pose: keep it on the host (float64,
+            # the values of the float32 device copy), so that the loop does not fetch it back from the device every frame
+            root = frame["meta"]["nocs2camera"][self.root]
+            out["gt_root_host"] = {k: np.asarray(torch.as_tensor(root[k]).float().double().cpu().numpy()) for k in ("rotation", "translation", "scale")}
         return out
 
     def _convert_npcs_frame(self, frame):
@@ -190,10 +198,13 @@ class EvalTrackModel(BaseModel):
             return None
         npcs_input["_canon"], npcs_input["_geom"] = cam, geom
         main = torch.cuda.current_stream(cam[0].device)
-        if getattr(self, "_side", None) is None:
-            self._side = torch.cuda.Stream(device=cam[0].device)
-        self._side.wait_stream(main)
-        with torch.cuda.stream(self._side):
+        # one side stream per calling stream: two lanes of trajectories (forward's nocs_otf lanes) must not meet in one
+        sides = self.__dict__.setdefault("_side_streams", {})
+        side = sides.get(main.cuda_stream)
+        if side is None:
+            side = sides[main.cuda_stream] = torch.cuda.Stream(device=cam[0].device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
             if P == 1 and self.share_geometry:            # one part: RotationNet's cloud IS CoordinateNet's
                 raw = self.net.regress_net.raw_point_rtvec(cam[0], cam_n3=cam[1], geom=geom)
             else:                                         # every part's cloud canonicalised with that part's previous pose
@@ -202,7 +213,7 @@ class EvalTrackModel(BaseModel):
                 raw = self.net.regress_net.raw_point_rtvec(rcam[0], cam_n3=rcam[1])
 
         def join():
-            main.wait_stream(self._side)
+            main.wait_stream(side)
             raw.record_stream(main)
             input["_raw"] = raw
         return join
@@ -239,26 +250,122 @@ class EvalTrackModel(BaseModel):
             self._graph.set_pose(pose)
         return self._graph
 
-    def _recrop(self, i, input, last_pose):
-        """nocs_otf (reference model.py:425-452): re-crop frame i around the pose predicted for frame i-1 -- on the device
-        (captra_amd/nocs_otf.py).  The frame must carry its depth image and instance mask (meta['pre_fetched'])."""
-        from .nocs_otf import full_data_batch
+    def _recrop_slice(self, i, input, last_pose, sl):
+        """nocs_otf (reference model.py:425-452) for the trajectories `sl` of frame i: re-crop around the pose predicted for
+        frame i-1 -- on the device (captra_amd/nocs_otf.py: one crop launch + one ragged sampling launch).  `last_pose` holds
+        those trajectories only.  -> (points (b,3,N) mean-subtracted, labels (b,N), nocs (b,3,N)).  Two host round trips on
+        the CURRENT stream: the predicted centre / scale, and the crops' member counts."""
+        from .nocs_otf import full_data_batch, to_host
         pre = input.get("pre_fetched")
         if pre is None:
             raise ValueError("nocs_otf=True needs the frame's depth and mask tensors (meta['pre_fetched']): reading depth.png / "
                              "mask.png from disk (cv2) is outside this build")
         npcs = self.npcs_feed_dict[i]
-        B, _, N = input["points"].shape
-        from .nocs_otf import to_host
-        centers = to_host(last_pose["translation"][:, self.root].reshape(B, 3).double())
-        scales = to_host(last_pose["scale"][:, self.root].reshape(B).double())
-        gt = {k: to_host(v[:, self.root].double().contiguous()) for k, v in input["gt_part"].items()}
-        full = full_data_batch([(pre["depth"][b], pre["mask"][b], centers[b], self.radius * float(scales[b]),
-                                 {k: gt[k][b] for k in gt}) for b in range(B)], N, stacked=True)   # one crop + one sampling launch
-        input["points"] = (full["points"].float() - npcs["points_mean"].reshape(B, 1, 3)).transpose(1, 2).contiguous()
-        input["labels"] = full["labels"].contiguous()
+        N = input["points"].shape[2]
+        b = last_pose["scale"].shape[0]
+        cs = to_host(torch.cat([last_pose["translation"][:, self.root].reshape(b, 3), last_pose["scale"][:, self.root].reshape(b, 1)], dim=1).double())
+        gt = input.get("gt_root_host")
+        if gt is None:
+            gt = {k: to_host(v[:, self.root].double().contiguous()) for k, v in input["gt_part"].items()}
+        gt = {k: v[sl] for k, v in gt.items()}
+        depth, mask = pre["depth"][sl], pre["mask"][sl]
+        full = full_data_batch([(depth[j], mask[j], cs[j, :3], self.radius * float(cs[j, 3]), {k: gt[k][j] for k in gt})
+                                for j in range(b)], N, stacked=True)
+        points = (full["points"].float() - npcs["points_mean"][sl].reshape(b, 1, 3)).transpose(1, 2).contiguous()
+        return points, full["labels"].contiguous(), full["nocs"].float().transpose(1, 2).contiguous()
+
+    def _recrop(self, i, input, last_pose):
+        """The whole batch of frame i re-cropped in place (input / npcs feed dicts)."""
+        npcs = self.npcs_feed_dict[i]
+        input["points"], input["labels"], npcs["nocs"] = self._recrop_slice(i, input, last_pose, slice(None))
         npcs["points"], npcs["labels"] = input["points"], input["labels"]
-        npcs["nocs"] = full["nocs"].float().transpose(1, 2).contiguous()
+
+    # ---- nocs_otf at batch >= 32: two lanes of trajectories, half a frame apart ------------------------------------------
+    def _otf_lanes_usable(self, input) -> bool:
+        """The re-crop's sampler (<= 20480 -> 4096 points: 4095 dependent rounds, ONE workgroup per trajectory) leaves
+        240 of the 256 CUs idle for 2.8 ms of a 10.8 ms step.  With the batch split into two lanes on two streams, started
+        half a cycle apart, one lane samples while the other runs its networks.  The host stays single-threaded: it serves
+        lane 0's frame i+1 as soon as lane 0's pose i is back (lane 1's frame i is executing meanwhile), then lane 1's."""
+        B = input["points"].shape[0]
+        return (self.nocs_otf and input["points"].is_cuda and not self.training and B >= 32 and B % 2 == 0
+                and not (self.track_cfg["gt_label"] or self.track_cfg["nocs2d_label"]))
+
+    def _forward_otf_lanes(self, pose0, frame_nums):
+        from .graph import TrackStepGraph
+        feed = self.feed_dict
+        B = feed[1]["points"].shape[0]
+        half = B // 2
+        slices = [slice(0, half), slice(half, B)]
+        dev = feed[1]["points"].device
+        cur = torch.cuda.current_stream(dev)
+        if getattr(self, "_otf_streams", None) is None:
+            self._otf_streams = [torch.cuda.Stream(device=dev) for _ in slices]
+        streams = self._otf_streams
+        use_graph = self._graph_usable(feed[1])
+        graphs = None
+        if use_graph:
+            key = ("otf", tuple(feed[1]["points"].shape), str(dev))
+            if self._graph is None or self._graph_key != key or any(g.stale() for g in self._graph):
+                self._graph = [TrackStepGraph(self, feed[1]["points"][s].contiguous(), feed[1]["points_mean"][s].contiguous(),
+                                              {k: v[s].contiguous() for k, v in pose0.items()}) for s in slices]
+                self._graph_key = key
+            graphs = self._graph
+        lane_pose = [{k: v[s].clone() for k, v in pose0.items()} for s in slices]
+        for st in streams:
+            st.wait_stream(cur)
+        pred_poses, npcs_pred = [pose0], [None]
+        sampled = None      # recorded on a lane's stream when its re-crop (crop + sampling launch) of the current frame is enqueued
+        for i in range(1, len(feed)):
+            input, npcs_in = feed[i], self.npcs_feed_dict[i]
+            frame_nums.append([p.split(".")[-2].split("/")[-1] for p in input["meta"]["path"]])
+            consume_noise_draws(feed[i - 1]["gt_part"], self.pose_perturb_cfg)
+            parts, done = [], []
+            for l, s in enumerate(slices):
+                if sampled is not None:
+                    # the other lane's sampling of ITS current frame is over before this lane starts to sample: the two
+                    # samplers never share the chip (each runs under the other lane's networks), whatever phase the lanes
+                    # would drift into by themselves.  The host has nothing else to do meanwhile.
+                    sampled.synchronize()
+                with torch.cuda.stream(streams[l]):
+                    pts, labels, nocs = self._recrop_slice(i, input, lane_pose[l], s)
+                    sampled = torch.cuda.Event()
+                    sampled.record(streams[l])
+                    mean = input["points_mean"][s]
+                    if graphs is not None:
+                        out = graphs[l].replay(pts, mean, lane_pose[l])
+                        pose = {k: v.clone() for k, v in out.items()}
+                        cur_npcs = {k: v.clone() for k, v in graphs[l].npcs_pred.items() if torch.is_tensor(v)}
+                    else:
+                        lin = {"points": pts, "points_mean": mean, "meta": {}, "labels": labels}
+                        lnp = {"points": pts, "points_mean": mean, "labels": labels}
+                        cur_npcs, pose = self.track_step(lin, lnp, lane_pose[l])
+                        cur_npcs = {k: v for k, v in cur_npcs.items() if torch.is_tensor(v)}
+                    lane_pose[l] = pose
+                    ev = torch.cuda.Event()
+                    ev.record(streams[l])
+                parts.append((pts, labels, nocs, pose, cur_npcs))
+                done.append(ev)
+            # the frame's batch-wide tensors, assembled on the caller's stream (GPU-side waits: the lanes do not stop)
+            for ev in done:
+                cur.wait_event(ev)
+            for part in parts:
+                for x in part[:3]:
+                    x.record_stream(cur)
+                for d in part[3:]:
+                    for v in d.values():
+                        v.record_stream(cur)
+            input["points"] = torch.cat([p[0] for p in parts])
+            input["labels"] = torch.cat([p[1] for p in parts])
+            npcs_in["nocs"] = torch.cat([p[2] for p in parts])
+            npcs_in["points"], npcs_in["labels"] = input["points"], input["labels"]
+            pose = {k: torch.cat([p[3][k] for p in parts]) for k in parts[0][3]}
+            npcs_pred.append({k: torch.cat([p[4][k] for p in parts]) for k in parts[0][4]})
+            pred_poses.append(pose)
+            if self.frame_hook is not None:
+                self.frame_hook(i, pose)
+        for st in streams:
+            cur.wait_stream(st)
+        return pred_poses, npcs_pred
 
     def forward(self, save=False):
         pred_poses = [self._initial_pose()]
@@ -268,6 +375,14 @@ class EvalTrackModel(BaseModel):
         frame_nums = []
         self.timer.tick()
         lanes = None
+        if len(self.feed_dict) > 1 and self._otf_lanes_usable(self.feed_dict[1]) and self.otf_lanes:
+            frame_nums.append([p.split(".")[-2].split("/")[-1] for p in self.feed_dict[0]["meta"]["path"]])
+            with torch.no_grad():
+                pred_poses, npcs_pred = self._forward_otf_lanes(pred_poses[0], frame_nums)
+            self.pred_dict = {"poses": pred_poses, "npcs_pred": npcs_pred}
+            if save:
+                self._save(frame_nums)
+            return
         with torch.no_grad():
             if len(self.feed_dict) > 1 and self._lanes_usable(self.feed_dict[1]):
                 lanes = self._lanes_for(self.feed_dict[1], pred_poses[0])

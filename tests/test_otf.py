@@ -78,6 +78,54 @@ def test_track_loop_with_on_the_fly_crop(device):
     np.testing.assert_allclose(got.cpu().numpy(), ref["points"].cpu().numpy(), atol=2e-7)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("hipgraph", [False, True])
+def test_track_loop_otf_lanes_equal_single_batch(device, hipgraph):
+    """nocs_otf at 32 trajectories: the two lanes half a frame apart (EvalTrackModel._forward_otf_lanes: one lane re-crops and
+    samples while the other runs its networks) give the SAME poses, CoordinateNet maps and re-cropped clouds as the whole
+    batch processed in one piece -- bit for bit, eager and with captured steps; the loss dict (IoUs included) agrees."""
+    from captra_amd.configs import make_config
+    from captra_amd.trainer import Trainer
+    from tests import clouds
+    from tests.weights import make_physical_state_dict
+    B, T = 32, 4
+    cfg = make_config("1", experiment_dir="/tmp/captra_otf_lanes_test", nocs_otf=True, hipgraph=hipgraph, **{"init_frame/gt": True})
+    cfg["device"] = device
+    trainer = Trainer(cfg)
+    trainer.model.load_state_dict(make_physical_state_dict({k: tuple(v.shape) for k, v in trainer.model.state_dict().items()}, 7, 1, True, "nocs"))
+    trainer.model.use_graph = hipgraph
+    frames = clouds.make_trajectory("nocs", B, T, seed=2)
+    views = [make_frame(1 + b % 3) for b in range(B)]            # three different synthetic depth frames over the batch
+    for f in frames:
+        f["meta"]["pre_fetched"] = {"depth": torch.from_numpy(np.stack([v[0].astype(np.int32) for v in views])),
+                                    "mask": torch.from_numpy(np.stack([v[1] for v in views]))}
+        for p in f["meta"]["nocs2camera"]:
+            p["rotation"] = torch.from_numpy(np.stack([v[3]["rotation"] for v in views])).float()
+            p["translation"] = torch.from_numpy(np.stack([v[3]["translation"] for v in views])).float()
+            p["scale"] = torch.tensor([float(v[3]["scale"]) for v in views])
+    runs = []
+    for lanes in (False, True):
+        trainer.model.otf_lanes = lanes
+        np.random.seed(5)
+        torch.manual_seed(5)
+        pred, loss = trainer.test(frames, save=False, no_eval=False)
+        runs.append(([{k: v.cpu().numpy() for k, v in p.items()} for p in pred["poses"]],
+                     [None if n is None else {k: v.cpu().numpy() for k, v in n.items()} for n in pred["npcs_pred"]],
+                     [trainer.model.feed_dict[i]["points"].cpu().numpy() for i in range(1, T)], loss))
+    (p0, n0, c0, l0), (p1, n1, c1, l1) = runs
+    for i in range(T):
+        for k in p0[i]:
+            np.testing.assert_array_equal(p0[i][k], p1[i][k], err_msg=f"frame {i} {k}")
+        if n0[i] is not None:
+            for k in n1[i]:
+                np.testing.assert_array_equal(n0[i][k], n1[i][k], err_msg=f"frame {i} npcs {k}")
+    for a, b in zip(c0, c1):
+        np.testing.assert_array_equal(a, b)
+    for k, v in l0["avg_pred"].items():
+        assert abs(float(v) - float(l1["avg_pred"][k])) < 1e-6
+    assert min(float(p["scale"].min()) for p in p1) > 0.05
+
+
 def _items(device, cases):
     items = []
     for tag, seed, radius, n in cases:

@@ -68,19 +68,20 @@ def main():
         print(f"  kernel {name:10s} {ms / max(n, 1):7.3f} ms per launch ({n} launches; HIP events on the launch stream)")
 
 
-def track_loop(batch: int, frames: int = 6):
+def track_loop(batch: int, frames: int = 12, configs=((False, False), (True, False), (True, True))):
     """The whole tracking loop with nocs_otf on (EvalTrackModel.forward: re-crop + hipGraph step per frame) vs off."""
     from captra_amd.configs import make_config
     from captra_amd.trainer import Trainer
     from tests import clouds
     from tests.weights import make_state_dict
     dev = torch.device("cuda:0")
-    for otf in (False, True):
+    for otf, lanes in configs:
         cfg = make_config("1", experiment_dir="/tmp/captra_otf_bench", nocs_otf=otf, **{"init_frame/gt": True})
         cfg["device"] = dev
         trainer = Trainer(cfg)
         trainer.model.load_state_dict(make_state_dict({k: tuple(v.shape) for k, v in trainer.model.state_dict().items()}, seed=7))
         trainer.model.use_graph = True
+        trainer.model.otf_lanes = bool(lanes)
         data = clouds.make_trajectory("nocs", batch, frames, seed=0)
         depth, mask, center, pose = make_frame(1)
         for f in data:
@@ -101,7 +102,7 @@ def track_loop(batch: int, frames: int = 6):
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / (frames - 1)
             best = dt if best is None or dt < best else best
-        print(f"EvalTrackModel loop, nocs_otf={otf}: {best * 1e3:7.2f} ms per step of {batch} trajectories = {batch / best:7.0f} frames/s", flush=True)
+        print(f"EvalTrackModel loop, nocs_otf={otf}{', two lanes half a frame apart' if lanes else ''}: {best * 1e3:7.2f} ms per step of {batch} trajectories = {batch / best:7.0f} frames/s", flush=True)
 
 
 if __name__ == "__main__":
