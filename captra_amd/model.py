@@ -198,11 +198,9 @@ class EvalTrackModel(BaseModel):
             return None
         npcs_input["_canon"], npcs_input["_geom"] = cam, geom
         main = torch.cuda.current_stream(cam[0].device)
-        # one side stream per calling stream: two lanes of trajectories (forward's nocs_otf lanes) must not meet in one
-        sides = self.__dict__.setdefault("_side_streams", {})
-        side = sides.get(main.cuda_stream)
-        if side is None:
-            side = sides[main.cuda_stream] = torch.cuda.Stream(device=cam[0].device)
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=cam[0].device)
+        side = self._side
         side.wait_stream(main)
         with torch.cuda.stream(side):
             if P == 1 and self.share_geometry:            # one part: RotationNet's cloud IS CoordinateNet's
