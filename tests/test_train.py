@@ -15,6 +15,7 @@ from tests.golden.make_golden_train import CASES, TORCH_SEED
 from tests.weights import make_state_dict
 
 G = np.load(Path(__file__).resolve().parent / "golden" / "g12_train.npz")
+G64 = np.load(Path(__file__).resolve().parent / "golden" / "g12_train64.npz")   # the same step, reference run in float64
 
 
 def _trainer(tag, device):
@@ -55,6 +56,24 @@ def test_losses_from_reference_outputs_cpu(tag):
         np.testing.assert_allclose(float(model.loss_dict[k]), float(G[f"{tag}/loss/{k}"]), rtol=2e-5, atol=1e-6, err_msg=k)
 
 
+@pytest.mark.parametrize("tag", [c[0] for c in CASES])
+def test_reference_fp32_gradient_noise_floor_cpu(tag):
+    """The two reference runs of the same step (fp32, G12; float64, G12-64) against each other: losses agree to 5e-5, the
+    head gradients to 1e-3, while the backbone gradients of the fp32 run sit 0.3-1.7 % off the float64 ones — the noise
+    floor the GPU gradient test is written against."""
+    for k in _loss_keys(tag):
+        if "loss" in k:
+            assert abs(float(G[f"{tag}/loss/{k}"]) - float(G64[f"{tag}/loss/{k}"])) < 5e-5, k
+    errs = {}
+    for k in G64.files:
+        if k.startswith(f"{tag}/grad/"):
+            errs[k.split("/", 2)[2]] = np.abs(G[k] - G64[k]).max() / np.abs(G64[k]).max()
+    heads = [v for n, v in errs.items() if "_head." in n or ".pose_pred." in n]
+    body = [v for n, v in errs.items() if not ("_head." in n or ".pose_pred." in n)]
+    assert heads and max(heads) < 1e-3
+    assert 3e-3 < max(body) < 2e-2, errs
+
+
 def test_trainer_schedules_cpu():
     """step_epoch: StepLR halves the rate every lr_step_size epochs down to lr_clip, BatchNorm momentum follows its own
     decay (reference trainer.py:125-145); save / resume round-trips the optimiser state."""
@@ -76,8 +95,11 @@ def test_trainer_schedules_cpu():
 def test_update_step_vs_reference_gpu(device, tag):
     """One `Trainer.update` on the GPU against the reference's on its CPU path: losses, predicted part poses, gradient
     norm, the gradients of parameters spread from the first SA layer to the heads, the parameters after the Adam step and
-    a BatchNorm running mean.  Tolerances: fp32 training-mode forward / backward with different reduction orders (the
-    reference sums on 8 CPU threads) — 2e-4 relative on losses, 2 % of a gradient tensor's largest entry."""
+    a BatchNorm running mean.  Tolerances: 2e-4 relative on losses.  Gradients are judged against the reference's backward
+    run in FLOAT64 (G12-64, make_golden_train64.py): the head probes to 1e-3 of the tensor's largest entry; the backbone
+    probes — where fp32 itself is 0.3-1.7 % away from the float64 gradient, as the reference's OWN fp32 run recorded in G12
+    shows — to 4x the error of that fp32 reference run (never more than 2 %), i.e. the GPU backward is held to the fp32
+    noise floor of this gradient, measured, not assumed."""
     trainer, data = _trainer(tag, device)
     model = trainer.model
     torch.manual_seed(TORCH_SEED)
@@ -101,6 +123,7 @@ def test_update_step_vs_reference_gpu(device, tag):
     params = dict(model.named_parameters())
     gn = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in params.values() if p.grad is not None)))
     np.testing.assert_allclose(gn, float(G[f"{tag}/grad_norm"]), rtol=2e-3)
+    np.testing.assert_allclose(gn, float(G64[f"{tag}/grad_norm"]), rtol=2e-3)
     lr = float(G[f"{tag}/meta"][0])
     probes = [k.split("/", 2)[2] for k in G.files if k.startswith(f"{tag}/grad/")]
     assert len(probes) >= 6
@@ -108,6 +131,11 @@ def test_update_step_vs_reference_gpu(device, tag):
         ref = G[f"{tag}/grad/{n}"]
         got = params[n].grad.cpu().numpy()
         assert np.abs(got - ref).max() <= 0.02 * np.abs(ref).max() + 1e-7, (n, np.abs(got - ref).max(), np.abs(ref).max())
+        ref64 = G64[f"{tag}/grad/{n}"]
+        top = np.abs(ref64).max()
+        err_gpu, err_ref32 = np.abs(got - ref64).max() / top, np.abs(ref - ref64).max() / top
+        bound = 1e-3 if ("_head." in n or ".pose_pred." in n) else min(max(1e-3, 4.0 * err_ref32), 0.02)
+        assert err_gpu <= bound, (n, "gpu vs float64", err_gpu, "reference fp32 vs float64", err_ref32)
         # Adam's first step moves every weight by lr * sign-like(g): compare the step where the gradient is not ~0
         step_ref = G[f"{tag}/param/{n}"] - before[n].cpu().numpy()
         step_got = params[n].detach().cpu().numpy() - before[n].cpu().numpy()
