@@ -44,6 +44,10 @@ struct CaptraDeviceOnce {
 // another thread (another GPU's stream in the same process) launches; the reference boundary has no global state.
 #define CAPTRA_KNOB thread_local
 
+// ---- work tickets of the persistent kernels (work_pool.hip) ---------------------------------------
+// a {next ticket, workgroups done} slot for ONE launch on `stream`, or nullptr (static tile walk)
+unsigned *captra_work_slot(hipStream_t stream);
+
 // ---- device helpers ---------------------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 

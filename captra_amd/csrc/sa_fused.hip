@@ -327,6 +327,7 @@ struct SwParams {
     int out_ctotal, co_off;
     const float *v1;           // PRE kernels: (B,C1,N) = b1 + W1[feature rows] * feat per source point, else null
     unsigned long long *prof;  // debug: per-phase wave-cycle totals of a sample of waves (sa_wave_kernel), else null
+    unsigned *work;            // persistent kernels: {next ticket, workgroups done} of this launch (work_pool.hip), or null
 };
 
 #define SW_TICK(slot)                                                         \
@@ -650,7 +651,13 @@ __global__ __launch_bounds__(SL_WAVES * 64) __attribute__((amdgpu_waves_per_eu(4
         const float *cp = p.new_xyz + ((size_t)tb * p.m + (int)(wp / p.k)) * 3;
         ctr_o[0] = cp[0]; ctr_o[1] = cp[1]; ctr_o[2] = cp[2];
     };
+    // tiles: the first two are blockIdx.x and blockIdx.x + gridDim.x; further ones by ticket (p.work, see work_pool.hip)
+    // or, without a slot, the static walk.  The ticket for the tile after next is drawn one tile ahead and crosses the
+    // workgroup through LDS; two static tiles, so that the first draw — every workgroup of the launch hits the counter at
+    // the same moment, ~25 ns each — resolves under a tile's MFMA work instead of in front of it.
+    __shared__ long long next_tile[2];
     long long tile = blockIdx.x;
+    if (tid == 0) next_tile[0] = tile + gridDim.x;
     load_task(tile, id, ctr);
     sl_stage_weights<CIN1, C1>(wl1, p.w1, tid);
     sl_stage_weights<C1, C2>(wl2, p.w2, tid);
@@ -660,7 +667,12 @@ __global__ __launch_bounds__(SL_WAVES * 64) __attribute__((amdgpu_waves_per_eu(4
     for (int e = tid; e < pad32c(C3); e += SL_WAVES * 64) bias3[e] = p.b3[e];
     __syncthreads();
 
-    for (; tile < total; tile += gridDim.x) {
+    int par = 0;
+    for (; tile < total; par ^= 1) {
+        const long long next = next_tile[par];     // written before the last barrier passed
+        unsigned ticket = 0;                       // of the tile after next: drawn behind this tile's loads, parked in a
+                                                   // register while the layers run (an early LDS store would make wave 0
+                                                   // wait for the atomic's return before its first MFMA)
         const int b = (int)(tile / tiles_per_cloud);
         const long long pos0 = (tile % tiles_per_cloud) * SL_POS;
         const bool active = pos0 + wave * 32 < L;  // wave-uniform (L is a multiple of 32)
@@ -676,13 +688,16 @@ __global__ __launch_bounds__(SL_WAVES * 64) __attribute__((amdgpu_waves_per_eu(4
                 else if (row < CIN1) v = p.xyz_cn[((size_t)b * 3 + (row - CF)) * p.n + id] - (row - CF == 0 ? ctr[0] : (row - CF == 1 ? ctr[1] : ctr[2]));
                 x1[j] = v;
             }
-            load_task(tile + gridDim.x, id_n, ctr_n);
+            load_task(next, id_n, ctr_n);
+            if (tid == 0 && p.work != nullptr) ticket = atomicAdd(p.work, 1u);
             sl_layer<CIN1, C1, false>(wl1, bias1, x1, h1, red, wave, lane);
             sl_layer<C1, C2, false>(wl2, bias2, h1, h2, red, wave, lane);
             sl_layer<C2, C3, true>(wl3, bias3, h2, none, red, wave, lane);
         } else {
-            load_task(tile + gridDim.x, id_n, ctr_n);
+            load_task(next, id_n, ctr_n);
+            if (tid == 0 && p.work != nullptr) ticket = atomicAdd(p.work, 1u);
         }
+        if (tid == 0) next_tile[par ^ 1] = p.work != nullptr ? 2ll * gridDim.x + ticket : next + gridDim.x;
         __syncthreads();  // every wave's 32-position maxima are in red
         const int tiles_per_group = p.k / 32;
         const int groups = SL_POS / p.k;
@@ -697,6 +712,15 @@ __global__ __launch_bounds__(SL_WAVES * 64) __attribute__((amdgpu_waves_per_eu(4
         }
         __syncthreads();  // red is free for the next tile
         id = id_n; ctr[0] = ctr_n[0]; ctr[1] = ctr_n[1]; ctr[2] = ctr_n[2];
+        tile = next;
+    }
+    // the last workgroup to leave hands the slot back clean (the next launch using it is ordered after this one)
+    if (p.work != nullptr && tid == 0) {
+        __threadfence();
+        if (atomicAdd(p.work + 1, 1u) == gridDim.x - 1) {
+            atomicExch(p.work, 0u);
+            atomicExch(p.work + 1, 0u);
+        }
     }
 }
 
@@ -733,7 +757,7 @@ extern "C" int captra_sa_scale_fused(int b, int n, int m, int k, int cfeat, int 
         // PointNet2Msg config); any other shape takes the generic LDS kernel below
         SwParams q;
         q.b = b; q.n = n; q.m = m; q.k = k; q.feat = feat; q.xyz_cn = xyz_cn; q.new_xyz = new_xyz; q.idx = idx;
-        q.w1 = w1; q.b1 = b1; q.w2 = w2; q.b2 = b2; q.w3 = w3; q.b3 = b3; q.out = out; q.out_ctotal = out_ctotal; q.co_off = co_off; q.v1 = nullptr; q.prof = g_sa_prof;
+        q.w1 = w1; q.b1 = b1; q.w2 = w2; q.b2 = b2; q.w3 = w3; q.b3 = b3; q.out = out; q.out_ctotal = out_ctotal; q.co_off = co_off; q.v1 = nullptr; q.prof = g_sa_prof; q.work = nullptr;
         const long long Lw = (long long)m * k;
         dim3 gridw((unsigned)((Lw + SF_POS - 1) / SF_POS), b);
         // small-input scales: persistent workgroups with the weights resident in LDS (mode 2 = streaming kernel for all)
@@ -757,6 +781,7 @@ extern "C" int captra_sa_scale_fused(int b, int n, int m, int k, int cfeat, int 
         }                                                                                                              \
         const long long tiles = ((Lw + SL_POS - 1) / SL_POS) * b;                                                      \
         q.b = b;                                                                                                       \
+        q.work = tiles >= 6ll * resident ? captra_work_slot((hipStream_t)stream) : nullptr;                            \
         CAPTRA_LAUNCH("sa_scale_fused", kern, dim3((unsigned)(tiles < resident ? tiles : resident)), dim3(SL_WAVES * 64), lds_bytes, \
                       (hipStream_t)stream, q);                                                                         \
         return captra_last_error();                                                                                    \
@@ -820,7 +845,7 @@ extern "C" int captra_sa_scale_pre(int b, int n, int m, int k, int cfeat, int c1
     SwParams q;
     q.b = b; q.n = n; q.m = m; q.k = k; q.feat = nullptr; q.xyz_cn = xyz_cn; q.new_xyz = new_xyz; q.idx = idx;
     q.w1 = w1; q.b1 = b2 /* unused by the PRE kernels: any valid packed bias */; q.w2 = w2; q.b2 = b2; q.w3 = w3; q.b3 = b3;
-    q.out = out; q.out_ctotal = out_ctotal; q.co_off = co_off; q.v1 = v1; q.prof = g_sa_prof;
+    q.out = out; q.out_ctotal = out_ctotal; q.co_off = co_off; q.v1 = v1; q.prof = g_sa_prof; q.work = nullptr;
     const long long Lw = (long long)m * k;
     dim3 gridw((unsigned)((Lw + SF_POS - 1) / SF_POS), b);
 #define SWP_CASE(CF_, C1_, C2_, C3_)                                                                                       \

@@ -40,6 +40,7 @@ struct SpParams {
     int chunk;              // tiles per staged output chunk (1..SP_MAXCH), divides tiles_per_cloud
     long long chunks;       // B * tiles_per_cloud / chunk
     unsigned long long *prof;  // debug: per-phase wave-cycle totals of a sample of workgroups (captra_sa_fused_set_prof), or null
+    unsigned *work;            // {next ticket, workgroups done} of this launch (work_pool.hip), or null = static chunk walk
 };
 
 #define SP_TICK(slot)                                                           \
@@ -240,6 +241,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     constexpr int NT1 = S1::NT;
     static_assert(NT1 <= 4 && C1 % 32 == 0, "first-layer width");
     __shared__ __attribute__((aligned(16))) float bias_lds[2 * 256];       // packed b2, b3 (zero padded)
+    // chunks: the first is blockIdx.x, further ones by ticket (p.work, work_pool.hip) or the static walk.  A wave needs the
+    // NEXT chunk's id before its last tile of this chunk (it prefetches that chunk's first tile) and the waves only meet at
+    // the chunk barrier, so tickets are drawn TWO chunks ahead: next_chunk[par] was written before the last barrier.
+    __shared__ int next_chunk[2];
     // maxima of a CHUNK of tiles: [chunk parity][row][tile of the chunk][2 * wave + row-of-16].  The four waves of a
     // workgroup meet once per chunk, not once per tile (a per-tile barrier cost ~3 k cycles of waiting for the slowest
     // wave); two buffers, so the next chunk's first tile may write while this chunk is still being read out.
@@ -250,6 +255,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int groups = SP_POS / p.k, tiles_per_group = p.k / 32;            // centres per tile, waves per centre
     const int cpc = p.chunk * groups;                                        // centres per chunk
 
+    // (two static chunks first: the launch's first draw, all workgroups at once, resolves under the first chunk's work)
+    auto draw = [&](int after) { return p.work != nullptr ? (int)(2 * gridDim.x + atomicAdd(p.work, 1u)) : after + (int)gridDim.x; };
+    if (tid == 0) next_chunk[0] = (int)(blockIdx.x + gridDim.x);
     for (int e = tid; e < 2 * 256; e += 256) {
         const int c = e & 255;
         bias_lds[e] = e < 256 ? (c < pad128c(C2) ? p.b2[c] : 0.f) : (c < pad128c(C3) ? p.b3[c] : 0.f);
@@ -309,13 +317,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         id = load_id(tb, pos0);
         load_rest(tb, pos0, id, bt, g4);
     }
-    for (; chunk_id < nchunks; chunk_id += gridDim.x) {
+    while (chunk_id < nchunks) {
+        const int chunk_n = next_chunk[par];
+        // the ticket of the chunk after next (tickets past the end are simply not used): drawn now, stored to LDS only
+        // before this chunk's barrier, so that wave 0 does not wait for the atomic's return in front of its first tile
+        const int chunk_nn = tid == 0 ? draw(chunk_n) : 0;
         int cb, cpos0;
         tile_of(chunk_id, 0, cb, cpos0);
         for (int j = 0; j < p.chunk; ++j) {
             // ---- what comes after this tile (wave-uniform) ----
             const bool last_in_chunk = j + 1 == p.chunk;
-            const int nchunk = last_in_chunk ? chunk_id + (int)gridDim.x : chunk_id;
+            const int nchunk = last_in_chunk ? chunk_n : chunk_id;
             const bool has_next = nchunk < nchunks;
             int nb = 0, npos0 = 0;
             if (has_next) tile_of(nchunk, last_in_chunk ? 0 : j + 1, nb, npos0);
@@ -365,6 +377,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             SP_TICK(3)
             if (p.prof != nullptr && lane == 0 && sampled) atomicAdd(p.prof + 9, 1ull);
         }
+        if (tid == 0) next_chunk[par ^ 1] = chunk_nn;
         __syncthreads();                             // every wave's maxima of the chunk's tiles are in red[par]
         const int centre0 = cpos0 / p.k;             // first centre of the chunk (a chunk never straddles clouds)
         const float *rb = red + par * RED_BUF;
@@ -376,14 +389,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             p.out[((size_t)cb * p.out_ctotal + p.co_off + row) * p.m + centre0 + ci] = v;
         }
         par ^= 1;
+        chunk_id = chunk_n;
         SP_TICK(4)
         // (this buffer is written again two chunks from now, after the next chunk's barrier: every thread has left by then)
+    }
+    // the last workgroup to leave hands the slot back clean (the next launch using it is ordered after this one)
+    if (p.work != nullptr && tid == 0) {              // (thread 0 drew every ticket of this workgroup itself)
+        __threadfence();
+        if (atomicAdd(p.work + 1, 1u) == gridDim.x - 1) {
+            atomicExch(p.work, 0u);
+            atomicExch(p.work + 1, 0u);
+        }
     }
 }
 
 }  // namespace
 
 extern unsigned long long *captra_sa_prof_ptr();   // sa_fused.hip: the debug counters set by captra_sa_fused_set_prof
+
+// experiment knob (not part of the reference boundary): chunks per CU the ticketed launch aims for
+static CAPTRA_KNOB int g_sp_chunks_per_cu = 4;
+extern "C" void captra_sa_set_chunks_per_cu(int n) { g_sp_chunks_per_cu = n < 1 ? 1 : n; }
 
 // SA scale with a pre-transformed, POINT-major first layer (see include/captra_hip.h): v1pm (B,N,c1).
 // -2: shape not instantiated / not tileable (the caller takes captra_sa_scale_pre).
@@ -413,9 +439,18 @@ extern "C" int captra_sa_scale_pre_pm(int b, int n, int m, int k, int cfeat, int
     }
     // one workgroup (4 waves, one per SIMD) per CU; chunks of up to SP_MAXCH consecutive tiles as long as that still gives
     // every CU work (small batches keep single-tile chunks: latency first)
+    // With tickets (work_pool.hip) a chunk is also the unit of load balance between the CUs that actually run: aim for
+    // g_sp_chunks_per_cu chunks per CU then (the first two of a workgroup are static, so fewer than three rounds of chunks
+    // leave nothing to hand out: static walk).
     const long long tiles = (long long)b * q.tiles_per_cloud;
-    int ch = SP_MAXCH;
-    while (ch > 1 && (q.tiles_per_cloud % ch != 0 || tiles / ch < cus)) ch >>= 1;
+    auto chunk_for = [&](long long want) {
+        int c = SP_MAXCH;
+        while (c > 1 && (q.tiles_per_cloud % c != 0 || tiles / c < want)) c >>= 1;
+        return c;
+    };
+    int ch = chunk_for((long long)cus * g_sp_chunks_per_cu);
+    q.work = tiles / ch >= 3ll * cus ? captra_work_slot((hipStream_t)stream) : nullptr;
+    if (q.work == nullptr) ch = chunk_for(cus);
     q.chunk = ch;
     q.chunks = tiles / ch;
     const unsigned grid = (unsigned)(q.chunks < cus ? q.chunks : cus);

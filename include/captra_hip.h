@@ -342,7 +342,7 @@ int captra_prof_names(char *buf, int buflen);
 /* ---- 4. Experiment switches (NOT part of the stable ABI; used by tests/ and tools/ to cross-check variants that compute the
  *         same bits).  Each switch is THREAD-LOCAL: it affects launches made by the calling host thread only, so the
  *         operators above keep the reference boundary's "no global state" property for every other thread / GPU of the
- *         process.  Defaults (0 / 1 for captra_pw_set_direct) select the production kernels. ---- */
+ *         process.  Defaults (0; 1 for captra_pw_set_direct / captra_sa_set_dynamic_tiles; 4 chunks per CU) select the production kernels. ---- */
 void captra_fps_set_waves(int waves);       /* FPS: waves per cloud (0 = heuristic) */
 void captra_fps_set_pruned_min(int n);     /* FPS: clouds of >= n points take the pruned kernel (default 8192; 0 = never) */
 void captra_fps_set_stats(unsigned long long *dev_counters); /* pruned FPS: accumulate 6 counters {bucket updates, refreshes, cycles of 4 phases} (NULL = off) */
@@ -352,6 +352,8 @@ void captra_sa_fused_set_mode(int mode);    /* SA scale: 0 = register-resident k
 void captra_sa_fused_set_wn(int wn);        /* generic LDS kernel: sub-tile width 32*wn (0 = heuristic) */
 void captra_sa_fused_set_prof(unsigned long long *dev_counters); /* sa_wave_kernel: 10 device counters of phase timers, or NULL */
 void captra_pw_set_direct(int on);          /* dense layers: 1 = direct-operand kernel (default), 0 = LDS-staged kernel */
+void captra_sa_set_dynamic_tiles(int on);   /* persistent SA kernels: 1 = tiles handed out by ticket (default; work_pool.hip), 0 = static walk */
+void captra_sa_set_chunks_per_cu(int n);    /* sa_wave_pipe_kernel with tickets: chunks per CU the launch aims for (default 4) */
 
 #ifdef __cplusplus
 }

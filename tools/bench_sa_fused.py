@@ -29,10 +29,16 @@ def main():
     ap.add_argument("--zeros", action="store_true", help="all-zero features / weights: same instruction stream at lower power (DVFS probe)")
     ap.add_argument("--mode", type=int, default=0, help="0 = register-resident kernels where instantiated, 1 = generic LDS kernel")
     ap.add_argument("--phases", action="store_true", help="debug: in-kernel s_memtime phase breakdown of sa_wave_kernel")
+    ap.add_argument("--static-tiles", action="store_true", help="persistent kernels without work tickets (A/B)")
+    ap.add_argument("--chunks-per-cu", type=int, default=0)
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     import ctypes
     _lib.lib().captra_sa_fused_set_wn(ctypes.c_int(a.wn))
+    if a.static_tiles:
+        _lib.lib().captra_sa_set_dynamic_tiles(ctypes.c_int(0))
+    if a.chunks_per_cu:
+        _lib.lib().captra_sa_set_chunks_per_cu(ctypes.c_int(a.chunks_per_cu))
     B = a.clouds
     names = list(SHAPES) if a.which == "all" else [a.which]
     for name in names:
