@@ -327,6 +327,7 @@ def main():
                          "BASELINE.json configs[2]'s serving mix: rank r tracks NOCS category 1 + r mod 6 with that category's weights")
     ap.add_argument("--static-tiles", action="store_true", help=argparse.SUPPRESS)      # A/B: persistent SA kernels without tickets
     ap.add_argument("--chunks-per-cu", type=int, default=0, help=argparse.SUPPRESS)    # A/B: ticket granularity of the SA2 kernel
+    ap.add_argument("--no-pw-pair", action="store_true", help=argparse.SUPPRESS)       # A/B: dense layers without paired column tiles
     args = ap.parse_args()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
@@ -338,8 +339,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"bench.py --gpus {args.gpus} launched with WORLD_SIZE={world}: the launcher must start exactly --gpus ranks")
-    if args.static_tiles or args.chunks_per_cu:
+    if args.static_tiles or args.chunks_per_cu or args.no_pw_pair:
         from captra_amd import _lib as _knobs
+        if args.no_pw_pair:
+            _knobs.lib().captra_pw_set_pair(ctypes.c_int(0))
         if args.static_tiles:
             _knobs.lib().captra_sa_set_dynamic_tiles(ctypes.c_int(0))
         if args.chunks_per_cu:

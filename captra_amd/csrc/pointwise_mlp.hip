@@ -336,9 +336,14 @@ __device__ __forceinline__ float half_wave_sum(float v) {
     return v;
 }
 
-template <int TM, int TN, int WGM, int WGN, bool AFF = false, bool ST = false>
+// PAIR (TN == 2, L even): the wave's 64 columns are dealt to its two column tiles ALTERNATELY (tile tn holds columns
+//      pos0 + 2i + tn), so one 8-byte load per lane and k-step feeds both tiles' B operands and one 8-byte store writes
+//      both tiles' outputs of a row -- half the vector-memory instructions of the B side.  Which column a lane's
+//      accumulator stands for changes, the per-element k-ascending chain does not: same bits per output element.
+template <int TM, int TN, int WGM, int WGN, bool AFF = false, bool ST = false, bool PAIR = false>
 __global__ __launch_bounds__(256) void pw_direct_kernel(PwParams p) {
     static_assert(WGM * WGN == 4, "4 waves");
+    static_assert(!PAIR || TN == 2, "paired column tiles");
     constexpr int KS = AFF ? 4 : 8;  // k-steps per register set (shorter sets pay for the coefficient registers of AFF)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -366,10 +371,12 @@ __global__ __launch_bounds__(256) void pw_direct_kernel(PwParams p) {
         if (tile >= ntile) tile = ntile - 1;                    // rows beyond cout: any valid tile (their results are not stored)
         wvoff[tm] = tile * kq * 1024 + lane * 16;
     }
+    // column of this lane in column tile tn
+    auto col_of = [&](int tn) { return PAIR ? pos0 + 2 * (lane & 31) + tn : pos0 + tn * 32 + (lane & 31); };
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
-        long long col = pos0 + tn * 32 + (lane & 31);
-        if (col >= p.L) col = p.L - 1;
+        long long col = col_of(tn);
+        if (col >= p.L) col = PAIR ? p.L - 2 + tn : p.L - 1;   // (PAIR: L and the pair's first column are even)
         xvoff[tn] = (int)(((long long)(lane >> 5) * p.L + col) * 4);
     }
 
@@ -386,10 +393,12 @@ __global__ __launch_bounds__(256) void pw_direct_kernel(PwParams p) {
     }
 
     float a0[TM][KS], a1[TM][KS], b0[TN][KS], b1[TN][KS];
-    float2 g0[AFF ? KS : 1], g1[AFF ? KS : 1];  // GroupNorm coefficients (a, b) of the set's k rows
-    const __amdgpu_buffer_rsrc_t gsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)(AFF ? p.ab_in + (size_t)b * p.cin * 2 : p.wt), 0, AFF ? p.cin * 8 : 0, 0x00020000);
-    const int gvoff = (lane >> 5) * 8;
+    // GroupNorm coefficients (a, b) of the set's k rows: the two rows of a k-step are wave-uniform, so they come through
+    // the scalar cache (one s_load per row pair) and the lane half picks its row with a select -- no vector-memory
+    // instruction, which is what the direct-operand kernels run out of first
+    float4 g0[AFF ? KS : 1], g1[AFF ? KS : 1];
+    const float2 *__restrict__ gab = reinterpret_cast<const float2 *>(AFF ? p.ab_in + (size_t)b * p.cin * 2 : p.wt);
+    const bool upper = (lane >> 5) != 0;
     const int nsets = (p.cin + 2 * KS - 1) / (2 * KS);
 #define PW_LOAD_SET(A, Bv, G, si)                                                                                        \
     _Pragma("unroll") for (int jq = 0; jq < KS / 4; ++jq)                                                               \
@@ -398,18 +407,29 @@ __global__ __launch_bounds__(256) void pw_direct_kernel(PwParams p) {
             A[tm][4 * jq + 0] = w4.x; A[tm][4 * jq + 1] = w4.y; A[tm][4 * jq + 2] = w4.z; A[tm][4 * jq + 3] = w4.w;       \
         }                                                                                                                \
     _Pragma("unroll") for (int j = 0; j < KS; ++j) {                                                                    \
-        _Pragma("unroll") for (int tn = 0; tn < TN; ++tn) Bv[tn][j] = __builtin_bit_cast(                                \
-            float, __builtin_amdgcn_raw_buffer_load_b32(xsrc, xvoff[tn] + ((si) * KS + j) * xstep, 0, 0));               \
-        if (AFF) G[j] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(gsrc, gvoff + ((si) * KS + j) * 16, 0, 0)); \
+        if (PAIR) {                                                                                                      \
+            const float2 x2 = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(xsrc, xvoff[0] + ((si) * KS + j) * xstep, 0, 0)); \
+            Bv[0][j] = x2.x; Bv[TN - 1][j] = x2.y;                                                                       \
+        } else {                                                                                                         \
+            _Pragma("unroll") for (int tn = 0; tn < TN; ++tn) Bv[tn][j] = __builtin_bit_cast(                            \
+                float, __builtin_amdgcn_raw_buffer_load_b32(xsrc, xvoff[tn] + ((si) * KS + j) * xstep, 0, 0));           \
+        }                                                                                                                \
+        if (AFF) {                                                                                                       \
+            const int r0 = 2 * ((si) * KS + j);                                                                          \
+            const float2 lo = gab[r0 < p.cin ? r0 : p.cin - 1], hi = gab[r0 + 1 < p.cin ? r0 + 1 : p.cin - 1];           \
+            G[j] = make_float4(lo.x, lo.y, hi.x, hi.y);                                                                  \
+        }                                                                                                                \
     }                                                                                                                    \
     __builtin_amdgcn_sched_barrier(0);
 #define PW_MFMA_SET(A, Bv, G)                                                                                            \
     if (AFF) {                                                                                                           \
-        _Pragma("unroll") for (int j = 0; j < KS; ++j)                                                                  \
+        _Pragma("unroll") for (int j = 0; j < KS; ++j) {                                                                \
+            const float ga = upper ? G[j].z : G[j].x, gb = upper ? G[j].w : G[j].y;                                      \
             _Pragma("unroll") for (int tn = 0; tn < TN; ++tn) {                                                         \
-                const float t = __builtin_fmaf(G[j].x, Bv[tn][j], G[j].y);                                               \
+                const float t = __builtin_fmaf(ga, Bv[tn][j], gb);                                                       \
                 Bv[tn][j] = t > 0.f ? t : 0.f;                                                                           \
             }                                                                                                            \
+        }                                                                                                                \
     }                                                                                                                    \
     _Pragma("unroll") for (int j = 0; j < KS; ++j)                                                                      \
         _Pragma("unroll") for (int tm = 0; tm < TM; ++tm)                                                               \
@@ -430,9 +450,24 @@ __global__ __launch_bounds__(256) void pw_direct_kernel(PwParams p) {
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
         const int row0 = co0 + tm * 32 + 4 * (lane >> 5);
+        if (PAIR && !p.y_pm) {
+            // both column tiles' outputs of a row are neighbours: one 8-byte store (col even, L even: aligned)
+            const long long col = col_of(0);
+            if (col < p.L) {
+                float *yp = p.y + ((size_t)b * p.cout + row0) * p.L + col;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ro = (r & 3) + 8 * (r >> 2);
+                    if (row0 + ro < p.cout)
+                        *reinterpret_cast<float2 *>(yp + (size_t)ro * p.L) =
+                            make_float2(apply_act(acc[tm][0][r], p.act), apply_act(acc[tm][TN - 1][r], p.act));
+                }
+            }
+            continue;
+        }
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
-            const long long col = pos0 + tn * 32 + (lane & 31);
+            const long long col = col_of(tn);
             if (col < p.L && p.y_pm) {
                 // point-major output: registers 4q..4q+3 are four consecutive channels of this lane's position
                 float *yp = p.y + ((size_t)b * p.L + col) * p.cout + row0;
@@ -463,7 +498,7 @@ __global__ __launch_bounds__(256) void pw_direct_kernel(PwParams p) {
                 float sm = 0.f, sq = 0.f;
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn) {
-                    const float v = (pos0 + tn * 32 + (lane & 31) < p.L) ? acc[tm][tn][r] : 0.f;
+                    const float v = (col_of(tn) < p.L) ? acc[tm][tn][r] : 0.f;
                     sm += v;
                     sq += v * v;
                 }
@@ -601,6 +636,12 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(int nb, int c, int cpg
 }
 
 static CAPTRA_KNOB int g_pw_direct = 1;  // experiment knob: 0 = LDS-staged kernel for dense layers too
+static CAPTRA_KNOB int g_pw_pair = 1;    // experiment knob: 0 = never the paired-column variant
+extern "C" void captra_pw_set_pair(int on) { g_pw_pair = on; }
+// paired column tiles need 8-byte aligned row segments: even L, 8-byte aligned tensors
+static inline bool pw_pairable(const PwParams &p) {
+    return g_pw_pair && p.L % 2 == 0 && ((reinterpret_cast<uintptr_t>(p.x) | reinterpret_cast<uintptr_t>(p.y)) & 7) == 0;
+}
 
 int launch_pw_direct(int b, const PwParams &p, hipStream_t s) {
     if ((long long)p.cin * p.L * 4 >= (1ll << 31)) return -3;  // buffer offsets are 32-bit: fall back
@@ -612,13 +653,13 @@ int launch_pw_direct(int b, const PwParams &p, hipStream_t s) {
         CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<1, 1, 2, 2>), grid, dim3(256), 0, s, p);
     } else if (p.cout > 64) {
         dim3 grid((unsigned)((p.L + 127) / 128), (p.cout + 127) / 128, b);
-        CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<2, 2, 2, 2>), grid, dim3(256), 0, s, p);
+        if (pw_pairable(p)) { CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<2, 2, 2, 2, false, false, true>), grid, dim3(256), 0, s, p); } else { CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<2, 2, 2, 2>), grid, dim3(256), 0, s, p); }
     } else if (p.cout > 32) {
         dim3 grid((unsigned)((p.L + 255) / 256), 1, b);
-        CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<2, 2, 1, 4>), grid, dim3(256), 0, s, p);
+        if (pw_pairable(p)) { CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<2, 2, 1, 4, false, false, true>), grid, dim3(256), 0, s, p); } else { CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<2, 2, 1, 4>), grid, dim3(256), 0, s, p); }
     } else {
         dim3 grid((unsigned)((p.L + 255) / 256), 1, b);
-        CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<1, 2, 1, 4>), grid, dim3(256), 0, s, p);
+        if (pw_pairable(p)) { CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<1, 2, 1, 4, false, false, true>), grid, dim3(256), 0, s, p); } else { CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<1, 2, 1, 4>), grid, dim3(256), 0, s, p); }
     }
     return captra_last_error();
 }
@@ -739,13 +780,13 @@ extern "C" int captra_pointwise_mlp_gn(int b, int cin, int cout, long long l, co
         if (stats_out != nullptr && stats_t != (int)((l + 127) / 128) * 2) return -1;
         dim3 grid((unsigned)((l + 127) / 128), (cout + 127) / 128, b);
         if (ab_in != nullptr && stats_out != nullptr) {
-            CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<2, 2, 2, 2, true, true>), grid, dim3(256), 0, s, p);
+            if (pw_pairable(p)) { CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<2, 2, 2, 2, true, true, true>), grid, dim3(256), 0, s, p); } else { CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<2, 2, 2, 2, true, true>), grid, dim3(256), 0, s, p); }
         } else if (stats_out != nullptr) {
-            CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<2, 2, 2, 2, false, true>), grid, dim3(256), 0, s, p);
+            if (pw_pairable(p)) { CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<2, 2, 2, 2, false, true, true>), grid, dim3(256), 0, s, p); } else { CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<2, 2, 2, 2, false, true>), grid, dim3(256), 0, s, p); }
         } else if (ab_in != nullptr) {
-            CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<2, 2, 2, 2, true, false>), grid, dim3(256), 0, s, p);
+            if (pw_pairable(p)) { CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<2, 2, 2, 2, true, false, true>), grid, dim3(256), 0, s, p); } else { CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<2, 2, 2, 2, true, false>), grid, dim3(256), 0, s, p); }
         } else {
-            CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<2, 2, 2, 2>), grid, dim3(256), 0, s, p);
+            if (pw_pairable(p)) { CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<2, 2, 2, 2, false, false, true>), grid, dim3(256), 0, s, p); } else { CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<2, 2, 2, 2>), grid, dim3(256), 0, s, p); }
         }
         return captra_last_error();
     }
@@ -753,14 +794,14 @@ extern "C" int captra_pointwise_mlp_gn(int b, int cin, int cout, long long l, co
     dim3 grid((unsigned)((l + 255) / 256), 1, b);
     if (cout > 32) {
         if (ab_in != nullptr) {
-            CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<2, 2, 1, 4, true, false>), grid, dim3(256), 0, s, p);
+            if (pw_pairable(p)) { CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<2, 2, 1, 4, true, false, true>), grid, dim3(256), 0, s, p); } else { CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<2, 2, 1, 4, true, false>), grid, dim3(256), 0, s, p); }
         } else {
-            CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<2, 2, 1, 4>), grid, dim3(256), 0, s, p);
+            if (pw_pairable(p)) { CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<2, 2, 1, 4, false, false, true>), grid, dim3(256), 0, s, p); } else { CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<2, 2, 1, 4>), grid, dim3(256), 0, s, p); }
         }
     } else if (ab_in != nullptr) {
-        CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<1, 2, 1, 4, true, false>), grid, dim3(256), 0, s, p);
+        if (pw_pairable(p)) { CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<1, 2, 1, 4, true, false, true>), grid, dim3(256), 0, s, p); } else { CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<1, 2, 1, 4, true, false>), grid, dim3(256), 0, s, p); }
     } else {
-        CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<1, 2, 1, 4>), grid, dim3(256), 0, s, p);
+        if (pw_pairable(p)) { CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<1, 2, 1, 4, false, false, true>), grid, dim3(256), 0, s, p); } else { CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<1, 2, 1, 4>), grid, dim3(256), 0, s, p); }
     }
     return captra_last_error();
 }

@@ -229,6 +229,57 @@ def test_ball_query_ragged_and_multi_tile(pn, device, n, m, k, radius):
     np.testing.assert_array_equal(got, O.ball_query(radius, k, xyz, new_xyz))
 
 
+@pytest.mark.parametrize("case", ["uniform", "surface", "outside", "duplicates", "flat", "clustered", "odd_n"])
+def test_ball_query_grid_path_vs_oracle(device, case):
+    """Opt-in grid path (ball_query.hip PRUNE): clouds of 1024..4096 points answer their small radii from a cell grid: bit-exact lists against
+    the oracle, and against the index-order scan of the same library, for centres inside / outside the cloud's box and NaN,
+    duplicate-padded clouds (thousands of points in one cell), degenerate extents (a plane; a single location), radii on
+    both sides of the grid / scan threshold, up to three radii per scan."""
+    import ctypes
+    from captra_amd import _lib
+    rng = np.random.default_rng(len(case) * 7 + 1)
+    B, n, m = 2, 4096, 100
+    xyz = (rng.random((B, n, 3), dtype=np.float32) - 0.5).astype(np.float32)
+    if case == "surface":
+        v = rng.standard_normal((B, n, 3)).astype(np.float32)
+        xyz = (0.5 * v / np.linalg.norm(v, axis=-1, keepdims=True)).astype(np.float32)
+    elif case == "duplicates":
+        xyz[:, 1500:] = xyz[:, :1]                      # duplicate-padded cloud (reference data_utils pads by repetition)
+    elif case == "flat":
+        xyz[..., 1] = 0.25
+        xyz[1] = xyz[1, :1]                             # second cloud: a single location (extent 0: no grid)
+    elif case == "clustered":
+        xyz[:, : n // 2] = (0.02 * rng.standard_normal((B, n // 2, 3)) + 0.3).astype(np.float32)
+    elif case == "odd_n":
+        n = 3001
+        xyz = xyz[:, :n].copy()
+    pick = rng.integers(0, n, (B, m))
+    new_xyz = np.take_along_axis(xyz, pick[..., None], 1).copy()
+    if case == "outside":
+        new_xyz[:, :30] += rng.choice([-0.7, 0.7, 0.04], (B, 30, 3)).astype(np.float32)
+        new_xyz[:, 30] = 50.0
+        new_xyz[:, 31] = np.nan
+        new_xyz[:, 32, 0] = -0.5 - 0.03                 # just outside the box, ball reaching in
+    d_xyz, d_new = _dev(xyz, device), _dev(new_xyz, device)
+    lib = _lib.lib()
+    for radii, ks in [((0.05, 0.1, 0.2), (32, 64, 128)), ((0.03,), (8,)), ((0.12, 0.6), (300, 16)), ((0.149, 0.151), (64, 64))]:
+        nr = len(radii)
+        res = {}
+        for prune in (1, 0):
+            lib.captra_ball_query_set_prune(ctypes.c_int(prune))
+            try:
+                outs = [torch.full((B, m, k), -1, dtype=torch.int32, device=device) for k in ks]
+                _lib.call("captra_ball_query_multi", B, n, m, nr, ctypes.cast((ctypes.c_float * nr)(*radii), ctypes.c_void_p),
+                          ctypes.cast((ctypes.c_int * nr)(*ks), ctypes.c_void_p), d_new.data_ptr(), d_xyz.data_ptr(),
+                          ctypes.cast((ctypes.c_void_p * nr)(*[o.data_ptr() for o in outs]), ctypes.c_void_p))
+                res[prune] = [o.cpu().numpy() for o in outs]
+            finally:
+                lib.captra_ball_query_set_prune(ctypes.c_int(0))
+        for r, k, a, b_ in zip(radii, ks, res[1], res[0]):
+            np.testing.assert_array_equal(a, b_, err_msg=f"grid vs scan, r={r}")
+            np.testing.assert_array_equal(a, O.ball_query(r, k, xyz, new_xyz), err_msg=f"vs oracle, r={r}")
+
+
 def test_ball_query_empty_balls_are_zero(pn, device):
     xyz = _nocs_batch(range(1))
     new_xyz = np.full((1, 9, 3), 5.0, np.float32)  # far from every point
