@@ -328,6 +328,7 @@ def main():
     ap.add_argument("--static-tiles", action="store_true", help=argparse.SUPPRESS)      # A/B: persistent SA kernels without tickets
     ap.add_argument("--chunks-per-cu", type=int, default=0, help=argparse.SUPPRESS)    # A/B: ticket granularity of the SA2 kernel
     ap.add_argument("--no-pw-pair", action="store_true", help=argparse.SUPPRESS)       # A/B: dense layers without paired column tiles
+    ap.add_argument("--pw-occ", type=int, default=0, help=argparse.SUPPRESS)           # A/B: dense layers' workgroups per CU (2 / 3)
     args = ap.parse_args()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
@@ -339,8 +340,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"bench.py --gpus {args.gpus} launched with WORLD_SIZE={world}: the launcher must start exactly --gpus ranks")
-    if args.static_tiles or args.chunks_per_cu or args.no_pw_pair:
+    if args.static_tiles or args.chunks_per_cu or args.no_pw_pair or args.pw_occ:
         from captra_amd import _lib as _knobs
+        if args.pw_occ:
+            _knobs.lib().captra_pw_set_occupancy(ctypes.c_int(args.pw_occ))
         if args.no_pw_pair:
             _knobs.lib().captra_pw_set_pair(ctypes.c_int(0))
         if args.static_tiles:

@@ -29,6 +29,7 @@
 // Pipeline: register-staged prefetch (global loads of chunk c+1 are issued before the MFMAs of
 // chunk c and written to LDS after them), 2 workgroups per CU.
 #include "common.h"
+#include <atomic>
 
 namespace {
 
@@ -341,10 +342,10 @@ __device__ __forceinline__ float half_wave_sum(float v) {
 //      both tiles' outputs of a row -- half the vector-memory instructions of the B side.  Which column a lane's
 //      accumulator stands for changes, the per-element k-ascending chain does not: same bits per output element.
 template <int TM, int TN, int WGM, int WGN, bool AFF = false, bool ST = false, bool PAIR = false>
-__global__ __launch_bounds__(256) void pw_direct_kernel(PwParams p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void pw_direct_kernel(PwParams p) {
     static_assert(WGM * WGN == 4, "4 waves");
     static_assert(!PAIR || TN == 2, "paired column tiles");
-    constexpr int KS = AFF ? 4 : 8;  // k-steps per register set (shorter sets pay for the coefficient registers of AFF)
+    constexpr int KS = (AFF || (TM == 2 && TN == 2)) ? 4 : 8;  // k-steps per register set
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -636,6 +637,16 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(int nb, int c, int cpg
 }
 
 static CAPTRA_KNOB int g_pw_direct = 1;  // experiment knob: 0 = LDS-staged kernel for dense layers too
+// Occupancy of the 64x64-wave-tile launches.  The kernels are built for FOUR workgroups per CU (<= 128 registers,
+// amdgpu_waves_per_eu(4); the first build took 148-160 and held three).  Every workgroup computes one equal tile and a launch
+// ends with its last ROUND of workgroups: 4096 tiles over 3 x 256 slots were 5.33 rounds paid as 6, over 4 x 256 they are 4.
+// tools/bench_dense.py (512 -> 512 at 32 clouds, 4 / 3 / 2 workgroups per CU): GroupNorm-consuming layers 577 / 593 / 671 us,
+// plain layers 651 / 630 / 570 us on random operands — but in the track step (real operands, the other network alongside)
+// two per CU loses everywhere (5320 against 5380 frames/s), so four it is; the knob below (a launch limits its own
+// residency by asking for unused dynamic LDS) stays for such measurements.
+static CAPTRA_KNOB int g_pw_occ = 0;       // experiment knob: 0 / 4 = as built, 3 / 2 = fewer workgroups per CU
+extern "C" void captra_pw_set_occupancy(int occ) { g_pw_occ = occ; }
+static inline unsigned pw_occupancy_pad() { return g_pw_occ == 2 ? 60000u : (g_pw_occ == 3 ? 45000u : 0u); }
 static CAPTRA_KNOB int g_pw_pair = 1;    // experiment knob: 0 = never the paired-column variant
 extern "C" void captra_pw_set_pair(int on) { g_pw_pair = on; }
 // paired column tiles need 8-byte aligned row segments: even L, 8-byte aligned tensors
@@ -653,7 +664,7 @@ int launch_pw_direct(int b, const PwParams &p, hipStream_t s) {
         CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<1, 1, 2, 2>), grid, dim3(256), 0, s, p);
     } else if (p.cout > 64) {
         dim3 grid((unsigned)((p.L + 127) / 128), (p.cout + 127) / 128, b);
-        if (pw_pairable(p)) { CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<2, 2, 2, 2, false, false, true>), grid, dim3(256), 0, s, p); } else { CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<2, 2, 2, 2>), grid, dim3(256), 0, s, p); }
+        if (pw_pairable(p)) { CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<2, 2, 2, 2, false, false, true>), grid, dim3(256), pw_occupancy_pad(), s, p); } else { CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<2, 2, 2, 2>), grid, dim3(256), pw_occupancy_pad(), s, p); }
     } else if (p.cout > 32) {
         dim3 grid((unsigned)((p.L + 255) / 256), 1, b);
         if (pw_pairable(p)) { CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<2, 2, 1, 4, false, false, true>), grid, dim3(256), 0, s, p); } else { CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<2, 2, 1, 4>), grid, dim3(256), 0, s, p); }
@@ -780,13 +791,13 @@ extern "C" int captra_pointwise_mlp_gn(int b, int cin, int cout, long long l, co
         if (stats_out != nullptr && stats_t != (int)((l + 127) / 128) * 2) return -1;
         dim3 grid((unsigned)((l + 127) / 128), (cout + 127) / 128, b);
         if (ab_in != nullptr && stats_out != nullptr) {
-            if (pw_pairable(p)) { CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<2, 2, 2, 2, true, true, true>), grid, dim3(256), 0, s, p); } else { CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<2, 2, 2, 2, true, true>), grid, dim3(256), 0, s, p); }
+            if (pw_pairable(p)) { CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<2, 2, 2, 2, true, true, true>), grid, dim3(256), pw_occupancy_pad(), s, p); } else { CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<2, 2, 2, 2, true, true>), grid, dim3(256), pw_occupancy_pad(), s, p); }
         } else if (stats_out != nullptr) {
-            if (pw_pairable(p)) { CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<2, 2, 2, 2, false, true, true>), grid, dim3(256), 0, s, p); } else { CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<2, 2, 2, 2, false, true>), grid, dim3(256), 0, s, p); }
+            if (pw_pairable(p)) { CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<2, 2, 2, 2, false, true, true>), grid, dim3(256), pw_occupancy_pad(), s, p); } else { CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<2, 2, 2, 2, false, true>), grid, dim3(256), pw_occupancy_pad(), s, p); }
         } else if (ab_in != nullptr) {
-            if (pw_pairable(p)) { CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<2, 2, 2, 2, true, false, true>), grid, dim3(256), 0, s, p); } else { CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<2, 2, 2, 2, true, false>), grid, dim3(256), 0, s, p); }
+            if (pw_pairable(p)) { CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<2, 2, 2, 2, true, false, true>), grid, dim3(256), pw_occupancy_pad(), s, p); } else { CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<2, 2, 2, 2, true, false>), grid, dim3(256), pw_occupancy_pad(), s, p); }
         } else {
-            if (pw_pairable(p)) { CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<2, 2, 2, 2, false, false, true>), grid, dim3(256), 0, s, p); } else { CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<2, 2, 2, 2>), grid, dim3(256), 0, s, p); }
+            if (pw_pairable(p)) { CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<2, 2, 2, 2, false, false, true>), grid, dim3(256), pw_occupancy_pad(), s, p); } else { CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<2, 2, 2, 2>), grid, dim3(256), pw_occupancy_pad(), s, p); }
         }
         return captra_last_error();
     }

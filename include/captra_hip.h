@@ -353,6 +353,7 @@ void captra_sa_fused_set_wn(int wn);        /* generic LDS kernel: sub-tile widt
 void captra_sa_fused_set_prof(unsigned long long *dev_counters); /* sa_wave_kernel: 10 device counters of phase timers, or NULL */
 void captra_pw_set_direct(int on);          /* dense layers: 1 = direct-operand kernel (default), 0 = LDS-staged kernel */
 void captra_ball_query_set_prune(int on);   /* ball query: 1 = small radii of 1024..4096-point clouds from a cell grid (exact; measured slower, off by default), 0 = index-order scan */
+void captra_pw_set_occupancy(int occ);      /* dense layers, 64x64 wave tiles: workgroups per CU, 0 / 4 = as built (default), 3 / 2 = fewer (measurements) */
 void captra_pw_set_pair(int on);            /* dense layers: 1 = paired column tiles where L is even (default), 0 = never */
 void captra_sa_set_dynamic_tiles(int on);   /* persistent SA kernels: 1 = tiles handed out by ticket (default; work_pool.hip), 0 = static walk */
 void captra_sa_set_chunks_per_cu(int n);    /* sa_wave_pipe_kernel with tickets: chunks per CU the launch aims for (default 4) */
