@@ -407,8 +407,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
 extern unsigned long long *captra_sa_prof_ptr();   // sa_fused.hip: the debug counters set by captra_sa_fused_set_prof
 
-// experiment knob (not part of the reference boundary): chunks per CU the ticketed launch aims for
-static CAPTRA_KNOB int g_sp_chunks_per_cu = 4;
+// experiment knob (not part of the reference boundary): chunks per CU the ticketed launch aims for.  2: at 32 clouds the
+// chunks stay 8 tiles long and the walk static (tickets start at 3 rounds of chunks = 48+ clouds); with 4 the chunks
+// shrink to 4 / 2 tiles and the extra chunk barriers cost 2.5-3.7 % of the kernel (5391 against 5407 frames/s on the step)
+static CAPTRA_KNOB int g_sp_chunks_per_cu = 2;
 extern "C" void captra_sa_set_chunks_per_cu(int n) { g_sp_chunks_per_cu = n < 1 ? 1 : n; }
 
 // SA scale with a pre-transformed, POINT-major first layer (see include/captra_hip.h): v1pm (B,N,c1).

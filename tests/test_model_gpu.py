@@ -199,6 +199,7 @@ def test_persistent_sa_kernels_tickets_equal_static_walk(device):
             return lambda out: fused.sa_scale_pre_pm(v1pm, xyz_cn, new_xyz, idx, packed, out, 0, cfeat), (B, chans[2], m)
         return lambda out: fused.sa_scale_fused(feat, xyz_cn, new_xyz, idx, packed, out, 0), (B, chans[2], m)
 
+    lib.captra_sa_set_chunks_per_cu(ctypes.c_int(4))     # short chunks: the SA2 kernel takes tickets at these batch sizes too
     try:
         for args in [(320, (128, 196, 256), 512, 128, 128, 9), (320, (128, 128, 256), 512, 128, 64, 33), (3, (64, 96, 128), 4096, 512, 128, 13)]:
             run, shape = case(*args)
@@ -221,6 +222,7 @@ def test_persistent_sa_kernels_tickets_equal_static_walk(device):
                 assert torch.equal(out, ref), ("graph", args)
     finally:
         lib.captra_sa_set_dynamic_tiles(ctypes.c_int(1))
+        lib.captra_sa_set_chunks_per_cu(ctypes.c_int(2))
 
 
 def _sa_scale_fused_case(device, cfeat, chans, n, m, k):

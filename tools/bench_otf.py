@@ -118,10 +118,12 @@ if __name__ == "__main__":
         import ctypes
         from captra_amd import _lib
         for rep in range(4):
-            for dyn in (0, 1):
+            for dyn, cpc in ((0, 4), (1, 4), (1, 2)):
                 _lib.lib().captra_sa_set_dynamic_tiles(ctypes.c_int(dyn))
-                print(f"[tickets {'on ' if dyn else 'off'}] ", end="")
+                _lib.lib().captra_sa_set_chunks_per_cu(ctypes.c_int(cpc))
+                print(f"[tickets {'on ' if dyn else 'off'}, {cpc} chunks per CU] ", end="")
                 track_loop(32, configs=((True, True),))
+        _lib.lib().captra_sa_set_chunks_per_cu(ctypes.c_int(2))
         for dyn in (0, 1):
             _lib.lib().captra_sa_set_dynamic_tiles(ctypes.c_int(dyn))
             print(f"[tickets {'on ' if dyn else 'off'}] ", end="")
