@@ -83,13 +83,15 @@ def track_loop(batch: int, frames: int = 12, configs=((False, False), (True, Fal
     from tests import clouds
     from tests.weights import make_state_dict
     dev = torch.device("cuda:0")
-    for otf, lanes in configs:
+    for otf, lanes, *rest in configs:
+        overlap = rest[0] if rest else True
         cfg = make_config("1", experiment_dir="/tmp/captra_otf_bench", nocs_otf=otf, **{"init_frame/gt": True})
         cfg["device"] = dev
         trainer = Trainer(cfg)
         trainer.model.load_state_dict(make_state_dict({k: tuple(v.shape) for k, v in trainer.model.state_dict().items()}, seed=7))
         trainer.model.use_graph = True
         trainer.model.otf_lanes = bool(lanes)
+        trainer.model.overlap_nets = bool(overlap)
         data = clouds.make_trajectory("nocs", batch, frames, seed=0)
         depth, mask, center, pose = make_frame(1)
         for f in data:
@@ -110,10 +112,15 @@ def track_loop(batch: int, frames: int = 12, configs=((False, False), (True, Fal
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / (frames - 1)
             best = dt if best is None or dt < best else best
-        print(f"EvalTrackModel loop, nocs_otf={otf}{', two lanes half a frame apart' if lanes else ''}: {best * 1e3:7.2f} ms per step of {batch} trajectories = {batch / best:7.0f} frames/s", flush=True)
+        print(f"EvalTrackModel loop, nocs_otf={otf}{', two lanes half a frame apart' if lanes else ''}{'' if overlap else ', networks in sequence inside a lane'}: {best * 1e3:7.2f} ms per step of {batch} trajectories = {batch / best:7.0f} frames/s", flush=True)
 
 
 if __name__ == "__main__":
+    if "--ab-overlap" in sys.argv:      # same process, alternating: CoordNet || RotationNet inside a lane, or in sequence
+        for rep in range(5):
+            track_loop(32, configs=((True, True, True), (True, True, False)))
+        track_loop(32, configs=((True, False, True), (True, False, False), (False, False, True), (False, False, False)))
+        sys.exit(0)
     if "--ab-tiles" in sys.argv:        # same process, alternating: persistent SA kernels with / without work tickets
         import ctypes
         from captra_amd import _lib
