@@ -49,6 +49,15 @@ struct CaptraDeviceOnce {
 unsigned *captra_work_slot(hipStream_t stream);
 
 // ---- device helpers ---------------------------------------------------------------------------
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a full workgroup-scope fence: its s_waitcnt also waits
+// for every global load and STORE the wave has in flight (a store's acknowledgement takes microseconds), which a barrier that
+// only hands LDS data between waves does not need.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
 // squared distance exactly as the reference kernels and the oracle write it:
@@ -80,8 +89,15 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
 // activation codes of the shared-MLP entry points (include/captra_hip.h: CAPTRA_ACT_*)
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_SIGMOID_M05 = 2 };
 
+// ReLU on the bit pattern: negative floats (and -0) are negative integers, so one v_max_i32 does it; written on floats the
+// compiler emits a canonicalising v_max_f32 x, x, x in front of the v_max_f32 x, 0 (IEEE mode).  NaNs with the sign bit
+// clear pass through, as in the reference's relu.
+__device__ __forceinline__ float relu_bits(float v) {
+    const int x = __float_as_int(v);
+    return __int_as_float(x > 0 ? x : 0);
+}
 __device__ __forceinline__ float apply_act(float v, int act) {
-    if (act == ACT_RELU) return v > 0.f ? v : 0.f;
+    if (act == ACT_RELU) return relu_bits(v);
     if (act == ACT_SIGMOID_M05) return 1.0f / (1.0f + expf(-v)) - 0.5f;
     return v;
 }

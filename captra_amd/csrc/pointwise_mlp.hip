@@ -428,7 +428,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void p
             const float ga = upper ? G[j].z : G[j].x, gb = upper ? G[j].w : G[j].y;                                      \
             _Pragma("unroll") for (int tn = 0; tn < TN; ++tn) {                                                         \
                 const float t = __builtin_fmaf(ga, Bv[tn][j], gb);                                                       \
-                Bv[tn][j] = t > 0.f ? t : 0.f;                                                                           \
+                Bv[tn][j] = relu_bits(t);                                                                                \
             }                                                                                                            \
         }                                                                                                                \
     }                                                                                                                    \

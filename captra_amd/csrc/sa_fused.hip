@@ -612,7 +612,7 @@ __device__ __forceinline__ void sl_layer(const float *wl, const float *bias_lds,
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm)
             if (2 * ps + tm < S::NT) {
-                if (LAST) sw_last_epilogue<COUT, SL_WAVES>(acc[tm], 2 * ps + tm, red, wave, lane);
+                if (LAST) sw_last_epilogue_bfly<COUT, SL_WAVES>(acc[tm], 2 * ps + tm, red, wave, lane);
                 else sw_mid_epilogue<NOUT>(acc[tm], 2 * ps + tm, hout);
             }
     }
@@ -638,26 +638,40 @@ __global__ __launch_bounds__(SL_WAVES * 64) __attribute__((amdgpu_waves_per_eu(4
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const long long L = (long long)p.m * p.k;
     const int tiles_per_cloud = (int)((L + SL_POS - 1) / SL_POS);
-    const long long total = (long long)p.b * tiles_per_cloud;
+    const int total = p.b * tiles_per_cloud;             // < 2^31 (checked by the launcher): tile arithmetic in 32 bits
 
     int id = 0;
     float ctr[3] = {0.f, 0.f, 0.f};
-    auto load_task = [&](long long tile, int &id_o, float (&ctr_o)[3]) {
+    auto load_task = [&](int tile, int &id_o, float (&ctr_o)[3]) {
         if (tile >= total) return;
-        const int tb = (int)(tile / tiles_per_cloud);
-        const long long wp = (tile % tiles_per_cloud) * SL_POS + wave * 32;
+        const int tb = tile / tiles_per_cloud;
+        const long long wp = (long long)(tile - tb * tiles_per_cloud) * SL_POS + wave * 32;
         if (wp >= L) return;
         id_o = p.idx[(size_t)tb * L + wp + (lane & 31)];
         const float *cp = p.new_xyz + ((size_t)tb * p.m + (int)(wp / p.k)) * 3;
         ctr_o[0] = cp[0]; ctr_o[1] = cp[1]; ctr_o[2] = cp[2];
     };
+    // first-layer B operand of a tile (k-step j = rows 2j, 2j+1: feature rows, then centre-relative xyz), gathered per lane
+    auto gather_x1 = [&](int t, int id_, const float (&c_)[3], float (&x_)[S1::KST]) {
+        if (t >= total) return;
+        const int tb = t / tiles_per_cloud;
+        if ((long long)(t - tb * tiles_per_cloud) * SL_POS + wave * 32 >= L) return;
+#pragma unroll
+        for (int j = 0; j < S1::KST; ++j) {
+            const int row = 2 * j + (lane >> 5);
+            float v = 0.f;
+            if (row < CF) v = p.feat[((size_t)tb * CF + row) * p.n + id_];
+            else if (row < CIN1) v = p.xyz_cn[((size_t)tb * 3 + (row - CF)) * p.n + id_] - (row - CF == 0 ? c_[0] : (row - CF == 1 ? c_[1] : c_[2]));
+            x_[j] = v;
+        }
+    };
     // tiles: the first two are blockIdx.x and blockIdx.x + gridDim.x; further ones by ticket (p.work, see work_pool.hip)
     // or, without a slot, the static walk.  The ticket for the tile after next is drawn one tile ahead and crosses the
     // workgroup through LDS; two static tiles, so that the first draw — every workgroup of the launch hits the counter at
     // the same moment, ~25 ns each — resolves under a tile's MFMA work instead of in front of it.
-    __shared__ long long next_tile[2];
-    long long tile = blockIdx.x;
-    if (tid == 0) next_tile[0] = tile + gridDim.x;
+    __shared__ int next_tile[2];
+    int tile = (int)blockIdx.x;
+    if (tid == 0) next_tile[0] = tile + (int)gridDim.x;
     load_task(tile, id, ctr);
     sl_stage_weights<CIN1, C1>(wl1, p.w1, tid);
     sl_stage_weights<C1, C2>(wl2, p.w2, tid);
@@ -667,38 +681,59 @@ __global__ __launch_bounds__(SL_WAVES * 64) __attribute__((amdgpu_waves_per_eu(4
     for (int e = tid; e < pad32c(C3); e += SL_WAVES * 64) bias3[e] = p.b3[e];
     __syncthreads();
 
+    float x1[S1::KST];
+#pragma unroll
+    for (int j = 0; j < S1::KST; ++j) x1[j] = 0.f;
+    gather_x1(tile, id, ctr, x1);
+    const bool sampled = blockIdx.x % 16 == 0;            // phase timers (captra_sa_fused_set_prof): a sample of workgroups
+    unsigned long long t_last = p.prof != nullptr ? __builtin_amdgcn_s_memtime() : 0ull;
     int par = 0;
     for (; tile < total; par ^= 1) {
-        const long long next = next_tile[par];     // written before the last barrier passed
+        const int next_raw = next_tile[par];     // written before the last barrier passed
+        const int next = next_raw < 0 || next_raw > total ? total : next_raw;   // (a wrapped ticket past the end)
         unsigned ticket = 0;                       // of the tile after next: drawn behind this tile's loads, parked in a
                                                    // register while the layers run (an early LDS store would make wave 0
                                                    // wait for the atomic's return before its first MFMA)
-        const int b = (int)(tile / tiles_per_cloud);
-        const long long pos0 = (tile % tiles_per_cloud) * SL_POS;
+        const int b = tile / tiles_per_cloud;
+        const long long pos0 = (long long)(tile - b * tiles_per_cloud) * SL_POS;
         const bool active = pos0 + wave * 32 < L;  // wave-uniform (L is a multiple of 32)
         int id_n = 0;
         float ctr_n[3] = {0.f, 0.f, 0.f};
-        if (active) {
-            float x1[S1::KST], h1[S2::KST], h2[S3::KST], none[1];
+        float x1_n[S1::KST];
 #pragma unroll
-            for (int j = 0; j < S1::KST; ++j) {
-                const int row = 2 * j + (lane >> 5);
-                float v = 0.f;
-                if (row < CF) v = p.feat[((size_t)b * CF + row) * p.n + id];
-                else if (row < CIN1) v = p.xyz_cn[((size_t)b * 3 + (row - CF)) * p.n + id] - (row - CF == 0 ? ctr[0] : (row - CF == 1 ? ctr[1] : ctr[2]));
-                x1[j] = v;
-            }
+        for (int j = 0; j < S1::KST; ++j) x1_n[j] = 0.f;
+        float h2[S3::KST];
+        if (active) {
+            float h1[S2::KST];
             load_task(next, id_n, ctr_n);
             if (tid == 0 && p.work != nullptr) ticket = atomicAdd(p.work, 1u);
+            SW_TICK(0)
             sl_layer<CIN1, C1, false>(wl1, bias1, x1, h1, red, wave, lane);
+            SW_TICK(1)
             sl_layer<C1, C2, false>(wl2, bias2, h1, h2, red, wave, lane);
-            sl_layer<C2, C3, true>(wl3, bias3, h2, none, red, wave, lane);
+            // the NEXT tile's first-layer operand: its neighbour ids were asked for two layers ago; the gather (a dependent
+            // global load) runs under the widest layer
+            gather_x1(next, id_n, ctr_n, x1_n);
+            SW_TICK(2)
         } else {
             load_task(next, id_n, ctr_n);
             if (tid == 0 && p.work != nullptr) ticket = atomicAdd(p.work, 1u);
+            gather_x1(next, id_n, ctr_n, x1_n);
         }
-        if (tid == 0) next_tile[par ^ 1] = p.work != nullptr ? 2ll * gridDim.x + ticket : next + gridDim.x;
-        __syncthreads();  // every wave's 32-position maxima are in red
+        // Two barriers per tile, both LDS-only (lds_barrier: the read-out's global stores and the prefetches stay in flight
+        // across them).  (A) before the last layer writes its maxima: every wave has read the previous tile's out of red —
+        // placed here, two layers after the read-out, nobody waits at it; (B) after the last layer: the maxima are complete.
+        lds_barrier();
+        SW_TICK(4)
+        if (active) {
+            float none[1];
+            sl_layer<C2, C3, true>(wl3, bias3, h2, none, red, wave, lane);
+            SW_TICK(3)
+            if (p.prof != nullptr && lane == 0 && sampled) atomicAdd(p.prof + 9, 1ull);
+        }
+        if (tid == 0) next_tile[par ^ 1] = p.work != nullptr ? (int)(2u * gridDim.x + ticket) : next + (int)gridDim.x;
+        lds_barrier();
+        SW_TICK(4)
         const int tiles_per_group = p.k / 32;
         const int groups = SL_POS / p.k;
         for (int e = tid; e < C3 * groups; e += SL_WAVES * 64) {
@@ -710,8 +745,8 @@ __global__ __launch_bounds__(SL_WAVES * 64) __attribute__((amdgpu_waves_per_eu(4
                 p.out[((size_t)b * p.out_ctotal + p.co_off + row) * p.m + centre] = v;
             }
         }
-        __syncthreads();  // red is free for the next tile
-        id = id_n; ctr[0] = ctr_n[0]; ctr[1] = ctr_n[1]; ctr[2] = ctr_n[2];
+#pragma unroll
+        for (int j = 0; j < S1::KST; ++j) x1[j] = x1_n[j];
         tile = next;
     }
     // the last workgroup to leave hands the slot back clean (the next launch using it is ordered after this one)
@@ -762,7 +797,8 @@ extern "C" int captra_sa_scale_fused(int b, int n, int m, int k, int cfeat, int 
         dim3 gridw((unsigned)((Lw + SF_POS - 1) / SF_POS), b);
         // small-input scales: persistent workgroups with the weights resident in LDS (mode 2 = streaming kernel for all)
 #define SL_CASE(CF_, C1_, C2_, C3_)                                                                                   \
-    if (g_sa_mode != 2 && cfeat == CF_ && c1 == C1_ && c2 == C2_ && c3 == C3_ && SL_POS % k == 0) {                    \
+    if (g_sa_mode != 2 && cfeat == CF_ && c1 == C1_ && c2 == C2_ && c3 == C3_ && SL_POS % k == 0 &&                     \
+        ((Lw + SL_POS - 1) / SL_POS) * b < (1ll << 30)) {                                                             \
         auto kern = sa_wave_lds_kernel<CF_, C1_, C2_, C3_>;                                                            \
         constexpr int lds_bytes = sl_lds_floats<CF_, C1_, C2_, C3_>() * 4;                                             \
         static std::atomic<int> resident_of[128];              /* per device: the attribute and the occupancy are */    \

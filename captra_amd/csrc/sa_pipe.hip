@@ -64,11 +64,14 @@ __device__ __forceinline__ void sp_mid_unit(const f32x16 &acc, int t, int q, flo
         return;
     }
 #endif
-    float a[4];
+    unsigned a[4];          // ReLU on the bit pattern: one v_max_i32 (the float form is canonicalise + max)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) a[i] = acc[4 * q + i] > 0.f ? acc[4 * q + i] : 0.f;
-    const auto p01 = __builtin_amdgcn_permlane32_swap(__float_as_uint(a[0]), __float_as_uint(a[1]), false, false);
-    const auto p23 = __builtin_amdgcn_permlane32_swap(__float_as_uint(a[2]), __float_as_uint(a[3]), false, false);
+    for (int i = 0; i < 4; ++i) {
+        const int x = __float_as_int(acc[4 * q + i]);
+        a[i] = (unsigned)(x > 0 ? x : 0);
+    }
+    const auto p01 = __builtin_amdgcn_permlane32_swap(a[0], a[1], false, false);
+    const auto p23 = __builtin_amdgcn_permlane32_swap(a[2], a[3], false, false);
     const int k0 = 16 * t + 4 * q;
     if (k0 + 0 < NOUT) hout[k0 + 0] = __uint_as_float(p01[0]);
     if (k0 + 1 < NOUT) hout[k0 + 1] = __uint_as_float(p23[0]);

@@ -114,12 +114,17 @@ __device__ __forceinline__ void sw_mid_epilogue(const f32x16 &acc, int t, float 
 #endif
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        float a[4];
+        // ReLU on the bit pattern (one v_max_i32: negative floats and -0 are negative integers; the float form costs a
+        // canonicalising v_max_f32 x, x, x in front of every v_max_f32 x, 0 -- 88 instructions per SA1 tile)
+        unsigned a[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) a[i] = acc[4 * q + i] > 0.f ? acc[4 * q + i] : 0.f;
+        for (int i = 0; i < 4; ++i) {
+            const int x = __float_as_int(acc[4 * q + i]);
+            a[i] = (unsigned)(x > 0 ? x : 0);
+        }
         // registers (4q, 4q+1) hold rows (8q, 8q+1) in the lower half-wave and (8q+4, 8q+5) in the upper one
-        const auto p01 = __builtin_amdgcn_permlane32_swap(__float_as_uint(a[0]), __float_as_uint(a[1]), false, false);
-        const auto p23 = __builtin_amdgcn_permlane32_swap(__float_as_uint(a[2]), __float_as_uint(a[3]), false, false);
+        const auto p01 = __builtin_amdgcn_permlane32_swap(a[0], a[1], false, false);
+        const auto p23 = __builtin_amdgcn_permlane32_swap(a[2], a[3], false, false);
         const int k0 = 16 * t + 4 * q;
         if (k0 + 0 < NOUT) hout[k0 + 0] = __uint_as_float(p01[0]);  // rows 8q,   8q+1
         if (k0 + 1 < NOUT) hout[k0 + 1] = __uint_as_float(p23[0]);  // rows 8q+2, 8q+3
@@ -137,6 +142,53 @@ __device__ __forceinline__ int dpp_max_i32(int v) {
     const int o = ROW_MASK == 0xF ? __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true)
                                   : __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xF, false);
     return o > v ? o : v;
+}
+
+// The same reduction as a transpose-reduce butterfly (the form sa_pipe.hip issues in deferred parts): neighbouring REGISTERS
+// are merged while neighbouring LANES are reduced -- stage k pairs lane l with l ^ 2^k and registers (2i, 2i+1); a lane with
+// bit k clear keeps register 2i and takes the partner's 2i, a lane with bit k set keeps 2i+1 -- so four stages take 16 + 8 +
+// 4 + 2 max steps instead of 16 x 4, ONE register then holds in lane l the maximum over its row of 16 lanes of accumulator
+// register (l & 15); a ds_swizzle (lane ^ 16) joins the two rows of a half-wave, one ReLU (max on the raw bit patterns: a
+// positive input wins the signed-integer maximum as the largest float, otherwise the result is negative and ReLU gives 0 =
+// ReLU-then-max) and one 32-lane ds_write_b32 finish the tile: ~55 instructions instead of ~112.  These kernels are bound
+// by the instructions a SIMD issues (MFMA issue + VALU do not overlap within it: the phase timers move when an
+// instruction count moves and not when a latency does), so that is ~5 % of an SA1 scale.
+template <int CTRL, int BANK_MASK>
+__device__ __forceinline__ int sw_dpp_sel(int old, int src) {
+    return __builtin_amdgcn_update_dpp(old, src, CTRL, 0xF, BANK_MASK, false);
+}
+__device__ __forceinline__ int sw_imax(int a, int b) { return a > b ? a : b; }
+
+template <int COUT, int RED_STRIDE = 4>
+__device__ __forceinline__ void sw_last_epilogue_bfly(const f32x16 &acc, int t, float *red, int wave, int lane) {
+    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
+    int w[8], v[4], u[2];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int x0 = __float_as_int(acc[2 * i]), x1 = __float_as_int(acc[2 * i + 1]);
+        const int own = b0 ? x1 : x0, oth = b0 ? x0 : x1;
+        w[i] = sw_imax(own, sw_dpp_sel<0xB1, 0xF>(own, oth));           // quad_perm [1,0,3,2]: lane ^ 1
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int own = b1 ? w[2 * j + 1] : w[2 * j], oth = b1 ? w[2 * j] : w[2 * j + 1];
+        v[j] = sw_imax(own, sw_dpp_sel<0x4E, 0xF>(own, oth));           // quad_perm [2,3,0,1]: lane ^ 2
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int own = b2 ? v[2 * m + 1] : v[2 * m], oth = b2 ? v[2 * m] : v[2 * m + 1];
+        const int p = sw_dpp_sel<0x104, 0x5>(own, oth);                  // lane ^ 4: row_shl:4 into banks 0, 2 ...
+        const int q = sw_dpp_sel<0x114, 0xA>(p, oth);                    // ... row_shr:4 into banks 1, 3
+        u[m] = sw_imax(own, q);
+    }
+    const int own = b3 ? u[1] : u[0], oth = b3 ? u[0] : u[1];
+    int z = sw_imax(own, sw_dpp_sel<0x128, 0xF>(own, oth));              // row_ror:8: lane ^ 8 within the row of 16
+    z = sw_imax(z, __builtin_amdgcn_ds_swizzle(z, 0x401F));              // lane ^ 16: the other row of the half-wave
+    z = z > 0 ? z : 0;                                                   // ReLU on the bit pattern
+    // lane l (l & 16 == 0) holds accumulator register r = l & 15 = output row 32 t + 8 (r >> 2) + (r & 3) + 4 (l >> 5)
+    const int r = lane & 15;
+    const int row = 32 * t + 8 * (r >> 2) + (r & 3) + 4 * (lane >> 5);
+    if ((lane & 16) == 0 && row < COUT) red[row * RED_STRIDE + wave] = __int_as_float(z);
 }
 
 // ReLU + max over the wave's 32 positions of output tile t -> red[row][wave]

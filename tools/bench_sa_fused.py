@@ -95,6 +95,7 @@ def main():
             c = cnt.tolist()
             waves = max(c[9], 1)
             labels = (["between", "L1", "L2", "L3", "combine"] if a.pipe else      # sa_wave_pipe_kernel: per tile
+                      ["read-out + loop top", "L1", "L2 + next gather", "L3 + max", "barriers"] if cfeat <= 3 else   # sa_wave_lds_kernel: per tile
                       ["start", "L1", "L2", "L3", "end-barrier"])                 # sa_wave_kernel's timers (streamed-weight scales)
             tot = sum(c[:len(labels)]) / waves
             if c[6]:
