@@ -544,10 +544,11 @@ void sa_wave_kernel(SwParams p) {
 // waves per CU stream them at different phases, so in sa_wave_kernel ~70 % of the A-operand lines come from
 // L2.  Here a persistent 8-wave workgroup stages the three weight matrices ONCE in LDS in MFMA-fragment
 // order -- element ((t*KQ + q)*64 + lane)*4 + i = W'^T[2(4q+i) + (lane>>5)][32t + (lane&31)] -- so a lane
-// fetches the A operands of four consecutive k-steps with one conflict-free ds_read_b128, and walks
-// 256-position tiles (8 waves x 32 neighbours), prefetching the next tile's neighbour ids and centre.
-// Everything else (gather in B-operand layout, activations in registers via v_permlane32_swap, integer DPP
-// max) is sa_wave_kernel's.  Same k-ascending fmaf chain: same bits.
+// fetches the A operands of four consecutive k-steps with one conflict-free ds_read_b128.  Each WAVE owns a
+// centre and walks its K neighbours in slices of 32 with the last layer's maximum kept in registers (see the
+// kernel), prefetching the next slice's neighbour ids and first-layer operand.  Everything else (gather in
+// B-operand layout, activations in registers via v_permlane32_swap, integer max) is sa_wave_kernel's.  Same
+// k-ascending fmaf chain: same bits.
 // =====================================================================================================
 constexpr int SL_WAVES = 8;
 constexpr int SL_POS = SL_WAVES * 32;
@@ -575,9 +576,9 @@ __device__ __forceinline__ void sl_stage_weights(float *dst, const float *__rest
     }
 }
 
-template <int CIN, int COUT, bool LAST, int NIN, int NOUT>
+template <int CIN, int COUT, bool LAST, int NIN, int NOUT, int NZ>
 __device__ __forceinline__ void sl_layer(const float *wl, const float *bias_lds, const float (&hin)[NIN], float (&hout)[NOUT],
-                                         float *red, int wave, int lane) {
+                                         int (&zrun)[NZ], int lane) {
     using S = SlShape<CIN, COUT>;
     static_assert(NIN >= S::KST, "input operand array too small");
     const float4 *wq = reinterpret_cast<const float4 *>(wl) + lane;
@@ -612,7 +613,7 @@ __device__ __forceinline__ void sl_layer(const float *wl, const float *bias_lds,
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm)
             if (2 * ps + tm < S::NT) {
-                if (LAST) sw_last_epilogue_bfly<COUT, SL_WAVES>(acc[tm], 2 * ps + tm, red, wave, lane);
+                if (LAST) sw_bfly_accumulate(acc[tm], zrun[2 * ps + tm], lane);
                 else sw_mid_epilogue<NOUT>(acc[tm], 2 * ps + tm, hout);
             }
     }
@@ -620,7 +621,7 @@ __device__ __forceinline__ void sl_layer(const float *wl, const float *bias_lds,
 
 template <int CF, int C1, int C2, int C3>
 constexpr int sl_lds_floats() {
-    return SlShape<CF + 3, C1>::FLOATS + SlShape<C1, C2>::FLOATS + SlShape<C2, C3>::FLOATS + pad32c(C1) + pad32c(C2) + pad32c(C3) + C3 * SL_WAVES;
+    return SlShape<CF + 3, C1>::FLOATS + SlShape<C1, C2>::FLOATS + SlShape<C2, C3>::FLOATS + pad32c(C1) + pad32c(C2) + pad32c(C3);
 }
 
 template <int CF, int C1, int C2, int C3>
@@ -633,29 +634,30 @@ __global__ __launch_bounds__(SL_WAVES * 64) __attribute__((amdgpu_waves_per_eu(4
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *wl1 = lds, *wl2 = wl1 + S1::FLOATS, *wl3 = wl2 + S2::FLOATS;
     float *bias1 = wl3 + S3::FLOATS, *bias2 = bias1 + pad32c(C1), *bias3 = bias2 + pad32c(C2);
-    float *red = bias3 + pad32c(C3);  // [C3][8 waves]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const long long L = (long long)p.m * p.k;
-    const int tiles_per_cloud = (int)((L + SL_POS - 1) / SL_POS);
-    const int total = p.b * tiles_per_cloud;             // < 2^31 (checked by the launcher): tile arithmetic in 32 bits
 
-    int id = 0;
-    float ctr[3] = {0.f, 0.f, 0.f};
-    auto load_task = [&](int tile, int &id_o, float (&ctr_o)[3]) {
-        if (tile >= total) return;
-        const int tb = tile / tiles_per_cloud;
-        const long long wp = (long long)(tile - tb * tiles_per_cloud) * SL_POS + wave * 32;
-        if (wp >= L) return;
-        id_o = p.idx[(size_t)tb * L + wp + (lane & 31)];
-        const float *cp = p.new_xyz + ((size_t)tb * p.m + (int)(wp / p.k)) * 3;
-        ctr_o[0] = cp[0]; ctr_o[1] = cp[1]; ctr_o[2] = cp[2];
+    // A WAVE owns a centre: it walks the centre's K neighbours in K / 32 slices of 32 (one neighbour per lane pair of
+    // k-steps, as before) and keeps the running maximum of the last layer in registers (sw_bfly_accumulate), so the eight
+    // waves of a workgroup share the LDS-resident weights and nothing else: no barrier after the staging one, no LDS
+    // traffic for the max, no read-out pass, and the waves of a SIMD drift out of phase with each other (one's epilogue
+    // under another's MFMAs) instead of meeting twice per tile.  Against the workgroup-tile form (8 waves x 32 positions,
+    // maxima combined through LDS, two barriers per tile) at 32 clouds: 647 -> 635, 260 -> 237, 50.5 -> 45.7 us for the
+    // three SA1 scales.  Centres are walked statically (gid, gid + nwaves, ...): every wave gets the same number, and
+    // per-wave work tickets (work_pool.hip) were measured worse here -- a centre is the unit, so the launch ends up to a
+    // whole centre (4 slices, ~150 us with four waves per SIMD) late, and the atomic's return is waited for at every
+    // centre end (674 / 298 / 210 us).
+    const int nwaves = (int)gridDim.x * SL_WAVES, gid = (int)blockIdx.x * SL_WAVES + wave;
+    const int ncentres = p.b * p.m;                       // < 2^30 (launcher)
+    const int nslices = p.k / 32;
+    auto load_ids = [&](int c, int sl) { return p.idx[(size_t)c * p.k + sl * 32 + (lane & 31)]; };
+    auto load_ctr = [&](int c, float (&o)[3]) {
+        const float *cp = p.new_xyz + (size_t)c * 3;
+        o[0] = cp[0]; o[1] = cp[1]; o[2] = cp[2];
     };
-    // first-layer B operand of a tile (k-step j = rows 2j, 2j+1: feature rows, then centre-relative xyz), gathered per lane
-    auto gather_x1 = [&](int t, int id_, const float (&c_)[3], float (&x_)[S1::KST]) {
-        if (t >= total) return;
-        const int tb = t / tiles_per_cloud;
-        if ((long long)(t - tb * tiles_per_cloud) * SL_POS + wave * 32 >= L) return;
+    // first-layer B operand of a slice (k-step j = rows 2j, 2j+1: feature rows, then centre-relative xyz), gathered per lane
+    auto gather_x1 = [&](int c, int id_, const float (&c_)[3], float (&x_)[S1::KST]) {
+        const int tb = c / p.m;
 #pragma unroll
         for (int j = 0; j < S1::KST; ++j) {
             const int row = 2 * j + (lane >> 5);
@@ -665,14 +667,14 @@ __global__ __launch_bounds__(SL_WAVES * 64) __attribute__((amdgpu_waves_per_eu(4
             x_[j] = v;
         }
     };
-    // tiles: the first two are blockIdx.x and blockIdx.x + gridDim.x; further ones by ticket (p.work, see work_pool.hip)
-    // or, without a slot, the static walk.  The ticket for the tile after next is drawn one tile ahead and crosses the
-    // workgroup through LDS; two static tiles, so that the first draw — every workgroup of the launch hits the counter at
-    // the same moment, ~25 ns each — resolves under a tile's MFMA work instead of in front of it.
-    __shared__ int next_tile[2];
-    int tile = (int)blockIdx.x;
-    if (tid == 0) next_tile[0] = tile + (int)gridDim.x;
-    load_task(tile, id, ctr);
+    int c = gid, sl = 0;                 // the slice being computed
+    int c_next = gid + nwaves;           // the centre after c
+    int id = 0;
+    float ctr[3] = {0.f, 0.f, 0.f};
+    if (c < ncentres) {
+        id = load_ids(c, 0);
+        load_ctr(c, ctr);
+    }
     sl_stage_weights<CIN1, C1>(wl1, p.w1, tid);
     sl_stage_weights<C1, C2>(wl2, p.w2, tid);
     sl_stage_weights<C2, C3>(wl3, p.w3, tid);
@@ -684,78 +686,58 @@ __global__ __launch_bounds__(SL_WAVES * 64) __attribute__((amdgpu_waves_per_eu(4
     float x1[S1::KST];
 #pragma unroll
     for (int j = 0; j < S1::KST; ++j) x1[j] = 0.f;
-    gather_x1(tile, id, ctr, x1);
+    if (c < ncentres) gather_x1(c, id, ctr, x1);
+    int zrun[S3::NT];
     const bool sampled = blockIdx.x % 16 == 0;            // phase timers (captra_sa_fused_set_prof): a sample of workgroups
     unsigned long long t_last = p.prof != nullptr ? __builtin_amdgcn_s_memtime() : 0ull;
-    int par = 0;
-    for (; tile < total; par ^= 1) {
-        const int next_raw = next_tile[par];     // written before the last barrier passed
-        const int next = next_raw < 0 || next_raw > total ? total : next_raw;   // (a wrapped ticket past the end)
-        unsigned ticket = 0;                       // of the tile after next: drawn behind this tile's loads, parked in a
-                                                   // register while the layers run (an early LDS store would make wave 0
-                                                   // wait for the atomic's return before its first MFMA)
-        const int b = tile / tiles_per_cloud;
-        const long long pos0 = (long long)(tile - b * tiles_per_cloud) * SL_POS;
-        const bool active = pos0 + wave * 32 < L;  // wave-uniform (L is a multiple of 32)
+    while (c < ncentres) {
+        if (sl == 0) {
+#pragma unroll
+            for (int t = 0; t < S3::NT; ++t) zrun[t] = 0;          // (0 = the ReLU)
+        }
+        // what comes after this slice (wave-uniform)
+        const bool last_slice = sl + 1 == nslices;
+        const int cn = last_slice ? c_next : c, sn = last_slice ? 0 : sl + 1;
+        const bool has_next = cn < ncentres;
         int id_n = 0;
-        float ctr_n[3] = {0.f, 0.f, 0.f};
+        float ctr_n[3] = {ctr[0], ctr[1], ctr[2]};
+        if (has_next) {
+            id_n = load_ids(cn, sn);
+            if (last_slice) load_ctr(cn, ctr_n);
+        }
+        float h1[S2::KST], h2[S3::KST], none[1];
         float x1_n[S1::KST];
 #pragma unroll
         for (int j = 0; j < S1::KST; ++j) x1_n[j] = 0.f;
-        float h2[S3::KST];
-        if (active) {
-            float h1[S2::KST];
-            load_task(next, id_n, ctr_n);
-            if (tid == 0 && p.work != nullptr) ticket = atomicAdd(p.work, 1u);
-            SW_TICK(0)
-            sl_layer<CIN1, C1, false>(wl1, bias1, x1, h1, red, wave, lane);
-            SW_TICK(1)
-            sl_layer<C1, C2, false>(wl2, bias2, h1, h2, red, wave, lane);
-            // the NEXT tile's first-layer operand: its neighbour ids were asked for two layers ago; the gather (a dependent
-            // global load) runs under the widest layer
-            gather_x1(next, id_n, ctr_n, x1_n);
-            SW_TICK(2)
-        } else {
-            load_task(next, id_n, ctr_n);
-            if (tid == 0 && p.work != nullptr) ticket = atomicAdd(p.work, 1u);
-            gather_x1(next, id_n, ctr_n, x1_n);
-        }
-        // Two barriers per tile, both LDS-only (lds_barrier: the read-out's global stores and the prefetches stay in flight
-        // across them).  (A) before the last layer writes its maxima: every wave has read the previous tile's out of red —
-        // placed here, two layers after the read-out, nobody waits at it; (B) after the last layer: the maxima are complete.
-        lds_barrier();
-        SW_TICK(4)
-        if (active) {
-            float none[1];
-            sl_layer<C2, C3, true>(wl3, bias3, h2, none, red, wave, lane);
-            SW_TICK(3)
-            if (p.prof != nullptr && lane == 0 && sampled) atomicAdd(p.prof + 9, 1ull);
-        }
-        if (tid == 0) next_tile[par ^ 1] = p.work != nullptr ? (int)(2u * gridDim.x + ticket) : next + (int)gridDim.x;
-        lds_barrier();
-        SW_TICK(4)
-        const int tiles_per_group = p.k / 32;
-        const int groups = SL_POS / p.k;
-        for (int e = tid; e < C3 * groups; e += SL_WAVES * 64) {
-            const int row = e / groups, gi = e % groups;
-            const long long centre = pos0 / p.k + gi;
-            if (centre < p.m) {
-                float v = red[row * SL_WAVES + gi * tiles_per_group];
-                for (int t = 1; t < tiles_per_group; ++t) v = fmaxf(v, red[row * SL_WAVES + gi * tiles_per_group + t]);
-                p.out[((size_t)b * p.out_ctotal + p.co_off + row) * p.m + centre] = v;
+        SW_TICK(0)
+        sl_layer<CIN1, C1, false>(wl1, bias1, x1, h1, zrun, lane);
+        SW_TICK(1)
+        sl_layer<C1, C2, false>(wl2, bias2, h1, h2, zrun, lane);
+        // the NEXT slice's first-layer operand: its neighbour ids were asked for two layers ago; the gather (a dependent
+        // global load) runs under the widest layer
+        if (has_next) gather_x1(cn, id_n, ctr_n, x1_n);
+        SW_TICK(2)
+        sl_layer<C2, C3, true>(wl3, bias3, h2, none, zrun, lane);
+        SW_TICK(3)
+        if (p.prof != nullptr && lane == 0 && sampled) atomicAdd(p.prof + 9, 1ull);
+        if (last_slice) {
+            // the centre's maxima: lane l with (l & 16) == 0 holds row 32 t + 8 ((l & 15) >> 2) + (l & 3) + 4 (l >> 5) of tile t
+            const int tb = c / p.m, centre = c - tb * p.m;
+            const int r = lane & 15;
+            const int row0 = 8 * (r >> 2) + (r & 3) + 4 * (lane >> 5);
+            float *op = p.out + ((size_t)tb * p.out_ctotal + p.co_off + row0) * p.m + centre;
+#pragma unroll
+            for (int t = 0; t < S3::NT; ++t) {
+                const float v = sw_bfly_finish(zrun[t]);
+                if ((lane & 16) == 0 && 32 * t + row0 < C3) op[(size_t)32 * t * p.m] = v;
             }
+            c_next += nwaves;
+            ctr[0] = ctr_n[0]; ctr[1] = ctr_n[1]; ctr[2] = ctr_n[2];
+            SW_TICK(4)
         }
+        c = cn; sl = sn;
 #pragma unroll
         for (int j = 0; j < S1::KST; ++j) x1[j] = x1_n[j];
-        tile = next;
-    }
-    // the last workgroup to leave hands the slot back clean (the next launch using it is ordered after this one)
-    if (p.work != nullptr && tid == 0) {
-        __threadfence();
-        if (atomicAdd(p.work + 1, 1u) == gridDim.x - 1) {
-            atomicExch(p.work, 0u);
-            atomicExch(p.work + 1, 0u);
-        }
     }
 }
 
@@ -797,8 +779,7 @@ extern "C" int captra_sa_scale_fused(int b, int n, int m, int k, int cfeat, int 
         dim3 gridw((unsigned)((Lw + SF_POS - 1) / SF_POS), b);
         // small-input scales: persistent workgroups with the weights resident in LDS (mode 2 = streaming kernel for all)
 #define SL_CASE(CF_, C1_, C2_, C3_)                                                                                   \
-    if (g_sa_mode != 2 && cfeat == CF_ && c1 == C1_ && c2 == C2_ && c3 == C3_ && SL_POS % k == 0 &&                     \
-        ((Lw + SL_POS - 1) / SL_POS) * b < (1ll << 30)) {                                                             \
+    if (g_sa_mode != 2 && cfeat == CF_ && c1 == C1_ && c2 == C2_ && c3 == C3_ && k % 32 == 0 && (long long)b * m < (1ll << 30)) { \
         auto kern = sa_wave_lds_kernel<CF_, C1_, C2_, C3_>;                                                            \
         constexpr int lds_bytes = sl_lds_floats<CF_, C1_, C2_, C3_>() * 4;                                             \
         static std::atomic<int> resident_of[128];              /* per device: the attribute and the occupancy are */    \
@@ -815,11 +796,12 @@ extern "C" int captra_sa_scale_fused(int b, int n, int m, int k, int cfeat, int 
             resident = (per_cu > 0 ? per_cu : 1) * (prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);    \
             resident_slot.store(resident, std::memory_order_relaxed);                                                  \
         }                                                                                                              \
-        const long long tiles = ((Lw + SL_POS - 1) / SL_POS) * b;                                                      \
+        const long long centres = (long long)b * m;            /* a wave per centre: 8 centres per workgroup round */           \
+        const long long wgs = (centres + SL_WAVES - 1) / SL_WAVES;                                                     \
         q.b = b;                                                                                                       \
-        q.work = tiles >= 6ll * resident ? captra_work_slot((hipStream_t)stream) : nullptr;                            \
-        CAPTRA_LAUNCH("sa_scale_fused", kern, dim3((unsigned)(tiles < resident ? tiles : resident)), dim3(SL_WAVES * 64), lds_bytes, \
-                      (hipStream_t)stream, q);                                                                         \
+        const unsigned grid_l = (unsigned)(wgs < resident ? wgs : resident);                                           \
+        q.work = nullptr;                                                                                              \
+        CAPTRA_LAUNCH("sa_scale_fused", kern, dim3(grid_l), dim3(SL_WAVES * 64), lds_bytes, (hipStream_t)stream, q);  \
         return captra_last_error();                                                                                    \
     }
         SL_CASE(0, 32, 32, 64)

@@ -108,7 +108,7 @@ __device__ __forceinline__ void sp_max_stage_a(const f32x16 &acc, SpMaxState &st
     for (int i = 0; i < 8; ++i) {
         const int x0 = __float_as_int(acc[2 * i]), x1 = __float_as_int(acc[2 * i + 1]);
         const int own = b0 ? x1 : x0, oth = b0 ? x0 : x1;
-        st.w[i] = sp_imax(own, sp_dpp<0xB1, 0xF>(own, oth));           // quad_perm [1,0,3,2]: lane ^ 1
+        st.w[i] = sw_imax_dpp<0xB1>(own, oth);                            // quad_perm [1,0,3,2]: lane ^ 1
     }
 }
 
@@ -119,7 +119,7 @@ __device__ __forceinline__ void sp_max_stage_bc(SpMaxState &st, int lane) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int own = b1 ? st.w[2 * j + 1] : st.w[2 * j], oth = b1 ? st.w[2 * j] : st.w[2 * j + 1];
-        v[j] = sp_imax(own, sp_dpp<0x4E, 0xF>(own, oth));               // quad_perm [2,3,0,1]: lane ^ 2
+        v[j] = sw_imax_dpp<0x4E>(own, oth);                                // quad_perm [2,3,0,1]: lane ^ 2
     }
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
@@ -138,7 +138,7 @@ __device__ __forceinline__ void sp_max_stage_d(const SpMaxState &st, int t, floa
     const int lane = (int)(threadIdx.x & 63);
     const bool b3 = lane & 8;
     const int own = b3 ? st.u[1] : st.u[0], oth = b3 ? st.u[0] : st.u[1];
-    int z = sp_imax(own, sp_dpp<0x128, 0xF>(own, oth));                  // row_ror:8: lane ^ 8 within the row
+    int z = sw_imax_dpp<0x128>(own, oth);                                   // row_ror:8: lane ^ 8 within the row
     z = z > 0 ? z : 0;                                                   // ReLU on the bit pattern
     red8_lane[32 * t * (SP_MAXCH * 8)] = __int_as_float(z);
 }

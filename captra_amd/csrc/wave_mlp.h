@@ -158,6 +158,14 @@ __device__ __forceinline__ int sw_dpp_sel(int old, int src) {
     return __builtin_amdgcn_update_dpp(old, src, CTRL, 0xF, BANK_MASK, false);
 }
 __device__ __forceinline__ int sw_imax(int a, int b) { return a > b ? a : b; }
+// max(own, oth of the partner lane) for a permutation in which EVERY lane has a source (quad_perm, row_ror): with
+// bound_ctrl and a dead `old` the compiler folds the DPP move into the max (one v_max_i32_dpp instead of
+// v_mov + v_mov_dpp + v_max)
+template <int CTRL>
+__device__ __forceinline__ int sw_imax_dpp(int own, int oth) {
+    const int o = __builtin_amdgcn_update_dpp(0, oth, CTRL, 0xF, 0xF, true);
+    return o > own ? o : own;
+}
 
 template <int COUT, int RED_STRIDE = 4>
 __device__ __forceinline__ void sw_last_epilogue_bfly(const f32x16 &acc, int t, float *red, int wave, int lane) {
@@ -167,12 +175,12 @@ __device__ __forceinline__ void sw_last_epilogue_bfly(const f32x16 &acc, int t, 
     for (int i = 0; i < 8; ++i) {
         const int x0 = __float_as_int(acc[2 * i]), x1 = __float_as_int(acc[2 * i + 1]);
         const int own = b0 ? x1 : x0, oth = b0 ? x0 : x1;
-        w[i] = sw_imax(own, sw_dpp_sel<0xB1, 0xF>(own, oth));           // quad_perm [1,0,3,2]: lane ^ 1
+        w[i] = sw_imax_dpp<0xB1>(own, oth);                             // quad_perm [1,0,3,2]: lane ^ 1
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int own = b1 ? w[2 * j + 1] : w[2 * j], oth = b1 ? w[2 * j] : w[2 * j + 1];
-        v[j] = sw_imax(own, sw_dpp_sel<0x4E, 0xF>(own, oth));           // quad_perm [2,3,0,1]: lane ^ 2
+        v[j] = sw_imax_dpp<0x4E>(own, oth);                             // quad_perm [2,3,0,1]: lane ^ 2
     }
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
@@ -182,13 +190,47 @@ __device__ __forceinline__ void sw_last_epilogue_bfly(const f32x16 &acc, int t, 
         u[m] = sw_imax(own, q);
     }
     const int own = b3 ? u[1] : u[0], oth = b3 ? u[0] : u[1];
-    int z = sw_imax(own, sw_dpp_sel<0x128, 0xF>(own, oth));              // row_ror:8: lane ^ 8 within the row of 16
+    int z = sw_imax_dpp<0x128>(own, oth);                                // row_ror:8: lane ^ 8 within the row of 16
     z = sw_imax(z, __builtin_amdgcn_ds_swizzle(z, 0x401F));              // lane ^ 16: the other row of the half-wave
     z = z > 0 ? z : 0;                                                   // ReLU on the bit pattern
     // lane l (l & 16 == 0) holds accumulator register r = l & 15 = output row 32 t + 8 (r >> 2) + (r & 3) + 4 (l >> 5)
     const int r = lane & 15;
     const int row = 32 * t + 8 * (r >> 2) + (r & 3) + 4 * (lane >> 5);
     if ((lane & 16) == 0 && row < COUT) red[row * RED_STRIDE + wave] = __int_as_float(z);
+}
+
+// The butterfly up to its row-of-16 stage, folded into a RUNNING maximum: zrun's lane l holds, for accumulator register
+// (l & 15), the maximum over the row of 16 lanes and over every 32-position slice passed so far.  A wave that walks all K
+// neighbours of a centre itself (K / 32 slices) needs no LDS and no barrier for the max: sw_bfly_finish joins the two rows
+// of a half-wave once per centre.  zrun starts at 0, which is the ReLU.
+__device__ __forceinline__ void sw_bfly_accumulate(const f32x16 &acc, int &zrun, int lane) {
+    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
+    int w[8], v[4], u[2];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int x0 = __float_as_int(acc[2 * i]), x1 = __float_as_int(acc[2 * i + 1]);
+        const int own = b0 ? x1 : x0, oth = b0 ? x0 : x1;
+        w[i] = sw_imax_dpp<0xB1>(own, oth);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int own = b1 ? w[2 * j + 1] : w[2 * j], oth = b1 ? w[2 * j] : w[2 * j + 1];
+        v[j] = sw_imax_dpp<0x4E>(own, oth);
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int own = b2 ? v[2 * m + 1] : v[2 * m], oth = b2 ? v[2 * m] : v[2 * m + 1];
+        const int p = sw_dpp_sel<0x104, 0x5>(own, oth);
+        const int q = sw_dpp_sel<0x114, 0xA>(p, oth);
+        u[m] = sw_imax(own, q);
+    }
+    const int own = b3 ? u[1] : u[0], oth = b3 ? u[0] : u[1];
+    zrun = sw_imax(zrun, sw_imax_dpp<0x128>(own, oth));
+}
+// the finished maximum of output tile t's rows: valid in the lanes with (lane & 16) == 0, lane l = row
+// 32 t + 8 ((l & 15) >> 2) + (l & 3) + 4 (l >> 5)
+__device__ __forceinline__ float sw_bfly_finish(int zrun) {
+    return __int_as_float(sw_imax(zrun, __builtin_amdgcn_ds_swizzle(zrun, 0x401F)));     // lane ^ 16
 }
 
 // ReLU + max over the wave's 32 positions of output tile t -> red[row][wave]

@@ -1,4 +1,4 @@
-// Work tickets for the persistent kernels (sa_wave_lds_kernel, sa_wave_pipe_kernel).
+// Work tickets for the persistent SA2 kernel (sa_wave_pipe_kernel; sa_wave_lds_kernel walks its centres statically, see there).
 //
 // A persistent kernel sized to the chip hands its tiles out STATICALLY when every workgroup takes tile
 // blockIdx.x + i * gridDim.x.  That is only optimal when the kernel has the chip to itself: the track step runs its two

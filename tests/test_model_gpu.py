@@ -177,8 +177,9 @@ def test_sa_scale_pipe_bit_exact(device, chans, n, m, k, B):
 
 
 def test_persistent_sa_kernels_tickets_equal_static_walk(device):
-    """csrc/work_pool.hip: the persistent SA kernels hand their tiles out by ticket (first two tiles of a workgroup static, the
-    rest from a per-launch counter that the last workgroup resets).  Which workgroup computes a tile must not matter: ticketed
+    """csrc/work_pool.hip: the persistent SA2 kernel hands its chunks out by ticket (first two of a workgroup static, the
+    rest from a per-launch counter that the last workgroup resets; the SA1 kernel walks statically and rides along as a
+    plain regression case).  Which workgroup computes a tile must not matter: ticketed
     launches == the static walk bit for bit — on the first use of a slot, on reuse, and as a node of a replayed hipGraph
     (a captured launch keeps its slot for the life of the graph)."""
     import ctypes
