@@ -325,8 +325,6 @@ def main():
     ap.add_argument("--category", default="bottle", choices=sorted(WORKLOADS) + ["mix6"],
                     help="bottle = BASELINE.json configs[1] (the metric's configuration); the other object classes; mix6 = "
                          "BASELINE.json configs[2]'s serving mix: rank r tracks NOCS category 1 + r mod 6 with that category's weights")
-    ap.add_argument("--static-tiles", action="store_true", help=argparse.SUPPRESS)      # A/B: persistent SA kernels without tickets
-    ap.add_argument("--chunks-per-cu", type=int, default=0, help=argparse.SUPPRESS)    # A/B: ticket granularity of the SA2 kernel
     ap.add_argument("--no-pw-pair", action="store_true", help=argparse.SUPPRESS)       # A/B: dense layers without paired column tiles
     ap.add_argument("--pw-occ", type=int, default=0, help=argparse.SUPPRESS)           # A/B: dense layers' workgroups per CU (2 / 3)
     args = ap.parse_args()
@@ -340,16 +338,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"bench.py --gpus {args.gpus} launched with WORLD_SIZE={world}: the launcher must start exactly --gpus ranks")
-    if args.static_tiles or args.chunks_per_cu or args.no_pw_pair or args.pw_occ:
+    if args.no_pw_pair or args.pw_occ:
         from captra_amd import _lib as _knobs
         if args.pw_occ:
             _knobs.lib().captra_pw_set_occupancy(ctypes.c_int(args.pw_occ))
         if args.no_pw_pair:
             _knobs.lib().captra_pw_set_pair(ctypes.c_int(0))
-        if args.static_tiles:
-            _knobs.lib().captra_sa_set_dynamic_tiles(ctypes.c_int(0))
-        if args.chunks_per_cu:
-            _knobs.lib().captra_sa_set_chunks_per_cu(ctypes.c_int(args.chunks_per_cu))
     if args.category == "mix6":
         args.category = MIX6[rank % 6]
         args.mix6 = True

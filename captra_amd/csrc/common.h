@@ -44,10 +44,6 @@ struct CaptraDeviceOnce {
 // another thread (another GPU's stream in the same process) launches; the reference boundary has no global state.
 #define CAPTRA_KNOB thread_local
 
-// ---- work tickets of the persistent kernels (work_pool.hip) ---------------------------------------
-// a {next ticket, workgroups done} slot for ONE launch on `stream`, or nullptr (static tile walk)
-unsigned *captra_work_slot(hipStream_t stream);
-
 // ---- device helpers ---------------------------------------------------------------------------
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() is a full workgroup-scope fence: its s_waitcnt also waits
 // for every global load and STORE the wave has in flight (a store's acknowledgement takes microseconds), which a barrier that

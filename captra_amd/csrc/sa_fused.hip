@@ -327,7 +327,6 @@ struct SwParams {
     int out_ctotal, co_off;
     const float *v1;           // PRE kernels: (B,C1,N) = b1 + W1[feature rows] * feat per source point, else null
     unsigned long long *prof;  // debug: per-phase wave-cycle totals of a sample of waves (sa_wave_kernel), else null
-    unsigned *work;            // persistent kernels: {next ticket, workgroups done} of this launch (work_pool.hip), or null
 };
 
 #define SW_TICK(slot)                                                         \
@@ -643,10 +642,10 @@ __global__ __launch_bounds__(SL_WAVES * 64) __attribute__((amdgpu_waves_per_eu(4
     // traffic for the max, no read-out pass, and the waves of a SIMD drift out of phase with each other (one's epilogue
     // under another's MFMAs) instead of meeting twice per tile.  Against the workgroup-tile form (8 waves x 32 positions,
     // maxima combined through LDS, two barriers per tile) at 32 clouds: 647 -> 635, 260 -> 237, 50.5 -> 45.7 us for the
-    // three SA1 scales.  Centres are walked statically (gid, gid + nwaves, ...): every wave gets the same number, and
-    // per-wave work tickets (work_pool.hip) were measured worse here -- a centre is the unit, so the launch ends up to a
-    // whole centre (4 slices, ~150 us with four waves per SIMD) late, and the atomic's return is waited for at every
-    // centre end (674 / 298 / 210 us).
+    // three SA1 scales.  Centres are walked statically (gid, gid + nwaves, ...): every wave gets the same number.  Handing
+    // centres out through a per-launch atomic counter instead was measured worse -- a centre is the unit, so the launch
+    // ends up to a whole centre (4 slices, ~150 us with four waves per SIMD) late, and the atomic's return is waited for
+    // at every centre end (674 / 298 / 210 us).
     const int nwaves = (int)gridDim.x * SL_WAVES, gid = (int)blockIdx.x * SL_WAVES + wave;
     const int ncentres = p.b * p.m;                       // < 2^30 (launcher)
     const int nslices = p.k / 32;
@@ -774,7 +773,7 @@ extern "C" int captra_sa_scale_fused(int b, int n, int m, int k, int cfeat, int 
         // PointNet2Msg config); any other shape takes the generic LDS kernel below
         SwParams q;
         q.b = b; q.n = n; q.m = m; q.k = k; q.feat = feat; q.xyz_cn = xyz_cn; q.new_xyz = new_xyz; q.idx = idx;
-        q.w1 = w1; q.b1 = b1; q.w2 = w2; q.b2 = b2; q.w3 = w3; q.b3 = b3; q.out = out; q.out_ctotal = out_ctotal; q.co_off = co_off; q.v1 = nullptr; q.prof = g_sa_prof; q.work = nullptr;
+        q.w1 = w1; q.b1 = b1; q.w2 = w2; q.b2 = b2; q.w3 = w3; q.b3 = b3; q.out = out; q.out_ctotal = out_ctotal; q.co_off = co_off; q.v1 = nullptr; q.prof = g_sa_prof;
         const long long Lw = (long long)m * k;
         dim3 gridw((unsigned)((Lw + SF_POS - 1) / SF_POS), b);
         // small-input scales: persistent workgroups with the weights resident in LDS (mode 2 = streaming kernel for all)
@@ -800,7 +799,7 @@ extern "C" int captra_sa_scale_fused(int b, int n, int m, int k, int cfeat, int 
         const long long wgs = (centres + SL_WAVES - 1) / SL_WAVES;                                                     \
         q.b = b;                                                                                                       \
         const unsigned grid_l = (unsigned)(wgs < resident ? wgs : resident);                                           \
-        q.work = nullptr;                                                                                              \
+                                                                                                     \
         CAPTRA_LAUNCH("sa_scale_fused", kern, dim3(grid_l), dim3(SL_WAVES * 64), lds_bytes, (hipStream_t)stream, q);  \
         return captra_last_error();                                                                                    \
     }
@@ -863,7 +862,7 @@ extern "C" int captra_sa_scale_pre(int b, int n, int m, int k, int cfeat, int c1
     SwParams q;
     q.b = b; q.n = n; q.m = m; q.k = k; q.feat = nullptr; q.xyz_cn = xyz_cn; q.new_xyz = new_xyz; q.idx = idx;
     q.w1 = w1; q.b1 = b2 /* unused by the PRE kernels: any valid packed bias */; q.w2 = w2; q.b2 = b2; q.w3 = w3; q.b3 = b3;
-    q.out = out; q.out_ctotal = out_ctotal; q.co_off = co_off; q.v1 = v1; q.prof = g_sa_prof; q.work = nullptr;
+    q.out = out; q.out_ctotal = out_ctotal; q.co_off = co_off; q.v1 = v1; q.prof = g_sa_prof;
     const long long Lw = (long long)m * k;
     dim3 gridw((unsigned)((Lw + SF_POS - 1) / SF_POS), b);
 #define SWP_CASE(CF_, C1_, C2_, C3_)                                                                                       \

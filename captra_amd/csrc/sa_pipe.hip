@@ -8,23 +8,25 @@
 //   * the epilogues between output-tile passes (ReLU + permlane swap; ReLU + five DPP max steps + LDS): ~9 %,
 //   * late weight sets (one 16-register set = 1024 MFMA cycles of lead against an L2 hit under load): ~7 %.
 // Here the same k-ascending fmaf chains (bit-identical results) are scheduled so that the matrix pipe always has work:
-//   1. persistent workgroups walk tiles; the NEXT tile's neighbour ids, centre and accumulator start values are fetched
-//      while the current tile's layers 2 / 3 run (the gather costs registers, not time).  v1 is read POINT-major
-//      (B,N,C1; written that way by captra_pointwise_mlp_pm): the four accumulator rows a lane needs are one 16-byte
-//      load, a wave-tile touches 128 cache lines instead of up to 4096;
+//   1. a WAVE owns a centre and walks its K neighbours in K / 32 slices (static walk over the centres); the NEXT slice's
+//      neighbour ids, centre and accumulator start values are fetched while the current slice's layers 2 / 3 run (the
+//      gather costs registers, not time).  v1 is read POINT-major (B,N,C1; written that way by captra_pointwise_mlp_pm):
+//      the four accumulator rows a lane needs are one 16-byte load, a slice touches 128 cache lines instead of up to 4096;
 //   2. every pass's epilogue is deferred by one pass and issued in parts behind the next pass's MFMA blocks (two
 //      accumulator pairs alternate), only a layer's last pass is exposed;
 //   3. weight sets stream two sets (2048 MFMA cycles) ahead through a ring of three;
-//   4. a workgroup keeps the maxima of CH consecutive tiles in LDS and writes each output row's CH..2CH consecutive
-//      centres at once (the old kernel's 4-byte stores strided along M hit one 32-byte sector each: 8x write traffic).
+//   4. the last layer's maximum over the centre's slices stays in registers (a transpose-reduce butterfly per slice folded
+//      into a running maximum, sw_bfly_finish once per centre): no LDS, no barrier after start-up.  (Round 2 first staged
+//      the maxima of chunks of 8 tiles in LDS and wrote consecutive centres per row -- one barrier per chunk -- and handed
+//      chunks out through an atomic ticket counter; the wave-per-centre form is 1-2 % faster in the step and needs
+//      neither.  The 4-byte stores strided along M it brings back are merged in L2: WRITE_SIZE stays near the output size.)
 // Replaces nothing of the reference one-to-one: it is the body of PointNetSetAbstractionMsg.forward's loop over radii
 // (pointnet_utils.py:228-248) for the SA2 shapes, as sa_wave_kernel is.
 #include "wave_mlp.h"
 
 namespace {
 
-constexpr int SP_POS = 128;   // positions per workgroup tile: 4 waves x 32 neighbours
-constexpr int SP_MAXCH = 8;   // tiles whose maxima a workgroup stages before it writes them out
+constexpr int SP_POS = 128;   // the launcher's tiling unit (M*K must be a multiple of it: shapes of the backbone)
 
 struct SpParams {
     int b, n, m, k;
@@ -36,11 +38,7 @@ struct SpParams {
     const float *w2, *b2, *w3, *b3;   // packed (row-major + fragment images); layers 2 / 3 stream the fragment image
     float *out;             // (B,out_ctotal,M)
     int out_ctotal, co_off;
-    int tiles_per_cloud;    // M*K / 128
-    int chunk;              // tiles per staged output chunk (1..SP_MAXCH), divides tiles_per_cloud
-    long long chunks;       // B * tiles_per_cloud / chunk
     unsigned long long *prof;  // debug: per-phase wave-cycle totals of a sample of workgroups (captra_sa_fused_set_prof), or null
-    unsigned *work;            // {next ticket, workgroups done} of this launch (work_pool.hip), or null = static chunk walk
 };
 
 #define SP_TICK(slot)                                                           \
@@ -131,20 +129,18 @@ __device__ __forceinline__ void sp_max_stage_bc(SpMaxState &st, int lane) {
     }
 }
 
-// stage D + ReLU + store: lane l of a row of 16 ends with accumulator register (l & 15) = output row
-// 32 t + 8 (r >> 2) + (r & 3) + 4 (l >> 5), maximum over the row's 16 positions -> red8[row][2 wave + row-of-16 in the half]
-__device__ __forceinline__ void sp_max_stage_d(const SpMaxState &st, int t, float *red8_lane) {
-    // red8_lane = red8 + (lane's row within a tile) * 8 + 2 * wave + ((lane >> 4) & 1), computed once per kernel
+// stage D, folded into the centre's running maximum: zr's lane l holds, for accumulator register (l & 15) = output row
+// 32 t + 8 (r >> 2) + (r & 3) + 4 (l >> 5), the maximum over the row of 16 lanes and over every slice so far (zr starts at
+// 0 = the ReLU; the two rows of 16 of a half-wave are joined once per centre, sw_bfly_finish)
+__device__ __forceinline__ void sp_max_stage_d(const SpMaxState &st, int &zr) {
     const int lane = (int)(threadIdx.x & 63);
     const bool b3 = lane & 8;
     const int own = b3 ? st.u[1] : st.u[0], oth = b3 ? st.u[0] : st.u[1];
-    int z = sw_imax_dpp<0x128>(own, oth);                                   // row_ror:8: lane ^ 8 within the row
-    z = z > 0 ? z : 0;                                                   // ReLU on the bit pattern
-    red8_lane[32 * t * (SP_MAXCH * 8)] = __int_as_float(z);
+    zr = sw_imax(zr, sw_imax_dpp<0x128>(own, oth));                        // row_ror:8: lane ^ 8 within the row
 }
 
-template <int COUT, bool LAST, int NPARTS, int NOUT>
-__device__ __forceinline__ void sp_epi_part(const f32x16 (&acc)[2], int ps, int c, float (&hout)[NOUT], float *red8_lane,
+template <int COUT, bool LAST, int NPARTS, int NOUT, int NZ>
+__device__ __forceinline__ void sp_epi_part(const f32x16 (&acc)[2], int ps, int c, float (&hout)[NOUT], int (&zrun)[NZ],
                                             SpMaxState (&mst)[2], int lane) {
     constexpr int NT = (COUT + 31) / 32;
     if constexpr (LAST) {
@@ -153,13 +149,9 @@ __device__ __forceinline__ void sp_epi_part(const f32x16 (&acc)[2], int ps, int 
         for (int u = 0; u < 6; ++u)
             if (u * NPARTS / 6 == c && 2 * ps + u / 3 < NT) {
                 const int tm = u / 3;
-#if defined(SP_EXP) && (SP_EXP & 4)
-                if (u % 3 == 2) red8_lane[32 * (2 * ps + tm) * (SP_MAXCH * 8)] = acc[tm][0] + acc[tm][5] + acc[tm][10] + acc[tm][15];   // EXPERIMENT: no max
-                continue;
-#endif
                 if (u % 3 == 0) sp_max_stage_a(acc[tm], mst[tm], lane);
                 else if (u % 3 == 1) sp_max_stage_bc(mst[tm], lane);
-                else sp_max_stage_d(mst[tm], 2 * ps + tm, red8_lane);
+                else sp_max_stage_d(mst[tm], zrun[2 * ps + tm < NZ ? 2 * ps + tm : 0]);
             }
     } else {
 #pragma unroll
@@ -177,9 +169,9 @@ __device__ __forceinline__ void sp_epi_part(const f32x16 (&acc)[2], int ps, int 
 // s[3]: the set of step g is s[(START + g) % 3]; this layer's first set must already be on its way (previous phase), the
 // following layer's first set is requested through `next(s[(START + STEPS) % 3])` two steps before the end.  `side(g)` runs
 // once per step before the MFMA block (the kernel hangs the next tile's prefetch on it).
-template <int CIN, int COUT, bool LAST, int START, int NIN, int NOUT, typename Next, typename Side>
+template <int CIN, int COUT, bool LAST, int START, int NIN, int NOUT, int NZ, typename Next, typename Side>
 __device__ __forceinline__ void sp_layer(const float *wt, const float *bias_lds, const float (&hin)[NIN], float (&hout)[NOUT],
-                                         float (&s)[3][16], float *red8_lane, int lane, Next next, Side side) {
+                                         float (&s)[3][16], int (&zrun)[NZ], int lane, Next next, Side side) {
     using S = SwShape<CIN, COUT>;
     static_assert(NIN >= S::KST, "input operand array too small");
     const __amdgpu_buffer_rsrc_t rsrc = sw_frag_rsrc<CIN, COUT>(wt);
@@ -212,12 +204,12 @@ __device__ __forceinline__ void sp_layer(const float *wt, const float *bias_lds,
         __builtin_amdgcn_sched_barrier(0);
         if (c == S::NSETS - 1 && ps + 1 < S::NPASS) {     // EXPERIMENT: epilogue right after its pass (not deferred)
 #pragma unroll
-            for (int cc = 0; cc < S::NSETS; ++cc) sp_epi_part<COUT, LAST, S::NSETS>(acc[pb], ps, cc, hout, red8_lane, mst, lane);
+            for (int cc = 0; cc < S::NSETS; ++cc) sp_epi_part<COUT, LAST, S::NSETS>(acc[pb], ps, cc, hout, zrun, mst, lane);
         }
 #else
         // the previous pass's epilogue, one part per step: issued behind this step's MFMAs, it runs while they execute
         if (ps > 0) {
-            sp_epi_part<COUT, LAST, S::NSETS>(acc[pb ^ 1], ps - 1, c, hout, red8_lane, mst, lane);
+            sp_epi_part<COUT, LAST, S::NSETS>(acc[pb ^ 1], ps - 1, c, hout, zrun, mst, lane);
 #if !(defined(SP_EXP) && (SP_EXP & 8))
             // one MFMA, then a few of the part's VALU instructions, sixteen times: each of them issues while an MFMA executes
             // (left to itself the scheduler puts the whole part behind the block, where only the last MFMA covers it)
@@ -233,7 +225,7 @@ __device__ __forceinline__ void sp_layer(const float *wt, const float *bias_lds,
     }
     constexpr int LP = S::NPASS - 1;
 #pragma unroll
-    for (int c = 0; c < S::NSETS; ++c) sp_epi_part<COUT, LAST, S::NSETS>(acc[LP & 1], LP, c, hout, red8_lane, mst, lane);
+    for (int c = 0; c < S::NSETS; ++c) sp_epi_part<COUT, LAST, S::NSETS>(acc[LP & 1], LP, c, hout, zrun, mst, lane);
 }
 
 template <int CF, int C1, int C2, int C3>
@@ -244,28 +236,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     constexpr int NT1 = S1::NT;
     static_assert(NT1 <= 4 && C1 % 32 == 0, "first-layer width");
     __shared__ __attribute__((aligned(16))) float bias_lds[2 * 256];       // packed b2, b3 (zero padded)
-    // chunks: the first is blockIdx.x, further ones by ticket (p.work, work_pool.hip) or the static walk.  A wave needs the
-    // NEXT chunk's id before its last tile of this chunk (it prefetches that chunk's first tile) and the waves only meet at
-    // the chunk barrier, so tickets are drawn TWO chunks ahead: next_chunk[par] was written before the last barrier.
-    __shared__ int next_chunk[2];
-    // maxima of a CHUNK of tiles: [chunk parity][row][tile of the chunk][2 * wave + row-of-16].  The four waves of a
-    // workgroup meet once per chunk, not once per tile (a per-tile barrier cost ~3 k cycles of waiting for the slowest
-    // wave); two buffers, so the next chunk's first tile may write while this chunk is still being read out.
-    extern __shared__ __attribute__((aligned(16))) float red[];              // 2 * pad32c(C3) * SP_MAXCH * 8 floats
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const long long L = (long long)p.m * p.k;
-    const int groups = SP_POS / p.k, tiles_per_group = p.k / 32;            // centres per tile, waves per centre
-    const int cpc = p.chunk * groups;                                        // centres per chunk
 
-    // (two static chunks first: the launch's first draw, all workgroups at once, resolves under the first chunk's work)
-    auto draw = [&](int after) { return p.work != nullptr ? (int)(2 * gridDim.x + atomicAdd(p.work, 1u)) : after + (int)gridDim.x; };
-    if (tid == 0) next_chunk[0] = (int)(blockIdx.x + gridDim.x);
     for (int e = tid; e < 2 * 256; e += 256) {
         const int c = e & 255;
         bias_lds[e] = e < 256 ? (c < pad128c(C2) ? p.b2[c] : 0.f) : (c < pad128c(C3) ? p.b3[c] : 0.f);
     }
-    // first layer's xyz rows of W1 (A operands of its two k-steps): the same for every tile
+    // first layer's xyz rows of W1 (A operands of its two k-steps): the same for every slice
     float at[2][NT1];
     {
         const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)p.w1, 0, S1::KP * S1::LDW * 4, 0x00020000);
@@ -278,18 +256,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     __syncthreads();
 
-    // a tile's per-lane inputs: neighbour id, relative xyz operands, accumulator start values (gathered v1 rows)
+    // A WAVE owns a centre (as in sa_wave_lds_kernel): it walks the centre's K neighbours in K / 32 slices and keeps the
+    // last layer's running maximum in registers, so the four waves of a workgroup share nothing but the biases: no LDS
+    // staging of maxima, no chunk barrier, no read-out pass.  Centres are walked statically: gid, gid + nwaves, ...
+    const int nwaves = (int)gridDim.x * 4, gid = (int)blockIdx.x * 4 + wave;
+    const int ncentres = p.b * p.m;                       // < 2^30 (launcher)
+    const int nslices = p.k / 32;
+    // a slice's per-lane inputs: neighbour id, relative xyz operands, accumulator start values (gathered v1 rows)
     int id = 0;
     float bt[2] = {0.f, 0.f};
     float4 g4[NT1][4];
-    auto tile_of = [&](int chunk_id, int j, int &tb, int &pos0) {     // 32-bit: tiles < 2^31 / 128 (checked by the launcher)
-        const int tile = chunk_id * p.chunk + j;
-        tb = tile / p.tiles_per_cloud;
-        pos0 = (tile - tb * p.tiles_per_cloud) * SP_POS;
-    };
-    auto load_id = [&](int tb, int pos0) { return p.idx[(size_t)tb * L + pos0 + wave * 32 + (lane & 31)]; };
-    auto load_rest = [&](int tb, int pos0, int id_, float (&bt_)[2], float4 (&g_)[NT1][4]) {
-        const float *cp = p.new_xyz + ((size_t)tb * p.m + (int)((pos0 + wave * 32) / p.k)) * 3;
+    auto load_id = [&](int c, int sl) { return p.idx[(size_t)c * p.k + sl * 32 + (lane & 31)]; };
+    auto load_rest = [&](int c, int id_, float (&bt_)[2], float4 (&g_)[NT1][4]) {
+        const int tb = c / p.m;
+        const float *cp = p.new_xyz + (size_t)c * 3;
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
             const int a = 2 * jj + half;
@@ -302,119 +282,87 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             for (int q = 0; q < 4; ++q) g_[t][q] = vp[8 * t + 2 * q];       // rows 32t + 8q + 4 half + (0..3)
     };
 
-    // this lane's slot in red for the butterfly's final register: accumulator register (lane & 15) of a tile
-    const int red_lane_off = (8 * ((lane & 15) >> 2) + (lane & 3) + 4 * half) * (SP_MAXCH * 8) + 2 * wave + ((lane >> 4) & 1);
-    constexpr int RED_BUF = pad32c(C3) * SP_MAXCH * 8;
     const bool sampled = blockIdx.x % 16 == 0;
     unsigned long long t_last = p.prof != nullptr ? __builtin_amdgcn_s_memtime() : 0ull;
     float s[3][16];
     constexpr int START3 = S2::STEPS % 3;                     // ring slot of layer 3's first set (layer 2 starts in slot 0)
-    constexpr int NEXT2 = (START3 + S3::STEPS) % 3;            // slot in which layer 3 leaves the NEXT tile's first layer-2 set
-    int chunk_id = blockIdx.x;
-    const int nchunks = (int)p.chunks;
-    int par = 0;
-    if (chunk_id < nchunks) {
+    constexpr int NEXT2 = (START3 + S3::STEPS) % 3;            // slot in which layer 3 leaves the NEXT slice's first layer-2 set
+    int zrun[S3::NT];
+    int c = gid, sl = 0;
+    if (c < ncentres) {
         sw_first_set<C1, C2>(s[NEXT2], p.w2, lane);
-        int tb, pos0;
-        tile_of(chunk_id, 0, tb, pos0);
-        id = load_id(tb, pos0);
-        load_rest(tb, pos0, id, bt, g4);
+        id = load_id(c, 0);
+        load_rest(c, id, bt, g4);
     }
-    while (chunk_id < nchunks) {
-        const int chunk_n = next_chunk[par];
-        // the ticket of the chunk after next (tickets past the end are simply not used): drawn now, stored to LDS only
-        // before this chunk's barrier, so that wave 0 does not wait for the atomic's return in front of its first tile
-        const int chunk_nn = tid == 0 ? draw(chunk_n) : 0;
-        int cb, cpos0;
-        tile_of(chunk_id, 0, cb, cpos0);
-        for (int j = 0; j < p.chunk; ++j) {
-            // ---- what comes after this tile (wave-uniform) ----
-            const bool last_in_chunk = j + 1 == p.chunk;
-            const int nchunk = last_in_chunk ? chunk_n : chunk_id;
-            const bool has_next = nchunk < nchunks;
-            int nb = 0, npos0 = 0;
-            if (has_next) tile_of(nchunk, last_in_chunk ? 0 : j + 1, nb, npos0);
-            int id_n = 0;
+    while (c < ncentres) {
+        if (sl == 0) {
+#pragma unroll
+            for (int t = 0; t < S3::NT; ++t) zrun[t] = 0;          // (0 = the ReLU)
+        }
+        // ---- what comes after this slice (wave-uniform) ----
+        const bool last_slice = sl + 1 == nslices;
+        const int cn = last_slice ? c + nwaves : c, sn = last_slice ? 0 : sl + 1;
+        const bool has_next = cn < ncentres;
+        int id_n = 0;
 
-            float h1[S2::KST], h2[S3::KST], none[1];
-            SP_TICK(0)
-            // layer 2's first weight set was requested two steps before the previous tile ended: move it to slot 0
-            if (NEXT2 != 0) {
+        float h1[S2::KST], h2[S3::KST], none[1];
+        SP_TICK(0)
+        // layer 2's first weight set was requested two steps before the previous slice ended: move it to slot 0
+        if (NEXT2 != 0) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) s[0][i] = s[NEXT2][i];
+            for (int i = 0; i < 16; ++i) s[0][i] = s[NEXT2][i];
+        }
+        // ---- layer 1: the chain continues from the gathered start values with the two relative-xyz k-steps ----
+        {
+            f32x16 acc[NT1];
+#pragma unroll
+            for (int t = 0; t < NT1; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    acc[t][4 * q + 0] = g4[t][q].x; acc[t][4 * q + 1] = g4[t][q].y;
+                    acc[t][4 * q + 2] = g4[t][q].z; acc[t][4 * q + 3] = g4[t][q].w;
+                }
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int t = 0; t < NT1; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(at[jj][t], bt[jj], acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT1; ++t) sw_mid_epilogue<S2::KST>(acc[t], t, h1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        SP_TICK(1)
+        // ---- layer 2; its second step asks for the next slice's neighbour ids ----
+        sp_layer<C1, C2, false, 0>(p.w2, bias_lds, h1, h2, s, zrun, lane,
+                                   [&](float (&dst)[16]) { sw_first_set<C2, C3>(dst, p.w3, lane); },
+                                   [&](int g) { if (g == 1 && has_next) id_n = load_id(cn, sn); });
+        SP_TICK(2)
+        // ---- layer 3 + running max over the slices; its third step gathers the next slice's start values ----
+        sp_layer<C2, C3, true, START3>(p.w3, bias_lds + 256, h2, none, s, zrun, lane,
+                                       [&](float (&dst)[16]) { sw_first_set<C1, C2>(dst, p.w2, lane); },
+                                       [&](int g) { if (g == 2 && has_next) load_rest(cn, id_n, bt, g4); });
+        id = id_n;
+        SP_TICK(3)
+        if (p.prof != nullptr && lane == 0 && sampled) atomicAdd(p.prof + 9, 1ull);
+        if (last_slice) {
+            // the centre's maxima: lane l with (l & 16) == 0 holds row 32 t + 8 ((l & 15) >> 2) + (l & 3) + 4 (l >> 5) of tile t
+            const int tb = c / p.m, centre = c - tb * p.m;
+            const int r = lane & 15;
+            const int row0 = 8 * (r >> 2) + (r & 3) + 4 * half;
+            float *op = p.out + ((size_t)tb * p.out_ctotal + p.co_off + row0) * p.m + centre;
+#pragma unroll
+            for (int t = 0; t < S3::NT; ++t) {
+                const float v = sw_bfly_finish(zrun[t]);
+                if ((lane & 16) == 0 && 32 * t + row0 < C3) op[(size_t)32 * t * p.m] = v;
             }
-            // ---- layer 1: the chain continues from the gathered start values with the two relative-xyz k-steps ----
-            {
-                f32x16 acc[NT1];
-#pragma unroll
-                for (int t = 0; t < NT1; ++t)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        acc[t][4 * q + 0] = g4[t][q].x; acc[t][4 * q + 1] = g4[t][q].y;
-                        acc[t][4 * q + 2] = g4[t][q].z; acc[t][4 * q + 3] = g4[t][q].w;
-                    }
-#pragma unroll
-                for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                    for (int t = 0; t < NT1; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(at[jj][t], bt[jj], acc[t], 0, 0, 0);
-#pragma unroll
-                for (int t = 0; t < NT1; ++t) sw_mid_epilogue<S2::KST>(acc[t], t, h1);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            SP_TICK(1)
-            // ---- layer 2; its second step asks for the next tile's neighbour ids ----
-            sp_layer<C1, C2, false, 0>(p.w2, bias_lds, h1, h2, s, red + par * RED_BUF + red_lane_off + j * 8, lane,
-                                       [&](float (&dst)[16]) { sw_first_set<C2, C3>(dst, p.w3, lane); },
-                                       [&](int g) { if (g == 1 && has_next) id_n = load_id(nb, npos0); });
-            SP_TICK(2)
-            // ---- layer 3 + max over the 32 neighbours; its third step gathers the next tile's start values ----
-            sp_layer<C2, C3, true, START3>(p.w3, bias_lds + 256, h2, none, s, red + par * RED_BUF + red_lane_off + j * 8, lane,
-                                           [&](float (&dst)[16]) { sw_first_set<C1, C2>(dst, p.w2, lane); },
-#if defined(SP_EXP) && (SP_EXP & 2)
-                                           [&](int) {});
-            if (has_next) load_rest(nb, npos0, id_n, bt, g4);   // EXPERIMENT: gather after layer 3 (exposed)
-#else
-                                           [&](int g) { if (g == 2 && has_next) load_rest(nb, npos0, id_n, bt, g4); });
-#endif
-            id = id_n;
-            SP_TICK(3)
-            if (p.prof != nullptr && lane == 0 && sampled) atomicAdd(p.prof + 9, 1ull);
+            SP_TICK(4)
         }
-        if (tid == 0) next_chunk[par ^ 1] = chunk_nn;
-        __syncthreads();                             // every wave's maxima of the chunk's tiles are in red[par]
-        const int centre0 = cpos0 / p.k;             // first centre of the chunk (a chunk never straddles clouds)
-        const float *rb = red + par * RED_BUF;
-        for (int e = tid; e < C3 * cpc; e += 256) {
-            const int row = e / cpc, ci = e % cpc;   // consecutive threads = consecutive centres of one output row
-            const float *rp = rb + (row * SP_MAXCH + ci / groups) * 8 + (ci % groups) * 2 * tiles_per_group;
-            float v = rp[0];                         // 2 slots (rows of 16 lanes) per wave of the centre
-            for (int tt = 1; tt < 2 * tiles_per_group; ++tt) v = fmaxf(v, rp[tt]);
-            p.out[((size_t)cb * p.out_ctotal + p.co_off + row) * p.m + centre0 + ci] = v;
-        }
-        par ^= 1;
-        chunk_id = chunk_n;
-        SP_TICK(4)
-        // (this buffer is written again two chunks from now, after the next chunk's barrier: every thread has left by then)
-    }
-    // the last workgroup to leave hands the slot back clean (the next launch using it is ordered after this one)
-    if (p.work != nullptr && tid == 0) {              // (thread 0 drew every ticket of this workgroup itself)
-        __threadfence();
-        if (atomicAdd(p.work + 1, 1u) == gridDim.x - 1) {
-            atomicExch(p.work, 0u);
-            atomicExch(p.work + 1, 0u);
-        }
+        c = cn; sl = sn;
     }
 }
 
 }  // namespace
 
 extern unsigned long long *captra_sa_prof_ptr();   // sa_fused.hip: the debug counters set by captra_sa_fused_set_prof
-
-// experiment knob (not part of the reference boundary): chunks per CU the ticketed launch aims for.  2: at 32 clouds the
-// chunks stay 8 tiles long and the walk static (tickets start at 3 rounds of chunks = 48+ clouds); with 4 the chunks
-// shrink to 4 / 2 tiles and the extra chunk barriers cost 2.5-3.7 % of the kernel (5391 against 5407 frames/s on the step)
-static CAPTRA_KNOB int g_sp_chunks_per_cu = 2;
-extern "C" void captra_sa_set_chunks_per_cu(int n) { g_sp_chunks_per_cu = n < 1 ? 1 : n; }
 
 // SA scale with a pre-transformed, POINT-major first layer (see include/captra_hip.h): v1pm (B,N,c1).
 // -2: shape not instantiated / not tileable (the caller takes captra_sa_scale_pre).
@@ -431,7 +379,6 @@ extern "C" int captra_sa_scale_pre_pm(int b, int n, int m, int k, int cfeat, int
     SpParams q;
     q.b = b; q.n = n; q.m = m; q.k = k; q.v1pm = v1pm; q.xyz_cn = xyz_cn; q.new_xyz = new_xyz; q.idx = idx;
     q.w1 = w1; q.w2 = w2; q.b2 = b2; q.w3 = w3; q.b3 = b3; q.out = out; q.out_ctotal = out_ctotal; q.co_off = co_off;
-    q.tiles_per_cloud = (int)(L / SP_POS);
     q.prof = captra_sa_prof_ptr();
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
@@ -442,31 +389,15 @@ extern "C" int captra_sa_scale_pre_pm(int b, int n, int m, int k, int cfeat, int
         cus = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
         cus_of[dev & 127].store(cus, std::memory_order_relaxed);
     }
-    // one workgroup (4 waves, one per SIMD) per CU; chunks of up to SP_MAXCH consecutive tiles as long as that still gives
-    // every CU work (small batches keep single-tile chunks: latency first)
-    // With tickets (work_pool.hip) a chunk is also the unit of load balance between the CUs that actually run: aim for
-    // g_sp_chunks_per_cu chunks per CU then (the first two of a workgroup are static, so fewer than three rounds of chunks
-    // leave nothing to hand out: static walk).
-    const long long tiles = (long long)b * q.tiles_per_cloud;
-    auto chunk_for = [&](long long want) {
-        int c = SP_MAXCH;
-        while (c > 1 && (q.tiles_per_cloud % c != 0 || tiles / c < want)) c >>= 1;
-        return c;
-    };
-    int ch = chunk_for((long long)cus * g_sp_chunks_per_cu);
-    q.work = tiles / ch >= 3ll * cus ? captra_work_slot((hipStream_t)stream) : nullptr;
-    if (q.work == nullptr) ch = chunk_for(cus);
-    q.chunk = ch;
-    q.chunks = tiles / ch;
-    const unsigned grid = (unsigned)(q.chunks < cus ? q.chunks : cus);
+    // one workgroup (4 waves, one per SIMD) per CU; a wave per centre
+    const long long centres = (long long)b * m;
+    if (centres >= (1ll << 30)) return -2;
+    const long long wgs = (centres + 3) / 4;
+    const unsigned grid = (unsigned)(wgs < cus ? wgs : cus);
 #define SPP_CASE(CF_, C1_, C2_, C3_)                                                                                  \
     if (cfeat == CF_ && c1 == C1_ && c2 == C2_ && c3 == C3_) {                                                        \
         auto kern = sa_wave_pipe_kernel<CF_, C1_, C2_, C3_>;                                                          \
-        constexpr int lds_bytes = 2 * pad32c(C3_) * SP_MAXCH * 8 * 4;                                                 \
-        static CaptraDeviceOnce once;                                                                                 \
-        if (once.first_use())                                                                                         \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); \
-        CAPTRA_LAUNCH("sa_scale_fused", kern, dim3(grid), dim3(256), lds_bytes, (hipStream_t)stream, q);               \
+        CAPTRA_LAUNCH("sa_scale_fused", kern, dim3(grid), dim3(256), 0, (hipStream_t)stream, q);                       \
         return captra_last_error();                                                                                   \
     }
     SPP_CASE(320, 128, 128, 256)

@@ -342,7 +342,7 @@ int captra_prof_names(char *buf, int buflen);
 /* ---- 4. Experiment switches (NOT part of the stable ABI; used by tests/ and tools/ to cross-check variants that compute the
  *         same bits).  Each switch is THREAD-LOCAL: it affects launches made by the calling host thread only, so the
  *         operators above keep the reference boundary's "no global state" property for every other thread / GPU of the
- *         process.  Defaults (0; 1 for captra_pw_set_direct / captra_pw_set_pair / captra_sa_set_dynamic_tiles; 2 chunks per CU) select the production kernels. ---- */
+ *         process.  Defaults (0; 1 for captra_pw_set_direct / captra_pw_set_pair) select the production kernels. ---- */
 void captra_fps_set_waves(int waves);       /* FPS: waves per cloud (0 = heuristic) */
 void captra_fps_set_pruned_min(int n);     /* FPS: clouds of >= n points take the pruned kernel (default 8192; 0 = never) */
 void captra_fps_set_stats(unsigned long long *dev_counters); /* pruned FPS: accumulate 6 counters {bucket updates, refreshes, cycles of 4 phases} (NULL = off) */
@@ -355,8 +355,6 @@ void captra_pw_set_direct(int on);          /* dense layers: 1 = direct-operand 
 void captra_ball_query_set_prune(int on);   /* ball query: 1 = small radii of 1024..4096-point clouds from a cell grid (exact; measured slower, off by default), 0 = index-order scan */
 void captra_pw_set_occupancy(int occ);      /* dense layers, 64x64 wave tiles: workgroups per CU, 0 / 4 = as built (default), 3 / 2 = fewer (measurements) */
 void captra_pw_set_pair(int on);            /* dense layers: 1 = paired column tiles where L is even (default), 0 = never */
-void captra_sa_set_dynamic_tiles(int on);   /* persistent SA kernels: 1 = tiles handed out by ticket (default; work_pool.hip), 0 = static walk */
-void captra_sa_set_chunks_per_cu(int n);    /* sa_wave_pipe_kernel with tickets: chunks per CU the launch aims for (default 2) */
 
 #ifdef __cplusplus
 }

@@ -176,56 +176,6 @@ def test_sa_scale_pipe_bit_exact(device, chans, n, m, k, B):
     assert torch.equal(out, out2)
 
 
-def test_persistent_sa_kernels_tickets_equal_static_walk(device):
-    """csrc/work_pool.hip: the persistent SA2 kernel hands its chunks out by ticket (first two of a workgroup static, the
-    rest from a per-launch counter that the last workgroup resets; the SA1 kernel walks statically and rides along as a
-    plain regression case).  Which workgroup computes a tile must not matter: ticketed
-    launches == the static walk bit for bit — on the first use of a slot, on reuse, and as a node of a replayed hipGraph
-    (a captured launch keeps its slot for the life of the graph)."""
-    import ctypes
-    from captra_amd import _lib, fused
-    lib = _lib.lib()
-    rng = np.random.default_rng(77)
-
-    def case(cfeat, chans, n, m, k, B):
-        xyz_cn = _dev(rng.random((B, 3, n), dtype=np.float32) - 0.5, device)
-        feat = _dev(rng.standard_normal((B, cfeat, n)).astype(np.float32), device)
-        new_xyz = _dev(rng.random((B, m, 3), dtype=np.float32) - 0.5, device)
-        idx = _dev(rng.integers(0, n, (B, m, k)).astype(np.int32), device)
-        dims = (cfeat + 3,) + chans
-        packed = [fused.pack(_dev((rng.standard_normal((dims[i], dims[i + 1])) / np.sqrt(dims[i])).astype(np.float32), device),
-                             _dev(rng.standard_normal(dims[i + 1]).astype(np.float32), device)) for i in range(3)]
-        if cfeat == 320:
-            v1pm = fused.sa_first_layer_pre_pm(feat, packed[0])
-            return lambda out: fused.sa_scale_pre_pm(v1pm, xyz_cn, new_xyz, idx, packed, out, 0, cfeat), (B, chans[2], m)
-        return lambda out: fused.sa_scale_fused(feat, xyz_cn, new_xyz, idx, packed, out, 0), (B, chans[2], m)
-
-    lib.captra_sa_set_chunks_per_cu(ctypes.c_int(4))     # short chunks: the SA2 kernel takes tickets at these batch sizes too
-    try:
-        for args in [(320, (128, 196, 256), 512, 128, 128, 9), (320, (128, 128, 256), 512, 128, 64, 33), (3, (64, 96, 128), 4096, 512, 128, 13)]:
-            run, shape = case(*args)
-            lib.captra_sa_set_dynamic_tiles(ctypes.c_int(0))
-            ref = torch.full(shape, -1.0, device=device)
-            run(ref)
-            lib.captra_sa_set_dynamic_tiles(ctypes.c_int(1))
-            for _ in range(3):
-                out = torch.full(shape, -1.0, device=device)
-                run(out)
-                assert torch.equal(out, ref), args
-            out = torch.full(shape, -1.0, device=device)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                run(out)
-            for _ in range(3):
-                out.fill_(-1.0)
-                g.replay()
-                torch.cuda.synchronize()
-                assert torch.equal(out, ref), ("graph", args)
-    finally:
-        lib.captra_sa_set_dynamic_tiles(ctypes.c_int(1))
-        lib.captra_sa_set_chunks_per_cu(ctypes.c_int(2))
-
-
 def _sa_scale_fused_case(device, cfeat, chans, n, m, k):
     from captra_amd import fused
     rng = np.random.default_rng(cfeat + sum(chans) + k)

@@ -27,16 +27,9 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--radius", type=float, default=0.30)
-    ap.add_argument("--static-tiles", action="store_true", help="A/B: persistent SA kernels without work tickets")
-    ap.add_argument("--chunks-per-cu", type=int, default=0)
     args = ap.parse_args()
     dev = torch.device("cuda:0")
-    import ctypes
-    from captra_amd import _lib
-    if args.static_tiles:
-        _lib.lib().captra_sa_set_dynamic_tiles(ctypes.c_int(0))
-    if args.chunks_per_cu:
-        _lib.lib().captra_sa_set_chunks_per_cu(ctypes.c_int(args.chunks_per_cu))
+
     items = []
     for b in range(args.batch):
         depth, mask, center, pose = make_frame(1 + b % 3)
@@ -120,21 +113,6 @@ if __name__ == "__main__":
         for rep in range(5):
             track_loop(32, configs=((True, True, True), (True, True, False)))
         track_loop(32, configs=((True, False, True), (True, False, False), (False, False, True), (False, False, False)))
-        sys.exit(0)
-    if "--ab-tiles" in sys.argv:        # same process, alternating: persistent SA kernels with / without work tickets
-        import ctypes
-        from captra_amd import _lib
-        for rep in range(4):
-            for dyn, cpc in ((0, 4), (1, 4), (1, 2)):
-                _lib.lib().captra_sa_set_dynamic_tiles(ctypes.c_int(dyn))
-                _lib.lib().captra_sa_set_chunks_per_cu(ctypes.c_int(cpc))
-                print(f"[tickets {'on ' if dyn else 'off'}, {cpc} chunks per CU] ", end="")
-                track_loop(32, configs=((True, True),))
-        _lib.lib().captra_sa_set_chunks_per_cu(ctypes.c_int(2))
-        for dyn in (0, 1):
-            _lib.lib().captra_sa_set_dynamic_tiles(ctypes.c_int(dyn))
-            print(f"[tickets {'on ' if dyn else 'off'}] ", end="")
-            track_loop(32, configs=((True, False),))
         sys.exit(0)
     main()
     track_loop(32)

@@ -29,16 +29,10 @@ def main():
     ap.add_argument("--zeros", action="store_true", help="all-zero features / weights: same instruction stream at lower power (DVFS probe)")
     ap.add_argument("--mode", type=int, default=0, help="0 = register-resident kernels where instantiated, 1 = generic LDS kernel")
     ap.add_argument("--phases", action="store_true", help="debug: in-kernel s_memtime phase breakdown of sa_wave_kernel")
-    ap.add_argument("--static-tiles", action="store_true", help="persistent kernels without work tickets (A/B)")
-    ap.add_argument("--chunks-per-cu", type=int, default=0)
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     import ctypes
     _lib.lib().captra_sa_fused_set_wn(ctypes.c_int(a.wn))
-    if a.static_tiles:
-        _lib.lib().captra_sa_set_dynamic_tiles(ctypes.c_int(0))
-    if a.chunks_per_cu:
-        _lib.lib().captra_sa_set_chunks_per_cu(ctypes.c_int(a.chunks_per_cu))
     B = a.clouds
     names = list(SHAPES) if a.which == "all" else [a.which]
     for name in names:
@@ -94,8 +88,8 @@ def main():
             _lib.lib().captra_sa_fused_set_prof(ctypes.c_void_p(0))
             c = cnt.tolist()
             waves = max(c[9], 1)
-            labels = (["between", "L1", "L2", "L3", "combine"] if a.pipe else      # sa_wave_pipe_kernel: per tile
-                      ["read-out + loop top", "L1", "L2 + next gather", "L3 + max", "barriers"] if cfeat <= 3 else   # sa_wave_lds_kernel: per tile
+            labels = (["loop top", "L1", "L2", "L3", "store (per centre)"] if a.pipe else      # sa_wave_pipe_kernel: per tile
+                      ["loop top", "L1", "L2 + next gather", "L3 + max", "store (per centre)"] if cfeat <= 3 else   # sa_wave_lds_kernel: per tile
                       ["start", "L1", "L2", "L3", "end-barrier"])                 # sa_wave_kernel's timers (streamed-weight scales)
             tot = sum(c[:len(labels)]) / waves
             if c[6]:
