@@ -394,12 +394,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void p
     }
 
     float a0[TM][KS], a1[TM][KS], b0[TN][KS], b1[TN][KS];
-    // GroupNorm coefficients (a, b) of the set's k rows: the two rows of a k-step are wave-uniform, so they come through
-    // the scalar cache (one s_load per row pair) and the lane half picks its row with a select -- no vector-memory
-    // instruction, which is what the direct-operand kernels run out of first
-    float4 g0[AFF ? KS : 1], g1[AFF ? KS : 1];
-    const float2 *__restrict__ gab = reinterpret_cast<const float2 *>(AFF ? p.ab_in + (size_t)b * p.cin * 2 : p.wt);
-    const bool upper = (lane >> 5) != 0;
+    // GroupNorm coefficients (a, b) of this lane half's row of every k-step of a set: one 8-byte load per k-step (two
+    // addresses per wave).  Through the scalar cache instead (the rows are wave-uniform) the pair costs four v_mov + two
+    // v_cndmask per k-step in a kernel that is bound by the vector instructions it issues: measured 4 % slower.
+    float2 g0[AFF ? KS : 1], g1[AFF ? KS : 1];
+    const __amdgpu_buffer_rsrc_t gsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(AFF ? p.ab_in + (size_t)b * p.cin * 2 : p.wt), 0, AFF ? p.cin * 8 : 0, 0x00020000);
+    const int gvoff = (lane >> 5) * 8;
     const int nsets = (p.cin + 2 * KS - 1) / (2 * KS);
 #define PW_LOAD_SET(A, Bv, G, si)                                                                                        \
     _Pragma("unroll") for (int jq = 0; jq < KS / 4; ++jq)                                                               \
@@ -415,19 +416,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void p
             _Pragma("unroll") for (int tn = 0; tn < TN; ++tn) Bv[tn][j] = __builtin_bit_cast(                            \
                 float, __builtin_amdgcn_raw_buffer_load_b32(xsrc, xvoff[tn] + ((si) * KS + j) * xstep, 0, 0));           \
         }                                                                                                                \
-        if (AFF) {                                                                                                       \
-            const int r0 = 2 * ((si) * KS + j);                                                                          \
-            const float2 lo = gab[r0 < p.cin ? r0 : p.cin - 1], hi = gab[r0 + 1 < p.cin ? r0 + 1 : p.cin - 1];           \
-            G[j] = make_float4(lo.x, lo.y, hi.x, hi.y);                                                                  \
-        }                                                                                                                \
+        if (AFF) G[j] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(gsrc, gvoff + ((si) * KS + j) * 16, 0, 0)); \
     }                                                                                                                    \
     __builtin_amdgcn_sched_barrier(0);
 #define PW_MFMA_SET(A, Bv, G)                                                                                            \
     if (AFF) {                                                                                                           \
         _Pragma("unroll") for (int j = 0; j < KS; ++j) {                                                                \
-            const float ga = upper ? G[j].z : G[j].x, gb = upper ? G[j].w : G[j].y;                                      \
             _Pragma("unroll") for (int tn = 0; tn < TN; ++tn) {                                                         \
-                const float t = __builtin_fmaf(ga, Bv[tn][j], gb);                                                       \
+                const float t = __builtin_fmaf(G[j].x, Bv[tn][j], G[j].y);                                               \
                 Bv[tn][j] = relu_bits(t);                                                                                \
             }                                                                                                            \
         }                                                                                                                \
