@@ -142,10 +142,11 @@ def test_sa_scale_pre_bit_exact(device, chans, n, m, k):
                                            ((128, 196, 256), 200, 6, 64, 3), ((128, 128, 256), 333, 36, 32, 2),
                                            ((128, 196, 256), 700, 1, 128, 1)])
 def test_sa_scale_pipe_bit_exact(device, chans, n, m, k, B):
-    """The pipelined SA2 kernel (csrc/sa_pipe.hip: persistent workgroups, next tile's gather prefetched, deferred epilogues,
-    weight ring of three, staged output rows) on the point-major pre-transformed first layer == the oracle's gather -> 3
-    layers -> max, bit for bit: single- and multi-tile chunks, several tiles per workgroup, batches that do not fill the
-    chip, channel offsets in the output; and the point-major dense layer == the channel-major one, transposed."""
+    """The pipelined SA2 kernel (csrc/sa_pipe.hip: a wave per centre walking K/32 slices, next slice's gather prefetched,
+    deferred epilogues, weight ring of three, running maximum in registers) on the point-major pre-transformed first layer
+    == the oracle's gather -> 3 layers -> max, bit for bit: one, two and four slices per centre, several centres per wave,
+    batches that do not fill the chip, channel offsets in the output; and the point-major dense layer == the channel-major
+    one, transposed."""
     from captra_amd import fused
     cfeat = 320
     rng = np.random.default_rng(sum(chans) + n + k + B)
