@@ -45,15 +45,6 @@ struct CaptraDeviceOnce {
 #define CAPTRA_KNOB thread_local
 
 // ---- device helpers ---------------------------------------------------------------------------
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a full workgroup-scope fence: its s_waitcnt also waits
-// for every global load and STORE the wave has in flight (a store's acknowledgement takes microseconds), which a barrier that
-// only hands LDS data between waves does not need.
-__device__ __forceinline__ void lds_barrier() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-}
-
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
 // squared distance exactly as the reference kernels and the oracle write it:

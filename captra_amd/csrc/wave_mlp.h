@@ -332,7 +332,7 @@ __device__ __forceinline__ void sw_layer_reg(const float *wt, const float *bias_
 #pragma unroll
             for (int tm = 0; tm < 2; ++tm)
                 if (2 * ps + tm < S::NT) {
-                    if (EPI == SW_EPI_MAX) sw_last_epilogue<COUT>(acc[tm], 2 * ps + tm, red, wave, lane);
+                    if (EPI == SW_EPI_MAX) sw_last_epilogue_bfly<COUT>(acc[tm], 2 * ps + tm, red, wave, lane);
                     else if (EPI == SW_EPI_STORE) sw_store_epilogue<COUT>(acc[tm], 2 * ps + tm, st, lane);
                     else sw_mid_epilogue<NOUT>(acc[tm], 2 * ps + tm, hout);
                 }
