@@ -133,18 +133,8 @@ __device__ __forceinline__ void sw_mid_epilogue(const f32x16 &acc, int t, float 
     }
 }
 
-// Non-negative floats order like their bit patterns, so after ReLU the 32-position max runs in the integer
-// domain: v_max_i32 with a DPP source operand (one instruction per step, no NaN-canonicalising extra max).
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ int dpp_max_i32(int v) {
-    // full row mask: every lane has a valid source (quad_perm / mirrors), so "old" is dead and bound_ctrl lets the
-    // compiler fold the DPP move into the max; partial row mask (row_bcast): masked-off lanes keep v
-    const int o = ROW_MASK == 0xF ? __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true)
-                                  : __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xF, false);
-    return o > v ? o : v;
-}
-
-// The same reduction as a transpose-reduce butterfly (the form sa_pipe.hip issues in deferred parts): neighbouring REGISTERS
+// ReLU + max over the wave's 32 positions of output tile t -> red[row][wave], as a transpose-reduce butterfly (the form
+// sa_pipe.hip issues in deferred parts; non-negative floats order like their bit patterns, so the max runs on integers): neighbouring REGISTERS
 // are merged while neighbouring LANES are reduced -- stage k pairs lane l with l ^ 2^k and registers (2i, 2i+1); a lane with
 // bit k clear keeps register 2i and takes the partner's 2i, a lane with bit k set keeps 2i+1 -- so four stages take 16 + 8 +
 // 4 + 2 max steps instead of 16 x 4, ONE register then holds in lane l the maximum over its row of 16 lanes of accumulator
@@ -233,44 +223,6 @@ __device__ __forceinline__ float sw_bfly_finish(int zrun) {
     return __int_as_float(sw_imax(zrun, __builtin_amdgcn_ds_swizzle(zrun, 0x401F)));     // lane ^ 16
 }
 
-// ReLU + max over the wave's 32 positions of output tile t -> red[row][wave]
-template <int COUT, int RED_STRIDE = 4>
-__device__ __forceinline__ void sw_last_epilogue(const f32x16 &acc, int t, float *red, int wave, int lane) {
-    int v[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int x = __float_as_int(acc[r]);
-        v[r] = x > 0 ? x : 0;  // ReLU on the bit pattern: negative floats (and -0) are negative integers
-    }
-#if defined(SW_EXP) && (SW_EXP & 1)
-    if ((lane & 31) == 16) {           // EXPERIMENT: no wave-wide max (wrong results)
-        float *rp = red + (32 * t + 4 * (lane >> 5)) * RED_STRIDE + wave;
-        int acc_or = 0;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc_or |= v[r];
-        rp[0] = __int_as_float(acc_or);
-    }
-    return;
-#endif
-#pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = dpp_max_i32<0xB1, 0xF>(v[r]);   // quad_perm [1,0,3,2]
-#pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = dpp_max_i32<0x4E, 0xF>(v[r]);   // quad_perm [2,3,0,1]
-#pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = dpp_max_i32<0x141, 0xF>(v[r]);  // row_half_mirror
-#pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = dpp_max_i32<0x140, 0xF>(v[r]);  // row_mirror: every lane holds its row-of-16 max
-#pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = dpp_max_i32<0x142, 0xA>(v[r]);  // row_bcast15 into rows 1, 3: the 32-lane max
-    if ((lane & 31) == 16) {
-        float *rp = red + (32 * t + 4 * (lane >> 5)) * RED_STRIDE + wave;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int ro = (r & 3) + 8 * (r >> 2);
-            if (32 * t + ro + 4 < COUT || 32 * t + ro + 4 * (lane >> 5) < COUT) rp[ro * RED_STRIDE] = __int_as_float(v[r]);
-        }
-    }
-}
 
 // One layer whose input activations are B-operand registers hin[].  START = parity of the register set
 // that holds this layer's first weight set (loaded by the previous phase); `next` loads the following
