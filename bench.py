@@ -598,8 +598,10 @@ def main():
             bq = fams["ball_query"]
             nbytes = fused.WORK["bytes"].get("ball_query", 0.0)
             gbs = nbytes / (bq["ms_total"] * 1e-3) / 1e9
+            bq_traffic, bq_src, bq_why = (None, None, "fp32 counter files only") if args.mlp_dtype != "fp32" else pmc_traffic(("ball_query_kernel",))
             out["roofline_ball_query"] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                          "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None,
+                                          "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None if bq_traffic is None else round(bq_traffic),
+                                          "traffic_source": bq_src if bq_traffic is not None else f"null: {bq_why}",
                                           "avg_launch_us": round(1e3 * bq["ms_total"] / bq["launches"], 2)}
         out["kernel_ms_per_step"] = {k: round(v["ms_total"] / timed_steps, 3) for k, v in sorted(fams.items(), key=lambda kv: -kv[1]["ms_total"])}
         out["kernel_ms_per_step"]["_sum_captra_kernels"] = round(total_ms / timed_steps, 3)
