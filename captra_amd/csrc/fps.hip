@@ -438,13 +438,21 @@ static int fps_gather_dispatch(int b, int n, const int *ns, int m, const float *
         const int rc = captra_fps_pruned_launch(b, n, ns, m, xyz, nullptr, idx, new_xyz_n3, new_xyz_cn, s);
         if (rc != -2) return rc;
     }
-    int waves = 1;
-    while (waves < 16 && waves * 64 * 8 < n) waves *= 2;
+    int waves = g_fps_waves;
+    if (waves == 0) {
+        waves = 1;
+        while (waves < 16 && waves * 64 * 8 < n) waves *= 2;
+        // 2049..4096 points: four waves (one per SIMD) x 16 points per lane instead of eight x 8 -- a round's fixed work
+        // (wave reduction, exchange) is issued once per SIMD instead of twice: 285 -> 270 us for 4096 -> 512 at 16 and 32
+        // clouds; two waves x 32 (385 us) and sixteen x 4 (328 us) lose
+        if (waves == 8) waves = 4;
+    }
     const int ppt = (n + waves * 64 - 1) / (waves * 64);
 #define FPSG_CASE(W, P) \
     if (waves == W && ppt <= P) return launch_fps<W, P>(b, n, m, xyz, nullptr, idx, s, new_xyz_n3, new_xyz_cn, true, ns);
     FPSG_CASE(1, 2) FPSG_CASE(1, 4) FPSG_CASE(1, 8)
-    FPSG_CASE(2, 8) FPSG_CASE(4, 8) FPSG_CASE(8, 8) FPSG_CASE(16, 8) FPSG_CASE(16, 12) FPSG_CASE(16, 16) FPSG_CASE(16, 20)
+    FPSG_CASE(2, 8) FPSG_CASE(4, 8) FPSG_CASE(8, 8) FPSG_CASE(4, 16) FPSG_CASE(2, 32) FPSG_CASE(16, 4)   /* (the last three: captra_fps_set_waves experiments; 4 x 16 is the default for 2049..4096 points) */
+    FPSG_CASE(16, 8) FPSG_CASE(16, 12) FPSG_CASE(16, 16) FPSG_CASE(16, 20)
     FPSG_CASE(16, 24) FPSG_CASE(16, 32)
 #undef FPSG_CASE
     return -2;
