@@ -253,7 +253,7 @@ class EvalTrackModel(BaseModel):
         frame i-1 -- on the device (captra_amd/nocs_otf.py: one crop launch + one ragged sampling launch).  `last_pose` holds
         those trajectories only.  -> (points (b,3,N) mean-subtracted, labels (b,N), nocs (b,3,N)).  Two host round trips on
         the CURRENT stream: the predicted centre / scale, and the crops' member counts."""
-        from .nocs_otf import full_data_batch, to_host
+        from .nocs_otf import full_data_batch_arrays, to_host
         pre = input.get("pre_fetched")
         if pre is None:
             raise ValueError("nocs_otf=True needs the frame's depth and mask tensors (meta['pre_fetched']): reading depth.png / "
@@ -267,8 +267,10 @@ class EvalTrackModel(BaseModel):
             gt = {k: to_host(v[:, self.root].double().contiguous()) for k, v in input["gt_part"].items()}
         gt = {k: v[sl] for k, v in gt.items()}
         depth, mask = pre["depth"][sl], pre["mask"][sl]
-        full = full_data_batch([(depth[j], mask[j], cs[j, :3], self.radius * float(cs[j, 3]), {k: gt[k][j] for k in gt})
-                                for j in range(b)], N, stacked=True)
+        full = full_data_batch_arrays(depth, mask, cs[:, :3], self.radius * cs[:, 3],
+                                      {"rotation": np.asarray(gt["rotation"], np.float64).reshape(b, 3, 3),
+                                       "translation": np.asarray(gt["translation"], np.float64).reshape(b, 3),
+                                       "scale": np.asarray(gt["scale"], np.float64).reshape(b)}, N, stacked=True)
         points = (full["points"].float() - npcs["points_mean"][sl].reshape(b, 1, 3)).transpose(1, 2).contiguous()
         return points, full["labels"].contiguous(), full["nocs"].float().transpose(1, 2).contiguous()
 

@@ -62,6 +62,27 @@ def proj_corners(height: int, width: int, center, radius: float, intrinsics=NOCS
     return out
 
 
+def proj_corners_batch(height: int, width: int, centers, radii, intrinsics=NOCS_REAL_INTRINSICS) -> np.ndarray:
+    """proj_corners for B instances at once -> (B, 2, 2) int64.  Same float64 operations per instance; the 3x3 projection is
+    written out (u = K00 x + K01 y + K02 z, ... with z = 1 after the homogeneous division), so nothing depends on how a BLAS
+    orders a 3-term sum."""
+    c = np.asarray(centers, np.float64).reshape(-1, 3)
+    r = np.maximum(np.asarray(radii, np.float64).reshape(-1, 1), 0.05)
+    lo, hi = c - r, c + r
+    sel = np.array([[x, y, z] for y in (0, 1) for x in (0, 1) for z in (0, 1)])                 # the 8 corners: lo / hi per axis
+    box = np.where(sel[None] == 0, lo[:, None, :], hi[:, None, :]) * 1000.0                       # (B, 8, 3)
+    homog = -box / box[:, :, 2:3]
+    homog[:, :, 2] = -homog[:, :, 2]
+    K = np.asarray(intrinsics, np.float64)
+    u = (K[0, 0] * homog[:, :, 0] + K[0, 1] * homog[:, :, 1]) + K[0, 2] * homog[:, :, 2]
+    v = (K[1, 0] * homog[:, :, 0] + K[1, 1] * homog[:, :, 1]) + K[1, 2] * homog[:, :, 2]
+    rows, cols = height - v.astype(np.int32), u.astype(np.int32)
+    out = np.stack([np.stack([rows.min(1), cols.min(1)], -1), np.stack([rows.max(1), cols.max(1)], -1)], 1).astype(np.int64)
+    out[:, 0] = np.maximum(out[:, 0], 0)
+    out[:, 1] = np.minimum(out[:, 1], np.array([height - 1, width - 1]))
+    return out
+
+
 def _device_fps(points_f32: torch.Tensor, num: int) -> torch.Tensor:
     from . import fused
     res = fused.fps_gather(points_f32.reshape(1, -1, 3).contiguous(), num)
@@ -183,18 +204,33 @@ def full_data_batch(frames, num_points: int, intrinsics=NOCS_REAL_INTRINSICS, us
     called once per trajectory in list order (the thinning permutations are drawn in that order; nothing else draws).
     Instances on a rare path — fewer than 10 ball members (radius growth), more than CROP_CAP — take the torch path.
     stacked=True returns one dict of (B, …) tensors instead of the list (no per-instance slicing when nothing was rare)."""
-    from . import _lib as L, fused
     dev = frames[0][0].device
     if not use_kernel or dev.type != "cuda":
         res = _full_data_batch_torch(frames, num_points, intrinsics)
         return stack_full_data(res) if stacked else res
-    B = len(frames)
-    depth = torch.stack([f[0] for f in frames]).to(torch.int32).contiguous()
-    mask = torch.stack([f[1] for f in frames]).to(torch.uint8).contiguous()
+    gt = {"rotation": np.stack([np.asarray(f[4]["rotation"], np.float64).reshape(3, 3) for f in frames]),
+          "translation": np.stack([np.asarray(f[4]["translation"], np.float64).reshape(3) for f in frames]),
+          "scale": np.array([float(np.asarray(f[4]["scale"], np.float64).reshape(-1)[0]) for f in frames])}
+    return full_data_batch_arrays(torch.stack([f[0] for f in frames]), torch.stack([f[1] for f in frames]),
+                                  np.stack([np.asarray(f[2], np.float64).reshape(3) for f in frames]),
+                                  np.array([float(f[3]) for f in frames], np.float64), gt, num_points, intrinsics, stacked)
+
+
+def full_data_batch_arrays(depth, mask, centers, radii_in, gt, num_points: int, intrinsics=NOCS_REAL_INTRINSICS, stacked: bool = True):
+    """full_data_batch on already-stacked inputs (the track loop's form: no per-trajectory Python on the frame's critical
+    path — the host work sits between two device round trips): depth (B,H,W), mask (B,H,W) device tensors; centers (B,3),
+    radii_in (B,) float64 host arrays (radius as handed to full_data_from_depth: clamped to 0.05 inside); gt = {'rotation'
+    (B,3,3), 'translation' (B,3), 'scale' (B,)} float64 host arrays."""
+    from . import _lib as L, fused
+    dev = depth.device
+    B = depth.shape[0]
+    depth = depth.to(torch.int32).contiguous()
+    mask = mask.to(torch.uint8).contiguous()
     _, H, W = depth.shape
-    centers = np.stack([np.asarray(f[2], np.float64).reshape(3) for f in frames])
-    radii = np.array([max(float(f[3]), 0.05) for f in frames], np.float64)
-    boxes = np.stack([proj_corners(H, W, centers[b], frames[b][3], intrinsics).reshape(4) for b in range(B)]).astype(np.int32)
+    centers = np.ascontiguousarray(np.asarray(centers, np.float64).reshape(B, 3))
+    radii_in = np.asarray(radii_in, np.float64).reshape(B)
+    radii = np.maximum(radii_in, 0.05)
+    boxes = proj_corners_batch(H, W, centers, radii_in, intrinsics).reshape(B, 4).astype(np.int32)
     kinv = np.linalg.inv(np.asarray(intrinsics, np.float64)).reshape(9)
     host = to_device(np.concatenate([centers.reshape(-1), radii, kinv]), dev)                   # one H2D for the doubles
     box_d = to_device(boxes, dev)
@@ -207,13 +243,16 @@ def full_data_batch(frames, num_points: int, intrinsics=NOCS_REAL_INTRINSICS, us
                host.data_ptr() + 8 * 3 * B, host.data_ptr() + 8 * 4 * B, L.ptr(pts), L.ptr(obj), L.ptr(pix), L.ptr(counts))
     n_members = to_host(counts[:, 0].contiguous())                                               # the one sync of the stage
 
+    def gt_of(b):
+        return {"rotation": gt["rotation"][b], "translation": np.asarray(gt["translation"][b]).reshape(3, 1), "scale": gt["scale"][b]}
+
     # host: the candidate list of every instance as indices into its member table (list doubling = index modulo count,
     # thinning = a prefix of numpy's permutation), in trajectory order because the permutations consume numpy's generator
     lengths, perms, slow = [0] * B, {}, {}
     for b in range(B):
         c = int(n_members[b])
         if c < 10 or c > CROP_CAP:
-            slow[b] = crop_candidates(frames[b][0], frames[b][1], frames[b][2], frames[b][3], num_points, intrinsics)
+            slow[b] = crop_candidates(depth[b], mask[b].bool(), centers[b], float(radii_in[b]), num_points, intrinsics)
             continue
         length = c
         while length < num_points:
@@ -243,9 +282,10 @@ def full_data_batch(frames, num_points: int, intrinsics=NOCS_REAL_INTRINSICS, us
         sel = torch.gather(table_d, 1, res[0].long())                                             # (F, N) member numbers
         P = torch.gather(pts_f, 1, sel.unsqueeze(-1).expand(-1, -1, 3))                            # (F, N, 3) float64
         O = torch.gather(obj_f, 1, sel).bool()
-        rot = to_device(np.stack([np.asarray(frames[b][4]["rotation"], np.float64).reshape(3, 3) for b in fast]), dev)
-        trans = to_device(np.stack([np.asarray(frames[b][4]["translation"], np.float64).reshape(1, 3) for b in fast]), dev)
-        scale = to_device(np.array([float(np.asarray(frames[b][4]["scale"], np.float64).reshape(-1)[0]) for b in fast]), dev)
+        sub = slice(None) if len(fast) == B else np.asarray(fast)
+        rot = to_device(np.ascontiguousarray(np.asarray(gt["rotation"], np.float64).reshape(B, 3, 3)[sub]), dev)
+        trans = to_device(np.ascontiguousarray(np.asarray(gt["translation"], np.float64).reshape(B, 1, 3)[sub]), dev)
+        scale = to_device(np.ascontiguousarray(np.asarray(gt["scale"], np.float64).reshape(B)[sub]), dev)
         nocs = torch.where(O.unsqueeze(-1), torch.bmm((P - trans) / scale.reshape(-1, 1, 1), rot), torch.zeros_like(P))
         labels = 1 - O.long()
         if stacked and len(fast) == B:
@@ -255,5 +295,5 @@ def full_data_batch(frames, num_points: int, intrinsics=NOCS_REAL_INTRINSICS, us
     for b, (p_all, raw_mask, idx, perm) in slow.items():
         picked = _device_fps(_candidate_cloud(p_all, idx, perm), num_points)
         sel_b = idx[perm[picked] if perm is not None else picked]
-        out[b] = _full_data(p_all[sel_b], raw_mask[sel_b], frames[b][4])
+        out[b] = _full_data(p_all[sel_b], raw_mask[sel_b], gt_of(b))
     return stack_full_data(out) if stacked else out

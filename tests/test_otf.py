@@ -39,6 +39,21 @@ def test_crop_and_resample_vs_reference_cpu(tag, seed, radius, n):
     _check(tag, seed, radius, n, "cpu", _oracle_fps)
 
 
+def test_proj_corners_batch_equals_per_instance_cpu():
+    """The track loop's vectorised box projection (nocs_otf.proj_corners_batch, written without a matrix product) == the
+    per-instance form pinned by G11, on the fixture frames and on random centres / radii incl. boxes clamped at the image
+    border and radii below the 0.05 floor."""
+    rng = np.random.default_rng(5)
+    centers = [make_frame(seed)[2] for _, seed, _, _ in CASES]
+    radii = [r for _, _, r, _ in CASES]
+    for _ in range(200):
+        centers.append(np.array([rng.uniform(-0.6, 0.6), rng.uniform(-0.45, 0.45), -rng.uniform(0.4, 2.5)]))
+        radii.append(float(rng.choice([0.01, 0.05, 0.12, 0.3, 0.8])))
+    got = nocs_otf.proj_corners_batch(480, 640, np.stack(centers), np.asarray(radii))
+    for i, (c, r) in enumerate(zip(centers, radii)):
+        np.testing.assert_array_equal(got[i], nocs_otf.proj_corners(480, 640, c, r), err_msg=str((c, r)))
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("tag,seed,radius,n", CASES)
 def test_crop_and_resample_vs_reference_gpu(device, tag, seed, radius, n):
