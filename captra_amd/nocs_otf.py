@@ -83,6 +83,18 @@ def proj_corners_batch(height: int, width: int, centers, radii, intrinsics=NOCS_
     return out
 
 
+_KINV_CACHE: dict = {}
+
+
+def _kinv(intrinsics) -> np.ndarray:
+    """Inverse intrinsics as 9 doubles (cached per matrix: numpy.linalg.inv costs 30 us of the loop's critical host path)."""
+    K = np.asarray(intrinsics, np.float64)
+    key = K.tobytes()
+    if key not in _KINV_CACHE:
+        _KINV_CACHE[key] = np.linalg.inv(K).reshape(9)
+    return _KINV_CACHE[key]
+
+
 def _device_fps(points_f32: torch.Tensor, num: int) -> torch.Tensor:
     from . import fused
     res = fused.fps_gather(points_f32.reshape(1, -1, 3).contiguous(), num)
@@ -231,16 +243,22 @@ def full_data_batch_arrays(depth, mask, centers, radii_in, gt, num_points: int, 
     radii_in = np.asarray(radii_in, np.float64).reshape(B)
     radii = np.maximum(radii_in, 0.05)
     boxes = proj_corners_batch(H, W, centers, radii_in, intrinsics).reshape(B, 4).astype(np.int32)
-    kinv = np.linalg.inv(np.asarray(intrinsics, np.float64)).reshape(9)
-    host = to_device(np.concatenate([centers.reshape(-1), radii, kinv]), dev)                   # one H2D for the doubles
-    box_d = to_device(boxes, dev)
+    kinv = _kinv(intrinsics)
+    # ONE host-to-device copy for everything the crop kernel reads from the host: the doubles (centres, radii, K^-1), then
+    # the int32 boxes (this stretch of host work sits between the pose round trip and the crop launch: the GPU waits for it)
+    ndbl = 4 * B + 9
+    blob = np.empty(8 * ndbl + 16 * B, np.uint8)
+    blob[:8 * ndbl].view(np.float64)[:] = np.concatenate([centers.reshape(-1), radii, kinv])
+    blob[8 * ndbl:].view(np.int32)[:] = boxes.reshape(-1)
+    host = to_device(blob, dev)
+    hp = host.data_ptr()
     pts = torch.empty(B, CROP_CAP, 3, dtype=torch.float64, device=dev)
     obj = torch.empty(B, CROP_CAP, dtype=torch.uint8, device=dev)
     pix = torch.empty(B, CROP_CAP, dtype=torch.int32, device=dev)
     counts = torch.empty(B, 2, dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
-        L.call("captra_crop_ball", B, H, W, CROP_CAP, L.ptr(depth), L.ptr(mask), L.ptr(box_d), host.data_ptr(),
-               host.data_ptr() + 8 * 3 * B, host.data_ptr() + 8 * 4 * B, L.ptr(pts), L.ptr(obj), L.ptr(pix), L.ptr(counts))
+        L.call("captra_crop_ball", B, H, W, CROP_CAP, L.ptr(depth), L.ptr(mask), hp + 8 * ndbl, hp,
+               hp + 8 * 3 * B, hp + 8 * 4 * B, L.ptr(pts), L.ptr(obj), L.ptr(pix), L.ptr(counts))
     n_members = to_host(counts[:, 0].contiguous())                                               # the one sync of the stage
 
     def gt_of(b):
