@@ -61,6 +61,9 @@ class BaseModel(nn.Module):
             self.per_diff_dict.setdefault(f"{instance}_{track_num}_{frame_i}", {}).update(get_ith_from_batch(per_diff, i))
 
 
+_OTF_LANE_STREAMS: dict = {}      # device index -> the two lane streams of EvalTrackModel._forward_otf_lanes
+
+
 class EvalTrackModel(BaseModel):
     def __init__(self, cfg):
         super().__init__(cfg)
@@ -91,10 +94,11 @@ class EvalTrackModel(BaseModel):
         # write (rank 0 writes the pickles of every rank's trajectories).  Both None = the single-process behaviour.
         self.frame_hook = None
         self.result_sink = None
-        # nocs_otf at batch >= 32 as two lanes half a frame apart (_forward_otf_lanes).  Opt-in (cfg['otf_lanes']): bit-identical
-        # results, 10.5 -> 9.3-9.8 ms per 32-trajectory step when the lanes' streams land on separate hardware queues
-        # (GPU_MAX_HW_QUEUES=8), 12 ms when they do not -- see DESIGN.md section 5
-        self.otf_lanes = bool(cfg.get("otf_lanes", False))
+        # nocs_otf at batch >= 32 as two lanes half a frame apart (_forward_otf_lanes): bit-identical results, 9.5 -> 7.9 ms per
+        # 32-trajectory step (3370 -> 4060 frames/s).  On by default (cfg['otf_lanes'] = False turns it off): with the lane
+        # streams created once per process the first eight model objects of a process all get the fast placement; what a
+        # later one may get (both lanes on one hardware queue, ~13 ms) is in DESIGN.md section 5
+        self.otf_lanes = bool(cfg.get("otf_lanes", True))
         self._graph = None
         self._graph_key = None
 
@@ -299,7 +303,13 @@ class EvalTrackModel(BaseModel):
         dev = feed[1]["points"].device
         cur = torch.cuda.current_stream(dev)
         if getattr(self, "_otf_streams", None) is None:
-            self._otf_streams = [torch.cuda.Stream(device=dev) for _ in slices]
+            # the two lane streams are created once per PROCESS and device: which hardware queue a stream gets is decided
+            # at creation, and a later model object that made fresh ones sometimes landed both lanes on one queue
+            # (11.6-14.4 ms per step instead of 7.9)
+            key = (dev.index if dev.index is not None else torch.cuda.current_device())
+            if key not in _OTF_LANE_STREAMS:
+                _OTF_LANE_STREAMS[key] = [torch.cuda.Stream(device=dev) for _ in slices]
+            self._otf_streams = _OTF_LANE_STREAMS[key]
         streams = self._otf_streams
         use_graph = self._graph_usable(feed[1])
         graphs = None
