@@ -1,0 +1,486 @@
+// bf16-native set-abstraction scale for gfx950 (BASELINE.json configs[2]: "bf16 shared-MLP on MFMA"): the body of the loop over
+// radii of PointNetSetAbstractionMsg.forward (reference network/models/pointnet_utils.py:228-248: gather, centre subtraction,
+// cat, 3 x (Conv2d 1x1 + BN + ReLU), max over K) as ONE launch on v_mfma_f32_32x32x16_bf16.
+//
+// Contract (include/captra_hip.h): every layer = act(b + sum_k bf16(w[k]) * bf16(x[k])), products exact, fp32 accumulation,
+// weights rounded once at pack time (RNE), every layer's input rounded when it becomes an MFMA operand.
+//
+// What makes it a bf16 design rather than the fp32 kernel with the operand type swapped (round 2: 0.09 of the bf16 peak):
+//  * ZERO-SWAP HAND-OVER.  The 32x32 accumulator tile (register r of lane l = row 8(r>>2)+(r&3)+4(l>>5), column l&31) is
+//    the next layer's B operand as it stands if that layer's weights are stored with their K order PERMUTED: registers
+//    8jj..8jj+7 of a lane become k-slots 8h..8h+7 of k-step 2t+jj, i.e. slot s of a 16-wide k-step holds channel
+//    perm[s] = {0,1,2,3,8,9,10,11,4,5,6,7,12,13,14,15}.  The hand-over is 8 v_cvt_pk_bf16_f32 + 4 v_pk_max_i16 (ReLU on the
+//    packed pairs: a negative bf16 is a negative int16) per 32x32 tile -- 12 instructions instead of 16 ReLU + 8
+//    v_permlane32_swap + 8 cvt.
+//  * THE LAST LAYER IS FLIPPED: activations are the A operand (rows = positions), weights the B operand (columns = output
+//    channels), so a lane owns ONE output channel and the max over the K neighbours is a max over its 16 accumulator
+//    registers (8 v_max3_f32) + one half-wave exchange per centre -- not a 45-instruction lane butterfly per tile.  The bias
+//    is added after the max (x -> fl(x + b) is monotone, so max_k fl(s_k + b) = fl(max_k s_k + b)).
+//  * EVERY WEIGHT FRAGMENT FEEDS TN = 2..4 POSITION TILES.  A bf16 MFMA consumes a 1 KiB A fragment every 32 cycles per SIMD;
+//    one fragment per MFMA (round 2) is 128 B/clk per CU against an L1 that delivers 64.  The weights are a FRAGMENT
+//    IMAGE (frag (t,kk): 64 lanes x 16 bytes, lane l = row 32t+(l&31), k-slots 8(l>>5)..+7) built once by
+//    captra_pack_sa_bf16; the SA1 scales (6-39 KB) copy it to LDS once per workgroup and read it with conflict-free
+//    ds_read_b128, the SA2 scales (98-164 KB) stream it from L2 with fully coalesced 1 KiB buffer loads, four tiles per load.
+//  * A WAVE OWNS CG CONSECUTIVE CENTRES: running max in registers, results staged in a wave-private LDS strip and written
+//    as 16-byte row segments (no 8x write amplification of 4-byte scattered stores).
+//  * Layer 1 of the small-input scales carries its bias as two constant-one input channels (hi + lo bf16 split of b1:
+//    2^-17 relative), so its accumulators start from the inline constant 0.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int cdiv_c(int a, int b) { return (a + b - 1) / b; }
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// one v_cvt_pk_bf16_f32 (the vector fptrunc; two scalar casts compile to two conversions and a v_perm_b32)
+__device__ __forceinline__ unsigned sb_pack(float lo, float hi) {
+    const f32x2 f = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2));
+}
+// ReLU on a packed bf16 pair
+__device__ __forceinline__ unsigned sb_relu2(unsigned v) {
+    const s16x2 z = {0, 0};
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, v), z));
+}
+__device__ __forceinline__ f32x16 sb_mfma(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// max of three as ONE instruction, two forms.
+//  ASM = false: v_maximum3_f32 from llvm.maximum (no canonicalising v_max_f32 x, x, x in front as fmaxf gets in IEEE mode).
+//    The form of the kernels whose accumulators live in VGPRs: the first VALU read of an MFMA result needs software wait
+//    states, which the compiler inserts for its own instructions and NOT inside asm statements (stale reads otherwise).
+//  ASM = true: v_max3_f32 as an asm statement.  The form of the one-wave-per-SIMD kernels: their accumulators are AGPRs, the
+//    operands reach the statement through compiler-issued v_accvgpr_read (hazards handled there), and the opaque statement
+//    keeps the scheduler from interleaving the read-outs, which with llvm.maximum costs 700 bytes of scratch per lane.
+template <bool ASM>
+__device__ __forceinline__ float sb_max3(float a, float b, float c) {
+    if constexpr (ASM) {
+        float r;
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+        return r;
+    } else {
+        return __builtin_elementwise_maximum(__builtin_elementwise_maximum(a, b), c);
+    }
+}
+
+template <int CF, int C1, int C2, int C3, bool PRE>
+struct SbShape {
+    static constexpr int CIN1 = PRE ? 3 : CF + 3;                 // input rows of the MFMA part of layer 1
+    static constexpr int NT1 = cdiv_c(C1, 32), NT2 = cdiv_c(C2, 32), NT3 = cdiv_c(C3, 32);
+    static constexpr int KST2 = cdiv_c(C1, 16), KST3 = cdiv_c(C2, 16);
+    static constexpr int F1 = 0, F2 = NT1, F3 = F2 + NT2 * KST2, NFRAG = F3 + NT3 * KST3;
+    static constexpr int WBYTES = NFRAG * 1024;
+    static constexpr int B2OFF = 0, B3OFF = NT2 * 32, NBIAS = (NT2 + NT3) * 32;   // floats behind the fragments
+    static constexpr int IMG_BYTES = WBYTES + NBIAS * 4;
+};
+
+// The order in which a pass consumes the image's fragments with RG row tiles per accumulator group (k-step major inside a
+// group): what the streamed-weight kernels prefetch along.
+template <typename S, int RG>
+struct SbUseOrder {
+    int f[S::NFRAG];
+    constexpr SbUseOrder() : f() {
+        int u = 0;
+        for (int t = 0; t < S::NT1; ++t) f[u++] = S::F1 + t;
+        for (int tg = 0; tg < S::NT2; tg += RG)
+            for (int kk = 0; kk < S::KST2; ++kk)
+                for (int r = 0; r < RG && tg + r < S::NT2; ++r) f[u++] = S::F2 + (tg + r) * S::KST2 + kk;
+        for (int tg = 0; tg < S::NT3; tg += RG)
+            for (int kk = 0; kk < S::KST3; ++kk)
+                for (int r = 0; r < RG && tg + r < S::NT3; ++r) f[u++] = S::F3 + (tg + r) * S::KST3 + kk;
+    }
+};
+
+// ---- image builder --------------------------------------------------------------------------------------------------
+// One thread per bf16 element of the fragment part, then the biases.  wt*: packed fp32 W'^T (row-major part: element
+// [k * ldw + cout]).  Layer 1: rows [row0, row0 + cin1) of wt1 (PRE: the three xyz rows behind the feature rows) and, when
+// fold_b1, bias b1 as rows cin1 (hi) and cin1 + 1 (lo).  Layers 2 / 3: K order permuted (header).
+struct SbPackParams {
+    int cin1, row0, fold_b1, c1, c2, c3, ldw1, ldw2, ldw3;
+    const float *wt1, *b1, *wt2, *b2, *wt3, *b3;
+    unsigned char *img;
+};
+
+__device__ __forceinline__ int sb_perm(int s) { return (s & 3) | ((s & 4) << 1) | ((s & 8) >> 1); }
+
+__global__ void pack_sa_bf16_kernel(SbPackParams p) {
+    const int nt1 = (p.c1 + 31) / 32, nt2 = (p.c2 + 31) / 32, nt3 = (p.c3 + 31) / 32;
+    const int kst2 = (p.c1 + 15) / 16, kst3 = (p.c2 + 15) / 16;
+    const int f2 = nt1, f3 = f2 + nt2 * kst2, nfrag = f3 + nt3 * kst3;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < nfrag * 512) {
+        const int f = e >> 9, lane = (e >> 3) & 63, el = e & 7;
+        const int slot = 8 * (lane >> 5) + el;
+        float v = 0.f;
+        if (f < f2) {
+            const int row = 32 * f + (lane & 31);
+            if (row < p.c1) {
+                if (slot < p.cin1) v = p.wt1[(size_t)(p.row0 + slot) * p.ldw1 + row];
+                else if (p.fold_b1 && slot < p.cin1 + 2) {
+                    const float b = p.b1[row];
+                    const float hi = (float)(__bf16)b;
+                    v = slot == p.cin1 ? hi : b - hi;
+                }
+            }
+        } else if (f < f3) {
+            const int t = (f - f2) / kst2, kk = (f - f2) % kst2;
+            const int row = 32 * t + (lane & 31), k = 16 * kk + sb_perm(slot);
+            if (row < p.c2 && k < p.c1) v = p.wt2[(size_t)k * p.ldw2 + row];
+        } else {
+            const int t = (f - f3) / kst3, kk = (f - f3) % kst3;
+            const int row = 32 * t + (lane & 31), k = 16 * kk + sb_perm(slot);
+            if (row < p.c3 && k < p.c2) v = p.wt3[(size_t)k * p.ldw3 + row];
+        }
+        const __bf16 h = (__bf16)v;
+        reinterpret_cast<unsigned short *>(p.img)[e] = __builtin_bit_cast(unsigned short, h);
+    } else {
+        const int i = e - nfrag * 512;
+        if (i < (nt2 + nt3) * 32) {
+            float *bias = reinterpret_cast<float *>(p.img + (size_t)nfrag * 1024);
+            bias[i] = i < nt2 * 32 ? (i < p.c2 ? p.b2[i] : 0.f) : (i - nt2 * 32 < p.c3 ? p.b3[i - nt2 * 32] : 0.f);
+        }
+    }
+}
+
+// ---- the kernel --------------------------------------------------------------------------------------------------------
+struct SbParams {
+    int n, m;
+    const float *feat;      // (B,CF,N) fp32 (small-input scales) or null
+    const float *v1pm;      // PRE: (B,N,C1) fp32 POINT-major = b1 + W1[feature rows] feat
+    const float *xyz_cn;    // (B,3,N)
+    const float *new_xyz;   // (B,M,3)
+    const int *idx;         // (B,M,K)
+    const unsigned char *img;
+    float *out;             // (B,out_ctotal,M)
+    int out_ctotal, co_off;
+    int jobs_per_cloud, njobs;
+};
+
+// output tile (rows 32t.., this wave's 32 columns) -> next layer's B operands hout[2t], hout[2t+1]: ReLU + round + pack
+template <int NOUT>
+__device__ __forceinline__ void sb_mid_epilogue(const f32x16 &acc, int t, u32x4 (&hout)[NOUT]) {
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+        if (2 * t + jj >= NOUT) continue;
+        u32x4 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = sb_relu2(sb_pack(acc[8 * jj + 2 * i], acc[8 * jj + 2 * i + 1]));
+        hout[2 * t + jj] = v;
+    }
+}
+
+template <bool ASM>
+__device__ __forceinline__ float sb_reduce16(float z, const f32x16 &a) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) z = sb_max3<ASM>(z, a[2 * i], a[2 * i + 1]);
+    return z;
+}
+
+// (WLDS kernels: at most 256 registers per lane asked for, which also keeps the accumulators in VGPRs -- with the whole
+// 512-register file allowed the compiler puts them in AGPRs and every epilogue element costs a v_accvgpr_read first)
+template <int CF, int C1, int C2, int C3, int K, bool PRE, int TN, int CG, bool WLDS>
+__global__ __launch_bounds__(256, WLDS ? 2 : 1) void sa_bf16_kernel(SbParams p) {
+    using S = SbShape<CF, C1, C2, C3, PRE>;
+    constexpr int TPC = K / 32;                        // 32-position tiles per centre
+    constexpr int CPP = TN > TPC ? TN / TPC : 1;       // centres per pass
+    constexpr int PPC = TPC > TN ? TPC / TN : 1;       // passes per centre
+    constexpr int NPASS = CG * TPC / TN;               // passes per job
+    constexpr int RG = TN >= 4 ? 1 : 2;                // row tiles per accumulator group
+    constexpr bool STAGE_OUT = CG >= 4;                // results through a wave-private LDS strip, written as 16-byte segments
+    static_assert((CG * TPC) % TN == 0 && (PRE || TN == 2) && K % 32 == 0, "shape");
+    static_assert(PRE || S::CIN1 + 2 <= 8, "first layer: inputs + two bias rows fit the lower half-wave's eight k-slots");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int WL = WLDS ? S::WBYTES : 0;
+    float *bias_lds = reinterpret_cast<float *>(smem + WL);
+    float *ost_all = bias_lds + S::NBIAS;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, col = lane & 31;
+    // ---- stage the image (WLDS) and the biases --------------------------------------------------------------
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(p.img + (WLDS ? 0 : S::WBYTES));
+        uint4 *dst = reinterpret_cast<uint4 *>(smem);
+        constexpr int N16 = (WL + S::NBIAS * 4) / 16;
+        for (int e = tid; e < N16; e += 256) dst[e] = src[e];
+    }
+    __syncthreads();
+    const int job = blockIdx.x * 4 + wave;
+    if (job >= p.njobs) return;                        // (no barrier below)
+    const int b = job / p.jobs_per_cloud;
+    const int centre0 = (job % p.jobs_per_cloud) * CG;
+    const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc((void *)p.img, 0, S::WBYTES, 0x00020000);
+    // streamed weights: a ring of RD fragments, loaded RD - 1 uses ahead of the MFMAs that read them (a fragment feeds TN
+    // MFMAs = TN x 32 cycles; an L2 hit takes 500+ cycles under this load)
+    constexpr int RD = WLDS ? 1 : 8;
+    constexpr SbUseOrder<S, RG> ORDER{};
+    u32x4 ring[RD];
+    auto wload = [&](int f) -> u32x4 { return __builtin_amdgcn_raw_buffer_load_b128(wsrc, lane * 16, f * 1024, 0); };
+    int use = 0;                                       // compile-time after unrolling: position in ORDER
+    auto wfrag = [&](int f) -> u32x4 {
+        if constexpr (WLDS) return *reinterpret_cast<const u32x4 *>(smem + f * 1024 + lane * 16);
+        else {
+            const u32x4 w = ring[use % RD];
+            if (use + RD - 1 < S::NFRAG) ring[(use + RD - 1) % RD] = wload(ORDER.f[use + RD - 1]);
+            ++use;
+            return w;
+        }
+    };
+    float b3r[S::NT3];
+#pragma unroll
+    for (int t = 0; t < S::NT3; ++t) b3r[t] = bias_lds[S::B3OFF + 32 * t + col];
+    float z[S::NT3][CPP];
+#pragma unroll
+    for (int t = 0; t < S::NT3; ++t)
+#pragma unroll
+        for (int c = 0; c < CPP; ++c) z[t][c] = -__builtin_inff();
+    float *ost = ost_all + wave * (CG * C3);
+    const size_t cloud_idx = (size_t)b * p.m * K;
+    const float *xb = p.xyz_cn + (size_t)b * 3 * p.n;
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll 1
+    for (int ps = 0; ps < NPASS; ++ps) {
+        u32x4 x1[TN];
+        int ids[TN];
+        // ---- gather: neighbour ids, relative coordinates (+ features) as layer 1's B operands --------------
+        if constexpr (!PRE) {
+            // 64 lanes fetch 64 consecutive positions: lanes 0-31 tile 0, lanes 32-63 tile 1; one half-wave exchange per
+            // register then leaves each tile's inputs in the lower half-wave (k-slots 0..7) over a zero upper half
+            const int tile = ps * 2 + h;
+            int c = centre0 + tile / TPC;
+            c = c < p.m ? c : p.m - 1;
+            const int id = p.idx[cloud_idx + (size_t)c * K + (tile % TPC) * 32 + col];
+            const float *cp = p.new_xyz + ((size_t)b * p.m + c) * 3;
+            float in[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) in[k] = 0.f;
+#pragma unroll
+            for (int k = 0; k < CF; ++k) in[k] = p.feat[((size_t)b * CF + k) * p.n + id];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) in[CF + a] = xb[(size_t)a * p.n + id] - cp[a];
+            in[CF + 3] = 1.f;
+            in[CF + 4] = 1.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                // (not swap(g, 0): hipcc 7.2 hoists the zero register out of the pass loop although the instruction
+                // overwrites it, and the next pass swaps stale data in)
+                const unsigned g = sb_pack(in[2 * i], in[2 * i + 1]);
+                const auto sw = __builtin_amdgcn_permlane32_swap(g, g, false, false);     // (lo, lo), (hi, hi)
+                x1[0][i] = h ? 0u : sw[0];
+                x1[1][i] = h ? 0u : sw[1];
+            }
+            ids[0] = ids[1] = 0;
+        } else {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int tile = ps * TN + j;
+                int c = centre0 + tile / TPC;
+                c = c < p.m ? c : p.m - 1;
+                const int id = p.idx[cloud_idx + (size_t)c * K + (tile % TPC) * 32 + col];
+                const float *cp = p.new_xyz + ((size_t)b * p.m + c) * 3;
+                const float r0 = xb[id] - cp[0], r1 = xb[(size_t)p.n + id] - cp[1], r2 = xb[(size_t)2 * p.n + id] - cp[2];
+                ids[j] = id;
+                x1[j][0] = h ? 0u : sb_pack(r0, r1);
+                x1[j][1] = h ? 0u : sb_pack(r2, 0.f);
+                x1[j][2] = 0u;
+                x1[j][3] = 0u;
+            }
+        }
+        u32x4 h1[TN][S::KST2], h2[TN][S::KST3];
+        if constexpr (!WLDS) {
+            use = 0;
+#pragma unroll
+            for (int i = 0; i < RD - 1; ++i) ring[i] = wload(ORDER.f[i]);
+        }
+        // ---- layer 1 ---------------------------------------------------------------------------------------
+#pragma unroll
+        for (int t = 0; t < S::NT1; ++t) {
+            const u32x4 w = wfrag(S::F1 + t);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                f32x16 acc;
+                if constexpr (PRE) {
+                    // accumulator start = gathered v1 (point-major: registers 4q..4q+3 = channels 32t + 8q + 4h + 0..3)
+                    const float *vp = p.v1pm + ((size_t)b * p.n + ids[j]) * C1 + 32 * t + 4 * h;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 v = *reinterpret_cast<const float4 *>(vp + 8 * q);
+                        acc[4 * q + 0] = v.x; acc[4 * q + 1] = v.y; acc[4 * q + 2] = v.z; acc[4 * q + 3] = v.w;
+                    }
+                    acc = sb_mfma(w, x1[j], acc);
+                } else {
+                    acc = sb_mfma(w, x1[j], zero16);
+                }
+                sb_mid_epilogue<S::KST2>(acc, t, h1[j]);
+            }
+        }
+        // ---- layer 2 ---------------------------------------------------------------------------------------
+#pragma unroll
+        for (int tg = 0; tg < S::NT2; tg += RG) {
+            f32x16 bias[RG], acc[RG][TN];
+#pragma unroll
+            for (int r = 0; r < RG; ++r)
+                if (tg + r < S::NT2) {
+                    const float4 *bp = reinterpret_cast<const float4 *>(bias_lds + S::B2OFF + 32 * (tg + r) + 4 * h);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 v = bp[2 * q];
+                        bias[r][4 * q + 0] = v.x; bias[r][4 * q + 1] = v.y; bias[r][4 * q + 2] = v.z; bias[r][4 * q + 3] = v.w;
+                    }
+                }
+#pragma unroll
+            for (int kk = 0; kk < S::KST2; ++kk)
+#pragma unroll
+                for (int r = 0; r < RG; ++r)
+                    if (tg + r < S::NT2) {
+                        const u32x4 w = wfrag(S::F2 + (tg + r) * S::KST2 + kk);
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) acc[r][j] = sb_mfma(w, h1[j][kk], kk == 0 ? bias[r] : acc[r][j]);
+                    }
+#pragma unroll
+            for (int r = 0; r < RG; ++r)
+                if (tg + r < S::NT2)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) sb_mid_epilogue<S::KST3>(acc[r][j], tg + r, h2[j]);
+        }
+        // ---- layer 3, flipped: D[position][channel]; running max over the centre's positions ------------------
+#pragma unroll
+        for (int tg = 0; tg < S::NT3; tg += RG) {
+            f32x16 acc[RG][TN];
+#pragma unroll
+            for (int kk = 0; kk < S::KST3; ++kk)
+#pragma unroll
+                for (int r = 0; r < RG; ++r)
+                    if (tg + r < S::NT3) {
+                        const u32x4 w = wfrag(S::F3 + (tg + r) * S::KST3 + kk);
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) acc[r][j] = sb_mfma(h2[j][kk], w, kk == 0 ? zero16 : acc[r][j]);
+                    }
+#pragma unroll
+            for (int r = 0; r < RG; ++r)
+                if (tg + r < S::NT3)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const int c = CPP > 1 ? j / (TN / CPP) : 0;
+                        z[tg + r][c] = sb_reduce16<!WLDS>(z[tg + r][c], acc[r][j]);
+                    }
+        }
+        // ---- a centre (or CPP centres) complete: join the half-waves, bias, ReLU, hand out ---------------------
+        if (PPC == 1 || (ps % PPC) == PPC - 1) {
+#pragma unroll
+            for (int c = 0; c < CPP; ++c) {
+                const int cl = PPC > 1 ? ps / PPC : ps * CPP + c;      // centre within the job
+#pragma unroll
+                for (int t = 0; t < S::NT3; ++t) {
+                    const unsigned u = __float_as_uint(z[t][c]);
+                    const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+                    float v = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1])) + b3r[t];
+                    v = v > 0.f ? v : 0.f;
+                    z[t][c] = -__builtin_inff();
+                    const int ch = 32 * t + col;
+                    if constexpr (STAGE_OUT) {
+                        if (h == 0 && ch < C3) ost[cl * C3 + ch] = v;
+                    } else {
+                        if (h == 0 && ch < C3 && centre0 + cl < p.m)
+                            p.out[((size_t)b * p.out_ctotal + p.co_off + ch) * p.m + centre0 + cl] = v;
+                    }
+                }
+            }
+        }
+    }
+    if constexpr (STAGE_OUT) {
+        // wave-private strip ost[centre][channel] -> out rows: lane l writes centres 4(l%(CG/4)).. of channel l/(CG/4) + ...
+        constexpr int QPC = CG / 4;                    // 16-byte segments per channel row
+        constexpr int CHS = 64 / QPC;                  // channels per sweep
+        float *ob = p.out + ((size_t)b * p.out_ctotal + p.co_off) * p.m + centre0;
+        const bool vec_ok = (p.m % 4) == 0 && centre0 + CG <= p.m;
+#pragma unroll 1
+        for (int c0 = 0; c0 < C3; c0 += CHS) {
+            const int ch = c0 + lane / QPC, cq = (lane % QPC) * 4;
+            if (ch < C3) {
+                float4 v;
+                v.x = ost[(cq + 0) * C3 + ch]; v.y = ost[(cq + 1) * C3 + ch];
+                v.z = ost[(cq + 2) * C3 + ch]; v.w = ost[(cq + 3) * C3 + ch];
+                float *dst = ob + (size_t)ch * p.m + cq;
+                if (vec_ok) *reinterpret_cast<float4 *>(dst) = v;
+                else {
+                    if (centre0 + cq + 0 < p.m) dst[0] = v.x;
+                    if (centre0 + cq + 1 < p.m) dst[1] = v.y;
+                    if (centre0 + cq + 2 < p.m) dst[2] = v.z;
+                    if (centre0 + cq + 3 < p.m) dst[3] = v.w;
+                }
+            }
+        }
+    }
+}
+
+template <int CF, int C1, int C2, int C3, int K, bool PRE, int TN, int CG, bool WLDS>
+int sb_launch(int b, SbParams p, hipStream_t stream) {
+    using S = SbShape<CF, C1, C2, C3, PRE>;
+    p.jobs_per_cloud = (p.m + CG - 1) / CG;
+    p.njobs = b * p.jobs_per_cloud;
+    const int lds = (WLDS ? S::WBYTES : 0) + S::NBIAS * 4 + (CG >= 4 ? 4 * CG * C3 * 4 : 0);
+    auto kern = sa_bf16_kernel<CF, C1, C2, C3, K, PRE, TN, CG, WLDS>;
+    static CaptraDeviceOnce once;
+    if (lds > 48 * 1024 && once.first_use())
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return (int)hipGetLastError();
+    CAPTRA_LAUNCH("sa_scale_fused", kern, dim3((p.njobs + 3) / 4), dim3(256), lds, stream, p);
+    return captra_last_error();
+}
+
+}  // namespace
+
+extern "C" long long captra_sa_bf16_image_bytes(int cfeat, int c1, int c2, int c3) {
+    if (c1 < 1 || c2 < 1 || c3 < 1) return -1;
+    const long long nfrag = (c1 + 31) / 32 + (long long)((c2 + 31) / 32) * ((c1 + 15) / 16) + (long long)((c3 + 31) / 32) * ((c2 + 15) / 16);
+    return nfrag * 1024 + ((c2 + 31) / 32 + (c3 + 31) / 32) * 32 * 4;
+}
+
+// wt1 / wt2 / wt3, b1 / b2 / b3: the layers' PACKED fp32 buffers (include/captra_hip.h "PACKED WEIGHTS").  pre != 0: the image's first
+// layer holds the three xyz rows only (rows cfeat.. of wt1) and no bias (it is inside v1); else all cfeat + 3 rows and b1.
+extern "C" int captra_pack_sa_bf16(int cfeat, int c1, int c2, int c3, int pre, const float *wt1, const float *b1, const float *wt2,
+                                   const float *b2, const float *wt3, const float *b3, unsigned char *img, captra_stream_t stream) {
+    if (cfeat < 0 || c1 < 1 || c2 < 1 || c3 < 1) return -1;
+    if (!pre && cfeat + 3 + 2 > 8) return -2;
+    SbPackParams p;
+    p.cin1 = pre ? 3 : cfeat + 3; p.row0 = pre ? cfeat : 0; p.fold_b1 = pre ? 0 : 1;
+    p.c1 = c1; p.c2 = c2; p.c3 = c3;
+    p.ldw1 = (c1 + 127) / 128 * 128; p.ldw2 = (c2 + 127) / 128 * 128; p.ldw3 = (c3 + 127) / 128 * 128;
+    p.wt1 = wt1; p.b1 = b1; p.wt2 = wt2; p.b2 = b2; p.wt3 = wt3; p.b3 = b3; p.img = img;
+    const long long total = captra_sa_bf16_image_bytes(cfeat, c1, c2, c3);
+    const long long nfrag = (total - ((c2 + 31) / 32 + (c3 + 31) / 32) * 128) / 1024;
+    const long long threads = nfrag * 512 + ((c2 + 31) / 32 + (c3 + 31) / 32) * 32;
+    CAPTRA_LAUNCH("pack_weights", pack_sa_bf16_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
+    return captra_last_error();
+}
+
+// One SA scale.  pre = 0: feat_or_v1 = feat (B,cfeat,N) fp32 (cfeat + 3 <= 6); pre = 1: feat_or_v1 = v1 (B,N,c1) fp32 POINT-major
+// = b1 + W1[feature rows] feat.  img: captra_pack_sa_bf16 with the same (cfeat, c1, c2, c3, pre).
+extern "C" int captra_sa_scale_bf16(int b, int n, int m, int k, int cfeat, int c1, int c2, int c3, int pre, const float *feat_or_v1,
+                                    const float *xyz_cn, const float *new_xyz, const int *idx, const unsigned char *img, float *out,
+                                    int out_ctotal, int co_off, captra_stream_t stream) {
+    if (b < 0 || n < 1 || m < 0 || k < 1 || cfeat < 0 || c1 < 1 || c2 < 1 || c3 < 1) return -1;
+    if (out_ctotal < co_off + c3 || co_off < 0) return -1;
+    if (b == 0 || m == 0) return 0;
+    if ((long long)b * m * k >= (1ll << 31) || (long long)n * (pre ? c1 : 1) * 4 >= (1ll << 31)) return -2;
+    SbParams p;
+    p.n = n; p.m = m; p.feat = pre ? nullptr : feat_or_v1; p.v1pm = pre ? feat_or_v1 : nullptr;
+    p.xyz_cn = xyz_cn; p.new_xyz = new_xyz; p.idx = idx; p.img = img; p.out = out; p.out_ctotal = out_ctotal; p.co_off = co_off;
+    p.jobs_per_cloud = p.njobs = 0;
+    hipStream_t s = (hipStream_t)stream;
+#define SB_CASE(CF_, C1_, C2_, C3_, K_, PRE_, TN_, CG_, WLDS_)                                              \
+    if (cfeat == CF_ && c1 == C1_ && c2 == C2_ && c3 == C3_ && k == K_ && (pre != 0) == PRE_)             \
+        return sb_launch<CF_, C1_, C2_, C3_, K_, PRE_, TN_, CG_, WLDS_>(b, p, s);
+    SB_CASE(0, 32, 32, 64, 32, false, 2, 8, true) SB_CASE(0, 64, 64, 128, 64, false, 2, 8, true) SB_CASE(0, 64, 96, 128, 128, false, 2, 8, true)
+    SB_CASE(3, 32, 32, 64, 32, false, 2, 8, true) SB_CASE(3, 64, 64, 128, 64, false, 2, 8, true) SB_CASE(3, 64, 96, 128, 128, false, 2, 8, true)
+    SB_CASE(320, 128, 128, 256, 64, true, 4, 2, false) SB_CASE(320, 128, 196, 256, 128, true, 4, 1, false)
+#undef SB_CASE
+    return -2;
+}

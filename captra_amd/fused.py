@@ -158,33 +158,54 @@ def sa_scale_pre_supported(cfeat, layers, k) -> bool:
             and (cfeat, layers[0].cout, layers[1].cout, layers[2].cout) in _SA_PRE_SHAPES)
 
 
-_SA_BF16_SHAPES = {(0, 32, 32, 64), (0, 64, 64, 128), (0, 64, 96, 128), (3, 32, 32, 64), (3, 64, 64, 128), (3, 64, 96, 128),
-                   (320, 128, 128, 256), (320, 128, 196, 256)}      # csrc/bf16_mlp.hip BS_CASE list
+_SA_BF16_SHAPES = {(0, 32, 32, 64, 32), (0, 64, 64, 128, 64), (0, 64, 96, 128, 128), (3, 32, 32, 64, 32), (3, 64, 64, 128, 64),
+                   (3, 64, 96, 128, 128), (320, 128, 128, 256, 64), (320, 128, 196, 256, 128)}      # csrc/sa_bf16.hip SB_CASE list
 
 
 def sa_scale_bf16_supported(cfeat, layers, k) -> bool:
-    return (mlp_dtype() == "bf16" and len(layers) == 3 and k % 32 == 0 and 128 % k == 0
-            and (cfeat, layers[0].cout, layers[1].cout, layers[2].cout) in _SA_BF16_SHAPES)
+    return (mlp_dtype() == "bf16" and len(layers) == 3
+            and (cfeat, layers[0].cout, layers[1].cout, layers[2].cout, k) in _SA_BF16_SHAPES)
+
+
+def sa_bf16_image(layers, cfeat: int, pre: bool) -> torch.Tensor:
+    """The weight image of one SA scale for captra_sa_scale_bf16 (fragment-ordered bf16 weights + fp32 biases), built once
+    on the device and cached with the scale's first layer."""
+    l1, l2, l3 = layers
+    key = ("sa_img", cfeat, pre, id(l2), id(l3))
+    cache = l1._bf16
+    if key not in cache:
+        nbytes = L.lib().captra_sa_bf16_image_bytes(cfeat, l1.cout, l2.cout, l3.cout)
+        img = torch.empty(nbytes, dtype=torch.uint8, device=l1.wt.device)
+        with torch.cuda.device(l1.wt.device):
+            L.call("captra_pack_sa_bf16", cfeat, l1.cout, l2.cout, l3.cout, 1 if pre else 0, L.ptr(l1.wt), L.ptr(l1.bias),
+                   L.ptr(l2.wt), L.ptr(l2.bias), L.ptr(l3.wt), L.ptr(l3.bias), L.ptr(img))
+        cache[key] = (img, l2, l3)          # the key holds ids: keep the layers it was built from alive with it
+    return cache[key][0]
 
 
 def sa_scale_bf16(feat, xyz_cn, new_xyz_n3, idx, layers, out, co_off):
-    """One SA scale with bf16 MFMA operands (captra_sa_scale_bf16); wide inputs go through the pre-transformed first layer."""
+    """One SA scale with bf16 MFMA operands (captra_sa_scale_bf16); wide inputs go through the pre-transformed first layer
+    (point-major, once per source point)."""
     l1, l2, l3 = layers
     B, _, N = xyz_cn.shape
     _, M, K = idx.shape
     cfeat = 0 if feat is None else feat.shape[1]
-    pre = cfeat + 3 > 8
+    pre = cfeat + 3 > 6
     if pre:
-        src = sa_first_layer_pre(feat, l1)                      # (B,c1,N) fp32 through the bf16 dense kernel
-        w1 = l1.bf16(cfeat, 3)                                   # the three xyz rows
+        lead = l1.leading_rows(cfeat)
+        src = torch.empty(B, N, l1.cout, dtype=torch.float32, device=feat.device)
+        L.require_device(feat)
+        with torch.cuda.device(feat.device):
+            L.call("captra_pointwise_mlp_bf16_pm", B, cfeat, l1.cout, N, L.ptr(feat), L.ptr(lead.bf16(0, cfeat)), L.ptr(lead.bias),
+                   ACT_NONE, L.ptr(src))
+        _work("pointwise_mlp", flops=2.0 * B * cfeat * l1.cout * N, nbytes=4.0 * B * N * (cfeat + l1.cout))
     else:
         src = feat
-        w1 = l1.bf16(0, cfeat + 3)
+    img = sa_bf16_image(layers, cfeat, pre)
     L.require_device(src, xyz_cn, new_xyz_n3, idx, out)
     with torch.cuda.device(xyz_cn.device):
         L.call("captra_sa_scale_bf16", B, N, M, K, cfeat, l1.cout, l2.cout, l3.cout, 1 if pre else 0, L.ptr(src), L.ptr(xyz_cn),
-               L.ptr(new_xyz_n3), L.ptr(idx), L.ptr(w1), L.ptr(l1.bias), L.ptr(l2.bf16()), L.ptr(l2.bias), L.ptr(l3.bf16()),
-               L.ptr(l3.bias), L.ptr(out), out.shape[1], co_off)
+               L.ptr(new_xyz_n3), L.ptr(idx), L.ptr(img), L.ptr(out), out.shape[1], co_off)
     _work("sa_scale_fused", flops=2.0 * B * M * K * ((3 if pre else cfeat + 3) * l1.cout + l1.cout * l2.cout + l2.cout * l3.cout),
           nbytes=4.0 * B * ((l1.cout if pre else cfeat) * N + 3 * N + M * K + 3 * M + l3.cout * M))
     return out

@@ -197,15 +197,26 @@ int captra_gn_finalize(int b, int c, int channels_per_group, int stats_t, long l
  * input is rounded when it becomes an MFMA operand; bias (the fp32 packed bias of captra_pack_weights) and accumulation
  * in fp32; tensors in memory stay fp32.
  *   captra_pointwise_mlp_bf16: as captra_pointwise_mlp.
- *   captra_sa_scale_bf16: one SA scale, register-resident.  pre = 0: feat_or_v1 = feat (B,cfeat,N) (cfeat + 3 <= 8), w1 packs
- *     all cfeat+3 input rows; pre = 1: feat_or_v1 = v1 (B,c1,N) fp32 = b1 + W1[feature rows] feat (captra_pointwise_mlp_bf16),
- *     w1 packs the three xyz rows only (cin = 3), b1 unused.  Instantiated for the CAPTRA backbone shapes; -2 otherwise. */
+ *   captra_pointwise_mlp_bf16_pm: the same layer with y POINT-major (B,L,cout) fp32, cout % 4 == 0.
+ *   captra_sa_scale_bf16 (csrc/sa_bf16.hip): one SA scale, register-resident, from a weight IMAGE built once per scale by
+ *     captra_pack_sa_bf16 (captra_sa_bf16_image_bytes bytes) from the three layers' packed fp32 buffers: MFMA-fragment-ordered
+ *     bf16 weights (layers 2 / 3 with the k order the in-register hand-over produces) followed by the fp32 biases of layers
+ *     2 / 3.  pre = 0: feat_or_v1 = feat (B,cfeat,N) fp32, cfeat + 3 <= 6, b1 rides as two constant-one input rows (hi + lo
+ *     bf16 split); pre = 1: feat_or_v1 = v1 (B,N,c1) fp32 POINT-major = b1 + W1[feature rows] feat (captra_pointwise_mlp_bf16_pm
+ *     on the layer's leading rows), the image's first layer holds the three xyz rows only.  Layer 3's bias is added after the
+ *     max over the neighbours (equal to adding it before: rounding is monotone).  Instantiated for the CAPTRA backbone shapes
+ *     (same list as captra_sa_scale_fused's register-resident kernels, k = 32 / 64 / 128 as in the configs); -2 otherwise. */
 int captra_pack_weights_bf16(int cin, int cout, const float *wt, unsigned short *wb, captra_stream_t stream);
 int captra_pointwise_mlp_bf16(int b, int cin, int cout, long long l, const float *x, const unsigned short *wb,
                               const float *bias_packed, int act, float *y, captra_stream_t stream);
+int captra_pointwise_mlp_bf16_pm(int b, int cin, int cout, long long l, const float *x, const unsigned short *wb,
+                                 const float *bias_packed, int act, float *y, captra_stream_t stream);
+long long captra_sa_bf16_image_bytes(int cfeat, int c1, int c2, int c3);
+int captra_pack_sa_bf16(int cfeat, int c1, int c2, int c3, int pre, const float *wt1_packed, const float *b1_packed,
+                        const float *wt2_packed, const float *b2_packed, const float *wt3_packed, const float *b3_packed,
+                        unsigned char *img, captra_stream_t stream);
 int captra_sa_scale_bf16(int b, int n, int m, int k, int cfeat, int c1, int c2, int c3, int pre, const float *feat_or_v1,
-                         const float *xyz_cn, const float *new_xyz, const int *idx, const unsigned short *w1, const float *b1,
-                         const unsigned short *w2, const float *b2, const unsigned short *w3, const float *b3, float *out,
+                         const float *xyz_cn, const float *new_xyz, const int *idx, const unsigned char *img, float *out,
                          int out_ctotal, int co_off, captra_stream_t stream);
 
 /* Furthest point sampling + index_points in one launch (pointnet_utils.py:222-223: new_xyz = index_points(xyz,

@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--wn", type=int, default=0)
     ap.add_argument("--pre", action="store_true", help="pre-transformed first layer (captra_sa_scale_pre) where supported; time includes the v1 launch")
     ap.add_argument("--pipe", action="store_true", help="pipelined SA2 kernel (captra_sa_scale_pre_pm); time includes the point-major v1 launch")
+    ap.add_argument("--bf16", action="store_true", help="the bf16-native kernel (csrc/sa_bf16.hip); time includes the point-major v1 launch of the SA2 scales")
     ap.add_argument("--zeros", action="store_true", help="all-zero features / weights: same instruction stream at lower power (DVFS probe)")
     ap.add_argument("--mode", type=int, default=0, help="0 = register-resident kernels where instantiated, 1 = generic LDS kernel")
     ap.add_argument("--phases", action="store_true", help="debug: in-kernel s_memtime phase breakdown of sa_wave_kernel")
@@ -53,6 +54,9 @@ def main():
                 lin.wt.zero_(); lin.bias.zero_()
 
         def run():
+            if a.bf16:
+                fused.sa_scale_bf16(feat, xyz, new_xyz, idx, layers, out, 0)
+                return
             if a.layered:
                 y = fused.sa_group_mlp(feat, xyz, new_xyz, idx, layers[0])
                 y = fused.pointwise_mlp(y, layers[1], fused.ACT_RELU)
@@ -66,7 +70,10 @@ def main():
             else:
                 fused.sa_scale_fused(feat, xyz, new_xyz, idx, layers, out, 0)
 
-        if not a.layered:
+        if a.bf16:
+            fused.set_mlp_dtype("bf16")
+            assert fused.sa_scale_bf16_supported(cfeat, layers, k), name
+        if not a.layered and not a.bf16:
             _lib.lib().captra_sa_fused_set_mode(ctypes.c_int(1))
             fused.sa_scale_fused(feat, xyz, new_xyz, idx, layers, out, 0)
             ref = out.clone()
@@ -102,6 +109,8 @@ def main():
         _lib.prof_enable(False)
         ms = sum(_lib.prof_read(nm)[0] for nm in _lib.prof_names()) / a.iters
         flops = 2.0 * B * m * k * sum(dims[i] * dims[i + 1] for i in range(3))
+        if a.bf16 and cfeat > 3:
+            flops = 2.0 * B * (m * k * (3 * dims[1] + dims[1] * dims[2] + dims[2] * dims[3]) + n * cfeat * dims[1])   # as executed
         print(f"{name:6s} {'layered' if a.layered else 'fused':7s} {ms * 1e3:9.1f} us  {flops / ms / 1e9:7.1f} TFLOP/s  ({flops / 1e9:.1f} GFLOP)", flush=True)
 
 

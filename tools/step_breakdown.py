@@ -24,7 +24,7 @@ def main():
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     fused.set_mlp_dtype(a.mlp_dtype)
-    cfg, sd, model, _ = bench.build_workload(a.batch, dev)
+    cfg, sd, model, _ = bench.build_workload(a.batch, dev, mlp_dtype=a.mlp_dtype)
     pose = {k: v.clone() for k, v in model.feed_dict[0]["gt_part"].items()}
     records = OrderedDict()
     orig_call = _lib.call
@@ -57,12 +57,13 @@ def main():
         us = 1e3 * sum(e0.elapsed_time(e1) for e0, e1 in evs) / len(evs)
         tot += us
         tf = ""
-        if name == "captra_pointwise_mlp":
+        if name in ("captra_pointwise_mlp", "captra_pointwise_mlp_bf16", "captra_pointwise_mlp_bf16_pm", "captra_pointwise_mlp_pm", "captra_pointwise_mlp_gn"):
             b, cin, cout, l = ints[:4]
             tf = f"{2.0 * b * cin * cout * l / us / 1e6:8.1f}"
-        elif name == "captra_sa_scale_fused":
+        elif name in ("captra_sa_scale_fused", "captra_sa_scale_bf16", "captra_sa_scale_pre", "captra_sa_scale_pre_pm"):
             b, n, m, k, cf, c1, c2, c3 = ints[:8]
-            tf = f"{2.0 * b * m * k * ((cf + 3) * c1 + c1 * c2 + c2 * c3) / us / 1e6:8.1f}"
+            cin1 = 3 if (name != "captra_sa_scale_fused" and cf > 3) else cf + 3      # pre-transformed first layer: xyz rows only
+            tf = f"{2.0 * b * m * k * (cin1 * c1 + c1 * c2 + c2 * c3) / us / 1e6:8.1f}"
         elif name == "captra_mlp_chain3":
             b, c0, c1, c2, c3, l = ints[:6]
             tf = f"{2.0 * b * l * (c0 * c1 + c1 * c2 + c2 * c3) / us / 1e6:8.1f}"
