@@ -47,6 +47,9 @@ _SIGNATURES = {
     "captra_pack_weights_frag": [_INT, _INT, _P, _P],
     "captra_pointwise_mlp_bf16": [_INT, _INT, _INT, _LL, _P, _P, _P, _INT, _P, _P],
     "captra_pointwise_mlp_bf16_pm": [_INT, _INT, _INT, _LL, _P, _P, _P, _INT, _P, _P],
+    "captra_pack_dense_bf16": [_INT, _INT, _INT, _P, _P, _P],
+    "captra_pointwise_mlp_bf16pm": [_INT, _INT, _INT, _LL, _INT, _P, _P, _P, _P, _INT, _INT, _P, _P],
+    "captra_gn_stats_bf16pm": [_INT, _INT, _LL, _P, _P, _P],
     "captra_pack_sa_bf16": [_INT] * 5 + [_P] * 7 + [_P],
     "captra_sa_scale_bf16": [_INT] * 9 + [_P] * 6 + [_INT, _INT, _P],
     "captra_coord_tail": [_INT, _INT, _INT, _INT, _LL, _P, _P, _P, _INT, _P, _P, _P],
@@ -103,6 +106,11 @@ def lib():
         if hasattr(l, "captra_packed_weight_floats"):
             l.captra_packed_weight_floats.argtypes = [_INT, _INT]
             l.captra_packed_weight_floats.restype = _LL
+        if hasattr(l, "captra_dense_bf16_image_bytes"):
+            l.captra_dense_bf16_image_bytes.argtypes = [_INT, _INT]
+            l.captra_dense_bf16_image_bytes.restype = _LL
+            l.captra_gn_stats_bf16pm_tiles.argtypes = [_LL]
+            l.captra_gn_stats_bf16pm_tiles.restype = _INT
         if hasattr(l, "captra_sa_bf16_image_bytes"):
             l.captra_sa_bf16_image_bytes.argtypes = [_INT] * 4
             l.captra_sa_bf16_image_bytes.restype = _LL

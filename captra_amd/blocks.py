@@ -62,6 +62,10 @@ def run_point_mlp(seq: nn.Sequential, x: torch.Tensor, cache: dict) -> torch.Ten
     mods = list(seq)
     i = 0
     x = x.contiguous()
+    if fused.mlp_dtype() == "bf16":
+        y = _run_gn_chain_bf16(mods, x, cache)
+        if y is not None:
+            return y
     pending = None      # GroupNorm coefficients (B,C,2) of the layer that produced x, not applied yet (fused GN chain)
     while i < len(mods):
         conv = mods[i]
@@ -117,6 +121,40 @@ def run_point_mlp(seq: nn.Sequential, x: torch.Tensor, cache: dict) -> torch.Ten
         i = j
     if pending is not None:          # (cannot happen for the heads of this network: their last conv has no norm)
         x = torch.relu(x * pending[:, :, 0:1] + pending[:, :, 1:2])
+    return x
+
+
+def _run_gn_chain_bf16(mods, x, cache):
+    """bf16 mode (cfg['mlp_dtype'] = 'bf16', BASELINE.json configs[2]): a Sequential of the exact form (Conv1d, GroupNorm,
+    ReLU) x n, Conv1d -- the rotation heads (reference blocks.py:147-165) -- with the hidden activations kept in HBM as bf16
+    point-major tensors (csrc/dense_bf16.hip): each hidden layer stores its raw output, one pass takes the group statistics
+    of what was stored, and the next layer applies relu(a x + b) while it loads its operand.  None when the Sequential has
+    another shape (the caller's generic path runs it)."""
+    layers, i = [], 0
+    while i < len(mods):
+        if not isinstance(mods[i], nn.Conv1d):
+            return None
+        if i + 2 < len(mods) and isinstance(mods[i + 1], nn.GroupNorm) and isinstance(mods[i + 2], nn.ReLU):
+            layers.append((mods[i], mods[i + 1]))
+            i += 3
+        elif i == len(mods) - 1:
+            layers.append((mods[i], None))
+            i += 1
+        else:
+            return None
+    if len(layers) < 2 or not fused.gn_chain_bf16_supported(x, [c.out_channels for c, g in layers if g is not None]):
+        return None
+    n = x.shape[2]
+    ab, in_pm = None, False
+    for conv, gn in layers:
+        if id(conv) not in cache:
+            cache[id(conv)] = fold_conv_bn(conv, None, x.device)
+        lin = cache[id(conv)]
+        x = fused.pointwise_mlp_bf16pm(x, lin, n, in_pm=in_pm, out_pm=gn is not None, ab=ab, act=fused.ACT_NONE)
+        if gn is not None:
+            stats = fused.gn_stats_bf16pm(x, lin.cout)
+            ab = fused.gn_finalize(stats, gn.num_groups, gn.weight, gn.bias, gn.eps, n)
+            in_pm = True
     return x
 
 

@@ -1,0 +1,344 @@
+// bf16-native dense layers for gfx950 (BASELINE.json configs[2]): the Conv1d 1x1 -> GroupNorm -> ReLU chains of the rotation
+// heads (reference network/models/blocks.py:147-193) with the activations kept in HBM as bf16, POINT-major:
+//
+//   tensor (B, L, CP) bf16, CP = ceil32(C), channels in SLOT ORDER: inside every aligned block of 16 channels, memory slot s
+//   holds channel perm[s] = {0,1,2,3,8,9,10,11,4,5,6,7,12,13,14,15} -- the order in which a 32x32 MFMA accumulator tile hands
+//   its rows to a lane (csrc/sa_bf16.hip header), so a producer's epilogue is 8 v_cvt_pk_bf16_f32 (+ 8 v_pk_max_i16 for a
+//   ReLU) and two 16-byte stores per tile, and a consumer's B operand is ONE 16-byte load per lane and k-step (the fp32
+//   tensors of round 2 took eight dword loads + four conversions, and twice the bytes).
+//
+// Contract per layer: y = act(b + sum_k bf16(w[k]) * bf16(x[k])), fp32 accumulation; with `ab` the input is
+// x = bf16(relu(a[c] * xraw + b[c])) -- the GroupNorm of the layer that produced xraw, applied while the operand is loaded,
+// exactly as the fp32 path's pw_direct_kernel<..., AFF> does; xraw is that layer's output as stored (rounded to bf16), and
+// the statistics are taken from the stored tensor (captra_gn_stats_bf16pm), so the normalisation is self-consistent.
+//
+// Kernel: no LDS for operands, no barriers; wave tile (TM*32 rows) x (TN*32 positions); A operands from the layer's FRAGMENT
+// IMAGE (captra_pack_dense_bf16: frag (t,kk) = 64 lanes x 16 bytes, coalesced 1 KiB loads), three k-steps in flight.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned db_pack(float lo, float hi) {
+    const f32x2 f = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2));
+}
+__device__ __forceinline__ unsigned db_relu2(unsigned v) {
+    const s16x2 z = {0, 0};
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, v), z));
+}
+__device__ __forceinline__ f32x16 db_mfma(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__host__ __device__ __forceinline__ int db_perm(int s) { return (s & 3) | ((s & 4) << 1) | ((s & 8) >> 1); }
+
+// ---- weight image: [NT][KST][64 lanes][8] bf16; perm != 0: k-slot s of k-step kk = input channel 16kk + perm[s] ------------
+__global__ void pack_dense_bf16_kernel(int cin, int cout, int ldw, int perm, const float *__restrict__ wt, unsigned short *__restrict__ img) {
+    const int kst = (cin + 15) / 16, nt = (cout + 31) / 32;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nt * kst * 512) return;
+    const int f = e >> 9, lane = (e >> 3) & 63, el = e & 7;
+    const int t = f / kst, kk = f % kst;
+    const int slot = 8 * (lane >> 5) + el;
+    const int row = 32 * t + (lane & 31), k = 16 * kk + (perm ? db_perm(slot) : slot);
+    const float v = (row < cout && k < cin) ? wt[(size_t)k * ldw + row] : 0.f;
+    const __bf16 h = (__bf16)v;
+    img[e] = __builtin_bit_cast(unsigned short, h);
+}
+
+struct DbParams {
+    int cin, cout, kst, nt;
+    int cp_in, cp_out;        // channel stride (elements) of a point-major input / output
+    long long L;
+    const void *x;            // IN_PM: (B,L,cp_in) bf16 slot order; else (B,cin,L) fp32
+    const unsigned char *wimg;
+    const float *bias;        // packed fp32 (ceil128(cout))
+    const float *ab;          // AFF: (B,cin,2) fp32
+    void *y;                  // OUT_PM: (B,L,cp_out) bf16 slot order; else (B,cout,L) fp32
+    int act;
+};
+
+// x = bf16(relu(a * x + b)) on the 8 channels of a lane's B-operand registers; t = 16 floats (a0..a7, b0..b7) in LDS
+__device__ __forceinline__ u32x4 db_affine(u32x4 v, const float *t) {
+    const float4 a0 = *reinterpret_cast<const float4 *>(t), a1 = *reinterpret_cast<const float4 *>(t + 4);
+    const float4 b0 = *reinterpret_cast<const float4 *>(t + 8), b1 = *reinterpret_cast<const float4 *>(t + 12);
+    const float a[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+    const float b[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+    u32x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float lo = __uint_as_float(v[i] << 16), hi = __uint_as_float(v[i] & 0xffff0000u);
+        r[i] = db_relu2(db_pack(__builtin_fmaf(lo, a[2 * i], b[2 * i]), __builtin_fmaf(hi, a[2 * i + 1], b[2 * i + 1])));
+    }
+    return r;
+}
+
+template <int TM, int TN, bool IN_PM, bool AFF, bool OUT_PM>
+__global__ __launch_bounds__(256, 2) void pw_bf16pm_kernel(DbParams p) {
+    static_assert(!AFF || IN_PM, "the on-load GroupNorm needs the point-major input");
+    constexpr int NS = 3;                                  // k-steps in flight
+    extern __shared__ __attribute__((aligned(16))) float aff_tab[];   // AFF: [kst][2 halves][16]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, col = lane & 31;
+    const int b = blockIdx.z;
+    const int t0 = blockIdx.y * TM;
+    const long long pos0 = ((long long)blockIdx.x * 4 + wave) * TN * 32;
+    if constexpr (AFF) {
+        const float *abp = p.ab + (size_t)b * p.cin * 2;
+        for (int e = tid; e < p.kst * 32; e += 256) {
+            const int kk = e >> 5, hh = (e >> 4) & 1, i = e & 15;
+            const int c = 16 * kk + db_perm(8 * hh + (i & 7));
+            aff_tab[e] = c < p.cin ? abp[2 * c + (i >> 3)] : 0.f;
+        }
+        __syncthreads();
+    }
+    if (pos0 >= p.L) return;                               // wave-uniform; no barrier below
+    const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc((void *)p.wimg, 0, p.nt * p.kst * 1024, 0x00020000);
+    __amdgpu_buffer_rsrc_t xsrc;
+    int xvoff[TN];
+    int woff[TM];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+        const int t = t0 + tm < p.nt ? t0 + tm : p.nt - 1;     // clamped row tile: computed, never stored
+        woff[tm] = t * p.kst * 1024;
+    }
+    if constexpr (IN_PM) {
+        const __bf16 *xb = reinterpret_cast<const __bf16 *>(p.x) + (size_t)b * p.L * p.cp_in;
+        xsrc = __builtin_amdgcn_make_buffer_rsrc((void *)xb, 0, (int)(p.L * p.cp_in * 2), 0x00020000);
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            long long c = pos0 + tn * 32 + col;
+            if (c >= p.L) c = p.L - 1;                         // clamped column: computed, never stored
+            xvoff[tn] = (int)((c * p.cp_in + 8 * h) * 2);
+        }
+    } else {
+        const float *xb = reinterpret_cast<const float *>(p.x) + (size_t)b * p.cin * p.L;
+        xsrc = __builtin_amdgcn_make_buffer_rsrc((void *)xb, 0, (int)((long long)p.cin * p.L * 4), 0x00020000);
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            long long c = pos0 + tn * 32 + col;
+            if (c >= p.L) c = p.L - 1;
+            xvoff[tn] = (int)(((long long)(8 * h) * p.L + c) * 4);   // rows >= cin fall outside the buffer and read as 0
+        }
+    }
+    const int xrow = (int)(p.L * 4);
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+        const float *bp = p.bias + (t0 + tm < p.nt ? t0 + tm : p.nt - 1) * 32 + 4 * h;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float bv = bp[(r & 3) + 8 * (r >> 2)];
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) acc[tm][tn][r] = bv;
+        }
+    }
+    u32x4 A[NS][TM];
+    u32x4 Bp[NS][TN];                 // IN_PM
+    float Bf[IN_PM ? 1 : NS][IN_PM ? 1 : TN][8];
+    const int kst = p.kst;
+    auto load = [&](int s, int kk) {
+        kk = kk < kst ? kk : kst - 1;                          // over-read of the last k-step (never multiplied)
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) A[s][tm] = __builtin_amdgcn_raw_buffer_load_b128(wsrc, lane * 16, woff[tm] + kk * 1024, 0);
+        if constexpr (IN_PM) {
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) Bp[s][tn] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, xvoff[tn], kk * 32, 0);
+        } else {
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    Bf[s][tn][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xsrc, xvoff[tn] + (kk * 16 + i) * xrow, 0, 0));
+        }
+    };
+    auto mma = [&](int s, int kk) {
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            u32x4 bb;
+            if constexpr (IN_PM) {
+                bb = Bp[s][tn];
+                if constexpr (AFF) bb = db_affine(bb, aff_tab + (kk * 2 + h) * 16);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bb[i] = db_pack(Bf[s][tn][2 * i], Bf[s][tn][2 * i + 1]);
+            }
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) acc[tm][tn] = db_mfma(A[s][tm], bb, acc[tm][tn]);
+        }
+    };
+    load(0, 0);
+    load(1, 1);
+    for (int kk = 0; kk < kst; kk += NS) {
+        load(2, kk + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(0, kk);
+        __builtin_amdgcn_sched_barrier(0);
+        load(0, kk + 3);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kk + 1 < kst) mma(1, kk + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        load(1, kk + 4);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kk + 2 < kst) mma(2, kk + 2);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- epilogue ------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+        if (t0 + tm >= p.nt) continue;
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const long long c = pos0 + tn * 32 + col;
+            if (c >= p.L) continue;
+            if constexpr (OUT_PM) {
+                __bf16 *yp = reinterpret_cast<__bf16 *>(p.y) + ((size_t)b * p.L + c) * p.cp_out + 32 * (t0 + tm) + 8 * h;
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    u32x4 v;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        v[i] = db_pack(acc[tm][tn][8 * jj + 2 * i], acc[tm][tn][8 * jj + 2 * i + 1]);
+                        if (p.act == ACT_RELU) v[i] = db_relu2(v[i]);
+                    }
+                    *reinterpret_cast<u32x4 *>(yp + 16 * jj) = v;
+                }
+            } else {
+                const int row0 = 32 * (t0 + tm) + 4 * h;
+                float *yp = reinterpret_cast<float *>(p.y) + ((size_t)b * p.cout + row0) * p.L + c;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ro = (r & 3) + 8 * (r >> 2);
+                    if (row0 + ro < p.cout) yp[(size_t)ro * p.L] = apply_act(acc[tm][tn][r], p.act);
+                }
+            }
+        }
+    }
+}
+
+// ---- GroupNorm partial statistics of a stored point-major tensor --------------------------------------------------------------
+// x (B,L,CP) bf16 slot order -> stats (B,C,T,2) fp32: per channel and chunk of `pch` positions (sum, sum of squares) of the
+// STORED values; captra_gn_finalize turns them into the (a, b) the consumer applies.  Block = (chunk, cloud); thread = one
+// 16-byte channel group of one position per step; fixed summation order (no atomics).
+__global__ __launch_bounds__(256) void gn_stats_bf16pm_kernel(int c, int cp, long long L, int pch, int T, const unsigned short *__restrict__ x,
+                                                              float *__restrict__ stats) {
+    __shared__ float red[256 * 16];
+    const int tid = threadIdx.x;
+    const int G = cp / 8, npar = 256 / G;
+    const int g = tid % G, pl = tid / G;
+    const int chunk = blockIdx.x, b = blockIdx.y;
+    const long long p0 = (long long)chunk * pch, p1 = p0 + pch < L ? p0 + pch : L;
+    float s[8], q[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s[i] = q[i] = 0.f;
+    const uint4 *xb = reinterpret_cast<const uint4 *>(x + (size_t)b * L * cp);
+    for (long long pos = p0 + pl; pos < p1; pos += npar) {
+        const uint4 v = xb[pos * G + g];
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float lo = __uint_as_float(w[i] << 16), hi = __uint_as_float(w[i] & 0xffff0000u);
+            s[2 * i] += lo; q[2 * i] = __builtin_fmaf(lo, lo, q[2 * i]);
+            s[2 * i + 1] += hi; q[2 * i + 1] = __builtin_fmaf(hi, hi, q[2 * i + 1]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        red[tid * 16 + i] = s[i];
+        red[tid * 16 + 8 + i] = q[i];
+    }
+    __syncthreads();
+    // thread (g2, e) sums the npar position-lanes of channel group g2, element e
+    for (int o = tid; o < G * 8; o += 256) {
+        const int g2 = o >> 3, e = o & 7;
+        float sm = 0.f, sq = 0.f;
+        for (int k = 0; k < npar; ++k) {
+            sm += red[(k * G + g2) * 16 + e];
+            sq += red[(k * G + g2) * 16 + 8 + e];
+        }
+        const int ch = 16 * (g2 >> 1) + db_perm(8 * (g2 & 1) + e);
+        if (ch < c) {
+            float *dst = stats + (((size_t)b * c + ch) * T + chunk) * 2;
+            dst[0] = sm;
+            dst[1] = sq;
+        }
+    }
+}
+
+template <int TM, int TN, bool IN_PM, bool AFF, bool OUT_PM>
+int db_launch(int b, const DbParams &p, hipStream_t s) {
+    dim3 grid((unsigned)((p.L + 4 * TN * 32 - 1) / (4 * TN * 32)), (p.nt + TM - 1) / TM, b);
+    const int lds = AFF ? p.kst * 32 * 4 : 0;
+    CAPTRA_LAUNCH("pointwise_mlp", (pw_bf16pm_kernel<TM, TN, IN_PM, AFF, OUT_PM>), grid, dim3(256), lds, s, p);
+    return captra_last_error();
+}
+
+}  // namespace
+
+extern "C" long long captra_dense_bf16_image_bytes(int cin, int cout) {
+    if (cin < 1 || cout < 1) return -1;
+    return (long long)((cout + 31) / 32) * ((cin + 15) / 16) * 1024;
+}
+
+// wt_packed: the layer's packed fp32 buffer (row-major part W'^T (ceil32(cin), ceil128(cout))).  perm = 1 for a layer whose
+// input is a point-major slot-order tensor, 0 for a channel-major fp32 input.
+extern "C" int captra_pack_dense_bf16(int cin, int cout, int perm, const float *wt_packed, unsigned char *img, captra_stream_t stream) {
+    if (cin < 1 || cout < 1) return -1;
+    const long long n = captra_dense_bf16_image_bytes(cin, cout) / 2;
+    CAPTRA_LAUNCH("pack_weights", pack_dense_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, cin, cout,
+                  (cout + 127) / 128 * 128, perm, wt_packed, reinterpret_cast<unsigned short *>(img));
+    return captra_last_error();
+}
+
+// One dense layer.  in_pm: x is (B,L,ceil32(cin)) bf16 slot order (image packed with perm = 1), else (B,cin,L) fp32 (perm = 0).
+// ab (in_pm only): (B,cin,2) GroupNorm coefficients of the producing layer, applied as relu(a x + b) on load; or NULL.
+// out_pm: y is (B,L,ceil32(cout)) bf16 slot order, else (B,cout,L) fp32.  act: CAPTRA_ACT_NONE / RELU (out_pm), any (fp32 out).
+extern "C" int captra_pointwise_mlp_bf16pm(int b, int cin, int cout, long long l, int in_pm, const void *x, const unsigned char *wimg,
+                                           const float *bias_packed, const float *ab, int act, int out_pm, void *y, captra_stream_t stream) {
+    if (b < 0 || cin < 1 || cout < 1 || l < 0 || act < 0 || act > 2) return -1;
+    if (ab != nullptr && !in_pm) return -1;
+    if (out_pm && act == ACT_SIGMOID_M05) return -1;
+    const int cp_in = (cin + 31) / 32 * 32, cp_out = (cout + 31) / 32 * 32;
+    if (in_pm ? l * cp_in * 2 >= (1ll << 31) : (long long)cin * l * 4 >= (1ll << 31)) return -2;
+    if (b == 0 || l == 0) return 0;
+    DbParams p;
+    p.cin = cin; p.cout = cout; p.kst = (cin + 15) / 16; p.nt = (cout + 31) / 32; p.cp_in = cp_in; p.cp_out = cp_out; p.L = l;
+    p.x = x; p.wimg = wimg; p.bias = bias_packed; p.ab = ab; p.y = y; p.act = act;
+    if (ab != nullptr && p.kst * 32 * 4 > 64 * 1024) return -2;
+    hipStream_t s = (hipStream_t)stream;
+    const bool wide = p.nt >= 4;
+#define DB_GO(TM_, TN_)                                                                              \
+    do {                                                                                             \
+        if (in_pm && ab && out_pm) return db_launch<TM_, TN_, true, true, true>(b, p, s);            \
+        if (in_pm && ab) return db_launch<TM_, TN_, true, true, false>(b, p, s);                     \
+        if (in_pm && out_pm) return db_launch<TM_, TN_, true, false, true>(b, p, s);                 \
+        if (in_pm) return db_launch<TM_, TN_, true, false, false>(b, p, s);                          \
+        if (out_pm) return db_launch<TM_, TN_, false, false, true>(b, p, s);                         \
+        return db_launch<TM_, TN_, false, false, false>(b, p, s);                                    \
+    } while (0)
+    if (wide) DB_GO(4, 2);
+    if (p.nt >= 2) DB_GO(2, 2);
+    DB_GO(1, 2);
+#undef DB_GO
+}
+
+extern "C" int captra_gn_stats_bf16pm_tiles(long long l) { return (int)((l + 127) / 128); }
+
+// x (B,L,ceil32(c)) bf16 slot order -> stats (B,c,T,2), T = captra_gn_stats_bf16pm_tiles(l) (chunks of 128 positions)
+extern "C" int captra_gn_stats_bf16pm(int b, int c, long long l, const void *x, float *stats, captra_stream_t stream) {
+    if (b < 0 || c < 1 || l < 1) return -1;
+    const int cp = (c + 31) / 32 * 32, G = cp / 8;
+    if (256 % G != 0) return -2;
+    if (b == 0) return 0;
+    const int T = captra_gn_stats_bf16pm_tiles(l);
+    CAPTRA_LAUNCH("gn_stats", gn_stats_bf16pm_kernel, dim3(T, b), dim3(256), 0, (hipStream_t)stream, c, cp, l, 128, T,
+                  reinterpret_cast<const unsigned short *>(x), stats);
+    return captra_last_error();
+}

@@ -94,6 +94,18 @@ class PackedLinear:
             cache[key] = wb
         return cache[key]
 
+    def bf16_frag(self, perm: bool) -> torch.Tensor:
+        """Fragment-ordered bf16 image of the whole layer for the bf16-native dense kernel (captra_pack_dense_bf16); perm: the
+        layer's input is a point-major slot-order tensor."""
+        from . import _lib as L
+        key = ("frag", bool(perm))
+        if key not in self._bf16:
+            img = torch.empty(L.lib().captra_dense_bf16_image_bytes(self.cin, self.cout), dtype=torch.uint8, device=self.wt.device)
+            with torch.cuda.device(self.wt.device):
+                L.call("captra_pack_dense_bf16", self.cin, self.cout, 1 if perm else 0, L.ptr(self.wt), L.ptr(img))
+            self._bf16[key] = img
+        return self._bf16[key]
+
 
 def fold_conv_bn(conv, bn=None, device=None) -> PackedLinear:
     """conv: nn.Conv1d/Conv2d with 1x1 kernel; bn: BatchNorm or None -> PackedLinear on `device`."""

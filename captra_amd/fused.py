@@ -128,6 +128,48 @@ def pointwise_mlp(x, lin: PackedLinear, act: int = ACT_RELU, out=None):
     return out
 
 
+def pm_channels(c: int) -> int:
+    """Channel stride of a point-major bf16 tensor (include/captra_hip.h "bf16-NATIVE dense layers")."""
+    return (c + 31) // 32 * 32
+
+
+def pointwise_mlp_bf16pm(x, lin: PackedLinear, l: int, in_pm: bool, out_pm: bool, ab=None, act: int = ACT_NONE):
+    """One bf16-native dense layer (captra_pointwise_mlp_bf16pm).  x: (B,cin,l) fp32, or (B,l,ceil32(cin)) bf16 slot order when
+    in_pm; result (B,cout,l) fp32, or (B,l,ceil32(cout)) bf16 slot order when out_pm.  ab (B,cin,2): GroupNorm coefficients of
+    the producer, applied as relu(a x + b) on load."""
+    B = x.shape[0]
+    L.require_device(x, ab)
+    if in_pm:
+        assert x.dtype == torch.bfloat16 and tuple(x.shape) == (B, l, pm_channels(lin.cin)), (x.shape, lin.cin, l)
+    else:
+        assert x.dtype == torch.float32 and x.shape[1] == lin.cin and x.numel() == B * lin.cin * l, (x.shape, lin.cin, l)
+    y = (torch.empty(B, l, pm_channels(lin.cout), dtype=torch.bfloat16, device=x.device) if out_pm
+         else torch.empty(B, lin.cout, l, dtype=torch.float32, device=x.device))
+    with torch.cuda.device(x.device):
+        L.call("captra_pointwise_mlp_bf16pm", B, lin.cin, lin.cout, l, 1 if in_pm else 0, L.ptr(x), L.ptr(lin.bf16_frag(in_pm)),
+               L.ptr(lin.bias), L.ptr(ab), act, 1 if out_pm else 0, L.ptr(y))
+    _work("pointwise_mlp", flops=2.0 * B * lin.cin * lin.cout * l, nbytes=B * l * ((2.0 if in_pm else 4.0) * lin.cin + (2.0 if out_pm else 4.0) * lin.cout))
+    return y
+
+
+def gn_stats_bf16pm(x, c: int):
+    """x (B,l,ceil32(c)) bf16 slot order -> partial statistics (B,c,T,2) of the stored values (captra_gn_stats_bf16pm)."""
+    L.require_device(x)
+    B, l, cp = x.shape
+    assert x.dtype == torch.bfloat16 and cp == pm_channels(c)
+    t = L.lib().captra_gn_stats_bf16pm_tiles(l)
+    stats = torch.empty(B, c, t, 2, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        L.call("captra_gn_stats_bf16pm", B, c, l, L.ptr(x), L.ptr(stats))
+    _work("gn_stats", nbytes=2.0 * B * l * cp)
+    return stats
+
+
+def gn_chain_bf16_supported(x, couts) -> bool:
+    """Conv -> GroupNorm -> ReLU chains in the bf16 mode: every normalised width must tile the statistics kernel."""
+    return mlp_dtype() == "bf16" and x.dim() == 3 and all(256 % (pm_channels(c) // 8) == 0 for c in couts)
+
+
 def fps_gather(xyz_n3, m: int, n_per_cloud=None):
     """xyz (B,N,3) -> (idx (B,m) int32, new_xyz (B,m,3), new_xyz (B,3,m)): sampling and the gather of the sampled
     coordinates in one launch; None when the cloud is too large for that kernel (caller samples and gathers separately).

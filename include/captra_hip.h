@@ -219,6 +219,23 @@ int captra_sa_scale_bf16(int b, int n, int m, int k, int cfeat, int c1, int c2, 
                          const float *xyz_cn, const float *new_xyz, const int *idx, const unsigned char *img, float *out,
                          int out_ctotal, int co_off, captra_stream_t stream);
 
+/* bf16-NATIVE dense layers (csrc/dense_bf16.hip): activations in HBM as bf16, POINT-major (B,L,ceil32(C)), channels in SLOT
+ * ORDER (inside every aligned block of 16 channels memory slot s holds channel perm[s] = {0,1,2,3,8,9,10,11,4,5,6,7,12,13,14,15},
+ * the order in which a 32x32 MFMA accumulator tile hands its rows to a lane; padding channels are zero).  Same per-layer
+ * contract as captra_pointwise_mlp_bf16.  The weights come as a fragment image built once by captra_pack_dense_bf16 from the
+ * layer's packed fp32 buffer (perm = 1 when the layer's INPUT is such a tensor, 0 for a channel-major fp32 input).
+ *   captra_pointwise_mlp_bf16pm: in_pm / out_pm choose the layouts of x / y ((B,cin,L) / (B,cout,L) fp32 when 0); ab != NULL
+ *     (in_pm only): (B,cin,2) GroupNorm coefficients of the layer that produced x, applied as relu(a x + b) while the operand is
+ *     loaded (blocks.py:150-165's GroupNorm + ReLU without a pass of its own).
+ *   captra_gn_stats_bf16pm: per-channel partial (sum, sum of squares) of a STORED tensor over chunks of 128 positions ->
+ *     stats (B,c,T,2), T = captra_gn_stats_bf16pm_tiles(l); captra_gn_finalize turns them into ab. */
+long long captra_dense_bf16_image_bytes(int cin, int cout);
+int captra_pack_dense_bf16(int cin, int cout, int perm, const float *wt_packed, unsigned char *img, captra_stream_t stream);
+int captra_pointwise_mlp_bf16pm(int b, int cin, int cout, long long l, int in_pm, const void *x, const unsigned char *wimg,
+                                const float *bias_packed, const float *ab, int act, int out_pm, void *y, captra_stream_t stream);
+int captra_gn_stats_bf16pm_tiles(long long l);
+int captra_gn_stats_bf16pm(int b, int c, long long l, const void *x, float *stats, captra_stream_t stream);
+
 /* Furthest point sampling + index_points in one launch (pointnet_utils.py:222-223: new_xyz = index_points(xyz,
  * farthest_point_sample(xyz, S))): xyz (B,N,3) -> idx (B,M) i32, new_xyz_n3 (B,M,3), new_xyz_cn (B,3,M) (either output
  * pointer may be NULL).  Same selection rule as captra_furthest_point_sampling with temp = 1e10.  Returns -2 when the

@@ -902,6 +902,94 @@ def test_bf16_sa_scale(device, cfeat, chans, n, m, k):
     assert np.mean(err) <= 2e-4 * scale, np.mean(err) / scale    # typical elements agree to accumulation-order noise
 
 
+_SLOT_PERM = np.array([0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15])
+
+
+def _pm_to_dense(t, c):
+    """(B,L,ceil32(c)) bf16 slot-order tensor (include/captra_hip.h "bf16-NATIVE dense layers") -> (B,c,L) float32."""
+    a = t.float().cpu().numpy()
+    B, L, cp = a.shape
+    a = a.reshape(B, L, cp // 16, 16)
+    nat = np.empty_like(a)
+    nat[..., _SLOT_PERM] = a                      # memory slot s holds channel perm[s] of its block of 16
+    nat = nat.reshape(B, L, cp)
+    assert not nat[:, :, c:].any(), "padding channels of a point-major tensor are zero"
+    return np.ascontiguousarray(nat[:, :, :c].transpose(0, 2, 1))
+
+
+def _dense_to_pm(x):
+    """(B,c,L) float32 (bf16-representable values) -> the (B,L,ceil32(c)) bf16 slot-order tensor."""
+    B, c, L = x.shape
+    cp = (c + 31) // 32 * 32
+    nat = np.zeros((B, L, cp), np.float32)
+    nat[:, :, :c] = x.transpose(0, 2, 1)
+    nat = nat.reshape(B, L, cp // 16, 16)
+    return torch.from_numpy(np.ascontiguousarray(nat[..., _SLOT_PERM]).reshape(B, L, cp)).to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("cin,cout,l", [(128, 512, 4096), (512, 512, 1000), (512, 256, 333), (256, 3, 4096), (40, 70, 77)])
+def test_bf16pm_dense_layer_layouts_and_groupnorm_on_load(device, cin, cout, l):
+    """The bf16-native dense kernel (csrc/dense_bf16.hip) in its four layout combinations, with and without the on-load
+    GroupNorm, against act(b + sum_k bf16(w) bf16(x)) in float64; the statistics kernel against numpy sums of the stored tensor."""
+    from captra_amd import fused
+    rng = np.random.default_rng(cin * 7 + cout + l)
+    B = 2
+    x = _bf16_round(rng.standard_normal((B, cin, l)).astype(np.float32))
+    w = (rng.standard_normal((cin, cout)) / np.sqrt(cin)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    lin = fused.pack(_dev(w, device), _dev(b, device))
+    ref = _bf16_layer(x, w, b, 0)
+    tol = 2e-5 * max(1.0, float(np.abs(ref).max()))
+    xpm = _dense_to_pm(x).to(device)
+    # fp32 channel-major in -> fp32 out / bf16 point-major out
+    y = fused.pointwise_mlp_bf16pm(_dev(x, device), lin, l, in_pm=False, out_pm=False).cpu().numpy()
+    np.testing.assert_allclose(y, ref, atol=tol, rtol=0)
+    ypm = fused.pointwise_mlp_bf16pm(_dev(x, device), lin, l, in_pm=False, out_pm=True)
+    got = _pm_to_dense(ypm, cout)
+    assert np.abs(got - _bf16_round(ref)).max() <= 2.0 ** -7 * np.abs(ref).max()          # one bf16 ulp of slack on rounding ties
+    assert np.mean(got == _bf16_round(ref)) > 0.995
+    # point-major in -> both outputs, plain
+    y2 = fused.pointwise_mlp_bf16pm(xpm, lin, l, in_pm=True, out_pm=False).cpu().numpy()
+    np.testing.assert_allclose(y2, ref, atol=tol, rtol=0)
+    y2r = fused.pointwise_mlp_bf16pm(xpm, lin, l, in_pm=True, out_pm=True, act=fused.ACT_RELU)
+    assert np.mean(_pm_to_dense(y2r, cout) == _bf16_round(np.maximum(ref, 0))) > 0.995
+    # statistics of the stored tensor
+    stats = fused.gn_stats_bf16pm(xpm, cin).cpu().numpy().astype(np.float64)
+    np.testing.assert_allclose(stats[..., 0].sum(-1), x.astype(np.float64).sum(-1), atol=1e-3 * np.sqrt(l), rtol=1e-5)
+    np.testing.assert_allclose(stats[..., 1].sum(-1), (x.astype(np.float64) ** 2).sum(-1), rtol=2e-5)
+    # on-load GroupNorm: x -> bf16(relu(a x + b))
+    ab = rng.standard_normal((B, cin, 2)).astype(np.float32)
+    xn = _bf16_round(np.maximum(np.float32(ab[:, :, 0:1]) * x + np.float32(ab[:, :, 1:2]), 0).astype(np.float32))
+    refn = _bf16_layer(xn, w, b, 0)
+    y3 = fused.pointwise_mlp_bf16pm(xpm, lin, l, in_pm=True, out_pm=False, ab=_dev(ab, device)).cpu().numpy()
+    err = np.abs(y3 - refn)
+    scale = max(1.0, float(np.abs(refn).max()))
+    assert err.max() <= 2e-2 * scale and err.mean() <= 1e-4 * scale, (err.max() / scale, err.mean() / scale)   # fma vs mul+add on a rounding tie
+
+
+def test_bf16_rotation_head_chain_vs_torch(device):
+    """MLPConv1d(128 -> 512 -> 512 -> 256 -> 3, GroupNorm) in the bf16 mode (hidden activations bf16 point-major in HBM, GroupNorm on
+    load) against the torch fp32 Sequential: bf16-level agreement on the head's raw output."""
+    from captra_amd import fused
+    from captra_amd.blocks import MLPConv1d
+    torch.manual_seed(3)
+    head = MLPConv1d(128, [512, 512, 256, 3], bn=True, gn=True, last_activation="none").to(device).eval()
+    with torch.no_grad():
+        for m in head.model:
+            if isinstance(m, torch.nn.GroupNorm):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.uniform_(-0.3, 0.3)
+    x = torch.randn(3, 128, 1000, device=device)
+    with torch.no_grad():
+        ref = head.model(x)
+        with fused.use_mlp_dtype("bf16"):
+            got = head(x)
+    assert got.shape == ref.shape and got.dtype == torch.float32
+    d = (got - ref).abs()
+    scale = float(ref.abs().max())
+    assert float(d.max()) <= 5e-2 * scale and float(d.mean()) <= 6e-3 * scale, (float(d.max()) / scale, float(d.mean()) / scale)
+
+
 def test_bf16_mode_track_step_close_to_fp32(device):
     """The whole tracking step with bf16 MFMA operands in the shared MLPs (fused.use_mlp_dtype / cfg['mlp_dtype'], BASELINE.json configs[2]) stays
     close to the exact-fp32 step on the same inputs: NOCS coordinates within bf16-level error, (almost) no label flips."""
