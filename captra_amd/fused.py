@@ -165,6 +165,19 @@ def gn_stats_bf16pm(x, c: int):
     return stats
 
 
+def mlp_chain_bf16(x, layers, acts, out_pm: bool = False):
+    """A run of dense layers in the bf16 mode with the hidden activations bf16 point-major in HBM: x (B,c0,*) fp32 ->
+    acts[-1](W_n ... relu(W_1 x + b_1) ...) as (B,c_n,*) fp32, or the (B,l,ceil32(c_n)) bf16 slot-order tensor when out_pm."""
+    B = x.shape[0]
+    l = x.numel() // max(B * x.shape[1], 1)
+    y, in_pm = x.contiguous(), False
+    for i, (lin, act) in enumerate(zip(layers, acts)):
+        last = i == len(layers) - 1
+        y = pointwise_mlp_bf16pm(y, lin, l, in_pm=in_pm, out_pm=out_pm or not last, act=act)
+        in_pm = True
+    return y if out_pm else y.view((B, layers[-1].cout) + tuple(x.shape[2:]))
+
+
 def gn_chain_bf16_supported(x, couts) -> bool:
     """Conv -> GroupNorm -> ReLU chains in the bf16 mode: every normalised width must tile the statistics kernel."""
     return mlp_dtype() == "bf16" and x.dim() == 3 and all(256 % (pm_channels(c) // 8) == 0 for c in couts)
@@ -383,6 +396,8 @@ def mlp_chain3(x, layers, act3: int = ACT_RELU):
     assert x.shape[1] == shape[0] and layers[1].cin == shape[1] and layers[2].cin == shape[2], (x.shape, shape)
     B = x.shape[0]
     l = x.numel() // max(B * shape[0], 1)
+    if mlp_dtype() == "bf16":
+        return mlp_chain_bf16(x, layers, [ACT_RELU, ACT_RELU, act3])
     if not (USE_MLP_CHAIN and mlp_dtype() == "fp32" and shape in _CHAIN3_SHAPES and shape[0] * l * 4 < (1 << 31)):
         y = pointwise_mlp(x, layers[0], ACT_RELU)
         y = pointwise_mlp(y, layers[1], ACT_RELU)

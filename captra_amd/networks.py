@@ -95,6 +95,14 @@ class CoordNet(nn.Module):
                     all_layers = list(layers) + head_layers
                     if fused.coord_tail_supported(x, all_layers):
                         return fused.coord_tail(x, all_layers)            # (seg logits, sigmoid(nocs) - 0.5)
+                    if fused.mlp_dtype() == "bf16":
+                        # bf16 mode: FP1 + conv1 leave the feature map as a bf16 point-major tensor both heads read
+                        n = x.shape[2]
+                        feat = fused.mlp_chain_bf16(x, layers, [fused.ACT_RELU] * len(layers), out_pm=True)
+                        seg_logits = fused.pointwise_mlp_bf16pm(feat, head_layers[0], n, in_pm=True, out_pm=False)
+                        hid = fused.pointwise_mlp_bf16pm(feat, head_layers[1], n, in_pm=True, out_pm=True, act=fused.ACT_RELU)
+                        return seg_logits, fused.pointwise_mlp_bf16pm(hid, head_layers[2], n, in_pm=True, out_pm=False,
+                                                                      act=fused.ACT_SIGMOID_M05)
                     seg_logits, nocs = self._heads(fused.mlp_chain3(x, layers, fused.ACT_RELU))
                     return seg_logits, nocs - 0.5
         out = self.backbone(cam_cn, input_n3=cam_n3, geom=input.get("_geom"), finish=fused_tail)

@@ -306,6 +306,8 @@ class PointNetFeaturePropagation(_FoldCache, nn.Module):
                 return finish(new_points, layers)
             if len(layers) == 3:
                 return fused.mlp_chain3(new_points, layers, fused.ACT_RELU)
+            if fused.mlp_dtype() == "bf16":
+                return fused.mlp_chain_bf16(new_points, layers, [fused.ACT_RELU] * len(layers))
             for lin in layers:
                 new_points = fused.pointwise_mlp(new_points, lin, fused.ACT_RELU)
             return new_points
@@ -348,6 +350,9 @@ class PointNetSetAbstraction(_FoldCache, nn.Module):
             # of 128 and the group maxima are maxed again (max is exact, so the split does not change a bit)
             folded = self._fold(xyz.device)
             groups, k = (1, N) if N <= 128 else (N // 128, 128)
+            if fused.mlp_dtype() == "bf16":      # hidden activations bf16 point-major; the (exact) max on the last layer's fp32 output
+                y = fused.mlp_chain_bf16(x.contiguous(), folded, [fused.ACT_RELU] * len(folded))
+                return new_xyz, y.view(B, self.out_channel, groups, k).max(dim=3)[0].max(dim=2, keepdim=True)[0]
             y = x.contiguous().view(B, x.shape[1], groups, k)
             for lin in folded[:-1]:
                 y = fused.pointwise_mlp(y, lin, fused.ACT_RELU)
