@@ -82,8 +82,8 @@ def build_workload(batch: int, device, frames: int = 8, category: str = "bottle"
     and `pose_match` can be asked of the timed trajectories themselves)."""
     from captra_amd.configs import make_config
     from captra_amd.trainer import Trainer
-    from tests import clouds
-    from tests.weights import make_physical_state_dict
+    from captra_amd import synthetic as clouds
+    from captra_amd.synthetic import make_physical_state_dict
 
     obj_category, obj_config, kind, _ = WORKLOADS[category]
     cfg = make_config(obj_category, obj_config, experiment_dir="/tmp/captra_bench")
@@ -113,7 +113,7 @@ def cpu_baseline(cfg, sd, budget_s: float = 15.0):
     batch 1 of the same workload, timed on this host's cores.  The thread count that runs a frame
     fastest (of 8/16/32/64, capped by the host) is used and reported as `cores`."""
     from oracle import model as OM
-    from tests import clouds
+    from captra_amd import synthetic as clouds
     data = clouds.make_trajectory("nocs", 1, 6, seed=0)
     pose0 = {k: v.numpy() for k, v in
              {"rotation": data[0]["meta"]["nocs2camera"][0]["rotation"].unsqueeze(1),
@@ -158,9 +158,9 @@ def otf_leg(batch: int, device, frames: int = 10, reps: int = 3):
     import tempfile
     from captra_amd.configs import make_config
     from captra_amd.trainer import Trainer
-    from tests import clouds
-    from tests.golden.make_golden_otf import make_frame
-    from tests.weights import make_state_dict
+    from captra_amd import synthetic as clouds
+    from captra_amd.synthetic import make_frame
+    from captra_amd.synthetic import make_state_dict
     depth, mask, _center, pose = make_frame(1)
     out = {"workload": f"EvalTrackModel.test, nocs_otf=True, bottle, {batch} trajectories x {frames} frames of a 480x640 depth image, "
                        f"~15 k candidate points per crop resampled to 4096", "unit": "frames/s"}
@@ -206,7 +206,7 @@ def hbm_ops_roofline(batch: int, device, reps: int = 5):
     import torch
     from captra_amd import _lib
     from captra_amd import pointnet2_cuda as pc
-    from tests import clouds
+    from captra_amd import synthetic as clouds
     B = batch
     pts = torch.from_numpy(np.stack([clouds.s_nocs(1000 + i)[0] for i in range(B)])).to(device).contiguous()   # (B,N,3), B distinct clouds
     gen = torch.Generator(device="cpu").manual_seed(3)

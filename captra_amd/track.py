@@ -164,7 +164,7 @@ def _load_source(src, args):
     (batch 1), so its content does not depend on the rank or the batch it is tracked in."""
     if isinstance(src, tuple):
         try:
-            from tests import clouds
+            from captra_amd import synthetic as clouds
         except ImportError as e:  # pragma: no cover
             raise SystemExit("--data synthetic needs the repository's tests/ package on sys.path") from e
         _, kind, seed = src

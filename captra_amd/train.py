@@ -39,7 +39,7 @@ def add_args(parser):
 def _batches(spec: str, batch: int, samples: int, rank: int):
     """-> list of frame dicts of `batch` samples each."""
     if spec.startswith("synthetic"):
-        from tests import clouds
+        from captra_amd import synthetic as clouds
         kind = spec.split(":")[1] if ":" in spec else "nocs"
         return [clouds.make_trajectory(kind, batch, 2, seed=1000 * rank + i)[1] for i in range(max(samples // batch, 1))]
     files = sorted(glob.glob(pjoin(spec, "*.npz")))

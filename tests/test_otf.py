@@ -194,3 +194,87 @@ def test_batched_recrop_rare_paths_and_golden(device):
         _same(a, b)
     np.testing.assert_allclose(batched[0]["points"].cpu().numpy(), G[f"{tag}_points"], atol=1e-15, rtol=0)
     np.testing.assert_array_equal(batched[0]["labels"].cpu().numpy(), G[f"{tag}_labels"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hipgraph", [False, True])
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_track_loop_otf_vs_reference_loop_golden(device, tag, hipgraph):
+    """Golden G15 = the REFERENCE's own `nocs_otf=True` loop (model.py:425-452 -> full_data_from_depth_image with pre_fetched)
+    under physical-regime weights at batch 1: centre / radius from the last predicted pose -> crop -> resample -> mean-subtract
+    -> networks -> pose, frame after frame, free-running.  Every pose of every frame to 1e-4, every re-cropped cloud to 2e-7
+    (identical pixels, identical labels), eager and with the captured step."""
+    from captra_amd.configs import make_config
+    from captra_amd.synthetic import OTF_LOOP_SETUPS, make_otf_trajectory, make_physical_state_dict
+    from captra_amd.trainer import Trainer
+    G15 = np.load(Path(__file__).resolve().parent / "golden" / "g15_otf_loop.npz")
+    frames, dseed, wseed, tseed = OTF_LOOP_SETUPS[tag]
+    cfg = make_config("1", experiment_dir="/tmp/captra_otf_loop_test", nocs_otf=True, hipgraph=hipgraph)
+    cfg["device"] = device
+    cfg["init_frame"]["gt"] = False
+    trainer = Trainer(cfg)
+    model = trainer.model
+    model.load_state_dict(make_physical_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, wseed, 1, True, "nocs"))
+    model.use_graph = hipgraph
+    data = make_otf_trajectory(1, frames, seed=dseed)
+    torch.manual_seed(tseed)
+    np.random.seed(tseed)
+    pred, _ = trainer.test(data, save=False, no_eval=True)
+    assert len(pred["poses"]) == frames
+    for i, pose in enumerate(pred["poses"]):
+        if i > 0:
+            np.testing.assert_array_equal(model.feed_dict[i]["labels"].cpu().numpy(), G15[f"{tag}_{i}_labels"], err_msg=f"labels of frame {i}")
+            np.testing.assert_allclose(model.feed_dict[i]["points"].cpu().numpy(), G15[f"{tag}_{i}_points"], atol=2e-7, rtol=0, err_msg=f"cloud of frame {i}")
+            np.testing.assert_allclose(model.npcs_feed_dict[i]["nocs"].cpu().numpy(), G15[f"{tag}_{i}_nocs"], atol=2e-6, rtol=0, err_msg=f"gt nocs of frame {i}")
+        for key in ("rotation", "translation", "scale"):
+            np.testing.assert_allclose(pose[key].cpu().numpy(), G15[f"{tag}_{i}_{key}"], atol=1e-4, rtol=0, err_msg=f"{key} of frame {i}")
+
+
+def _cat_trajectories(parts):
+    """Concatenate single-trajectory frame lists (captra_amd.synthetic.make_otf_trajectory(1, ...)) along the batch axis."""
+    out = []
+    for frames in zip(*parts):
+        f0 = frames[0]
+        meta = {"path": sum([f["meta"]["path"] for f in frames], []), "ori_path": sum([f["meta"]["ori_path"] for f in frames], []),
+                "points_mean": torch.cat([f["meta"]["points_mean"] for f in frames]), "nocs_corners": torch.cat([f["meta"]["nocs_corners"] for f in frames]),
+                "pre_fetched": {k: torch.cat([f["meta"]["pre_fetched"][k] for f in frames]) for k in ("depth", "mask")},
+                "nocs2camera": [{k: torch.cat([f["meta"]["nocs2camera"][p][k] for f in frames]) for k in ("rotation", "translation", "scale")}
+                                for p in range(len(f0["meta"]["nocs2camera"]))]}
+        out.append({"points": torch.cat([f["points"] for f in frames]), "labels": torch.cat([f["labels"] for f in frames]),
+                    "nocs": torch.cat([f["nocs"] for f in frames]), "meta": meta})
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lanes", [True, False])
+def test_track_loop_otf_batch32_vs_reference_loop_golden(device, lanes):
+    """The 32-trajectory forms of the re-crop loop (two lanes half a frame apart, and the single batch) anchored to the
+    REFERENCE: the batch is 16 copies each of golden G15's two trajectories, started from the golden's (seeded, perturbed)
+    initial poses; every trajectory must reproduce the reference's batch-1 loop to 1e-4 on every frame."""
+    from captra_amd.configs import make_config
+    from captra_amd.synthetic import OTF_LOOP_SETUPS, make_otf_trajectory, make_physical_state_dict
+    from captra_amd.trainer import Trainer
+    G15 = np.load(Path(__file__).resolve().parent / "golden" / "g15_otf_loop.npz")
+    T = min(OTF_LOOP_SETUPS[t][0] for t in ("a", "b"))
+    assert OTF_LOOP_SETUPS["a"][2] != OTF_LOOP_SETUPS["b"][2]      # different weight seeds: one model per golden, run one after the other
+    for tag in ("a", "b"):
+        _, dseed, wseed, _ = OTF_LOOP_SETUPS[tag]
+        cfg = make_config("1", experiment_dir="/tmp/captra_otf_b32_test", nocs_otf=True, hipgraph=True, otf_lanes=lanes)
+        cfg["device"] = device
+        cfg["init_frame"]["gt"] = False
+        trainer = Trainer(cfg)
+        model = trainer.model
+        model.load_state_dict(make_physical_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, wseed, 1, True, "nocs"))
+        model.use_graph = True
+        model.otf_lanes = lanes
+        single = make_otf_trajectory(1, T, seed=dseed)
+        data = _cat_trajectories([single] * 32)
+        init = {k: torch.from_numpy(np.repeat(G15[f"{tag}_0_{k}"], 32, axis=0)).to(device) for k in ("rotation", "translation", "scale")}
+        model._initial_pose = lambda init=init: {k: v.clone() for k, v in init.items()}
+        np.random.seed(1)
+        pred, _ = trainer.test(data, save=False, no_eval=True)
+        for i in range(1, T):
+            for key in ("rotation", "translation", "scale"):
+                got = pred["poses"][i][key].cpu().numpy()
+                ref = np.repeat(G15[f"{tag}_{i}_{key}"], 32, axis=0)
+                np.testing.assert_allclose(got, ref, atol=1e-4, rtol=0, err_msg=f"{tag}: {key} of frame {i}")

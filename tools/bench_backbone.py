@@ -27,8 +27,8 @@ import torch
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 
-from tests import clouds  # noqa: E402
-from tests.weights import make_state_dict  # noqa: E402
+from captra_amd import synthetic as clouds  # noqa: E402
+from captra_amd.synthetic import make_state_dict  # noqa: E402
 
 PEAK_MFMA_F32 = 157.3   # TFLOP/s, 256 CUs x 4 SIMDs x 64 flop/cycle x 2.4 GHz
 PEAK_HBM = 8000.0       # GB/s

@@ -10,7 +10,7 @@ import torch
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from captra_amd import _lib  # noqa: E402
-from tests import clouds  # noqa: E402
+from captra_amd import synthetic as clouds  # noqa: E402
 
 
 def main():

@@ -1,7 +1,7 @@
 import sys, ctypes, time, numpy as np, torch
 sys.path.insert(0, '/root/repo')
 from captra_amd import _lib, fused
-from tests import clouds
+from captra_amd import synthetic as clouds
 dev = torch.device('cuda:0')
 def surf(seed, n):
     rng = np.random.default_rng(seed)

@@ -19,7 +19,7 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 
 from captra_amd import _lib, nocs_otf  # noqa: E402
-from tests.golden.make_golden_otf import make_frame  # noqa: E402
+from captra_amd.synthetic import make_frame  # noqa: E402
 
 
 def main():
@@ -73,8 +73,8 @@ def track_loop(batch: int, frames: int = 12, configs=((False, False), (True, Fal
     """The whole tracking loop with nocs_otf on (EvalTrackModel.forward: re-crop + hipGraph step per frame) vs off."""
     from captra_amd.configs import make_config
     from captra_amd.trainer import Trainer
-    from tests import clouds
-    from tests.weights import make_state_dict
+    from captra_amd import synthetic as clouds
+    from captra_amd.synthetic import make_state_dict
     dev = torch.device("cuda:0")
     for otf, lanes, *rest in configs:
         overlap = rest[0] if rest else True

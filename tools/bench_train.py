@@ -25,8 +25,8 @@ sys.path.insert(0, str(ROOT))
 
 from captra_amd.configs import make_config  # noqa: E402
 from captra_amd.trainer import Trainer  # noqa: E402
-from tests import clouds  # noqa: E402
-from tests.weights import make_state_dict  # noqa: E402
+from captra_amd import synthetic as clouds  # noqa: E402
+from captra_amd.synthetic import make_state_dict  # noqa: E402
 
 
 def main():

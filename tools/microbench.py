@@ -19,7 +19,7 @@ sys.path.insert(0, str(ROOT))
 
 from captra_amd import _lib  # noqa: E402
 from captra_amd.pointnet_lib import pointnet2_utils as pn  # noqa: E402
-from tests import clouds  # noqa: E402
+from captra_amd import synthetic as clouds  # noqa: E402
 
 
 def main():

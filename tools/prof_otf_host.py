@@ -1,7 +1,7 @@
 import sys, cProfile, pstats, numpy as np, torch
 sys.path.insert(0, '/root/repo')
 from captra_amd import nocs_otf
-from tests.golden.make_golden_otf import make_frame
+from captra_amd.synthetic import make_frame
 dev = torch.device('cuda:0')
 items = []
 for b in range(32):

@@ -10,8 +10,8 @@ import torch
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from captra_amd.configs import make_config  # noqa: E402
 from captra_amd.trainer import Trainer  # noqa: E402
-from tests import clouds  # noqa: E402
-from tests.weights import make_state_dict  # noqa: E402
+from captra_amd import synthetic as clouds  # noqa: E402
+from captra_amd.synthetic import make_state_dict  # noqa: E402
 
 dev = torch.device("cuda:0")
 cfg = make_config("1", experiment_dir="/tmp/captra_prof", hipgraph=True)
