@@ -9,14 +9,46 @@ The reference has no equivalent (eager PyTorch, one ATen launch at a time, model
 """
 from __future__ import annotations
 
+import os
+
 import torch
+
+
+# The streams the lanes of the re-crop loop run on: lane l's MAIN stream and the SIDE stream its RotationNet branch runs on,
+# created ONCE per process and device, back to back.  Which hardware queue a HIP stream feeds is decided when it is created
+# (GPU_MAX_HW_QUEUES = 4 queues), and two chains of kernels overlap only from different queues.  Round 2 captured a lane's step
+# as ONE graph with the two networks as parallel branches: the runtime then runs the second branch on a stream of its own,
+# made when the graph is instantiated -- wherever the queue assignment stands at that moment.  With the re-crop loop's four
+# concurrent chains (2 lanes x 2 networks, a lane's sampler in front of its networks) every model object drew its own
+# placement: 8.1 ms per 32-trajectory step, or 11.0, or 13.4 (tools/bench_otf.py --objects 14: 5 / 6 / 3 of 14 objects).
+# SPLIT (TrackStepGraph(split_side=stream)): the step is captured as four LINEAR graphs (prep | RotationNet | CoordinateNet |
+# read-out + pose fit) replayed on explicit streams with two events, so no stream is created behind the scenes and the four
+# chains keep their queues for the life of the process: 8.56-8.64 ms for every one of 12 objects.  Measured alternatives:
+# GPU_MAX_HW_QUEUES=8 with the split form 13.9 ms; a three-graph form whose side chain repeats the geometry kernels instead of
+# waiting for a prep graph 8.5-8.7 ms and -6 % on the pre-cropped bench.  The pre-cropped lanes (TrackLanes) keep the one-graph
+# form: in a fresh process it has been in its good placement in every session, and the split form's blocks vary more there
+# (5.60-5.90 ms per step against 5.59-5.64; medians equal).
+SPLIT_OTF_LANES = os.environ.get("CAPTRA_SPLIT_LANES", "1") != "0"      # (the environment switch is for A/B runs)
+_LANE_STREAMS: dict = {}
+
+
+def lane_streams(dev, lanes: int = 2):
+    """[(main, side)] * lanes for device `dev`: process-wide, created back to back on first use."""
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    have = _LANE_STREAMS.setdefault(key, [])
+    while len(have) < lanes:
+        have.append((torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)))
+    return have[:lanes]
 
 
 class TrackStepGraph:
     def __init__(self, model, points: torch.Tensor, points_mean: torch.Tensor, pose: dict, labels: torch.Tensor | None = None,
-                 warmup: int = 2):
-        """model: EvalTrackModel (eval mode, on the GPU); points (B,3,N), points_mean (B,3,1), pose: example inputs."""
+                 warmup: int = 2, split_side=None):
+        """model: EvalTrackModel (eval mode, on the GPU); points (B,3,N), points_mean (B,3,1), pose: example inputs.
+        split_side: a stream -> the step is captured as four linear graphs and its RotationNet branch replays on that stream
+        (see SPLIT_OTF_LANES); None -> one graph, the networks as its two branches when model.overlap_nets."""
         self.model = model
+        self.split_side = split_side
         dev = points.device
         self.points = points.clone()
         self.points_mean = points_mean.clone()
@@ -34,6 +66,9 @@ class TrackStepGraph:
         from .fold import collect_folded, weights_version
         self.weights = collect_folded(model)
         self.weights_version = weights_version()
+        if split_side is not None and self._capture_split():
+            return
+        self.split_side = None
         try:
             self._capture()
         except RuntimeError:
@@ -50,6 +85,60 @@ class TrackStepGraph:
         # thread_local: other host threads (RCCL's watchdog under torch.distributed) may touch the runtime while this thread captures
         with torch.cuda.graph(self.graph, capture_error_mode="thread_local"), torch.no_grad():
             self.npcs_pred, self.out_pose = self._step()
+
+    def _capture_split(self) -> bool:
+        """[prep] -> [rot || coord] -> [post] as four linear graphs.  RotationNet's graph allocates from a pool of its own: it
+        replays beside CoordinateNet's, so memory one of them frees while being captured must not be handed to the other."""
+        from . import fused
+        m = self.model
+        inp = {"points": self.points, "points_mean": self.points_mean, "meta": {}}
+        npcs_in = {"points": self.points, "points_mean": self.points_mean}
+        if self.labels is not None:
+            inp["labels"] = npcs_in["labels"] = self.labels
+        if not m._overlap_nets(inp):
+            return False
+        cap = torch.cuda.Stream(device=self.points.device)
+        pool_main, pool_side = torch.cuda.graph_pool_handle(), torch.cuda.graph_pool_handle()
+        self._graphs = [torch.cuda.CUDAGraph() for _ in range(4)]
+        state = {}
+
+        def capture(g, pool, fn):
+            with torch.cuda.graph(g, pool=pool, stream=cap, capture_error_mode="thread_local"), torch.no_grad(), fused.use_mlp_dtype(m.mlp_dtype):
+                return fn()
+
+        def prep():
+            m._step_begin(inp, npcs_in, self.pose)
+            return m._step_prep(inp, npcs_in, self.pose)
+
+        if not capture(self._graphs[0], pool_main, prep):
+            return False
+        state["raw"] = capture(self._graphs[1], pool_side, lambda: m._step_rot(inp, npcs_in, self.pose))
+        self.npcs_pred = capture(self._graphs[2], pool_main, lambda: m._step_coord(npcs_in))
+
+        def post():
+            inp["_raw"] = state["raw"]
+            return m._step_post(inp, npcs_in, self.npcs_pred, self.pose)
+
+        self.out_pose = capture(self._graphs[3], pool_main, post)
+        self._keep = (inp, npcs_in, state)                 # tensors one graph hands to the next
+        self._ev_prep, self._ev_rot = torch.cuda.Event(), torch.cuda.Event()
+        return True
+
+    def _replay_graphs(self):
+        if self.split_side is None:
+            self.graph.replay()
+            return
+        main, side = torch.cuda.current_stream(self.points.device), self.split_side
+        g_prep, g_rot, g_coord, g_post = self._graphs
+        g_prep.replay()
+        self._ev_prep.record(main)
+        side.wait_event(self._ev_prep)
+        with torch.cuda.stream(side):
+            g_rot.replay()
+            self._ev_rot.record(side)
+        g_coord.replay()
+        main.wait_event(self._ev_rot)
+        g_post.replay()
 
     def _step(self):
         input = {"points": self.points, "points_mean": self.points_mean, "meta": {}}
@@ -78,7 +167,7 @@ class TrackStepGraph:
                 self.pose[k].copy_(pose[k])
         if self.labels is not None and labels is not None:
             self.labels.copy_(labels)
-        self.graph.replay()
+        self._replay_graphs()
         return self.out_pose
 
 

@@ -161,15 +161,49 @@ class EvalTrackModel(BaseModel):
             return self._track_step(input, npcs_input, last_pose)
 
     def _track_step(self, input, npcs_input, last_pose):
+        self._step_begin(input, npcs_input, last_pose)
+        join = self._fork_rotation_net(input, npcs_input, last_pose) if self._overlap_nets(input) else None
+        npcs_pred = self._step_coord(npcs_input)
+        if join is not None:
+            join()
+        return npcs_pred, self._step_post(input, npcs_input, npcs_pred, last_pose)
+
+    # ---- the step in four phases (what `_track_step` composes; captra_amd.graph.TrackStepGraph(split=True) captures each as a
+    # hipGraph of its own and replays [prep] -> [rot || coord] -> [post] on two EXPLICIT streams) ---------------------------
+    def _step_begin(self, input, npcs_input, last_pose):
         npcs_input["canon_pose"] = {k: last_pose[k][:, self.root].clone() for k in ("rotation", "translation", "scale")}
         npcs_input["init_part"] = last_pose
         for k in ("_canon", "_geom"):
             npcs_input.pop(k, None)
         input.pop("_raw", None)
-        join = self._fork_rotation_net(input, npcs_input, last_pose) if self._overlap_nets(input) else None
-        npcs_pred = self.npcs_net(npcs_input)
-        if join is not None:
-            join()
+
+    def _step_prep(self, input, npcs_input, last_pose, level1_only=False) -> bool:
+        """The part both networks wait for: CoordinateNet's canonicalised cloud and its geometry (sampling, neighbour lists,
+        interpolation weights).  False when the cloud does not fit the one-launch sampler (no side-by-side schedule then)."""
+        from .networks import _canonicalize
+        cam = _canonicalize(npcs_input["points"], npcs_input["points_mean"], npcs_input["canon_pose"])
+        geom = self.npcs_net.backbone.precompute_geometry(cam[1], level1_only=level1_only)
+        if geom is None:
+            return False
+        npcs_input["_canon"], npcs_input["_geom"] = cam, geom
+        return True
+
+    def _step_rot(self, input, npcs_input, last_pose):
+        """RotationNet up to its heads' raw per-point output (needs nothing of CoordinateNet's but, for one part, its geometry)."""
+        from .networks import _canonicalize
+        P = self.num_parts
+        cam, geom = npcs_input["_canon"], npcs_input["_geom"]
+        if P == 1 and self.share_geometry:            # one part: RotationNet's cloud IS CoordinateNet's
+            return self.net.regress_net.raw_point_rtvec(cam[0], cam_n3=cam[1], geom=geom)
+        # every part's cloud canonicalised with that part's previous pose
+        canon = {k: last_pose[k].reshape((-1,) + last_pose[k].shape[2:]) for k in ("rotation", "translation", "scale")}
+        rcam = _canonicalize(input["points"], input["points_mean"], canon, num_parts=P)
+        return self.net.regress_net.raw_point_rtvec(rcam[0], cam_n3=rcam[1])
+
+    def _step_coord(self, npcs_input):
+        return self.npcs_net(npcs_input)
+
+    def _step_post(self, input, npcs_input, npcs_pred, last_pose):
         pred_npcs = npcs_pred["nocs"].reshape(len(npcs_pred["nocs"]), self.num_parts, 3, -1)
         input["state"] = {"part": last_pose}
         input["pred_labels"] = torch.argmax(npcs_pred["seg"], dim=-2)
@@ -180,7 +214,7 @@ class EvalTrackModel(BaseModel):
         input.pop("shared_geometry", None)
         if self.share_geometry and self.num_parts == 1 and not self.npcs_net.training:
             input["shared_geometry"] = (self.npcs_net.last_canon, self.npcs_net.backbone.last_geom)
-        return npcs_pred, self.net(input, test_mode=True)["part"]
+        return self.net(input, test_mode=True)["part"]
 
     # ---- the two networks side by side -------------------------------------------------------------------------------
     def _overlap_nets(self, input) -> bool:
@@ -193,26 +227,17 @@ class EvalTrackModel(BaseModel):
                 and not (self.track_cfg["gt_label"] or self.track_cfg["nocs2d_label"]) and not self.net.return_point_rotation)
 
     def _fork_rotation_net(self, input, npcs_input, last_pose):
-        from .networks import _canonicalize
-        P = self.num_parts
-        cam = _canonicalize(npcs_input["points"], npcs_input["points_mean"], npcs_input["canon_pose"])
         small = len(input["points"]) <= 2      # one or two trajectories: every kernel is latency-bound, overlap all that can be (no gain from 4 up)
-        geom = self.npcs_net.backbone.precompute_geometry(cam[1], level1_only=small)
-        if geom is None:
+        if not self._step_prep(input, npcs_input, last_pose, level1_only=small):
             return None
-        npcs_input["_canon"], npcs_input["_geom"] = cam, geom
-        main = torch.cuda.current_stream(cam[0].device)
+        dev = npcs_input["_canon"][0].device
+        main = torch.cuda.current_stream(dev)
         if getattr(self, "_side", None) is None:
-            self._side = torch.cuda.Stream(device=cam[0].device)
+            self._side = torch.cuda.Stream(device=dev)
         side = self._side
         side.wait_stream(main)
         with torch.cuda.stream(side):
-            if P == 1 and self.share_geometry:            # one part: RotationNet's cloud IS CoordinateNet's
-                raw = self.net.regress_net.raw_point_rtvec(cam[0], cam_n3=cam[1], geom=geom)
-            else:                                         # every part's cloud canonicalised with that part's previous pose
-                canon = {k: last_pose[k].reshape((-1,) + last_pose[k].shape[2:]) for k in ("rotation", "translation", "scale")}
-                rcam = _canonicalize(input["points"], input["points_mean"], canon, num_parts=P)
-                raw = self.net.regress_net.raw_point_rtvec(rcam[0], cam_n3=rcam[1])
+            raw = self._step_rot(input, npcs_input, last_pose)
 
         def join():
             main.wait_stream(side)
@@ -302,22 +327,24 @@ class EvalTrackModel(BaseModel):
         slices = [slice(0, half), slice(half, B)]
         dev = feed[1]["points"].device
         cur = torch.cuda.current_stream(dev)
-        if getattr(self, "_otf_streams", None) is None:
-            # the two lane streams are created once per PROCESS and device: which hardware queue a stream gets is decided
-            # at creation, and a later model object that made fresh ones sometimes landed both lanes on one queue
-            # (11.6-14.4 ms per step instead of 7.9)
-            key = (dev.index if dev.index is not None else torch.cuda.current_device())
-            if key not in _OTF_LANE_STREAMS:
-                _OTF_LANE_STREAMS[key] = [torch.cuda.Stream(device=dev) for _ in slices]
-            self._otf_streams = _OTF_LANE_STREAMS[key]
-        streams = self._otf_streams
+        from . import graph as G
+        if G.SPLIT_OTF_LANES:
+            pairs = G.lane_streams(dev, 2)       # process-wide explicit streams: see captra_amd/graph.py SPLIT_OTF_LANES
+            streams, sides = [m_ for m_, _ in pairs], [s_ for _, s_ in pairs]
+        else:
+            if getattr(self, "_otf_streams", None) is None:
+                key = (dev.index if dev.index is not None else torch.cuda.current_device())
+                if key not in _OTF_LANE_STREAMS:
+                    _OTF_LANE_STREAMS[key] = [torch.cuda.Stream(device=dev) for _ in slices]
+                self._otf_streams = _OTF_LANE_STREAMS[key]
+            streams, sides = self._otf_streams, [None, None]
         use_graph = self._graph_usable(feed[1])
         graphs = None
         if use_graph:
             key = ("otf", tuple(feed[1]["points"].shape), str(dev))
             if self._graph is None or self._graph_key != key or any(g.stale() for g in self._graph):
                 self._graph = [TrackStepGraph(self, feed[1]["points"][s].contiguous(), feed[1]["points_mean"][s].contiguous(),
-                                              {k: v[s].contiguous() for k, v in pose0.items()}) for s in slices]
+                                              {k: v[s].contiguous() for k, v in pose0.items()}, split_side=side) for s, side in zip(slices, sides)]
                 self._graph_key = key
             graphs = self._graph
         lane_pose = [{k: v[s].clone() for k, v in pose0.items()} for s in slices]

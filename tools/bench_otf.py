@@ -108,7 +108,48 @@ def track_loop(batch: int, frames: int = 12, configs=((False, False), (True, Fal
         print(f"EvalTrackModel loop, nocs_otf={otf}{', two lanes half a frame apart' if lanes else ''}{'' if overlap else ', networks in sequence inside a lane'}: {best * 1e3:7.2f} ms per step of {batch} trajectories = {batch / best:7.0f} frames/s", flush=True)
 
 
+def objects_loop(n_objects: int, batch: int = 32, frames: int = 8, loops: int = 3):
+    """`n_objects` EvalTrackModel objects one after the other in ONE process, each timed on the two-lane
+    re-crop loop (median of `loops` loops over 32 distinct depth frames): the schedule must not depend on how many streams /
+    graphs the process created before."""
+    from captra_amd.configs import make_config
+    from captra_amd.synthetic import make_otf_trajectory, make_state_dict
+    from captra_amd.trainer import Trainer
+    dev = torch.device("cuda:0")
+    data = make_otf_trajectory(batch, frames, seed=1)
+    for f in data:
+        f["meta"]["pre_fetched"] = {k: v.to(dev) for k, v in f["meta"]["pre_fetched"].items()}
+    out = []
+    for k in range(n_objects):
+        cfg = make_config("1", experiment_dir="/tmp/captra_otf_bench", nocs_otf=True, **{"init_frame/gt": True})
+        cfg["device"] = dev
+        trainer = Trainer(cfg)
+        trainer.model.load_state_dict(make_state_dict({k2: tuple(v.shape) for k2, v in trainer.model.state_dict().items()}, seed=7))
+        trainer.model.use_graph = True
+        if "--no-overlap" in sys.argv:
+            trainer.model.overlap_nets = False
+        np.random.seed(0)
+        ts = []
+        for rep in range(loops + 1):
+            trainer.model.eval()
+            trainer.model.set_data(data)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            trainer.model.test(save=False, no_eval=True)
+            torch.cuda.synchronize()
+            if rep:                     # the first loop captures the graphs
+                ts.append((time.perf_counter() - t0) / (frames - 1))
+        ms = 1e3 * sorted(ts)[len(ts) // 2]
+        out.append(ms)
+        print(f"object {k:2d}: {ms:6.2f} ms per step (median of {loops}; all: {[round(1e3 * t, 2) for t in ts]})  schedule: {getattr(trainer.model, 'otf_schedule', '?')}", flush=True)
+        del trainer
+    print(f"{n_objects} objects: min {min(out):.2f}  max {max(out):.2f} ms per step")
+
+
 if __name__ == "__main__":
+    if "--objects" in sys.argv:
+        objects_loop(int(sys.argv[sys.argv.index("--objects") + 1]))
+        sys.exit(0)
     if "--ab-overlap" in sys.argv:      # same process, alternating: CoordNet || RotationNet inside a lane, or in sequence
         for rep in range(5):
             track_loop(32, configs=((True, True, True), (True, True, False)))
