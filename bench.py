@@ -331,6 +331,29 @@ def _free_port() -> int:
         return s.getsockname()[1]
 
 
+def spawn_command(n: int, port: int | None = None) -> list:
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port if port is not None else _free_port()), os.path.abspath(__file__)] + [a for a in sys.argv[1:] if a != "--dry-run"]
+
+
+def launch_plan(n: int) -> dict:
+    """What `python bench.py --gpus n` would do, without doing it (no GPU is touched): the launcher command, one rank per
+    GPU (LOCAL_RANK r -> cuda:r), RCCL ("nccl") for the per-frame pose all-gather, 32 trajectories per rank."""
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    share = os.environ.get("CAPTRA_BENCH_SHARE_GPU") == "1"
+    return {"gpus_requested": n, "gpus_visible": have,
+            "would_refuse": bool(n > 1 and have < n and not share),
+            "command": "python bench.py (this process, no launcher)" if n == 1 else " ".join(spawn_command(n, port=29500)) + "   # port: a free one is picked at launch",
+            "env": {"HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")},
+            "ranks": [{"rank": r, "local_rank": r, "device": f"cuda:{r % have if share and have else r}",
+                       "tracks": "32 trajectories (--batch), seeds (10 + rank) * 100 + b; category per --category (mix6: NOCS category 1 + rank mod 6)"}
+                      for r in range(n)],
+            "collective": "none (single rank)" if n == 1 else ("gloo (CAPTRA_BENCH_SHARE_GPU functional mode)" if share else
+                          "nccl = RCCL: one async all_gather_into_tensor of the (32,P,14) fp32 pose records per step, waited for one step later; "
+                          "barrier + device synchronize around every timed block"),
+            "scaling": "weak"}
+
+
 def self_spawn(n: int) -> int:
     """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) of this very command under
     torch.distributed.run on 127.0.0.1 and return its exit code.  Refuses when the node has fewer than N GPUs (unless
@@ -339,9 +362,7 @@ def self_spawn(n: int) -> int:
     have = torch.cuda.device_count()
     if have < n and os.environ.get("CAPTRA_BENCH_SHARE_GPU") != "1":
         raise SystemExit(f"bench.py --gpus {n}: this node has {have} GPU(s); one rank per GPU is the only measured configuration")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.run(cmd).returncode
+    return subprocess.run(spawn_command(n)).returncode
 
 
 def main():
@@ -374,9 +395,15 @@ def main():
     ap.add_argument("--category", default="bottle", choices=sorted(WORKLOADS) + ["mix6"],
                     help="bottle = BASELINE.json configs[1] (the metric's configuration); the other object classes; mix6 = "
                          "BASELINE.json configs[2]'s serving mix: rank r tracks NOCS category 1 + r mod 6 with that category's weights")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="print the launch plan of `--gpus N` as one JSON object (the exact torch.distributed.run command the self-spawn "
+                         "would run, the rank -> device map, the collective backend, what each rank tracks) and exit without touching a GPU")
     ap.add_argument("--no-pw-pair", action="store_true", help=argparse.SUPPRESS)       # A/B: dense layers without paired column tiles
     ap.add_argument("--pw-occ", type=int, default=0, help=argparse.SUPPRESS)           # A/B: dense layers' workgroups per CU (2 / 3)
     args = ap.parse_args()
+    if args.dry_run:
+        print(json.dumps(launch_plan(args.gpus)))
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     if args.otf_only:
@@ -408,7 +435,8 @@ def main():
     device = torch.device("cuda", dev_index)
     dist = None
     backend = None
-    if world > 1:
+    force_dist = os.environ.get("CAPTRA_BENCH_FORCE_DIST") == "1" and "WORLD_SIZE" in os.environ   # world 1 through RCCL too (1-GPU boxes)
+    if world > 1 or force_dist:
         import torch.distributed as dist
         backend = "gloo" if share else "nccl"        # "nccl" IS RCCL on ROCm; gloo only in the shared-GPU functional test mode
         if backend == "nccl":
@@ -425,7 +453,7 @@ def main():
         args.lanes = 2 if B >= 32 and B % 2 == 0 else 1
     if args.no_overlap or args.no_graph:
         args.lanes = 1
-    exchange = PoseExchange(B, P, device, world, rank)
+    exchange = PoseExchange(B, P, device, world, rank, collective=dist is not None)
     nframes = len(model.feed_dict)
     pose = {k: v.clone() for k, v in model.feed_dict[0]["gt_part"].items()}
 
@@ -456,7 +484,10 @@ def main():
         else:
             with torch.no_grad():
                 _, new_pose = model.track_step(model.feed_dict[f], model.npcs_feed_dict[f], pose)
-        exchange.all_gather(new_pose)          # every rank ends the step holding all poses
+        # every rank ends up holding all poses of the frame; the gather of step i completes under step i + 1's kernels
+        # (no rank needs remote poses to proceed) -- the wait below is for step i - 1's
+        exchange.wait()
+        exchange.all_gather(new_pose, async_op=True)
         return new_pose
 
     warm = max(args.warmup, args.min_warmup)
@@ -464,6 +495,7 @@ def main():
         pose = step(i, pose)
 
     def sync():
+        exchange.wait()                           # the last step's gather belongs to the block it was issued in
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -559,7 +591,7 @@ def main():
                          "value_from": "median block; every block = exactly `steps` steps between barrier + device synchronize, max over ranks",
                          "warmup_steps_run": warm},
         "rccl_world_size": rccl_world,
-        "collective_backend": ("none (single rank)" if world == 1 else "nccl (RCCL)" if backend == "nccl" else
+        "collective_backend": ("none (single rank)" if dist is None else "nccl (RCCL)" if backend == "nccl" else
                                "gloo -- CAPTRA_BENCH_SHARE_GPU functional test mode: ranks share GPUs, NOT a scaling measurement"),
         "per_rank_ms_per_step": [[round(x, 3) for x in row] for row in per_rank_ms],
     }

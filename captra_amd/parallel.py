@@ -43,8 +43,11 @@ class PoseExchange:
     """All-gather of the packed pose records of one frame.  Buffers are allocated once; with
     world == 1 it degenerates to a local copy so that the single-GPU step does the same packing."""
 
-    def __init__(self, batch_per_rank: int, num_parts: int, device, world: int = 1, rank: int = 0):
+    def __init__(self, batch_per_rank: int, num_parts: int, device, world: int = 1, rank: int = 0, collective: bool | None = None):
+        """collective: issue the all-gather through torch.distributed even at world 1 (None = only when world > 1): what a
+        1-GPU box can exercise of the RCCL path."""
         self.world, self.rank = world, rank
+        self.collective = world > 1 if collective is None else bool(collective)
         self.local = torch.empty(batch_per_rank, num_parts, POSE_RECORD, dtype=torch.float32, device=device)
         self.gathered = torch.empty(world * batch_per_rank, num_parts, POSE_RECORD, dtype=torch.float32, device=device)
         self.handle = None
@@ -55,7 +58,7 @@ class PoseExchange:
 
     def all_gather_packed(self, async_op: bool = False) -> torch.Tensor:
         """All-gather whatever `self.local` holds (records packed by the caller, e.g. a short batch padded with invalid ones)."""
-        if self.world == 1:
+        if not self.collective:
             self.gathered.copy_(self.local)
             return self.gathered
         import torch.distributed as dist

@@ -88,3 +88,36 @@ def test_bench_line_contract_single_gpu(device):
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == out["unit"] and c["sample"]
     assert out["pose_match"]["within_1e-4"] and out["pose_match"]["agree_5deg5cm"] == 1.0
     assert out["otf"]["single_batch"]["value"] > 0 and out["otf"]["two_lanes"]["value"] > 0
+
+
+def test_rccl_communicator_world1_graph_lanes_and_exchange(device):
+    """What a 1-GPU box can exercise of the RCCL path, in a process of its own (tools/check_dist_graph.py):
+    init_process_group("nccl", world_size=1, device_id=...), the step captured AFTER the communicator is up, five replays and
+    twelve free-running lane steps each followed by bench.py's asynchronous all_gather_into_tensor (waited for one step
+    later), the product harness's FramePoseGather incl. its short-batch padding, barrier, clean destroy_process_group."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_dist_graph.py")], env=env, cwd=ROOT, capture_output=True,
+                         text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    for line in ("ok: captured with overlap_nets", "ok: free-running lanes + all-gather", "ok: track harness frame exchange",
+                 "ok: process group destroyed"):
+        assert line in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]
+
+
+def test_bench_under_a_launcher_runs_its_exchange_through_rccl_at_world1(device):
+    """`torch.distributed.run --nproc-per-node 1 bench.py --gpus 1` with CAPTRA_BENCH_FORCE_DIST=1: the very code an 8-GPU
+    launch runs per rank -- init_process_group("nccl", device_id), async per-step all-gather, barrier inside the timed
+    blocks' sync, the world-size all-gather, destroy -- with the one rank this box has."""
+    env = dict(os.environ, CAPTRA_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1", "--master-port", "29543",
+           os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--min-warmup", "1", "--repeats", "2", "--batch", "32",
+           "--no-cpu-baseline", "--no-kernel-timing", "--no-otf"]
+    res = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    out = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["collective_backend"] == "nccl (RCCL)" and out["rccl_world_size"] == 1 and out["n_gpus"] == 1
+    assert "2 free-running lanes" in out["config"]["launch"] and out["pose_match"]["within_1e-4"]

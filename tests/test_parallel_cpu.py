@@ -204,3 +204,23 @@ def test_track_harness_shards_trajectories_over_ranks_gloo(tmp_path):
     assert "rank 0 of 2" in out2
     res = _compare_track_worlds(tmp_path, ["w1", "w2", "w3"])
     assert any(k.startswith("avg_pred/") for k in res["loss"])
+
+
+def test_bench_dry_run_prints_the_launch_plan_without_a_gpu():
+    """`python bench.py --gpus 8 --dry-run`: the exact launcher command of the self-spawn, the rank -> device map and the
+    collective, as JSON, with no GPU touched (this container has none: it would refuse the real launch and says so)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--dry-run", "--steps", "7"], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    plan = json.loads(res.stdout.strip().splitlines()[-1])
+    assert plan["gpus_requested"] == 8 and len(plan["ranks"]) == 8
+    assert [r["device"] for r in plan["ranks"]] == [f"cuda:{i}" for i in range(8)]
+    assert "torch.distributed.run" in plan["command"] and "--nproc-per-node=8" in plan["command"] and "--master-addr 127.0.0.1" in plan["command"]
+    assert "--steps 7" in plan["command"] and "--dry-run" not in plan["command"]
+    assert "nccl" in plan["collective"] and plan["scaling"] == "weak"
+    import torch
+    assert plan["would_refuse"] == (torch.cuda.device_count() < 8 if torch.cuda.is_available() else True)
