@@ -194,6 +194,85 @@ def otf_leg(batch: int, device, frames: int = 10, reps: int = 5):
     return out
 
 
+def b1_leg(device, steps: int = 200, otf_frames: int = 24, reps: int = 5):
+    """Single-trajectory latency, the reference's own measuring convention (`--batch_size=1`, /root/reference README.md:267; the
+    on-the-fly crop asserts batch 1, model.py:319; BASELINE.json configs[0]'s workload): ms per frame at B = 1 for (a) the
+    pre-cropped step (captured graph, pose chained frame to frame) with its per-family kernel times from an eager pass, and
+    (b) the `nocs_otf=True` loop (re-crop + 15 k -> 4096 sampling + step per frame, Python included)."""
+    import tempfile
+    from captra_amd import _lib, fused
+    from captra_amd.configs import make_config
+    from captra_amd.graph import TrackStepGraph
+    from captra_amd.synthetic import make_otf_trajectory, make_state_dict
+    from captra_amd.trainer import Trainer
+    cfg, sd, model, data = build_workload(1, device, frames=8)
+    pose = {k: v.clone() for k, v in model.feed_dict[0]["gt_part"].items()}
+    f1 = model.feed_dict[1]
+    graph = TrackStepGraph(model, f1["points"], f1["points_mean"], pose)
+    nfr = len(model.feed_dict)
+    times = []
+    for rep in range(reps + 1):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            fd = model.feed_dict[1 + i % (nfr - 1)]
+            pose = graph.replay(fd["points"], fd["points_mean"], pose)
+        torch.cuda.synchronize()
+        if rep:
+            times.append((time.perf_counter() - t0) / steps)
+    times.sort()
+    pre = times[(len(times) - 1) // 2]
+    # kernel families of one frame (eager launches, networks one after the other: a launch's duration is the kernel's own)
+    model.overlap_nets = False
+    p2 = {k: v.clone() for k, v in pose.items()}
+    _lib.prof_reset()
+    _lib.prof_enable(True)
+    with torch.no_grad():
+        for i in range(20):
+            _, p2 = model.track_step(model.feed_dict[1 + i % (nfr - 1)], model.npcs_feed_dict[1 + i % (nfr - 1)], p2)
+    torch.cuda.synchronize()
+    _lib.prof_enable(False)
+    fams = {n: _lib.prof_read(n)[0] / 20 for n in _lib.prof_names() if _lib.prof_read(n)[1]}
+    out = {"unit": "ms per frame", "convention": "reference README.md:267 (--batch_size=1), model.py:319",
+           "pre_cropped": {"ms_per_frame": round(pre * 1e3, 4), "frames_per_s": round(1.0 / pre, 1), "launch": "hipGraph replay of the step, pose chained",
+                           "kernel_ms_per_frame_networks_in_sequence": {k: round(v, 4) for k, v in sorted(fams.items(), key=lambda kv: -kv[1])}}}
+    del graph, model
+    cfg = make_config("1", experiment_dir=tempfile.mkdtemp(prefix="captra_bench_b1_"), nocs_otf=True, **{"init_frame/gt": True})
+    cfg["device"] = device
+    trainer = Trainer(cfg)
+    trainer.model.load_state_dict(make_state_dict({k: tuple(v.shape) for k, v in trainer.model.state_dict().items()}, seed=7))
+    trainer.model.use_graph = True
+    otf = make_otf_trajectory(1, otf_frames, seed=1, step_px=2.0)
+    for f in otf:
+        f["meta"]["pre_fetched"] = {k: v.to(device) for k, v in f["meta"]["pre_fetched"].items()}
+    np.random.seed(0)
+    times = []
+    for rep in range(reps + 1):
+        trainer.model.eval()
+        trainer.model.set_data(otf)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        trainer.model.test(save=False, no_eval=True)
+        torch.cuda.synchronize()
+        if rep:
+            times.append((time.perf_counter() - t0) / (otf_frames - 1))
+    times.sort()
+    med = times[(len(times) - 1) // 2]
+    _lib.prof_reset()
+    _lib.prof_enable(True)
+    trainer.model.set_data(otf)
+    trainer.model.test(save=False, no_eval=True)
+    torch.cuda.synchronize()
+    _lib.prof_enable(False)
+    crop = {n: _lib.prof_read(n)[0] / (otf_frames - 1) for n in ("crop_ball", "fps")}
+    out["nocs_otf"] = {"ms_per_frame": round(med * 1e3, 4), "frames_per_s": round(1.0 / med, 1),
+                       "launch": "EvalTrackModel.test, nocs_otf=True: re-crop (crop kernel + pruned sampler ~15 k -> 4096) + captured step per frame, Python included",
+                       "kernel_ms_per_frame": {"crop_ball": round(crop["crop_ball"], 4),
+                                               "fps (re-crop sampler + the step's two levels, eager passes only)": round(crop["fps"], 4)}}
+    out["note"] = f"median of {reps} runs each; the sampler is ONE workgroup per cloud: 4095 dependent rounds bound the nocs_otf frame"
+    return out
+
+
 def hbm_ops_roofline(batch: int, device, reps: int = 5):
     """The drop-in ops ball_query + group_points (SURVEY.md §8d "materialised-op" byte definition: ball query
     12N + 12M + 4MK, group 4CN + 4MK + 4CMK bytes per cloud) on the workload's SA1 / SA2 shapes for one frame
@@ -380,6 +459,8 @@ def main():
     ap.add_argument("--no-pose-match", action="store_true", help="skip the CPU-oracle check of the timed trajectories' last step")
     ap.add_argument("--no-otf", action="store_true", help="skip the `otf` leg (the EvalTrackModel loop with the on-the-fly re-crop)")
     ap.add_argument("--otf-only", action="store_true", help=argparse.SUPPRESS)          # the `otf` leg's own process: prints that object only
+    ap.add_argument("--b1-only", action="store_true", help=argparse.SUPPRESS)           # the `b1` leg's own process
+    ap.add_argument("--no-b1", action="store_true", help="skip the `b1` leg (single-trajectory latency, pre-cropped and nocs_otf)")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     ap.add_argument("--no-graph", action="store_true", help="launch the step eagerly instead of replaying a hipGraph")
     ap.add_argument("--lanes", type=int, default=0,
@@ -408,6 +489,9 @@ def main():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     if args.otf_only:
         print(json.dumps(otf_leg(args.batch, torch.device("cuda", 0))))
+        return
+    if args.b1_only:
+        print(json.dumps(b1_leg(torch.device("cuda", 0))))
         return
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(self_spawn(args.gpus))        # one rank per GPU, rendezvous on 127.0.0.1
@@ -658,6 +742,11 @@ def main():
         res = subprocess.run([sys.executable, os.path.abspath(__file__), "--otf-only", "--batch", str(B)], capture_output=True, text=True)
         lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
         out["otf"] = json.loads(lines[-1]) if res.returncode == 0 and lines else {"error": (res.stderr or res.stdout)[-500:]}
+    if world == 1 and not args.no_b1 and args.mlp_dtype == "fp32" and args.category == "bottle":
+        import subprocess
+        res = subprocess.run([sys.executable, os.path.abspath(__file__), "--b1-only"], capture_output=True, text=True)
+        lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+        out["b1"] = json.loads(lines[-1]) if res.returncode == 0 and lines else {"error": (res.stderr or res.stdout)[-500:]}
     if world == 1 and not args.no_cpu_baseline and args.category == "bottle":
         out["cpu_baseline"] = cpu_baseline(cfg, sd, args.cpu_budget)
         out["cpu_baseline"]["reference_cpu_path_in_authoring_container"] = {
