@@ -24,6 +24,7 @@ _SIGNATURES = {
     "captra_furthest_point_sampling": [_INT, _INT, _INT, _P, _P, _P, _P],
     "captra_ball_query": [_INT, _INT, _INT, _F, _INT, _P, _P, _P, _P],
     "captra_group_points": [_INT, _INT, _INT, _INT, _INT, _P, _P, _P, _P],
+    "captra_group_points_multi": [_INT, _INT, _INT, _P, _P, _P, _P, _P, _P, _P],
     "captra_group_points_grad": [_INT, _INT, _INT, _INT, _INT, _P, _P, _P, _P],
     "captra_group_points_grad_ws": [_INT, _INT, _INT, _INT, _INT, _P, _P, _P, _P, C.c_size_t, _P],
     "captra_three_interpolate_grad_ws": [_INT, _INT, _INT, _INT, _P, _P, _P, _P, _P, C.c_size_t, _P],

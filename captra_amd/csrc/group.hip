@@ -26,16 +26,13 @@ constexpr int GP_POS_PER_BLOCK = 4096;   // output positions handled by one work
 // (32 interleaved 1-KiB streams per wave), of the 5.9-6.3 TB/s a plain fill reaches on this part
 // (tools/ubench/hbm_probe.hip).  Streaming (non-temporal) stores: written once, never re-read here.
 template <int VEC>
-__global__ __launch_bounds__(GP_THREADS) void group_points_kernel(int c, int n, long long npos, int cc, int ppb,
-                                                                  const float *__restrict__ points,
-                                                                  const int *__restrict__ idx,
-                                                                  float *__restrict__ out) {
+__device__ __forceinline__ void group_points_body(int c, int n, long long npos, int cc, int ppb, const float *__restrict__ points,
+                                                  const int *__restrict__ idx, float *__restrict__ out, int bx, int by, int b) {
     extern __shared__ __attribute__((aligned(16))) float rows[];
     typedef float f32x4 __attribute__((ext_vector_type(4)));
-    const int b = blockIdx.z;
-    const int c0 = blockIdx.y * cc;
+    const int c0 = by * cc;
     const int ccv = (c - c0) < cc ? (c - c0) : cc;
-    const long long p0 = (long long)blockIdx.x * ppb;
+    const long long p0 = (long long)bx * ppb;
     const long long p1 = (p0 + ppb) < npos ? (p0 + ppb) : npos;
     const int tid = threadIdx.x;
 
@@ -80,6 +77,41 @@ __global__ __launch_bounds__(GP_THREADS) void group_points_kernel(int c, int n, 
     }
 }
 
+template <int VEC>
+__global__ __launch_bounds__(GP_THREADS) void group_points_kernel(int c, int n, long long npos, int cc, int ppb,
+                                                                  const float *__restrict__ points,
+                                                                  const int *__restrict__ idx,
+                                                                  float *__restrict__ out) {
+    group_points_body<VEC>(c, n, npos, cc, ppb, points, idx, out, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Several grouping jobs on the SAME source clouds' size (one set-abstraction level: every radius x every feature tensor of
+// both networks) in ONE launch: the 10-35 MB jobs of a level are per-launch-latency bound one at a time (seventeen launches
+// per frame, ~0.09 ms of ramps and tails in a 0.46 ms job).  blockIdx.x walks the jobs' (position block, channel chunk)
+// grids back to back; each workgroup runs the single-job body on its job's descriptor.
+constexpr int GP_MAX_JOBS = 12;
+struct GpJob {
+    const float *points;
+    const int *idx;
+    float *out;
+    long long npos;
+    int c, cc, ppb, pos_blocks, blk0;
+};
+struct GpMulti {
+    GpJob job[GP_MAX_JOBS];
+    int njobs, n;
+};
+
+__global__ __launch_bounds__(GP_THREADS) void group_points_multi_kernel(GpMulti m) {
+    int j = 0;
+#pragma unroll 1
+    for (int k = 1; k < m.njobs; ++k)
+        if ((int)blockIdx.x >= m.job[k].blk0) j = k;
+    const GpJob &g = m.job[j];
+    const int local = (int)blockIdx.x - g.blk0;
+    group_points_body<4>(g.c, m.n, g.npos, g.cc, g.ppb, g.points, g.idx, g.out, local % g.pos_blocks, local / g.pos_blocks, blockIdx.z);
+}
+
 // Rows too long for LDS staging (n*4 > budget): gather straight from global / L2.
 __global__ __launch_bounds__(GP_THREADS) void group_points_direct_kernel(int c, int n, long long npos,
                                                                          const float *__restrict__ points,
@@ -106,6 +138,20 @@ __global__ __launch_bounds__(GP_THREADS) void group_points_grad_kernel(int c, in
         atomicAdd(grad_points + ((size_t)b * c + ch) * n + id, grad_out[((size_t)b * c + ch) * npos + p]);
 }
 
+// channel-chunk size, positions per workgroup and position blocks of one job (rows fit the LDS budget)
+void gp_shape(int b, int c, int n, long long npos, int &cc, int &ppb, long long &pos_blocks) {
+    const size_t row_bytes = (size_t)n * sizeof(float);
+    cc = (int)(GP_LDS_BYTES / row_bytes);
+    if (cc > c) cc = c;
+    if (cc > 32) cc = 32;
+    // long rows (SA1: 16 KiB each): amortise the staging over twice the positions
+    ppb = n >= 2048 ? 2 * GP_POS_PER_BLOCK : GP_POS_PER_BLOCK;
+    pos_blocks = (npos + ppb - 1) / ppb;
+    // few-channel inputs: split the channels over more workgroups until the chip is covered (staging cost per
+    // output byte is n / ppb whatever cc is; only the idx quads are re-read)
+    while (cc > 1 && pos_blocks * ((c + cc - 1) / cc) * b < 1024) cc = (cc + 1) / 2;
+}
+
 int launch_group(int b, int c, int n, long long npos, const float *points, const int *idx, float *out,
                  hipStream_t s) {
     if (b < 0 || c < 0 || n < 0 || npos < 0) return -1;
@@ -118,15 +164,9 @@ int launch_group(int b, int c, int n, long long npos, const float *points, const
                       points, idx, out);
         return captra_last_error();
     }
-    int cc = (int)(GP_LDS_BYTES / row_bytes);
-    if (cc > c) cc = c;
-    if (cc > 32) cc = 32;
-    // long rows (SA1: 16 KiB each): amortise the staging over twice the positions
-    const int ppb = n >= 2048 ? 2 * GP_POS_PER_BLOCK : GP_POS_PER_BLOCK;
-    const long long pos_blocks = (npos + ppb - 1) / ppb;
-    // few-channel inputs: split the channels over more workgroups until the chip is covered (staging cost per
-    // output byte is n / ppb whatever cc is; only the idx quads are re-read)
-    while (cc > 1 && pos_blocks * ((c + cc - 1) / cc) * b < 1024) cc = (cc + 1) / 2;
+    int cc, ppb;
+    long long pos_blocks;
+    gp_shape(b, c, n, npos, cc, ppb, pos_blocks);
     dim3 grid((unsigned)pos_blocks, (c + cc - 1) / cc, b);
     size_t shmem = (size_t)cc * row_bytes;
     const bool vec = (npos % 4 == 0) && ((reinterpret_cast<uintptr_t>(idx) & 15) == 0) &&
@@ -199,4 +239,46 @@ extern "C" int captra_gather_points(int b, int c, int n, int npoints, const floa
 extern "C" int captra_gather_points_grad(int b, int c, int n, int npoints, const float *grad_out,
                                          const int *idx, float *grad_points, captra_stream_t stream) {
     return launch_group_grad(b, c, n, (long long)npoints, grad_out, idx, grad_points, nullptr, 0, (hipStream_t)stream);
+}
+
+// njobs grouping jobs over clouds of the same size n (host arrays of length njobs: channel counts, centres, samples per centre,
+// DEVICE pointers): out[j] (B,c[j],npoints[j],nsample[j]) = points[j] (B,c[j],N) gathered through idx[j] (B,npoints[j],nsample[j]).
+// One launch when every job has 16-byte aligned idx / out rows with npoints*nsample % 4 == 0, the rows fit the LDS staging and
+// njobs <= 12; otherwise the jobs are launched one by one (same results).
+extern "C" int captra_group_points_multi(int b, int n, int njobs, const int *c, const int *npoints, const int *nsample,
+                                         const float *const *points, const int *const *idx, float *const *out, captra_stream_t stream) {
+    if (b < 0 || n < 1 || njobs < 0) return -1;
+    if (b == 0 || njobs == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    bool one = njobs <= GP_MAX_JOBS && (size_t)n * sizeof(float) <= (size_t)GP_LDS_BYTES;
+    for (int j = 0; j < njobs && one; ++j) {
+        const long long npos = (long long)npoints[j] * nsample[j];
+        one = c[j] >= 1 && npos >= 1 && npos % 4 == 0 && (reinterpret_cast<uintptr_t>(idx[j]) & 15) == 0 && (reinterpret_cast<uintptr_t>(out[j]) & 15) == 0;
+    }
+    if (!one) {
+        for (int j = 0; j < njobs; ++j) {
+            const int rc = launch_group(b, c[j], n, (long long)npoints[j] * nsample[j], points[j], idx[j], out[j], s);
+            if (rc != 0) return rc;
+        }
+        return 0;
+    }
+    GpMulti m;
+    m.njobs = njobs;
+    m.n = n;
+    int blocks = 0, ccmax = 0;
+    for (int j = 0; j < njobs; ++j) {
+        GpJob &g = m.job[j];
+        long long pb;
+        g.points = points[j]; g.idx = idx[j]; g.out = out[j]; g.c = c[j]; g.npos = (long long)npoints[j] * nsample[j];
+        gp_shape(b, g.c, n, g.npos, g.cc, g.ppb, pb);
+        g.pos_blocks = (int)pb;
+        g.blk0 = blocks;
+        blocks += (int)pb * ((g.c + g.cc - 1) / g.cc);
+        ccmax = g.cc > ccmax ? g.cc : ccmax;
+    }
+    static CaptraDeviceOnce once;
+    if (once.first_use())
+        hipFuncSetAttribute(reinterpret_cast<const void *>(group_points_multi_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, GP_LDS_BYTES);
+    CAPTRA_LAUNCH("group_points", group_points_multi_kernel, dim3(blocks, 1, b), dim3(GP_THREADS), (size_t)ccmax * n * sizeof(float), s, m);
+    return captra_last_error();
 }

@@ -69,6 +69,25 @@ def ball_query_multi(radii, nsamples, xyz_n3, new_xyz_n3):
     return outs
 
 
+def group_points_multi(points_list, idx_list, outs=None):
+    """[grouping_operation(points_j (B,C_j,N), idx_j (B,M_j,K_j))] for jobs over clouds of the same size in ONE launch
+    (captra_group_points_multi): every radius x every feature tensor of a set-abstraction level."""
+    nj = len(points_list)
+    assert nj == len(idx_list) and nj > 0
+    B, _, N = points_list[0].shape
+    if outs is None:
+        outs = [torch.empty(B, p.shape[1], i.shape[1], i.shape[2], dtype=torch.float32, device=p.device) for p, i in zip(points_list, idx_list)]
+    for p, i, o in zip(points_list, idx_list, outs):
+        L.require_device(p, i, o)
+        assert p.shape[0] == B and p.shape[2] == N and i.dtype == torch.int32 and tuple(o.shape) == (B, p.shape[1], i.shape[1], i.shape[2])
+    arr = lambda ctype, vals: C.cast((ctype * nj)(*vals), C.c_void_p)      # noqa: E731
+    with torch.cuda.device(points_list[0].device):
+        L.call("captra_group_points_multi", B, N, nj, arr(C.c_int, [p.shape[1] for p in points_list]), arr(C.c_int, [i.shape[1] for i in idx_list]),
+               arr(C.c_int, [i.shape[2] for i in idx_list]), arr(C.c_void_p, [p.data_ptr() for p in points_list]),
+               arr(C.c_void_p, [i.data_ptr() for i in idx_list]), arr(C.c_void_p, [o.data_ptr() for o in outs]))
+    return outs
+
+
 def pack(wt_dense, bias_dense) -> PackedLinear:
     """Dense W^T (cin,cout) + bias (cout) -> the packed layout the kernels take."""
     return PackedLinear(wt_dense.float(), bias_dense.float())

@@ -51,6 +51,12 @@ int captra_ball_query(int b, int n, int m, float radius, int nsample, const floa
  * points (B,C,N) f32, idx (B,npoints,nsample) i32 -> out (B,C,npoints,nsample). */
 int captra_group_points(int b, int c, int n, int npoints, int nsample, const float *points,
                         const int *idx, float *out, captra_stream_t stream);
+/* Several grouping jobs over clouds of the same size in ONE launch (all radii x all feature tensors of a set-abstraction level):
+ * host arrays of length njobs (channel counts, centres, samples per centre, DEVICE pointers); job j is exactly
+ * captra_group_points(b, c[j], n, npoints[j], nsample[j], points[j], idx[j], out[j]).  Falls back to one launch per job for
+ * unaligned / odd-sized jobs or more than 12 of them. */
+int captra_group_points_multi(int b, int n, int njobs, const int *c, const int *npoints, const int *nsample,
+                              const float *const *points, const int *const *idx, float *const *out, captra_stream_t stream);
 
 /* Replaces group_points_grad_wrapper (group_points.cpp:11-22, kernel group_points_gpu.cu:8-25).
  * grad_out (B,C,npoints,nsample), idx -> grad_points (B,C,N) += scatter (caller pre-zeroes): atomicAdd like the reference

@@ -536,3 +536,28 @@ def test_three_interpolate_grad_csr_path_vs_float64(pn, device, c, m, n):
             np.add.at(ref64[b].T, idx[b, :, j], (g[b].astype(np.float64) * w[b, :, j].astype(np.float64)).T)
     scale = np.abs(ref64).max(axis=-1, keepdims=True) + 1e-30
     assert float((np.abs(got - ref64) / scale).max()) <= 4e-6
+
+
+@pytest.mark.gpu
+def test_group_points_multi_equals_single_jobs(device):
+    """captra_group_points_multi: all jobs of a level in one launch == the drop-in op job by job (bit-exact copies), at the
+    tracking shapes (SA1: 3 radii x 3-channel tensors; SA2: 2 radii x {3, 320} channels) and through the fallback (an odd-sized job)."""
+    from captra_amd import fused
+    from captra_amd import pointnet2_cuda as pc
+    rng = np.random.default_rng(11)
+    for n, m, ks, chans in ((4096, 512, (32, 64, 128), (3, 3, 3)), (512, 128, (64, 128), (3, 320, 3, 320)), (300, 7, (5,), (3, 2))):
+        B = 3
+        feats = {c: torch.from_numpy(rng.standard_normal((B, c, n)).astype(np.float32)).to(device) for c in set(chans)}
+        pts, idxs = [], []
+        for k in ks:
+            idx = torch.from_numpy(rng.integers(0, n, (B, m, k)).astype(np.int32)).to(device)
+            for c in chans:
+                pts.append(feats[c])
+                idxs.append(idx)
+        outs = fused.group_points_multi(pts, idxs)
+        for p, i, o in zip(pts, idxs, outs):
+            ref = torch.empty_like(o)
+            pc.group_points_wrapper(B, p.shape[1], n, i.shape[1], i.shape[2], p, i, ref)
+            assert torch.equal(o, ref)
+            exp = torch.gather(p.unsqueeze(2).expand(-1, -1, i.shape[1], -1), 3, i.long().unsqueeze(1).expand(-1, p.shape[1], -1, -1))
+            assert torch.equal(o, exp)
