@@ -30,6 +30,7 @@ _SIGNATURES = {
     "captra_three_interpolate_grad_ws": [_INT, _INT, _INT, _INT, _P, _P, _P, _P, _P, C.c_size_t, _P],
     "captra_gather_points": [_INT, _INT, _INT, _INT, _P, _P, _P, _P],
     "captra_gather_points_grad": [_INT, _INT, _INT, _INT, _P, _P, _P, _P],
+    "captra_gather_points_grad_ws": [_INT, _INT, _INT, _INT, _P, _P, _P, _P, C.c_size_t, _P],
     "captra_knn": [_INT, _INT, _INT, _INT, _P, _P, _P, _P, _P],
     "captra_three_nn": [_INT, _INT, _INT, _P, _P, _P, _P, _P],
     "captra_three_interpolate": [_INT, _INT, _INT, _INT, _P, _P, _P, _P, _P],
@@ -100,7 +101,8 @@ def lib():
         l.captra_prof_read.restype = _INT
         l.captra_prof_names.argtypes = [C.c_char_p, _INT]
         l.captra_prof_names.restype = _INT
-        for name, args in (("captra_group_points_grad_ws_bytes", [_INT] * 5), ("captra_three_interpolate_grad_ws_bytes", [_INT] * 4)):
+        for name, args in (("captra_group_points_grad_ws_bytes", [_INT] * 5), ("captra_three_interpolate_grad_ws_bytes", [_INT] * 4),
+                           ("captra_gather_points_grad_ws_bytes", [_INT] * 4)):
             if hasattr(l, name):
                 getattr(l, name).argtypes = args
                 getattr(l, name).restype = C.c_size_t

@@ -420,16 +420,20 @@ int launch_ball_query(int b, int n, int m, int nr, const float *radius, const in
         constexpr size_t extra = (size_t)(BQ_MAXCELLS + 1 + BQ_WAVES * NR * BQ_BMW) * 4 + BQ_WAVES * 6 * 4; \
         constexpr size_t cap = (size_t)BQ_PRUNE_MAXN * (12 + 16) + extra;                        \
         static CaptraDeviceOnce once;                                                            \
-        if (once.first_use())                                                                    \
+        if (once.first_use()) {                                                                  \
             hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                            \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap);           \
+            once.done();                                                                         \
+        }                                                                                        \
         CAPTRA_LAUNCH("ball_query", kern, grid, block, shmem + (size_t)tile_cap * 16 + extra, s, n, m, new_xyz, xyz, prm); \
     } else {                                                                                     \
         auto kern = ball_query_kernel<NR, false>;                                                \
         static CaptraDeviceOnce once;                                                            \
-        if (once.first_use())                                                                    \
+        if (once.first_use()) {                                                                  \
             hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                            \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, BQ_TILE * 12);       \
+            once.done();                                                                         \
+        }                                                                                        \
         CAPTRA_LAUNCH("ball_query", kern, grid, block, shmem, s, n, m, new_xyz, xyz, prm);       \
     }
     switch (nr) {

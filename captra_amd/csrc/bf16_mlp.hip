@@ -1,5 +1,5 @@
 // bf16-input / fp32-accumulate variants of the shared-MLP kernels (BASELINE.json configs[2]: "bf16 shared-MLP on
-// MFMA") for gfx950: v_mfma_f32_32x32x16_bf16.  Opt-in (captra_amd.fused.MLP_DTYPE = "bf16"); the default path and
+// MFMA") for gfx950: v_mfma_f32_32x32x16_bf16.  Opt-in (cfg['mlp_dtype'] = "bf16" / fused.use_mlp_dtype); the default path and
 // every parity claim of this package are exact fp32.
 //
 // Semantics of one layer:  y = act(b + sum_k bf16(w[k]) * bf16(x[k]))  -- weights rounded once at pack time, the input

@@ -27,16 +27,26 @@ static inline int captra_last_error() { return (int)hipGetLastError(); }
 
 // ---- per-device one-shot (kernel function attributes) ---------------------------------------------
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per DEVICE: a process that launches on a second GPU must set it
-// there too.  captra_first_use_on_device(flags) is true the first time it is called for the current device with this
-// flag word (one bit per device ordinal, atomic; two threads racing both set the attribute, which is idempotent).
+// there too.  Usage:  if (once.first_use()) { hipFuncSetAttribute(...); once.done(); }
+// first_use() only LOOKS (true until done() ran for the current device): the device is marked after the attribute calls
+// returned, so a second host thread racing the first either sees the mark (attributes already applied) or applies them
+// itself (idempotent) -- it can never launch with more dynamic LDS than the attribute allows yet.  A caller that never
+// calls done() simply re-applies the attribute on every launch (correct, a few microseconds).
 #include <atomic>
 struct CaptraDeviceOnce {
     std::atomic<unsigned long long> seen[2] = {{0ull}, {0ull}};   // device ordinals 0..127
-    bool first_use() {
+    static int device() {
         int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 128) return true;   // unknown device: always (re)set
-        const unsigned long long bit = 1ull << (dev & 63);
-        return (seen[dev >> 6].fetch_or(bit, std::memory_order_relaxed) & bit) == 0ull;
+        return (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 128) ? dev : -1;
+    }
+    bool first_use() const {
+        const int dev = device();
+        if (dev < 0) return true;                                  // unknown device: always (re)set
+        return (seen[dev >> 6].load(std::memory_order_acquire) & (1ull << (dev & 63))) == 0ull;
+    }
+    void done() {
+        const int dev = device();
+        if (dev >= 0) seen[dev >> 6].fetch_or(1ull << (dev & 63), std::memory_order_release);
     }
 };
 

@@ -356,8 +356,10 @@ int launch_fps(int b, int n, int m, const float *xyz, float *temp, int *idx, hip
         if (g_fps_variant == 0 && slots + lds_xyz <= 150 * 1024) {
             auto kern2 = fps_kernel_blocked<NWAVES, PPT, true>;
             static CaptraDeviceOnce once2;
-            if (once2.first_use())
+            if (once2.first_use()) {
                 hipFuncSetAttribute(reinterpret_cast<const void *>(kern2), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+                once2.done();
+            }
             CAPTRA_LAUNCH("fps", kern2, dim3(b), dim3(NWAVES * 64), slots + lds_xyz, s, n, m, xyz, temp, idx, new_n3, new_cn, ns);
             return captra_last_error();
         }
@@ -371,9 +373,11 @@ int launch_fps(int b, int n, int m, const float *xyz, float *temp, int *idx, hip
     if (slots + lds_xyz <= 150 * 1024) {
         auto kern = fps_kernel<NWAVES, PPT, true>;
         static CaptraDeviceOnce once;
-        if (once.first_use())
+        if (once.first_use()) {
             hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            once.done();
+        }
         CAPTRA_LAUNCH("fps", kern, dim3(b), dim3(NWAVES * 64), slots + lds_xyz, s, n, m, xyz, temp, idx);
     } else {
         CAPTRA_LAUNCH("fps", (fps_kernel<NWAVES, PPT, false>), dim3(b), dim3(NWAVES * 64), slots, s, n, m,

@@ -339,6 +339,7 @@ int launch_pruned(int b, int n_stride, const int *ns, int m, const float *xyz, f
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         hipFuncSetAttribute(reinterpret_cast<const void *>(fps_pruned_kernel<FP_NW, A, B, true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        once.done();
     }
     if (g_fps_stats != nullptr) {   // instrumented build of the same kernel (counters + s_memtime per phase)
         CAPTRA_LAUNCH("fps", (fps_pruned_kernel<FP_NW, A, B, true>), dim3(b), dim3(FP_T), shmem, s, n_stride, ns, m, xyz, temp,

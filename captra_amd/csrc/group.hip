@@ -177,6 +177,7 @@ int launch_group(int b, int c, int n, long long npos, const float *points, const
                             hipFuncAttributeMaxDynamicSharedMemorySize, GP_LDS_BYTES);
         hipFuncSetAttribute(reinterpret_cast<const void *>(group_points_kernel<1>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, GP_LDS_BYTES);
+        once.done();
     }
     if (vec) {
         CAPTRA_LAUNCH("group_points", group_points_kernel<4>, grid, dim3(GP_THREADS), shmem, s, c, n, npos, cc, ppb,
@@ -241,6 +242,16 @@ extern "C" int captra_gather_points_grad(int b, int c, int n, int npoints, const
     return launch_group_grad(b, c, n, (long long)npoints, grad_out, idx, grad_points, nullptr, 0, (hipStream_t)stream);
 }
 
+// caller-owned scratch, as captra_group_points_grad_ws: the atomic-free, bit-reproducible path
+extern "C" size_t captra_gather_points_grad_ws_bytes(int b, int c, int n, int npoints) {
+    return captra_scatter_ws_bytes(b, c, n, (long long)npoints);
+}
+
+extern "C" int captra_gather_points_grad_ws(int b, int c, int n, int npoints, const float *grad_out, const int *idx,
+                                            float *grad_points, void *workspace, size_t workspace_bytes, captra_stream_t stream) {
+    return launch_group_grad(b, c, n, (long long)npoints, grad_out, idx, grad_points, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
 // njobs grouping jobs over clouds of the same size n (host arrays of length njobs: channel counts, centres, samples per centre,
 // DEVICE pointers): out[j] (B,c[j],npoints[j],nsample[j]) = points[j] (B,c[j],N) gathered through idx[j] (B,npoints[j],nsample[j]).
 // One launch when every job has 16-byte aligned idx / out rows with npoints*nsample % 4 == 0, the rows fit the LDS staging and
@@ -277,8 +288,10 @@ extern "C" int captra_group_points_multi(int b, int n, int njobs, const int *c, 
         ccmax = g.cc > ccmax ? g.cc : ccmax;
     }
     static CaptraDeviceOnce once;
-    if (once.first_use())
+    if (once.first_use()) {
         hipFuncSetAttribute(reinterpret_cast<const void *>(group_points_multi_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, GP_LDS_BYTES);
+        once.done();
+    }
     CAPTRA_LAUNCH("group_points", group_points_multi_kernel, dim3(blocks, 1, b), dim3(GP_THREADS), (size_t)ccmax * n * sizeof(float), s, m);
     return captra_last_error();
 }

@@ -229,9 +229,11 @@ extern "C" int captra_three_interpolate(int b, int c, int m, int n, const float 
     if (cc > c) cc = c;
     if (cc > 32) cc = 32;
     static CaptraDeviceOnce once;
-    if (once.first_use())
+    if (once.first_use()) {
         hipFuncSetAttribute(reinterpret_cast<const void *>(three_interpolate_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, TI_LDS_BYTES);
+        once.done();
+    }
     dim3 grid((n + TI_POS_PER_BLOCK - 1) / TI_POS_PER_BLOCK, (c + cc - 1) / cc, b);
     CAPTRA_LAUNCH("three_interpolate", three_interpolate_kernel, grid, dim3(TI_THREADS), (size_t)cc * row_bytes, s,
                   c, m, n, cc, points, idx, weight, out);

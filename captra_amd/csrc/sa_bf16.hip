@@ -429,8 +429,10 @@ int sb_launch(int b, SbParams p, hipStream_t stream) {
     const int lds = (WLDS ? S::WBYTES : 0) + S::NBIAS * 4 + (CG >= 4 ? 4 * CG * C3 * 4 : 0);
     auto kern = sa_bf16_kernel<CF, C1, C2, C3, K, PRE, TN, CG, WLDS>;
     static CaptraDeviceOnce once;
-    if (lds > 48 * 1024 && once.first_use())
+    if (lds > 48 * 1024 && once.first_use()) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return (int)hipGetLastError();
+        once.done();
+    }
     CAPTRA_LAUNCH("sa_scale_fused", kern, dim3((p.njobs + 3) / 4), dim3(256), lds, stream, p);
     return captra_last_error();
 }

@@ -841,6 +841,7 @@ extern "C" int captra_sa_scale_fused(int b, int n, int m, int k, int cfeat, int 
     if (once.first_use()) {
         hipFuncSetAttribute(reinterpret_cast<const void *>(sa_fused_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipFuncSetAttribute(reinterpret_cast<const void *>(sa_fused_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        once.done();
     }
     if (wn == 2) {
         CAPTRA_LAUNCH("sa_scale_fused", sa_fused_kernel<2>, grid, dim3(512), lds64, (hipStream_t)stream, p);

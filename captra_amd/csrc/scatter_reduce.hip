@@ -156,9 +156,11 @@ int captra_scatter_reduce(bool interp, int b, int c, int n_src, long long npos, 
     int *ws = static_cast<int *>(workspace);
     int *start = ws, *order = ws + (size_t)b * (n_src + 1);
     static CaptraDeviceOnce once;
-    if (once.first_use())
+    if (once.first_use()) {
         hipFuncSetAttribute(reinterpret_cast<const void *>(build_csr_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             CSR_MAX_SRC * (int)sizeof(int));
+        once.done();
+    }
     CAPTRA_LAUNCH("scatter_csr", build_csr_kernel, dim3(b), dim3(CSR_T), (size_t)n_src * sizeof(int), s, n_src, (int)npos, idx,
                   start, order);
     dim3 grid((n_src + 255) / 256, (c + SR_CH - 1) / SR_CH, b);
@@ -170,6 +172,7 @@ int captra_scatter_reduce(bool interp, int b, int c, int n_src, long long npos, 
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * (int)sizeof(float));
             hipFuncSetAttribute(reinterpret_cast<const void *>(scatter_reduce_lds_kernel<false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * (int)sizeof(float));
+            once_lds.done();
         }
         int cpb = 1;
         while ((long long)((c + cpb - 1) / cpb) * b > 1024 && cpb < 16) cpb *= 2;   // ~2-4 workgroups per CU

@@ -295,8 +295,14 @@ def sa_first_layer_pre(feat, lin: PackedLinear):
 USE_SA_PIPE = True       # SA2 scales on the pipelined kernel (csrc/sa_pipe.hip); False = sa_wave_kernel<..., PRE> (A/B, tests)
 
 
-def sa_scale_pipe_supported(cfeat, layers, m: int, k: int) -> bool:
-    return USE_SA_PIPE and sa_scale_pre_supported(cfeat, layers, k) and (m * k) % 128 == 0
+def sa_scale_pipe_supported(cfeat, layers, m: int, k: int, b: int = 1, n: int = 1) -> bool:
+    """The launchers' own -2 conditions, mirrored (captra_sa_scale_pre_pm: tile-aligned positions, 32-bit buffer offsets of the
+    point-major v1 and of the position index; captra_pointwise_mlp_pm: 16-byte rows of v1, 32-bit offsets of its input), so that
+    a shape outside them takes the captra_sa_scale_pre path instead of raising."""
+    if not (USE_SA_PIPE and sa_scale_pre_supported(cfeat, layers, k) and (m * k) % 128 == 0):
+        return False
+    c1 = layers[0].cout
+    return c1 % 4 == 0 and c1 * n * 4 < (1 << 31) and b * m * k < (1 << 31) and cfeat * n * 4 < (1 << 31)
 
 
 def sa_first_layer_pre_pm(feat, lin: PackedLinear):

@@ -149,10 +149,20 @@ class TrackStepGraph:
         return self.model.track_step(input, npcs_input, self.pose)
 
     def stale(self) -> bool:
-        """True when some module re-folded (or dropped) its weights after this graph was captured: the replay would still
-        compute with the weights it owns, i.e. the OLD parameters."""
-        from .fold import weights_version
-        return weights_version() != self.weights_version
+        """True when a module UNDER THIS GRAPH'S MODEL re-folded (or dropped) its weights after the capture: the replay would
+        still compute with the weights the graph owns, i.e. the OLD parameters.  The process-wide version counter
+        (fold.weights_version) is only the fast path: when it moved -- any model of the process may have re-folded -- the
+        model's current packed layers are compared by identity with the ones captured, and an unrelated model's change
+        leaves this graph valid."""
+        from .fold import collect_folded, weights_version
+        now = weights_version()
+        if now == self.weights_version:
+            return False
+        current = collect_folded(self.model)
+        if len(current) == len(self.weights) and all(a is b for a, b in zip(current, self.weights)):
+            self.weights_version = now
+            return False
+        return True
 
     def replay(self, points, points_mean, pose, labels=None):
         """Copies the inputs into the captured buffers, replays, returns the (static) output pose dict —

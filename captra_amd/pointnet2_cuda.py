@@ -79,7 +79,10 @@ def gather_points_grad_wrapper(b, c, n, npoints, grad_out, idx, grad_points):
     _chk(grad_out, torch.float32, "grad_out"); _chk(idx, torch.int32, "idx"); _chk(grad_points, torch.float32, "grad_points")
     _need(grad_out, b * c * npoints, "grad_out"); _need(idx, b * npoints, "idx"); _need(grad_points, b * c * n, "grad_points")
     with torch.cuda.device(grad_out.device):
-        L.call("captra_gather_points_grad", b, c, n, npoints, L.ptr(grad_out), L.ptr(idx), L.ptr(grad_points))
+        # scratch for the atomic-free, bit-reproducible path is the caller's (as for group_points_grad): 0 bytes = atomics
+        need = int(L.lib().captra_gather_points_grad_ws_bytes(b, c, n, npoints))
+        ws = torch.empty(need, dtype=torch.uint8, device=grad_out.device) if need else None
+        L.call("captra_gather_points_grad_ws", b, c, n, npoints, L.ptr(grad_out), L.ptr(idx), L.ptr(grad_points), L.ptr(ws), need)
     return 1
 
 

@@ -202,7 +202,7 @@ class PointNetSetAbstractionMsg(_FoldCache, nn.Module):
                 fused.sa_scale_bf16(feat, xyz_cn, new_xyz_n3, idx, layers, out, off)
                 off += layers[-1].cout
                 continue
-            if feat is not None and fused.mlp_dtype() == "fp32" and fused.sa_scale_pipe_supported(feat.shape[1], layers, idx.shape[1], idx.shape[2]):
+            if feat is not None and fused.mlp_dtype() == "fp32" and fused.sa_scale_pipe_supported(feat.shape[1], layers, idx.shape[1], idx.shape[2], b=B, n=feat.shape[2]):
                 v1pm = fused.sa_first_layer_pre_pm(feat, layers[0])  # (B,N,c1) point-major: one 16-byte gather per register quad
                 fused.sa_scale_pre_pm(v1pm, xyz_cn, new_xyz_n3, idx, layers, out, off, feat.shape[1])
                 off += layers[-1].cout

@@ -79,6 +79,11 @@ int captra_gather_points(int b, int c, int n, int npoints, const float *points, 
 /* Replaces gather_points_grad_wrapper (sampling.cpp:24-35, kernel sampling_gpu.cu:46-63). */
 int captra_gather_points_grad(int b, int c, int n, int npoints, const float *grad_out,
                               const int *idx, float *grad_points, captra_stream_t stream);
+/* The same with caller-owned scratch (atomic-free, bit-reproducible; see captra_group_points_grad_ws).  What
+ * captra_amd.pointnet2_cuda.gather_points_grad_wrapper calls. */
+size_t captra_gather_points_grad_ws_bytes(int b, int c, int n, int npoints);
+int captra_gather_points_grad_ws(int b, int c, int n, int npoints, const float *grad_out, const int *idx, float *grad_points,
+                                 void *workspace, size_t workspace_bytes, captra_stream_t stream);
 
 /* Replaces knn_wrapper (interpolate.cpp:26-36, kernel interpolate_gpu.cu:9-57).
  * unknown (B,N,3), known (B,M,3) -> dist2 (B,N,k) squared distances ascending, idx (B,N,k);

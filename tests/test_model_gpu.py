@@ -406,6 +406,33 @@ def test_track_loop_with_graph_and_lanes_equals_eager(device):
     model.use_graph = False
 
 
+def test_captured_graph_stays_valid_when_another_model_refolds(device):
+    """the weights version is a process-wide counter, staleness is per model -- a second model that loads new
+    weights (or flips train / eval) must not invalidate this model's captured step, while this model's own reload does."""
+    from tests.weights import make_physical_state_dict
+    trainer, cfg, sd, _, _ = _trainer_physical("bottle", device)
+    model = trainer.model
+    model.use_graph = True
+    data = clouds.make_trajectory("nocs", 2, 3, seed=5)
+    torch.manual_seed(3)
+    first, _ = trainer.test(data, save=False, no_eval=True)
+    g = model._graph
+    other, _, _, _, _ = _trainer_physical("bottle", device)                   # a second model object of the process ...
+    other.model.load_state_dict(make_physical_state_dict({k: tuple(v.shape) for k, v in other.model.state_dict().items()}, 9, 1, True, "nocs"))
+    other.model.train()
+    other.model.eval()                                                       # ... re-folding its own weights
+    assert not g.stale()
+    torch.manual_seed(3)
+    second, _ = trainer.test(data, save=False, no_eval=True)
+    assert model._graph is g
+    for a, b in zip(first["poses"], second["poses"]):
+        for k in a:
+            np.testing.assert_array_equal(a[k].cpu().numpy(), b[k].cpu().numpy())
+    model.load_state_dict(make_physical_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, 8, 1, True, "nocs"))
+    assert g.stale()
+    model.use_graph = False
+
+
 def test_captured_graph_owns_its_weights_and_is_recaptured_when_they_change(device):
     """a captured step reads the folded weights through raw device pointers.  (a) Trainer.test() calls
     model.eval() every time -- on a model already in eval mode that must NOT drop the folded tensors (same tensor objects

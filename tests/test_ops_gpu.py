@@ -561,3 +561,26 @@ def test_group_points_multi_equals_single_jobs(device):
             assert torch.equal(o, ref)
             exp = torch.gather(p.unsqueeze(2).expand(-1, -1, i.shape[1], -1), 3, i.long().unsqueeze(1).expand(-1, p.shape[1], -1, -1))
             assert torch.equal(o, exp)
+
+
+@pytest.mark.gpu
+def test_gather_points_grad_takes_the_csr_path_bit_reproducibly(device):
+    """GatherOperation.backward with c >= 8 takes the caller-scratch CSR path (captra_gather_points_grad_ws through
+    pointnet2_cuda.gather_points_grad_wrapper): equal to a float64 scatter to fp32 rounding, and bit-identical from run to run
+    (the float-atomic path is neither ordered nor reproducible)."""
+    from captra_amd import _lib as L
+    from captra_amd import pointnet2_cuda as pc
+    rng = np.random.default_rng(5)
+    B, C, N, M = 4, 64, 512, 4096
+    assert L.lib().captra_gather_points_grad_ws_bytes(B, C, N, M) > 0
+    grad_out = torch.from_numpy(rng.standard_normal((B, C, M)).astype(np.float32)).to(device)
+    idx = torch.from_numpy(rng.integers(0, N, (B, M)).astype(np.int32)).to(device)
+    outs = []
+    for _ in range(3):
+        g = torch.zeros(B, C, N, device=device)
+        pc.gather_points_grad_wrapper(B, C, N, M, grad_out, idx, g)
+        outs.append(g.cpu())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    ref = torch.zeros(B, C, N, dtype=torch.float64)
+    ref.scatter_add_(2, idx.cpu().long().unsqueeze(1).expand(-1, C, -1), grad_out.cpu().double())
+    np.testing.assert_allclose(outs[0].numpy(), ref.numpy(), atol=4e-6 * float(ref.abs().max()), rtol=0)
