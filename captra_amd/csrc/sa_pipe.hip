@@ -53,15 +53,6 @@ struct SpParams {
 // Part c of NPARTS takes the units with u * NPARTS / UNITS == c, so the work spreads evenly over a pass's k-step sets.
 template <int NOUT>
 __device__ __forceinline__ void sp_mid_unit(const f32x16 &acc, int t, int q, float (&hout)[NOUT]) {
-#if defined(SP_EXP) && (SP_EXP & 4)
-    {   // EXPERIMENT: no ReLU / swap (wrong results, same data flow)
-        const int k0 = 16 * t + 4 * q;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (k0 + i < NOUT) hout[k0 + i] = acc[4 * q + i];
-        return;
-    }
-#endif
     unsigned a[4];          // ReLU on the bit pattern: one v_max_i32 (the float form is canonicalise + max)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -163,7 +154,7 @@ __device__ __forceinline__ void sp_epi_part(const f32x16 (&acc)[2], int ps, int 
 // Weight sets: the fragment image of the packed buffer (wave_mlp.h: sw_load_set / sw_first_set), 4 loads per set instead of
 // 16.  With one dword load per MFMA the four waves of a CU kept its vector-memory address unit (one 64-lane instruction per
 // ~16 cycles) exactly as busy as its matrix pipes (one MFMA per SIMD per 64 cycles): 19 % of a tile's cycles went into
-// waiting for weights that were in L2 all along (tools/exp_sw.sh, SW_EXP=2).
+// waiting for weights that were in L2 all along (measured in round 2 with the weight loads compiled out).
 
 // One layer: hin[] (B operands) -> hout[] (LAST = false) or per-wave maxima in red (LAST = true).  Weight sets in the ring
 // s[3]: the set of step g is s[(START + g) % 3]; this layer's first set must already be on its way (previous phase), the
@@ -200,17 +191,9 @@ __device__ __forceinline__ void sp_layer(const float *wt, const float *bias_lds,
                 if (kk < S::KST && 2 * ps + tm < S::NT)
                     acc[pb][tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(s[(START + g) % 3][tm * SW_KS + j], hin[kk], acc[pb][tm], 0, 0, 0);
             }
-#if defined(SP_EXP) && (SP_EXP & 1)
-        __builtin_amdgcn_sched_barrier(0);
-        if (c == S::NSETS - 1 && ps + 1 < S::NPASS) {     // EXPERIMENT: epilogue right after its pass (not deferred)
-#pragma unroll
-            for (int cc = 0; cc < S::NSETS; ++cc) sp_epi_part<COUT, LAST, S::NSETS>(acc[pb], ps, cc, hout, zrun, mst, lane);
-        }
-#else
         // the previous pass's epilogue, one part per step: issued behind this step's MFMAs, it runs while they execute
         if (ps > 0) {
             sp_epi_part<COUT, LAST, S::NSETS>(acc[pb ^ 1], ps - 1, c, hout, zrun, mst, lane);
-#if !(defined(SP_EXP) && (SP_EXP & 8))
             // one MFMA, then a few of the part's VALU instructions, sixteen times: each of them issues while an MFMA executes
             // (left to itself the scheduler puts the whole part behind the block, where only the last MFMA covers it)
 #pragma unroll
@@ -218,9 +201,7 @@ __device__ __forceinline__ void sp_layer(const float *wt, const float *bias_lds,
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
                 __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);   // VALU
             }
-#endif
         }
-#endif
         __builtin_amdgcn_sched_barrier(0);
     }
     constexpr int LP = S::NPASS - 1;

@@ -73,11 +73,7 @@ __device__ __forceinline__ void sw_load_set(float (&dst)[16], const __amdgpu_buf
         for (int qq = 0; qq < SW_KS / 4; ++qq) {
             const int q = c * (SW_KS / 4) + qq, t = 2 * ps + tm;
             if (q < F::KQ && t < S::NT) {
-#if defined(SW_EXP) && (SW_EXP & 2)
-                const float4 v = make_float4(__int_as_float(0x3c000000 + voff + q), __int_as_float(0x3c100000 + voff + t), 0.5f, 0.25f);  // EXPERIMENT: no weight loads
-#else
                 const float4 v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, (t * F::KQ + q) * 1024, 0));
-#endif
                 dst[tm * SW_KS + qq * 4 + 0] = v.x; dst[tm * SW_KS + qq * 4 + 1] = v.y;
                 dst[tm * SW_KS + qq * 4 + 2] = v.z; dst[tm * SW_KS + qq * 4 + 3] = v.w;
             }
@@ -102,16 +98,6 @@ __device__ __forceinline__ void sw_bias_init(f32x16 &acc, const float *bias_lds,
 // ReLU, then turn output tile t (rows 32t..32t+31) into B operands hout[16t..16t+15] (k-step = row pair)
 template <int NOUT>
 __device__ __forceinline__ void sw_mid_epilogue(const f32x16 &acc, int t, float (&hout)[NOUT]) {
-#if defined(SW_EXP) && (SW_EXP & 1)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {      // EXPERIMENT: no ReLU / swap (wrong results, same data flow)
-        const int k0 = 16 * t + 4 * q;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (k0 + i < NOUT) hout[k0 + i] = acc[4 * q + i];
-    }
-    return;
-#endif
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         // ReLU on the bit pattern (one v_max_i32: negative floats and -0 are negative integers; the float form costs a
