@@ -500,6 +500,8 @@ def main():
     ap.add_argument("--repeats", type=int, default=10,
                     help="the timed block of exactly --steps steps (barrier + synchronize on both sides) is run this many times back to "
                          "back; `value` / `ms_per_step` come from the MEDIAN block, min / max are reported beside it")
+    ap.add_argument("--min-timed-s", type=float, default=10.0,
+                    help="keep running timed blocks (beyond --repeats) until they add up to this many seconds of GPU work")
     ap.add_argument("--batch", type=int, default=32, help="trajectories per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket kernels with HIP events")
@@ -636,7 +638,13 @@ def main():
     eager_timing = timing and graph is None       # events can bracket kernels only when they are launched eagerly
     done = warm
     blocks = []                                   # seconds per timed block of exactly args.steps steps, this rank
-    for r in range(max(args.repeats, 1)):
+    r = -1
+    while True:
+        r += 1
+        # at least --repeats blocks, and blocks until the timed region adds up to --min-timed-s (the GPU stays busy long enough
+        # for an outside sampler to see it; the value is still the MEDIAN block of exactly --steps steps)
+        if r >= max(args.repeats, 1) and (sum(blocks) >= args.min_timed_s or r >= 2000):
+            break
         sync()
         if eager_timing and r == 0:
             _lib.prof_reset()

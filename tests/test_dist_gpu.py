@@ -41,7 +41,7 @@ def test_bench_gpus_n_without_a_launcher_spawns_n_ranks(device):
     """`python bench.py --gpus 2` with WORLD_SIZE unset starts two ranks itself (torch.distributed.run on 127.0.0.1), never
     a silent single-GPU run: the line reports n_gpus 2, the world size seen by an actual all-gather, and one row of block
     times per rank.  (Two ranks share this box's GPU over gloo here: functional test mode, flagged in the line.)"""
-    res = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--min-warmup", "1", "--repeats", "2", "--batch", "4",
+    res = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--min-warmup", "1", "--repeats", "2", "--min-timed-s", "0", "--batch", "4",
                   "--no-cpu-baseline", "--no-kernel-timing"], {"CAPTRA_BENCH_SHARE_GPU": "1"})
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
     line = [l for l in res.stdout.splitlines() if l.startswith("{")]
@@ -70,7 +70,7 @@ def test_bench_line_contract_single_gpu(device):
     read: metric / value / unit / n_gpus / steps / warmup / ms_per_step / higher_is_better / scaling / vs_baseline / dtype /
     data / config.workload, `roofline` {bound, achieved, peak, unit, frac, traffic} on the MFMA family, `cpu_baseline`
     {value, unit, cores, kind, sample}, the accuracy of the timed trajectories (`pose_match`) and the `otf` leg."""
-    res = _bench(["--steps", "2", "--warmup", "1", "--min-warmup", "2", "--repeats", "2", "--cpu-budget", "3"])
+    res = _bench(["--steps", "2", "--warmup", "1", "--min-warmup", "2", "--repeats", "2", "--min-timed-s", "0", "--cpu-budget", "3"])
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
     line = [l for l in res.stdout.splitlines() if l.startswith("{")]
     assert len(line) == 1, res.stdout
@@ -88,6 +88,10 @@ def test_bench_line_contract_single_gpu(device):
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == out["unit"] and c["sample"]
     assert out["pose_match"]["within_1e-4"] and out["pose_match"]["agree_5deg5cm"] == 1.0
     assert out["otf"]["single_batch"]["value"] > 0 and out["otf"]["two_lanes"]["value"] > 0
+    b1 = out["b1"]                     # single-trajectory latency (the reference's own measuring convention, README.md:267)
+    assert 0.3 < b1["pre_cropped"]["ms_per_frame"] < 5.0 and b1["pre_cropped"]["ms_per_frame"] < b1["nocs_otf"]["ms_per_frame"] < 20.0
+    h = out["hbm_ops"]
+    assert h["per_level"]["frac"] > h["frac"] and h["fill_probe_GB/s"] > 1000 and "equivalent_frac" not in h["product_path"]
 
 
 def test_rccl_communicator_world1_graph_lanes_and_exchange(device):
@@ -114,7 +118,7 @@ def test_bench_under_a_launcher_runs_its_exchange_through_rccl_at_world1(device)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1", "--master-port", "29543",
-           os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--min-warmup", "1", "--repeats", "2", "--batch", "32",
+           os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--min-warmup", "1", "--repeats", "2", "--min-timed-s", "0", "--batch", "32",
            "--no-cpu-baseline", "--no-kernel-timing", "--no-otf"]
     res = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]

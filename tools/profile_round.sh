@@ -14,7 +14,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 # --no-overlap: the two networks one after the other, so that a dispatch's duration is the kernel's own (bench.py's roofline
 # figures are measured the same way); the default bench line runs them side by side on two streams
-QUICK="--repeats 1 --min-warmup 2 --no-pose-match --no-cpu-baseline --no-kernel-timing --no-otf --no-b1 $EXTRA"
+QUICK="--repeats 1 --min-timed-s 0 --min-warmup 2 --no-pose-match --no-cpu-baseline --no-kernel-timing --no-otf --no-b1 $EXTRA"
 BENCH="python $ROOT/bench.py --steps 5 --warmup 2 $QUICK --no-overlap --lanes 1"
 BENCH_EAGER="python $ROOT/bench.py --steps 2 --warmup 1 $QUICK --no-graph --no-overlap"
 BENCH_OVERLAP="python $ROOT/bench.py --steps 5 --warmup 2 $QUICK"
