@@ -67,6 +67,9 @@ _SIGNATURES = {
     "captra_fp_interpolate_concat": [_INT, _INT, _INT, _INT, _INT, _P, _P, _P, _P, _P, _P, _P, _P],
     "captra_group_norm_relu": [_INT, _INT, _INT, _INT, _F, _INT, _P, _P, _P, _P, _P],
     "captra_part_fit_st": [_INT, _INT, _INT, _INT, _P, _P, _P, _INT, _P, _P, _P, _P, _P, _P],
+    "captra_part_fit_st_track": [_INT, _INT, _INT, _INT, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "captra_seg_softmax_argmax": [_INT, _INT, _INT, _P, _P, _P, _P],
+    "captra_copy_multi": [_INT, _P, _P, _P, _P],
     "captra_procrustes_rot3": [_INT, _INT, _P, _P, _P, _P],
 }
 

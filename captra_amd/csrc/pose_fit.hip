@@ -53,12 +53,18 @@ __global__ __launch_bounds__(PF_THREADS) void part_fit_st_kernel(int p, int n, i
                                                                  const float *__restrict__ given_scale,
                                                                  float *__restrict__ scale,
                                                                  float *__restrict__ trans,
-                                                                 int *__restrict__ valid) {
+                                                                 int *__restrict__ valid,
+                                                                 const float *__restrict__ tgt_mean,
+                                                                 const float *__restrict__ prev_scale,
+                                                                 const float *__restrict__ prev_trans) {
     __shared__ double smem[15 * 4];
     const int q = blockIdx.x;
     const int bi = q / p, pi = q % p;
     const float *S = src + (size_t)q * 3 * n;
     const float *T = tgt + (size_t)(tgt_per_part ? q : bi) * 3 * n;
+    // tgt_mean (B,3): the target is tgt + mean, formed here with the same single fp32 addition as the `points + points_mean`
+    // tensor the reference builds (networks.py:219)
+    const float tm[3] = {tgt_mean ? tgt_mean[bi * 3 + 0] : 0.f, tgt_mean ? tgt_mean[bi * 3 + 1] : 0.f, tgt_mean ? tgt_mean[bi * 3 + 2] : 0.f};
     const int *lab = labels + (size_t)bi * n;
     const int tid = threadIdx.x;
 
@@ -70,7 +76,7 @@ __global__ __launch_bounds__(PF_THREADS) void part_fit_st_kernel(int p, int n, i
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
                 fs[a] += S[(size_t)a * n + i];
-                ft[a] += T[(size_t)a * n + i];
+                ft[a] += tgt_mean ? T[(size_t)a * n + i] + tm[a] : T[(size_t)a * n + i];
             }
         }
     }
@@ -92,7 +98,7 @@ __global__ __launch_bounds__(PF_THREADS) void part_fit_st_kernel(int p, int n, i
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
                 sc[a] = S[(size_t)a * n + i] - sbf[a];
-                tc[a] = T[(size_t)a * n + i] - tbf[a];
+                tc[a] = (tgt_mean ? T[(size_t)a * n + i] + tm[a] : T[(size_t)a * n + i]) - tbf[a];
             }
 #pragma unroll
             for (int a = 0; a < 3; ++a)
@@ -159,14 +165,15 @@ __global__ __launch_bounds__(PF_THREADS) void part_fit_st_kernel(int p, int n, i
         }
         const float scf = (float)sca;
         const float trf[3] = {(float)tr[0], (float)tr[1], (float)tr[2]};
-        scale[q] = scf;
-        trans[(size_t)q * 3 + 0] = trf[0];
-        trans[(size_t)q * 3 + 1] = trf[1];
-        trans[(size_t)q * 3 + 2] = trf[2];
         double rsum = 0;
         for (int i = 0; i < 9; ++i) rsum += R[i];
         const float tsum = (trf[0] + trf[1]) + trf[2];
-        valid[q] = (cnt > 3.0) && isfinite(scf) && isfinite(tsum) && isfinite(rsum);
+        const bool ok = (cnt > 3.0) && isfinite(scf) && isfinite(tsum) && isfinite(rsum);
+        // prev_*: an invalid fit (<= 3 points, non-finite) keeps the previous scale / translation (networks.py:230-232)
+        scale[q] = (ok || !prev_scale) ? scf : prev_scale[q];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) trans[(size_t)q * 3 + a] = (ok || !prev_trans) ? trf[a] : prev_trans[(size_t)q * 3 + a];
+        valid[q] = ok;
     }
 }
 
@@ -398,7 +405,20 @@ extern "C" int captra_part_fit_st(int b, int p, int n, int sym, const int *label
     if (b < 0 || p < 1 || n < 0) return -1;
     if (b == 0) return 0;
     CAPTRA_LAUNCH("part_fit_st", part_fit_st_kernel, dim3(b * p), dim3(PF_THREADS), 0, (hipStream_t)stream, p, n,
-                  sym, tgt_per_part, labels, src, tgt, rot, given_scale, scale, trans, valid);
+                  sym, tgt_per_part, labels, src, tgt, rot, given_scale, scale, trans, valid, (const float *)nullptr,
+                  (const float *)nullptr, (const float *)nullptr);
+    return captra_last_error();
+}
+
+// The track loop's form of captra_part_fit_st (networks.py:219-232 in one launch): the target is pts (B,3,N) + pts_mean (B,3)
+// -- formed in the kernel, no (B,3,N) temporary -- and a part whose fit is invalid keeps prev_scale (B,P) / prev_trans (B,P,3).
+extern "C" int captra_part_fit_st_track(int b, int p, int n, int sym, const int *labels, const float *src, const float *pts,
+                                        const float *pts_mean, const float *rot, const float *prev_scale, const float *prev_trans,
+                                        float *scale, float *trans, int *valid, captra_stream_t stream) {
+    if (b < 0 || p < 1 || n < 0) return -1;
+    if (b == 0) return 0;
+    CAPTRA_LAUNCH("part_fit_st", part_fit_st_kernel, dim3(b * p), dim3(PF_THREADS), 0, (hipStream_t)stream, p, n,
+                  sym, 0, labels, src, pts, rot, (const float *)nullptr, scale, trans, valid, pts_mean, prev_scale, prev_trans);
     return captra_last_error();
 }
 

@@ -237,6 +237,71 @@ __global__ __launch_bounds__(GN_THREADS) void group_norm_relu_kernel(int c, int 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// CoordinateNet read-out: softmax over the S segmentation logits of every point (networks.py:50, F.softmax(dim=1)) and the
+// label = first index of the largest logit (model.py:466, torch.max(seg, dim=-2)[1] on the softmax: the exponential is
+// monotone, so the arg max is the logits') in ONE launch -- replaces a softmax, an arg-max reduction and an int64 -> int32
+// copy.  S <= 8.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void seg_softmax_argmax_kernel(int s, int n, const float *__restrict__ logits,
+                                                                 float *__restrict__ seg, int *__restrict__ labels) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float *x = logits + (size_t)b * s * n + i;
+    float v[8];
+    float m = 0.f;
+    int arg = 0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+        if (c < s) {
+            v[c] = x[(size_t)c * n];
+            if (c == 0 || v[c] > m) {      // strict '>': the FIRST index of the maximum, as torch.max / argmax return
+                arg = c;
+                m = v[c];
+            }
+        }
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+        if (c < s) {
+            v[c] = expf(v[c] - m);
+            sum += v[c];
+        }
+    if (seg != nullptr) {
+        float *y = seg + (size_t)b * s * n + i;
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            if (c < s) y[(size_t)c * n] = v[c] / sum;
+    }
+    if (labels != nullptr) labels[(size_t)b * n + i] = arg;
+}
+
+// ---------------------------------------------------------------------------------------------
+// several small device-to-device copies in one launch (the lanes' pose / record hand-over: ten 4-microsecond copy
+// kernels per lane and frame otherwise).  Jobs of 4-byte words; blockIdx.y = job.
+// ---------------------------------------------------------------------------------------------
+constexpr int CM_MAX_JOBS = 16;
+struct CopyMulti {
+    const unsigned *src[CM_MAX_JOBS];
+    unsigned *dst[CM_MAX_JOBS];
+    long long words[CM_MAX_JOBS];
+};
+__global__ __launch_bounds__(256) void copy_multi_kernel(CopyMulti m) {
+    const int j = blockIdx.y;
+    const long long nw = m.words[j];
+    const unsigned *s = m.src[j];
+    unsigned *d = m.dst[j];
+    const long long t0 = (long long)blockIdx.x * 256 + threadIdx.x, step = (long long)gridDim.x * 256;
+    if (((reinterpret_cast<uintptr_t>(s) | reinterpret_cast<uintptr_t>(d)) & 15) == 0) {
+        const long long n4 = nw >> 2;
+        for (long long e = t0; e < n4; e += step) reinterpret_cast<uint4 *>(d)[e] = reinterpret_cast<const uint4 *>(s)[e];
+        for (long long e = (n4 << 2) + t0; e < nw; e += step) d[e] = s[e];
+    } else {
+        for (long long e = t0; e < nw; e += step) d[e] = s[e];
+    }
+}
+
 }  // namespace
 
 extern "C" int captra_canonicalize(int b, int p, int n, const float *pts, const float *mean, const float *rot,
@@ -293,5 +358,35 @@ extern "C" int captra_group_norm_relu(int b, int c, int n, int channels_per_grou
     if (b == 0) return 0;
     CAPTRA_LAUNCH("group_norm_relu", group_norm_relu_kernel, dim3(b * (c / channels_per_group)), dim3(GN_THREADS), 0,
                   (hipStream_t)stream, c, n, channels_per_group, eps, relu, x, gamma, beta, y);
+    return captra_last_error();
+}
+
+// logits (B,S,N), S <= 8 -> seg (B,S,N) = softmax over S (may be NULL), labels (B,N) i32 = first index of the largest logit
+// (may be NULL): networks.py:50 + model.py:466 in one launch.
+extern "C" int captra_seg_softmax_argmax(int b, int s, int n, const float *logits, float *seg, int *labels, captra_stream_t stream) {
+    if (b < 0 || s < 1 || n < 0) return -1;
+    if (s > 8) return -2;
+    if (b == 0 || n == 0) return 0;
+    CAPTRA_LAUNCH("seg_readout", seg_softmax_argmax_kernel, dim3((n + 255) / 256, b), dim3(256), 0, (hipStream_t)stream, s, n, logits, seg, labels);
+    return captra_last_error();
+}
+
+// njobs <= 16 device-to-device copies of bytes[j] (multiples of 4) bytes each, one launch; host arrays of DEVICE pointers.
+extern "C" int captra_copy_multi(int njobs, const void *const *src, void *const *dst, const long long *bytes, captra_stream_t stream) {
+    if (njobs < 0 || njobs > CM_MAX_JOBS) return -1;
+    if (njobs == 0) return 0;
+    CopyMulti m;
+    long long most = 0;
+    for (int j = 0; j < njobs; ++j) {
+        if (bytes[j] < 0 || (bytes[j] & 3) != 0 || ((reinterpret_cast<uintptr_t>(src[j]) | reinterpret_cast<uintptr_t>(dst[j])) & 3) != 0) return -1;
+        m.src[j] = reinterpret_cast<const unsigned *>(src[j]);
+        m.dst[j] = reinterpret_cast<unsigned *>(dst[j]);
+        m.words[j] = bytes[j] >> 2;
+        most = m.words[j] > most ? m.words[j] : most;
+    }
+    if (most == 0) return 0;
+    long long blocks = (most / 4 + 255) / 256;
+    blocks = blocks < 1 ? 1 : (blocks > 256 ? 256 : blocks);
+    CAPTRA_LAUNCH("copy_multi", copy_multi_kernel, dim3((unsigned)blocks, njobs), dim3(256), 0, (hipStream_t)stream, m);
     return captra_last_error();
 }

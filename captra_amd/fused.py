@@ -88,6 +88,31 @@ def group_points_multi(points_list, idx_list, outs=None):
     return outs
 
 
+def seg_softmax_argmax(logits):
+    """logits (B,S,N) -> (softmax over S (B,S,N), labels (B,N) int32 = first index of the largest logit): CoordinateNet's
+    read-out (networks.py:50 + model.py:466) in one launch."""
+    L.require_device(logits)
+    B, S, N = logits.shape
+    seg = torch.empty_like(logits)
+    labels = torch.empty(B, N, dtype=torch.int32, device=logits.device)
+    with torch.cuda.device(logits.device):
+        L.call("captra_seg_softmax_argmax", B, S, N, L.ptr(logits), L.ptr(seg), L.ptr(labels))
+    return seg, labels
+
+
+def copy_multi(pairs) -> None:
+    """[(src, dst)] device tensors of equal byte size (contiguous, 4-byte words), at most 16: all copies in ONE launch."""
+    n = len(pairs)
+    if n == 0:
+        return
+    for a, b in pairs:
+        assert a.is_contiguous() and b.is_contiguous() and a.numel() * a.element_size() == b.numel() * b.element_size(), (a.shape, b.shape)
+    arr = lambda ctype, vals: C.cast((ctype * n)(*vals), C.c_void_p)      # noqa: E731
+    with torch.cuda.device(pairs[0][0].device):
+        L.call("captra_copy_multi", n, arr(C.c_void_p, [a.data_ptr() for a, _ in pairs]), arr(C.c_void_p, [b.data_ptr() for _, b in pairs]),
+               arr(C.c_longlong, [a.numel() * a.element_size() for a, _ in pairs]))
+
+
 def pack(wt_dense, bias_dense) -> PackedLinear:
     """Dense W^T (cin,cout) + bias (cout) -> the packed layout the kernels take."""
     return PackedLinear(wt_dense.float(), bias_dense.float())

@@ -231,6 +231,7 @@ class TrackLanes:
         """Enqueue one frame on every lane; returns the ring slot its poses will be in.  The frame's inputs must already be
         resident; if the caller's stream is still producing them pass sync_inputs=True (the lanes then wait for that
         stream, which joins them whenever it also carries the previous frame's gather)."""
+        from . import fused
         self._mark_consumed()
         slot = self.frame % len(self.ring)
         self.frame += 1
@@ -242,12 +243,11 @@ class TrackLanes:
                 st.wait_event(self.consumed[slot])
             with torch.cuda.stream(st):
                 out = g.replay(points[s], points_mean[s], g.pose, None if labels is None else labels[s])
-                for k in out:
-                    self.ring[slot][k][s].copy_(out[k])
-                    g.pose[k].copy_(out[k])    # hand-over inside the lane
+                # the frame's record and the hand-over inside the lane (and CoordinateNet's maps): ONE launch, not ten copies
+                pairs = [(out[k], self.ring[slot][k][s]) for k in out] + [(out[k], g.pose[k]) for k in out]
                 if self.npcs_ring is not None:
-                    for k, dst in self.npcs_ring[slot].items():
-                        dst[s].copy_(g.npcs_pred[k])
+                    pairs += [(g.npcs_pred[k], dst[s]) for k, dst in self.npcs_ring[slot].items()]
+                fused.copy_multi(pairs)
                 self.written[slot][l].record(st)
         return slot
 

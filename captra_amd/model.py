@@ -171,7 +171,9 @@ class EvalTrackModel(BaseModel):
     # ---- the step in four phases (what `_track_step` composes; captra_amd.graph.TrackStepGraph(split=True) captures each as a
     # hipGraph of its own and replays [prep] -> [rot || coord] -> [post] on two EXPLICIT streams) ---------------------------
     def _step_begin(self, input, npcs_input, last_pose):
-        npcs_input["canon_pose"] = {k: last_pose[k][:, self.root].clone() for k in ("rotation", "translation", "scale")}
+        # (a view when it is contiguous -- one part: the clones are three copy kernels per step and nothing writes into them)
+        npcs_input["canon_pose"] = {k: (v if v.is_contiguous() else v.clone()) for k, v in
+                                    ((k, last_pose[k][:, self.root]) for k in ("rotation", "translation", "scale"))}
         npcs_input["init_part"] = last_pose
         for k in ("_canon", "_geom"):
             npcs_input.pop(k, None)
@@ -206,7 +208,13 @@ class EvalTrackModel(BaseModel):
     def _step_post(self, input, npcs_input, npcs_pred, last_pose):
         pred_npcs = npcs_pred["nocs"].reshape(len(npcs_pred["nocs"]), self.num_parts, 3, -1)
         input["state"] = {"part": last_pose}
-        input["pred_labels"] = torch.argmax(npcs_pred["seg"], dim=-2)
+        lab32 = npcs_pred.pop("labels_i32", None)        # CoordinateNet's fused read-out: int32 labels next to the softmax
+        if lab32 is not None and not (self.track_cfg["gt_label"] or self.track_cfg["nocs2d_label"]):
+            input["pred_labels_i32"] = lab32             # what the one-launch rotation read-out and pose fit take
+            input["pred_labels"] = lab32 if self._overlap_nets(input) else lab32.long()
+        else:
+            input.pop("pred_labels_i32", None)
+            input["pred_labels"] = torch.argmax(npcs_pred["seg"], dim=-2)
         input["pred_nocs"] = pred_npcs
         input["pred_label_conf"] = npcs_pred["seg"][:, 0]
         if self.track_cfg["gt_label"] or self.track_cfg["nocs2d_label"]:

@@ -17,7 +17,7 @@ from .backbones import PointNet2Msg
 from .blocks import RotationRegressor, get_point_mlp, run_point_mlp
 from .fold import fold_conv_bn
 from .pose_utils.part_dof_utils import convert_pred_rtvec_to_matrix, merge_reenact_canon_part_pose
-from .pose_utils.pose_fit import part_fit_st_cn
+from .pose_utils.pose_fit import part_fit_st_cn, part_fit_st_track
 from .pose_utils.procrustes import (rot_around_yaxis_to_3d, scale_pts_mask, transform_pts_2d_mask,
                                     translate_pts_mask)
 
@@ -111,7 +111,11 @@ class CoordNet(nn.Module):
         else:
             seg_logits, nocs = self._heads(out)
             nocs_m05 = nocs - 0.5
-        pred = {"seg": F.softmax(seg_logits, dim=1), "nocs": nocs_m05, "points": cam_cn}
+        if (not self.training) and seg_logits.is_cuda and seg_logits.dim() == 3 and seg_logits.shape[1] <= 8:
+            seg, labels_i32 = fused.seg_softmax_argmax(seg_logits.contiguous())      # softmax + arg max + int32 labels: one launch
+            pred = {"seg": seg, "nocs": nocs_m05, "points": cam_cn, "labels_i32": labels_i32}
+        else:
+            pred = {"seg": F.softmax(seg_logits, dim=1), "nocs": nocs_m05, "points": cam_cn}
         if "gt_part" in input:
             pred["part"] = self._fit_with_gt_rotation(input, pred, test)
         return pred
@@ -232,14 +236,15 @@ class PartCanonNet(nn.Module):
             raw = input.get("_raw")                                                       # computed ahead on a side stream?
             if raw is None:
                 raw = self.regress_net.raw_point_rtvec(cam_cn, cam_n3=cam_n3, geom=geom)   # (B*P,R,N), head p on cloud (b,p)
-            labels_i32 = input["pred_labels"].int().contiguous()
+            labels_i32 = input.get("pred_labels_i32")
+            if labels_i32 is None:
+                labels_i32 = input["pred_labels"].int().contiguous()
             rotation = fused.rot_pool_compose(raw, labels_i32, part_pose["rotation"].float().contiguous(), self.sym)
             npcs = input["pred_nocs"].reshape(B, P, 3, -1).float().contiguous()
-            cam_points = (input["points"] + input["points_mean"]).float().contiguous()        # (B,3,N)
-            scale, trans, valid = part_fit_st_cn(labels_i32, npcs, cam_points, rotation, self.sym)
-            return {"part": {"rotation": rotation,
-                             "scale": torch.where(valid, scale, part_pose["scale"]),
-                             "translation": torch.where(valid[..., None, None], trans, part_pose["translation"])}}
+            # camera points = points + mean and "an invalid fit keeps the previous scale / translation" inside the launch
+            scale, trans, _ = part_fit_st_track(labels_i32, npcs, input["points"].float().contiguous(), input["points_mean"], rotation,
+                                                part_pose["scale"], part_pose["translation"], self.sym)
+            return {"part": {"rotation": rotation, "scale": scale, "translation": trans}}
         seg_rep = cam_seg.unsqueeze(1).expand(-1, P, -1).reshape(B * P, -1)
         pred = self.regress_net(cam_cn, seg_rep, cam_n3=cam_n3, geom=geom)
 

@@ -34,6 +34,24 @@ def part_fit_st_cn(labels_i32, src_cn, tgt_cn, rotation, sym: bool, given_scale=
     return scale, trans.unsqueeze(-1), valid.bool()
 
 
+def part_fit_st_track(labels_i32, src_cn, pts_cn, pts_mean, rotation, prev_scale, prev_trans, sym: bool):
+    """The track loop's fit in one launch (networks.py:219-232): target = pts (B,3,N) + pts_mean (B,3,1) formed inside the
+    kernel, invalid fits keep prev_scale (B,P) / prev_trans (B,P,3,1) -> scale (B,P), translation (B,P,3,1), valid (B,P) bool."""
+    B, P, _, N = src_cn.shape
+    dev = src_cn.device
+    pts_mean = pts_mean.reshape(B, 3).float().contiguous()
+    prev_scale = prev_scale.float().contiguous()
+    prev_trans = prev_trans.reshape(B, P, 3).float().contiguous()
+    L.require_device(labels_i32, src_cn, pts_cn, pts_mean, rotation, prev_scale, prev_trans)
+    scale = torch.empty(B, P, dtype=torch.float32, device=dev)
+    trans = torch.empty(B, P, 3, dtype=torch.float32, device=dev)
+    valid = torch.empty(B, P, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        L.call("captra_part_fit_st_track", B, P, N, 1 if sym else 0, L.ptr(labels_i32), L.ptr(src_cn), L.ptr(pts_cn), L.ptr(pts_mean),
+               L.ptr(rotation), L.ptr(prev_scale), L.ptr(prev_trans), L.ptr(scale), L.ptr(trans), L.ptr(valid))
+    return scale, trans.unsqueeze(-1), valid.bool()
+
+
 def part_fit_st_no_ransac(labels, source, target, rotation, cfg, given_scale=None):
     """labels (B,N); source, target (B,P,N,3); rotation (B,P,3,3); cfg {'num_parts','sym'}
     -> ({'rotation','scale' (B,P),'translation' (B,P,3,1)}, valid (B,P) bool)."""

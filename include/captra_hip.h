@@ -350,6 +350,21 @@ int captra_part_fit_st(int b, int p, int n, int sym, const int *labels, const fl
                        const float *tgt, int tgt_per_part, const float *rot, const float *given_scale,
                        float *scale, float *trans, int *valid, captra_stream_t stream);
 
+/* The track loop's form (networks.py:219-232 in one launch): target = pts (B,3,N) + pts_mean (B,3), formed in the kernel with the
+ * same single fp32 addition as the reference's `points + points_mean`; a part whose fit is invalid keeps prev_scale (B,P) /
+ * prev_trans (B,P,3) (NULL: the raw fit is written, as captra_part_fit_st does). */
+int captra_part_fit_st_track(int b, int p, int n, int sym, const int *labels, const float *src, const float *pts,
+                             const float *pts_mean, const float *rot, const float *prev_scale, const float *prev_trans,
+                             float *scale, float *trans, int *valid, captra_stream_t stream);
+
+/* CoordinateNet read-out (networks.py:50 F.softmax(dim=1) + model.py:466 torch.max(seg, dim=-2)[1]) in one launch: logits (B,S,N),
+ * S <= 8 -> seg (B,S,N) softmax (or NULL), labels (B,N) i32 = FIRST index of the largest logit (or NULL). */
+int captra_seg_softmax_argmax(int b, int s, int n, const float *logits, float *seg, int *labels, captra_stream_t stream);
+
+/* njobs <= 16 device-to-device copies (bytes[j] % 4 == 0, 4-byte aligned) in one launch: host arrays of DEVICE pointers.  The
+ * lanes' per-frame pose / record hand-over. */
+int captra_copy_multi(int njobs, const void *const *src, void *const *dst, const long long *bytes, captra_stream_t stream);
+
 /* Rotation read-out of one tracking step (blocks.py:147-156, networks.py:127-138 and 200-203,
  * part_dof_utils.py:124-141, rotations.py:302-387) in one launch.  raw = the rotation heads' raw outputs on the B*P
  * canonicalised clouds (R = 3 symmetric: y-axis; R = 6: ortho6d): (B*P, P, R, N) with all P heads per cloud as the

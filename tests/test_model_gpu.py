@@ -1167,3 +1167,38 @@ def test_transform_pts_batch_free_rotation_vs_reference(device):
     np.testing.assert_allclose(r.cpu().numpy(), g["tpb_free_rot"], atol=2e-5)
     np.testing.assert_allclose(s.cpu().numpy(), g["tpb_free_scale"], atol=2e-5)
     np.testing.assert_allclose(t.cpu().numpy(), g["tpb_free_trans"], atol=2e-5)
+
+
+def test_seg_readout_and_track_fit_one_launch_forms(device):
+    """The step's folded read-outs against the torch ops they replace: captra_seg_softmax_argmax == F.softmax + first-index arg
+    max (ties included); captra_part_fit_st_track == captra_part_fit_st on points + mean with torch.where fallbacks, bit for
+    bit (same additions, same reductions), with an empty and a 3-point part in the batch; captra_copy_multi copies."""
+    from captra_amd import fused
+    from captra_amd.pose_utils.pose_fit import part_fit_st_cn, part_fit_st_track
+    g = torch.Generator().manual_seed(4)
+    logits = torch.randn(3, 4, 1000, generator=g)
+    logits[0, 1, :50] = logits[0, 3, :50] = 7.0                      # exact ties at the maximum: the FIRST index wins
+    seg, lab = fused.seg_softmax_argmax(logits.to(device))
+    np.testing.assert_allclose(seg.cpu().numpy(), torch.softmax(logits, 1).numpy(), atol=1e-6, rtol=0)
+    np.testing.assert_array_equal(lab.cpu().numpy(), torch.argmax(logits, 1).numpy().astype(np.int32))
+    assert (lab[0, :50] == 1).all()
+    B, P, N = 4, 2, 2048
+    labels = torch.randint(0, P + 1, (B, N), generator=g).int()
+    labels[1] = torch.where(labels[1] == 1, torch.full_like(labels[1], 2), labels[1])      # trajectory 1: part 1 is empty
+    labels[2, 3:] = torch.where(labels[2, 3:] == 0, torch.full_like(labels[2, 3:], 2), labels[2, 3:])
+    labels[2, :3] = 0                                                                         # trajectory 2: part 0 has 3 points
+    src = torch.randn(B, P, 3, N, generator=g)
+    pts, mean = torch.randn(B, 3, N, generator=g) * 0.2, torch.randn(B, 3, 1, generator=g)
+    rot = torch.linalg.qr(torch.randn(B, P, 3, 3, generator=g))[0]
+    prev_s, prev_t = torch.rand(B, P, generator=g) + 0.5, torch.randn(B, P, 3, 1, generator=g)
+    d = lambda t: t.to(device).contiguous()      # noqa: E731
+    for sym in (True, False):
+        s0, t0, v0 = part_fit_st_cn(d(labels), d(src), d(pts + mean), d(rot), sym)
+        exp_s, exp_t = torch.where(v0, s0, d(prev_s)), torch.where(v0[..., None, None], t0, d(prev_t))
+        s1, t1, v1 = part_fit_st_track(d(labels), d(src), d(pts), d(mean), d(rot), d(prev_s), d(prev_t), sym)
+        assert torch.equal(v0, v1) and not bool(v1[1, 1]) and not bool(v1[2, 0]) and bool(v1[0].all())
+        assert torch.equal(s1, exp_s) and torch.equal(t1, exp_t)
+    a = [torch.randn(n, generator=g).to(device) for n in (9, 36, 4096, 5)]
+    b = [torch.zeros_like(x) for x in a]
+    fused.copy_multi(list(zip(a, b)))
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
