@@ -223,6 +223,147 @@ __global__ __launch_bounds__(256, 2) void pw_bf16pm_kernel(DbParams p) {
     }
 }
 
+// ---- the wide GroupNorm-consuming layers: one transform per operand element ------------------------------------------------
+// pw_bf16pm_kernel<.., AFF> applies relu(a x + b) to its B fragments in every wave, i.e. once per 128-row block: for the
+// 512-wide layers every input element is unpacked, scaled, rounded and re-packed FOUR times (28 VALU instructions per fragment
+// beside 8 MFMAs: the kernel ran at 0.22 of the matrix pipe, 64 % of its wave cycles issue stalls).  Here the four waves of a
+// workgroup own the four row blocks of the SAME 64 positions and share the operand: per super-step of four k-steps each wave
+// loads and transforms two of the eight B fragments, parks them in LDS (double-buffered, one barrier per super-step), and all
+// four read the eight fragments back with conflict-free ds_read_b128 -- 2.8 instructions per MFMA instead of 10.
+// A operands: fragment image, three k-steps in flight, as in pw_bf16pm_kernel.
+template <int TM, bool OUT_PM>
+__global__ __launch_bounds__(256, 2) void pw_bf16pm_affs_kernel(DbParams p) {
+    constexpr int TN = 2, SS = 4;                          // position tiles per wave, k-steps per super-step
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    float *aff_tab = reinterpret_cast<float *>(lds);       // [kst][2 halves][16]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, col = lane & 31;
+    const int b = blockIdx.z;
+    const int t0 = (blockIdx.y * 4 + wave) * TM;           // this wave's first row tile
+    const long long pos0 = (long long)blockIdx.x * TN * 32;
+    const int kst = p.kst;
+    const int nss = (kst + SS - 1) / SS;
+    unsigned char *bbuf = lds + (size_t)((kst * 32 * 4 + 1023) / 1024) * 1024;     // 2 x SS*TN KiB of transformed B fragments
+    {
+        const float *abp = p.ab + (size_t)b * p.cin * 2;
+        for (int e = tid; e < kst * 32; e += 256) {
+            const int kk = e >> 5, hh = (e >> 4) & 1, i = e & 15;
+            const int c = 16 * kk + db_perm(8 * hh + (i & 7));
+            aff_tab[e] = c < p.cin ? abp[2 * c + (i >> 3)] : 0.f;
+        }
+    }
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc((void *)p.wimg, 0, p.nt * kst * 1024, 0x00020000);
+    const __bf16 *xb = reinterpret_cast<const __bf16 *>(p.x) + (size_t)b * p.L * p.cp_in;
+    const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc((void *)xb, 0, (int)(p.L * p.cp_in * 2), 0x00020000);
+    // the two fragments this wave prepares per super-step: position tile wave & 1, k-steps 2 (wave >> 1) + {0, 1}
+    const int my_tn = wave & 1, my_k0 = 2 * (wave >> 1);
+    long long mc = pos0 + my_tn * 32 + col;
+    if (mc >= p.L) mc = p.L - 1;                           // clamped column: computed, never stored
+    const int xvoff = (int)((mc * p.cp_in + 8 * h) * 2);
+    int woff[TM];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) woff[tm] = (t0 + tm < p.nt ? t0 + tm : p.nt - 1) * kst * 1024;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+        const float *bp = p.bias + (t0 + tm < p.nt ? t0 + tm : p.nt - 1) * 32 + 4 * h;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float bv = bp[(r & 3) + 8 * (r >> 2)];
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) acc[tm][tn][r] = bv;
+        }
+    }
+    constexpr int NS = SS;                                 // A register sets: k-step kk lives in set kk % SS, loaded three k-steps ahead
+    u32x4 A[NS][TM];
+    auto loadA = [&](int s, int kk) {
+        kk = kk < kst ? kk : kst - 1;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) A[s][tm] = __builtin_amdgcn_raw_buffer_load_b128(wsrc, lane * 16, woff[tm] + kk * 1024, 0);
+    };
+    u32x4 raw0, raw1;                                      // this wave's two untransformed fragments of the NEXT super-step
+    auto loadB = [&](int ss) {
+        int k0 = ss * SS + my_k0, k1 = k0 + 1;             // (ss may run past the last super-step: clamped, loaded, never used)
+        k0 = k0 < kst ? k0 : kst - 1;                      // beyond the last k-step: loaded and parked, never multiplied
+        k1 = k1 < kst ? k1 : kst - 1;
+        raw0 = __builtin_amdgcn_raw_buffer_load_b128(xsrc, xvoff, k0 * 32, 0);
+        raw1 = __builtin_amdgcn_raw_buffer_load_b128(xsrc, xvoff, k1 * 32, 0);
+    };
+    // park this wave's two fragments of super-step `ss_` (transformed from raw0 / raw1) in buffer ss_ & 1
+    auto park = [&](int ss_) {
+        const int k0 = ss_ * SS + my_k0;
+        unsigned char *dst = bbuf + (size_t)(ss_ & 1) * (SS * TN * 1024);
+        const u32x4 f0 = db_affine(raw0, aff_tab + ((k0 < kst ? k0 : kst - 1) * 2 + h) * 16);
+        const u32x4 f1 = db_affine(raw1, aff_tab + ((k0 + 1 < kst ? k0 + 1 : kst - 1) * 2 + h) * 16);
+        *reinterpret_cast<u32x4 *>(dst + ((my_k0 + 0) * TN + my_tn) * 1024 + lane * 16) = f0;
+        *reinterpret_cast<u32x4 *>(dst + ((my_k0 + 1) * TN + my_tn) * 1024 + lane * 16) = f1;
+    };
+    loadB(0);
+    loadA(0, 0);
+    loadA(1, 1);
+    loadA(2, 2);
+    park(0);
+    loadB(1);                                              // (clamped k-steps: always issued, so the load counts stay static)
+    __syncthreads();
+    for (int ss = 0; ss < nss; ++ss) {
+        // four k-steps on the shared fragments of buffer ss & 1; between the second and the third this wave transforms and
+        // parks its two fragments of the NEXT super-step (the VALU work issues while the MFMAs of k-steps 0-1 execute) and
+        // fetches the ones after; one barrier per super-step
+        const unsigned char *src = bbuf + (size_t)(ss & 1) * (SS * TN * 1024);
+#pragma unroll
+        for (int ks = 0; ks < SS; ++ks) {
+            const int kk = ss * SS + ks;
+            loadA((ks + 3) % NS, kk + 3);                  // three k-steps (24 MFMAs, ~770 cycles) ahead: an L2 hit under load
+            if (kk < kst) {
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    const u32x4 bb = *reinterpret_cast<const u32x4 *>(src + (ks * TN + tn) * 1024 + lane * 16);
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm) acc[tm][tn] = db_mfma(A[ks % NS][tm], bb, acc[tm][tn]);
+                }
+            }
+            if (ks == 1) {
+                park(ss + 1);
+                loadB(ss + 2);
+            }
+        }
+        __syncthreads();
+    }
+    // ---- epilogue (as pw_bf16pm_kernel) -------------------------------------------------------------------------
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+        if (t0 + tm >= p.nt) continue;
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const long long c = pos0 + tn * 32 + col;
+            if (c >= p.L) continue;
+            if constexpr (OUT_PM) {
+                __bf16 *yp = reinterpret_cast<__bf16 *>(p.y) + ((size_t)b * p.L + c) * p.cp_out + 32 * (t0 + tm) + 8 * h;
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    u32x4 v;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        v[i] = db_pack(acc[tm][tn][8 * jj + 2 * i], acc[tm][tn][8 * jj + 2 * i + 1]);
+                        if (p.act == ACT_RELU) v[i] = db_relu2(v[i]);
+                    }
+                    *reinterpret_cast<u32x4 *>(yp + 16 * jj) = v;
+                }
+            } else {
+                const int row0 = 32 * (t0 + tm) + 4 * h;
+                float *yp = reinterpret_cast<float *>(p.y) + ((size_t)b * p.cout + row0) * p.L + c;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ro = (r & 3) + 8 * (r >> 2);
+                    if (row0 + ro < p.cout) yp[(size_t)ro * p.L] = apply_act(acc[tm][tn][r], p.act);
+                }
+            }
+        }
+    }
+}
+
 // ---- GroupNorm partial statistics of a stored point-major tensor --------------------------------------------------------------
 // x (B,L,CP) bf16 slot order -> stats (B,C,T,2) fp32: per channel and chunk of `pch` positions (sum, sum of squares) of the
 // STORED values; captra_gn_finalize turns them into the (a, b) the consumer applies.  Block = (chunk, cloud); thread = one
@@ -272,6 +413,14 @@ __global__ __launch_bounds__(256) void gn_stats_bf16pm_kernel(int c, int cp, lon
     }
 }
 
+template <int TM, bool OUT_PM>
+int db_launch_affs(int b, const DbParams &p, hipStream_t s) {
+    dim3 grid((unsigned)((p.L + 63) / 64), (p.nt + 4 * TM - 1) / (4 * TM), b);
+    const int lds = (p.kst * 32 * 4 + 1023) / 1024 * 1024 + 2 * 4 * 2 * 1024;
+    CAPTRA_LAUNCH("pointwise_mlp", (pw_bf16pm_affs_kernel<TM, OUT_PM>), grid, dim3(256), lds, s, p);
+    return captra_last_error();
+}
+
 template <int TM, int TN, bool IN_PM, bool AFF, bool OUT_PM>
 int db_launch(int b, const DbParams &p, hipStream_t s) {
     dim3 grid((unsigned)((p.L + 4 * TN * 32 - 1) / (4 * TN * 32)), (p.nt + TM - 1) / TM, b);
@@ -281,6 +430,9 @@ int db_launch(int b, const DbParams &p, hipStream_t s) {
 }
 
 }  // namespace
+
+static CAPTRA_KNOB int g_db_affs = 1;      // experiment knob: 0 = every wave transforms its own operand (pw_bf16pm_kernel<.., AFF>)
+extern "C" void captra_dense_bf16_set_shared_affine(int on) { g_db_affs = on; }
 
 extern "C" long long captra_dense_bf16_image_bytes(int cin, int cout) {
     if (cin < 1 || cout < 1) return -1;
@@ -313,6 +465,11 @@ extern "C" int captra_pointwise_mlp_bf16pm(int b, int cin, int cout, long long l
     p.x = x; p.wimg = wimg; p.bias = bias_packed; p.ab = ab; p.y = y; p.act = act;
     if (ab != nullptr && p.kst * 32 * 4 > 64 * 1024) return -2;
     hipStream_t s = (hipStream_t)stream;
+    if (in_pm && ab != nullptr && p.nt >= 8 && g_db_affs) {
+        // wide GroupNorm-consuming layers: the operand transformed once per workgroup and shared through LDS
+        if (p.nt >= 16) return out_pm ? db_launch_affs<4, true>(b, p, s) : db_launch_affs<4, false>(b, p, s);
+        return out_pm ? db_launch_affs<2, true>(b, p, s) : db_launch_affs<2, false>(b, p, s);
+    }
     const bool wide = p.nt >= 4;
 #define DB_GO(TM_, TN_)                                                                              \
     do {                                                                                             \
