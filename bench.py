@@ -402,16 +402,18 @@ def hbm_ops_roofline(batch: int, device, reps: int = 5):
     return out
 
 
-def pmc_traffic(kernel_prefixes):
+def pmc_traffic(kernel_prefixes, suffix: str = ""):
     """HBM bytes per launch of the MFMA family from the newest committed PMC summary (profiles/*_bench_pmc.json,
     written by tools/profile_round.sh from separate rocprofv3 --pmc passes): 2 x FETCH_SIZE (gfx950 correction,
     MI355X_MICROARCH.md) + WRITE_SIZE, KiB -> bytes, averaged over the family's launches.  The file carries the fingerprint
     of the kernel sources it was profiled on (`csrc_sha16`, tools/pmc_summary.py); a file taken on other sources is NOT
     used: -> (None, name, reason)."""
     import glob
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_bench_pmc.json")))
+    # suffix: the counter file of another configuration of the same command (tools/profile_round.sh <tag> _bf16 --mlp-dtype bf16
+    # writes profiles/<tag>_bench_bf16_pmc.json)
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"*_bench{suffix}_pmc.json")))
     if not files:
-        return None, None, "no profiles/*_bench_pmc.json"
+        return None, None, f"no profiles/*_bench{suffix}_pmc.json"
     with open(files[-1]) as fh:
         data = json.load(fh)
     name = os.path.basename(files[-1])
@@ -754,12 +756,12 @@ def main():
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                                "frac": round(ach / peak, 4), "traffic": None,
                                "kernel": ("fp32 MFMA shared-MLP kernels: sa_wave_kernel / sa_wave_lds_kernel (dominant) + mlp_chain3_kernel + coord_tail_kernel + pw_direct_kernel + pw_direct_max_kernel"
-                                          if args.mlp_dtype == "fp32" else "bf16 MFMA 32x32x16 shared-MLP kernels: sa_wave_bf16_kernel + pw_bf16_kernel"),
+                                          if args.mlp_dtype == "fp32" else "bf16 MFMA 32x32x16 shared-MLP kernels: sa_bf16_kernel (SA scales, dominant) + pw_bf16pm_kernel / pw_bf16pm_affs_kernel (dense layers, bf16 point-major activations) + pw_bf16_kernel"),
                                "avg_launch_us": round(1e3 * mlp_ms / max(mlp_launches, 1), 2),
                                "flops_per_launch": round(mlp_flops / max(mlp_launches, 1)),
                                "share_of_kernel_time": round(mlp_ms / max(total_ms, 1e-9), 3), "dominant_family": dominant}
-            traffic, src, why = (None, None, "fp32 counter files only") if args.mlp_dtype != "fp32" else pmc_traffic(
-                ["sa_wave_kernel", "sa_wave_lds_kernel", "sa_fused_kernel", "mlp_chain3_kernel", "coord_tail_kernel", "pw_direct_kernel", "pw_direct_max_kernel", "pw_mlp_kernel"])
+            traffic, src, why = pmc_traffic(["sa_bf16_kernel", "pw_bf16pm_kernel", "pw_bf16pm_affs_kernel", "pw_bf16_kernel"], "_bf16") if args.mlp_dtype != "fp32" else pmc_traffic(
+                ["sa_wave_kernel", "sa_wave_lds_kernel", "sa_wave_pipe_kernel", "sa_fused_kernel", "mlp_chain3_kernel", "coord_tail_kernel", "pw_direct_kernel", "pw_direct_max_kernel", "pw_mlp_kernel"])
             if traffic is not None:
                 out["roofline"]["traffic"] = round(traffic)
                 out["roofline"]["traffic_source"] = (f"profiles/{src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch; "
@@ -771,7 +773,7 @@ def main():
             bq = fams["ball_query"]
             nbytes = fused.WORK["bytes"].get("ball_query", 0.0)
             gbs = nbytes / (bq["ms_total"] * 1e-3) / 1e9
-            bq_traffic, bq_src, bq_why = (None, None, "fp32 counter files only") if args.mlp_dtype != "fp32" else pmc_traffic(("ball_query_kernel",))
+            bq_traffic, bq_src, bq_why = pmc_traffic(("ball_query_kernel",), "_bf16" if args.mlp_dtype != "fp32" else "")
             out["roofline_ball_query"] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                           "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None if bq_traffic is None else round(bq_traffic),
                                           "traffic_source": bq_src if bq_traffic is not None else f"null: {bq_why}",
