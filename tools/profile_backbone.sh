@@ -19,4 +19,6 @@ rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_AC
     --kernel-trace --output-format csv -d $OUT/${TAG}_bb_sq -o p -- $CMD_EAGER > $OUT/${TAG}_bb_sq.log 2>&1
 cd $ROOT
 python tools/pmc_summary.py $OUT/${TAG}_bb_fetch $OUT/${TAG}_bb_write $OUT/${TAG}_bb_sq --json $OUT/${TAG}_backbone16k_pmc.json > $OUT/${TAG}_backbone16k_pmc_summary.txt 2>&1
+# the raw rocprofv3 output (rocpd databases, counter CSVs) is tens of MiB per pass: dropped unless KEEP_RAW=1 (gpurun merges <= 64 MiB back)
+[ "${KEEP_RAW:-0}" = 1 ] || rm -rf $OUT/${TAG}_bb_trace $OUT/${TAG}_bb_trace_overlap $OUT/${TAG}_bb_fetch $OUT/${TAG}_bb_write $OUT/${TAG}_bb_sq
 echo done

@@ -34,4 +34,6 @@ rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_AC
     --kernel-trace --output-format csv -d $OUT/${TAG}${SUF}_sq -o p -- $BENCH_EAGER > $OUT/${TAG}${SUF}_sq.log 2>&1
 cd $ROOT
 python tools/pmc_summary.py $OUT/${TAG}${SUF}_fetch $OUT/${TAG}${SUF}_write $OUT/${TAG}${SUF}_sq --json $OUT/${TAG}_bench${SUF}_pmc.json > $OUT/${TAG}_bench${SUF}_pmc_summary.txt 2>&1
+# the raw rocprofv3 output (rocpd databases, counter CSVs) is tens of MiB per pass: dropped unless KEEP_RAW=1 (gpurun merges <= 64 MiB back)
+[ "${KEEP_RAW:-0}" = 1 ] || rm -rf $OUT/${TAG}${SUF}_trace $OUT/${TAG}${SUF}_trace_overlap $OUT/${TAG}${SUF}_fetch $OUT/${TAG}${SUF}_write $OUT/${TAG}${SUF}_sq
 echo done
