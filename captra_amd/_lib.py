@@ -52,6 +52,7 @@ _SIGNATURES = {
     "captra_pack_dense_bf16": [_INT, _INT, _INT, _P, _P, _P],
     "captra_pointwise_mlp_bf16pm": [_INT, _INT, _INT, _LL, _INT, _P, _P, _P, _P, _INT, _INT, _P, _P],
     "captra_gn_stats_bf16pm": [_INT, _INT, _LL, _P, _P, _P],
+    "captra_mlp_chain_bf16": [_INT, _INT, _LL, _INT, _INT, _INT, _P, _P, _P, _P, _P, _P],
     "captra_pack_sa_bf16": [_INT] * 5 + [_P] * 7 + [_P],
     "captra_sa_scale_bf16": [_INT] * 9 + [_P] * 6 + [_INT, _INT, _P],
     "captra_coord_tail": [_INT, _INT, _INT, _INT, _LL, _P, _P, _P, _INT, _P, _P, _P],
@@ -117,6 +118,9 @@ def lib():
             l.captra_dense_bf16_image_bytes.restype = _LL
             l.captra_gn_stats_bf16pm_tiles.argtypes = [_LL]
             l.captra_gn_stats_bf16pm_tiles.restype = _INT
+        if hasattr(l, "captra_chain_bf16_image_bytes"):
+            l.captra_chain_bf16_image_bytes.argtypes = [_INT, _INT]
+            l.captra_chain_bf16_image_bytes.restype = _LL
         if hasattr(l, "captra_sa_bf16_image_bytes"):
             l.captra_sa_bf16_image_bytes.argtypes = [_INT] * 4
             l.captra_sa_bf16_image_bytes.restype = _LL

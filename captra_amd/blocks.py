@@ -142,10 +142,14 @@ def _run_gn_chain_bf16(mods, x, cache):
             i += 1
         else:
             return None
+    pm_in = isinstance(x, fused.PMTensor)
+    if pm_in:
+        x, n, in_pm = x.data, x.data.shape[1], True
+    else:
+        n, in_pm = x.shape[2], False
     if len(layers) < 2 or not fused.gn_chain_bf16_supported(x, [c.out_channels for c, g in layers if g is not None]):
         return None
-    n = x.shape[2]
-    ab, in_pm = None, False
+    ab = None
     for conv, gn in layers:
         if id(conv) not in cache:
             cache[id(conv)] = fold_conv_bn(conv, None, x.device)
@@ -192,6 +196,10 @@ class MLPConv1d(nn.Module):
         return super()._apply(fn, *a, **k)
 
     def forward(self, input):
+        if isinstance(input, fused.PMTensor):                # bf16 mode: the producer handed its output over point-major
+            y = _run_gn_chain_bf16(list(self.model), input, self._cache)
+            assert y is not None, "a point-major input needs the (Conv, GroupNorm, ReLU)*, Conv form"
+            return y
         if (not self.training) and input.is_cuda:
             return run_point_mlp(self.model, input, self._cache)
         return self.model(input)
@@ -221,6 +229,11 @@ class RotationRegressor(nn.Module):
         P = self.num_parts
         if P == 1:
             return self.rtvec_head[0](feat)
+        if isinstance(feat, fused.PMTensor):                 # (Q,N,C) point-major: the clouds of part p, contiguous, per head
+            Q, N, C = feat.data.shape
+            per_part = feat.data.view(Q // P, P, N, C)
+            return torch.stack([self.rtvec_head[p](fused.PMTensor(per_part[:, p].contiguous(), feat.channels)) for p in range(P)],
+                               dim=1).reshape(Q, -1, N)
         Q, C, N = feat.shape
         per_part = feat.view(Q // P, P, C, N)
         return torch.stack([self.rtvec_head[p](per_part[:, p].contiguous()) for p in range(P)], dim=1).reshape(Q, -1, N)

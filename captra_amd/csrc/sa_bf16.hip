@@ -486,3 +486,192 @@ extern "C" int captra_sa_scale_bf16(int b, int n, int m, int k, int cfeat, int c
 #undef SB_CASE
     return -2;
 }
+
+// ======================================================================================================================
+// Dense CHAIN, register-resident: FP1's shared MLP + the backbone's conv1 (pointnet_utils.py:296-298, backbones.py:66-68) and,
+// for CoordinateNet, both heads behind them (networks.py:29-32, 44-46) -- [c0 -> 128 -> 128 -> 128] (+ 128 -> S logits,
+// 128 -> 128 -> 3P NOCS) -- as ONE launch in the bf16 mode: a wave carries 64 consecutive positions through every layer with
+// the zero-swap hand-over of the SA kernels, the layers' fragment images (100-148 KB) sit in LDS for the workgroup's eight
+// waves, the input is read once (fp32 channel-major rows, rounded when it becomes the first operand) and only the last
+// layer(s) are stored: the 128-wide feature map as a bf16 point-major tensor (what the rotation heads' first layer reads), or
+// the segmentation logits / sigmoid(NOCS) - 0.5 as fp32 (B,S,N) / (B,3P,N).  Replaces three to six launches with two to five
+// round trips of (B,128,4096) tensors through HBM.
+// ======================================================================================================================
+namespace {
+
+struct CbParams {
+    int c0, s, no;                 // input channels, segmentation logits (0: no heads), NOCS outputs
+    long long L;
+    const float *x;                // (B,c0,L) fp32
+    const unsigned char *img;      // fragments of every layer back to back, then the biases (32 floats per row tile)
+    void *feat_pm;                 // (B,L,128) bf16 slot order, or null
+    float *seg, *nocs;             // (B,s,L), (B,no,L) fp32 (heads only)
+};
+
+// one 128-wide layer from register-resident activations: RG = 2 row tiles x TN = 2 position tiles per accumulator group
+template <int KST, int NOUT>
+__device__ __forceinline__ void cb_layer(const unsigned char *wl, const float *bias, const u32x4 (&hin)[2][KST], u32x4 (&hout)[2][NOUT], int lane) {
+    const int h = lane >> 5;
+#pragma unroll
+    for (int tg = 0; tg < 4; tg += 2) {
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const float4 *bp = reinterpret_cast<const float4 *>(bias + 32 * (tg + r) + 4 * h);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = bp[2 * q];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) { acc[r][j][4 * q + 0] = v.x; acc[r][j][4 * q + 1] = v.y; acc[r][j][4 * q + 2] = v.z; acc[r][j][4 * q + 3] = v.w; }
+            }
+        }
+#pragma unroll
+        for (int kk = 0; kk < KST; ++kk)
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const u32x4 w = *reinterpret_cast<const u32x4 *>(wl + ((tg + r) * KST + kk) * 1024 + lane * 16);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[r][j] = sb_mfma(w, hin[j][kk], acc[r][j]);
+            }
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) sb_mid_epilogue<NOUT>(acc[r][j], tg + r, hout[j]);
+    }
+}
+
+// a narrow output layer (cout <= 32: one row tile) -> fp32 rows y[(b*cout + row) * L + pos]
+template <int KST>
+__device__ __forceinline__ void cb_out_layer(const unsigned char *wl, const float *bias, const u32x4 (&hin)[2][KST], int cout, int act,
+                                             float *y, long long L, long long pos0, int lane) {
+    const int h = lane >> 5, col = lane & 31;
+    f32x16 acc[2];
+    const float4 *bp = reinterpret_cast<const float4 *>(bias + 4 * h);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 v = bp[2 * q];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { acc[j][4 * q + 0] = v.x; acc[j][4 * q + 1] = v.y; acc[j][4 * q + 2] = v.z; acc[j][4 * q + 3] = v.w; }
+    }
+#pragma unroll
+    for (int kk = 0; kk < KST; ++kk) {
+        const u32x4 w = *reinterpret_cast<const u32x4 *>(wl + kk * 1024 + lane * 16);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[j] = sb_mfma(w, hin[j][kk], acc[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const long long c = pos0 + 32 * j + col;
+        if (c >= L) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (row < cout) y[(size_t)row * L + c] = apply_act(acc[j][r], act);
+        }
+    }
+}
+
+template <int KST0, bool HEADS>
+__global__ __launch_bounds__(512, 2) void chain_bf16_kernel(CbParams p) {
+    constexpr int NF_TRUNK = 4 * KST0 + 32 + 32;                   // fragments of the three 128-wide layers
+    constexpr int NF = NF_TRUNK + (HEADS ? 8 + 32 + 8 : 0);        // + seg (1 tile x 8), hidden (4 x 8), out (1 x 8)
+    constexpr int NBT = 12 + (HEADS ? 6 : 0);                      // bias row tiles
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *bias = reinterpret_cast<float *>(smem + NF * 1024);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, col = lane & 31;
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(p.img);
+        uint4 *dst = reinterpret_cast<uint4 *>(smem);
+        constexpr int N16 = (NF * 1024 + NBT * 32 * 4) / 16;
+        for (int e = tid; e < N16; e += 512) dst[e] = src[e];
+    }
+    __syncthreads();
+    const int b = blockIdx.y;
+    const long long pos0 = ((long long)blockIdx.x * 8 + wave) * 64;
+    if (pos0 >= p.L) return;                                       // (no barrier below)
+    // ---- layer 1's B operands straight from the fp32 rows: k-step kk, lane (col, h) = channels 16kk + 8h + 0..7 of its position
+    const float *xb = p.x + (size_t)b * p.c0 * p.L;
+    const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc((void *)xb, 0, (int)((long long)p.c0 * p.L * 4), 0x00020000);
+    u32x4 x0[2][KST0];
+    const int xrow = (int)(p.L * 4);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        long long c = pos0 + 32 * j + col;
+        if (c >= p.L) c = p.L - 1;                                 // clamped column: computed, never stored
+        const int voff = (int)(((long long)(8 * h) * p.L + c) * 4); // rows >= c0 fall outside the buffer and read as 0
+#pragma unroll
+        for (int kk = 0; kk < KST0; ++kk) {
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xsrc, voff + (kk * 16 + i) * xrow, 0, 0));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) x0[j][kk][i] = sb_pack(v[2 * i], v[2 * i + 1]);
+        }
+    }
+    u32x4 ha[2][8], hb[2][8];
+    cb_layer<KST0, 8>(smem, bias, x0, ha, lane);                                                // FP1 layer 1
+    cb_layer<8, 8>(smem + (4 * KST0) * 1024, bias + 128, ha, hb, lane);                         // FP1 layer 2
+    cb_layer<8, 8>(smem + (4 * KST0 + 32) * 1024, bias + 256, hb, ha, lane);                    // conv1 + bn1 + ReLU
+    if (p.feat_pm != nullptr) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const long long c = pos0 + 32 * j + col;
+            if (c >= p.L) continue;
+            __bf16 *yp = reinterpret_cast<__bf16 *>(p.feat_pm) + ((size_t)b * p.L + c) * 128 + 8 * h;
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) *reinterpret_cast<u32x4 *>(yp + 16 * kk) = ha[j][kk];
+        }
+    }
+    if constexpr (HEADS) {
+        const unsigned char *wh = smem + NF_TRUNK * 1024;
+        cb_out_layer<8>(wh, bias + 384, ha, p.s, ACT_NONE, p.seg + (size_t)b * p.s * p.L, p.L, pos0, lane);            // segmentation logits
+        cb_layer<8, 8>(wh + 8 * 1024, bias + 416, ha, hb, lane);                                                        // NOCS hidden
+        cb_out_layer<8>(wh + 40 * 1024, bias + 544, hb, p.no, ACT_SIGMOID_M05, p.nocs + (size_t)b * p.no * p.L, p.L, pos0, lane);
+    }
+}
+
+template <int KST0, bool HEADS>
+int cb_launch(int b, const CbParams &p, hipStream_t stream) {
+    constexpr int NF = 4 * KST0 + 64 + (HEADS ? 48 : 0), NBT = 12 + (HEADS ? 6 : 0);
+    const int lds = NF * 1024 + NBT * 32 * 4;
+    auto kern = chain_bf16_kernel<KST0, HEADS>;
+    static CaptraDeviceOnce once;
+    if (once.first_use()) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return (int)hipGetLastError();
+        once.done();
+    }
+    CAPTRA_LAUNCH("mlp_chain3", kern, dim3((unsigned)((p.L + 511) / 512), b), dim3(512), lds, stream, p);
+    return captra_last_error();
+}
+
+}  // namespace
+
+extern "C" long long captra_chain_bf16_image_bytes(int c0, int heads) {
+    if (c0 < 1 || c0 > 144) return -1;
+    const long long nf = 4 * ((c0 + 15) / 16) + 64 + (heads ? 48 : 0), nbt = 12 + (heads ? 6 : 0);
+    return nf * 1024 + nbt * 128;
+}
+
+// x (B,c0,L) fp32 -> relu(W3 relu(W2 relu(W1 x + b1) + b2) + b3), three 128-wide layers, in one launch; feat_pm (B,L,128) bf16
+// slot order receives it when non-NULL.  heads != 0: also seg (B,s,L) = Ws feat + bs and nocs (B,no,L) = sigmoid(Wo relu(Wh feat +
+// bh) + bo) - 0.5 (s, no <= 32).  img: the layers' captra_pack_dense_bf16 images back to back (layer 1 with perm = 0, the others
+// with perm = 1; order: the three trunk layers, then seg, hidden, out), followed by each layer's bias as 32 floats per row tile
+// (zero padded) in the same order -- captra_chain_bf16_image_bytes(c0, heads) bytes.  c0 <= 144.
+extern "C" int captra_mlp_chain_bf16(int b, int c0, long long l, int heads, int s, int no, const float *x, const unsigned char *img,
+                                     void *feat_pm, float *seg, float *nocs, captra_stream_t stream) {
+    if (b < 0 || c0 < 1 || l < 0) return -1;
+    if (c0 > 144 || (heads && (s < 1 || s > 32 || no < 1 || no > 32 || seg == nullptr || nocs == nullptr))) return -2;
+    if ((long long)c0 * l * 4 >= (1ll << 31)) return -2;
+    if (b == 0 || l == 0) return 0;
+    CbParams p;
+    p.c0 = c0; p.s = s; p.no = no; p.L = l; p.x = x; p.img = img; p.feat_pm = feat_pm; p.seg = seg; p.nocs = nocs;
+    const int kst0 = (c0 + 15) / 16;
+    hipStream_t st = (hipStream_t)stream;
+#define CB_CASE(K_)                                                                      \
+    if (kst0 == K_) return heads ? cb_launch<K_, true>(b, p, st) : cb_launch<K_, false>(b, p, st);
+    CB_CASE(9) CB_CASE(8)
+#undef CB_CASE
+    return -2;
+}

@@ -222,6 +222,65 @@ def mlp_chain_bf16(x, layers, acts, out_pm: bool = False):
     return y if out_pm else y.view((B, layers[-1].cout) + tuple(x.shape[2:]))
 
 
+class PMTensor:
+    """A bf16 point-major activation tensor handed from one fused module to the next in the bf16 mode: `data` (B,L,ceil32(C))
+    bf16 in slot order (include/captra_hip.h), `channels` = C."""
+    __slots__ = ("data", "channels")
+
+    def __init__(self, data, channels: int):
+        self.data, self.channels = data, channels
+
+
+USE_CHAIN_BF16 = True     # FP1 + conv1 (+ CoordinateNet's heads) register-resident in one launch (captra_mlp_chain_bf16)
+
+
+def chain_bf16_supported(x, layers, heads=None) -> bool:
+    if not (USE_CHAIN_BF16 and mlp_dtype() == "bf16" and len(layers) == 3 and x.dim() == 3 and x.shape[1] <= 144):
+        return False
+    if not all(lin.cout == 128 for lin in layers) or layers[1].cin != 128 or layers[2].cin != 128 or x.shape[1] * x.shape[2] * 4 >= (1 << 31):
+        return False
+    if heads is not None:
+        seg, hid, out = heads
+        return seg.cin == 128 and hid.cin == 128 and hid.cout == 128 and out.cin == 128 and seg.cout <= 32 and out.cout <= 32
+    return True
+
+
+def _chain_bf16_image(layers, heads):
+    """The chain's weight image (fragments of every layer back to back, then 32 bias floats per row tile), built once and cached
+    with the first layer."""
+    alls = list(layers) + (list(heads) if heads is not None else [])
+    key = ("chain_img",) + tuple(id(l) for l in alls)
+    cache = layers[0]._bf16
+    if key not in cache:
+        parts = [lin.bf16_frag(i > 0) for i, lin in enumerate(alls)]
+        biases = [lin.bias[:pm_channels(lin.cout)].contiguous().view(torch.uint8) for lin in alls]
+        img = torch.cat(parts + biases).contiguous()
+        assert img.numel() == L.lib().captra_chain_bf16_image_bytes(layers[0].cin, 1 if heads is not None else 0), img.numel()
+        cache[key] = (img, alls)
+    return cache[key][0]
+
+
+def mlp_chain_bf16_fused(x, layers, heads=None):
+    """x (B,c0,L) fp32 through three 128-wide Conv+BN+ReLU layers in ONE launch.  heads None -> the feature map as a PMTensor;
+    heads = (seg, hidden, out) packed layers -> (seg logits (B,S,L), sigmoid(nocs) - 0.5 (B,3P,L)) fp32."""
+    L.require_device(x)
+    B, c0, l = x.shape
+    img = _chain_bf16_image(layers, heads)
+    if heads is None:
+        feat = torch.empty(B, l, 128, dtype=torch.bfloat16, device=x.device)
+        with torch.cuda.device(x.device):
+            L.call("captra_mlp_chain_bf16", B, c0, l, 0, 0, 0, L.ptr(x), L.ptr(img), L.ptr(feat), None, None)
+        _work("mlp_chain3", flops=2.0 * B * l * (c0 * 128 + 2 * 128 * 128), nbytes=B * l * (4.0 * c0 + 2.0 * 128))
+        return PMTensor(feat, 128)
+    seg = torch.empty(B, heads[0].cout, l, dtype=torch.float32, device=x.device)
+    nocs = torch.empty(B, heads[2].cout, l, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        L.call("captra_mlp_chain_bf16", B, c0, l, 1, heads[0].cout, heads[2].cout, L.ptr(x), L.ptr(img), None, L.ptr(seg), L.ptr(nocs))
+    _work("coord_tail", flops=2.0 * B * l * (c0 * 128 + 3 * 128 * 128 + 128 * (heads[0].cout + heads[2].cout)),
+          nbytes=4.0 * B * l * (c0 + heads[0].cout + heads[2].cout))
+    return seg, nocs
+
+
 def gn_chain_bf16_supported(x, couts) -> bool:
     """Conv -> GroupNorm -> ReLU chains in the bf16 mode: every normalised width must tile the statistics kernel."""
     return mlp_dtype() == "bf16" and x.dim() == 3 and all(256 % (pm_channels(c) // 8) == 0 for c in couts)

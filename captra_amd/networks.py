@@ -95,6 +95,8 @@ class CoordNet(nn.Module):
                     all_layers = list(layers) + head_layers
                     if fused.coord_tail_supported(x, all_layers):
                         return fused.coord_tail(x, all_layers)            # (seg logits, sigmoid(nocs) - 0.5)
+                    if fused.chain_bf16_supported(x, layers, head_layers):
+                        return fused.mlp_chain_bf16_fused(x.contiguous(), layers, head_layers)      # one launch, nothing in between stored
                     if fused.mlp_dtype() == "bf16":
                         # bf16 mode: FP1 + conv1 leave the feature map as a bf16 point-major tensor both heads read
                         n = x.shape[2]
@@ -173,7 +175,14 @@ class RotationRegressionBackbone(nn.Module):
     def raw_point_rtvec(self, cam, cam_n3=None, geom=None):
         """cam (B*P,3,N) -> (B*P,R,N): backbone + rotation head p on the clouds of part p (fused read-out path:
         captra_rot_pool_compose does the per-point normalisation, the masked mean and the pose algebra)."""
-        return self.pose_pred.raw_diag(self.encoder(cam, input_n3=cam_n3, geom=geom))
+        finish = None
+        if fused.mlp_dtype() == "bf16" and cam.is_cuda and not self.training:
+            # bf16 mode: FP1 + conv1 in one launch, the feature map goes to the heads as a bf16 point-major tensor
+            def finish(x, layers):
+                if fused.chain_bf16_supported(x, layers):
+                    return fused.mlp_chain_bf16_fused(x.contiguous(), layers)
+                return fused.mlp_chain3(x, layers, fused.ACT_RELU)
+        return self.pose_pred.raw_diag(self.encoder(cam, input_n3=cam_n3, geom=geom, finish=finish))
 
     def forward(self, cam, cam_labels, cam_n3=None, geom=None):
         """cam (B,3,N), cam_labels (B,N) -> {'rtvec' (B,P,D) masked mean, 'point_rtvec' (B,P,D,N)}."""

@@ -247,6 +247,16 @@ int captra_pointwise_mlp_bf16pm(int b, int cin, int cout, long long l, int in_pm
 int captra_gn_stats_bf16pm_tiles(long long l);
 int captra_gn_stats_bf16pm(int b, int c, long long l, const void *x, float *stats, captra_stream_t stream);
 
+/* bf16 mode, register-resident dense CHAIN (csrc/sa_bf16.hip): FP1's shared MLP + the backbone's conv1 (+ CoordinateNet's two heads)
+ * in one launch.  x (B,c0,L) fp32, c0 <= 144 -> three 128-wide Conv+BN+ReLU layers; feat_pm (B,L,128) bf16 slot order receives the
+ * result when non-NULL; heads != 0: seg (B,s,L) = Ws feat + bs and nocs (B,no,L) = sigmoid(Wo relu(Wh feat + bh) + bo) - 0.5
+ * (s, no <= 32).  img (captra_chain_bf16_image_bytes bytes): the layers' captra_pack_dense_bf16 images back to back -- trunk
+ * layer 1 with perm = 0, every other layer with perm = 1; order trunk 1-3, seg, hidden, out -- followed by each layer's bias
+ * as 32 floats per row tile (zero padded), same order. */
+long long captra_chain_bf16_image_bytes(int c0, int heads);
+int captra_mlp_chain_bf16(int b, int c0, long long l, int heads, int s, int no, const float *x, const unsigned char *img,
+                          void *feat_pm, float *seg, float *nocs, captra_stream_t stream);
+
 /* Furthest point sampling + index_points in one launch (pointnet_utils.py:222-223: new_xyz = index_points(xyz,
  * farthest_point_sample(xyz, S))): xyz (B,N,3) -> idx (B,M) i32, new_xyz_n3 (B,M,3), new_xyz_cn (B,3,M) (either output
  * pointer may be NULL).  Same selection rule as captra_furthest_point_sampling with temp = 1e10.  Returns -2 when the

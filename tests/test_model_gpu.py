@@ -1017,6 +1017,43 @@ def test_bf16_rotation_head_chain_vs_torch(device):
     assert float(d.max()) <= 5e-2 * scale and float(d.mean()) <= 6e-3 * scale, (float(d.max()) / scale, float(d.mean()) / scale)
 
 
+@pytest.mark.parametrize("c0,l", [(131, 4096), (134, 1000), (128, 77)])
+def test_bf16_chain_one_launch_equals_layer_by_layer(device, c0, l):
+    """captra_mlp_chain_bf16 (FP1 + conv1 register-resident, optionally CoordinateNet's heads behind them, one launch) against the
+    same layers through captra_pointwise_mlp_bf16pm with bf16 point-major tensors in between: the same roundings at the same
+    places and the same k-ascending accumulation, so the feature map agrees element for element (a rare 1-ulp bf16 flip from the
+    MFMA's internal order aside) and the heads' outputs to 1e-5; and against the float64 layer contract."""
+    from captra_amd import fused
+    rng = np.random.default_rng(c0 + l)
+    B = 2
+    x = rng.standard_normal((B, c0, l)).astype(np.float32)
+    dims = [c0, 128, 128, 128]
+    ws = [((rng.standard_normal((dims[i], dims[i + 1])) / np.sqrt(dims[i])).astype(np.float32), rng.standard_normal(dims[i + 1]).astype(np.float32)) for i in range(3)]
+    hw = [((rng.standard_normal((128, c)) / np.sqrt(128)).astype(np.float32), rng.standard_normal(c).astype(np.float32)) for c in (2, 128, 3)]
+    layers = [fused.pack(_dev(w, device), _dev(b, device)) for w, b in ws]
+    heads = [fused.pack(_dev(w, device), _dev(b, device)) for w, b in hw]
+    xd = _dev(x, device)
+    with fused.use_mlp_dtype("bf16"):
+        assert fused.chain_bf16_supported(xd, layers) and fused.chain_bf16_supported(xd, layers, heads)
+        feat = fused.mlp_chain_bf16_fused(xd, layers)
+        seg, nocs = fused.mlp_chain_bf16_fused(xd, layers, heads)
+        ref_pm = fused.mlp_chain_bf16(xd, layers, [fused.ACT_RELU] * 3, out_pm=True)
+        ref_seg = fused.pointwise_mlp_bf16pm(ref_pm, heads[0], l, in_pm=True, out_pm=False)
+        hid = fused.pointwise_mlp_bf16pm(ref_pm, heads[1], l, in_pm=True, out_pm=True, act=fused.ACT_RELU)
+        ref_nocs = fused.pointwise_mlp_bf16pm(hid, heads[2], l, in_pm=True, out_pm=False, act=fused.ACT_SIGMOID_M05)
+    got, ref = _pm_to_dense(feat.data, 128), _pm_to_dense(ref_pm, 128)
+    assert feat.channels == 128 and np.mean(got == ref) > 0.999 and np.abs(got - ref).max() <= 2.0 ** -7 * np.abs(ref).max()
+    np.testing.assert_allclose(seg.cpu().numpy(), ref_seg.cpu().numpy(), atol=2e-2 * float(ref_seg.abs().max()), rtol=0)
+    assert float((seg - ref_seg).abs().mean()) <= 1e-4 * float(ref_seg.abs().max())
+    assert float((nocs - ref_nocs).abs().mean()) <= 1e-4 and float((nocs - ref_nocs).abs().max()) <= 2e-2
+    h = x
+    for w, b in ws:
+        h = _bf16_layer(h, w, b, 1)
+    scale = float(np.abs(h).max())
+    err = np.abs(got - _bf16_round(h))
+    assert err.max() <= 3e-2 * scale and err.mean() <= 2e-4 * scale
+
+
 def test_bf16_mode_track_step_close_to_fp32(device):
     """The whole tracking step with bf16 MFMA operands in the shared MLPs (fused.use_mlp_dtype / cfg['mlp_dtype'], BASELINE.json configs[2]) stays
     close to the exact-fp32 step on the same inputs: NOCS coordinates within bf16-level error, (almost) no label flips."""
