@@ -128,6 +128,11 @@ def lib():
             l.captra_pointwise_mlp_gn_tiles.argtypes = [_INT, _INT, _LL]
             l.captra_pointwise_mlp_gn_tiles.restype = _INT
         _lib = l
+        # A/B switches for measurements (thread-local knobs of the library, set for the importing thread)
+        import os
+        for env, fn in (("CAPTRA_BF16_SHARED_AFFINE", "captra_dense_bf16_set_shared_affine"), ("CAPTRA_BF16_STREAM", "captra_sa_bf16_set_stream")):
+            if env in os.environ and hasattr(l, fn):
+                getattr(l, fn)(C.c_int(int(os.environ[env])))
     return _lib
 
 
