@@ -21,6 +21,25 @@
 // same arithmetic for every distance that can matter, and "lowest original index among equal maxima"
 // is resolved exactly (the original index of a sorted position is kept in LDS and consulted whenever
 // a maximum is attained more than once — always the case in duplicate-padded clouds).
+//
+// SEVERAL PICKS PER ROUND (round 3).  A round costs ~420 instructions per wave whatever it decides (bucket tests, wave
+// candidate, barrier, exchange) and the CU is issue-bound on them (two waves per SIMD in lock step), and there were m - 1
+// rounds.  But the NEXT pick is often known before the current one is applied: let a be this round's pick and c the best
+// remaining candidate.  Every running minimum only ever decreases, so after the update with a no point can exceed its old
+// value; if c itself is untouched by a -- dist(c, a) >= dmin(c) in the very fp32 arithmetic the update would use -- and
+// positive, c is still the maximum (ties: c was the lowest original index among equals before, and whoever equals it
+// afterwards equalled it before), i.e. c IS the next pick, and so on down the sorted list.  A wave knows only its TOP point,
+// so the list is the NW wave tops, and a wave whose top was taken contributes an OBSTACLE instead: an upper bound on
+// everything else it holds (its second-largest bucket maximum, and the runner-up of the top's own bucket, kept per bucket
+// next to its maximum).  A candidate must beat, strictly, the obstacles of the waves already picked from.  The certification
+// runs on the 8 x 8 pairs of wave tops, one pair per lane, after the one barrier of the round (two ballots give every top
+// its predecessors and whether one of them spoils it); the picks are then applied together, each touched bucket read and
+// written once for all of them.  Picks are identical to the one-per-round kernel's (the same tests pass, incl.
+// duplicate-padded and all-identical clouds).  Up to KP = 4 per round: 4095 picks take ~1440 rounds on the re-crop's clouds
+// (2.8 per round); KP = 8 certifies 3.1 per round but its longer sample loops cost more than they save.  Measured against
+// the one-per-round kernel in the same process (tools/bench_fps.py): 15000 -> 4096 2.86 -> 2.58 ms, 20480 -> 4096
+// 3.47 -> 3.09 ms, 16384 -> 2048 1.53 -> 1.46 ms on surface-like clouds; uniform clouds -2 .. -7 %, except 16384 uniform
+// points (+6 %: every slot of every wave in use, and a round now waits for the wave with the most buckets to update).
 #include "common.h"
 #include <type_traits>
 
@@ -91,7 +110,8 @@ __global__ __launch_bounds__(FP_NW * 64) void fps_pruned_kernel(int n_stride, co
     uint2 *slots = reinterpret_cast<uint2 *>(smem_raw);                                   // [2][16] (bmax, sorted pos)
     float4 *slotc = reinterpret_cast<float4 *>(smem_raw + 2 * 16 * sizeof(uint2));       // [2][16] the candidates' coordinates
     float *red = reinterpret_cast<float *>(smem_raw + 2 * 16 * (sizeof(uint2) + sizeof(float4)));   // [6][16] bbox partials
-    unsigned short *oidx = reinterpret_cast<unsigned short *>(red + 6 * 16);             // [CAP] original index of a sorted position (< 65535)
+    float4 *picks = reinterpret_cast<float4 *>(red + 6 * 16);                             // [NW][8] a round's picks, one copy per wave
+    unsigned short *oidx = reinterpret_cast<unsigned short *>(picks + FP_NW * 8);             // [CAP] original index of a sorted position (< 65535)
     unsigned char *scratch = reinterpret_cast<unsigned char *>(oidx + CAP);
     unsigned *hist = reinterpret_cast<unsigned *>(scratch);                               // [FP_BINS] (sort phase)
     unsigned *wsum = hist + FP_BINS;                                                      // [16]
@@ -205,23 +225,36 @@ __global__ __launch_bounds__(FP_NW * 64) void fps_pruned_kernel(int n_stride, co
     }
 
     // ---- 4. bucket metadata: lane i of these registers describes bucket (slot) i of this wave
+    constexpr int KP = 4;   // picks per round, at most
     float blx = __builtin_inff(), bly = blx, blz = blx, bhx = -blx, bhy = -blx, bhz = -blx;   // lanes >= SLOTS: empty box
-    unsigned bmax = 0u, bq = 0u;
+    unsigned bmax = 0u;
+    unsigned brun = 0u;      // upper bound on the bucket's SECOND largest running minimum (refreshed with bmax; values only decrease)
+    unsigned boi = 0xFFFFu;  // original index of the point holding bmax
     float bwx = 0.f, bwy = 0.f, bwz = 0.f;
-    // Update bucket s (wave-uniform, run time) against the sample (sx, sy, sz): the lane's point of that bucket is read
+    // the samples still to be applied (wave-uniform; position order of the previous round's picks)
+    float ox[KP], oy[KP], oz[KP];
+    int np = 1;
+    // Update bucket s (wave-uniform, run time) against the np pending samples: the lane's point of that bucket is read
     // out of the register vectors by index, so ONE copy of this code serves every slot (an unrolled per-slot version
-    // is ~90 KB of instructions and lost more to instruction fetch than the pruning saved).
+    // is ~90 KB of instructions and lost more to instruction fetch than the pruning saved).  A sample whose box test
+    // excluded this bucket changes nothing here (lb <= d for every point of the bucket), so all of them are applied.
     unsigned n_upd = 0, n_ref = 0;   // experiment counters (captra_fps_set_stats)
-    auto update = [&](int s, float sx_, float sy_, float sz_, bool first) __attribute__((always_inline)) {
+    auto update = [&](int s, bool first) __attribute__((always_inline)) {
         ++n_upd;
         float x, y, z, dm;
         float *o = ovf_w + (s - A) * 256;
         if (B == 0 || s < A) { x = px.get(s); y = py.get(s); z = pz.get(s); dm = dmin.get(s); }
         else { x = o[0]; y = o[64]; z = o[128]; dm = o[192]; }
-        const float dx = x - sx_, dy = y - sy_, dz = z - sz_;
-        const unsigned d = __float_as_uint((dx * dx + dy * dy) + dz * dz);
         const unsigned dold = __float_as_uint(dm);
-        const unsigned dnew = d < dold ? d : dold;
+        unsigned dnew = dold;
+#pragma unroll
+        for (int t = 0; t < KP; ++t) {
+            if (t < np) {
+                const float dx = x - ox[t], dy = y - oy[t], dz = z - oz[t];
+                const unsigned d = __float_as_uint((dx * dx + dy * dy) + dz * dz);
+                dnew = d < dnew ? d : dnew;
+            }
+        }
         if (B == 0 || s < A) dmin.set(s, __uint_as_float(dnew));
         else o[192] = __uint_as_float(dnew);
         if (first) {   // the bucket's bounding box (once)
@@ -238,81 +271,119 @@ __global__ __launch_bounds__(FP_NW * 64) void fps_pruned_kernel(int n_stride, co
         const unsigned long long hit = __ballot(dnew == bm);
         int wl = __ffsll((long long)hit) - 1;
         const int q0 = (s * FP_NW + wave) << 6;
+        const unsigned oi = (unsigned)oidx[q0 + lane];
         if (hit & (hit - 1)) {   // the maximum is attained more than once: lowest ORIGINAL index wins
-            const unsigned oi = (dnew == bm) ? (unsigned)oidx[q0 + lane] : 0xFFFFFFFFu;
-            const unsigned best = fp_wave_min(oi);
-            wl = __ffsll((long long)__ballot(oi == best)) - 1;
+            const unsigned best = fp_wave_min((dnew == bm) ? oi : 0xFFFFFFFFu);
+            wl = __ffsll((long long)__ballot(dnew == bm && oi == best)) - 1;
         }
         const float wx = fp_readlane(x, wl), wy = fp_readlane(y, wl), wz = fp_readlane(z, wl);
-        if (lane == s) { bmax = bm; bq = (unsigned)(q0 + wl); bwx = wx; bwy = wy; bwz = wz; }
+        const unsigned woi = (unsigned)__builtin_amdgcn_readlane((int)oi, wl);
+        const unsigned ru = fp_wave_max(lane == wl ? 0u : dnew);      // the rest of the bucket never exceeds this
+        if (lane == s) { bmax = bm; boi = woi; bwx = wx; bwy = wy; bwz = wz; brun = ru; }
     };
-    // initial maxima: an "update" against a sample at infinity leaves every running minimum as it is
-    const int slots_used = (n + FP_T - 1) / FP_T;   // buckets beyond the cloud keep bmax = 0 and an empty box: never touched
-    for (int s = 0; s < slots_used; ++s) update(s, __builtin_inff(), __builtin_inff(), __builtin_inff(), true);
-
-    // ---- 5. the selection rounds
-    if (tid == 0) idx[0] = 0;
-    float ox = xyz[0], oy = xyz[1], oz = xyz[2];
-    unsigned long long tph[4] = {0ull, 0ull, 0ull, 0ull};   // phase cycles (stats only)
-    for (int j = 1; j < m; ++j) {
-        const unsigned long long t0 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
-        if (tid == 0) emit(j - 1, ox, oy, oz);
-        // which buckets can change?  same operations as the point distance: fl(p - o), squares, (x + y) + z
-        {
-            const float ddx = fmaxf(fmaxf(blx - ox, ox - bhx), 0.f), ddy = fmaxf(fmaxf(bly - oy, oy - bhy), 0.f),
-                        ddz = fmaxf(fmaxf(blz - oz, oz - bhz), 0.f);
-            const float lb = (ddx * ddx + ddy * ddy) + ddz * ddz;
-            unsigned long long need = __ballot(lane < SLOTS && __float_as_uint(lb) < bmax);
-            while (need) {
-                const int s = __ffsll((long long)need) - 1;
-                need &= need - 1;
-                update(s, ox, oy, oz, false);
+    // test every bucket of the wave against the pending samples (same operations as the point distance: fl(p - o), squares,
+    // (x + y) + z) and update those that can change
+    auto apply_pending = [&]() __attribute__((always_inline)) {
+        unsigned long long need = 0ull;
+#pragma unroll
+        for (int t = 0; t < KP; ++t) {
+            if (t < np) {
+                const float ddx = fmaxf(fmaxf(blx - ox[t], ox[t] - bhx), 0.f), ddy = fmaxf(fmaxf(bly - oy[t], oy[t] - bhy), 0.f),
+                            ddz = fmaxf(fmaxf(blz - oz[t], oz[t] - bhz), 0.f);
+                const float lb = (ddx * ddx + ddy * ddy) + ddz * ddz;
+                need |= __ballot(lane < SLOTS && __float_as_uint(lb) < bmax);
             }
         }
+        while (need) {
+            const int s = __ffsll((long long)need) - 1;
+            need &= need - 1;
+            update(s, false);
+        }
+    };
+    // initial maxima: an "update" against a sample at infinity leaves every running minimum as it is
+#pragma unroll
+    for (int t = 0; t < KP; ++t) { ox[t] = __builtin_inff(); oy[t] = ox[t]; oz[t] = ox[t]; }
+    const int slots_used = (n + FP_T - 1) / FP_T;   // buckets beyond the cloud keep bmax = 0 and an empty box: never touched
+    for (int s = 0; s < slots_used; ++s) update(s, true);
+
+    // ---- 5. the selection rounds: up to KP certified picks each (header)
+    static_assert(FP_NW * FP_NW <= 64 && (FP_NW & (FP_NW - 1)) == 0, "pairs of wave tops on the lanes of one wave");
+    if (tid == 0) { idx[0] = 0; emit(0, xyz[0], xyz[1], xyz[2]); }
+    ox[0] = xyz[0]; oy[0] = xyz[1]; oz[0] = xyz[2];
+    unsigned long long tph[4] = {0ull, 0ull, 0ull, 0ull};   // phase cycles (stats only)
+    int rounds = 0;
+    for (int j = 1; j < m;) {
+        const unsigned long long t0 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
+        apply_pending();
         const unsigned long long t1 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
-        // the wave's candidate
+        // the wave's candidate (its largest bucket maximum, lowest original index among equals) and its obstacle: nothing
+        // else this wave holds exceeds max(second-largest bucket maximum, runner-up bound of the candidate's bucket)
         const unsigned wm = fp_wave_max(bmax);
         const unsigned long long hitb = __ballot(bmax == wm);
         int li = __ffsll((long long)hitb) - 1;
         if (hitb & (hitb - 1)) {
-            const unsigned oi = (bmax == wm) ? (unsigned)oidx[bq] : 0xFFFFFFFFu;
-            const unsigned best = fp_wave_min(oi);
-            li = __ffsll((long long)__ballot(oi == best)) - 1;
+            const unsigned best = fp_wave_min((bmax == wm) ? boi : 0xFFFFFFFFu);
+            li = __ffsll((long long)__ballot(bmax == wm && boi == best)) - 1;
         }
-        uint2 *slot = slots + (j & 1) * 16;
-        float4 *sc = slotc + (j & 1) * 16;
+        const unsigned second = fp_wave_max(lane == li ? 0u : bmax);
+        const unsigned topru = (unsigned)__builtin_amdgcn_readlane((int)brun, li);
+        const unsigned obst = second > topru ? second : topru;
+        uint2 *slot = slots + (rounds & 1) * 16;
+        float4 *sc = slotc + (rounds & 1) * 16;
         if (lane == li) {
-            slot[wave] = make_uint2(bmax, bq);
-            sc[wave] = make_float4(bwx, bwy, bwz, 0.f);
+            slot[wave] = make_uint2(bmax, boi);
+            sc[wave] = make_float4(bwx, bwy, bwz, __uint_as_float(obst));
         }
         const unsigned long long t2 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
         __syncthreads();
         const unsigned long long t3 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
-        const uint2 kv = slot[lane & (FP_NW - 1)];
-        const float4 kc = sc[lane & (FP_NW - 1)];
-        const unsigned gmax = fp_row_max(kv.x);
-        const unsigned long long hit2 = __ballot(kv.x == gmax) & ((1ull << FP_NW) - 1);
-        int gl = __ffsll((long long)hit2) - 1;
-        if (hit2 & (hit2 - 1)) {
-            const unsigned oi = (lane < FP_NW && kv.x == gmax) ? (unsigned)oidx[kv.y] : 0xFFFFFFFFu;
-            const unsigned best = fp_wave_min(oi);
-            gl = __ffsll((long long)__ballot(oi == best)) - 1;
+        // every wave certifies the picks of this round, lane (i, w) = (lane / NW, lane % NW) comparing wave top i with wave
+        // top w: in the order (value descending, original index ascending) a top is picked iff everything before it is
+        // picked, it is positive, no sample before it would lower it, and it beats (strictly) what those samples' waves
+        // still hold.  (NW * NW <= 64.)
+        const int ci = (lane / FP_NW) & (FP_NW - 1), cw = lane & (FP_NW - 1);
+        const uint2 av = slot[ci], kv = slot[cw];
+        const float4 ac = sc[ci], kc = sc[cw];
+        const bool bf = kv.x > av.x || (kv.x == av.x && (kv.y < av.y || (kv.y == av.y && cw < ci)));
+        const float pdx = ac.x - kc.x, pdy = ac.y - kc.y, pdz = ac.z - kc.z;
+        const unsigned pd = __float_as_uint((pdx * pdx + pdy * pdy) + pdz * pdz);
+        const bool in_pairs = lane < FP_NW * FP_NW;
+        const unsigned long long bm64 = __ballot(in_pairs && bf);
+        const unsigned long long bad64 = __ballot(in_pairs && bf && (pd < av.x || __float_as_uint(kc.w) >= av.x));
+        // from here on lane l speaks for wave top l % NW
+        const unsigned before = (unsigned)(bm64 >> (FP_NW * cw)) & ((1u << FP_NW) - 1u);
+        const unsigned bad = (unsigned)(bad64 >> (FP_NW * cw)) & ((1u << FP_NW) - 1u);
+        const int pos = __popc(before);
+        const bool ok = pos == 0 || (bad == 0u && kv.x > 0u);
+        const unsigned okmask = (unsigned)__ballot(ok && lane < FP_NW);
+        const bool picked = lane < FP_NW && ok && (before & ~okmask) == 0u && pos < KP && j + pos < m;
+        np = __popcll(__ballot(picked));
+        float4 *mine = picks + wave * KP;        // wave-private: no barrier
+        if (picked) {
+            mine[pos] = kc;
+            if (wave == 0) { idx[j + pos] = (int)kv.y; emit(j + pos, kc.x, kc.y, kc.z); }
         }
-        const unsigned sel = (unsigned)__builtin_amdgcn_readlane((int)kv.y, gl);
-        ox = fp_readlane(kc.x, gl); oy = fp_readlane(kc.y, gl); oz = fp_readlane(kc.z, gl);
-        if (tid == 0) idx[j] = (int)sel;   // sorted position for now: the LDS look-up of the original index would sit on wave 0's critical path
+#pragma unroll
+        for (int t = 0; t < KP; ++t) {
+            const float4 pk = mine[t];           // (stale beyond np: never used)
+            ox[t] = pk.x; oy[t] = pk.y; oz[t] = pk.z;
+        }
+        j += np;
+        ++rounds;
         if (STATS) {
             const unsigned long long t4 = __builtin_amdgcn_s_memtime();
             tph[0] += t1 - t0; tph[1] += t2 - t1; tph[2] += t3 - t2; tph[3] += t4 - t3;
         }
     }
-    if (tid == 0) emit(m - 1, ox, oy, oz);
-    __syncthreads();   // (same-workgroup global writes of thread 0 are visible after the barrier)
-    for (int j = 1 + tid; j < m; j += FP_T) idx[j] = (int)oidx[idx[j]];
+    if (temp != nullptr && np > 1) {   // the running minima handed back have seen every sample but the last one
+        np -= 1;
+        apply_pending();
+    }
     if (STATS && stats != nullptr && lane == 0) {   // per wave: bucket updates, maximum refreshes (both include the SLOTS initial ones)
         atomicAdd(stats + 0, (unsigned long long)n_upd);
         atomicAdd(stats + 1, (unsigned long long)n_ref);
         for (int i = 0; i < 4; ++i) atomicAdd(stats + 2 + i, tph[i]);   // test + updates | candidate | barrier wait | exchange
+        atomicAdd(stats + 6, (unsigned long long)rounds);
     }
     if (temp != nullptr) {
 #pragma unroll
@@ -330,7 +401,7 @@ int launch_pruned(int b, int n_stride, const int *ns, int m, const float *xyz, f
                   float *new_cn, hipStream_t s) {
     constexpr int CAP = FP_NW * (A + B) * 64;
     const size_t sort_bytes = (size_t)(FP_BINS + 16) * sizeof(unsigned), ovf_bytes = (size_t)FP_NW * B * 256 * sizeof(float);
-    const size_t shmem = 2 * 16 * (sizeof(uint2) + sizeof(float4)) + 6 * 16 * sizeof(float) + (size_t)CAP * 2 +
+    const size_t shmem = 2 * 16 * (sizeof(uint2) + sizeof(float4)) + 6 * 16 * sizeof(float) + FP_NW * 8 * sizeof(float4) + (size_t)CAP * 2 +
                          (sort_bytes > ovf_bytes ? sort_bytes : ovf_bytes);
     constexpr int FP_T = FP_NW * 64;
     static CaptraDeviceOnce once;
