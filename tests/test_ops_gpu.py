@@ -163,6 +163,43 @@ def test_fps_pruned_duplicate_padded_cloud(device):
     np.testing.assert_array_equal(fused.fps_gather(_dev(mixed, device), 5)[0].cpu().numpy(), O.furthest_point_sample(mixed, 5))
 
 
+@pytest.mark.parametrize("kind", ["lattice", "coarse_grid", "two_clusters", "line"])
+def test_fps_pruned_many_picks_per_round_under_ties(device, kind):
+    """The pruned sampler certifies up to four picks per round (csrc/fps_pruned.hip header): a candidate must be positive,
+    untouched by the picks before it and strictly above what their waves still hold.  Clouds built to stress exactly
+    that: a lattice (all points distinct, almost every distance shared by many pairs), a coarse grid (1728 distinct
+    positions, each held ~6 times: every maximum attained several times, then all-zero), two far-apart clusters (the
+    first picks alternate between them: candidates far from every earlier pick), points on a line (one Morton axis)."""
+    from captra_amd import _lib, fused
+    rng = np.random.default_rng(11)
+    if kind == "lattice":
+        g = np.arange(21, dtype=np.float32) * 0.05
+        pts = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)              # 9261 distinct points
+        xyz, m = rng.permutation(pts)[None], 3000
+    elif kind == "coarse_grid":
+        xyz, m = (rng.integers(0, 12, (1, 10000, 3)).astype(np.float32) * 0.125), 2500     # more picks than distinct points
+    elif kind == "two_clusters":
+        a = rng.normal(0, 0.01, (6000, 3)) + (1.0, 0, 0)
+        b = rng.normal(0, 0.01, (6000, 3)) - (1.0, 0, 0)
+        xyz, m = rng.permutation(np.concatenate([a, b])).astype(np.float32)[None], 1024
+    else:
+        t = rng.random(9000).astype(np.float32)
+        xyz, m = np.stack([t, np.zeros_like(t), np.zeros_like(t)], -1)[None], 2048
+    xyz = np.ascontiguousarray(xyz, np.float32)
+    ref = O.furthest_point_sample(xyz, m)
+    idx, n3, _ = fused.fps_gather(_dev(xyz, device), m)
+    np.testing.assert_array_equal(idx.cpu().numpy(), ref)
+    np.testing.assert_array_equal(n3.cpu().numpy()[0], xyz[0, ref[0]])
+    # the drop-in op's running-minimum array (every sample but the last applied, whatever round it was picked in)
+    temp = torch.full((1, xyz.shape[1]), 1e10, device=device)
+    out = torch.zeros(1, m, dtype=torch.int32, device=device)
+    _lib.call("captra_furthest_point_sampling", 1, xyz.shape[1], m, _dev(xyz, device).data_ptr(), temp.data_ptr(), out.data_ptr())
+    t_ref = np.full((1, xyz.shape[1]), 1e10, np.float32)
+    O.furthest_point_sample(xyz, m, temp=t_ref)
+    np.testing.assert_array_equal(out.cpu().numpy(), ref)
+    np.testing.assert_array_equal(temp.cpu().numpy(), t_ref)
+
+
 def test_fps_gather_ragged_batch(device):
     """captra_fps_gather_ragged: clouds padded to a common stride, each sampling from its own prefix — equal to sampling
     every cloud on its own (pruned kernel at 20480 stride, register kernel at 3000)."""
