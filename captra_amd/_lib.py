@@ -45,12 +45,14 @@ _SIGNATURES = {
     "captra_three_nn_weights": [_INT, _INT, _INT, _P, _P, _P, _P, _P],
     "captra_pointwise_mlp_gn": [_INT, _INT, _INT, _LL, _P, _P, _P, _P, _INT, _P, _P, _INT, _P],
     "captra_gn_finalize": [_INT, _INT, _INT, _INT, _LL, _F, _P, _P, _P, _P, _P],
+    "captra_gn_finalize_tm": [_INT, _INT, _INT, _INT, _LL, _F, _P, _P, _P, _P, _P],
     "captra_pack_weights_bf16": [_INT, _INT, _P, _P, _P],
     "captra_pack_weights_frag": [_INT, _INT, _P, _P],
     "captra_pointwise_mlp_bf16": [_INT, _INT, _INT, _LL, _P, _P, _P, _INT, _P, _P],
     "captra_pointwise_mlp_bf16_pm": [_INT, _INT, _INT, _LL, _P, _P, _P, _INT, _P, _P],
     "captra_pack_dense_bf16": [_INT, _INT, _INT, _P, _P, _P],
     "captra_pointwise_mlp_bf16pm": [_INT, _INT, _INT, _LL, _INT, _P, _P, _P, _P, _INT, _INT, _P, _P],
+    "captra_pointwise_mlp_bf16pm_stats": [_INT, _INT, _INT, _LL, _INT, _P, _P, _P, _P, _INT, _P, _P, _P],
     "captra_gn_stats_bf16pm": [_INT, _INT, _LL, _P, _P, _P],
     "captra_mlp_chain_bf16": [_INT, _INT, _LL, _INT, _INT, _INT, _P, _P, _P, _P, _P, _P],
     "captra_pack_sa_bf16": [_INT] * 5 + [_P] * 7 + [_P],
@@ -71,6 +73,7 @@ _SIGNATURES = {
     "captra_part_fit_st_track": [_INT, _INT, _INT, _INT, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "captra_seg_softmax_argmax": [_INT, _INT, _INT, _P, _P, _P, _P],
     "captra_copy_multi": [_INT, _P, _P, _P, _P],
+    "captra_pack_pose": [_INT, _P, _P, _P, _P, _P, _P, _P],
     "captra_procrustes_rot3": [_INT, _INT, _P, _P, _P, _P],
 }
 
@@ -118,6 +121,8 @@ def lib():
             l.captra_dense_bf16_image_bytes.restype = _LL
             l.captra_gn_stats_bf16pm_tiles.argtypes = [_LL]
             l.captra_gn_stats_bf16pm_tiles.restype = _INT
+            l.captra_dense_bf16_stats_tiles.argtypes = [_LL]
+            l.captra_dense_bf16_stats_tiles.restype = _INT
         if hasattr(l, "captra_chain_bf16_image_bytes"):
             l.captra_chain_bf16_image_bytes.argtypes = [_INT, _INT]
             l.captra_chain_bf16_image_bytes.restype = _LL

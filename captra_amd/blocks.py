@@ -127,8 +127,8 @@ def run_point_mlp(seq: nn.Sequential, x: torch.Tensor, cache: dict) -> torch.Ten
 def _run_gn_chain_bf16(mods, x, cache):
     """bf16 mode (cfg['mlp_dtype'] = 'bf16', BASELINE.json configs[2]): a Sequential of the exact form (Conv1d, GroupNorm,
     ReLU) x n, Conv1d -- the rotation heads (reference blocks.py:147-165) -- with the hidden activations kept in HBM as bf16
-    point-major tensors (csrc/dense_bf16.hip): each hidden layer stores its raw output, one pass takes the group statistics
-    of what was stored, and the next layer applies relu(a x + b) while it loads its operand.  None when the Sequential has
+    point-major tensors (csrc/dense_bf16.hip): each hidden layer stores its raw output and, from its epilogue, the group statistics
+    of what it stored, and the next layer applies relu(a x + b) while it loads its operand.  None when the Sequential has
     another shape (the caller's generic path runs it)."""
     layers, i = [], 0
     while i < len(mods):
@@ -154,10 +154,14 @@ def _run_gn_chain_bf16(mods, x, cache):
         if id(conv) not in cache:
             cache[id(conv)] = fold_conv_bn(conv, None, x.device)
         lin = cache[id(conv)]
-        x = fused.pointwise_mlp_bf16pm(x, lin, n, in_pm=in_pm, out_pm=gn is not None, ab=ab, act=fused.ACT_NONE)
+        epi = gn is not None and fused.USE_STATS_EPILOGUE   # the layer's epilogue leaves the statistics of what it stored
+        if epi:
+            x, stats = fused.pointwise_mlp_bf16pm(x, lin, n, in_pm=in_pm, out_pm=True, ab=ab, act=fused.ACT_NONE, with_stats=True)
+        else:
+            x = fused.pointwise_mlp_bf16pm(x, lin, n, in_pm=in_pm, out_pm=gn is not None, ab=ab, act=fused.ACT_NONE)
+            stats = fused.gn_stats_bf16pm(x, lin.cout) if gn is not None else None
         if gn is not None:
-            stats = fused.gn_stats_bf16pm(x, lin.cout)
-            ab = fused.gn_finalize(stats, gn.num_groups, gn.weight, gn.bias, gn.eps, n)
+            ab = fused.gn_finalize(stats, gn.num_groups, gn.weight, gn.bias, gn.eps, n, tile_major=epi)
             in_pm = True
     return x
 

@@ -62,7 +62,46 @@ struct DbParams {
     const float *ab;          // AFF: (B,cin,2) fp32
     void *y;                  // OUT_PM: (B,L,cp_out) bf16 slot order; else (B,cout,L) fp32
     int act;
+    float *stats;             // ST: (B,T,cout,2) partial (sum, sum of squares) of the STORED values, T = ceil(L / 64)
+    int st_t;
 };
+
+// ST epilogue: per-channel (sum, sum of squares) of what a wave just stored for one row tile -- 16 channels x (TN x 32)
+// positions per half-wave -- reduced over the 32 columns by a halving butterfly (16 + 8 + 4 + 2 + 1 exchanges instead of
+// 5 x 32: the lane with column c ends up holding value c of {s[0..15], q[0..15]}), fixed order, no atomics; one float per
+// lane goes to stats[b][chunk][channel][0 / 1] (tile-major: a channel-major table would take 64 scattered 4-byte stores per
+// wave and row tile, into 128-byte lines shared by 16 workgroups -- measured 4x the layer's own time).  The separate statistics pass (gn_stats_bf16pm_kernel) re-read the whole
+// tensor: 134 MB and ~40 us per 512-wide layer at 32 x 4096 points.
+template <int CNT>
+__device__ __forceinline__ void db_stats_fold(float (&vals)[32], int col) {   // (every index a compile-time constant: registers)
+    const bool up = (col & CNT) != 0;
+#pragma unroll
+    for (int k = 0; k < CNT; ++k) {
+        const float keep = up ? vals[k + CNT] : vals[k], send = up ? vals[k] : vals[k + CNT];
+        vals[k] = keep + __shfl_xor(send, CNT, 64);
+    }
+}
+__device__ __forceinline__ void db_stats_tile(float (&vals)[32], int col, int h, int row_tile, int cout, float *dst_b, int T, int chunk) {
+    db_stats_fold<16>(vals, col);
+    db_stats_fold<8>(vals, col);
+    db_stats_fold<4>(vals, col);
+    db_stats_fold<2>(vals, col);
+    db_stats_fold<1>(vals, col);
+    const int r = col & 15;
+    const int ch = 32 * row_tile + (r & 3) + 8 * (r >> 2) + 4 * h;
+    if (ch < cout) dst_b[((size_t)chunk * cout + ch) * 2 + (col >> 4)] = vals[0];   // tile-major: a wave's 64 floats are 256 contiguous bytes
+}
+// accumulate the 8 stored values of one 16-byte store (acc registers 8 jj .. 8 jj + 7) into s / q
+__device__ __forceinline__ void db_stats_acc(float (&vals)[32], int jj, u32x4 v) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float lo = __uint_as_float(v[i] << 16), hi = __uint_as_float(v[i] & 0xffff0000u);
+        vals[8 * jj + 2 * i] += lo;
+        vals[8 * jj + 2 * i + 1] += hi;
+        vals[16 + 8 * jj + 2 * i] = __builtin_fmaf(lo, lo, vals[16 + 8 * jj + 2 * i]);
+        vals[16 + 8 * jj + 2 * i + 1] = __builtin_fmaf(hi, hi, vals[16 + 8 * jj + 2 * i + 1]);
+    }
+}
 
 // x = bf16(relu(a * x + b)) on the 8 channels of a lane's B-operand registers; t = 16 floats (a0..a7, b0..b7) in LDS
 __device__ __forceinline__ u32x4 db_affine(u32x4 v, const float *t) {
@@ -79,9 +118,10 @@ __device__ __forceinline__ u32x4 db_affine(u32x4 v, const float *t) {
     return r;
 }
 
-template <int TM, int TN, bool IN_PM, bool AFF, bool OUT_PM>
+template <int TM, int TN, bool IN_PM, bool AFF, bool OUT_PM, bool ST = false>
 __global__ __launch_bounds__(256, 2) void pw_bf16pm_kernel(DbParams p) {
     static_assert(!AFF || IN_PM, "the on-load GroupNorm needs the point-major input");
+    static_assert(!ST || (OUT_PM && TN == 2), "statistics of the stored bf16 tensor, chunks of 64 positions");
     constexpr int NS = 3;                                  // k-steps in flight
     extern __shared__ __attribute__((aligned(16))) float aff_tab[];   // AFF: [kst][2 halves][16]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -194,6 +234,11 @@ __global__ __launch_bounds__(256, 2) void pw_bf16pm_kernel(DbParams p) {
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
         if (t0 + tm >= p.nt) continue;
+        float sv[ST ? 32 : 1];
+        if constexpr (ST) {
+#pragma unroll
+            for (int i = 0; i < 32; ++i) sv[i] = 0.f;
+        }
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
             const long long c = pos0 + tn * 32 + col;
@@ -209,6 +254,7 @@ __global__ __launch_bounds__(256, 2) void pw_bf16pm_kernel(DbParams p) {
                         if (p.act == ACT_RELU) v[i] = db_relu2(v[i]);
                     }
                     *reinterpret_cast<u32x4 *>(yp + 16 * jj) = v;
+                    if constexpr (ST) db_stats_acc(sv, jj, v);
                 }
             } else {
                 const int row0 = 32 * (t0 + tm) + 4 * h;
@@ -220,6 +266,8 @@ __global__ __launch_bounds__(256, 2) void pw_bf16pm_kernel(DbParams p) {
                 }
             }
         }
+        if constexpr (ST)
+            db_stats_tile(sv, col, h, t0 + tm, p.cout, p.stats + (size_t)b * p.cout * p.st_t * 2, p.st_t, (int)(pos0 >> 6));
     }
 }
 
@@ -231,8 +279,9 @@ __global__ __launch_bounds__(256, 2) void pw_bf16pm_kernel(DbParams p) {
 // loads and transforms two of the eight B fragments, parks them in LDS (double-buffered, one barrier per super-step), and all
 // four read the eight fragments back with conflict-free ds_read_b128 -- 2.8 instructions per MFMA instead of 10.
 // A operands: fragment image, three k-steps in flight, as in pw_bf16pm_kernel.
-template <int TM, bool OUT_PM>
+template <int TM, bool OUT_PM, bool ST = false>
 __global__ __launch_bounds__(256, 2) void pw_bf16pm_affs_kernel(DbParams p) {
+    static_assert(!ST || OUT_PM, "statistics of the stored bf16 tensor");
     constexpr int TN = 2, SS = 4;                          // position tiles per wave, k-steps per super-step
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     float *aff_tab = reinterpret_cast<float *>(lds);       // [kst][2 halves][16]
@@ -335,6 +384,11 @@ __global__ __launch_bounds__(256, 2) void pw_bf16pm_affs_kernel(DbParams p) {
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
         if (t0 + tm >= p.nt) continue;
+        float sv[ST ? 32 : 1];
+        if constexpr (ST) {
+#pragma unroll
+            for (int i = 0; i < 32; ++i) sv[i] = 0.f;
+        }
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
             const long long c = pos0 + tn * 32 + col;
@@ -350,6 +404,7 @@ __global__ __launch_bounds__(256, 2) void pw_bf16pm_affs_kernel(DbParams p) {
                         if (p.act == ACT_RELU) v[i] = db_relu2(v[i]);
                     }
                     *reinterpret_cast<u32x4 *>(yp + 16 * jj) = v;
+                    if constexpr (ST) db_stats_acc(sv, jj, v);
                 }
             } else {
                 const int row0 = 32 * (t0 + tm) + 4 * h;
@@ -361,6 +416,8 @@ __global__ __launch_bounds__(256, 2) void pw_bf16pm_affs_kernel(DbParams p) {
                 }
             }
         }
+        if constexpr (ST)
+            db_stats_tile(sv, col, h, t0 + tm, p.cout, p.stats + (size_t)b * p.cout * p.st_t * 2, p.st_t, (int)(pos0 >> 6));
     }
 }
 
@@ -413,19 +470,19 @@ __global__ __launch_bounds__(256) void gn_stats_bf16pm_kernel(int c, int cp, lon
     }
 }
 
-template <int TM, bool OUT_PM>
+template <int TM, bool OUT_PM, bool ST = false>
 int db_launch_affs(int b, const DbParams &p, hipStream_t s) {
     dim3 grid((unsigned)((p.L + 63) / 64), (p.nt + 4 * TM - 1) / (4 * TM), b);
     const int lds = (p.kst * 32 * 4 + 1023) / 1024 * 1024 + 2 * 4 * 2 * 1024;
-    CAPTRA_LAUNCH("pointwise_mlp", (pw_bf16pm_affs_kernel<TM, OUT_PM>), grid, dim3(256), lds, s, p);
+    CAPTRA_LAUNCH("pointwise_mlp", (pw_bf16pm_affs_kernel<TM, OUT_PM, ST>), grid, dim3(256), lds, s, p);
     return captra_last_error();
 }
 
-template <int TM, int TN, bool IN_PM, bool AFF, bool OUT_PM>
+template <int TM, int TN, bool IN_PM, bool AFF, bool OUT_PM, bool ST = false>
 int db_launch(int b, const DbParams &p, hipStream_t s) {
     dim3 grid((unsigned)((p.L + 4 * TN * 32 - 1) / (4 * TN * 32)), (p.nt + TM - 1) / TM, b);
     const int lds = AFF ? p.kst * 32 * 4 : 0;
-    CAPTRA_LAUNCH("pointwise_mlp", (pw_bf16pm_kernel<TM, TN, IN_PM, AFF, OUT_PM>), grid, dim3(256), lds, s, p);
+    CAPTRA_LAUNCH("pointwise_mlp", (pw_bf16pm_kernel<TM, TN, IN_PM, AFF, OUT_PM, ST>), grid, dim3(256), lds, s, p);
     return captra_last_error();
 }
 
@@ -452,27 +509,32 @@ extern "C" int captra_pack_dense_bf16(int cin, int cout, int perm, const float *
 // One dense layer.  in_pm: x is (B,L,ceil32(cin)) bf16 slot order (image packed with perm = 1), else (B,cin,L) fp32 (perm = 0).
 // ab (in_pm only): (B,cin,2) GroupNorm coefficients of the producing layer, applied as relu(a x + b) on load; or NULL.
 // out_pm: y is (B,L,ceil32(cout)) bf16 slot order, else (B,cout,L) fp32.  act: CAPTRA_ACT_NONE / RELU (out_pm), any (fp32 out).
-extern "C" int captra_pointwise_mlp_bf16pm(int b, int cin, int cout, long long l, int in_pm, const void *x, const unsigned char *wimg,
-                                           const float *bias_packed, const float *ab, int act, int out_pm, void *y, captra_stream_t stream) {
+static int db_dispatch(int b, int cin, int cout, long long l, int in_pm, const void *x, const unsigned char *wimg, const float *bias_packed,
+                       const float *ab, int act, int out_pm, void *y, float *stats, hipStream_t s) {
     if (b < 0 || cin < 1 || cout < 1 || l < 0 || act < 0 || act > 2) return -1;
     if (ab != nullptr && !in_pm) return -1;
     if (out_pm && act == ACT_SIGMOID_M05) return -1;
+    if (stats != nullptr && !out_pm) return -1;
     const int cp_in = (cin + 31) / 32 * 32, cp_out = (cout + 31) / 32 * 32;
     if (in_pm ? l * cp_in * 2 >= (1ll << 31) : (long long)cin * l * 4 >= (1ll << 31)) return -2;
     if (b == 0 || l == 0) return 0;
     DbParams p;
     p.cin = cin; p.cout = cout; p.kst = (cin + 15) / 16; p.nt = (cout + 31) / 32; p.cp_in = cp_in; p.cp_out = cp_out; p.L = l;
     p.x = x; p.wimg = wimg; p.bias = bias_packed; p.ab = ab; p.y = y; p.act = act;
+    p.stats = stats; p.st_t = (int)((l + 63) / 64);
     if (ab != nullptr && p.kst * 32 * 4 > 64 * 1024) return -2;
-    hipStream_t s = (hipStream_t)stream;
+    const bool st = stats != nullptr;
     if (in_pm && ab != nullptr && p.nt >= 8 && g_db_affs) {
         // wide GroupNorm-consuming layers: the operand transformed once per workgroup and shared through LDS
-        if (p.nt >= 16) return out_pm ? db_launch_affs<4, true>(b, p, s) : db_launch_affs<4, false>(b, p, s);
-        return out_pm ? db_launch_affs<2, true>(b, p, s) : db_launch_affs<2, false>(b, p, s);
+        if (p.nt >= 16) return st ? db_launch_affs<4, true, true>(b, p, s) : out_pm ? db_launch_affs<4, true>(b, p, s) : db_launch_affs<4, false>(b, p, s);
+        return st ? db_launch_affs<2, true, true>(b, p, s) : out_pm ? db_launch_affs<2, true>(b, p, s) : db_launch_affs<2, false>(b, p, s);
     }
     const bool wide = p.nt >= 4;
 #define DB_GO(TM_, TN_)                                                                              \
     do {                                                                                             \
+        if (st && in_pm && ab) return db_launch<TM_, TN_, true, true, true, true>(b, p, s);          \
+        if (st && in_pm) return db_launch<TM_, TN_, true, false, true, true>(b, p, s);               \
+        if (st) return db_launch<TM_, TN_, false, false, true, true>(b, p, s);                       \
         if (in_pm && ab && out_pm) return db_launch<TM_, TN_, true, true, true>(b, p, s);            \
         if (in_pm && ab) return db_launch<TM_, TN_, true, true, false>(b, p, s);                     \
         if (in_pm && out_pm) return db_launch<TM_, TN_, true, false, true>(b, p, s);                 \
@@ -484,6 +546,21 @@ extern "C" int captra_pointwise_mlp_bf16pm(int b, int cin, int cout, long long l
     if (p.nt >= 2) DB_GO(2, 2);
     DB_GO(1, 2);
 #undef DB_GO
+}
+
+extern "C" int captra_pointwise_mlp_bf16pm(int b, int cin, int cout, long long l, int in_pm, const void *x, const unsigned char *wimg,
+                                           const float *bias_packed, const float *ab, int act, int out_pm, void *y, captra_stream_t stream) {
+    return db_dispatch(b, cin, cout, l, in_pm, x, wimg, bias_packed, ab, act, out_pm, y, nullptr, (hipStream_t)stream);
+}
+
+// The same layer with a point-major bf16 output, also leaving the GroupNorm partial statistics of what it stored:
+// stats (B,T,cout,2) fp32 TILE-major, T = captra_dense_bf16_stats_tiles(l) (chunks of 64 positions), for captra_gn_finalize_tm.
+extern "C" int captra_dense_bf16_stats_tiles(long long l) { return (int)((l + 63) / 64); }
+extern "C" int captra_pointwise_mlp_bf16pm_stats(int b, int cin, int cout, long long l, int in_pm, const void *x, const unsigned char *wimg,
+                                                 const float *bias_packed, const float *ab, int act, void *y, float *stats,
+                                                 captra_stream_t stream) {
+    if (stats == nullptr) return -1;
+    return db_dispatch(b, cin, cout, l, in_pm, x, wimg, bias_packed, ab, act, 1, y, stats, (hipStream_t)stream);
 }
 
 extern "C" int captra_gn_stats_bf16pm_tiles(long long l) { return (int)((l + 127) / 128); }

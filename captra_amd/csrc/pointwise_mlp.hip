@@ -599,6 +599,9 @@ __global__ __launch_bounds__(256) void pw_direct_max_kernel(PwParams p) {
 
 // One wave per (cloud, group): fixed-order double-precision sum of the partials -> mean, rstd -> per-channel (a, b) with
 // GroupNorm(x) = a*x + b  (a = gamma*rstd, b = beta - mean*a).
+// TILE_MAJOR: stats (B,t,c,2) instead of (B,c,t,2) (the bf16 dense layers' statistics epilogue writes a wave's 32 channels of
+// one chunk as 256 contiguous bytes).
+template <bool TILE_MAJOR>
 __global__ __launch_bounds__(256) void gn_finalize_kernel(int nb, int c, int cpg, int t, long long n, float eps,
                                                           const float *__restrict__ stats, const float *__restrict__ gamma,
                                                           const float *__restrict__ beta, float *__restrict__ ab) {
@@ -607,13 +610,22 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(int nb, int c, int cpg
     const int groups = c / cpg;
     if (e >= nb * groups) return;  // wave-uniform
     const int bi = e / groups, g = e % groups;
-    // the group's partials are contiguous: cpg channels x t tiles x (sum, sumsq)
-    const float2 *s2 = reinterpret_cast<const float2 *>(stats + ((size_t)bi * c + (size_t)g * cpg) * t * 2);
     double sm = 0.0, sq = 0.0;
-    for (int i = lane; i < cpg * t; i += 64) {
-        const float2 v = s2[i];
-        sm += (double)v.x;
-        sq += (double)v.y;
+    if (TILE_MAJOR) {
+        const float2 *s2 = reinterpret_cast<const float2 *>(stats + (size_t)bi * c * t * 2) + (size_t)g * cpg;
+        for (int i = lane; i < cpg * t; i += 64) {
+            const float2 v = s2[(size_t)(i / cpg) * c + (i % cpg)];
+            sm += (double)v.x;
+            sq += (double)v.y;
+        }
+    } else {
+        // the group's partials are contiguous: cpg channels x t tiles x (sum, sumsq)
+        const float2 *s2 = reinterpret_cast<const float2 *>(stats + ((size_t)bi * c + (size_t)g * cpg) * t * 2);
+        for (int i = lane; i < cpg * t; i += 64) {
+            const float2 v = s2[i];
+            sm += (double)v.x;
+            sq += (double)v.y;
+        }
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
@@ -824,7 +836,19 @@ extern "C" int captra_gn_finalize(int b, int c, int channels_per_group, int stat
     if (b < 0 || c < 1 || channels_per_group < 1 || c % channels_per_group != 0 || stats_t < 1 || n < 1) return -1;
     if (b == 0) return 0;
     const int total = b * (c / channels_per_group);
-    CAPTRA_LAUNCH("gn_finalize", gn_finalize_kernel, dim3((total + 3) / 4), dim3(256), 0, (hipStream_t)stream, b, c,
+    CAPTRA_LAUNCH("gn_finalize", gn_finalize_kernel<false>, dim3((total + 3) / 4), dim3(256), 0, (hipStream_t)stream, b, c,
+                  channels_per_group, stats_t, n, eps, stats, gamma, beta, ab);
+    return captra_last_error();
+}
+
+// The same for TILE-major partials, stats (B,stats_t,c,2) (captra_pointwise_mlp_bf16pm_stats).
+extern "C" int captra_gn_finalize_tm(int b, int c, int channels_per_group, int stats_t, long long n, float eps,
+                                     const float *stats, const float *gamma, const float *beta, float *ab,
+                                     captra_stream_t stream) {
+    if (b < 0 || c < 1 || channels_per_group < 1 || c % channels_per_group != 0 || stats_t < 1 || n < 1) return -1;
+    if (b == 0) return 0;
+    const int total = b * (c / channels_per_group);
+    CAPTRA_LAUNCH("gn_finalize", gn_finalize_kernel<true>, dim3((total + 3) / 4), dim3(256), 0, (hipStream_t)stream, b, c,
                   channels_per_group, stats_t, n, eps, stats, gamma, beta, ab);
     return captra_last_error();
 }

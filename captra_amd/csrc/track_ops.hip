@@ -302,6 +302,18 @@ __global__ __launch_bounds__(256) void copy_multi_kernel(CopyMulti m) {
     }
 }
 
+// The packed pose record of the per-frame exchange (captra_amd/parallel.py: [R(9) t(3) s(1) valid(1)] per trajectory and part)
+__global__ __launch_bounds__(256) void pack_pose_kernel(int n, const float *__restrict__ rot, const float *__restrict__ trans,
+                                                        const float *__restrict__ scale, const float *__restrict__ valid,
+                                                        float *__restrict__ out0, float *__restrict__ out1) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= n * 14) return;
+    const int r = e / 14, f = e - r * 14;
+    const float v = f < 9 ? rot[r * 9 + f] : f < 12 ? trans[r * 3 + (f - 9)] : f == 12 ? scale[r] : (valid != nullptr ? valid[r] : 1.f);
+    out0[e] = v;
+    if (out1 != nullptr) out1[e] = v;
+}
+
 }  // namespace
 
 extern "C" int captra_canonicalize(int b, int p, int n, const float *pts, const float *mean, const float *rot,
@@ -388,5 +400,16 @@ extern "C" int captra_copy_multi(int njobs, const void *const *src, void *const 
     long long blocks = (most / 4 + 255) / 256;
     blocks = blocks < 1 ? 1 : (blocks > 256 ? 256 : blocks);
     CAPTRA_LAUNCH("copy_multi", copy_multi_kernel, dim3((unsigned)blocks, njobs), dim3(256), 0, (hipStream_t)stream, m);
+    return captra_last_error();
+}
+
+// n = B*P pose records [R(9) t(3) s(1) valid(1)] from rot (n,3,3), trans (n,3), scale (n), valid (n) floats (NULL = all 1)
+// -> out0 (n,14) and, when non-NULL, a second copy out1: the per-frame exchange's packing in one launch.
+extern "C" int captra_pack_pose(int n, const float *rot, const float *trans, const float *scale, const float *valid, float *out0,
+                                float *out1, captra_stream_t stream) {
+    if (n < 0) return -1;
+    if (n == 0) return 0;
+    CAPTRA_LAUNCH("pack_pose", pack_pose_kernel, dim3((n * 14 + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, rot, trans, scale,
+                  valid, out0, out1);
     return captra_last_error();
 }

@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import contextlib
 import ctypes as C
+import os
 import threading
 
 import torch
@@ -177,11 +178,25 @@ def pm_channels(c: int) -> int:
     return (c + 31) // 32 * 32
 
 
-def pointwise_mlp_bf16pm(x, lin: PackedLinear, l: int, in_pm: bool, out_pm: bool, ab=None, act: int = ACT_NONE):
+USE_STATS_EPILOGUE = os.environ.get("CAPTRA_STATS_EPILOGUE", "1") != "0"   # bf16 GroupNorm chains: the producing layer leaves the partial statistics of what it stored
+
+
+def pointwise_mlp_bf16pm(x, lin: PackedLinear, l: int, in_pm: bool, out_pm: bool, ab=None, act: int = ACT_NONE, with_stats: bool = False):
     """One bf16-native dense layer (captra_pointwise_mlp_bf16pm).  x: (B,cin,l) fp32, or (B,l,ceil32(cin)) bf16 slot order when
     in_pm; result (B,cout,l) fp32, or (B,l,ceil32(cout)) bf16 slot order when out_pm.  ab (B,cin,2): GroupNorm coefficients of
-    the producer, applied as relu(a x + b) on load."""
+    the producer, applied as relu(a x + b) on load.  with_stats (out_pm): -> (y, stats (B,T,cout,2), TILE-major), the partial (sum, sum of
+    squares) of the STORED values per chunk of 64 positions, written by the layer's own epilogue (captra_pointwise_mlp_bf16pm_stats)."""
     B = x.shape[0]
+    if with_stats:
+        assert out_pm
+        L.require_device(x, ab)
+        y = torch.empty(B, l, pm_channels(lin.cout), dtype=torch.bfloat16, device=x.device)
+        stats = torch.empty(B, L.lib().captra_dense_bf16_stats_tiles(l), lin.cout, 2, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            L.call("captra_pointwise_mlp_bf16pm_stats", B, lin.cin, lin.cout, l, 1 if in_pm else 0, L.ptr(x), L.ptr(lin.bf16_frag(in_pm)),
+                   L.ptr(lin.bias), L.ptr(ab), act, L.ptr(y), L.ptr(stats))
+        _work("pointwise_mlp", flops=2.0 * B * lin.cin * lin.cout * l, nbytes=B * l * ((2.0 if in_pm else 4.0) * lin.cin + 2.0 * lin.cout))
+        return y, stats
     L.require_device(x, ab)
     if in_pm:
         assert x.dtype == torch.bfloat16 and tuple(x.shape) == (B, l, pm_channels(lin.cin)), (x.shape, lin.cin, l)
@@ -483,13 +498,17 @@ def pointwise_mlp_gn(x, lin: PackedLinear, ab_in=None, act: int = ACT_NONE, want
     return (y, stats) if want_stats else y
 
 
-def gn_finalize(stats, num_groups: int, gamma, beta, eps: float, n: int):
-    """stats (B,C,T,2) partial (sum, sum of squares) -> ab (B,C,2) with GroupNorm(x) = a*x + b."""
+def gn_finalize(stats, num_groups: int, gamma, beta, eps: float, n: int, tile_major: bool = False):
+    """stats (B,C,T,2) -- or (B,T,C,2) when tile_major -- partial (sum, sum of squares) -> ab (B,C,2) with GroupNorm(x) = a*x + b."""
     L.require_device(stats, gamma, beta)
-    B, C, T, _ = stats.shape
+    if tile_major:
+        B, T, C, _ = stats.shape
+    else:
+        B, C, T, _ = stats.shape
     ab = torch.empty(B, C, 2, dtype=torch.float32, device=stats.device)
     with torch.cuda.device(stats.device):
-        L.call("captra_gn_finalize", B, C, C // num_groups, T, n, float(eps), L.ptr(stats), L.ptr(gamma), L.ptr(beta), L.ptr(ab))
+        L.call("captra_gn_finalize_tm" if tile_major else "captra_gn_finalize", B, C, C // num_groups, T, n, float(eps),
+               L.ptr(stats), L.ptr(gamma), L.ptr(beta), L.ptr(ab))
     return ab
 
 

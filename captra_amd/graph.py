@@ -170,13 +170,18 @@ class TrackStepGraph:
         if self.stale():
             raise RuntimeError("the model's weights changed after this hipGraph was captured (train()/load_state_dict()/.to()); "
                                "capture a new TrackStepGraph")
-        self.points.copy_(points)
-        self.points_mean.copy_(points_mean)
+        pairs = [(points, self.points), (points_mean, self.points_mean)]
         if pose is not self.pose:          # (a lane of TrackLanes hands its pose over in place)
-            for k in self.pose:
-                self.pose[k].copy_(pose[k])
+            pairs += [(pose[k], self.pose[k]) for k in self.pose]
         if self.labels is not None and labels is not None:
-            self.labels.copy_(labels)
+            pairs.append((labels, self.labels))
+        # the step's inputs into the captured buffers: one launch when they are plain device tensors of the captured types
+        if all(a.is_cuda and a.is_contiguous() and a.dtype == b.dtype and a.shape == b.shape and a.element_size() % 4 == 0 for a, b in pairs):
+            from . import fused
+            fused.copy_multi(pairs)
+        else:
+            for a, b in pairs:
+                b.copy_(a)
         self._replay_graphs()
         return self.out_pose
 

@@ -53,8 +53,27 @@ class PoseExchange:
         self.handle = None
 
     def all_gather(self, pose: dict, valid: torch.Tensor | None = None, async_op: bool = False) -> torch.Tensor:
+        if self._pack_on_device(pose, valid):
+            return self.gathered if not self.collective else self.all_gather_packed(async_op)
         self.local.copy_(pack_pose(pose, valid))
         return self.all_gather_packed(async_op)
+
+    def _pack_on_device(self, pose: dict, valid) -> bool:
+        """One launch for the packing (and, on a single rank without a collective, the "gathered" copy) instead of a cat, a
+        fill and two or three copies per frame; False when the tensors are not what the kernel takes."""
+        if not self.local.is_cuda:
+            return False
+        t = [pose["rotation"], pose["translation"], pose["scale"]] + ([] if valid is None else [valid])
+        if not all(x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() for x in t):
+            return False
+        n = self.local.shape[0] * self.local.shape[1]
+        if pose["scale"].numel() != n:
+            return False
+        from . import _lib as L
+        with torch.cuda.device(self.local.device):
+            L.call("captra_pack_pose", n, L.ptr(t[0]), L.ptr(t[1]), L.ptr(t[2]), None if valid is None else L.ptr(valid),
+                   L.ptr(self.local), None if self.collective else L.ptr(self.gathered))
+        return True
 
     def all_gather_packed(self, async_op: bool = False) -> torch.Tensor:
         """All-gather whatever `self.local` holds (records packed by the caller, e.g. a short batch padded with invalid ones)."""

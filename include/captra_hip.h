@@ -239,12 +239,22 @@ int captra_sa_scale_bf16(int b, int n, int m, int k, int cfeat, int c1, int c2, 
  *     (in_pm only): (B,cin,2) GroupNorm coefficients of the layer that produced x, applied as relu(a x + b) while the operand is
  *     loaded (blocks.py:150-165's GroupNorm + ReLU without a pass of its own).
  *   captra_gn_stats_bf16pm: per-channel partial (sum, sum of squares) of a STORED tensor over chunks of 128 positions ->
- *     stats (B,c,T,2), T = captra_gn_stats_bf16pm_tiles(l); captra_gn_finalize turns them into ab. */
+ *     stats (B,c,T,2), T = captra_gn_stats_bf16pm_tiles(l); captra_gn_finalize turns them into ab.
+ *   captra_pointwise_mlp_bf16pm_stats: the layer with a point-major output that ALSO leaves those partial statistics of what it
+ *     stored, from its own epilogue (no second pass over the tensor): stats (B,T,cout,2) TILE-major, T =
+ *     captra_dense_bf16_stats_tiles(l) (chunks of 64 positions; fixed summation order, no atomics); captra_gn_finalize_tm
+ *     is captra_gn_finalize for that layout. */
 long long captra_dense_bf16_image_bytes(int cin, int cout);
 int captra_pack_dense_bf16(int cin, int cout, int perm, const float *wt_packed, unsigned char *img, captra_stream_t stream);
 int captra_pointwise_mlp_bf16pm(int b, int cin, int cout, long long l, int in_pm, const void *x, const unsigned char *wimg,
                                 const float *bias_packed, const float *ab, int act, int out_pm, void *y, captra_stream_t stream);
 int captra_gn_stats_bf16pm_tiles(long long l);
+int captra_dense_bf16_stats_tiles(long long l);
+int captra_gn_finalize_tm(int b, int c, int channels_per_group, int stats_t, long long n, float eps, const float *stats,
+                          const float *gamma, const float *beta, float *ab, captra_stream_t stream);
+int captra_pointwise_mlp_bf16pm_stats(int b, int cin, int cout, long long l, int in_pm, const void *x, const unsigned char *wimg,
+                                      const float *bias_packed, const float *ab, int act, void *y, float *stats,
+                                      captra_stream_t stream);
 int captra_gn_stats_bf16pm(int b, int c, long long l, const void *x, float *stats, captra_stream_t stream);
 
 /* bf16 mode, register-resident dense CHAIN (csrc/sa_bf16.hip): FP1's shared MLP + the backbone's conv1 (+ CoordinateNet's two heads)
@@ -374,6 +384,12 @@ int captra_seg_softmax_argmax(int b, int s, int n, const float *logits, float *s
 /* njobs <= 16 device-to-device copies (bytes[j] % 4 == 0, 4-byte aligned) in one launch: host arrays of DEVICE pointers.  The
  * lanes' per-frame pose / record hand-over. */
 int captra_copy_multi(int njobs, const void *const *src, void *const *dst, const long long *bytes, captra_stream_t stream);
+
+/* The packed pose records of the per-frame exchange (no reference counterpart: the reference is one
+ * process): n = B*P records [R(9) t(3) s(1) valid(1)] from rot (n,3,3), trans (n,3), scale (n), valid (n) floats (NULL = 1)
+ * -> out0 (n,14) and, when non-NULL, a second copy out1 (the single-rank "gathered" buffer). */
+int captra_pack_pose(int n, const float *rot, const float *trans, const float *scale, const float *valid, float *out0,
+                     float *out1, captra_stream_t stream);
 
 /* Rotation read-out of one tracking step (blocks.py:147-156, networks.py:127-138 and 200-203,
  * part_dof_utils.py:124-141, rotations.py:302-387) in one launch.  raw = the rotation heads' raw outputs on the B*P

@@ -125,3 +125,22 @@ def test_bench_under_a_launcher_runs_its_exchange_through_rccl_at_world1(device)
     out = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
     assert out["collective_backend"] == "nccl (RCCL)" and out["rccl_world_size"] == 1 and out["n_gpus"] == 1
     assert "2 free-running lanes" in out["config"]["launch"] and out["pose_match"]["within_1e-4"]
+
+
+def test_pose_exchange_packs_on_the_device_like_pack_pose(device):
+    """PoseExchange.all_gather on CUDA tensors packs the records with one kernel (captra_pack_pose) — the same (B,P,14)
+    records as parallel.pack_pose, with and without a validity mask, also for non-contiguous inputs (torch path)."""
+    from captra_amd.parallel import PoseExchange, pack_pose, unpack_pose
+    g = torch.Generator().manual_seed(3)
+    B, P = 5, 3
+    pose = {"rotation": torch.randn(B, P, 3, 3, generator=g).to(device), "translation": torch.randn(B, P, 3, 1, generator=g).to(device),
+            "scale": torch.rand(B, P, generator=g).to(device)}
+    valid = (torch.rand(B, P, generator=g) > 0.4).float().to(device)
+    ex = PoseExchange(B, P, device)
+    assert torch.equal(ex.all_gather(pose).clone(), pack_pose(pose))
+    assert torch.equal(ex.local, pack_pose(pose))
+    assert torch.equal(ex.all_gather(pose, valid).clone(), pack_pose(pose, valid))
+    back, ok = unpack_pose(ex.gathered)
+    assert torch.equal(back["rotation"], pose["rotation"]) and torch.equal(ok, valid > 0.5)
+    strided = dict(pose, rotation=pose["rotation"].transpose(2, 3))
+    assert torch.equal(ex.all_gather(strided).clone(), pack_pose(strided))

@@ -984,6 +984,21 @@ def test_bf16pm_dense_layer_layouts_and_groupnorm_on_load(device, cin, cout, l):
     stats = fused.gn_stats_bf16pm(xpm, cin).cpu().numpy().astype(np.float64)
     np.testing.assert_allclose(stats[..., 0].sum(-1), x.astype(np.float64).sum(-1), atol=1e-3 * np.sqrt(l), rtol=1e-5)
     np.testing.assert_allclose(stats[..., 1].sum(-1), (x.astype(np.float64) ** 2).sum(-1), rtol=2e-5)
+    # the same statistics left by the producing layer's own epilogue (chunks of 64 positions, fixed order): of what it STORED,
+    # and the stored tensor bit-identical to the plain launch's
+    for src, in_pm in ((_dev(x, device), False), (xpm, True)):
+        ys, st = fused.pointwise_mlp_bf16pm(src, lin, l, in_pm=in_pm, out_pm=True, with_stats=True)
+        plain = fused.pointwise_mlp_bf16pm(src, lin, l, in_pm=in_pm, out_pm=True)
+        assert torch.equal(ys.view(torch.int16), plain.view(torch.int16))
+        stored = _pm_to_dense(ys, cout).astype(np.float64)
+        st = st.cpu().numpy().astype(np.float64)
+        assert st.shape == (B, (l + 63) // 64, cout, 2)                                     # tile-major
+        for t in range(st.shape[1]):
+            seg = stored[:, :, 64 * t:64 * t + 64]
+            np.testing.assert_allclose(st[:, t, :, 0], seg.sum(-1), atol=1e-4 * max(1.0, np.abs(seg).max()), rtol=1e-5)
+            np.testing.assert_allclose(st[:, t, :, 1], (seg ** 2).sum(-1), atol=1e-6, rtol=1e-5)
+        st2 = fused.pointwise_mlp_bf16pm(src, lin, l, in_pm=in_pm, out_pm=True, with_stats=True)[1]
+        assert torch.equal(st2.cpu(), torch.from_numpy(st.astype(np.float32)))              # no atomics: run-to-run identical
     # on-load GroupNorm: x -> bf16(relu(a x + b))
     ab = rng.standard_normal((B, cin, 2)).astype(np.float32)
     xn = _bf16_round(np.maximum(np.float32(ab[:, :, 0:1]) * x + np.float32(ab[:, :, 1:2]), 0).astype(np.float32))
@@ -992,6 +1007,13 @@ def test_bf16pm_dense_layer_layouts_and_groupnorm_on_load(device, cin, cout, l):
     err = np.abs(y3 - refn)
     scale = max(1.0, float(np.abs(refn).max()))
     assert err.max() <= 2e-2 * scale and err.mean() <= 1e-4 * scale, (err.max() / scale, err.mean() / scale)   # fma vs mul+add on a rounding tie
+    # ... and with the statistics epilogue (the shared-operand kernel for the wide layers): same stored tensor, its sums
+    y4, st4 = fused.pointwise_mlp_bf16pm(xpm, lin, l, in_pm=True, out_pm=True, ab=_dev(ab, device), with_stats=True)
+    assert torch.equal(y4.view(torch.int16), fused.pointwise_mlp_bf16pm(xpm, lin, l, in_pm=True, out_pm=True, ab=_dev(ab, device)).view(torch.int16))
+    stored = _pm_to_dense(y4, cout).astype(np.float64)
+    st4 = st4.cpu().numpy().astype(np.float64)
+    np.testing.assert_allclose(st4[..., 0].sum(1), stored.sum(-1), atol=1e-3 * max(1.0, np.abs(stored).max()), rtol=1e-5)
+    np.testing.assert_allclose(st4[..., 1].sum(1), (stored ** 2).sum(-1), atol=1e-6, rtol=2e-5)
 
 
 def test_bf16_rotation_head_chain_vs_torch(device):
