@@ -19,6 +19,8 @@ import pickle
 from copy import deepcopy
 from os.path import join as pjoin
 
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -81,6 +83,7 @@ class EvalTrackModel(BaseModel):
         # single-part objects: RotationNet canonicalises with the very pose CoordNet used, so both nets see
         # the same cloud and FPS / ball query / 3-NN run once per frame instead of twice
         self.share_geometry = True
+        self.overlap_geometry = os.environ.get("CAPTRA_OVERLAP_GEOM", "1") != "0"   # the shared geometry's two levels side by side
         self.overlap_nets = True     # CoordinateNet and RotationNet side by side on two streams (one part: they share the cloud)
         # replay one captured hipGraph per frame instead of launching the ~140 kernels of a step one by one
         # (captra_amd/graph.py); opt-in: `--hipgraph` of captra_amd.track / cfg['hipgraph'].  Same kernels, same bits.
@@ -179,12 +182,12 @@ class EvalTrackModel(BaseModel):
             npcs_input.pop(k, None)
         input.pop("_raw", None)
 
-    def _step_prep(self, input, npcs_input, last_pose, level1_only=False) -> bool:
+    def _step_prep(self, input, npcs_input, last_pose, level1_only=False, side=None) -> bool:
         """The part both networks wait for: CoordinateNet's canonicalised cloud and its geometry (sampling, neighbour lists,
         interpolation weights).  False when the cloud does not fit the one-launch sampler (no side-by-side schedule then)."""
         from .networks import _canonicalize
         cam = _canonicalize(npcs_input["points"], npcs_input["points_mean"], npcs_input["canon_pose"])
-        geom = self.npcs_net.backbone.precompute_geometry(cam[1], level1_only=level1_only)
+        geom = self.npcs_net.backbone.precompute_geometry(cam[1], level1_only=level1_only, side=side)
         if geom is None:
             return False
         npcs_input["_canon"], npcs_input["_geom"] = cam, geom
@@ -236,13 +239,13 @@ class EvalTrackModel(BaseModel):
 
     def _fork_rotation_net(self, input, npcs_input, last_pose):
         small = len(input["points"]) <= 2      # one or two trajectories: every kernel is latency-bound, overlap all that can be (no gain from 4 up)
-        if not self._step_prep(input, npcs_input, last_pose, level1_only=small):
-            return None
-        dev = npcs_input["_canon"][0].device
-        main = torch.cuda.current_stream(dev)
+        dev = input["points"].device
         if getattr(self, "_side", None) is None:
             self._side = torch.cuda.Stream(device=dev)
         side = self._side
+        if not self._step_prep(input, npcs_input, last_pose, level1_only=small, side=side if self.overlap_geometry else None):
+            return None
+        main = torch.cuda.current_stream(dev)
         side.wait_stream(main)
         with torch.cuda.stream(side):
             raw = self._step_rot(input, npcs_input, last_pose)
