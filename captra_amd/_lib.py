@@ -52,6 +52,7 @@ _SIGNATURES = {
     "captra_pointwise_mlp_bf16_pm": [_INT, _INT, _INT, _LL, _P, _P, _P, _INT, _P, _P],
     "captra_pack_dense_bf16": [_INT, _INT, _INT, _P, _P, _P],
     "captra_pointwise_mlp_bf16pm": [_INT, _INT, _INT, _LL, _INT, _P, _P, _P, _P, _INT, _INT, _P, _P],
+    "captra_pointwise_mlp_bf16pm_cb": [_INT, _INT, _INT, _LL, _INT, _P, _P, _P, _INT, _INT, _P, _P],
     "captra_pointwise_mlp_bf16pm_stats": [_INT, _INT, _INT, _LL, _INT, _P, _P, _P, _P, _INT, _P, _P, _P],
     "captra_gn_stats_bf16pm": [_INT, _INT, _LL, _P, _P, _P],
     "captra_mlp_chain_bf16": [_INT, _INT, _LL, _INT, _INT, _INT, _P, _P, _P, _P, _P, _P],
@@ -73,6 +74,7 @@ _SIGNATURES = {
     "captra_part_fit_st_track": [_INT, _INT, _INT, _INT, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "captra_seg_softmax_argmax": [_INT, _INT, _INT, _P, _P, _P, _P],
     "captra_copy_multi": [_INT, _P, _P, _P, _P],
+    "captra_row_max": [_LL, _INT, _P, _P, _P],
     "captra_pack_pose": [_INT, _P, _P, _P, _P, _P, _P, _P],
     "captra_procrustes_rot3": [_INT, _INT, _P, _P, _P, _P],
 }

@@ -58,7 +58,8 @@ struct DbParams {
     long long L;
     const void *x;            // IN_PM: (B,L,cp_in) bf16 slot order; else (B,cin,L) fp32
     const unsigned char *wimg;
-    const float *bias;        // packed fp32 (ceil128(cout))
+    const float *bias;        // packed fp32 (ceil128(cout)); cloud b reads bias + b * bias_bs (0: one bias for all)
+    long long bias_bs;
     const float *ab;          // AFF: (B,cin,2) fp32
     void *y;                  // OUT_PM: (B,L,cp_out) bf16 slot order; else (B,cout,L) fp32
     int act;
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(256, 2) void pw_bf16pm_kernel(DbParams p) {
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
-        const float *bp = p.bias + (t0 + tm < p.nt ? t0 + tm : p.nt - 1) * 32 + 4 * h;
+        const float *bp = p.bias + (size_t)b * p.bias_bs + (t0 + tm < p.nt ? t0 + tm : p.nt - 1) * 32 + 4 * h;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float bv = bp[(r & 3) + 8 * (r >> 2)];
@@ -317,7 +318,7 @@ __global__ __launch_bounds__(256, 2) void pw_bf16pm_affs_kernel(DbParams p) {
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
-        const float *bp = p.bias + (t0 + tm < p.nt ? t0 + tm : p.nt - 1) * 32 + 4 * h;
+        const float *bp = p.bias + (size_t)b * p.bias_bs + (t0 + tm < p.nt ? t0 + tm : p.nt - 1) * 32 + 4 * h;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float bv = bp[(r & 3) + 8 * (r >> 2)];
@@ -510,7 +511,7 @@ extern "C" int captra_pack_dense_bf16(int cin, int cout, int perm, const float *
 // ab (in_pm only): (B,cin,2) GroupNorm coefficients of the producing layer, applied as relu(a x + b) on load; or NULL.
 // out_pm: y is (B,L,ceil32(cout)) bf16 slot order, else (B,cout,L) fp32.  act: CAPTRA_ACT_NONE / RELU (out_pm), any (fp32 out).
 static int db_dispatch(int b, int cin, int cout, long long l, int in_pm, const void *x, const unsigned char *wimg, const float *bias_packed,
-                       const float *ab, int act, int out_pm, void *y, float *stats, hipStream_t s) {
+                       const float *ab, int act, int out_pm, void *y, float *stats, hipStream_t s, long long bias_bs = 0) {
     if (b < 0 || cin < 1 || cout < 1 || l < 0 || act < 0 || act > 2) return -1;
     if (ab != nullptr && !in_pm) return -1;
     if (out_pm && act == ACT_SIGMOID_M05) return -1;
@@ -522,6 +523,7 @@ static int db_dispatch(int b, int cin, int cout, long long l, int in_pm, const v
     p.cin = cin; p.cout = cout; p.kst = (cin + 15) / 16; p.nt = (cout + 31) / 32; p.cp_in = cp_in; p.cp_out = cp_out; p.L = l;
     p.x = x; p.wimg = wimg; p.bias = bias_packed; p.ab = ab; p.y = y; p.act = act;
     p.stats = stats; p.st_t = (int)((l + 63) / 64);
+    p.bias_bs = bias_bs;
     if (ab != nullptr && p.kst * 32 * 4 > 64 * 1024) return -2;
     const bool st = stats != nullptr;
     if (in_pm && ab != nullptr && p.nt >= 8 && g_db_affs) {
@@ -551,6 +553,14 @@ static int db_dispatch(int b, int cin, int cout, long long l, int in_pm, const v
 extern "C" int captra_pointwise_mlp_bf16pm(int b, int cin, int cout, long long l, int in_pm, const void *x, const unsigned char *wimg,
                                            const float *bias_packed, const float *ab, int act, int out_pm, void *y, captra_stream_t stream) {
     return db_dispatch(b, cin, cout, l, in_pm, x, wimg, bias_packed, ab, act, out_pm, y, nullptr, (hipStream_t)stream);
+}
+
+// The layer with a bias PER CLOUD: bias (B, cout) fp32, cout a multiple of 32 (a feature-propagation layer whose second input
+// is one vector per cloud -- pointnet_utils.py:265-268, S == 1: W [x; v 1^T] + b = W1 x + (W2 v + b) -- takes the bracket as its bias).
+extern "C" int captra_pointwise_mlp_bf16pm_cb(int b, int cin, int cout, long long l, int in_pm, const void *x, const unsigned char *wimg,
+                                              const float *bias_per_cloud, int act, int out_pm, void *y, captra_stream_t stream) {
+    if (cout % 32 != 0) return -1;
+    return db_dispatch(b, cin, cout, l, in_pm, x, wimg, bias_per_cloud, nullptr, act, out_pm, y, nullptr, (hipStream_t)stream, cout);
 }
 
 // The same layer with a point-major bf16 output, also leaving the GroupNorm partial statistics of what it stored:

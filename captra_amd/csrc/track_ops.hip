@@ -302,6 +302,28 @@ __global__ __launch_bounds__(256) void copy_multi_kernel(CopyMulti m) {
     }
 }
 
+// out[r] = max over the l floats of row r (group_all pooling of a (B,C,N) tensor: pointnet_utils.py:342 torch.max(new_points, 2)):
+// 32 lanes per row, 16-byte loads when the rows allow it
+__global__ __launch_bounds__(256) void row_max_kernel(long long rows, int l, const float *__restrict__ x, float *__restrict__ out) {
+    const long long r = (long long)blockIdx.x * 8 + (threadIdx.x >> 5);
+    const int lane = threadIdx.x & 31;
+    float m = -__builtin_inff();
+    if (r < rows) {
+        const float *row = x + r * l;
+        if ((l & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+            for (int i = lane * 4; i < l; i += 128) {
+                const float4 v = *reinterpret_cast<const float4 *>(row + i);
+                m = fmaxf(fmaxf(m, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+            }
+        } else {
+            for (int i = lane; i < l; i += 32) m = fmaxf(m, row[i]);
+        }
+    }
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 32));
+    if (r < rows && lane == 0) out[r] = m;
+}
+
 // The packed pose record of the per-frame exchange (captra_amd/parallel.py: [R(9) t(3) s(1) valid(1)] per trajectory and part)
 __global__ __launch_bounds__(256) void pack_pose_kernel(int n, const float *__restrict__ rot, const float *__restrict__ trans,
                                                         const float *__restrict__ scale, const float *__restrict__ valid,
@@ -411,5 +433,13 @@ extern "C" int captra_pack_pose(int n, const float *rot, const float *trans, con
     if (n == 0) return 0;
     CAPTRA_LAUNCH("pack_pose", pack_pose_kernel, dim3((n * 14 + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, rot, trans, scale,
                   valid, out0, out1);
+    return captra_last_error();
+}
+
+// out (rows) = max over each row of x (rows, l), l >= 1: the pooling of a group_all set abstraction on a (B,C,N) tensor (rows = B*C).
+extern "C" int captra_row_max(long long rows, int l, const float *x, float *out, captra_stream_t stream) {
+    if (rows < 0 || l < 1) return -1;
+    if (rows == 0) return 0;
+    CAPTRA_LAUNCH("row_max", row_max_kernel, dim3((unsigned)((rows + 7) / 8)), dim3(256), 0, (hipStream_t)stream, rows, l, x, out);
     return captra_last_error();
 }

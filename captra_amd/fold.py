@@ -78,6 +78,14 @@ class PackedLinear:
             self._bf16[key] = PackedLinear(self.wt2d[:rows, :self.cout].contiguous(), self.bias[:self.cout].contiguous())
         return self._bf16[key]
 
+    def trailing_rows(self, row0: int) -> "PackedLinear":
+        """The layer restricted to its input channels from `row0` on (same bias), cached with the layer."""
+        assert 0 <= row0 < self.cin
+        key = ("trail", row0)
+        if key not in self._bf16:
+            self._bf16[key] = PackedLinear(self.wt2d[row0:self.cin, :self.cout].contiguous(), self.bias[:self.cout].contiguous())
+        return self._bf16[key]
+
     def bf16(self, row0: int = 0, rows: int | None = None) -> torch.Tensor:
         """bf16 image of input rows [row0, row0+rows) of this layer for the bf16 kernels (include/captra_hip.h:
         Wb [ceil32(cout)][ceil32(rows)], untransposed, zero padded), built once per (row0, rows) on the device."""

@@ -114,6 +114,17 @@ def copy_multi(pairs) -> None:
                arr(C.c_longlong, [a.numel() * a.element_size() for a, _ in pairs]))
 
 
+def row_max(x):
+    """x (B,C,N) fp32 contiguous -> (B,C,1): max over the positions in one launch (captra_row_max)."""
+    L.require_device(x)
+    B, Cc, N = x.shape
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    out = torch.empty(B, Cc, 1, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        L.call("captra_row_max", B * Cc, N, L.ptr(x), L.ptr(out))
+    return out
+
+
 def pack(wt_dense, bias_dense) -> PackedLinear:
     """Dense W^T (cin,cout) + bias (cout) -> the packed layout the kernels take."""
     return PackedLinear(wt_dense.float(), bias_dense.float())
@@ -176,6 +187,22 @@ def pointwise_mlp(x, lin: PackedLinear, act: int = ACT_RELU, out=None):
 def pm_channels(c: int) -> int:
     """Channel stride of a point-major bf16 tensor (include/captra_hip.h "bf16-NATIVE dense layers")."""
     return (c + 31) // 32 * 32
+
+
+def pointwise_mlp_bf16pm_cloud_bias(x, lin: PackedLinear, l: int, bias_bc, out_pm: bool, act: int = ACT_NONE):
+    """The bf16-native dense layer on a channel-major fp32 x (B,cin,l) with a bias per cloud, bias_bc (B,cout) fp32
+    (captra_pointwise_mlp_bf16pm_cb): act(W x + bias_bc[b])."""
+    B = x.shape[0]
+    L.require_device(x, bias_bc)
+    assert x.dtype == torch.float32 and x.shape[1] == lin.cin and x.numel() == B * lin.cin * l and lin.cout % 32 == 0
+    assert bias_bc.dtype == torch.float32 and bias_bc.is_contiguous() and bias_bc.numel() == B * lin.cout
+    y = (torch.empty(B, l, pm_channels(lin.cout), dtype=torch.bfloat16, device=x.device) if out_pm
+         else torch.empty(B, lin.cout, l, dtype=torch.float32, device=x.device))
+    with torch.cuda.device(x.device):
+        L.call("captra_pointwise_mlp_bf16pm_cb", B, lin.cin, lin.cout, l, 0, L.ptr(x), L.ptr(lin.bf16_frag(False)), L.ptr(bias_bc), act,
+               1 if out_pm else 0, L.ptr(y))
+    _work("pointwise_mlp", flops=2.0 * B * lin.cin * lin.cout * l, nbytes=B * l * (4.0 * lin.cin + (2.0 if out_pm else 4.0) * lin.cout))
+    return y
 
 
 USE_STATS_EPILOGUE = os.environ.get("CAPTRA_STATS_EPILOGUE", "1") != "0"   # bf16 GroupNorm chains: the producing layer leaves the partial statistics of what it stored

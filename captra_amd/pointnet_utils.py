@@ -279,6 +279,20 @@ class PointNetFeaturePropagation(_FoldCache, nn.Module):
         if not _has_points(points1):
             points1 = None
         fuse = (not self.training) and xyz1.is_cuda
+        if (S == 1 and fuse and fused.mlp_dtype() == "bf16" and points1 is not None and points2.shape[2] == 1 and finish is None
+                and tail is None and self._fold(xyz1.device)[0].cout % 32 == 0):
+            # bf16 mode, one source vector per cloud: W [x; v 1^T] + b = W1 x + (W2 v + b) -- the bracket is one small
+            # product per cloud and becomes the first layer's bias; the (B, C1 + C2, N) repeat + concat is never built and the
+            # layer runs on C1 instead of C1 + C2 input channels (1536 -> 512 for FP3)
+            layers = list(self._fold(xyz1.device))
+            c1 = points1.shape[1]
+            lin0 = layers[0]
+            bias_bc = fused.pointwise_mlp_bf16pm(points2.contiguous(), lin0.trailing_rows(c1), 1, in_pm=False, out_pm=False)
+            y = fused.pointwise_mlp_bf16pm_cloud_bias(points1.contiguous(), lin0.leading_rows(c1), N, bias_bc.view(B, lin0.cout),
+                                                      out_pm=len(layers) > 1, act=fused.ACT_RELU)
+            for i, lin in enumerate(layers[1:]):
+                y = fused.pointwise_mlp_bf16pm(y, lin, N, in_pm=True, out_pm=i < len(layers) - 2, act=fused.ACT_RELU)
+            return y.view(B, layers[-1].cout, N)
         if S == 1:
             interpolated = points2.expand(-1, -1, N) if points2.shape[2] == 1 else points2.repeat(1, 1, N)
             new_points = torch.cat([points1, interpolated], dim=1) if points1 is not None else interpolated.contiguous()
@@ -344,7 +358,14 @@ class PointNetSetAbstraction(_FoldCache, nn.Module):
         assert self.group_all, "only group_all is implemented (as in the reference, l.330)"
         B, C, N = xyz.shape
         x = torch.cat([xyz, points], dim=1) if _has_points(points) else xyz       # (B,3+D,N), xyz first
-        new_xyz = torch.zeros(B, C, 1, device=xyz.device, dtype=xyz.dtype)
+        if (not self.training) and xyz.is_cuda:
+            # (eval: the all-zero "centre" of the pooled level is a constant nobody writes -- one tensor per shape, not a fill per step)
+            key = (B, C, xyz.device, xyz.dtype)
+            if getattr(self, "_zero_xyz", (None, None))[0] != key:
+                self._zero_xyz = (key, torch.zeros(B, C, 1, device=xyz.device, dtype=xyz.dtype))
+            new_xyz = self._zero_xyz[1]
+        else:
+            new_xyz = torch.zeros(B, C, 1, device=xyz.device, dtype=xyz.dtype)
         if (not self.training) and xyz.is_cuda and N % 32 == 0 and (128 % N == 0 or N % 128 == 0):
             # the fused max handles groups of 32 / 64 / 128 positions: a larger cloud is pooled as N/128 groups
             # of 128 and the group maxima are maxed again (max is exact, so the split does not change a bit)
@@ -352,7 +373,7 @@ class PointNetSetAbstraction(_FoldCache, nn.Module):
             groups, k = (1, N) if N <= 128 else (N // 128, 128)
             if fused.mlp_dtype() == "bf16":      # hidden activations bf16 point-major; the (exact) max on the last layer's fp32 output
                 y = fused.mlp_chain_bf16(x.contiguous(), folded, [fused.ACT_RELU] * len(folded))
-                return new_xyz, y.view(B, self.out_channel, groups, k).max(dim=3)[0].max(dim=2, keepdim=True)[0]
+                return new_xyz, fused.row_max(y.view(B, self.out_channel, N))
             y = x.contiguous().view(B, x.shape[1], groups, k)
             for lin in folded[:-1]:
                 y = fused.pointwise_mlp(y, lin, fused.ACT_RELU)

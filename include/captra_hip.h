@@ -248,6 +248,10 @@ long long captra_dense_bf16_image_bytes(int cin, int cout);
 int captra_pack_dense_bf16(int cin, int cout, int perm, const float *wt_packed, unsigned char *img, captra_stream_t stream);
 int captra_pointwise_mlp_bf16pm(int b, int cin, int cout, long long l, int in_pm, const void *x, const unsigned char *wimg,
                                 const float *bias_packed, const float *ab, int act, int out_pm, void *y, captra_stream_t stream);
+/* ... with a bias per cloud, bias_per_cloud (B,cout) fp32, cout % 32 == 0: a feature-propagation layer whose interpolated input
+ * is ONE vector per cloud (pointnet_utils.py:265-268, S == 1: the repeat + concat + 1x1 conv is W1 x + (W2 v + b)). */
+int captra_pointwise_mlp_bf16pm_cb(int b, int cin, int cout, long long l, int in_pm, const void *x, const unsigned char *wimg,
+                                   const float *bias_per_cloud, int act, int out_pm, void *y, captra_stream_t stream);
 int captra_gn_stats_bf16pm_tiles(long long l);
 int captra_dense_bf16_stats_tiles(long long l);
 int captra_gn_finalize_tm(int b, int c, int channels_per_group, int stats_t, long long n, float eps, const float *stats,
@@ -384,6 +388,10 @@ int captra_seg_softmax_argmax(int b, int s, int n, const float *logits, float *s
 /* njobs <= 16 device-to-device copies (bytes[j] % 4 == 0, 4-byte aligned) in one launch: host arrays of DEVICE pointers.  The
  * lanes' per-frame pose / record hand-over. */
 int captra_copy_multi(int njobs, const void *const *src, void *const *dst, const long long *bytes, captra_stream_t stream);
+
+/* out (rows) = max over each row of x (rows, l) fp32: the pooling of a group_all set abstraction (pointnet_utils.py:342,
+ * torch.max(new_points, 2)[0]) on a (B,C,N) tensor, rows = B*C.  NaN handling as fmaxf (a NaN is ignored), unlike torch.max. */
+int captra_row_max(long long rows, int l, const float *x, float *out, captra_stream_t stream);
 
 /* The packed pose records of the per-frame exchange (no reference counterpart: the reference is one
  * process): n = B*P records [R(9) t(3) s(1) valid(1)] from rot (n,3,3), trans (n,3), scale (n), valid (n) floats (NULL = 1)

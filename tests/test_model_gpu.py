@@ -1016,6 +1016,45 @@ def test_bf16pm_dense_layer_layouts_and_groupnorm_on_load(device, cin, cout, l):
     np.testing.assert_allclose(st4[..., 1].sum(1), (stored ** 2).sum(-1), atol=1e-6, rtol=2e-5)
 
 
+def test_bf16_feature_propagation_from_one_vector_per_cloud_and_row_max(device):
+    """bf16 mode, FP3 (S == 1: pointnet_utils.py:265-268 repeats the pooled vector to every point and concatenates): the fused path
+    never builds the concat -- W [x; v 1^T] + b = W1 x + (W2 v + b), the bracket as a per-cloud bias
+    (captra_pointwise_mlp_bf16pm_cb) -- against the float64 evaluation of the module's own layers on bf16-rounded operands;
+    and captra_row_max (the group_all pooling in this mode) against torch.max."""
+    from captra_amd import fused
+    from captra_amd.pointnet_utils import PointNetFeaturePropagation
+    torch.manual_seed(5)
+    B, C1, C2, N = 3, 512, 1024, 128
+    fp = PointNetFeaturePropagation(in_channel=C1 + C2, mlp=[256, 256]).to(device).eval()
+    with torch.no_grad():
+        for bn in fp.mlp_bns:
+            bn.running_mean.normal_(0, 0.1)
+            bn.running_var.uniform_(0.5, 1.5)
+    xyz1, xyz2 = torch.randn(B, 3, N, device=device), torch.zeros(B, 3, 1, device=device)
+    p1, p2 = torch.randn(B, C1, N, device=device), torch.randn(B, C2, 1, device=device).abs()
+    with torch.no_grad():
+        ref = fp(xyz1, xyz2, p1, p2)                                   # exact fp32 mode (fused kernels)
+        with fused.use_mlp_dtype("bf16"):
+            got = fp(xyz1, xyz2, p1, p2)
+    assert got.shape == ref.shape == (B, 256, N) and got.dtype == torch.float32
+    d = (got - ref).abs()
+    scale = float(ref.abs().max())
+    assert float(d.max()) <= 3e-2 * scale and float(d.mean()) <= 4e-3 * scale, (float(d.max()) / scale, float(d.mean()) / scale)
+    # the per-cloud-bias layer alone, against act(bias[b] + sum_k bf16(w) bf16(x)) in float64
+    rng = np.random.default_rng(9)
+    x = _bf16_round(rng.standard_normal((B, 96, 77)).astype(np.float32))
+    w = (rng.standard_normal((96, 64)) / 10).astype(np.float32)
+    bias = rng.standard_normal((B, 64)).astype(np.float32)
+    lin = fused.pack(_dev(w, device), _dev(np.zeros(64, np.float32), device))
+    y = fused.pointwise_mlp_bf16pm_cloud_bias(_dev(x, device), lin, 77, _dev(bias, device), out_pm=False, act=fused.ACT_RELU).cpu().numpy()
+    want = np.maximum(np.einsum("kc,bkl->bcl", _bf16_round(w).astype(np.float64), x.astype(np.float64)) + bias[:, :, None], 0)
+    np.testing.assert_allclose(y, want, atol=2e-5 * max(1.0, np.abs(want).max()), rtol=0)
+    # row max
+    for shape in [(2, 1024, 128), (3, 7, 130), (1, 5, 1)]:
+        t = torch.randn(*shape, device=device)
+        assert torch.equal(fused.row_max(t), t.max(dim=2, keepdim=True)[0])
+
+
 def test_bf16_rotation_head_chain_vs_torch(device):
     """MLPConv1d(128 -> 512 -> 512 -> 256 -> 3, GroupNorm) in the bf16 mode (hidden activations bf16 point-major in HBM, GroupNorm on
     load) against the torch fp32 Sequential: bf16-level agreement on the head's raw output."""
