@@ -1,0 +1,43 @@
+"""The bf16-native dense layers of the rotation heads, one kernel at a time (HIP events, L2-cold rotation of buffers).
+    python tools/bench_dense_bf16.py [--clouds 32] [--points 4096]
+Prints us and TFLOP/s per variant (plain / ReLU / GroupNorm on load / statistics epilogue)."""
+import argparse
+import sys
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from captra_amd import fused  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--clouds", type=int, default=32)
+    ap.add_argument("--points", type=int, default=4096)
+    ap.add_argument("--iters", type=int, default=10)
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    B, L = a.clouds, a.points
+    for cin, cout in [(128, 512), (512, 512), (512, 256)]:
+        lin = fused.pack(torch.randn(cin, cout, device=dev) / cin ** 0.5, torch.randn(cout, device=dev))
+        xs = [torch.randn(B, L, fused.pm_channels(cin), device=dev).to(torch.bfloat16) for _ in range(3)]
+        ab = torch.randn(B, cin, 2, device=dev)
+        if True:
+            for name, kw in [("plain", {}), ("relu", {"act": fused.ACT_RELU}), ("gn-on-load", {"ab": ab}), ("stats", {"with_stats": True}),
+                             ("gn-on-load+stats", {"ab": ab, "with_stats": True})]:
+                for i in range(3):
+                    fused.pointwise_mlp_bf16pm(xs[i % 3], lin, L, in_pm=True, out_pm=True, **kw)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for i in range(a.iters):
+                    fused.pointwise_mlp_bf16pm(xs[i % 3], lin, L, in_pm=True, out_pm=True, **kw)
+                e1.record()
+                torch.cuda.synchronize()
+                us = 1e3 * e0.elapsed_time(e1) / a.iters
+                print(f"{cin:4d} -> {cout:4d}  {name:18s} {us:8.1f} us  {2.0 * B * L * cin * cout / us / 1e6:7.1f} TFLOP/s", flush=True)
+
+
+if __name__ == "__main__":
+    main()
