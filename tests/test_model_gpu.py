@@ -345,6 +345,16 @@ def test_hipgraph_replay_equals_eager(device, tag):
         pg = {k: v.clone() for k, v in g.replay(f["points"], f["points_mean"], pg).items()}
         for k in pe:
             np.testing.assert_array_equal(pe[k].cpu().numpy(), pg[k].cpu().numpy(), err_msg=f"frame {i} {k}")
+    # the inputs go into the captured buffers in ONE launch (captra_copy_multi) when they are plain contiguous tensors, through
+    # torch copies otherwise: a strided view of the same values replays to the same pose
+    f = model.feed_dict[1]
+    want = {k: v.clone() for k, v in g.replay(f["points"], f["points_mean"], pose0).items()}
+    wide = torch.stack([f["points"], f["points"]], dim=-1)
+    pose_nc = dict(pose0, rotation=pose0["rotation"].transpose(-1, -2).contiguous().transpose(-1, -2))
+    assert not wide[..., 0].is_contiguous() and not pose_nc["rotation"].is_contiguous()
+    got = g.replay(wide[..., 0], f["points_mean"], pose_nc)
+    for k in want:
+        assert torch.equal(got[k], want[k]), k
 
 
 @pytest.mark.parametrize("tag", ["bottle", "drawers"])
