@@ -137,18 +137,48 @@ __global__ __launch_bounds__(IC_THREADS) void interp_concat_kernel(int n, int s,
     __syncthreads();
     int j0[4], j1[4], j2[4];
     float w0[4], w1[4], w2[4];
+    // a lane owns FOUR CONSECUTIVE positions when the rows allow 16-byte accesses (n % 4 == 0, aligned tensors): its twelve
+    // indices / weights are three 16-byte loads each and every output row segment one 16-byte store (a wave writes 1 KiB
+    // contiguous per channel instead of four 256-byte pieces 1 KiB apart); otherwise positions tid, tid + 256, ...
+    const bool vec = (n & 3) == 0 && ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(skip) |
+                                       reinterpret_cast<uintptr_t>(idx) | reinterpret_cast<uintptr_t>(weight)) & 15) == 0;
+    const int pbase = vec ? p0 + tid * 4 : p0 + tid, pstep = vec ? 1 : IC_THREADS;
+    if (vec && pbase + 3 < n) {
+        const int4 *ii = reinterpret_cast<const int4 *>(idx + ((size_t)b * n + pbase) * 3);
+        const float4 *ww = reinterpret_cast<const float4 *>(weight + ((size_t)b * n + pbase) * 3);
+        const int4 a0 = ii[0], a1 = ii[1], a2 = ii[2];
+        const float4 b0 = ww[0], b1 = ww[1], b2 = ww[2];
+        j0[0] = a0.x; j1[0] = a0.y; j2[0] = a0.z; j0[1] = a0.w; j1[1] = a1.x; j2[1] = a1.y;
+        j0[2] = a1.z; j1[2] = a1.w; j2[2] = a2.x; j0[3] = a2.y; j1[3] = a2.z; j2[3] = a2.w;
+        w0[0] = b0.x; w1[0] = b0.y; w2[0] = b0.z; w0[1] = b0.w; w1[1] = b1.x; w2[1] = b1.y;
+        w0[2] = b1.z; w1[2] = b1.w; w2[2] = b2.x; w0[3] = b2.y; w1[3] = b2.z; w2[3] = b2.w;
+    } else {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        int pt = p0 + tid + u * IC_THREADS;
-        if (pt >= n) pt = n - 1;
-        const int *ii = idx + ((size_t)b * n + pt) * 3;
-        const float *ww = weight + ((size_t)b * n + pt) * 3;
-        j0[u] = ii[0]; j1[u] = ii[1]; j2[u] = ii[2];
-        w0[u] = ww[0]; w1[u] = ww[1]; w2[u] = ww[2];
+        for (int u = 0; u < 4; ++u) {
+            int pt = pbase + u * pstep;
+            if (pt >= n) pt = n - 1;
+            const int *ii = idx + ((size_t)b * n + pt) * 3;
+            const float *ww = weight + ((size_t)b * n + pt) * 3;
+            j0[u] = ii[0]; j1[u] = ii[1]; j2[u] = ii[2];
+            w0[u] = ww[0]; w1[u] = ww[1]; w2[u] = ww[2];
+        }
     }
     for (int ch = ch0; ch < ch1; ++ch) {
         float *orow = out + ((size_t)b * ct + ch) * n;
-        if (ch < c1) {
+        if (vec) {
+            if (pbase >= n) continue;            // (n % 4 == 0: a lane's four positions are all inside or all outside)
+            float4 v;
+            if (ch < c1) {
+                v = *reinterpret_cast<const float4 *>(skip + ((size_t)b * c1 + ch) * n + pbase);
+            } else {
+                const float *row = rows + (size_t)(ch - c1 - f0) * s;
+                v.x = (w0[0] * row[j0[0]] + w1[0] * row[j1[0]]) + w2[0] * row[j2[0]];
+                v.y = (w0[1] * row[j0[1]] + w1[1] * row[j1[1]]) + w2[1] * row[j2[1]];
+                v.z = (w0[2] * row[j0[2]] + w1[2] * row[j1[2]]) + w2[2] * row[j2[2]];
+                v.w = (w0[3] * row[j0[3]] + w1[3] * row[j1[3]]) + w2[3] * row[j2[3]];
+            }
+            *reinterpret_cast<float4 *>(orow + pbase) = v;
+        } else if (ch < c1) {
             const float *srow = skip + ((size_t)b * c1 + ch) * n;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
