@@ -69,15 +69,18 @@ __global__ __launch_bounds__(PF_THREADS) void part_fit_st_kernel(int p, int n, i
     const int tid = threadIdx.x;
 
     // pass 1: count and centroids
+    // (every point is loaded, members or not, and a non-member adds +0: the loads of the 16 iterations no longer wait for the
+    // label they used to hide behind -- same sums bit for bit, since x + 0 = x -- and the loop pipelines)
     float fc = 0.f, fs[3] = {0.f, 0.f, 0.f}, ft[3] = {0.f, 0.f, 0.f};
+#pragma unroll 4
     for (int i = tid; i < n; i += PF_THREADS) {
-        if (lab[i] == pi) {
-            fc += 1.f;
+        const bool in = lab[i] == pi;
+        fc += in ? 1.f : 0.f;
 #pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                fs[a] += S[(size_t)a * n + i];
-                ft[a] += tgt_mean ? T[(size_t)a * n + i] + tm[a] : T[(size_t)a * n + i];
-            }
+        for (int a = 0; a < 3; ++a) {
+            const float sv = S[(size_t)a * n + i], tv = tgt_mean ? T[(size_t)a * n + i] + tm[a] : T[(size_t)a * n + i];
+            fs[a] += in ? sv : 0.f;
+            ft[a] += in ? tv : 0.f;
         }
     }
     double r1[7] = {fc, fs[0], fs[1], fs[2], ft[0], ft[1], ft[2]};
@@ -92,21 +95,25 @@ __global__ __launch_bounds__(PF_THREADS) void part_fit_st_kernel(int p, int n, i
     // pass 2: centred cross-covariance C[a][c] = sum (t_a - tb_a)(s_c - sb_c), ss = sum |s - sb|^2
     float fC[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     float fS[6] = {0, 0, 0, 0, 0, 0};  // sum sc sc^T: xx xy xz yy yz zz
+#pragma unroll 4
     for (int i = tid; i < n; i += PF_THREADS) {
-        if (lab[i] == pi) {
-            float sc[3], tc[3];
+        const bool in = lab[i] == pi;
+        float sc[3], tc[3];
 #pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                sc[a] = S[(size_t)a * n + i] - sbf[a];
-                tc[a] = (tgt_mean ? T[(size_t)a * n + i] + tm[a] : T[(size_t)a * n + i]) - tbf[a];
-            }
-#pragma unroll
-            for (int a = 0; a < 3; ++a)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) fC[a * 3 + c] += tc[a] * sc[c];
-            fS[0] += sc[0] * sc[0]; fS[1] += sc[0] * sc[1]; fS[2] += sc[0] * sc[2];
-            fS[3] += sc[1] * sc[1]; fS[4] += sc[1] * sc[2]; fS[5] += sc[2] * sc[2];
+        for (int a = 0; a < 3; ++a) {
+            sc[a] = S[(size_t)a * n + i] - sbf[a];
+            tc[a] = (tgt_mean ? T[(size_t)a * n + i] + tm[a] : T[(size_t)a * n + i]) - tbf[a];
         }
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float v = tc[a] * sc[c];
+                fC[a * 3 + c] += in ? v : 0.f;
+            }
+        const float q0 = sc[0] * sc[0], q1 = sc[0] * sc[1], q2 = sc[0] * sc[2], q3 = sc[1] * sc[1], q4 = sc[1] * sc[2], q5 = sc[2] * sc[2];
+        fS[0] += in ? q0 : 0.f; fS[1] += in ? q1 : 0.f; fS[2] += in ? q2 : 0.f;
+        fS[3] += in ? q3 : 0.f; fS[4] += in ? q4 : 0.f; fS[5] += in ? q5 : 0.f;
     }
     double r2[15];
 #pragma unroll
@@ -324,14 +331,17 @@ __global__ __launch_bounds__(PF_THREADS) void rot_pool_compose_kernel(int p, int
     double acc[10];
 #pragma unroll
     for (int i = 0; i < 10; ++i) acc[i] = 0.0;
+    // (every point is loaded and normalised, a non-member adds +0.0 through a select -- no NaN of a degenerate non-member can
+    // leak in: the loads no longer wait for the label, the loop pipelines, the sums are the same bit for bit)
+#pragma unroll 4
     for (int e = threadIdx.x; e < n; e += PF_THREADS) {
-        if (lab[e] != pi) continue;
-        acc[9] += 1.0;
+        const bool in = lab[e] == pi;
+        acc[9] += in ? 1.0 : 0.0;
         if (sym) {
             const float v[3] = {src[e], src[n + e], src[2 * (size_t)n + e]};
             float u[3];
             normalize3(v, u);
-            acc[0] += u[0]; acc[1] += u[1]; acc[2] += u[2];
+            acc[0] += in ? (double)u[0] : 0.0; acc[1] += in ? (double)u[1] : 0.0; acc[2] += in ? (double)u[2] : 0.0;
         } else {
             const float a[3] = {src[e], src[n + e], src[2 * (size_t)n + e]};
             const float c[3] = {src[3 * (size_t)n + e], src[4 * (size_t)n + e], src[5 * (size_t)n + e]};
@@ -341,9 +351,9 @@ __global__ __launch_bounds__(PF_THREADS) void rot_pool_compose_kernel(int p, int
             normalize3(zr, z);
             cross3(z, x, y);
             // row-major 3x3 with columns x, y, z
-            acc[0] += x[0]; acc[1] += y[0]; acc[2] += z[0];
-            acc[3] += x[1]; acc[4] += y[1]; acc[5] += z[1];
-            acc[6] += x[2]; acc[7] += y[2]; acc[8] += z[2];
+            acc[0] += in ? (double)x[0] : 0.0; acc[1] += in ? (double)y[0] : 0.0; acc[2] += in ? (double)z[0] : 0.0;
+            acc[3] += in ? (double)x[1] : 0.0; acc[4] += in ? (double)y[1] : 0.0; acc[5] += in ? (double)z[1] : 0.0;
+            acc[6] += in ? (double)x[2] : 0.0; acc[7] += in ? (double)y[2] : 0.0; acc[8] += in ? (double)z[2] : 0.0;
         }
     }
     block_reduce_sum<10>(acc, smem);
