@@ -55,6 +55,8 @@ _SIGNATURES = {
     "captra_pointwise_mlp_bf16pm_cb": [_INT, _INT, _INT, _LL, _INT, _P, _P, _P, _INT, _INT, _P, _P],
     "captra_pointwise_mlp_bf16pm_stats": [_INT, _INT, _INT, _LL, _INT, _P, _P, _P, _P, _INT, _P, _P, _P],
     "captra_gn_stats_bf16pm": [_INT, _INT, _LL, _P, _P, _P],
+    "captra_dense_bf16_tile": [_INT, _INT, _INT, _LL, _P, _P, _P, _LL, _P, _INT, _P, _P, _P],
+    "captra_head12_bf16": [_INT, _INT, _LL, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "captra_mlp_chain_bf16": [_INT, _INT, _LL, _INT, _INT, _INT, _P, _P, _P, _P, _P, _P],
     "captra_pack_sa_bf16": [_INT] * 5 + [_P] * 7 + [_P],
     "captra_sa_scale_bf16": [_INT] * 9 + [_P] * 6 + [_INT, _INT, _P],
@@ -125,6 +127,9 @@ def lib():
             l.captra_gn_stats_bf16pm_tiles.restype = _INT
             l.captra_dense_bf16_stats_tiles.argtypes = [_LL]
             l.captra_dense_bf16_stats_tiles.restype = _INT
+        if hasattr(l, "captra_dense_bf16_tile_stats_tiles"):
+            l.captra_dense_bf16_tile_stats_tiles.argtypes = [_LL]
+            l.captra_dense_bf16_tile_stats_tiles.restype = _INT
         if hasattr(l, "captra_chain_bf16_image_bytes"):
             l.captra_chain_bf16_image_bytes.argtypes = [_INT, _INT]
             l.captra_chain_bf16_image_bytes.restype = _LL

@@ -153,7 +153,23 @@ def _run_gn_chain_bf16(mods, x, cache):
     for conv, gn in layers:
         if id(conv) not in cache:
             cache[id(conv)] = fold_conv_bn(conv, None, x.device)
+    skip = 0
+    if in_pm and len(layers) >= 3 and layers[0][1] is not None and layers[1][1] is not None \
+            and fused.head12_bf16_supported(x, cache[id(layers[0][0])], cache[id(layers[1][0])]):
+        # layers 1 + 2 in one launch (csrc/tile_bf16.hip): a statistics pass over y1 = W1 x + b1 (nothing stored), then y1 recomputed,
+        # normalised in registers and consumed from LDS -- y1 (134 MB written + read at 32 x 4096 points) never reaches HBM
+        (c1, g1), (c2, g2) = layers[0], layers[1]
+        lin1, lin2 = cache[id(c1)], cache[id(c2)]
+        ab1 = fused.gn_finalize(fused.head12_bf16_stats(x, lin1), g1.num_groups, g1.weight, g1.bias, g1.eps, n, tile_major=True)
+        x, stats = fused.head12_bf16(x, lin1, ab1, lin2)
+        ab = fused.gn_finalize(stats, g2.num_groups, g2.weight, g2.bias, g2.eps, n, tile_major=True)
+        skip = 2
+    for conv, gn in layers[skip:]:
         lin = cache[id(conv)]
+        if in_pm and gn is not None and fused.dense_bf16_tile_supported(x, lin):
+            x, stats = fused.dense_bf16_tile(x, lin, ab=ab, with_stats=True)      # LDS-tiled layer, statistics from its epilogue
+            ab = fused.gn_finalize(stats, gn.num_groups, gn.weight, gn.bias, gn.eps, n, tile_major=True)
+            continue
         epi = gn is not None and fused.USE_STATS_EPILOGUE   # the layer's epilogue leaves the statistics of what it stored
         if epi:
             x, stats = fused.pointwise_mlp_bf16pm(x, lin, n, in_pm=in_pm, out_pm=True, ab=ab, act=fused.ACT_NONE, with_stats=True)

@@ -238,6 +238,64 @@ def pointwise_mlp_bf16pm(x, lin: PackedLinear, l: int, in_pm: bool, out_pm: bool
     return y
 
 
+USE_TILE_BF16 = os.environ.get("CAPTRA_TILE_BF16", "1") != "0"   # point-major bf16 layers through the LDS-tiled kernel (csrc/tile_bf16.hip)
+
+
+def dense_bf16_tile_supported(x, lin: PackedLinear) -> bool:
+    """Point-major bf16 in / out layers the LDS-tiled kernel is instantiated for (captra_dense_bf16_tile)."""
+    return (USE_TILE_BF16 and x.dtype == torch.bfloat16 and x.dim() == 3 and lin.cout >= 64
+            and x.shape[1] * x.shape[2] * 2 < (1 << 31))
+
+
+def dense_bf16_tile(x, lin: PackedLinear, ab=None, act: int = ACT_NONE, with_stats: bool = False, bias_bc=None):
+    """One dense layer on a point-major bf16 tensor through the LDS-tiled kernel: x (B,l,ceil32(cin)) -> y (B,l,ceil32(cout)) bf16
+    slot order [, stats (B,T,cout,2) tile-major: partial sums of the fp32 outputs per chunk of 128 positions].  ab (B,cin,2): the
+    producer's GroupNorm applied as relu(a x + b) while the operand is staged.  bias_bc (B,cout): a bias per cloud."""
+    L.require_device(x, ab, bias_bc)
+    B, l, cp = x.shape
+    assert x.dtype == torch.bfloat16 and cp == pm_channels(lin.cin), (x.shape, lin.cin)
+    y = torch.empty(B, l, pm_channels(lin.cout), dtype=torch.bfloat16, device=x.device)
+    stats = (torch.empty(B, L.lib().captra_dense_bf16_tile_stats_tiles(l), lin.cout, 2, dtype=torch.float32, device=x.device)
+             if with_stats else None)
+    if bias_bc is not None:
+        assert bias_bc.dtype == torch.float32 and bias_bc.numel() == B * lin.cout and lin.cout % 32 == 0
+    with torch.cuda.device(x.device):
+        L.call("captra_dense_bf16_tile", B, lin.cin, lin.cout, l, L.ptr(x), L.ptr(lin.bf16_frag(True)),
+               L.ptr(lin.bias if bias_bc is None else bias_bc), 0 if bias_bc is None else lin.cout, L.ptr(ab), act, L.ptr(y), L.ptr(stats))
+    _work("pointwise_mlp", flops=2.0 * B * lin.cin * lin.cout * l, nbytes=2.0 * B * l * (lin.cin + lin.cout))
+    return (y, stats) if with_stats else y
+
+
+def head12_bf16_supported(x, lin1: PackedLinear, lin2: PackedLinear) -> bool:
+    return (USE_TILE_BF16 and x.dtype == torch.bfloat16 and x.dim() == 3 and lin1.cin <= 128 and lin1.cout == 512 and lin2.cin == 512
+            and lin2.cout == 512 and x.shape[1] * 512 * 2 < (1 << 31))
+
+
+def head12_bf16_stats(x, lin1: PackedLinear):
+    """Statistics pass of a head's first layer: x (B,l,ceil32(cin)) bf16 -> partial sums (B,T,512,2) of y1 = W1 x + b1 (never stored)."""
+    L.require_device(x)
+    B, l, cp = x.shape
+    assert cp == pm_channels(lin1.cin)
+    stats = torch.empty(B, L.lib().captra_dense_bf16_tile_stats_tiles(l), 512, 2, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        L.call("captra_head12_bf16", B, lin1.cin, l, L.ptr(x), L.ptr(lin1.bf16_frag(True)), L.ptr(lin1.bias), None, None, None, None, L.ptr(stats))
+    _work("pointwise_mlp", flops=2.0 * B * lin1.cin * 512 * l, nbytes=2.0 * B * l * lin1.cin)
+    return stats
+
+
+def head12_bf16(x, lin1: PackedLinear, ab1, lin2: PackedLinear):
+    """Layers 1 + 2 of a Conv -> GroupNorm -> ReLU head in one launch: -> (y2 (B,l,512) bf16 raw, y2's partial statistics)."""
+    L.require_device(x, ab1)
+    B, l, cp = x.shape
+    y2 = torch.empty(B, l, 512, dtype=torch.bfloat16, device=x.device)
+    stats = torch.empty(B, L.lib().captra_dense_bf16_tile_stats_tiles(l), 512, 2, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        L.call("captra_head12_bf16", B, lin1.cin, l, L.ptr(x), L.ptr(lin1.bf16_frag(True)), L.ptr(lin1.bias), L.ptr(ab1),
+               L.ptr(lin2.bf16_frag(True)), L.ptr(lin2.bias), L.ptr(y2), L.ptr(stats))
+    _work("pointwise_mlp", flops=2.0 * B * l * (lin1.cin * 512 + 512 * 512), nbytes=2.0 * B * l * (lin1.cin + 512))
+    return y2, stats
+
+
 def gn_stats_bf16pm(x, c: int):
     """x (B,l,ceil32(c)) bf16 slot order -> partial statistics (B,c,T,2) of the stored values (captra_gn_stats_bf16pm)."""
     L.require_device(x)

@@ -261,6 +261,24 @@ int captra_pointwise_mlp_bf16pm_stats(int b, int cin, int cout, long long l, int
                                       captra_stream_t stream);
 int captra_gn_stats_bf16pm(int b, int c, long long l, const void *x, float *stats, captra_stream_t stream);
 
+/* bf16-native dense layers, LDS-tiled (csrc/tile_bf16.hip; round 4): the same per-layer contract on point-major tensors, with the
+ * operand tile (128 positions x 128 channels per K-chunk) staged through LDS -- the producer's GroupNorm applied once per element
+ * while it is staged -- and every weight fragment feeding four position tiles.  Replaces, inside the rotation heads
+ * (blocks.py:147-193) and the backbone's point-major layers, the streaming kernels above where the shape is instantiated.
+ *   captra_dense_bf16_tile: x (B,L,ceil32(cin)) -> y (B,L,ceil32(cout)), both bf16 slot order; wimg packed with perm = 1; bias_bs = 0
+ *     (one bias) or cout (bias (B,cout), cout % 32 == 0); ab (B,cin,2) or NULL; act CAPTRA_ACT_NONE / RELU; stats (B,T,cout,2) or
+ *     NULL: partial (sum, sum of squares) of the layer's fp32 outputs per chunk of 128 positions, T =
+ *     captra_dense_bf16_tile_stats_tiles(l), for captra_gn_finalize_tm.  Returns -2 for cout < 64 (use captra_pointwise_mlp_bf16pm).
+ *   captra_head12_bf16: layers 1 + 2 of a Conv -> GroupNorm -> ReLU head, cin <= 128 -> 512 -> 512, without y1 ever reaching HBM.
+ *     ab1 == NULL: the statistics pass (stats <- y1's partial sums; w2img, bias2, y2 unused).  ab1 != NULL: y1 is recomputed,
+ *     normalised in registers, parked in LDS as the second layer's operand; y2 (B,L,512) raw bf16 and stats <- y2's partial sums. */
+int captra_dense_bf16_tile_stats_tiles(long long l);
+int captra_dense_bf16_tile(int b, int cin, int cout, long long l, const void *x, const unsigned char *wimg, const float *bias_packed,
+                           long long bias_bs, const float *ab, int act, void *y, float *stats, captra_stream_t stream);
+int captra_head12_bf16(int b, int cin, long long l, const void *x, const unsigned char *w1img, const float *bias1_packed,
+                       const float *ab1, const unsigned char *w2img, const float *bias2_packed, void *y2, float *stats,
+                       captra_stream_t stream);
+
 /* bf16 mode, register-resident dense CHAIN (csrc/sa_bf16.hip): FP1's shared MLP + the backbone's conv1 (+ CoordinateNet's two heads)
  * in one launch.  x (B,c0,L) fp32, c0 <= 144 -> three 128-wide Conv+BN+ReLU layers; feat_pm (B,L,128) bf16 slot order receives the
  * result when non-NULL; heads != 0: seg (B,s,L) = Ws feat + bs and nocs (B,no,L) = sigmoid(Wo relu(Wh feat + bh) + bo) - 0.5

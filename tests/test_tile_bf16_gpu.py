@@ -1,0 +1,143 @@
+"""GPU parity of the LDS-tiled bf16 dense kernels (csrc/tile_bf16.hip; BASELINE.json configs[2]'s arithmetic).
+
+The per-layer contract is the streaming kernels' (csrc/dense_bf16.hip): y = act(b + sum_k bf16(w) bf16(x)), k ascending, fp32
+accumulation -- the same MFMA sequence, so the tiled layer must reproduce the streaming layer BIT FOR BIT, with and without the
+on-load GroupNorm; its statistics are the partial sums of the fp32 outputs.  The fused head (layers 1 + 2 in one launch, y1
+never stored) is checked against the float64 evaluation of the same chain on bf16-rounded operands and against the torch
+Sequential (reference network/models/blocks.py:147-165).
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests.test_model_gpu import _bf16_layer, _bf16_round, _dense_to_pm, _dev, _pm_to_dense
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("cin,cout,l", [(512, 512, 4096), (512, 256, 1000), (128, 512, 333), (256, 128, 512), (576, 256, 512),
+                                         (512, 1024, 128), (40, 70, 77), (1536, 256, 128), (200, 64, 129)])
+def test_tile_layer_equals_streaming_layer_bit_for_bit(device, cin, cout, l):
+    from captra_amd import fused
+    rng = np.random.default_rng(cin * 3 + cout + l)
+    B = 2
+    x = _bf16_round(rng.standard_normal((B, cin, l)).astype(np.float32))
+    w = (rng.standard_normal((cin, cout)) / np.sqrt(cin)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    lin = fused.pack(_dev(w, device), _dev(b, device))
+    xpm = _dense_to_pm(x).to(device)
+    assert fused.dense_bf16_tile_supported(xpm, lin)
+    for act in (fused.ACT_NONE, fused.ACT_RELU):
+        want = fused.pointwise_mlp_bf16pm(xpm, lin, l, in_pm=True, out_pm=True, act=act)
+        got = fused.dense_bf16_tile(xpm, lin, act=act)
+        assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+    # against the float64 contract
+    ref = _bf16_layer(x, w, b, 0)
+    got = _pm_to_dense(fused.dense_bf16_tile(xpm, lin), cout)
+    assert np.abs(got - _bf16_round(ref)).max() <= 2.0 ** -7 * np.abs(ref).max()
+    assert np.mean(got == _bf16_round(ref)) > 0.995
+    # on-load GroupNorm: x -> bf16(relu(a x + b)), bit-identical to the streaming kernels' transform
+    ab = rng.standard_normal((B, cin, 2)).astype(np.float32)
+    want = fused.pointwise_mlp_bf16pm(xpm, lin, l, in_pm=True, out_pm=True, ab=_dev(ab, device))
+    got, st = fused.dense_bf16_tile(xpm, lin, ab=_dev(ab, device), with_stats=True)
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+    # statistics: partial sums of the fp32 outputs per chunk of 128 positions; the stored tensor is those outputs rounded
+    xn = _bf16_round(np.maximum(np.float32(ab[:, :, 0:1]) * x + np.float32(ab[:, :, 1:2]), 0).astype(np.float32))
+    y64 = np.einsum("kc,bkl->bcl", _bf16_round(w).astype(np.float64), xn.astype(np.float64)) + b[None, :, None]
+    st = st.cpu().numpy().astype(np.float64)
+    T = (l + 127) // 128
+    assert st.shape == (B, T, cout, 2)
+    scale = max(1.0, float(np.abs(y64).max()))
+    for t in range(T):
+        seg = y64[:, :, 128 * t:128 * t + 128]
+        np.testing.assert_allclose(st[:, t, :, 0], seg.sum(-1), atol=2e-2 * scale, rtol=1e-3)      # (a rounding tie in the transform flips an operand)
+        np.testing.assert_allclose(st[:, t, :, 1], (seg ** 2).sum(-1), atol=2e-2 * scale * scale, rtol=2e-3)
+    st2 = fused.dense_bf16_tile(xpm, lin, ab=_dev(ab, device), with_stats=True)[1]
+    assert torch.equal(st2.cpu(), torch.from_numpy(st.astype(np.float32)))                      # no atomics: run-to-run identical
+    # a bias per cloud
+    if cout % 32 == 0:
+        bias_bc = rng.standard_normal((B, cout)).astype(np.float32)
+        got = _pm_to_dense(fused.dense_bf16_tile(xpm, lin, bias_bc=_dev(bias_bc, device)), cout)
+        refb = np.einsum("kc,bkl->bcl", _bf16_round(w).astype(np.float64), x.astype(np.float64)) + bias_bc[:, :, None]
+        assert np.abs(got - _bf16_round(refb.astype(np.float32))).max() <= 2.0 ** -7 * np.abs(refb).max()
+
+
+def _gn_coeffs(y, gamma, beta, eps, cpg):
+    """GroupNorm(y) = a y + b per (cloud, channel), float64."""
+    B, C, L = y.shape
+    g = y.reshape(B, C // cpg, cpg * L)
+    mean, var = g.mean(-1), g.var(-1)
+    rstd = 1.0 / np.sqrt(var + eps)
+    a = gamma[None, :] * np.repeat(rstd, cpg, axis=1)
+    return a, beta[None, :] - np.repeat(mean, cpg, axis=1) * a
+
+
+@pytest.mark.parametrize("cin,l", [(128, 4096), (128, 1000), (96, 77)])
+def test_head12_one_launch_vs_float64_chain(device, cin, l):
+    """captra_head12_bf16: statistics pass + fused layers 1-2 against y2 = W2 bf16(relu(GN(W1 x + b1))) + b2 in float64."""
+    from captra_amd import fused
+    rng = np.random.default_rng(cin + l)
+    B, cpg, eps = 2, 2, 1e-5
+    x = _bf16_round(rng.standard_normal((B, cin, l)).astype(np.float32))
+    w1 = (rng.standard_normal((cin, 512)) / np.sqrt(cin)).astype(np.float32)
+    b1 = rng.standard_normal(512).astype(np.float32)
+    w2 = (rng.standard_normal((512, 512)) / np.sqrt(512)).astype(np.float32)
+    b2 = rng.standard_normal(512).astype(np.float32)
+    g1, be1 = rng.uniform(0.5, 1.5, 512), rng.uniform(-0.3, 0.3, 512)
+    lin1, lin2 = fused.pack(_dev(w1, device), _dev(b1, device)), fused.pack(_dev(w2, device), _dev(b2, device))
+    xpm = _dense_to_pm(x).to(device)
+    assert fused.head12_bf16_supported(xpm, lin1, lin2)
+    st1 = fused.head12_bf16_stats(xpm, lin1)
+    y1 = np.einsum("kc,bkl->bcl", _bf16_round(w1).astype(np.float64), x.astype(np.float64)) + b1[None, :, None]
+    s = st1.cpu().numpy().astype(np.float64)
+    np.testing.assert_allclose(s[..., 0].sum(1), y1.sum(-1), atol=1e-3 * np.sqrt(l) * max(1.0, np.abs(y1).max()), rtol=1e-5)
+    np.testing.assert_allclose(s[..., 1].sum(1), (y1 ** 2).sum(-1), rtol=2e-5)
+    gam, bet = _dev(g1.astype(np.float32), device), _dev(be1.astype(np.float32), device)
+    ab1 = fused.gn_finalize(st1, 512 // cpg, gam, bet, eps, l, tile_major=True)
+    a64, b64 = _gn_coeffs(y1, g1.astype(np.float32).astype(np.float64), be1.astype(np.float32).astype(np.float64), eps, cpg)
+    ab = ab1.cpu().numpy()
+    np.testing.assert_allclose(ab[..., 0], a64, rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(ab[..., 1], b64, rtol=1e-3, atol=1e-4)
+    y2pm, st2 = fused.head12_bf16(xpm, lin1, ab1, lin2)
+    h = _bf16_round(np.maximum(ab[..., 0:1].astype(np.float64) * y1 + ab[..., 1:2], 0).astype(np.float32))
+    y2 = np.einsum("kc,bkl->bcl", _bf16_round(w2).astype(np.float64), h.astype(np.float64)) + b2[None, :, None]
+    got = _pm_to_dense(y2pm, 512)
+    scale = float(np.abs(y2).max())
+    err = np.abs(got - y2)
+    assert err.max() <= 3e-2 * scale and err.mean() <= 3e-3 * scale, (err.max() / scale, err.mean() / scale)
+    s2 = st2.cpu().numpy().astype(np.float64)
+    np.testing.assert_allclose(s2[..., 0].sum(1), y2.sum(-1), atol=3e-2 * l ** 0.5 * scale, rtol=1e-3)
+    np.testing.assert_allclose(s2[..., 1].sum(1), (y2 ** 2).sum(-1), rtol=5e-3)
+    # run-to-run identical (no atomics), also for the stored tensor
+    y2b, st2b = fused.head12_bf16(xpm, lin1, ab1, lin2)
+    assert torch.equal(y2b.view(torch.int16), y2pm.view(torch.int16)) and torch.equal(st2b, st2)
+
+
+def test_rotation_head_chain_tiled_vs_streaming_and_torch(device):
+    """MLPConv1d(128 -> 512 -> 512 -> 256 -> 3, GroupNorm) fed point-major in the bf16 mode: the round-4 route (fused layers 1-2,
+    tiled layer 3) against the round-3 route (streaming kernels) and the torch fp32 Sequential."""
+    from captra_amd import fused
+    from captra_amd.blocks import MLPConv1d
+    torch.manual_seed(11)
+    head = MLPConv1d(128, [512, 512, 256, 3], bn=True, gn=True, last_activation="none").to(device).eval()
+    with torch.no_grad():
+        for m in head.model:
+            if isinstance(m, torch.nn.GroupNorm):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.uniform_(-0.3, 0.3)
+    x = torch.randn(3, 128, 1000, device=device)
+    xpm = _dense_to_pm(_bf16_round(x.cpu().numpy())).to(device)
+    with torch.no_grad():
+        ref = head.model(torch.from_numpy(_bf16_round(x.cpu().numpy())).to(device))
+        with fused.use_mlp_dtype("bf16"):
+            got = head(fused.PMTensor(xpm, 128))
+            fused.USE_TILE_BF16 = False
+            try:
+                old = head(fused.PMTensor(xpm, 128))
+            finally:
+                fused.USE_TILE_BF16 = True
+    assert got.shape == ref.shape and got.dtype == torch.float32
+    scale = float(ref.abs().max())
+    for name, other, mx, mean in (("torch", ref, 5e-2, 6e-3), ("round-3 route", old, 5e-2, 6e-3)):
+        d = (got - other).abs()
+        assert float(d.max()) <= mx * scale and float(d.mean()) <= mean * scale, (name, float(d.max()) / scale, float(d.mean()) / scale)
