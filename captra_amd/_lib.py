@@ -56,6 +56,8 @@ _SIGNATURES = {
     "captra_pointwise_mlp_bf16pm_stats": [_INT, _INT, _INT, _LL, _INT, _P, _P, _P, _P, _INT, _P, _P, _P],
     "captra_gn_stats_bf16pm": [_INT, _INT, _LL, _P, _P, _P],
     "captra_dense_bf16_tile": [_INT, _INT, _INT, _LL, _P, _P, _P, _LL, _P, _INT, _P, _P, _P],
+    "captra_dense_bf16_tile_ex": [_INT, _INT, _INT, _LL, _INT, _P, _P, _INT, _P, _P, _LL, _P, _INT, _INT, _P, _P, _P],
+    "captra_gemv_bf16": [_INT, _INT, _INT, _P, _P, _P, _P, _P],
     "captra_head12_bf16": [_INT, _INT, _LL, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "captra_mlp_chain_bf16": [_INT, _INT, _LL, _INT, _INT, _INT, _P, _P, _P, _P, _P, _P],
     "captra_pack_sa_bf16": [_INT] * 5 + [_P] * 7 + [_P],

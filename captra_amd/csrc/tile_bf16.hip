@@ -33,12 +33,14 @@ constexpr int TB_CHUNK = 32768;    // one staged K-chunk: 128 positions x 128 ch
 struct TbParams {
     int cin, cout, kst, nt, cp_in, cp_out;
     long long L;
-    const unsigned char *x;        // (B,L,cp_in) bf16 slot order
+    const unsigned char *x;        // IN 0: (B,L,cp_in) bf16 slot order; IN 1: (B,csplit,L) fp32 channel-major (channels < csplit)
+    const float *x2;               // IN 1: channels >= csplit, (B,cin - csplit,L) fp32 (the concat [x, x2] is never built)
+    int csplit;
     const unsigned char *wimg;     // captra_pack_dense_bf16(perm = 1)
     const float *bias;
     long long bias_bs;             // per-cloud bias stride (0: one bias)
     const float *ab;               // AFF: (B,cin,2)
-    unsigned char *y;              // (B,L,cp_out) bf16 slot order
+    unsigned char *y;              // OUT 0: (B,L,cp_out) bf16 slot order; OUT 1: (B,cout,L) fp32; OUT 2: (B,cout) fp32 = max over the positions
     int act;
     float *stats;                  // ST: (B,st_t,cout,2)
     int st_t;
@@ -77,9 +79,11 @@ __device__ __forceinline__ void tb_stats_acc(float (&sv)[32], const f32x16 &acc,
     }
 }
 
-template <int MT, int NW, bool AFF, bool ST, bool KF>
+template <int MT, int NW, int IN, bool AFF, int OUT, bool ST, bool KF>
 __global__ __launch_bounds__(NW * 64, 2) void tb_layer_kernel(TbParams p) {
+    static_assert(!(AFF && IN == 1) && !(ST && OUT != 0), "GroupNorm on load / statistics are point-major features");
     constexpr int NT = NW * 64, UN = 2048 / NT, PSTEP = NT / 16;
+    constexpr int ITEMS = 512 / NT;                                   // IN 1: (position quad, slot) items per thread and chunk
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     float *aff_tab = reinterpret_cast<float *>(lds + 2 * TB_CHUNK);   // AFF: [2 kst slots][a0..a7, b0..b7]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -91,8 +95,8 @@ __global__ __launch_bounds__(NW * 64, 2) void tb_layer_kernel(TbParams p) {
     const int kst = p.kst, nch = (kst + 7) >> 3;
     // ---- staging geometry: this thread moves the 16-byte slot `sslot` of positions spos, spos + PSTEP, ... ----------
     const int sslot = tid & 15, spos = tid >> 4;
-    const unsigned char *xb = p.x + (size_t)b * p.L * p.cp_in * 2;
-    const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc((void *)xb, 0, (int)(p.L * p.cp_in * 2), 0x00020000);
+    const unsigned char *xb = p.x + (IN == 0 ? (size_t)b * p.L * p.cp_in * 2 : 0);
+    const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc((void *)xb, 0, (int)(IN == 0 ? p.L * p.cp_in * 2 : 0), 0x00020000);
     const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc((void *)p.wimg, 0, p.nt * kst * 1024, 0x00020000);
     int xoff[UN];
 #pragma unroll
@@ -130,13 +134,59 @@ __global__ __launch_bounds__(NW * 64, 2) void tb_layer_kernel(TbParams p) {
 #pragma unroll
         for (int tm = 0; tm < MT; ++tm) A[s][tm] = __builtin_amdgcn_raw_buffer_load_b128(wsrc, lane * 16, woff[tm] + kk * 1024, 0);
     };
-    u32x4 st[UN];                                                     // the NEXT chunk's units, in flight / waiting to be parked
+    u32x4 st[IN == 0 ? UN : 1];                                       // IN 0: the NEXT chunk's units, in flight / waiting to be parked
+    float4 sf[IN == 1 ? ITEMS : 1][8];                                // IN 1: 8 channels x 4 positions per item
+    // IN 1 geometry: item u = tid + i NT -> position quad u & 31, slot u >> 5 of the chunk; the slot's 8 channels are
+    // base + {0,1,2,3,8,9,10,11}, base = 16 kk + 4 hh (slot order); a channel-major fp32 source, float4 = 4 positions
+    const float *x0b = reinterpret_cast<const float *>(p.x) + (IN == 1 ? (size_t)b * p.csplit * p.L : 0);
+    const float *x1b = p.x2 + (IN == 1 ? (size_t)b * (p.cin - p.csplit) * p.L : 0);
     auto gload = [&](int c) {
         c = c < nch ? c : nch - 1;                                    // (always issued: the load counts stay static)
+        if constexpr (IN == 0) {
 #pragma unroll
-        for (int i = 0; i < UN; ++i) st[i] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, xoff[i], c * 256, 0);
+            for (int i = 0; i < UN; ++i) st[i] = __builtin_amdgcn_raw_buffer_load_b128(xsrc, xoff[i], c * 256, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < ITEMS; ++i) {
+                const int u = tid + i * NT, pq = u & 31, sl = u >> 5;
+                long long pos = pos0 + 4 * pq;
+                if (pos > p.L - 4) pos = p.L - 4;                     // clamped quad: computed, never stored
+                const int base = 16 * (8 * c + (sl >> 1)) + 4 * (sl & 1);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    int ch = base + (e & 3) + 8 * (e >> 2);
+                    ch = ch < p.cin ? ch : p.cin - 1;                 // clamped channel: loaded, zeroed when parked
+                    const float *src = ch < p.csplit ? x0b + (size_t)ch * p.L : x1b + (size_t)(ch - p.csplit) * p.L;
+                    sf[i][e] = *reinterpret_cast<const float4 *>(src + pos);
+                }
+            }
+        }
     };
     auto park = [&](int c) {
+        if constexpr (IN == 1) {
+#pragma unroll
+            for (int i = 0; i < ITEMS; ++i) {
+                const int u = tid + i * NT, pq = u & 31, sl = u >> 5;
+                const int base = 16 * (8 * c + (sl >> 1)) + 4 * (sl & 1);
+                float m[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) m[e] = base + (e & 3) + 8 * (e >> 2) < p.cin ? 1.f : 0.f;
+                unsigned char *dst = lds + (c & 1) * TB_CHUNK;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int pos = 4 * pq + r;
+                    u32x4 v;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float lo = r == 0 ? sf[i][2 * q].x : r == 1 ? sf[i][2 * q].y : r == 2 ? sf[i][2 * q].z : sf[i][2 * q].w;
+                        const float hi = r == 0 ? sf[i][2 * q + 1].x : r == 1 ? sf[i][2 * q + 1].y : r == 2 ? sf[i][2 * q + 1].z : sf[i][2 * q + 1].w;
+                        v[q] = db_pack(m[2 * q] != 0.f ? lo : 0.f, m[2 * q + 1] != 0.f ? hi : 0.f);
+                    }
+                    *reinterpret_cast<u32x4 *>(dst + pos * 256 + ((sl ^ (pos & 15)) << 4)) = v;
+                }
+            }
+            return;
+        }
         unsigned char *dst = lds + (c & 1) * TB_CHUNK + lw0;
         if constexpr (AFF) {
             const int s = 16 * c + sslot;
@@ -146,7 +196,7 @@ __global__ __launch_bounds__(NW * 64, 2) void tb_layer_kernel(TbParams p) {
             const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
             for (int i = 0; i < UN; ++i) *reinterpret_cast<u32x4 *>(dst + i * PSTEP * 256) = tb_affine(st[i], a, bb);
-        } else {
+        } else if constexpr (IN == 0) {
 #pragma unroll
             for (int i = 0; i < UN; ++i) *reinterpret_cast<u32x4 *>(dst + i * PSTEP * 256) = st[i];
         }
@@ -204,11 +254,45 @@ __global__ __launch_bounds__(NW * 64, 2) void tb_layer_kernel(TbParams p) {
 #pragma unroll
             for (int i = 0; i < 32; ++i) sv[i] = 0.f;
         }
+        if constexpr (OUT == 2) {
+            // max over the workgroup's positions (the launcher guarantees one position tile per cloud): lane-local over the
+            // four tiles, then a 32-column butterfly; act(max) == max(act) for the monotone activations
+            float mx[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                mx[r] = -INFINITY;
+#pragma unroll
+                for (int tn = 0; tn < TB_TN; ++tn) mx[r] = pos0 + tn * 32 + col < p.L ? fmaxf(mx[r], acc[tm][tn][r]) : mx[r];
+#pragma unroll
+                for (int off = 16; off >= 1; off >>= 1) mx[r] = fmaxf(mx[r], __shfl_xor(mx[r], off, 64));
+            }
+            if (col == 0) {
+                float *yp = reinterpret_cast<float *>(p.y) + (size_t)b * p.cout + 32 * t + 4 * h;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ro = (r & 3) + 8 * (r >> 2);
+                    if (32 * t + 4 * h + ro < p.cout) yp[ro] = apply_act(mx[r], p.act);
+                }
+            }
+            continue;
+        }
 #pragma unroll
         for (int tn = 0; tn < TB_TN; ++tn) {
             const long long c = pos0 + tn * 32 + col;
             const bool valid = c < p.L;
-            if (valid) tb_store_tile(acc[tm][tn], p.y + (((size_t)b * p.L + c) * p.cp_out + 32 * t + 8 * h) * 2, relu);
+            if constexpr (OUT == 0) {
+                if (valid) tb_store_tile(acc[tm][tn], p.y + (((size_t)b * p.L + c) * p.cp_out + 32 * t + 8 * h) * 2, relu);
+            } else if constexpr (OUT == 1) {
+                const int row0 = 32 * t + 4 * h;
+                float *yp = reinterpret_cast<float *>(p.y) + ((size_t)b * p.cout + row0) * p.L + c;
+                if (valid) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int ro = (r & 3) + 8 * (r >> 2);
+                        if (row0 + ro < p.cout) yp[(size_t)ro * p.L] = apply_act(acc[tm][tn][r], p.act);
+                    }
+                }
+            }
             if constexpr (ST) tb_stats_acc(sv, acc[tm][tn], valid);
         }
         if constexpr (ST) db_stats_tile(sv, col, h, t, p.cout, p.stats + (size_t)b * p.cout * p.st_t * 2, p.st_t, (int)blockIdx.x);
@@ -403,64 +487,142 @@ __global__ __launch_bounds__(512, 2) void tb_head12_kernel(HbParams p) {
     }
 }
 
-template <int MT, int NW, bool AFF, bool ST>
+template <int MT, int NW, int IN, bool AFF, int OUT, bool ST>
 int tb_launch(int b, const TbParams &p, hipStream_t s) {
     dim3 grid((unsigned)((p.L + TB_P - 1) / TB_P), (p.nt + NW * MT - 1) / (NW * MT), b);
     const int lds = 2 * TB_CHUNK + (AFF ? p.kst * 128 : 0);
     static CaptraDeviceOnce once_f, once_p;
-    if (p.kst % 8 == 0) {
+    constexpr bool CAN_KF = IN == 0 && OUT == 0;
+    if (CAN_KF && p.kst % 8 == 0) {
         if (once_f.first_use()) {
-            hipFuncSetAttribute(reinterpret_cast<const void *>(&tb_layer_kernel<MT, NW, AFF, ST, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TB_CHUNK + 65536);
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&tb_layer_kernel<MT, NW, IN, AFF, OUT, ST, CAN_KF>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TB_CHUNK + 65536);
             once_f.done();
         }
-        CAPTRA_LAUNCH("pointwise_mlp", (tb_layer_kernel<MT, NW, AFF, ST, true>), grid, dim3(NW * 64), lds, s, p);
+        CAPTRA_LAUNCH("pointwise_mlp", (tb_layer_kernel<MT, NW, IN, AFF, OUT, ST, CAN_KF>), grid, dim3(NW * 64), lds, s, p);
     } else {
         if (once_p.first_use()) {
-            hipFuncSetAttribute(reinterpret_cast<const void *>(&tb_layer_kernel<MT, NW, AFF, ST, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TB_CHUNK + 65536);
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&tb_layer_kernel<MT, NW, IN, AFF, OUT, ST, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TB_CHUNK + 65536);
             once_p.done();
         }
-        CAPTRA_LAUNCH("pointwise_mlp", (tb_layer_kernel<MT, NW, AFF, ST, false>), grid, dim3(NW * 64), lds, s, p);
+        CAPTRA_LAUNCH("pointwise_mlp", (tb_layer_kernel<MT, NW, IN, AFF, OUT, ST, false>), grid, dim3(NW * 64), lds, s, p);
     }
     return captra_last_error();
 }
 
+// ---- one vector per cloud through a layer: y[b] = bias + W bf16(x[b]) ---------------------------------------------------
+// (FP3's per-cloud bias W2 v + b, pointnet_utils.py:265-268 with S == 1.)  A lane owns FOUR consecutive output channels (16-byte
+// loads of the row-major W'^T rows), the sixteen waves split k as k = 16 i + wave -- 64 dependent steps for cin = 1024, sixteen
+// loads in flight per wave -- and their partial sums are added in wave order.
+__global__ __launch_bounds__(1024) void tb_gemv_kernel(int cin, int cout, int ldw, const float *__restrict__ x, const float *__restrict__ wt,
+                                                        const float *__restrict__ bias, float *__restrict__ y) {
+    __shared__ float4 red[16][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int co = (blockIdx.x * 64 + lane) * 4, b = blockIdx.y;
+    const int cc = co < ldw ? co : ldw - 4;                            // (ldw = ceil128(cout): whole float4s, zero padded)
+    const float *xb = x + (size_t)b * cin;
+    float4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 16
+    for (int k = wave; k < cin; k += 16) {
+        const float xv = (float)(__bf16)xb[k];
+        const float4 w = *reinterpret_cast<const float4 *>(wt + (size_t)k * ldw + cc);
+        acc.x = __builtin_fmaf((float)(__bf16)w.x, xv, acc.x);
+        acc.y = __builtin_fmaf((float)(__bf16)w.y, xv, acc.y);
+        acc.z = __builtin_fmaf((float)(__bf16)w.z, xv, acc.z);
+        acc.w = __builtin_fmaf((float)(__bf16)w.w, xv, acc.w);
+    }
+    red[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0) {
+        float4 s = red[0][lane];
+        for (int w = 1; w < 16; ++w) {
+            const float4 t = red[w][lane];
+            s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+        }
+        const float v[4] = {s.x, s.y, s.z, s.w};
+        for (int i = 0; i < 4; ++i)
+            if (co + i < cout) y[(size_t)b * cout + co + i] = bias[co + i] + v[i];
+    }
+}
+
 }  // namespace
+
+// x (B,cin) fp32, wt_packed / bias_packed: the layer's packed fp32 buffers -> y (B,cout) fp32 = bias + sum_k bf16(w[k]) bf16(x[k]).
+extern "C" int captra_gemv_bf16(int b, int cin, int cout, const float *x, const float *wt_packed, const float *bias_packed, float *y,
+                                captra_stream_t stream) {
+    if (b < 0 || cin < 1 || cout < 1) return -1;
+    if (b == 0) return 0;
+    CAPTRA_LAUNCH("pointwise_mlp", tb_gemv_kernel, dim3((cout + 255) / 256, b), dim3(1024), 0, (hipStream_t)stream, cin, cout,
+                  (cout + 127) / 128 * 128, x, wt_packed, bias_packed, y);
+    return captra_last_error();
+}
 
 static CAPTRA_KNOB int g_tb_dbg = 0;
 extern "C" void captra_tile_bf16_set_debug(int v) { g_tb_dbg = v; }
 
 extern "C" int captra_dense_bf16_tile_stats_tiles(long long l) { return (int)((l + TB_P - 1) / TB_P); }
 
-// One dense layer on point-major tensors through the LDS-tiled kernel.  x (B,L,ceil32(cin)) bf16 slot order (image packed with
-// perm = 1), y (B,L,ceil32(cout)) bf16 slot order; ab (B,cin,2) or NULL: the producer's GroupNorm, applied as relu(a x + b)
-// while the operand is staged; act CAPTRA_ACT_NONE / RELU; stats (B,T,cout,2) or NULL, T = captra_dense_bf16_tile_stats_tiles(l)
-// (chunks of 128 positions, of the fp32 accumulator values) for captra_gn_finalize_tm.  bias_bs: 0, or cout for a bias per cloud.
-// Returns -2 for shapes the kernel is not instantiated for (cout < 64; rows beyond 2^31 bytes): the caller uses captra_pointwise_mlp_bf16pm.
-extern "C" int captra_dense_bf16_tile(int b, int cin, int cout, long long l, const void *x, const unsigned char *wimg, const float *bias_packed,
-                                      long long bias_bs, const float *ab, int act, void *y, float *stats, captra_stream_t stream) {
-    if (b < 0 || cin < 1 || cout < 1 || l < 0 || act < 0 || act > 1) return -1;
+// One dense layer through the LDS-tiled kernel.
+//   in_cm = 0: x (B,L,ceil32(cin)) bf16 slot order.  in_cm = 1: x (B,csplit,L) fp32 channel-major holds input channels
+//     [0, csplit) and x2 (B,cin - csplit,L) the rest (csplit = cin, x2 = NULL: one tensor) -- the [xyz, feat] / [skip, interp]
+//     concats of pointnet_utils.py:286-294, 318-321 are never built; needs l % 4 == 0.
+//   out_mode = 0: y (B,L,ceil32(cout)) bf16 slot order; 1: y (B,cout,L) fp32; 2: y (B,cout) fp32 = max over the l <= 128 positions.
+//   wimg packed with perm = 1 in every case (the LDS image is in slot order).  ab (in_cm = 0 only): (B,cin,2) or NULL; act
+//   CAPTRA_ACT_NONE / RELU (any of the three for fp32 outputs); stats (out_mode 0 only) (B,T,cout,2) or NULL; bias_bs: 0, or cout
+//   for a bias per cloud.  Returns -2 for shapes the kernel is not instantiated for: the caller uses captra_pointwise_mlp_bf16pm.
+extern "C" int captra_dense_bf16_tile_ex(int b, int cin, int cout, long long l, int in_cm, const void *x, const float *x2, int csplit,
+                                         const unsigned char *wimg, const float *bias_packed, long long bias_bs, const float *ab, int act,
+                                         int out_mode, void *y, float *stats, captra_stream_t stream) {
+    if (b < 0 || cin < 1 || cout < 1 || l < 0 || act < 0 || act > 2 || out_mode < 0 || out_mode > 2) return -1;
+    if (out_mode == 0 && act == ACT_SIGMOID_M05) return -1;
+    if (in_cm && (ab != nullptr || csplit < 0 || csplit > cin || (csplit < cin && x2 == nullptr))) return -1;
+    if (stats != nullptr && out_mode != 0) return -1;
     const int cp_in = (cin + 31) / 32 * 32, cp_out = (cout + 31) / 32 * 32;
-    if (l * cp_in * 2 >= (1ll << 31)) return -2;
-    if (cout < 64) return -2;
+    if (!in_cm && l * cp_in * 2 >= (1ll << 31)) return -2;
+    if (in_cm && (l % 4 != 0 || l < 4)) return -2;
+    if (out_mode == 2 && l > TB_P) return -2;
+    if (cout < 64 && !(in_cm && cout >= 32)) return -2;
     if (b == 0 || l == 0) return 0;
     TbParams p;
     p.cin = cin; p.cout = cout; p.kst = (cin + 15) / 16; p.nt = (cout + 31) / 32; p.cp_in = cp_in; p.cp_out = cp_out; p.L = l;
-    p.x = reinterpret_cast<const unsigned char *>(x); p.wimg = wimg; p.bias = bias_packed; p.bias_bs = bias_bs; p.ab = ab;
+    p.x = reinterpret_cast<const unsigned char *>(x); p.x2 = x2; p.csplit = in_cm ? csplit : cin;
+    p.wimg = wimg; p.bias = bias_packed; p.bias_bs = bias_bs; p.ab = ab;
     p.y = reinterpret_cast<unsigned char *>(y); p.act = act; p.stats = stats; p.st_t = captra_dense_bf16_tile_stats_tiles(l);
     if (ab != nullptr && p.kst * 128 > 65536) return -2;
     hipStream_t s = (hipStream_t)stream;
     const bool aff = ab != nullptr, st = stats != nullptr;
-#define TB_GO(MT_, NW_)                                                       \
-    do {                                                                      \
-        if (aff && st) return tb_launch<MT_, NW_, true, true>(b, p, s);       \
-        if (aff) return tb_launch<MT_, NW_, true, false>(b, p, s);            \
-        if (st) return tb_launch<MT_, NW_, false, true>(b, p, s);             \
-        return tb_launch<MT_, NW_, false, false>(b, p, s);                    \
+    // few position tiles (the 128- / 512-point levels of the backbone): narrow row blocks, so that the launch has workgroups
+    const long long ptiles = (long long)b * ((l + TB_P - 1) / TB_P);
+    if (in_cm) {
+#define TB_GO_CM(MT_, NW_)                                                                  \
+    do {                                                                                    \
+        if (out_mode == 0) return tb_launch<MT_, NW_, 1, false, 0, false>(b, p, s);         \
+        if (out_mode == 1) return tb_launch<MT_, NW_, 1, false, 1, false>(b, p, s);         \
+        return tb_launch<MT_, NW_, 1, false, 2, false>(b, p, s);                            \
     } while (0)
-    if (p.nt >= 16) TB_GO(2, 8);
-    if (p.nt >= 5) TB_GO(2, 4);
+        if (p.nt >= 16 && ptiles >= 512) TB_GO_CM(2, 8);
+        if (p.nt >= 8 && ptiles >= 128) TB_GO_CM(1, 8);
+        TB_GO_CM(1, 4);
+#undef TB_GO_CM
+    }
+#define TB_GO(MT_, NW_)                                                                     \
+    do {                                                                                    \
+        if (out_mode == 1) return tb_launch<MT_, NW_, 0, false, 1, false>(b, p, s);         \
+        if (out_mode == 2) return tb_launch<MT_, NW_, 0, false, 2, false>(b, p, s);         \
+        if (aff && st) return tb_launch<MT_, NW_, 0, true, 0, true>(b, p, s);               \
+        if (aff) return tb_launch<MT_, NW_, 0, true, 0, false>(b, p, s);                    \
+        if (st) return tb_launch<MT_, NW_, 0, false, 0, true>(b, p, s);                     \
+        return tb_launch<MT_, NW_, 0, false, 0, false>(b, p, s);                            \
+    } while (0)
+    if (out_mode != 0 && aff) return -2;
+    if (p.nt >= 16 && ptiles >= 512) TB_GO(2, 8);
+    if (p.nt >= 5 && ptiles >= 256) TB_GO(2, 4);
     TB_GO(1, 4);
 #undef TB_GO
+}
+
+extern "C" int captra_dense_bf16_tile(int b, int cin, int cout, long long l, const void *x, const unsigned char *wimg, const float *bias_packed,
+                                      long long bias_bs, const float *ab, int act, void *y, float *stats, captra_stream_t stream) {
+    return captra_dense_bf16_tile_ex(b, cin, cout, l, 0, x, nullptr, cin, wimg, bias_packed, bias_bs, ab, act, 0, y, stats, stream);
 }
 
 // Layers 1 + 2 of a Conv -> GroupNorm -> ReLU head in one launch (cin <= 128 -> 512 -> 512).  ab1 == NULL: the statistics

@@ -247,23 +247,73 @@ def dense_bf16_tile_supported(x, lin: PackedLinear) -> bool:
             and x.shape[1] * x.shape[2] * 2 < (1 << 31))
 
 
-def dense_bf16_tile(x, lin: PackedLinear, ab=None, act: int = ACT_NONE, with_stats: bool = False, bias_bc=None):
-    """One dense layer on a point-major bf16 tensor through the LDS-tiled kernel: x (B,l,ceil32(cin)) -> y (B,l,ceil32(cout)) bf16
-    slot order [, stats (B,T,cout,2) tile-major: partial sums of the fp32 outputs per chunk of 128 positions].  ab (B,cin,2): the
-    producer's GroupNorm applied as relu(a x + b) while the operand is staged.  bias_bc (B,cout): a bias per cloud."""
-    L.require_device(x, ab, bias_bc)
-    B, l, cp = x.shape
-    assert x.dtype == torch.bfloat16 and cp == pm_channels(lin.cin), (x.shape, lin.cin)
-    y = torch.empty(B, l, pm_channels(lin.cout), dtype=torch.bfloat16, device=x.device)
+OUT_PM, OUT_CM, OUT_MAX = 0, 1, 2      # captra_dense_bf16_tile_ex out_mode
+
+
+def dense_bf16_tile(x, lin: PackedLinear, ab=None, act: int = ACT_NONE, with_stats: bool = False, bias_bc=None, x2=None, l=None,
+                    out_mode: int = OUT_PM):
+    """One dense layer through the LDS-tiled kernel (captra_dense_bf16_tile_ex).  x: (B,l,ceil32(cin)) bf16 slot order, or -- fp32
+    -- (B,c,l) channel-major, optionally with x2 (B,cin - c,l) holding the remaining input channels (the concat is never built).
+    out_mode OUT_PM: y (B,l,ceil32(cout)) bf16 slot order [, stats (B,T,cout,2) tile-major: partial sums of the fp32 outputs per
+    chunk of 128 positions]; OUT_CM: (B,cout,l) fp32; OUT_MAX: (B,cout,1) fp32, the max over the l <= 128 positions.  ab (B,cin,2):
+    the producer's GroupNorm applied as relu(a x + b) while the operand is staged.  bias_bc (B,cout): a bias per cloud."""
+    L.require_device(x, ab, bias_bc, x2)
+    in_cm = x.dtype == torch.float32
+    B = x.shape[0]
+    if in_cm:
+        csplit = x.shape[1]
+        l = x.numel() // max(B * csplit, 1) if l is None else l
+        assert csplit + (0 if x2 is None else x2.shape[1]) == lin.cin and (x2 is None or x2.dtype == torch.float32), (x.shape, lin.cin)
+    else:
+        l, csplit = x.shape[1], lin.cin
+        assert x.dtype == torch.bfloat16 and x.shape[2] == pm_channels(lin.cin), (x.shape, lin.cin)
+    if out_mode == OUT_PM:
+        y = torch.empty(B, l, pm_channels(lin.cout), dtype=torch.bfloat16, device=x.device)
+    elif out_mode == OUT_CM:
+        y = torch.empty(B, lin.cout, l, dtype=torch.float32, device=x.device)
+    else:
+        y = torch.empty(B, lin.cout, 1, dtype=torch.float32, device=x.device)
     stats = (torch.empty(B, L.lib().captra_dense_bf16_tile_stats_tiles(l), lin.cout, 2, dtype=torch.float32, device=x.device)
              if with_stats else None)
     if bias_bc is not None:
         assert bias_bc.dtype == torch.float32 and bias_bc.numel() == B * lin.cout and lin.cout % 32 == 0
     with torch.cuda.device(x.device):
-        L.call("captra_dense_bf16_tile", B, lin.cin, lin.cout, l, L.ptr(x), L.ptr(lin.bf16_frag(True)),
-               L.ptr(lin.bias if bias_bc is None else bias_bc), 0 if bias_bc is None else lin.cout, L.ptr(ab), act, L.ptr(y), L.ptr(stats))
-    _work("pointwise_mlp", flops=2.0 * B * lin.cin * lin.cout * l, nbytes=2.0 * B * l * (lin.cin + lin.cout))
+        L.call("captra_dense_bf16_tile_ex", B, lin.cin, lin.cout, l, 1 if in_cm else 0, L.ptr(x), L.ptr(x2), csplit, L.ptr(lin.bf16_frag(True)),
+               L.ptr(lin.bias if bias_bc is None else bias_bc), 0 if bias_bc is None else lin.cout, L.ptr(ab), act, out_mode, L.ptr(y), L.ptr(stats))
+    _work("pointwise_mlp", flops=2.0 * B * lin.cin * lin.cout * l,
+          nbytes=B * l * ((4.0 if in_cm else 2.0) * lin.cin + (2.0 if out_mode == OUT_PM else 4.0 if out_mode == OUT_CM else 0.0) * lin.cout))
     return (y, stats) if with_stats else y
+
+
+def gemv_bf16(v, lin: PackedLinear):
+    """One vector per cloud through a layer: v (B,cin[,1]) fp32 -> (B,cout) fp32 = b + sum_k bf16(w) bf16(v) (captra_gemv_bf16)."""
+    L.require_device(v)
+    B = v.shape[0]
+    assert v.dtype == torch.float32 and v.numel() == B * lin.cin
+    y = torch.empty(B, lin.cout, dtype=torch.float32, device=v.device)
+    with torch.cuda.device(v.device):
+        L.call("captra_gemv_bf16", B, lin.cin, lin.cout, L.ptr(v), L.ptr(lin.wt), L.ptr(lin.bias), L.ptr(y))
+    return y
+
+
+def chain_tile_bf16_supported(c0: int, l: int, layers, pool: bool = False) -> bool:
+    """A run of dense layers on a channel-major fp32 input, every layer through the LDS-tiled kernel."""
+    return (USE_TILE_BF16 and mlp_dtype() == "bf16" and l % 4 == 0 and l >= 4 and layers[0].cout >= 32
+            and all(lin.cout >= 64 for lin in layers[1:]) and (not pool or l <= 128))
+
+
+def mlp_chain_bf16_tile(x, layers, acts, x2=None, out_pm: bool = False, pool: bool = False, bias_bc=None):
+    """x (B,c,l) fp32 [+ x2 (B,c',l): the input is their channel concat, never built] through `layers`, hidden activations bf16
+    point-major in HBM; the result as (B,c_n,l) fp32, the point-major bf16 tensor (out_pm), or (B,c_n,1) = its max over the
+    positions (pool).  bias_bc (B,c_1): a per-cloud bias for the first layer."""
+    B = x.shape[0]
+    l = x.numel() // max(B * x.shape[1], 1)
+    y = x.contiguous()
+    for i, (lin, act) in enumerate(zip(layers, acts)):
+        last = i == len(layers) - 1
+        mode = OUT_PM if (not last or out_pm) else (OUT_MAX if pool else OUT_CM)
+        y = dense_bf16_tile(y, lin, act=act, x2=x2 if i == 0 else None, l=l, out_mode=mode, bias_bc=bias_bc if i == 0 else None)
+    return y
 
 
 def head12_bf16_supported(x, lin1: PackedLinear, lin2: PackedLinear) -> bool:
@@ -314,6 +364,9 @@ def mlp_chain_bf16(x, layers, acts, out_pm: bool = False):
     acts[-1](W_n ... relu(W_1 x + b_1) ...) as (B,c_n,*) fp32, or the (B,l,ceil32(c_n)) bf16 slot-order tensor when out_pm."""
     B = x.shape[0]
     l = x.numel() // max(B * x.shape[1], 1)
+    if chain_tile_bf16_supported(x.shape[1], l, layers):
+        y = mlp_chain_bf16_tile(x.view(B, x.shape[1], l), layers, acts, out_pm=out_pm)
+        return y if out_pm else y.view((B, layers[-1].cout) + tuple(x.shape[2:]))
     y, in_pm = x.contiguous(), False
     for i, (lin, act) in enumerate(zip(layers, acts)):
         last = i == len(layers) - 1

@@ -287,6 +287,11 @@ class PointNetFeaturePropagation(_FoldCache, nn.Module):
             layers = list(self._fold(xyz1.device))
             c1 = points1.shape[1]
             lin0 = layers[0]
+            if fused.chain_tile_bf16_supported(c1, N, layers):
+                # LDS-tiled kernels (csrc/tile_bf16.hip): the per-cloud product as one small launch, then the layers
+                bias_bc = fused.gemv_bf16(points2.contiguous(), lin0.trailing_rows(c1))
+                sub = [lin0.leading_rows(c1)] + layers[1:]
+                return fused.mlp_chain_bf16_tile(points1.contiguous(), sub, [fused.ACT_RELU] * len(sub), bias_bc=bias_bc).view(B, layers[-1].cout, N)
             bias_bc = fused.pointwise_mlp_bf16pm(points2.contiguous(), lin0.trailing_rows(c1), 1, in_pm=False, out_pm=False)
             y = fused.pointwise_mlp_bf16pm_cloud_bias(points1.contiguous(), lin0.leading_rows(c1), N, bias_bc.view(B, lin0.cout),
                                                       out_pm=len(layers) > 1, act=fused.ACT_RELU)
@@ -357,7 +362,6 @@ class PointNetSetAbstraction(_FoldCache, nn.Module):
         """xyz (B,3,N), points (B,D,N) -> (new_xyz zeros (B,3,1), features (B,D',1))."""
         assert self.group_all, "only group_all is implemented (as in the reference, l.330)"
         B, C, N = xyz.shape
-        x = torch.cat([xyz, points], dim=1) if _has_points(points) else xyz       # (B,3+D,N), xyz first
         if (not self.training) and xyz.is_cuda:
             # (eval: the all-zero "centre" of the pooled level is a constant nobody writes -- one tensor per shape, not a fill per step)
             key = (B, C, xyz.device, xyz.dtype)
@@ -371,6 +375,10 @@ class PointNetSetAbstraction(_FoldCache, nn.Module):
             # of 128 and the group maxima are maxed again (max is exact, so the split does not change a bit)
             folded = self._fold(xyz.device)
             groups, k = (1, N) if N <= 128 else (N // 128, 128)
+            if fused.mlp_dtype() == "bf16" and _has_points(points) and fused.chain_tile_bf16_supported(C + points.shape[1], N, folded, pool=True):
+                # LDS-tiled kernels: [xyz, feat] read as two sources (no concat), the max over the points in the last layer's epilogue
+                return new_xyz, fused.mlp_chain_bf16_tile(xyz.contiguous(), folded, [fused.ACT_RELU] * len(folded), x2=points.contiguous(), pool=True)
+            x = torch.cat([xyz, points], dim=1) if _has_points(points) else xyz       # (B,3+D,N), xyz first
             if fused.mlp_dtype() == "bf16":      # hidden activations bf16 point-major; the (exact) max on the last layer's fp32 output
                 y = fused.mlp_chain_bf16(x.contiguous(), folded, [fused.ACT_RELU] * len(folded))
                 return new_xyz, fused.row_max(y.view(B, self.out_channel, N))
@@ -380,6 +388,7 @@ class PointNetSetAbstraction(_FoldCache, nn.Module):
             out = torch.empty(B, self.out_channel, groups, dtype=torch.float32, device=xyz.device)
             fused.mlp_max(y, folded[-1], out, 0)
             return new_xyz, (out if groups == 1 else out.max(dim=2, keepdim=True)[0])
+        x = torch.cat([xyz, points], dim=1) if _has_points(points) else xyz           # (B,3+D,N), xyz first
         y = x.unsqueeze(-1)                                                        # (B,3+D,N,1)
         for conv, bn in zip(self.mlp_convs, self.mlp_bns):
             y = F.relu(bn(conv(y)))

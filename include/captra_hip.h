@@ -275,6 +275,19 @@ int captra_gn_stats_bf16pm(int b, int c, long long l, const void *x, float *stat
 int captra_dense_bf16_tile_stats_tiles(long long l);
 int captra_dense_bf16_tile(int b, int cin, int cout, long long l, const void *x, const unsigned char *wimg, const float *bias_packed,
                            long long bias_bs, const float *ab, int act, void *y, float *stats, captra_stream_t stream);
+/* captra_dense_bf16_tile_ex: the same kernel with a channel-major fp32 input and / or an fp32 or pooled output (the 128- and
+ * 512-point levels of the backbone: SA3's group_all MLP + max, FP3, FP2 -- pointnet_utils.py:253-343).  in_cm = 1: x (B,csplit,L)
+ * fp32 holds input channels [0, csplit), x2 (B,cin - csplit,L) the rest (csplit = cin, x2 = NULL for one tensor): the
+ * [xyz, feat] concat of sample_and_group_all (pointnet_utils.py:171-188) is never built; l % 4 == 0.  out_mode 0: y (B,L,ceil32(cout))
+ * bf16 slot order; 1: y (B,cout,L) fp32; 2: y (B,cout) fp32 = max over the l <= 128 positions (torch.max(-1) of pointnet_utils.py:341).
+ * wimg packed with perm = 1 in every case. */
+int captra_dense_bf16_tile_ex(int b, int cin, int cout, long long l, int in_cm, const void *x, const float *x2, int csplit,
+                              const unsigned char *wimg, const float *bias_packed, long long bias_bs, const float *ab, int act,
+                              int out_mode, void *y, float *stats, captra_stream_t stream);
+/* One vector per cloud through a layer (FP3's per-cloud bias W2 v + b, pointnet_utils.py:265-268 with S == 1): x (B,cin) fp32 ->
+ * y (B,cout) fp32 = bias + sum_k bf16(w[k]) bf16(x[k]); wt_packed / bias_packed as for captra_pointwise_mlp. */
+int captra_gemv_bf16(int b, int cin, int cout, const float *x, const float *wt_packed, const float *bias_packed, float *y,
+                     captra_stream_t stream);
 int captra_head12_bf16(int b, int cin, long long l, const void *x, const unsigned char *w1img, const float *bias1_packed,
                        const float *ab1, const unsigned char *w2img, const float *bias2_packed, void *y2, float *stats,
                        captra_stream_t stream);

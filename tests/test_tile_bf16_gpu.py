@@ -141,3 +141,93 @@ def test_rotation_head_chain_tiled_vs_streaming_and_torch(device):
     for name, other, mx, mean in (("torch", ref, 5e-2, 6e-3), ("round-3 route", old, 5e-2, 6e-3)):
         d = (got - other).abs()
         assert float(d.max()) <= mx * scale and float(d.mean()) <= mean * scale, (name, float(d.max()) / scale, float(d.mean()) / scale)
+
+
+@pytest.mark.parametrize("cin,csplit,cout,l", [(515, 3, 256, 128), (576, 576, 256, 512), (512, 512, 256, 128), (134, 6, 128, 4096),
+                                               (40, 17, 70, 76), (320, 320, 32, 512), (512, 100, 1024, 128)])
+def test_tile_layer_channel_major_input_and_fp32_outputs(device, cin, csplit, cout, l):
+    """captra_dense_bf16_tile_ex with a channel-major fp32 input (optionally two tensors standing for their concat) and its three
+    output forms, against the streaming kernel on the concatenated input and the float64 contract; the pooled form is the exact
+    max of the fp32 form."""
+    from captra_amd import fused
+    rng = np.random.default_rng(cin + 5 * cout + l)
+    B = 3
+    x = rng.standard_normal((B, cin, l)).astype(np.float32)
+    w = (rng.standard_normal((cin, cout)) / np.sqrt(cin)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    lin = fused.pack(_dev(w, device), _dev(b, device))
+    xd = _dev(x, device)
+    xa = xd[:, :csplit].contiguous()
+    xb = xd[:, csplit:].contiguous() if csplit < cin else None
+    for act in (fused.ACT_NONE, fused.ACT_RELU):
+        want_pm = fused.pointwise_mlp_bf16pm(xd, lin, l, in_pm=False, out_pm=True, act=act)
+        want_cm = fused.pointwise_mlp_bf16pm(xd, lin, l, in_pm=False, out_pm=False, act=act)
+        got_pm = fused.dense_bf16_tile(xa, lin, act=act, x2=xb, out_mode=fused.OUT_PM)
+        got_cm = fused.dense_bf16_tile(xa, lin, act=act, x2=xb, out_mode=fused.OUT_CM)
+        # (the streaming kernel multiplies a k-step's 16 channels in natural order, this one in slot order: the MFMA's internal
+        # summation differs, so fp32 results agree to rounding and a bf16 output may flip by one ulp on a tie)
+        scale = max(1.0, float(want_cm.abs().max()))
+        assert float((got_cm - want_cm).abs().max()) <= 2e-5 * scale
+        a, w_ = got_pm.float(), want_pm.float()
+        assert float((a - w_).abs().max()) <= 2.0 ** -7 * scale and float((a == w_).float().mean()) > 0.995
+        if l <= 128:
+            got_mx = fused.dense_bf16_tile(xa, lin, act=act, x2=xb, out_mode=fused.OUT_MAX)
+            assert torch.equal(got_mx, got_cm.max(dim=2, keepdim=True)[0])
+    ref = _bf16_layer(x, w, b, 1)
+    np.testing.assert_allclose(got_cm.cpu().numpy(), ref, atol=2e-5 * max(1.0, float(np.abs(ref).max())), rtol=0)
+    # point-major in -> fp32 out / pooled
+    if cout >= 64:
+        xpm = _dense_to_pm(_bf16_round(x)).to(device)
+        want = fused.pointwise_mlp_bf16pm(xpm, lin, l, in_pm=True, out_pm=False, act=fused.ACT_RELU)
+        assert torch.equal(fused.dense_bf16_tile(xpm, lin, act=fused.ACT_RELU, out_mode=fused.OUT_CM), want)
+        if l <= 128:
+            assert torch.equal(fused.dense_bf16_tile(xpm, lin, act=fused.ACT_RELU, out_mode=fused.OUT_MAX), want.max(dim=2, keepdim=True)[0])
+
+
+def test_gemv_bf16_vs_float64(device):
+    from captra_amd import fused
+    rng = np.random.default_rng(4)
+    for B, cin, cout in [(32, 1024, 256), (3, 77, 70)]:
+        v = rng.standard_normal((B, cin)).astype(np.float32)
+        w = (rng.standard_normal((cin, cout)) / np.sqrt(cin)).astype(np.float32)
+        b = rng.standard_normal(cout).astype(np.float32)
+        got = fused.gemv_bf16(_dev(v, device), fused.pack(_dev(w, device), _dev(b, device))).cpu().numpy()
+        want = _bf16_round(v).astype(np.float64) @ _bf16_round(w).astype(np.float64) + b
+        np.testing.assert_allclose(got, want, atol=2e-5 * max(1.0, np.abs(want).max()), rtol=0)
+
+
+def test_sa3_and_fp_levels_tiled_vs_streaming_route(device):
+    """The 128- / 512-point levels in the bf16 mode (pointnet_utils.py:253-343: group_all SA3, FP3 with one source vector per cloud,
+    FP2): the round-4 route (LDS-tiled kernels, no concat, pooled epilogue, per-cloud product as a GEMV) against the round-3 route
+    (streaming kernels) -- the same contract layer by layer, so agreement to accumulation-order noise."""
+    from captra_amd import fused
+    from captra_amd.pointnet_utils import PointNetFeaturePropagation, PointNetSetAbstraction
+    torch.manual_seed(2)
+    B = 4
+    sa3 = PointNetSetAbstraction(None, None, None, 512 + 3, [256, 512, 1024], True).to(device).eval()
+    fp3 = PointNetFeaturePropagation(in_channel=1536, mlp=[256, 256]).to(device).eval()
+    fp2 = PointNetFeaturePropagation(in_channel=576, mlp=[256, 128]).to(device).eval()
+    with torch.no_grad():
+        for m in list(sa3.mlp_bns) + list(fp3.mlp_bns) + list(fp2.mlp_bns):
+            m.running_mean.normal_(0, 0.1)
+            m.running_var.uniform_(0.5, 1.5)
+    l1_xyz, l2_xyz = torch.rand(B, 3, 512, device=device) - 0.5, torch.rand(B, 3, 128, device=device) - 0.5
+    l1_pts, l2_pts = torch.randn(B, 320, 512, device=device), torch.randn(B, 512, 128, device=device).relu()
+
+    def run():
+        with torch.no_grad(), fused.use_mlp_dtype("bf16"):
+            l3_xyz, l3 = sa3(l2_xyz, l2_pts)
+            l2n = fp3(l2_xyz, l3_xyz, l2_pts, l3)
+            return l3, l2n, fp2(l1_xyz, l2_xyz, l1_pts, l2n)
+
+    new = run()
+    fused.USE_TILE_BF16 = False
+    try:
+        old = run()
+    finally:
+        fused.USE_TILE_BF16 = True
+    for a, o, name in zip(new, old, ("sa3", "fp3", "fp2")):
+        assert a.shape == o.shape and a.dtype == o.dtype == torch.float32, name
+        scale = float(o.abs().max())
+        d = (a - o).abs()
+        assert float(d.max()) <= 3e-2 * scale and float(d.mean()) <= 5e-4 * scale, (name, float(d.max()) / scale, float(d.mean()) / scale)
