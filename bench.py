@@ -402,6 +402,36 @@ def hbm_ops_roofline(batch: int, device, reps: int = 5):
     return out
 
 
+def config_leg(name: str, extra: list, timeout_s: int = 120):
+    """Another BASELINE.json configuration in a process of its own (as the `otf` / `b1` legs): this command with `extra`
+    arguments and --leg (a short timed region, no legs / CPU baseline of its own), or tools/bench_backbone.py for configs[4].
+    -> the compact record that goes into the main line."""
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    if name == "backbone16k":
+        cmd = [sys.executable, os.path.join(here, "tools", "bench_backbone.py"), "--npoint", "2048", "512", "--steps", "20", "--warmup", "10"]
+    else:
+        cmd = [sys.executable, os.path.abspath(__file__), "--leg"] + extra
+    t0 = time.perf_counter()
+    try:
+        res = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        return {"error": f"timed out after {timeout_s} s", "command": " ".join(cmd[1:])}
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    if res.returncode != 0 or not lines:
+        return {"error": (res.stderr or res.stdout)[-500:], "command": " ".join(cmd[1:])}
+    d = json.loads(lines[-1])
+    keep = ("metric", "value", "unit", "ms_per_step", "dtype", "steps", "roofline", "kernel_ms_per_step", "timed_blocks", "config")
+    out = {k: d[k] for k in keep if k in d}
+    if isinstance(out.get("config"), dict):
+        out["config"] = {"workload": out["config"].get("workload")}
+    if isinstance(out.get("timed_blocks"), dict):
+        out["timed_blocks"] = {k: out["timed_blocks"][k] for k in ("n", "ms_per_step_median", "ms_per_step_min", "ms_per_step_max") if k in out["timed_blocks"]}
+    out["command"] = "python " + " ".join(os.path.relpath(c, here) if c.startswith(here) else c for c in cmd[1:])
+    out["leg_wall_s"] = round(time.perf_counter() - t0, 1)
+    return out
+
+
 def pmc_traffic(kernel_prefixes, suffix: str = ""):
     """HBM bytes per launch of the MFMA family from the newest committed PMC summary (profiles/*_bench_pmc.json,
     written by tools/profile_round.sh from separate rocprofv3 --pmc passes): 2 x FETCH_SIZE (gfx950 correction,
@@ -512,6 +542,9 @@ def main():
     ap.add_argument("--otf-only", action="store_true", help=argparse.SUPPRESS)          # the `otf` leg's own process: prints that object only
     ap.add_argument("--b1-only", action="store_true", help=argparse.SUPPRESS)           # the `b1` leg's own process
     ap.add_argument("--no-b1", action="store_true", help="skip the `b1` leg (single-trajectory latency, pre-cropped and nocs_otf)")
+    ap.add_argument("--no-legs", action="store_true",
+                    help="skip the `bf16` (BASELINE.json configs[2]'s arithmetic), `drawers` (configs[3]) and `backbone16k` (configs[4]) legs")
+    ap.add_argument("--leg", action="store_true", help=argparse.SUPPRESS)               # a configuration leg's own process: short timed region, the line only
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     ap.add_argument("--no-graph", action="store_true", help="launch the step eagerly instead of replaying a hipGraph")
     ap.add_argument("--lanes", type=int, default=0,
@@ -536,6 +569,10 @@ def main():
     if args.dry_run:
         print(json.dumps(launch_plan(args.gpus)))
         return
+    if args.leg:
+        args.no_cpu_baseline = args.no_otf = args.no_b1 = args.no_legs = args.no_pose_match = True
+        args.min_timed_s = min(args.min_timed_s, 2.0)
+        args.repeats = min(args.repeats, 5)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     if args.otf_only:
@@ -722,7 +759,7 @@ def main():
                    "points": 4096, "trajectories_per_gpu": B, "distinct_clouds_per_gpu": B,
                    "parallelism": f"dp{world} (trajectory-sharded, RCCL all-gather of poses)",
                    "weights": f"seeded default_rng(7) on the real architecture ({sum(v.numel() for v in sd.values()) / 1e6:.2f} M params incl. BN statistics), "
-                              "physical-regime plants (tests/weights.make_physical_state_dict)",
+                              "physical-regime plants (captra_amd/synthetic.make_physical_state_dict)",
                    "launch": (f"{args.lanes} free-running lanes of {B // args.lanes} trajectories, each a hipGraph replay of the step on its own stream" if lanes is not None
                               else "hipGraph replay of the step" if graph is not None else "eager launches")
                              + (", CoordinateNet and RotationNet side by side on two streams" + (" (two branches of the graph)" if graph is not None else "")
@@ -730,7 +767,12 @@ def main():
         "timed_blocks": {"n": len(blocks), "steps_each": args.steps, "ms_per_step_median": round(1e3 * elapsed / args.steps, 3),
                          "ms_per_step_min": round(1e3 * order[0] / args.steps, 3), "ms_per_step_max": round(1e3 * order[-1] / args.steps, 3),
                          "value_from": "median block; every block = exactly `steps` steps between barrier + device synchronize, max over ranks",
-                         "warmup_steps_run": warm},
+                         "warmup_steps_run": warm,
+                         # which hardware queues the lanes' streams were given is decided when the process creates them (DESIGN.md
+                         # section 5); a bad draw shows as a second mode of the block times, so the distribution is reported
+                         "ms_per_step_p10": round(1e3 * order[len(order) // 10] / args.steps, 3),
+                         "ms_per_step_p90": round(1e3 * order[(9 * len(order)) // 10 if len(order) > 1 else 0] / args.steps, 3),
+                         "bimodal": bool(len(order) >= 5 and order[(9 * len(order)) // 10] > 1.05 * order[len(order) // 10])},
         "rccl_world_size": rccl_world,
         "collective_backend": ("none (single rank)" if dist is None else "nccl (RCCL)" if backend == "nccl" else
                                "gloo -- CAPTRA_BENCH_SHARE_GPU functional test mode: ranks share GPUs, NOT a scaling measurement"),
@@ -756,12 +798,14 @@ def main():
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                                "frac": round(ach / peak, 4), "traffic": None,
                                "kernel": ("fp32 MFMA shared-MLP kernels: sa_wave_kernel / sa_wave_lds_kernel (dominant) + mlp_chain3_kernel + coord_tail_kernel + pw_direct_kernel + pw_direct_max_kernel"
-                                          if args.mlp_dtype == "fp32" else "bf16 MFMA 32x32x16 shared-MLP kernels: sa_bf16_kernel (SA scales, dominant) + pw_bf16pm_kernel / pw_bf16pm_affs_kernel (dense layers, bf16 point-major activations) + pw_bf16_kernel"),
+                                          if args.mlp_dtype == "fp32" else "bf16 MFMA 32x32x16 shared-MLP kernels: sa_bf16_kernel (SA scales, dominant) + tb_head12_kernel / tb_layer_kernel (LDS-tiled dense layers, bf16 point-major activations) + chain_bf16_kernel + pw_bf16pm_kernel / pw_bf16_kernel"),
                                "avg_launch_us": round(1e3 * mlp_ms / max(mlp_launches, 1), 2),
                                "flops_per_launch": round(mlp_flops / max(mlp_launches, 1)),
                                "share_of_kernel_time": round(mlp_ms / max(total_ms, 1e-9), 3), "dominant_family": dominant}
-            traffic, src, why = pmc_traffic(["sa_bf16_kernel", "pw_bf16pm_kernel", "pw_bf16pm_affs_kernel", "pw_bf16_kernel"], "_bf16") if args.mlp_dtype != "fp32" else pmc_traffic(
-                ["sa_wave_kernel", "sa_wave_lds_kernel", "sa_wave_pipe_kernel", "sa_fused_kernel", "mlp_chain3_kernel", "coord_tail_kernel", "pw_direct_kernel", "pw_direct_max_kernel", "pw_mlp_kernel"])
+            # the counter file of THIS configuration (tools/profile_round.sh <tag> <suffix> ...): bf16 / drawers have their own
+            sfx = ("_bf16" if args.mlp_dtype != "fp32" else "") + ("_drawers" if args.category == "drawers" else "")
+            traffic, src, why = pmc_traffic(["sa_bf16_kernel", "tb_layer_kernel", "tb_head12_kernel", "chain_bf16_kernel", "pw_bf16pm_kernel", "pw_bf16pm_affs_kernel", "pw_bf16_kernel"], sfx) if args.mlp_dtype != "fp32" else pmc_traffic(
+                ["sa_wave_kernel", "sa_wave_lds_kernel", "sa_wave_pipe_kernel", "sa_fused_kernel", "mlp_chain3_kernel", "coord_tail_kernel", "pw_direct_kernel", "pw_direct_max_kernel", "pw_mlp_kernel"], sfx)
             if traffic is not None:
                 out["roofline"]["traffic"] = round(traffic)
                 out["roofline"]["traffic_source"] = (f"profiles/{src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch; "
@@ -770,13 +814,20 @@ def main():
                 out["roofline"]["traffic_source"] = f"null: {why}"
                 print(f"bench.py: roofline.traffic dropped -- {why}", file=sys.stderr)
         if "ball_query" in fams:
+            # the scan is N x M distance tests per cloud (VALU work: 8 packed-fp32 instructions per 128 tests + the ordered
+            # compaction), not a byte stream: reported as pair tests per second against the packed-fp32 VALU rate, with the
+            # section 8(d) bytes beside it for the record
             bq = fams["ball_query"]
             nbytes = fused.WORK["bytes"].get("ball_query", 0.0)
-            gbs = nbytes / (bq["ms_total"] * 1e-3) / 1e9
-            bq_traffic, bq_src, bq_why = pmc_traffic(("ball_query_kernel",), "_bf16" if args.mlp_dtype != "fp32" else "")
-            out["roofline_ball_query"] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                          "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None if bq_traffic is None else round(bq_traffic),
-                                          "traffic_source": bq_src if bq_traffic is not None else f"null: {bq_why}",
+            pairs = fused.WORK["flops"].get("ball_query", 0.0)
+            sec = bq["ms_total"] * 1e-3
+            peak_pairs = 256 * 4 * 2.4e9 * 64 / 8.0              # one wave-instruction per 2 cycles per SIMD, 8 instructions per 64 lanes x 2 tests ... upper bound
+            out["roofline_ball_query"] = {"bound": "valu", "unit": "pair tests/s", "achieved": round(pairs / sec) if pairs else None,
+                                          "peak": round(peak_pairs), "frac": round(pairs / sec / peak_pairs, 4) if pairs else None,
+                                          "peak_note": "1024 SIMDs x 2.4 GHz x 8 tests per cycle: a pair test is 8 fp32 operations (3 sub, 3 mul, 2 add, unfused as the "
+                                                       "reference) = 4 packed instructions per lane, a wave64 instruction issues in 2 cycles; the distance "
+                                                       "arithmetic alone, no compaction; `achieved` counts all N x M pairs although the scan exits early",
+                                          "algorithmic_GB/s": round(nbytes / sec / 1e9, 1),
                                           "avg_launch_us": round(1e3 * bq["ms_total"] / bq["launches"], 2)}
         out["kernel_ms_per_step"] = {k: round(v["ms_total"] / timed_steps, 3) for k, v in sorted(fams.items(), key=lambda kv: -kv[1]["ms_total"])}
         out["kernel_ms_per_step"]["_sum_captra_kernels"] = round(total_ms / timed_steps, 3)
@@ -804,6 +855,11 @@ def main():
         res = subprocess.run([sys.executable, os.path.abspath(__file__), "--b1-only"], capture_output=True, text=True)
         lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
         out["b1"] = json.loads(lines[-1]) if res.returncode == 0 and lines else {"error": (res.stderr or res.stdout)[-500:]}
+    if world == 1 and not args.no_legs and args.mlp_dtype == "fp32" and args.category == "bottle":
+        # BASELINE.json configs[2] (arithmetic), [3] and [4], each measured by this run in a process of its own
+        out["legs"] = {"bf16": config_leg("bf16", ["--mlp-dtype", "bf16", "--batch", str(B)]),
+                       "drawers": config_leg("drawers", ["--category", "drawers", "--batch", str(B)]),
+                       "backbone16k": config_leg("backbone16k", [])}
     if world == 1 and not args.no_cpu_baseline and args.category == "bottle":
         out["cpu_baseline"] = cpu_baseline(cfg, sd, args.cpu_budget)
         out["cpu_baseline"]["reference_cpu_path_in_authoring_container"] = {

@@ -66,7 +66,8 @@ def ball_query_multi(radii, nsamples, xyz_n3, new_xyz_n3):
         L.call("captra_ball_query_multi", B, N, M, nr, C.cast(c_r, C.c_void_p), C.cast(c_k, C.c_void_p),
                L.ptr(new_xyz_n3), L.ptr(xyz_n3), C.cast(c_p, C.c_void_p))
     # ball_query = 12N + 12M + 4MK bytes per cloud and radius
-    _work("ball_query", nbytes=B * sum(12 * N + 12 * M + 4 * M * int(k) for k in nsamples))
+    # (`flops` carries the scan's N x M pair tests -- one scan serves every radius; the early exit makes it an upper bound)
+    _work("ball_query", flops=float(B) * N * M, nbytes=B * sum(12 * N + 12 * M + 4 * M * int(k) for k in nsamples))
     return outs
 
 
@@ -388,7 +389,8 @@ USE_CHAIN_BF16 = True     # FP1 + conv1 (+ CoordinateNet's heads) register-resid
 
 
 def chain_bf16_supported(x, layers, heads=None) -> bool:
-    if not (USE_CHAIN_BF16 and mlp_dtype() == "bf16" and len(layers) == 3 and x.dim() == 3 and x.shape[1] <= 144):
+    # (captra_mlp_chain_bf16 instantiates 8 and 9 input k-steps: 113 .. 144 input channels; anything else returns -2)
+    if not (USE_CHAIN_BF16 and mlp_dtype() == "bf16" and len(layers) == 3 and x.dim() == 3 and (x.shape[1] + 15) // 16 in (8, 9)):
         return False
     if not all(lin.cout == 128 for lin in layers) or layers[1].cin != 128 or layers[2].cin != 128 or x.shape[1] * x.shape[2] * 4 >= (1 << 31):
         return False

@@ -211,7 +211,7 @@ class EvalTrackModel(BaseModel):
     def _step_post(self, input, npcs_input, npcs_pred, last_pose):
         pred_npcs = npcs_pred["nocs"].reshape(len(npcs_pred["nocs"]), self.num_parts, 3, -1)
         input["state"] = {"part": last_pose}
-        lab32 = npcs_pred.pop("labels_i32", None)        # CoordinateNet's fused read-out: int32 labels next to the softmax
+        lab32 = getattr(self.npcs_net, "last_labels_i32", None)   # CoordinateNet's fused read-out: int32 labels beside the softmax
         if lab32 is not None and not (self.track_cfg["gt_label"] or self.track_cfg["nocs2d_label"]):
             input["pred_labels_i32"] = lab32             # what the one-launch rotation read-out and pose fit take
             input["pred_labels"] = lab32 if self._overlap_nets(input) else lab32.long()

@@ -67,7 +67,9 @@ class PoseExchange:
         if not all(x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() for x in t):
             return False
         n = self.local.shape[0] * self.local.shape[1]
-        if pose["scale"].numel() != n:
+        # the kernel reads 9 n / 3 n / n / n floats unchecked: every tensor must have exactly that many, on the records' device
+        if (pose["scale"].numel() != n or pose["rotation"].numel() != 9 * n or pose["translation"].numel() != 3 * n
+                or (valid is not None and valid.numel() != n) or any(x.device != self.local.device for x in t)):
             return False
         from . import _lib as L
         with torch.cuda.device(self.local.device):

@@ -364,10 +364,12 @@ class PointNetSetAbstraction(_FoldCache, nn.Module):
         B, C, N = xyz.shape
         if (not self.training) and xyz.is_cuda:
             # (eval: the all-zero "centre" of the pooled level is a constant nobody writes -- one tensor per shape, not a fill per step)
+            # kept per shape and never freed while the module lives: a hipGraph captured at another batch size holds the address
             key = (B, C, xyz.device, xyz.dtype)
-            if getattr(self, "_zero_xyz", (None, None))[0] != key:
-                self._zero_xyz = (key, torch.zeros(B, C, 1, device=xyz.device, dtype=xyz.dtype))
-            new_xyz = self._zero_xyz[1]
+            cache = self.__dict__.setdefault("_zero_xyz", {})
+            if key not in cache:
+                cache[key] = torch.zeros(B, C, 1, device=xyz.device, dtype=xyz.dtype)
+            new_xyz = cache[key]
         else:
             new_xyz = torch.zeros(B, C, 1, device=xyz.device, dtype=xyz.dtype)
         if (not self.training) and xyz.is_cuda and N % 32 == 0 and (128 % N == 0 or N % 128 == 0):

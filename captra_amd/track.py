@@ -339,8 +339,9 @@ def _write_gathered_results(cfg, ranks: Ranks, records, gathered, capacity: int)
                     mine = torch.as_tensor(pose[key])
                     # bit patterns, not values: a NaN pose (diverged / empty part under --random_init) equals itself on the wire
                     if not torch.equal(wire.float().contiguous().view(torch.int32), mine.float().contiguous().view(torch.int32)):
-                        print(f"WARNING: pose exchange of {name} frame {i} {key} differs from the owning rank's record "
-                              f"(max |diff| {float((wire.float() - mine.float()).abs().nan_to_num(0.0).max()):.3g}); writing the all-gathered one", flush=True)
+                        raise RuntimeError(f"pose exchange of {name} frame {i} {key}: the all-gathered record differs from what rank {r} "
+                                           f"computed (max |diff| {float((wire.float() - mine.float()).abs().nan_to_num(0.0).max()):.3g}); "
+                                           "refusing to write a corrupted wire copy into the result pickles")
                     pose[key] = wire.clone() if torch.is_tensor(pose[key]) else wire.numpy().copy()
             out.append((name, rec))
     write_result_pickles(cfg["experiment_dir"], out)
