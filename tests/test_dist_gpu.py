@@ -144,3 +144,18 @@ def test_pose_exchange_packs_on_the_device_like_pack_pose(device):
     assert torch.equal(back["rotation"], pose["rotation"]) and torch.equal(ok, valid > 0.5)
     strided = dict(pose, rotation=pose["rotation"].transpose(2, 3))
     assert torch.equal(ex.all_gather(strided).clone(), pack_pose(strided))
+
+
+def test_headline_is_stable_across_fresh_processes(device):
+    """which hardware queues the lanes' streams get is decided when a process creates them, and the
+    pre-cropped lanes keep the one-graph form (captra_amd/graph.py) -- five fresh processes of the headline command (short timed
+    region) must agree within 5 % and none may report a bimodal block distribution."""
+    vals, bimodal = [], []
+    for _ in range(5):
+        res = _bench(["--leg", "--steps", "20", "--repeats", "5", "--min-timed-s", "1.5", "--no-kernel-timing"])
+        assert res.returncode == 0, res.stderr[-2000:]
+        line = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+        vals.append(line["ms_per_step"])
+        bimodal.append(line["timed_blocks"]["bimodal"])
+    assert max(vals) <= 1.05 * min(vals), vals
+    assert not any(bimodal), (vals, bimodal)

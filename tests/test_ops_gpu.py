@@ -214,6 +214,46 @@ def test_fps_gather_ragged_batch(device):
             np.testing.assert_array_equal(n3[i].cpu().numpy(), full[i, ref])
 
 
+def test_fps_dispatcher_is_never_far_behind_the_better_kernel(device):
+    """the plain / pruned dispatch (csrc/fps.hip: clouds of >= 8192 points take the pruned kernel) over the
+    grid of tools/bench_fps.py -- surface-like and uniform clouds around the crossover -- must stay within 10 % of whichever
+    kernel is faster (best of three timings each; same picks from both)."""
+    import ctypes
+    import time
+    from captra_amd import _lib, fused
+    lib = _lib.lib()
+
+    def best(x, m, pm):
+        lib.captra_fps_set_pruned_min(ctypes.c_int(pm))
+        out = fused.fps_gather(x, m)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            out = fused.fps_gather(x, m)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        return min(ts), out[0]
+
+    try:
+        for n, m, B in [(8192, 1024, 8), (12288, 2048, 8), (16384, 2048, 8), (15000, 4096, 16)]:
+            for kind in ("surface", "uniform"):
+                rng = np.random.default_rng(n + len(kind))
+                if kind == "uniform":
+                    xyz = np.stack([clouds.s_uni(i, n) for i in range(B)])
+                else:
+                    th, hh = rng.random((B, n)) * 2 * np.pi, rng.random((B, n)) - 0.5
+                    xyz = (np.stack([0.2 * np.cos(th), hh, 0.2 * np.sin(th)], -1) + rng.normal(0, 0.004, (B, n, 3))).astype(np.float32)
+                x = torch.from_numpy(np.ascontiguousarray(xyz, np.float32)).to(device)
+                t_plain, i_plain = best(x, m, 0)
+                t_pruned, i_pruned = best(x, m, 1)
+                t_disp, i_disp = best(x, m, 8192)                     # the library's default threshold
+                assert torch.equal(i_plain, i_pruned) and torch.equal(i_disp, i_plain)
+                assert t_disp <= 1.10 * min(t_plain, t_pruned), (n, m, kind, t_plain, t_pruned, t_disp)
+    finally:
+        lib.captra_fps_set_pruned_min(ctypes.c_int(8192))
+
+
 def test_fps_big_cloud_fallback(pn, device):
     xyz = clouds.s_uni(0, 40000)[None]
     got = pn.furthest_point_sample(_dev(xyz, device), 64).cpu().numpy()
