@@ -503,6 +503,7 @@ def launch_plan(n: int) -> dict:
             "would_refuse": bool(n > 1 and have < n and not share),
             "command": "python bench.py (this process, no launcher)" if n == 1 else " ".join(spawn_command(n, port=29500)) + "   # port: a free one is picked at launch",
             "env": {"HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")},
+            "cpu_binding": "each rank pins its host threads to its share of the cores NUMA-local to its GPU (sysfs local_cpulist; an even split of the allowed cores when unknown)",
             "ranks": [{"rank": r, "local_rank": r, "device": f"cuda:{r % have if share and have else r}",
                        "tracks": "32 trajectories (--batch), seeds (10 + rank) * 100 + b; category per --category (mix6: NOCS category 1 + rank mod 6)"}
                       for r in range(n)],
@@ -617,7 +618,8 @@ def main():
             dist.init_process_group(backend="gloo")
 
     from captra_amd import _lib, fused
-    from captra_amd.parallel import PoseExchange
+    from captra_amd.parallel import PoseExchange, bind_rank_cpus
+    bound_cpus = bind_rank_cpus(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)), dev_index) if world > 1 else None
 
     cfg, sd, model, data = build_workload(args.batch, device, category=args.category, traj_seed=rank, mlp_dtype=args.mlp_dtype)
     B, P = args.batch, cfg["num_parts"]
@@ -774,6 +776,8 @@ def main():
                          "ms_per_step_p90": round(1e3 * order[(9 * len(order)) // 10 if len(order) > 1 else 0] / args.steps, 3),
                          "bimodal": bool(len(order) >= 5 and order[(9 * len(order)) // 10] > 1.05 * order[len(order) // 10])},
         "rccl_world_size": rccl_world,
+        "rank0_cpu_affinity": (f"{len(bound_cpus)} cores next to its GPU ({bound_cpus[0]}..{bound_cpus[-1]}); every rank binds to its own share "
+                               "(captra_amd.parallel.bind_rank_cpus)") if bound_cpus else "unbound (single rank)",
         "collective_backend": ("none (single rank)" if dist is None else "nccl (RCCL)" if backend == "nccl" else
                                "gloo -- CAPTRA_BENCH_SHARE_GPU functional test mode: ranks share GPUs, NOT a scaling measurement"),
         "per_rank_ms_per_step": [[round(x, 3) for x in row] for row in per_rank_ms],

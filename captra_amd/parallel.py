@@ -23,6 +23,64 @@ def shard_range(total: int, world: int, rank: int) -> range:
     return range(start, start + base + (1 if rank < extra else 0))
 
 
+def parse_cpulist(text: str) -> list[int]:
+    """'0-3,8,10-11' (the sysfs cpulist format) -> [0, 1, 2, 3, 8, 10, 11]."""
+    cpus = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.extend(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def cpu_slice(cpus: list[int], local_rank: int, local_world: int, sharers: list[int] | None = None) -> list[int]:
+    """The host cores of one rank: `cpus` (the GPU's NUMA-local cores, or every allowed core) dealt evenly among the ranks that
+    share them (`sharers`: the local ranks whose GPUs sit on the same NUMA node; None = all local ranks); never empty."""
+    sharers = list(range(local_world)) if sharers is None else sorted(sharers)
+    if local_rank not in sharers or not cpus:
+        return list(cpus)
+    per = max(len(cpus) // len(sharers), 1)
+    i = sharers.index(local_rank)
+    part = cpus[i * per:(i + 1) * per] if (i + 1) * per <= len(cpus) else cpus[-per:]
+    return part or list(cpus)
+
+
+def gpu_local_cpus(device_index: int) -> list[int] | None:
+    """NUMA-local cores of GPU `device_index` from sysfs (/sys/bus/pci/devices/<bdf>/local_cpulist), None when unknown."""
+    try:
+        props = torch.cuda.get_device_properties(device_index)
+        bdf = f"{getattr(props, 'pci_domain_id', 0):04x}:{props.pci_bus_id:02x}:{props.pci_device_id:02x}.0"
+        with open(f"/sys/bus/pci/devices/{bdf}/local_cpulist") as fh:
+            cpus = parse_cpulist(fh.read())
+        return cpus or None
+    except Exception:
+        return None
+
+
+def bind_rank_cpus(local_rank: int, local_world: int, device_index: int | None = None) -> list[int] | None:
+    """Pin this rank's host threads (the launch loop is single-threaded Python: one busy core per GPU) to its share of the
+    cores next to its GPU, so that eight ranks do not migrate across sockets.  Returns the cores, or None when nothing was
+    changed (one rank, or an OS without sched_setaffinity)."""
+    import os
+    if local_world <= 1 or not hasattr(os, "sched_setaffinity"):
+        return None
+    allowed = sorted(os.sched_getaffinity(0))
+    local = gpu_local_cpus(device_index) if device_index is not None else None
+    sharers = None
+    if local:
+        local = [c for c in local if c in set(allowed)] or None
+    if local:
+        # the ranks whose GPUs report the same core list share it
+        sharers = [r for r in range(local_world) if (gpu_local_cpus(r) or []) and set(gpu_local_cpus(r)) & set(local)]
+    cores = cpu_slice(local or allowed, local_rank, local_world, sharers if local else None)
+    try:
+        os.sched_setaffinity(0, cores)
+    except OSError:
+        return None
+    return cores
+
+
 def pack_pose(pose: dict, valid: torch.Tensor | None = None) -> torch.Tensor:
     """{'rotation' (B,P,3,3), 'translation' (B,P,3,1), 'scale' (B,P)} -> (B,P,14) fp32."""
     B, P = pose["scale"].shape

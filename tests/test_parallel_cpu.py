@@ -224,3 +224,39 @@ def test_bench_dry_run_prints_the_launch_plan_without_a_gpu():
     assert "nccl" in plan["collective"] and plan["scaling"] == "weak"
     import torch
     assert plan["would_refuse"] == (torch.cuda.device_count() < 8 if torch.cuda.is_available() else True)
+
+
+def test_rank_cpu_binding_helpers():
+    """captra_amd.parallel: the sysfs cpulist parser and the split of a GPU's NUMA-local cores among the ranks that share them."""
+    from captra_amd.parallel import cpu_slice, parse_cpulist
+    assert parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11] and parse_cpulist("") == []
+    cpus = list(range(96))
+    parts = [cpu_slice(cpus, r, 8) for r in range(8)]
+    assert all(len(p) == 12 for p in parts) and sorted(sum(parts, [])) == cpus            # even, disjoint, complete
+    # four GPUs per socket: ranks 4..7 share the second socket's cores
+    second = list(range(96, 192))
+    parts = [cpu_slice(second, r, 8, sharers=[4, 5, 6, 7]) for r in (4, 5, 6, 7)]
+    assert all(len(p) == 24 for p in parts) and sorted(sum(parts, [])) == second
+    assert cpu_slice(second, 0, 8, sharers=[4, 5, 6, 7]) == second                         # not a sharer: left alone
+    assert cpu_slice([5], 3, 8) == [5] and cpu_slice([], 0, 2) == []                      # fewer cores than ranks: never empty
+
+
+def test_scale_tool_dry_run_lists_the_north_star_table():
+    """tools/scale.py --dry-run: configs[1] at 1 / 2 / 4 / 8 ranks, configs[2] (mix6, bf16) and configs[4] at 8, each with the
+    exact command and (for bench.py runs) the launch plan -- no GPU touched."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, "tools", "scale.py"), "--dry-run"], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    plan = json.loads(res.stdout.strip().splitlines()[-1])
+    names = [r["name"] for r in plan["runs"]]
+    assert names[:4] == [f"configs[1] bottle fp32 x{n}" for n in (1, 2, 4, 8)]
+    assert any("mix6 bf16 x8" in n for n in names) and any("backbone16k x8" in n for n in names)
+    by = {r["name"]: r for r in plan["runs"]}
+    p8 = by["configs[1] bottle fp32 x8"]["launch_plan"]
+    assert p8["gpus_requested"] == 8 and "nccl" in p8["collective"] and "cpu_binding" in p8
+    assert "--category mix6 --mlp-dtype bf16" in by["configs[2] mix6 bf16 x8"]["command"]
+    assert "--nproc-per-node=8" in by["configs[4] backbone16k x8"]["command"]
