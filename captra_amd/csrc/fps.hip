@@ -181,7 +181,7 @@ template <int NWAVES, int PPT, bool XYZ_LDS>
 __global__ __launch_bounds__(NWAVES * 64) void fps_kernel_blocked(int n_stride, int m, const float *__restrict__ xyz_all,
                                                                   float *__restrict__ temp_all, int *__restrict__ idx_all,
                                                                   float *__restrict__ new_n3, float *__restrict__ new_cn,
-                                                                  const int *__restrict__ n_per_cloud) {
+                                                                  const int *__restrict__ n_per_cloud, int defer) {
     static_assert(PPT % 2 == 0, "two points per packed instruction");
     constexpr int H = PPT / 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -190,6 +190,10 @@ __global__ __launch_bounds__(NWAVES * 64) void fps_kernel_blocked(int n_stride, 
     float *xs = reinterpret_cast<float *>(smem_raw + 2 * 16 * sizeof(uint2) + (XYZ_LDS ? 0 : 2 * 16 * sizeof(float4)));
     float *ys = xs + n_stride;
     float *zs = ys + n_stride;
+    // defer (XYZ_LDS only, LDS permitting): the picks are parked in LDS and every output -- idx, the gathered coordinates in
+    // both layouts -- is written after the last round by all threads; a round then issues no global store and no exec-masked
+    // address arithmetic at all (seven single-lane stores per round before)
+    int *picks = reinterpret_cast<int *>(zs + n_stride);
     const int b = blockIdx.x;
     // ragged batches: clouds padded to n_stride points, cloud b has n_per_cloud[b] of them (slots beyond n never win)
     const int n = n_per_cloud != nullptr ? n_per_cloud[b] : n_stride;
@@ -226,7 +230,10 @@ __global__ __launch_bounds__(NWAVES * 64) void fps_kernel_blocked(int n_stride, 
         px[i / 2][i & 1] = x; py[i / 2][i & 1] = y; pz[i / 2][i & 1] = z;
         dmin[i] = d0;
     }
-    if (tid == 0) idx[0] = 0;
+    if (tid == 0) {
+        if (XYZ_LDS && defer) picks[0] = 0;
+        else idx[0] = 0;
+    }
     __syncthreads();
 
     int old = 0;
@@ -238,7 +245,7 @@ __global__ __launch_bounds__(NWAVES * 64) void fps_kernel_blocked(int n_stride, 
         const float ox = XYZ_LDS ? xs[old] : nx;
         const float oy = XYZ_LDS ? ys[old] : ny;
         const float oz = XYZ_LDS ? zs[old] : nz;
-        if (tid == 0) emit(j - 1, ox, oy, oz);
+        if (!(XYZ_LDS && defer) && tid == 0) emit(j - 1, ox, oy, oz);
         const f32x2 o2x = {ox, ox}, o2y = {oy, oy}, o2z = {oz, oz};
         unsigned best = 0u;
 #pragma unroll
@@ -294,9 +301,18 @@ __global__ __launch_bounds__(NWAVES * 64) void fps_kernel_blocked(int n_stride, 
             }
         }
         old = (int)sel;
-        if (tid == 0) idx[j] = old;
+        if (XYZ_LDS && defer) {
+            if (wave == 0) picks[j] = old;                      // (uniform branch; the 64 lanes store one word)
+        } else if (tid == 0) idx[j] = old;
     }
-    if (tid == 0) emit(m - 1, xyz[(size_t)old * 3 + 0], xyz[(size_t)old * 3 + 1], xyz[(size_t)old * 3 + 2]);
+    if (XYZ_LDS && defer) {
+        __syncthreads();
+        for (int j = tid; j < m; j += NWAVES * 64) {
+            const int id = picks[j];
+            idx[j] = id;
+            emit(j, xs[id], ys[id], zs[id]);
+        }
+    } else if (tid == 0) emit(m - 1, xyz[(size_t)old * 3 + 0], xyz[(size_t)old * 3 + 1], xyz[(size_t)old * 3 + 2]);
     if (temp != nullptr) {
 #pragma unroll
         for (int i = 0; i < PPT; ++i) {
@@ -345,6 +361,7 @@ __global__ __launch_bounds__(1024) void fps_kernel_big(int n, int m, const float
     }
 }
 
+static CAPTRA_KNOB int g_fps_defer = 1;    // blocked kernel: outputs written after the last round (0 = inside the rounds, the first form)
 static CAPTRA_KNOB int g_fps_variant = 0;  // 0 = blocked / ballot / packed-math kernel where it applies, 1 = first-generation kernel
 
 template <int NWAVES, int PPT>
@@ -360,12 +377,14 @@ int launch_fps(int b, int n, int m, const float *xyz, float *temp, int *idx, hip
                 hipFuncSetAttribute(reinterpret_cast<const void *>(kern2), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
                 once2.done();
             }
-            CAPTRA_LAUNCH("fps", kern2, dim3(b), dim3(NWAVES * 64), slots + lds_xyz, s, n, m, xyz, temp, idx, new_n3, new_cn, ns);
+            const size_t picks_b = (size_t)m * sizeof(int);
+            const int defer = (g_fps_defer && slots + lds_xyz + picks_b <= 150 * 1024) ? 1 : 0;
+            CAPTRA_LAUNCH("fps", kern2, dim3(b), dim3(NWAVES * 64), slots + lds_xyz + (defer ? picks_b : 0), s, n, m, xyz, temp, idx, new_n3, new_cn, ns, defer);
             return captra_last_error();
         }
         if (g_fps_variant == 0) {  // cloud larger than the LDS mirror: same kernel, winner coordinates from global memory
             CAPTRA_LAUNCH("fps", (fps_kernel_blocked<NWAVES, PPT, false>), dim3(b), dim3(NWAVES * 64),
-                          slots + 2 * 16 * sizeof(float4), s, n, m, xyz, temp, idx, new_n3, new_cn, ns);
+                          slots + 2 * 16 * sizeof(float4), s, n, m, xyz, temp, idx, new_n3, new_cn, ns, 0);
             return captra_last_error();
         }
     }
@@ -399,6 +418,7 @@ extern "C" void captra_fps_set_pruned_min(int n) { g_fps_pruned_min = n; }
 static CAPTRA_KNOB int g_fps_waves = 0;
 extern "C" void captra_fps_set_waves(int w) { g_fps_waves = w; }
 extern "C" void captra_fps_set_variant(int v) { g_fps_variant = v; }
+extern "C" void captra_fps_set_defer(int v) { g_fps_defer = v; }
 
 extern "C" int captra_furthest_point_sampling(int b, int n, int m, const float *xyz, float *temp,
                                               int *idx, captra_stream_t stream) {

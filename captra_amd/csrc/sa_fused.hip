@@ -327,6 +327,7 @@ struct SwParams {
     int out_ctotal, co_off;
     const float *v1;           // PRE kernels: (B,C1,N) = b1 + W1[feature rows] * feat per source point, else null
     unsigned long long *prof;  // debug: per-phase wave-cycle totals of a sample of waves (sa_wave_kernel), else null
+    int split;                 // sa_wave_lds_kernel: a wave owns ONE 32-neighbour slice of a centre (small batches), maxima combined by atomic max
 };
 
 #define SW_TICK(slot)                                                         \
@@ -666,12 +667,20 @@ __global__ __launch_bounds__(SL_WAVES * 64) __attribute__((amdgpu_waves_per_eu(4
             x_[j] = v;
         }
     };
-    int c = gid, sl = 0;                 // the slice being computed
+    // SPLIT (small batches: fewer centres than resident waves -- a single trajectory's 512 centres would leave three quarters of
+    // the chip idle while each wave walks four slices): a wave owns ONE slice, tasks t = gid, gid + nwaves, ... with centre
+    // t / nslices and slice t % nslices; every task ends with its own maxima, combined across a centre's slices by an integer
+    // atomic max on the pre-zeroed output (post-ReLU values are non-negative floats: they order like their bit patterns, and
+    // max is exact and order-free -- the same bits as the running maximum).
+    const bool split = p.split != 0;
+    const int ssh = __builtin_ctz((unsigned)nslices);           // nslices is 1, 2 or 4
+    int task = gid;
+    int c = split ? gid >> ssh : gid, sl = split ? gid & (nslices - 1) : 0;                 // the slice being computed
     int c_next = gid + nwaves;           // the centre after c
     int id = 0;
     float ctr[3] = {0.f, 0.f, 0.f};
     if (c < ncentres) {
-        id = load_ids(c, 0);
+        id = load_ids(c, sl);
         load_ctr(c, ctr);
     }
     sl_stage_weights<CIN1, C1>(wl1, p.w1, tid);
@@ -690,13 +699,13 @@ __global__ __launch_bounds__(SL_WAVES * 64) __attribute__((amdgpu_waves_per_eu(4
     const bool sampled = blockIdx.x % 16 == 0;            // phase timers (captra_sa_fused_set_prof): a sample of workgroups
     unsigned long long t_last = p.prof != nullptr ? __builtin_amdgcn_s_memtime() : 0ull;
     while (c < ncentres) {
-        if (sl == 0) {
+        if (sl == 0 || split) {
 #pragma unroll
             for (int t = 0; t < S3::NT; ++t) zrun[t] = 0;          // (0 = the ReLU)
         }
         // what comes after this slice (wave-uniform)
-        const bool last_slice = sl + 1 == nslices;
-        const int cn = last_slice ? c_next : c, sn = last_slice ? 0 : sl + 1;
+        const bool last_slice = split || sl + 1 == nslices;
+        const int cn = split ? (task + nwaves) >> ssh : (last_slice ? c_next : c), sn = split ? (task + nwaves) & (nslices - 1) : (last_slice ? 0 : sl + 1);
         const bool has_next = cn < ncentres;
         int id_n = 0;
         float ctr_n[3] = {ctr[0], ctr[1], ctr[2]};
@@ -728,13 +737,16 @@ __global__ __launch_bounds__(SL_WAVES * 64) __attribute__((amdgpu_waves_per_eu(4
 #pragma unroll
             for (int t = 0; t < S3::NT; ++t) {
                 const float v = sw_bfly_finish(zrun[t]);
-                if ((lane & 16) == 0 && 32 * t + row0 < C3) op[(size_t)32 * t * p.m] = v;
+                if ((lane & 16) == 0 && 32 * t + row0 < C3) {
+                    if (split) atomicMax(reinterpret_cast<int *>(op + (size_t)32 * t * p.m), __float_as_int(v));
+                    else op[(size_t)32 * t * p.m] = v;
+                }
             }
             c_next += nwaves;
             ctr[0] = ctr_n[0]; ctr[1] = ctr_n[1]; ctr[2] = ctr_n[2];
             SW_TICK(4)
         }
-        c = cn; sl = sn;
+        c = cn; sl = sn; task += nwaves;
 #pragma unroll
         for (int j = 0; j < S1::KST; ++j) x1[j] = x1_n[j];
     }
@@ -748,6 +760,9 @@ extern "C" void captra_sa_fused_set_wn(int wn) { g_sa_wn = wn; }
 static CAPTRA_KNOB int g_sa_mode = 0;  // 0 = heuristic (register-resident kernels where instantiated), 1 = always the generic LDS kernel,
                            // 2 = register-resident kernels with streamed weights only (no LDS-weight variant)
 extern "C" void captra_sa_fused_set_mode(int mode) { g_sa_mode = mode; }
+static CAPTRA_KNOB int g_sa_split = 1;  // a wave per slice for small batches: 0 = never, 1 = heuristic, 2 = always (tests)
+extern "C" void captra_sa_fused_set_split(int v) { g_sa_split = v; }
+int captra_sa_split_knob() { return g_sa_split; }
 static unsigned long long *g_sa_prof = nullptr;  // device buffer of 10 counters: sa_wave_kernel's opt-in phase timers
 extern "C" void captra_sa_fused_set_prof(unsigned long long *dev_counters) { g_sa_prof = dev_counters; }
 unsigned long long *captra_sa_prof_ptr() { return g_sa_prof; }
@@ -773,7 +788,7 @@ extern "C" int captra_sa_scale_fused(int b, int n, int m, int k, int cfeat, int 
         // PointNet2Msg config); any other shape takes the generic LDS kernel below
         SwParams q;
         q.b = b; q.n = n; q.m = m; q.k = k; q.feat = feat; q.xyz_cn = xyz_cn; q.new_xyz = new_xyz; q.idx = idx;
-        q.w1 = w1; q.b1 = b1; q.w2 = w2; q.b2 = b2; q.w3 = w3; q.b3 = b3; q.out = out; q.out_ctotal = out_ctotal; q.co_off = co_off; q.v1 = nullptr; q.prof = g_sa_prof;
+        q.w1 = w1; q.b1 = b1; q.w2 = w2; q.b2 = b2; q.w3 = w3; q.b3 = b3; q.out = out; q.out_ctotal = out_ctotal; q.co_off = co_off; q.v1 = nullptr; q.prof = g_sa_prof; q.split = 0;
         const long long Lw = (long long)m * k;
         dim3 gridw((unsigned)((Lw + SF_POS - 1) / SF_POS), b);
         // small-input scales: persistent workgroups with the weights resident in LDS (mode 2 = streaming kernel for all)
@@ -796,10 +811,13 @@ extern "C" int captra_sa_scale_fused(int b, int n, int m, int k, int cfeat, int 
             resident_slot.store(resident, std::memory_order_relaxed);                                                  \
         }                                                                                                              \
         const long long centres = (long long)b * m;            /* a wave per centre: 8 centres per workgroup round */           \
-        const long long wgs = (centres + SL_WAVES - 1) / SL_WAVES;                                                     \
+        /* fewer centres than resident waves: a wave per SLICE instead (see the kernel), output pre-zeroed for the atomic max */ \
+        q.split = (g_sa_split != 0 && k > 32 && (g_sa_split == 2 || centres < (long long)resident * SL_WAVES)) ? 1 : 0;    \
+        const long long units = q.split ? centres * (k / 32) : centres;                                                \
+        const long long wgs = (units + SL_WAVES - 1) / SL_WAVES;                                                       \
         q.b = b;                                                                                                       \
         const unsigned grid_l = (unsigned)(wgs < resident ? wgs : resident);                                           \
-                                                                                                     \
+        if (q.split) (void)hipMemset2DAsync(out + (size_t)co_off * m, (size_t)out_ctotal * m * 4, 0, (size_t)c3 * m * 4, b, (hipStream_t)stream); \
         CAPTRA_LAUNCH("sa_scale_fused", kern, dim3(grid_l), dim3(SL_WAVES * 64), lds_bytes, (hipStream_t)stream, q);  \
         return captra_last_error();                                                                                    \
     }
@@ -863,7 +881,7 @@ extern "C" int captra_sa_scale_pre(int b, int n, int m, int k, int cfeat, int c1
     SwParams q;
     q.b = b; q.n = n; q.m = m; q.k = k; q.feat = nullptr; q.xyz_cn = xyz_cn; q.new_xyz = new_xyz; q.idx = idx;
     q.w1 = w1; q.b1 = b2 /* unused by the PRE kernels: any valid packed bias */; q.w2 = w2; q.b2 = b2; q.w3 = w3; q.b3 = b3;
-    q.out = out; q.out_ctotal = out_ctotal; q.co_off = co_off; q.v1 = v1; q.prof = g_sa_prof;
+    q.out = out; q.out_ctotal = out_ctotal; q.co_off = co_off; q.v1 = v1; q.prof = g_sa_prof; q.split = 0;
     const long long Lw = (long long)m * k;
     dim3 gridw((unsigned)((Lw + SF_POS - 1) / SF_POS), b);
 #define SWP_CASE(CF_, C1_, C2_, C3_)                                                                                       \

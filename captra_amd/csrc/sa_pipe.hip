@@ -39,6 +39,7 @@ struct SpParams {
     float *out;             // (B,out_ctotal,M)
     int out_ctotal, co_off;
     unsigned long long *prof;  // debug: per-phase wave-cycle totals of a sample of workgroups (captra_sa_fused_set_prof), or null
+    int split;                 // a wave owns ONE 32-neighbour slice of a centre (small batches); maxima combined by atomic max on the zeroed output
 };
 
 #define SP_TICK(slot)                                                           \
@@ -269,20 +270,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     constexpr int START3 = S2::STEPS % 3;                     // ring slot of layer 3's first set (layer 2 starts in slot 0)
     constexpr int NEXT2 = (START3 + S3::STEPS) % 3;            // slot in which layer 3 leaves the NEXT slice's first layer-2 set
     int zrun[S3::NT];
-    int c = gid, sl = 0;
+    // SPLIT (small batches, as in sa_wave_lds_kernel): a wave owns ONE slice -- task t = gid, gid + nwaves, ... is slice
+    // t % nslices of centre t / nslices -- and a centre's slices meet in an integer atomic max on the pre-zeroed output
+    // (non-negative floats order like their bit patterns; max is exact and order-free: the running maximum's bits).
+    const bool split = p.split != 0;
+    const int ssh = __builtin_ctz((unsigned)nslices);
+    int task = gid;
+    int c = split ? gid >> ssh : gid, sl = split ? gid & (nslices - 1) : 0;
     if (c < ncentres) {
         sw_first_set<C1, C2>(s[NEXT2], p.w2, lane);
-        id = load_id(c, 0);
+        id = load_id(c, sl);
         load_rest(c, id, bt, g4);
     }
     while (c < ncentres) {
-        if (sl == 0) {
+        if (sl == 0 || split) {
 #pragma unroll
             for (int t = 0; t < S3::NT; ++t) zrun[t] = 0;          // (0 = the ReLU)
         }
         // ---- what comes after this slice (wave-uniform) ----
-        const bool last_slice = sl + 1 == nslices;
-        const int cn = last_slice ? c + nwaves : c, sn = last_slice ? 0 : sl + 1;
+        const bool last_slice = split || sl + 1 == nslices;
+        const int cn = split ? (task + nwaves) >> ssh : (last_slice ? c + nwaves : c), sn = split ? (task + nwaves) & (nslices - 1) : (last_slice ? 0 : sl + 1);
         const bool has_next = cn < ncentres;
         int id_n = 0;
 
@@ -333,17 +340,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
             for (int t = 0; t < S3::NT; ++t) {
                 const float v = sw_bfly_finish(zrun[t]);
-                if ((lane & 16) == 0 && 32 * t + row0 < C3) op[(size_t)32 * t * p.m] = v;
+                if ((lane & 16) == 0 && 32 * t + row0 < C3) {
+                    if (split) atomicMax(reinterpret_cast<int *>(op + (size_t)32 * t * p.m), __float_as_int(v));
+                    else op[(size_t)32 * t * p.m] = v;
+                }
             }
             SP_TICK(4)
         }
-        c = cn; sl = sn;
+        c = cn; sl = sn; task += nwaves;
     }
 }
 
 }  // namespace
 
 extern unsigned long long *captra_sa_prof_ptr();   // sa_fused.hip: the debug counters set by captra_sa_fused_set_prof
+extern int captra_sa_split_knob();                  // sa_fused.hip: captra_sa_fused_set_split
 
 // SA scale with a pre-transformed, POINT-major first layer (see include/captra_hip.h): v1pm (B,N,c1).
 // -2: shape not instantiated / not tileable (the caller takes captra_sa_scale_pre).
@@ -373,8 +384,11 @@ extern "C" int captra_sa_scale_pre_pm(int b, int n, int m, int k, int cfeat, int
     // one workgroup (4 waves, one per SIMD) per CU; a wave per centre
     const long long centres = (long long)b * m;
     if (centres >= (1ll << 30)) return -2;
-    const long long wgs = (centres + 3) / 4;
+    const int split_knob = captra_sa_split_knob();
+    q.split = (split_knob != 0 && k > 32 && (split_knob == 2 || centres < 4ll * cus)) ? 1 : 0;     // fewer centres than resident waves
+    const long long wgs = ((q.split ? centres * (k / 32) : centres) + 3) / 4;
     const unsigned grid = (unsigned)(wgs < cus ? wgs : cus);
+    if (q.split) (void)hipMemset2DAsync(out + (size_t)co_off * m, (size_t)out_ctotal * m * 4, 0, (size_t)c3 * m * 4, b, (hipStream_t)stream);
 #define SPP_CASE(CF_, C1_, C2_, C3_)                                                                                  \
     if (cfeat == CF_ && c1 == C1_ && c2 == C2_ && c3 == C3_) {                                                        \
         auto kern = sa_wave_pipe_kernel<CF_, C1_, C2_, C3_>;                                                          \

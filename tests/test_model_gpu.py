@@ -177,6 +177,47 @@ def test_sa_scale_pipe_bit_exact(device, chans, n, m, k, B):
     assert torch.equal(out, out2)
 
 
+@pytest.mark.parametrize("cfeat,chans,n,m,k,B", [(0, (64, 96, 128), 4096, 512, 128, 1), (3, (64, 64, 128), 4096, 512, 64, 1),
+                                                  (3, (64, 96, 128), 700, 41, 128, 3), (320, (128, 196, 256), 512, 128, 128, 1),
+                                                  (320, (128, 128, 256), 512, 128, 64, 1), (320, (128, 196, 256), 200, 6, 64, 3)])
+def test_sa_scale_split_slices_bit_exact_at_batch_one(device, cfeat, chans, n, m, k, B):
+    """Small batches (the reference's own speed convention is --batch_size 1, README.md:267): a wave owns ONE 32-neighbour slice of
+    a centre instead of the whole centre, the slices' maxima meet in an integer atomic max on the zeroed output.  Same chain per
+    position, exact max: the forced-split launch, the never-split launch and the oracle agree bit for bit, and rows outside the
+    scale's channel block are untouched."""
+    import ctypes
+    from captra_amd import _lib, fused
+    rng = np.random.default_rng(cfeat + sum(chans) + k + B)
+    xyz_cn = (rng.random((B, 3, n), dtype=np.float32) - 0.5)
+    feat = rng.standard_normal((B, cfeat, n)).astype(np.float32) if cfeat else None
+    new_xyz = (rng.random((B, m, 3), dtype=np.float32) - 0.5)
+    idx = rng.integers(0, n, (B, m, k)).astype(np.int32)
+    dims = (cfeat + 3,) + chans
+    layers = [((rng.standard_normal((dims[i], dims[i + 1])) / np.sqrt(dims[i])).astype(np.float32),
+               rng.standard_normal(dims[i + 1]).astype(np.float32)) for i in range(3)]
+    packed = [fused.pack(_dev(w, device), _dev(b, device)) for w, b in layers]
+    outs = []
+    for knob in (0, 2, 1):
+        _lib.lib().captra_sa_fused_set_split(ctypes.c_int(knob))
+        try:
+            out = torch.full((B, chans[2] + 9, m), -1.0, device=device)
+            if cfeat == 320:
+                v1pm = fused.sa_first_layer_pre_pm(_dev(feat, device), packed[0])
+                fused.sa_scale_pre_pm(v1pm, _dev(xyz_cn, device), _dev(new_xyz, device), _dev(idx, device), packed, out, 4, cfeat)
+            else:
+                fused.sa_scale_fused(None if feat is None else _dev(feat, device), _dev(xyz_cn, device), _dev(new_xyz, device), _dev(idx, device), packed, out, 4)
+            outs.append(out)
+        finally:
+            _lib.lib().captra_sa_fused_set_split(ctypes.c_int(1))
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    x = O.sa_group(feat, xyz_cn, new_xyz, idx)
+    for w, b in layers:
+        x = O.pointwise_mlp(x, w, b, 1)
+    got = outs[1].cpu().numpy()
+    np.testing.assert_array_equal(got[:, 4:4 + chans[2]], O.max_over_k(x))
+    assert (got[:, :4] == -1).all() and (got[:, 4 + chans[2]:] == -1).all()
+
+
 def _sa_scale_fused_case(device, cfeat, chans, n, m, k):
     from captra_amd import fused
     rng = np.random.default_rng(cfeat + sum(chans) + k)
