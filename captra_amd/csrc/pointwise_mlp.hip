@@ -62,6 +62,10 @@ struct PwParams {
     float *stats_out;     // (B,cout,T,2) or null: per output row and 64-column tile, (sum, sum of squares) of y
     int stats_t;          // T
     int y_pm;             // direct kernel only: 1 = y is POINT-major (B,L,cout), cout % 4 == 0 (captra_pointwise_mlp_pm)
+    // SRC2 (captra_pointwise_mlp2): input channels >= csplit come from x2 (B,cin - csplit,L2), L2 = L or 1 (one vector per
+    // cloud, read for every position); both tensors are addressed from ONE buffer descriptor based at the lower of the two
+    const float *x2;
+    int csplit, x2_bcast;
 };
 
 template <int CTRL>
@@ -341,10 +345,11 @@ __device__ __forceinline__ float half_wave_sum(float v) {
 //      pos0 + 2i + tn), so one 8-byte load per lane and k-step feeds both tiles' B operands and one 8-byte store writes
 //      both tiles' outputs of a row -- half the vector-memory instructions of the B side.  Which column a lane's
 //      accumulator stands for changes, the per-element k-ascending chain does not: same bits per output element.
-template <int TM, int TN, int WGM, int WGN, bool AFF = false, bool ST = false, bool PAIR = false>
+template <int TM, int TN, int WGM, int WGN, bool AFF = false, bool ST = false, bool PAIR = false, bool SRC2 = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void pw_direct_kernel(PwParams p) {
     static_assert(WGM * WGN == 4, "4 waves");
     static_assert(!PAIR || TN == 2, "paired column tiles");
+    static_assert(!SRC2 || (!PAIR && !AFF), "two-source input: plain layers only");
     constexpr int KS = (AFF || (TM == 2 && TN == 2)) ? 4 : 8;  // k-steps per register set
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -362,9 +367,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void p
     const int kq = ((p.cin + 1) / 2 + 3) / 4;                  // quads of k-steps per output tile
     const int ntile = (p.cout + 31) / 32;
     const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(p.wt + (size_t)kp * p.ldw), 0, ntile * kq * 1024, 0x00020000);
-    const float *xb = p.x + (size_t)b * p.cin * p.L;
-    const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc((void *)xb, 0, (int)((long long)p.cin * p.L * 4), 0x00020000);
+    const float *xb = p.x + (size_t)b * (SRC2 ? p.csplit : p.cin) * p.L;
+    // SRC2: the concat [x; x2] is never built -- row r of the operand is row r of x (r < csplit) or row r - csplit of x2; one
+    // descriptor based at the lower of the two per-cloud blocks, a per-lane byte offset per k-step (the launcher checked that both
+    // blocks lie within 2^31 bytes of it)
+    const float *x2b = SRC2 ? p.x2 + (size_t)b * (p.cin - p.csplit) * (p.x2_bcast ? 1 : p.L) : nullptr;
+    const float *xbase = SRC2 && x2b < xb ? x2b : xb;
+    const int off1 = SRC2 ? (int)((const char *)xb - (const char *)xbase) : 0, off2 = SRC2 ? (int)((const char *)x2b - (const char *)xbase) : 0;
+    const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc((void *)xbase, 0, SRC2 ? 0x7ffffff0 : (int)((long long)p.cin * p.L * 4), 0x00020000);
     const int xstep = (int)(2 * p.L * 4);     // bytes per k-step in X
+    int xcol4[TN];                            // SRC2: byte offset of this lane's column in a row
     int wvoff[TM], xvoff[TN];
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
@@ -379,7 +391,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void p
         long long col = col_of(tn);
         if (col >= p.L) col = PAIR ? p.L - 2 + tn : p.L - 1;   // (PAIR: L and the pair's first column are even)
         xvoff[tn] = (int)(((long long)(lane >> 5) * p.L + col) * 4);
+        xcol4[tn] = (int)(col * 4);
     }
+    // SRC2: byte offset of row 2 ks + (lane >> 5) of the virtual concat, column tile tn (rows beyond cin: the last row, their weights are zero)
+    auto src2_off = [&](int ks, int tn) {
+        const int r = 2 * ks + (lane >> 5);
+        if (r >= p.cin) return 0x7ffffffc;      // beyond the descriptor: reads as 0, like the one-tensor kernel's rows >= cin (a set may run
+                                                // past the layer's last k-step quad, where the A fragments are another tile's weights)
+        return r < p.csplit ? off1 + r * (int)(p.L * 4) + xcol4[tn]
+                            : off2 + (r - p.csplit) * (p.x2_bcast ? 4 : (int)(p.L * 4)) + (p.x2_bcast ? 0 : xcol4[tn]);
+    };
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -414,7 +435,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void p
             Bv[0][j] = x2.x; Bv[TN - 1][j] = x2.y;                                                                       \
         } else {                                                                                                         \
             _Pragma("unroll") for (int tn = 0; tn < TN; ++tn) Bv[tn][j] = __builtin_bit_cast(                            \
-                float, __builtin_amdgcn_raw_buffer_load_b32(xsrc, xvoff[tn] + ((si) * KS + j) * xstep, 0, 0));           \
+                float, __builtin_amdgcn_raw_buffer_load_b32(xsrc, SRC2 ? src2_off((si) * KS + j, tn) : xvoff[tn] + ((si) * KS + j) * xstep, 0, 0)); \
         }                                                                                                                \
         if (AFF) G[j] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(gsrc, gvoff + ((si) * KS + j) * 16, 0, 0)); \
     }                                                                                                                    \
@@ -751,6 +772,33 @@ extern "C" int captra_pointwise_mlp(int b, int cin, int cout, long long l, const
     const bool vec = (l % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
     if (vec) return launch_pw<PRO_PLAIN, EPI_STORE, true>(b, p, (hipStream_t)stream, "pointwise_mlp");
     return launch_pw<PRO_PLAIN, EPI_STORE, false>(b, p, (hipStream_t)stream, "pointwise_mlp");
+}
+
+// The layer on the channel concat [x; x2] WITHOUT building it (SA3's [xyz, feat], pointnet_utils.py:171-188; FP3's
+// [points1, repeat(points2)], pointnet_utils.py:265-270): x (B,csplit,L), x2 (B,cin - csplit,L), or (B,cin - csplit) with x2_bcast
+// (one vector per cloud, the same for every position).  The operand rows are read in the concat's order, so the k-ascending chain
+// -- and every output bit -- is that of captra_pointwise_mlp on the concatenated tensor.  -2 outside the direct kernel's small-launch
+// shape or when the two tensors lie more than 2^30 bytes apart (the caller concatenates).
+extern "C" int captra_pointwise_mlp2(int b, int cin, int csplit, int cout, long long l, const float *x, const float *x2, int x2_bcast,
+                                     const float *wt_packed, const float *bias_packed, int act, float *y, captra_stream_t stream) {
+    if (b < 0 || cin < 2 || csplit < 1 || csplit >= cin || cout < 1 || l < 0 || act < 0 || act > 2 || x2 == nullptr) return -1;
+    if (b == 0 || l == 0) return 0;
+    const long long span1 = (long long)b * csplit * l * 4, span2 = (long long)b * (cin - csplit) * (x2_bcast ? 1 : l) * 4;
+    const long long gap = (const char *)x2 > (const char *)x ? (const char *)x2 - (const char *)x : (const char *)x - (const char *)x2;
+    if (gap + span1 + span2 >= (1ll << 30)) return -2;
+    const long long waves22 = ((l + 63) / 64) * ((cout + 63) / 64) * b;
+    if (cout <= 64) return -2;
+    PwParams p = {};
+    p.cin = cin; p.cout = cout; p.ldw = (cout + 127) / 128 * 128; p.L = l; p.x = x; p.wt = wt_packed; p.bias = bias_packed;
+    p.y = y; p.act = act; p.x2 = x2; p.csplit = csplit; p.x2_bcast = x2_bcast;
+    if (waves22 < 2048) {
+        dim3 grid((unsigned)((l + 63) / 64), (cout + 63) / 64, b);
+        CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<1, 1, 2, 2, false, false, false, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    } else {
+        dim3 grid((unsigned)((l + 127) / 128), (cout + 127) / 128, b);
+        CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<2, 2, 2, 2, false, false, false, true>), grid, dim3(256), pw_occupancy_pad(), (hipStream_t)stream, p);
+    }
+    return captra_last_error();
 }
 
 // The same layer with a POINT-major result y (B,L,cout): what a consumer that gathers whole points reads with 16-byte loads

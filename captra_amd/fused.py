@@ -185,6 +185,26 @@ def pointwise_mlp(x, lin: PackedLinear, act: int = ACT_RELU, out=None):
     return out
 
 
+def pointwise_mlp2(x, x2, lin: PackedLinear, act: int = ACT_RELU):
+    """act(W [x; x2] + b) without building the concat (captra_pointwise_mlp2): x (B,c,l), x2 (B,c2,l) or (B,c2,1) (one vector per
+    cloud, read for every position); exact fp32, bit-identical to pointwise_mlp on the concatenated tensor.  None when the shape is
+    outside the kernel's range or the tensors lie too far apart for one buffer descriptor: the caller concatenates."""
+    if mlp_dtype() != "fp32" or lin.cout <= 64 or x.dim() != 3 or x2.dim() != 3:
+        return None
+    L.require_device(x, x2)
+    B, c, l = x.shape
+    bcast = x2.shape[2] == 1 and l != 1
+    assert lin.cin == c + x2.shape[1] and (bcast or x2.shape[2] == l), (x.shape, x2.shape, lin.cin)
+    span = 4 * (x.numel() + x2.numel())
+    if abs(x2.data_ptr() - x.data_ptr()) + span >= (1 << 30):
+        return None
+    out = torch.empty(B, lin.cout, l, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        L.call("captra_pointwise_mlp2", B, lin.cin, c, lin.cout, l, L.ptr(x), L.ptr(x2), 1 if bcast else 0, L.ptr(lin.wt), L.ptr(lin.bias), act, L.ptr(out))
+    _work("pointwise_mlp", flops=2.0 * B * lin.cin * lin.cout * l, nbytes=4.0 * B * l * (lin.cin + lin.cout))
+    return out
+
+
 def pm_channels(c: int) -> int:
     """Channel stride of a point-major bf16 tensor (include/captra_hip.h "bf16-NATIVE dense layers")."""
     return (c + 31) // 32 * 32

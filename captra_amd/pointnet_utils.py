@@ -298,6 +298,15 @@ class PointNetFeaturePropagation(_FoldCache, nn.Module):
             for i, lin in enumerate(layers[1:]):
                 y = fused.pointwise_mlp_bf16pm(y, lin, N, in_pm=True, out_pm=i < len(layers) - 2, act=fused.ACT_RELU)
             return y.view(B, layers[-1].cout, N)
+        if S == 1 and fuse and points1 is not None and points2.shape[2] == 1 and finish is None and fused.mlp_dtype() == "fp32":
+            # one source vector per cloud (pointnet_utils.py:265-270): the first layer reads [points1; repeat(points2)] from the two
+            # tensors as they are (captra_pointwise_mlp2: rows in the concat's order, so the same bits) -- no repeat, no concat
+            layers = list(self._fold(xyz1.device)) + ([tail] if tail is not None else [])
+            y = fused.pointwise_mlp2(points1.contiguous(), points2.contiguous(), layers[0], fused.ACT_RELU)
+            if y is not None:
+                for lin in layers[1:]:
+                    y = fused.pointwise_mlp(y, lin, fused.ACT_RELU)
+                return y
         if S == 1:
             interpolated = points2.expand(-1, -1, N) if points2.shape[2] == 1 else points2.repeat(1, 1, N)
             new_points = torch.cat([points1, interpolated], dim=1) if points1 is not None else interpolated.contiguous()
@@ -380,12 +389,22 @@ class PointNetSetAbstraction(_FoldCache, nn.Module):
             if fused.mlp_dtype() == "bf16" and _has_points(points) and fused.chain_tile_bf16_supported(C + points.shape[1], N, folded, pool=True):
                 # LDS-tiled kernels: [xyz, feat] read as two sources (no concat), the max over the points in the last layer's epilogue
                 return new_xyz, fused.mlp_chain_bf16_tile(xyz.contiguous(), folded, [fused.ACT_RELU] * len(folded), x2=points.contiguous(), pool=True)
-            x = torch.cat([xyz, points], dim=1) if _has_points(points) else xyz       # (B,3+D,N), xyz first
             if fused.mlp_dtype() == "bf16":      # hidden activations bf16 point-major; the (exact) max on the last layer's fp32 output
+                x = torch.cat([xyz, points], dim=1) if _has_points(points) else xyz   # (B,3+D,N), xyz first
                 y = fused.mlp_chain_bf16(x.contiguous(), folded, [fused.ACT_RELU] * len(folded))
                 return new_xyz, fused.row_max(y.view(B, self.out_channel, N))
-            y = x.contiguous().view(B, x.shape[1], groups, k)
-            for lin in folded[:-1]:
+            y = None
+            if _has_points(points) and len(folded) > 1:
+                # [xyz; feat] read from the two tensors as they are (captra_pointwise_mlp2): no concat, the same bits
+                y = fused.pointwise_mlp2(xyz.contiguous(), points.contiguous(), folded[0], fused.ACT_RELU)
+            if y is not None:
+                y = y.view(B, folded[0].cout, groups, k)
+                rest = folded[1:-1]
+            else:
+                x = torch.cat([xyz, points], dim=1) if _has_points(points) else xyz   # (B,3+D,N), xyz first
+                y = x.contiguous().view(B, x.shape[1], groups, k)
+                rest = folded[:-1]
+            for lin in rest:
                 y = fused.pointwise_mlp(y, lin, fused.ACT_RELU)
             out = torch.empty(B, self.out_channel, groups, dtype=torch.float32, device=xyz.device)
             fused.mlp_max(y, folded[-1], out, 0)

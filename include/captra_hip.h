@@ -350,6 +350,13 @@ int captra_sa_scale_pre_pm(int b, int n, int m, int k, int cfeat, int c1, int c2
                            const float *b2, const float *w3, const float *b3, float *out, int out_ctotal, int co_off,
                            captra_stream_t stream);
 
+/* captra_pointwise_mlp2: the same layer on the channel concat [x; x2] WITHOUT building it -- SA3's [xyz, feat] of
+ * sample_and_group_all (pointnet_utils.py:171-188) and FP3's [points1, repeat(points2)] (pointnet_utils.py:265-270).  x (B,csplit,L),
+ * x2 (B,cin - csplit,L), or (B,cin - csplit) with x2_bcast = 1 (one vector per cloud, read for every position).  Rows are consumed
+ * in the concat's order: bit-identical to captra_pointwise_mlp on the concatenated tensor.  -2: outside the instantiated shapes
+ * (cout <= 64) or the tensors lie more than 2^30 bytes apart -- the caller concatenates. */
+int captra_pointwise_mlp2(int b, int cin, int csplit, int cout, long long l, const float *x, const float *x2, int x2_bcast,
+                          const float *wt_packed, const float *bias_packed, int act, float *y, captra_stream_t stream);
 /* captra_pointwise_mlp with a POINT-major result y (B,l,cout) (cout % 4 == 0, y 16-byte aligned; -2 otherwise or when the
  * layer is outside the direct-operand kernel's 32-bit offset range). */
 int captra_pointwise_mlp_pm(int b, int cin, int cout, long long l, const float *x, const float *wt_packed,

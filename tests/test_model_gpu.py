@@ -177,6 +177,33 @@ def test_sa_scale_pipe_bit_exact(device, chans, n, m, k, B):
     assert torch.equal(out, out2)
 
 
+@pytest.mark.parametrize("c1,c2,cout,l,bcast,B", [(3, 512, 256, 128, False, 4), (512, 1024, 256, 128, True, 4), (3, 512, 256, 128, False, 40),
+                                                   (7, 130, 70, 77, False, 2), (320, 256, 256, 512, True, 3)])
+def test_pointwise_mlp_two_sources_equals_concat_bit_for_bit(device, c1, c2, cout, l, bcast, B):
+    """captra_pointwise_mlp2: the dense layer on [x; x2] read from the two tensors as they are (SA3's [xyz, feat], FP3's
+    [points1, repeat(points2)]: pointnet_utils.py:171-188, 265-270) == captra_pointwise_mlp on the concatenated tensor, bit for bit
+    (the operand rows are consumed in the concat's order), small- and large-launch shapes, and == the oracle's chain."""
+    from captra_amd import fused
+    rng = np.random.default_rng(c1 + c2 + cout + l)
+    x = rng.standard_normal((B, c1, l)).astype(np.float32)
+    x2 = rng.standard_normal((B, c2, 1 if bcast else l)).astype(np.float32)
+    w = (rng.standard_normal((c1 + c2, cout)) / np.sqrt(c1 + c2)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    lin = fused.pack(_dev(w, device), _dev(b, device))
+    cat = np.concatenate([x, np.broadcast_to(x2, (B, c2, l))], axis=1)
+    want = fused.pointwise_mlp(_dev(cat, device), lin, fused.ACT_RELU)
+    # (the two tensors must lie within 2^30 bytes of each other for the one buffer descriptor -- the wrapper returns None otherwise
+    # and the caller concatenates; here both are carved out of one allocation)
+    flat = torch.empty(x.size + x2.size, dtype=torch.float32, device=device)
+    xd, x2d = flat[:x.size].view(x.shape), flat[x.size:].view(x2.shape)
+    xd.copy_(torch.from_numpy(x)); x2d.copy_(torch.from_numpy(x2))
+    got = fused.pointwise_mlp2(xd, x2d, lin, fused.ACT_RELU)
+    assert got is not None and torch.equal(got, want)
+    far = fused.pointwise_mlp2(_dev(x, device), _dev(x2, device), lin, fused.ACT_RELU)       # wherever the allocator put them
+    assert far is None or torch.equal(far, want)
+    np.testing.assert_array_equal(got.cpu().numpy(), O.pointwise_mlp(cat, w, b, 1))
+
+
 @pytest.mark.parametrize("cfeat,chans,n,m,k,B", [(0, (64, 96, 128), 4096, 512, 128, 1), (3, (64, 64, 128), 4096, 512, 64, 1),
                                                   (3, (64, 96, 128), 700, 41, 128, 3), (320, (128, 196, 256), 512, 128, 128, 1),
                                                   (320, (128, 128, 256), 512, 128, 64, 1), (320, (128, 196, 256), 200, 6, 64, 3)])
