@@ -81,7 +81,7 @@ __device__ __forceinline__ void tb_stats_acc(float (&sv)[32], const f32x16 &acc,
 
 template <int MT, int NW, int IN, bool AFF, int OUT, bool ST, bool KF>
 __global__ __launch_bounds__(NW * 64, 2) void tb_layer_kernel(TbParams p) {
-    static_assert(!(AFF && IN == 1) && !(ST && OUT != 0) && !(OUT == 3 && IN != 1), "GroupNorm on load / statistics are point-major features");
+    static_assert(!(AFF && IN == 1) && !(ST && OUT != 0), "GroupNorm on load / statistics are point-major features");
     constexpr int NT = NW * 64, UN = 2048 / NT, PSTEP = NT / 16;
     constexpr int ITEMS = 512 / NT;                                   // IN 1: (position quad, slot) items per thread and chunk
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -282,18 +282,6 @@ __global__ __launch_bounds__(NW * 64, 2) void tb_layer_kernel(TbParams p) {
             const bool valid = c < p.L;
             if constexpr (OUT == 0) {
                 if (valid) tb_store_tile(acc[tm][tn], p.y + (((size_t)b * p.L + c) * p.cp_out + 32 * t + 8 * h) * 2, relu);
-            } else if constexpr (OUT == 3) {
-                // fp32 POINT-major (B,L,cout), cout % 4 == 0: registers 4 q .. 4 q + 3 are rows 32 t + 8 q + 4 h + (0..3)
-                float *yp = reinterpret_cast<float *>(p.y) + ((size_t)b * p.L + c) * p.cout + 32 * t + 4 * h;
-                if (valid) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (32 * t + 8 * q + 4 * h < p.cout) {
-                            const float4 v = {apply_act(acc[tm][tn][4 * q], p.act), apply_act(acc[tm][tn][4 * q + 1], p.act),
-                                              apply_act(acc[tm][tn][4 * q + 2], p.act), apply_act(acc[tm][tn][4 * q + 3], p.act)};
-                            *reinterpret_cast<float4 *>(yp + 8 * q) = v;
-                        }
-                }
             } else if constexpr (OUT == 1) {
                 const int row0 = 32 * t + 4 * h;
                 float *yp = reinterpret_cast<float *>(p.y) + ((size_t)b * p.cout + row0) * p.L + c;
@@ -577,16 +565,14 @@ extern "C" int captra_dense_bf16_tile_stats_tiles(long long l) { return (int)((l
 //   in_cm = 0: x (B,L,ceil32(cin)) bf16 slot order.  in_cm = 1: x (B,csplit,L) fp32 channel-major holds input channels
 //     [0, csplit) and x2 (B,cin - csplit,L) the rest (csplit = cin, x2 = NULL: one tensor) -- the [xyz, feat] / [skip, interp]
 //     concats of pointnet_utils.py:286-294, 318-321 are never built; needs l % 4 == 0.
-//   out_mode = 0: y (B,L,ceil32(cout)) bf16 slot order; 1: y (B,cout,L) fp32; 2: y (B,cout) fp32 = max over the l <= 128 positions;
-//     3 (in_cm only, cout % 4 == 0): y (B,L,cout) fp32 POINT-major -- the SA2 scales' pre-transformed first layer (csrc/sa_bf16.hip).
+//   out_mode = 0: y (B,L,ceil32(cout)) bf16 slot order; 1: y (B,cout,L) fp32; 2: y (B,cout) fp32 = max over the l <= 128 positions.
 //   wimg packed with perm = 1 in every case (the LDS image is in slot order).  ab (in_cm = 0 only): (B,cin,2) or NULL; act
 //   CAPTRA_ACT_NONE / RELU (any of the three for fp32 outputs); stats (out_mode 0 only) (B,T,cout,2) or NULL; bias_bs: 0, or cout
 //   for a bias per cloud.  Returns -2 for shapes the kernel is not instantiated for: the caller uses captra_pointwise_mlp_bf16pm.
 extern "C" int captra_dense_bf16_tile_ex(int b, int cin, int cout, long long l, int in_cm, const void *x, const float *x2, int csplit,
                                          const unsigned char *wimg, const float *bias_packed, long long bias_bs, const float *ab, int act,
                                          int out_mode, void *y, float *stats, captra_stream_t stream) {
-    if (b < 0 || cin < 1 || cout < 1 || l < 0 || act < 0 || act > 2 || out_mode < 0 || out_mode > 3) return -1;
-    if (out_mode == 3 && (cout % 4 != 0 || !in_cm)) return -2;
+    if (b < 0 || cin < 1 || cout < 1 || l < 0 || act < 0 || act > 2 || out_mode < 0 || out_mode > 2) return -1;
     if (out_mode == 0 && act == ACT_SIGMOID_M05) return -1;
     if (in_cm && (ab != nullptr || csplit < 0 || csplit > cin || (csplit < cin && x2 == nullptr))) return -1;
     if (stats != nullptr && out_mode != 0) return -1;
@@ -611,7 +597,6 @@ extern "C" int captra_dense_bf16_tile_ex(int b, int cin, int cout, long long l, 
     do {                                                                                    \
         if (out_mode == 0) return tb_launch<MT_, NW_, 1, false, 0, false>(b, p, s);         \
         if (out_mode == 1) return tb_launch<MT_, NW_, 1, false, 1, false>(b, p, s);         \
-        if (out_mode == 3) return tb_launch<MT_, NW_, 1, false, 3, false>(b, p, s);         \
         return tb_launch<MT_, NW_, 1, false, 2, false>(b, p, s);                            \
     } while (0)
         if (p.nt >= 16 && ptiles >= 512) TB_GO_CM(2, 8);

@@ -108,6 +108,90 @@ __global__ __launch_bounds__(NW_THREADS) void three_nn_weights_kernel(int n, int
     }
 }
 
+// The same search with FOUR lanes per unknown point.  One lane per point is a chain of s dependent insertions (distance ->
+// three compares -> ten selects per known point): 512 known points are ~150 cycles each with nothing to overlap them when the
+// launch has one wave per SIMD (4096 unknowns x 16 clouds), and the kernel sits on the serial prefix of every frame (geometry
+// before both networks).  Here lane q of a point's four takes the groups of four known points g = q, q + 4, ... (adjacent lanes
+// read adjacent 16-byte LDS words: no bank conflict), keeps its own sorted triple, and the four triples are merged through
+// lane shuffles by (distance, index) -- the three smallest in that order are exactly what the sequential strict-'<' scan keeps,
+// so indices and weights are bit-identical.
+__global__ __launch_bounds__(NW_THREADS) void three_nn_weights4_kernel(int n, int s, const float *__restrict__ unknown,
+                                                                       const float *__restrict__ known,
+                                                                       int *__restrict__ idx, float *__restrict__ weight) {
+    __shared__ __attribute__((aligned(16))) float xs[NW_TILE];
+    __shared__ __attribute__((aligned(16))) float ys[NW_TILE];
+    __shared__ __attribute__((aligned(16))) float zs[NW_TILE];
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x, q = tid & 3;
+    const int pt = blockIdx.x * (NW_THREADS / 4) + (tid >> 2);
+    const bool live = pt < n;
+    float ux = 0.f, uy = 0.f, uz = 0.f;
+    if (live) {
+        const float *u = unknown + ((size_t)b * n + pt) * 3;
+        ux = u[0]; uy = u[1]; uz = u[2];
+    }
+    float b1 = INFINITY, b2 = INFINITY, b3 = INFINITY;
+    int i1 = 0x7fffffff, i2 = 0x7fffffff, i3 = 0x7fffffff;
+    const float *kn = known + (size_t)b * s * 3;
+    for (int t0 = 0; t0 < s; t0 += NW_TILE) {
+        const int tn = (s - t0) < NW_TILE ? (s - t0) : NW_TILE;
+        if (t0 > 0) __syncthreads();
+        for (int e = tid; e < tn * 3; e += NW_THREADS) {
+            const float v = kn[(size_t)t0 * 3 + e];
+            const int pp = e / 3, comp = e - pp * 3;
+            (comp == 0 ? xs : (comp == 1 ? ys : zs))[pp] = v;
+        }
+        const int tn4 = (tn + 3) & ~3;
+        for (int e = tn + tid; e < tn4; e += NW_THREADS) { xs[e] = INFINITY; ys[e] = INFINITY; zs[e] = INFINITY; }
+        __syncthreads();
+        for (int k = 4 * q; k < tn4; k += 16) {
+            const float4 kx = *reinterpret_cast<const float4 *>(xs + k);
+            const float4 ky = *reinterpret_cast<const float4 *>(ys + k);
+            const float4 kz = *reinterpret_cast<const float4 *>(zs + k);
+            const float qx[4] = {kx.x, kx.y, kx.z, kx.w}, qy[4] = {ky.x, ky.y, ky.z, ky.w}, qz[4] = {kz.x, kz.y, kz.z, kz.w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float d = dist2_unfused(ux, uy, uz, qx[u], qy[u], qz[u]);   // padding: inf - never inserted
+                const int kk = t0 + k + u;
+                const bool c1 = d < b1, c2 = d < b2, c3 = d < b3;                 // (a lane's own indices ascend: strict '<')
+                b3 = c2 ? b2 : (c3 ? d : b3);  i3 = c2 ? i2 : (c3 ? kk : i3);
+                b2 = c1 ? b1 : (c2 ? d : b2);  i2 = c1 ? i1 : (c2 ? kk : i2);
+                b1 = c1 ? d : b1;              i1 = c1 ? kk : i1;
+            }
+        }
+    }
+    // merge the other three lanes' triples: order by (distance, index)
+    const int lane0 = (tid & 63) & ~3;
+    float m1 = b1, m2 = b2, m3 = b3;
+    int j1 = i1, j2 = i2, j3 = i3;
+#pragma unroll
+    for (int r = 1; r < 4; ++r) {
+        const int srcl = lane0 + ((q + r) & 3);
+        const float od[3] = {__shfl(b1, srcl, 64), __shfl(b2, srcl, 64), __shfl(b3, srcl, 64)};
+        const int oi[3] = {__shfl(i1, srcl, 64), __shfl(i2, srcl, 64), __shfl(i3, srcl, 64)};
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            const float d = od[e];
+            const int kk = oi[e];
+            const bool c1 = d < m1 || (d == m1 && kk < j1), c2 = d < m2 || (d == m2 && kk < j2), c3 = d < m3 || (d == m3 && kk < j3);
+            m3 = c2 ? m2 : (c3 ? d : m3);  j3 = c2 ? j2 : (c3 ? kk : j3);
+            m2 = c1 ? m1 : (c2 ? d : m2);  j2 = c1 ? j1 : (c2 ? kk : j2);
+            m1 = c1 ? d : m1;              j1 = c1 ? kk : j1;
+        }
+    }
+    if (live && q == 0) {
+        const float r0 = 1.0f / (sqrtf(m1) + 1e-8f);
+        const float r1 = 1.0f / (sqrtf(m2) + 1e-8f);
+        const float r2 = 1.0f / (sqrtf(m3) + 1e-8f);
+        const float norm = (r0 + r1) + r2;
+        int *ii = idx + ((size_t)b * n + pt) * 3;
+        float *ww = weight + ((size_t)b * n + pt) * 3;
+        // (fewer than three known points: the sequential scan leaves index 0 in the unused slots)
+        ii[0] = j1 == 0x7fffffff ? 0 : j1; ii[1] = j2 == 0x7fffffff ? 0 : j2; ii[2] = j3 == 0x7fffffff ? 0 : j3;
+        ww[0] = r0 / norm; ww[1] = r1 / norm; ww[2] = r2 / norm;
+    }
+}
+
 constexpr int IC_THREADS = 256;
 constexpr int IC_POS = 1024;           // positions per workgroup (4 per lane)
 constexpr int IC_LDS_FLOATS = 8 * 1024;  // 32 KiB of feature rows per workgroup
@@ -379,11 +463,22 @@ extern "C" int captra_canonicalize(int b, int p, int n, const float *pts, const 
     return captra_last_error();
 }
 
+static CAPTRA_KNOB int g_nn_split = 1;     // experiment knob: 0 = one lane per unknown point (the first form)
+extern "C" void captra_three_nn_set_split(int on) { g_nn_split = on; }
+
 extern "C" int captra_three_nn_weights(int b, int n, int s, const float *unknown, const float *known, int *idx,
                                       float *weight, captra_stream_t stream) {
     if (b < 0 || n < 0 || s < 0) return -1;
     if (b == 0 || n == 0) return 0;
     if (s == 0) return -1;
+    if (g_nn_split) {
+        // four lanes per unknown point (a quarter of the dependent chain each); the one-lane form when that would only add waves
+        // to a chip that is full anyway
+        dim3 grid4((n + NW_THREADS / 4 - 1) / (NW_THREADS / 4), b);
+        CAPTRA_LAUNCH("three_nn_weights", three_nn_weights4_kernel, grid4, dim3(NW_THREADS), 0, (hipStream_t)stream, n, s,
+                      unknown, known, idx, weight);
+        return captra_last_error();
+    }
     dim3 grid((n + NW_THREADS - 1) / NW_THREADS, b);
     CAPTRA_LAUNCH("three_nn_weights", three_nn_weights_kernel, grid, dim3(NW_THREADS), 0, (hipStream_t)stream, n, s,
                   unknown, known, idx, weight);

@@ -529,12 +529,10 @@ def sa_scale_bf16(feat, xyz_cn, new_xyz_n3, idx, layers, out, co_off):
         src = torch.empty(B, N, l1.cout, dtype=torch.float32, device=feat.device)
         L.require_device(feat)
         with torch.cuda.device(feat.device):
-            if USE_TILE_BF16 and N % 4 == 0 and l1.cout % 4 == 0 and l1.cout >= 32:      # LDS-tiled kernel, fp32 point-major output
-                L.call("captra_dense_bf16_tile_ex", B, cfeat, l1.cout, N, 1, L.ptr(feat), None, cfeat, L.ptr(lead.bf16_frag(True)), L.ptr(lead.bias), 0,
-                       None, ACT_NONE, 3, L.ptr(src), None)
-            else:
-                L.call("captra_pointwise_mlp_bf16_pm", B, cfeat, l1.cout, N, L.ptr(feat), L.ptr(lead.bf16(0, cfeat)), L.ptr(lead.bias),
-                       ACT_NONE, L.ptr(src))
+            # (the LDS-tiled kernel with an fp32 point-major output was measured here and lost: 17.2 us against 13.5 us per launch
+            # at 32 clouds -- three K-chunks of 512 points are three exposed staging latencies; the streaming kernel prefetches deeper)
+            L.call("captra_pointwise_mlp_bf16_pm", B, cfeat, l1.cout, N, L.ptr(feat), L.ptr(lead.bf16(0, cfeat)), L.ptr(lead.bias),
+                   ACT_NONE, L.ptr(src))
         _work("pointwise_mlp", flops=2.0 * B * cfeat * l1.cout * N, nbytes=4.0 * B * N * (cfeat + l1.cout))
     else:
         src = feat

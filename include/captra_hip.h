@@ -279,8 +279,7 @@ int captra_dense_bf16_tile(int b, int cin, int cout, long long l, const void *x,
  * 512-point levels of the backbone: SA3's group_all MLP + max, FP3, FP2 -- pointnet_utils.py:253-343).  in_cm = 1: x (B,csplit,L)
  * fp32 holds input channels [0, csplit), x2 (B,cin - csplit,L) the rest (csplit = cin, x2 = NULL for one tensor): the
  * [xyz, feat] concat of sample_and_group_all (pointnet_utils.py:171-188) is never built; l % 4 == 0.  out_mode 0: y (B,L,ceil32(cout))
- * bf16 slot order; 1: y (B,cout,L) fp32; 2: y (B,cout) fp32 = max over the l <= 128 positions (torch.max(-1) of pointnet_utils.py:341);
- * 3 (in_cm, cout % 4 == 0): y (B,L,cout) fp32 POINT-major (the SA2 scales' pre-transformed first layer, pointnet_utils.py:234-242).
+ * bf16 slot order; 1: y (B,cout,L) fp32; 2: y (B,cout) fp32 = max over the l <= 128 positions (torch.max(-1) of pointnet_utils.py:341).
  * wimg packed with perm = 1 in every case. */
 int captra_dense_bf16_tile_ex(int b, int cin, int cout, long long l, int in_cm, const void *x, const float *x2, int csplit,
                               const unsigned char *wimg, const float *bias_packed, long long bias_bs, const float *ab, int act,

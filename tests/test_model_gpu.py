@@ -177,6 +177,30 @@ def test_sa_scale_pipe_bit_exact(device, chans, n, m, k, B):
     assert torch.equal(out, out2)
 
 
+@pytest.mark.parametrize("n,s,B,dup", [(4096, 512, 3, False), (512, 128, 5, False), (700, 37, 2, True), (130, 2, 2, False), (64, 1, 1, False),
+                                        (4096, 512, 1, True)])
+def test_three_nn_weights_four_lanes_per_point_equals_one_lane(device, n, s, B, dup):
+    """captra_three_nn_weights with four lanes per unknown point (quarter chains merged by (distance, index)) == the one-lane scan,
+    indices and weights bit for bit -- also under exact distance ties (duplicated known points: the earlier index wins), fewer than
+    three known points and tile tails that are not multiples of four."""
+    import ctypes
+    from captra_amd import _lib, fused
+    rng = np.random.default_rng(n + s + B)
+    unknown = (rng.random((B, n, 3), dtype=np.float32) - 0.5)
+    known = (rng.random((B, s, 3), dtype=np.float32) - 0.5)
+    if dup and s >= 8:
+        known[:, s // 2:] = known[:, :s - s // 2]                  # every point twice: ties everywhere
+        unknown[:, :s // 2] = known[:, :s // 2]                     # and exact zeros
+    res = []
+    for knob in (0, 1):
+        _lib.lib().captra_three_nn_set_split(ctypes.c_int(knob))
+        try:
+            res.append(fused.three_nn_weights(_dev(unknown, device), _dev(known, device)))
+        finally:
+            _lib.lib().captra_three_nn_set_split(ctypes.c_int(1))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
 @pytest.mark.parametrize("c1,c2,cout,l,bcast,B", [(3, 512, 256, 128, False, 4), (512, 1024, 256, 128, True, 4), (3, 512, 256, 128, False, 40),
                                                    (7, 130, 70, 77, False, 2), (320, 256, 256, 512, True, 3)])
 def test_pointwise_mlp_two_sources_equals_concat_bit_for_bit(device, c1, c2, cout, l, bcast, B):
