@@ -53,7 +53,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __host__ __device__ constexpr int bq_pad(int v) { return (v + 255) & ~255; }
 
-template <int NR, bool PRUNE>
+template <int NR, bool PRUNE, int CPW = BQ_CPW>
 __global__ __launch_bounds__(BQ_WAVES * 64) void ball_query_kernel(int n, int m,
                                                                    const float *__restrict__ new_xyz_all,
                                                                    const float *__restrict__ xyz_all,
@@ -79,11 +79,11 @@ __global__ __launch_bounds__(BQ_WAVES * 64) void ball_query_kernel(int n, int m,
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const float *xyz = xyz_all + (size_t)b * n * 3;
     const float *new_xyz = new_xyz_all + (size_t)b * m * 3;
-    const int c_base = (blockIdx.x * BQ_WAVES + wave) * BQ_CPW;
-    int cnt[BQ_CPW][NR];
-    int first[BQ_CPW][NR];
+    const int c_base = (blockIdx.x * BQ_WAVES + wave) * CPW;
+    int cnt[CPW][NR];
+    int first[CPW][NR];
 #pragma unroll
-    for (int ci = 0; ci < BQ_CPW; ++ci)
+    for (int ci = 0; ci < CPW; ++ci)
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             cnt[ci][r] = 0;
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(BQ_WAVES * 64) void ball_query_kernel(int n, int m,
         }
 
 #pragma unroll
-        for (int ci = 0; ci < BQ_CPW; ++ci) {
+        for (int ci = 0; ci < CPW; ++ci) {
             const int c = c_base + ci;
             if (c >= m) continue;
             if (PRUNE && any_pruned) {
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(BQ_WAVES * 64) void ball_query_kernel(int n, int m,
 
     // pad the tail of every list with the first hit (0 when the ball is empty)
 #pragma unroll
-    for (int ci = 0; ci < BQ_CPW; ++ci) {
+    for (int ci = 0; ci < CPW; ++ci) {
         const int c = c_base + ci;
         if (c >= m) continue;
 #pragma unroll
@@ -389,6 +389,7 @@ __global__ __launch_bounds__(BQ_WAVES * 64) void ball_query_kernel(int n, int m,
     }
 }
 
+CAPTRA_KNOB int g_bq_cpw = 0;     // experiment knob: centres per wave, 0 / 1 = one (default), 2 = two (the first form)
 CAPTRA_KNOB int g_bq_prune = 0;   // opt-in: 1 = small radii of 1024..4096-point clouds from the cell grid
 
 int launch_ball_query(int b, int n, int m, int nr, const float *radius, const int *nsample,
@@ -411,9 +412,15 @@ int launch_ball_query(int b, int n, int m, int nr, const float *radius, const in
     }
     const int tile_cap = bq_pad(n < BQ_TILE ? n : BQ_TILE);
     size_t shmem = (size_t)(tile_cap > 0 ? tile_cap : 256) * 3 * sizeof(float);
-    dim3 grid((m + BQ_WAVES * BQ_CPW - 1) / (BQ_WAVES * BQ_CPW), b);
-    dim3 block(BQ_WAVES * 64);
     const bool prune = g_bq_prune && n >= BQ_PRUNE_MINN && n <= BQ_PRUNE_MAXN && nr <= 3;   // (four bitmaps per wave do not fit in LDS)
+    // One centre per wave: a wave walks its centres one after the other, so with two of them the scan's latency -- the kernel sits on
+    // the serial prefix of every frame -- is paid twice.  Measured (tools/bq_ab.py, three-radius SA1 scan, us): 1 cloud 37.5 -> 20.1,
+    // 16 clouds 40.9 -> 33.9, 32 clouds 70.9 -> 59.4, 64 clouds 132 -> 110, identical lists; staging the cloud once more per
+    // workgroup costs less than the second walk.  The grid path (opt-in) keeps two.
+    const bool one = !prune && g_bq_cpw != 2;
+    const int cpw = one ? 1 : BQ_CPW;
+    dim3 grid((m + BQ_WAVES * cpw - 1) / (BQ_WAVES * cpw), b);
+    dim3 block(BQ_WAVES * 64);
 #define BQ_LAUNCH(NR)                                                                            \
     if (prune) {                                                                                 \
         auto kern = ball_query_kernel<NR, true>;                                                 \
@@ -428,13 +435,17 @@ int launch_ball_query(int b, int n, int m, int nr, const float *radius, const in
         CAPTRA_LAUNCH("ball_query", kern, grid, block, shmem + (size_t)tile_cap * 16 + extra, s, n, m, new_xyz, xyz, prm); \
     } else {                                                                                     \
         auto kern = ball_query_kernel<NR, false>;                                                \
+        auto kern1 = ball_query_kernel<NR, false, 1>;                                            \
         static CaptraDeviceOnce once;                                                            \
         if (once.first_use()) {                                                                  \
             hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                            \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, BQ_TILE * 12);       \
+            hipFuncSetAttribute(reinterpret_cast<const void *>(kern1),                           \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, BQ_TILE * 12);       \
             once.done();                                                                         \
         }                                                                                        \
-        CAPTRA_LAUNCH("ball_query", kern, grid, block, shmem, s, n, m, new_xyz, xyz, prm);       \
+        if (one) { CAPTRA_LAUNCH("ball_query", kern1, grid, block, shmem, s, n, m, new_xyz, xyz, prm); } \
+        else { CAPTRA_LAUNCH("ball_query", kern, grid, block, shmem, s, n, m, new_xyz, xyz, prm); }     \
     }
     switch (nr) {
         case 1: BQ_LAUNCH(1) break;
@@ -449,6 +460,7 @@ int launch_ball_query(int b, int n, int m, int nr, const float *radius, const in
 }  // namespace
 
 extern "C" void captra_ball_query_set_prune(int on) { g_bq_prune = on; }
+extern "C" void captra_ball_query_set_cpw(int v) { g_bq_cpw = v; }
 
 extern "C" int captra_ball_query(int b, int n, int m, float radius, int nsample, const float *new_xyz,
                                  const float *xyz, int *idx, captra_stream_t stream) {
