@@ -1,5 +1,5 @@
-Q="--mlp-dtype bf16 --no-cpu-baseline --no-otf --no-b1 --no-pose-match --no-kernel-timing --min-timed-s 1 --repeats 3"
-for v in "" "--lanes 1" "--lanes 1 --no-overlap" "--batch 16 --lanes 1" "--batch 16 --lanes 1 --no-overlap" "--lanes 3" "--lanes 4" "--batch 64" "--batch 64 --lanes 4"; do
+Q="--mlp-dtype bf16 --no-cpu-baseline --no-otf --no-b1 --no-legs --no-pose-match --no-kernel-timing --min-timed-s 1 --repeats 3"
+for v in "" "--lanes 1" "--lanes 1 --no-overlap" "--batch 16 --lanes 1" "--lanes 3" "--lanes 4" "--batch 64" "--batch 64 --lanes 4" "--batch 48 --lanes 3"; do
   echo "== $v"; python bench.py $Q $v 2>/dev/null | python -c "
 import sys,json
 for l in sys.stdin:
