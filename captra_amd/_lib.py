@@ -147,7 +147,8 @@ def lib():
         import os
         for env, fn in (("CAPTRA_BF16_SHARED_AFFINE", "captra_dense_bf16_set_shared_affine"), ("CAPTRA_BF16_STREAM", "captra_sa_bf16_set_stream"),
                         ("CAPTRA_FPS_DEFER", "captra_fps_set_defer"), ("CAPTRA_NN_SPLIT", "captra_three_nn_set_split"),
-                        ("CAPTRA_BQ_CPW", "captra_ball_query_set_cpw"), ("CAPTRA_SA_SPLIT", "captra_sa_fused_set_split")):
+                        ("CAPTRA_BQ_CPW", "captra_ball_query_set_cpw"), ("CAPTRA_SA_SPLIT", "captra_sa_fused_set_split"),
+                        ("CAPTRA_HEAD_PERSIST", "captra_tile_bf16_set_persistent")):
             if env in os.environ and hasattr(l, fn):
                 getattr(l, fn)(C.c_int(int(os.environ[env])))
     return _lib

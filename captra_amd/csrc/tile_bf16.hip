@@ -23,6 +23,7 @@
 // (B, T, C, 2) for captra_gn_finalize_tm; fixed summation order, no atomics.
 #include "common.h"
 #include "bf16_dense.h"
+#include <atomic>
 
 namespace {
 
@@ -487,6 +488,187 @@ __global__ __launch_bounds__(512, 2) void tb_head12_kernel(HbParams p) {
     }
 }
 
+// ---- the same pair, PERSISTENT: a workgroup per CU walks a contiguous run of 128-position tiles ----------------------------
+// tb_head12_kernel<1> pays, per tile: the x tile's HBM latency at workgroup start, the bias loads of both layers, the
+// GroupNorm coefficients' loads in the hand-over (all on the critical path of eight waves that meet at the same barriers), and
+// a launch ramp per round of workgroups (four rounds at 32 x 4096 points) -- 30 of its 99 us (ablation).  Here the
+// biases and the cloud's coefficients live in LDS (reloaded when the run crosses into another cloud), the NEXT tile's x rows are
+// requested right after the hand-over and travel under layer 2's 256 MFMAs per wave, and the kernel has one ramp.
+struct HpParams {
+    HbParams q;
+    int ntiles, tpc, tpw;          // tiles in the launch, tiles per cloud, tiles per workgroup (contiguous runs)
+};
+
+__global__ __launch_bounds__(512, 2) void tb_head12p_kernel(HpParams pp) {
+    const HbParams &p = pp.q;
+    constexpr int MT = 2, C1 = 512;
+    constexpr int XOFF = 98304, TAB = 131072;                          // x tile in the tail of the y1 image; tables behind it
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    float *ab_l = reinterpret_cast<float *>(lds + TAB);                // [512][2] coefficients of the current cloud
+    float *b1_l = ab_l + 1024, *b2_l = b1_l + 512;                     // [512] biases of layers 1 and 2
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, col = lane & 31;
+    const int t0 = wave * MT;
+    const int kst1 = p.kst1;
+    const __amdgpu_buffer_rsrc_t w1src = __builtin_amdgcn_make_buffer_rsrc((void *)p.w1, 0, 16 * kst1 * 1024, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w2src = __builtin_amdgcn_make_buffer_rsrc((void *)p.w2, 0, 16 * 32 * 1024, 0x00020000);
+    const int tile0 = blockIdx.x * pp.tpw;
+    const int tile1 = tile0 + pp.tpw < pp.ntiles ? tile0 + pp.tpw : pp.ntiles;
+    if (tile0 >= tile1) return;
+    for (int e = tid; e < 512; e += 512) { b1_l[e] = p.bias1[e]; b2_l[e] = p.bias2[e]; }
+    __syncthreads();
+    // x tile staging: thread -> 16-byte slot sslot of positions spos + 32 i
+    const int sslot = tid & 15, spos = tid >> 4, nsl = p.cp_x >> 3;
+    u32x4 xr[4];
+    auto xload = [&](int tile) {
+        const int b = tile / pp.tpc;
+        const long long pos0 = (long long)(tile - b * pp.tpc) * TB_P;
+        const unsigned char *xb = p.x + (size_t)b * p.L * p.cp_x * 2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            long long c = pos0 + spos + i * 32;
+            if (c >= p.L) c = p.L - 1;
+            xr[i] = u32x4{0u, 0u, 0u, 0u};
+            if (sslot < nsl) xr[i] = *reinterpret_cast<const u32x4 *>(xb + (size_t)c * p.cp_x * 2 + sslot * 16);
+        }
+    };
+    auto xpark = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4 *>(lds + XOFF + (spos + i * 32) * 256 + ((sslot ^ (spos & 15)) << 4)) = xr[i];
+    };
+    f32x16 acc[MT][TB_TN];
+    auto init_acc = [&](const float *bias_l) {
+#pragma unroll
+        for (int tm = 0; tm < MT; ++tm) {
+            const float *bp = bias_l + (t0 + tm) * 32 + 4 * h;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 bv = *reinterpret_cast<const float4 *>(bp + 8 * q);
+#pragma unroll
+                for (int tn = 0; tn < TB_TN; ++tn) { acc[tm][tn][4 * q] = bv.x; acc[tm][tn][4 * q + 1] = bv.y; acc[tm][tn][4 * q + 2] = bv.z; acc[tm][tn][4 * q + 3] = bv.w; }
+            }
+        }
+    };
+    u32x4 A[4][MT];
+    auto loadA1 = [&](int s, int kk) {
+        kk = kk < kst1 ? kk : kst1 - 1;
+#pragma unroll
+        for (int tm = 0; tm < MT; ++tm) A[s][tm] = __builtin_amdgcn_raw_buffer_load_b128(w1src, lane * 16, ((t0 + tm) * kst1 + kk) * 1024, 0);
+    };
+    auto loadA2 = [&](int s, int kk) {
+        kk = kk < 32 ? kk : 31;
+#pragma unroll
+        for (int tm = 0; tm < MT; ++tm) A[s][tm] = __builtin_amdgcn_raw_buffer_load_b128(w2src, lane * 16, ((t0 + tm) * 32 + kk) * 1024, 0);
+    };
+    const int e0 = (h ^ (col & 15)) << 4;
+    xload(tile0);
+    xpark();
+    int cur_b = -1;
+    for (int tile = tile0; tile < tile1; ++tile) {
+        const int b = tile / pp.tpc;
+        const long long pos0 = (long long)(tile - b * pp.tpc) * TB_P;
+        if (b != cur_b) {                                              // (workgroup-uniform) the cloud's GroupNorm coefficients
+            const float *abp = p.ab1 + (size_t)b * C1 * 2;
+            for (int e = tid; e < 1024; e += 512) ab_l[e] = abp[e];
+            cur_b = b;
+        }
+        init_acc(b1_l);
+        loadA1(0, 0);
+        loadA1(1, 1);
+        loadA1(2, 2);
+        __syncthreads();                                               // A: the x tile (and the tables) are in LDS
+        {
+            const unsigned char *src = lds + XOFF + col * 256;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                loadA1((j + 3) & 3, j + 3);
+                if (j < kst1) {
+                    u32x4 Bf[TB_TN];
+#pragma unroll
+                    for (int tn = 0; tn < TB_TN; ++tn) Bf[tn] = *reinterpret_cast<const u32x4 *>(src + tn * 8192 + ((32 * j) ^ e0));
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int tn = 0; tn < TB_TN; ++tn)
+#pragma unroll
+                        for (int tm = 0; tm < MT; ++tm) acc[tm][tn] = db_mfma(A[j & 3][tm], Bf[tn], acc[tm][tn]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        loadA2(0, 0);
+        loadA2(1, 1);
+        loadA2(2, 2);
+        __syncthreads();                                               // B: every wave is done with the x tile
+#pragma unroll
+        for (int tm = 0; tm < MT; ++tm) {
+            const int t = t0 + tm;
+            float ca[16], cb[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 *s4 = reinterpret_cast<const float4 *>(ab_l + (32 * t + 8 * q + 4 * h) * 2);
+                const float4 u0 = s4[0], u1 = s4[1];
+                ca[4 * q + 0] = u0.x; cb[4 * q + 0] = u0.y; ca[4 * q + 1] = u0.z; cb[4 * q + 1] = u0.w;
+                ca[4 * q + 2] = u1.x; cb[4 * q + 2] = u1.y; ca[4 * q + 3] = u1.z; cb[4 * q + 3] = u1.w;
+            }
+#pragma unroll
+            for (int tn = 0; tn < TB_TN; ++tn) {
+                unsigned char *row = lds + (tn * 32 + col) * 1024;
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    u32x4 v;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int r = 8 * jj + 2 * i;
+                        v[i] = db_relu2(db_pack(__builtin_fmaf(acc[tm][tn][r], ca[r], cb[r]), __builtin_fmaf(acc[tm][tn][r + 1], ca[r + 1], cb[r + 1])));
+                    }
+                    *reinterpret_cast<u32x4 *>(row + (((4 * t + 2 * jj + h) ^ (col & 15)) << 4)) = v;
+                }
+            }
+        }
+        init_acc(b2_l);
+        __syncthreads();                                               // C: y1 is in LDS
+        const unsigned char *src = lds + col * 1024;
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int kk = 8 * c + j;
+                loadA2((j + 3) & 3, kk + 3);
+                u32x4 Bf[TB_TN];
+#pragma unroll
+                for (int tn = 0; tn < TB_TN; ++tn) Bf[tn] = *reinterpret_cast<const u32x4 *>(src + tn * 32768 + c * 256 + ((32 * j) ^ e0));
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int tn = 0; tn < TB_TN; ++tn)
+#pragma unroll
+                    for (int tm = 0; tm < MT; ++tm) acc[tm][tn] = db_mfma(A[j & 3][tm], Bf[tn], acc[tm][tn]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // the next tile's x rows, requested BEHIND the last weight fragment this tile needs (the load counter retires in order: issued
+        // earlier, every later fragment wait would also wait for this HBM round trip) and once the operand registers are free (with
+        // them live the kernel spills); they travel under the epilogue's stores and statistics
+        if (tile + 1 < tile1) xload(tile + 1);
+#pragma unroll
+        for (int tm = 0; tm < MT; ++tm) {
+            const int t = t0 + tm;
+            float sv[32];
+#pragma unroll
+            for (int i = 0; i < 32; ++i) sv[i] = 0.f;
+#pragma unroll
+            for (int tn = 0; tn < TB_TN; ++tn) {
+                const long long c = pos0 + tn * 32 + col;
+                const bool valid = c < p.L;
+                if (valid) tb_store_tile(acc[tm][tn], p.y2 + (((size_t)b * p.L + c) * C1 + 32 * t + 8 * h) * 2, false);
+                tb_stats_acc(sv, acc[tm][tn], valid);
+            }
+            db_stats_tile(sv, col, h, t, C1, p.stats + (size_t)b * C1 * p.st_t * 2, p.st_t, (int)(tile - b * pp.tpc));
+        }
+        __syncthreads();                                               // D: every wave is done with y1
+        if (tile + 1 < tile1) xpark();
+    }
+}
+
 template <int MT, int NW, int IN, bool AFF, int OUT, bool ST>
 int tb_launch(int b, const TbParams &p, hipStream_t s) {
     dim3 grid((unsigned)((p.L + TB_P - 1) / TB_P), (p.nt + NW * MT - 1) / (NW * MT), b);
@@ -558,6 +740,8 @@ extern "C" int captra_gemv_bf16(int b, int cin, int cout, const float *x, const 
 
 static CAPTRA_KNOB int g_tb_dbg = 0;
 extern "C" void captra_tile_bf16_set_debug(int v) { g_tb_dbg = v; }
+static CAPTRA_KNOB int g_tb_persist = 1;       // fused head pair: 1 = the persistent form when the launch has more tiles than CUs
+extern "C" void captra_tile_bf16_set_persistent(int v) { g_tb_persist = v; }
 
 extern "C" int captra_dense_bf16_tile_stats_tiles(long long l) { return (int)((l + TB_P - 1) / TB_P); }
 
@@ -647,9 +831,26 @@ extern "C" int captra_head12_bf16(int b, int cin, long long l, const void *x, co
         return captra_last_error();
     }
     static CaptraDeviceOnce once;
+    static std::atomic<int> cus_of[128];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
     if (once.first_use()) {
         hipFuncSetAttribute(reinterpret_cast<const void *>(&tb_head12_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&tb_head12p_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 8192);
+        hipDeviceProp_t prop;
+        cus_of[dev & 127].store((hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256);
         once.done();
+    }
+    const int cus = cus_of[dev & 127].load() > 0 ? cus_of[dev & 127].load() : 256;
+    const long long tpc = (l + TB_P - 1) / TB_P, ntiles = (long long)b * tpc;
+    if (g_tb_persist && ntiles > cus && ntiles < (1ll << 30)) {
+        // persistent: one workgroup per CU, contiguous runs of tiles
+        HpParams pp;
+        pp.q = p; pp.tpc = (int)tpc; pp.ntiles = (int)ntiles;
+        pp.tpw = (int)((ntiles + cus - 1) / cus);
+        const int nwg = (int)((ntiles + pp.tpw - 1) / pp.tpw);
+        CAPTRA_LAUNCH("pointwise_mlp", tb_head12p_kernel, dim3(nwg), dim3(512), 131072 + 8192, s, pp);
+        return captra_last_error();
     }
     CAPTRA_LAUNCH("pointwise_mlp", tb_head12_kernel<1>, grid, dim3(512), 131072, s, p);
     return captra_last_error();

@@ -231,3 +231,25 @@ def test_sa3_and_fp_levels_tiled_vs_streaming_route(device):
         scale = float(o.abs().max())
         d = (a - o).abs()
         assert float(d.max()) <= 3e-2 * scale and float(d.mean()) <= 5e-4 * scale, (name, float(d.max()) / scale, float(d.mean()) / scale)
+
+
+@pytest.mark.parametrize("B,l", [(10, 4096), (3, 12000), (40, 1000)])
+def test_head12_persistent_form_equals_one_tile_per_workgroup(device, B, l):
+    """captra_head12_bf16 with more tiles than CUs runs persistent (a workgroup walks a contiguous run of tiles, biases and GroupNorm
+    coefficients in LDS, the next tile's rows prefetched under the epilogue): the same arithmetic in the same order, so y2 and its
+    statistics equal the one-tile-per-workgroup launch bit for bit -- runs that cross cloud boundaries and ragged last tiles included."""
+    import ctypes
+    from captra_amd import _lib, fused
+    rng = np.random.default_rng(B + l)
+    lin1 = fused.pack(_dev((rng.standard_normal((128, 512)) / 11.3).astype(np.float32), device), _dev(rng.standard_normal(512).astype(np.float32), device))
+    lin2 = fused.pack(_dev((rng.standard_normal((512, 512)) / 22.6).astype(np.float32), device), _dev(rng.standard_normal(512).astype(np.float32), device))
+    x = torch.randn(B, l, 128, device=device).to(torch.bfloat16)
+    ab1 = torch.randn(B, 512, 2, device=device)
+    res = []
+    for v in (0, 1):
+        _lib.lib().captra_tile_bf16_set_persistent(ctypes.c_int(v))
+        try:
+            res.append(fused.head12_bf16(x, lin1, ab1, lin2))
+        finally:
+            _lib.lib().captra_tile_bf16_set_persistent(ctypes.c_int(1))
+    assert torch.equal(res[0][0].view(torch.int16), res[1][0].view(torch.int16)) and torch.equal(res[0][1], res[1][1])

@@ -67,12 +67,20 @@ def main():
     us = timeit(lambda i: fused.head12_bf16(xs[i % 3], lin1, ab1, lin2))
     print(f"head12 fused (128 -> 512 -> 512, y2 + stats)        {us:8.1f} us  {2.0 * B * L * (128 * 512 + 512 * 512) / us / 1e6:7.1f} TFLOP/s", flush=True)
     from captra_amd import _lib
+    import ctypes
+    if hasattr(_lib.lib(), "captra_tile_bf16_set_persistent"):
+        for v in (0, 1, 0, 1):
+            _lib.lib().captra_tile_bf16_set_persistent(ctypes.c_int(v))
+            us = timeit(lambda i: fused.head12_bf16(xs[i % 3], lin1, ab1, lin2))
+            print(f"   fused pair, persistent={v}: {us:8.1f} us", flush=True)
     if hasattr(_lib.lib(), "captra_tile_bf16_set_debug"):
+        _lib.lib().captra_tile_bf16_set_persistent(ctypes.c_int(0))      # (the ablation switches are the one-tile-per-workgroup kernel's)
         for dbg in (1, 2, 4, 8, 16, 6, 14, 30):
             _lib.lib().captra_tile_bf16_set_debug(dbg)
             us = timeit(lambda i: fused.head12_bf16(xs[i % 3], lin1, ab1, lin2))
             print(f"   ablation dbg={dbg:2d} (1 A same frag, 2 no stores, 4 no stats, 8 no B reads, 16 no A loads): {us:8.1f} us", flush=True)
         _lib.lib().captra_tile_bf16_set_debug(0)
+        _lib.lib().captra_tile_bf16_set_persistent(ctypes.c_int(1))
 
 
 if __name__ == "__main__":
