@@ -386,7 +386,7 @@ def mlp_chain_bf16(x, layers, acts, out_pm: bool = False):
     B = x.shape[0]
     l = x.numel() // max(B * x.shape[1], 1)
     if chain_tile_bf16_supported(x.shape[1], l, layers):
-        y = mlp_chain_bf16_tile(x.view(B, x.shape[1], l), layers, acts, out_pm=out_pm)
+        y = mlp_chain_bf16_tile(x.reshape(B, x.shape[1], l), layers, acts, out_pm=out_pm)
         return y if out_pm else y.view((B, layers[-1].cout) + tuple(x.shape[2:]))
     y, in_pm = x.contiguous(), False
     for i, (lin, act) in enumerate(zip(layers, acts)):
