@@ -370,6 +370,23 @@ def hbm_ops_roofline(batch: int, device, reps: int = 5):
     torch.cuda.synchronize()
     _lib.prof_enable(False)
     ms_lvl = {k: _lib.prof_read(k)[0] / reps for k in nbytes}
+
+    def sequence_ms(fn):
+        """the whole job between ONE pair of events on the launch stream: what the sequence takes end to end (the per-op figures
+        above bracket every launch on its own, which puts an event's signal + dispatch between any two kernels)"""
+        s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        fn()
+        torch.cuda.synchronize()
+        best = []
+        for _ in range(3):
+            s0.record()
+            for _ in range(reps):
+                fn()
+            s1.record()
+            torch.cuda.synchronize()
+            best.append(s0.elapsed_time(s1) / reps)
+        return sorted(best)[1]
+    seq_plain, seq_multi, seq_lvl = sequence_ms(run), sequence_ms(lambda: run(multi=True)), sequence_ms(run_multi_group)
     # what a plain write stream reaches on this box, measured in this run: the ceiling the group op's 4*C*M*K output bytes face
     probe = torch.empty(128 << 20, dtype=torch.float32, device=device)
     probe.fill_(1.0)
@@ -386,6 +403,11 @@ def hbm_ops_roofline(batch: int, device, reps: int = 5):
            "achieved": round(tot_b / (tot_ms * 1e-3) / 1e9, 1), "frac": round(tot_b / (tot_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
            "bytes_per_frame": round(tot_b / B), "us_per_frame": round(1e3 * tot_ms / B, 2),
            "ops": {k: {"GB/s": round(nbytes[k] / (ms[k] * 1e-3) / 1e9, 1), "ms": round(ms[k], 3)} for k in nbytes},
+           "sequence": {"ms": round(seq_plain, 3), "frac": round(tot_b / (seq_plain * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                        "multi_radius_ms": round(seq_multi, 3), "multi_radius_frac": round(tot_b / (seq_multi * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                        "per_level_ms": round(seq_lvl, 3), "per_level_frac": round(tot_b / (seq_lvl * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                        "note": "the same three jobs, each between ONE pair of HIP events on the launch stream (launches back to back, "
+                                "inter-kernel gaps included); `frac` / `ops` above sum per-launch brackets"},
            "multi_radius": {"frac": round(tot_b / (sum(ms_multi.values()) * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
                             "ball_query_ms": round(ms_multi["ball_query"], 3), "group_points_ms": round(ms_multi["group_points"], 3),
                             "note": "same job with captra_ball_query_multi: one scan per level serves all its radii (identical lists)"},

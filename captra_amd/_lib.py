@@ -145,7 +145,7 @@ def lib():
         _lib = l
         # A/B switches for measurements (thread-local knobs of the library, set for the importing thread)
         import os
-        for env, fn in (("CAPTRA_BF16_SHARED_AFFINE", "captra_dense_bf16_set_shared_affine"), ("CAPTRA_BF16_STREAM", "captra_sa_bf16_set_stream"),
+        for env, fn in (("CAPTRA_BF16_SHARED_AFFINE", "captra_dense_bf16_set_shared_affine"), ("CAPTRA_SA_BF16_VARIANT", "captra_sa_bf16_set_variant"),
                         ("CAPTRA_FPS_DEFER", "captra_fps_set_defer"), ("CAPTRA_NN_SPLIT", "captra_three_nn_set_split"),
                         ("CAPTRA_BQ_CPW", "captra_ball_query_set_cpw"), ("CAPTRA_SA_SPLIT", "captra_sa_fused_set_split"),
                         ("CAPTRA_HEAD_PERSIST", "captra_tile_bf16_set_persistent")):

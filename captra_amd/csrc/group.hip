@@ -18,6 +18,8 @@ namespace {
 constexpr int GP_THREADS = 256;
 constexpr int GP_LDS_BYTES = 64 * 1024;  // channel-chunk staging budget (2 workgroups / CU)
 constexpr int GP_POS_PER_BLOCK = 4096;   // output positions handled by one workgroup
+// measurement knobs (tools/bench_group.py --sweep): staging budget in KiB (<= 64), channel-chunk cap, positions per workgroup
+CAPTRA_KNOB int g_gp_lds_kb = 64, g_gp_ccmax = 32, g_gp_ppb = 0;
 
 // VEC = 4: npos % 4 == 0 and 16-byte aligned idx/out rows; VEC = 1 otherwise.
 // Channel-outer order: a thread keeps the idx quads of its positions in registers and the workgroup
@@ -141,11 +143,13 @@ __global__ __launch_bounds__(GP_THREADS) void group_points_grad_kernel(int c, in
 // channel-chunk size, positions per workgroup and position blocks of one job (rows fit the LDS budget)
 void gp_shape(int b, int c, int n, long long npos, int &cc, int &ppb, long long &pos_blocks) {
     const size_t row_bytes = (size_t)n * sizeof(float);
-    cc = (int)(GP_LDS_BYTES / row_bytes);
+    cc = (int)((size_t)g_gp_lds_kb * 1024 / row_bytes);
+    if (cc < 1) cc = 1;
     if (cc > c) cc = c;
-    if (cc > 32) cc = 32;
+    if (cc > g_gp_ccmax) cc = g_gp_ccmax;
     // long rows (SA1: 16 KiB each): amortise the staging over twice the positions
     ppb = n >= 2048 ? 2 * GP_POS_PER_BLOCK : GP_POS_PER_BLOCK;
+    if (g_gp_ppb > 0) ppb = g_gp_ppb;
     pos_blocks = (npos + ppb - 1) / ppb;
     // few-channel inputs: split the channels over more workgroups until the chip is covered (staging cost per
     // output byte is n / ppb whatever cc is; only the idx quads are re-read)
@@ -207,6 +211,12 @@ int launch_group_grad(int b, int c, int n, long long npos, const float *grad_out
 }
 
 }  // namespace
+
+extern "C" void captra_group_set_shape(int lds_kb, int ccmax, int ppb) {
+    g_gp_lds_kb = lds_kb < 1 ? 1 : (lds_kb > 64 ? 64 : lds_kb);
+    g_gp_ccmax = ccmax < 1 ? 1 : ccmax;
+    g_gp_ppb = ppb > 0 ? (ppb + 4095) / 4096 * 4096 : 0;
+}
 
 extern "C" int captra_group_points(int b, int c, int n, int npoints, int nsample, const float *points,
                                    const int *idx, float *out, captra_stream_t stream) {

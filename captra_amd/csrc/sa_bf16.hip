@@ -184,14 +184,18 @@ __device__ __forceinline__ float sb_reduce16(float z, const f32x16 &a) {
 
 // (WLDS kernels: at most 256 registers per lane asked for, which also keeps the accumulators in VGPRs -- with the whole
 // 512-register file allowed the compiler puts them in AGPRs and every epilogue element costs a v_accvgpr_read first)
-template <int CF, int C1, int C2, int C3, int K, bool PRE, int TN, int CG, bool WLDS>
-__global__ __launch_bounds__(256, WLDS ? 2 : 1) void sa_bf16_kernel(SbParams p) {
+// OCC: waves per SIMD the register budget is cut for; RGS: row tiles per accumulator group (0: 1 for TN >= 4, else 2);
+// PF (small-input scales): the NEXT pass's gather in flight under this pass's MFMAs -- neighbour ids two passes ahead, raw
+// coordinates / features one pass ahead (a pass of the SA1 scales is 1-2 us of MFMA work behind two dependent global-memory
+// latencies; same arithmetic, same bits)
+template <int CF, int C1, int C2, int C3, int K, bool PRE, int TN, int CG, bool WLDS, int OCC = (WLDS ? 2 : 1), int RGS = 0, bool PF = false, int DBG = 0, int LRD = 1>
+__global__ __launch_bounds__(256, OCC) void sa_bf16_kernel(SbParams p) {
     using S = SbShape<CF, C1, C2, C3, PRE>;
     constexpr int TPC = K / 32;                        // 32-position tiles per centre
     constexpr int CPP = TN > TPC ? TN / TPC : 1;       // centres per pass
     constexpr int PPC = TPC > TN ? TPC / TN : 1;       // passes per centre
     constexpr int NPASS = CG * TPC / TN;               // passes per job
-    constexpr int RG = TN >= 4 ? 1 : 2;                // row tiles per accumulator group
+    constexpr int RG = RGS > 0 ? RGS : (TN >= 4 ? 1 : 2);   // row tiles per accumulator group
     constexpr bool STAGE_OUT = CG >= 4;                // results through a wave-private LDS strip, written as 16-byte segments
     static_assert((CG * TPC) % TN == 0 && (PRE || TN == 2) && K % 32 == 0, "shape");
     static_assert(PRE || S::CIN1 + 2 <= 8, "first layer: inputs + two bias rows fit the lower half-wave's eight k-slots");
@@ -218,13 +222,18 @@ __global__ __launch_bounds__(256, WLDS ? 2 : 1) void sa_bf16_kernel(SbParams p) 
     const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc((void *)p.img, 0, S::WBYTES, 0x00020000);
     // streamed weights: a ring of RD fragments, loaded RD - 1 uses ahead of the MFMAs that read them (a fragment feeds TN
     // MFMAs = TN x 32 cycles; an L2 hit takes 500+ cycles under this load)
-    constexpr int RD = WLDS ? 1 : 8;
+    // (LDS-resident weights, LRD > 1: the same ring over ds_read_b128 -- left to itself the compiler issues a fragment's read right in
+    // front of the two MFMAs that consume it, and every k-step waits out the LDS latency)
+    constexpr int RD = WLDS ? LRD : 8;
     constexpr SbUseOrder<S, RG> ORDER{};
     u32x4 ring[RD];
-    auto wload = [&](int f) -> u32x4 { return __builtin_amdgcn_raw_buffer_load_b128(wsrc, lane * 16, f * 1024, 0); };
+    auto wload = [&](int f) -> u32x4 {
+        if constexpr (WLDS) return *reinterpret_cast<const u32x4 *>(smem + ((DBG & 2) ? (f & 3) : f) * 1024 + lane * 16);
+        else return __builtin_amdgcn_raw_buffer_load_b128(wsrc, lane * 16, ((DBG & 2) ? (f & 7) : f) * 1024, 0);
+    };
     int use = 0;                                       // compile-time after unrolling: position in ORDER
     auto wfrag = [&](int f) -> u32x4 {
-        if constexpr (WLDS) return *reinterpret_cast<const u32x4 *>(smem + f * 1024 + lane * 16);
+        if constexpr (WLDS && RD == 1) return *reinterpret_cast<const u32x4 *>(smem + ((DBG & 2) ? (f & 3) : f) * 1024 + lane * 16);
         else {
             const u32x4 w = ring[use % RD];
             if (use + RD - 1 < S::NFRAG) ring[(use + RD - 1) % RD] = wload(ORDER.f[use + RD - 1]);
@@ -245,6 +254,38 @@ __global__ __launch_bounds__(256, WLDS ? 2 : 1) void sa_bf16_kernel(SbParams p) 
     const float *xb = p.xyz_cn + (size_t)b * 3 * p.n;
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
+    // small-input scales: the gather of pass ps (this lane's position: tile 2 ps + h, column col)
+    auto gather_id = [&](int ps) -> int {
+        const int tile = ps * 2 + h;
+        int c = centre0 + tile / TPC;
+        c = c < p.m ? c : p.m - 1;
+        if constexpr (DBG & 1) return col + 32 * (tile & 3);
+        return p.idx[cloud_idx + (size_t)c * K + (tile % TPC) * 32 + col];
+    };
+    // raw[0..CF) features, raw[CF..CF+3) coordinates, raw[CF+3..CF+6) the centre: loads only (the prefetching form keeps them
+    // raw across the loop edge, so that nothing waits for them before the next pass begins)
+    auto gather_raw = [&](int ps, int id, float (&raw)[CF + 6]) {
+        const int tile = ps * 2 + h;
+        int c = centre0 + tile / TPC;
+        c = c < p.m ? c : p.m - 1;
+        const float *cp = p.new_xyz + ((size_t)b * p.m + c) * 3;
+        if constexpr (!PRE) {
+#pragma unroll
+            for (int k = 0; k < CF; ++k) raw[k] = p.feat[((size_t)b * CF + k) * p.n + id];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) raw[CF + a] = xb[(size_t)a * p.n + id];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) raw[CF + 3 + a] = cp[a];
+        }
+    };
+    float pf_raw[CF + 6];
+    int pf_id = 0;
+    if constexpr (PF && !PRE) {
+        const int id0 = gather_id(0);
+        pf_id = gather_id(NPASS > 1 ? 1 : 0);
+        gather_raw(0, id0, pf_raw);
+    }
+
 #pragma unroll 1
     for (int ps = 0; ps < NPASS; ++ps) {
         u32x4 x1[TN];
@@ -253,18 +294,22 @@ __global__ __launch_bounds__(256, WLDS ? 2 : 1) void sa_bf16_kernel(SbParams p) 
         if constexpr (!PRE) {
             // 64 lanes fetch 64 consecutive positions: lanes 0-31 tile 0, lanes 32-63 tile 1; one half-wave exchange per
             // register then leaves each tile's inputs in the lower half-wave (k-slots 0..7) over a zero upper half
-            const int tile = ps * 2 + h;
-            int c = centre0 + tile / TPC;
-            c = c < p.m ? c : p.m - 1;
-            const int id = p.idx[cloud_idx + (size_t)c * K + (tile % TPC) * 32 + col];
-            const float *cp = p.new_xyz + ((size_t)b * p.m + c) * 3;
-            float in[8];
+            float raw[CF + 6], in[8];
+            if constexpr (PF) {
+                // unconditional (the last passes re-load their own position): no branch splits the pass's block
+#pragma unroll
+                for (int k = 0; k < CF + 6; ++k) raw[k] = pf_raw[k];
+                gather_raw(ps + 1 < NPASS ? ps + 1 : NPASS - 1, pf_id, pf_raw);      // (pf_id: requested one pass ago)
+                pf_id = gather_id(ps + 2 < NPASS ? ps + 2 : NPASS - 1);
+            } else {
+                gather_raw(ps, gather_id(ps), raw);
+            }
 #pragma unroll
             for (int k = 0; k < 8; ++k) in[k] = 0.f;
 #pragma unroll
-            for (int k = 0; k < CF; ++k) in[k] = p.feat[((size_t)b * CF + k) * p.n + id];
+            for (int k = 0; k < CF; ++k) in[k] = raw[k];
 #pragma unroll
-            for (int a = 0; a < 3; ++a) in[CF + a] = xb[(size_t)a * p.n + id] - cp[a];
+            for (int a = 0; a < 3; ++a) in[CF + a] = raw[CF + a] - raw[CF + 3 + a];
             in[CF + 3] = 1.f;
             in[CF + 4] = 1.f;
 #pragma unroll
@@ -283,7 +328,7 @@ __global__ __launch_bounds__(256, WLDS ? 2 : 1) void sa_bf16_kernel(SbParams p) 
                 const int tile = ps * TN + j;
                 int c = centre0 + tile / TPC;
                 c = c < p.m ? c : p.m - 1;
-                const int id = p.idx[cloud_idx + (size_t)c * K + (tile % TPC) * 32 + col];
+                const int id = (DBG & 1) ? col + 32 * j : p.idx[cloud_idx + (size_t)c * K + (tile % TPC) * 32 + col];
                 const float *cp = p.new_xyz + ((size_t)b * p.m + c) * 3;
                 const float r0 = xb[id] - cp[0], r1 = xb[(size_t)p.n + id] - cp[1], r2 = xb[(size_t)2 * p.n + id] - cp[2];
                 ids[j] = id;
@@ -294,7 +339,7 @@ __global__ __launch_bounds__(256, WLDS ? 2 : 1) void sa_bf16_kernel(SbParams p) 
             }
         }
         u32x4 h1[TN][S::KST2], h2[TN][S::KST3];
-        if constexpr (!WLDS) {
+        if constexpr (RD > 1) {
             use = 0;
 #pragma unroll
             for (int i = 0; i < RD - 1; ++i) ring[i] = wload(ORDER.f[i]);
@@ -388,14 +433,14 @@ __global__ __launch_bounds__(256, WLDS ? 2 : 1) void sa_bf16_kernel(SbParams p) 
                     if constexpr (STAGE_OUT) {
                         if (h == 0 && ch < C3) ost[cl * C3 + ch] = v;
                     } else {
-                        if (h == 0 && ch < C3 && centre0 + cl < p.m)
+                        if (h == 0 && ch < C3 && centre0 + cl < p.m && (!(DBG & 4) || v == 12345.f))
                             p.out[((size_t)b * p.out_ctotal + p.co_off + ch) * p.m + centre0 + cl] = v;
                     }
                 }
             }
         }
     }
-    if constexpr (STAGE_OUT) {
+    if constexpr (STAGE_OUT && !(DBG & 4)) {
         // wave-private strip ost[centre][channel] -> out rows: lane l writes centres 4(l%(CG/4)).. of channel l/(CG/4) + ...
         constexpr int QPC = CG / 4;                    // 16-byte segments per channel row
         constexpr int CHS = 64 / QPC;                  // channels per sweep
@@ -421,13 +466,15 @@ __global__ __launch_bounds__(256, WLDS ? 2 : 1) void sa_bf16_kernel(SbParams p) 
     }
 }
 
-template <int CF, int C1, int C2, int C3, int K, bool PRE, int TN, int CG, bool WLDS>
+CAPTRA_KNOB int g_sb_variant = 0;      // A/B: bit 0 = small-input scales as before (no gather prefetch, no fragment ring); bits 1-2: ring depth 4 / 2 / 3 / 6; bits 4..: ablations
+
+template <int CF, int C1, int C2, int C3, int K, bool PRE, int TN, int CG, bool WLDS, int OCC = (WLDS ? 2 : 1), int RGS = 0, bool PF = false, int DBG = 0, int LRD = 1>
 int sb_launch(int b, SbParams p, hipStream_t stream) {
     using S = SbShape<CF, C1, C2, C3, PRE>;
     p.jobs_per_cloud = (p.m + CG - 1) / CG;
     p.njobs = b * p.jobs_per_cloud;
     const int lds = (WLDS ? S::WBYTES : 0) + S::NBIAS * 4 + (CG >= 4 ? 4 * CG * C3 * 4 : 0);
-    auto kern = sa_bf16_kernel<CF, C1, C2, C3, K, PRE, TN, CG, WLDS>;
+    auto kern = sa_bf16_kernel<CF, C1, C2, C3, K, PRE, TN, CG, WLDS, OCC, RGS, PF, DBG, LRD>;
     static CaptraDeviceOnce once;
     if (lds > 48 * 1024 && once.first_use()) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return (int)hipGetLastError();
@@ -477,15 +524,51 @@ extern "C" int captra_sa_scale_bf16(int b, int n, int m, int k, int cfeat, int c
     p.xyz_cn = xyz_cn; p.new_xyz = new_xyz; p.idx = idx; p.img = img; p.out = out; p.out_ctotal = out_ctotal; p.co_off = co_off;
     p.jobs_per_cloud = p.njobs = 0;
     hipStream_t s = (hipStream_t)stream;
-#define SB_CASE(CF_, C1_, C2_, C3_, K_, PRE_, TN_, CG_, WLDS_)                                              \
-    if (cfeat == CF_ && c1 == C1_ && c2 == C2_ && c3 == C3_ && k == K_ && (pre != 0) == PRE_)             \
-        return sb_launch<CF_, C1_, C2_, C3_, K_, PRE_, TN_, CG_, WLDS_>(b, p, s);
-    SB_CASE(0, 32, 32, 64, 32, false, 2, 8, true) SB_CASE(0, 64, 64, 128, 64, false, 2, 8, true) SB_CASE(0, 64, 96, 128, 128, false, 2, 8, true)
-    SB_CASE(3, 32, 32, 64, 32, false, 2, 8, true) SB_CASE(3, 64, 64, 128, 64, false, 2, 8, true) SB_CASE(3, 64, 96, 128, 128, false, 2, 8, true)
-    SB_CASE(320, 128, 128, 256, 64, true, 4, 2, false) SB_CASE(320, 128, 196, 256, 128, true, 4, 1, false)
-#undef SB_CASE
+#define SB_MATCH(CF_, C1_, C2_, C3_, K_, PRE_) (cfeat == CF_ && c1 == C1_ && c2 == C2_ && c3 == C3_ && k == K_ && (pre != 0) == PRE_)
+    // PF_: the gather prefetch pays from 64 neighbours on (sa1s3 82 -> 79 us at 32 clouds, 54 -> 50 at 16; sa1s2 26 -> 23 at 16); the
+    // K = 32 scale (four passes per wave) loses to its two extra loads
+#define SB_CASE1(CF_, C1_, C2_, C3_, K_, PF_)                                                                \
+    if (SB_MATCH(CF_, C1_, C2_, C3_, K_, false)) {                                                          \
+        if (g_sb_variant & 1) return sb_launch<CF_, C1_, C2_, C3_, K_, false, 2, 8, true, 2, 0, false, 0, 1>(b, p, s);   \
+        switch ((g_sb_variant >> 1) & 3) {                                                                  \
+        case 1: return sb_launch<CF_, C1_, C2_, C3_, K_, false, 2, 8, true, 2, 0, PF_, 0, 2>(b, p, s);      \
+        case 2: return sb_launch<CF_, C1_, C2_, C3_, K_, false, 2, 8, true, 2, 0, PF_, 0, 3>(b, p, s);      \
+        case 3: return sb_launch<CF_, C1_, C2_, C3_, K_, false, 2, 8, true, 2, 0, PF_, 0, 6>(b, p, s);      \
+        default: return sb_launch<CF_, C1_, C2_, C3_, K_, false, 2, 8, true, 2, 0, PF_, 0, 4>(b, p, s);     \
+        }                                                                                                   \
+    }
+    if (SB_MATCH(0, 64, 96, 128, 128, false)) {
+        switch (g_sb_variant >> 4) {
+        case 1: return sb_launch<0, 64, 96, 128, 128, false, 2, 8, true, 2, 0, false, 1>(b, p, s);
+        case 2: return sb_launch<0, 64, 96, 128, 128, false, 2, 8, true, 2, 0, false, 2>(b, p, s);
+        case 3: return sb_launch<0, 64, 96, 128, 128, false, 2, 8, true, 2, 0, false, 3>(b, p, s);
+        case 4: return sb_launch<0, 64, 96, 128, 128, false, 2, 8, true, 2, 0, false, 4>(b, p, s);
+        case 7: return sb_launch<0, 64, 96, 128, 128, false, 2, 8, true, 2, 0, false, 7>(b, p, s);
+        default: break;
+        }
+    }
+    SB_CASE1(0, 32, 32, 64, 32, false) SB_CASE1(0, 64, 64, 128, 64, true) SB_CASE1(0, 64, 96, 128, 128, true)
+    SB_CASE1(3, 32, 32, 64, 32, false) SB_CASE1(3, 64, 64, 128, 64, true) SB_CASE1(3, 64, 96, 128, 128, true)
+    // (two tiles per wave on two waves per SIMD was measured for the SA2 scales: 63 -> 59 us for K = 64, and the 196-wide scale
+    // does not fit 256 registers -- 500 bytes of scratch, 122 -> 155 us)
+    if (SB_MATCH(320, 128, 128, 256, 64, true)) return sb_launch<320, 128, 128, 256, 64, true, 4, 2, false>(b, p, s);
+    if (SB_MATCH(320, 128, 196, 256, 128, true)) {
+        switch (g_sb_variant >> 4) {      // ablations (results wrong by construction): 1 coalesced gather, 2 eight fragments only, 4 no stores
+        case 1: return sb_launch<320, 128, 196, 256, 128, true, 4, 1, false, 1, 0, false, 1>(b, p, s);
+        case 2: return sb_launch<320, 128, 196, 256, 128, true, 4, 1, false, 1, 0, false, 2>(b, p, s);
+        case 3: return sb_launch<320, 128, 196, 256, 128, true, 4, 1, false, 1, 0, false, 3>(b, p, s);
+        case 4: return sb_launch<320, 128, 196, 256, 128, true, 4, 1, false, 1, 0, false, 4>(b, p, s);
+        case 7: return sb_launch<320, 128, 196, 256, 128, true, 4, 1, false, 1, 0, false, 7>(b, p, s);
+        default: break;
+        }
+        return sb_launch<320, 128, 196, 256, 128, true, 4, 1, false>(b, p, s);
+    }
+#undef SB_CASE1
+#undef SB_MATCH
     return -2;
 }
+
+extern "C" void captra_sa_bf16_set_variant(int v) { g_sb_variant = v; }
 
 // ======================================================================================================================
 // Dense CHAIN, register-resident: FP1's shared MLP + the backbone's conv1 (pointnet_utils.py:296-298, backbones.py:66-68) and,

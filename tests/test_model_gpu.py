@@ -1031,6 +1031,36 @@ def test_bf16_sa_scale(device, cfeat, chans, n, m, k):
     assert np.mean(err) <= 2e-4 * scale, np.mean(err) / scale    # typical elements agree to accumulation-order noise
 
 
+@pytest.mark.parametrize("cfeat,chans,n,m,k,b", [(3, (64, 96, 128), 4096, 512, 128, 2), (0, (32, 32, 64), 700, 41, 32, 3), (3, (64, 64, 128), 900, 67, 64, 2),
+                                                  (0, (64, 96, 128), 1000, 9, 128, 1), (320, (128, 196, 256), 512, 128, 128, 2),
+                                                  (320, (128, 128, 256), 200, 5, 64, 3), (320, (128, 128, 256), 512, 128, 64, 2)])
+def test_bf16_sa_scale_forms_bit_identical(device, cfeat, chans, n, m, k, b):
+    """The launch forms of captra_sa_scale_bf16 (gather of the next pass prefetched or not) run the same MFMA sequence per
+    position: identical bits."""
+    import ctypes
+    from captra_amd import _lib, fused
+    rng = np.random.default_rng(7 * cfeat + sum(chans) + k + m)
+    xyz_cn = _dev(rng.random((b, 3, n), dtype=np.float32) - 0.5, device)
+    feat = _dev(rng.standard_normal((b, cfeat, n)).astype(np.float32), device) if cfeat else None
+    new_xyz = _dev(rng.random((b, m, 3), dtype=np.float32) - 0.5, device)
+    idx = _dev(rng.integers(0, n, (b, m, k)).astype(np.int32), device)
+    dims = (cfeat + 3,) + chans
+    packed = [fused.pack(_dev((rng.standard_normal((dims[i], dims[i + 1])) / np.sqrt(dims[i])).astype(np.float32), device),
+                         _dev(rng.standard_normal(dims[i + 1]).astype(np.float32), device)) for i in range(3)]
+    outs = {}
+    fused.set_mlp_dtype("bf16")
+    try:
+        for variant in (1, 0):
+            _lib.lib().captra_sa_bf16_set_variant(ctypes.c_int(variant))
+            out = torch.full((b, chans[2], m), -7.0, device=device)
+            fused.sa_scale_bf16(feat, xyz_cn, new_xyz, idx, packed, out, 0)
+            outs[variant] = out
+    finally:
+        _lib.lib().captra_sa_bf16_set_variant(ctypes.c_int(0))
+        fused.set_mlp_dtype("fp32")
+    assert torch.equal(outs[1], outs[0])
+
+
 _SLOT_PERM = np.array([0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15])
 
 
