@@ -431,7 +431,7 @@ def config_leg(name: str, extra: list, timeout_s: int = 120):
     import subprocess
     here = os.path.dirname(os.path.abspath(__file__))
     if name == "backbone16k":
-        cmd = [sys.executable, os.path.join(here, "tools", "bench_backbone.py"), "--npoint", "2048", "512", "--steps", "20", "--warmup", "10"]
+        cmd = [sys.executable, os.path.join(here, "tools", "bench_backbone.py"), "--npoint", "2048", "512", "--steps", "60", "--warmup", "10"]
     else:
         cmd = [sys.executable, os.path.abspath(__file__), "--leg"] + extra
     t0 = time.perf_counter()
@@ -443,10 +443,10 @@ def config_leg(name: str, extra: list, timeout_s: int = 120):
     if res.returncode != 0 or not lines:
         return {"error": (res.stderr or res.stdout)[-500:], "command": " ".join(cmd[1:])}
     d = json.loads(lines[-1])
-    keep = ("metric", "value", "unit", "ms_per_step", "dtype", "steps", "roofline", "kernel_ms_per_step", "timed_blocks", "config")
+    keep = ("metric", "value", "unit", "ms_per_step", "dtype", "steps", "roofline", "kernel_ms_per_step", "timed_blocks", "config", "one_graph")
     out = {k: d[k] for k in keep if k in d}
     if isinstance(out.get("config"), dict):
-        out["config"] = {"workload": out["config"].get("workload")}
+        out["config"] = {k: out["config"].get(k) for k in ("workload", "launch") if out["config"].get(k)}
     if isinstance(out.get("timed_blocks"), dict):
         out["timed_blocks"] = {k: out["timed_blocks"][k] for k in ("n", "ms_per_step_median", "ms_per_step_min", "ms_per_step_max") if k in out["timed_blocks"]}
     out["command"] = "python " + " ".join(os.path.relpath(c, here) if c.startswith(here) else c for c in cmd[1:])

@@ -23,6 +23,9 @@ struct CaptraProfScope {
         hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);             \
     } while (0)
 
+// prof.cpp: CUs the calling thread's persistent launches leave free (captra_set_reserved_cus)
+int captra_reserved_cus();
+
 static inline int captra_last_error() { return (int)hipGetLastError(); }
 
 // ---- per-device one-shot (kernel function attributes) ---------------------------------------------

@@ -125,4 +125,14 @@ const char *captra_error_string(int err) {
 
 const char *captra_version(void) { return "captra_hip 0.1 (gfx950)"; }
 
+// Persistent kernels (one workgroup per CU slot, centres walked statically) launched by the calling thread size their grid for
+// `n` CUs fewer: a schedule that runs one-workgroup-per-cloud samplers on another stream at the same time (captra_amd/graph.py
+// BackbonePipe) keeps every persistent workgroup resident that way.  A workgroup that finds its CU taken starts when another
+// one ENDS, i.e. the launch takes twice as long (measured: the MLP stage of configs[4] 2.05 -> 3.4 ms with 8 of 256 CUs masked).
+static thread_local int g_reserved_cus = 0;
+void captra_set_reserved_cus(int n) { g_reserved_cus = n < 0 ? 0 : n; }
+
 }  // extern "C"
+
+int captra_reserved_cus() { return g_reserved_cus; }
+

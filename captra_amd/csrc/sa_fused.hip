@@ -328,6 +328,8 @@ struct SwParams {
     const float *v1;           // PRE kernels: (B,C1,N) = b1 + W1[feature rows] * feat per source point, else null
     unsigned long long *prof;  // debug: per-phase wave-cycle totals of a sample of waves (sa_wave_kernel), else null
     int split;                 // sa_wave_lds_kernel: a wave owns ONE 32-neighbour slice of a centre (small batches), maxima combined by atomic max
+    int *dyn;                  // sa_wave_lds_kernel: a zeroed counter -> centres beyond every wave's first are handed out through it
+                               // (captra_sa_set_dynamic), null = static walk gid, gid + nwaves, ...
 };
 
 #define SW_TICK(slot)                                                         \
@@ -677,6 +679,18 @@ __global__ __launch_bounds__(SL_WAVES * 64) __attribute__((amdgpu_waves_per_eu(4
     int task = gid;
     int c = split ? gid >> ssh : gid, sl = split ? gid & (nslices - 1) : 0;                 // the slice being computed
     int c_next = gid + nwaves;           // the centre after c
+    // DYNAMIC hand-out (p.dyn, centres of >= 2 slices): the static walk assumes every workgroup of the grid is resident.  Beside
+    // another stream's one-workgroup-per-cloud samplers some are not -- they start when a resident workgroup ENDS, and the launch
+    // takes twice as long (graph.py BackbonePipe).  Here every wave takes its centres from a counter: the first one before
+    // anything else, each further one asked for at the current centre's FIRST slice and read at its last (that return is never
+    // waited for): late workgroups find the counter exhausted and leave, the resident ones have done the work.  Which wave
+    // computes a centre changes nothing in its bits.
+    const bool dyn = p.dyn != nullptr && !split && nslices > 1;
+    int dyn_raw = 0;
+    if (dyn) {
+        if (lane == 0) dyn_raw = atomicAdd(p.dyn, 1);
+        c = __builtin_amdgcn_readfirstlane(dyn_raw);
+    }
     int id = 0;
     float ctr[3] = {0.f, 0.f, 0.f};
     if (c < ncentres) {
@@ -705,6 +719,10 @@ __global__ __launch_bounds__(SL_WAVES * 64) __attribute__((amdgpu_waves_per_eu(4
         }
         // what comes after this slice (wave-uniform)
         const bool last_slice = split || sl + 1 == nslices;
+        if (dyn) {
+            if (sl == 0 && lane == 0) dyn_raw = atomicAdd(p.dyn, 1);
+            if (last_slice) c_next = __builtin_amdgcn_readfirstlane(dyn_raw);
+        }
         const int cn = split ? (task + nwaves) >> ssh : (last_slice ? c_next : c), sn = split ? (task + nwaves) & (nslices - 1) : (last_slice ? 0 : sl + 1);
         const bool has_next = cn < ncentres;
         int id_n = 0;
@@ -742,7 +760,7 @@ __global__ __launch_bounds__(SL_WAVES * 64) __attribute__((amdgpu_waves_per_eu(4
                     else op[(size_t)32 * t * p.m] = v;
                 }
             }
-            c_next += nwaves;
+            if (!dyn) c_next += nwaves;
             ctr[0] = ctr_n[0]; ctr[1] = ctr_n[1]; ctr[2] = ctr_n[2];
             SW_TICK(4)
         }
@@ -763,6 +781,18 @@ extern "C" void captra_sa_fused_set_mode(int mode) { g_sa_mode = mode; }
 static CAPTRA_KNOB int g_sa_split = 1;  // a wave per slice for small batches: 0 = never, 1 = heuristic, 2 = always (tests)
 extern "C" void captra_sa_fused_set_split(int v) { g_sa_split = v; }
 int captra_sa_split_knob() { return g_sa_split; }
+// Dynamic centre hand-out of the persistent SA kernels (sa_wave_lds_kernel, sa_wave_pipe_kernel): a caller-owned device buffer
+// of `nslots` ints; every launch of the calling thread takes the next slot (round robin), zeroes it on its stream and counts
+// its centres through it.  (nullptr, 0) = static walk (default).  A captured graph owns the slots its launches were given.
+static CAPTRA_KNOB int *g_sa_dyn_pool = nullptr;
+static CAPTRA_KNOB int g_sa_dyn_slots = 0, g_sa_dyn_next = 0;
+extern "C" void captra_sa_set_dynamic(int *pool, int nslots) { g_sa_dyn_pool = pool; g_sa_dyn_slots = pool ? nslots : 0; g_sa_dyn_next = 0; }
+int *captra_sa_dyn_slot(hipStream_t stream) {
+    if (g_sa_dyn_pool == nullptr || g_sa_dyn_slots < 1) return nullptr;
+    int *slot = g_sa_dyn_pool + (g_sa_dyn_next++ % g_sa_dyn_slots);
+    if (hipMemsetAsync(slot, 0, sizeof(int), stream) != hipSuccess) return nullptr;
+    return slot;
+}
 static unsigned long long *g_sa_prof = nullptr;  // device buffer of 10 counters: sa_wave_kernel's opt-in phase timers
 extern "C" void captra_sa_fused_set_prof(unsigned long long *dev_counters) { g_sa_prof = dev_counters; }
 unsigned long long *captra_sa_prof_ptr() { return g_sa_prof; }
@@ -788,7 +818,7 @@ extern "C" int captra_sa_scale_fused(int b, int n, int m, int k, int cfeat, int 
         // PointNet2Msg config); any other shape takes the generic LDS kernel below
         SwParams q;
         q.b = b; q.n = n; q.m = m; q.k = k; q.feat = feat; q.xyz_cn = xyz_cn; q.new_xyz = new_xyz; q.idx = idx;
-        q.w1 = w1; q.b1 = b1; q.w2 = w2; q.b2 = b2; q.w3 = w3; q.b3 = b3; q.out = out; q.out_ctotal = out_ctotal; q.co_off = co_off; q.v1 = nullptr; q.prof = g_sa_prof; q.split = 0;
+        q.w1 = w1; q.b1 = b1; q.w2 = w2; q.b2 = b2; q.w3 = w3; q.b3 = b3; q.out = out; q.out_ctotal = out_ctotal; q.co_off = co_off; q.v1 = nullptr; q.prof = g_sa_prof; q.split = 0; q.dyn = nullptr;
         const long long Lw = (long long)m * k;
         dim3 gridw((unsigned)((Lw + SF_POS - 1) / SF_POS), b);
         // small-input scales: persistent workgroups with the weights resident in LDS (mode 2 = streaming kernel for all)
@@ -800,22 +830,26 @@ extern "C" int captra_sa_scale_fused(int b, int n, int m, int k, int cfeat, int 
         int dev = 0;                                                                                                   \
         (void)hipGetDevice(&dev);                                                                                      \
         std::atomic<int> &resident_slot = resident_of[dev & 127];                                                      \
-        int resident = resident_slot.load(std::memory_order_relaxed);                                                  \
-        if (resident == 0) {                                                                                           \
+        int packed = resident_slot.load(std::memory_order_relaxed);      /* workgroups per CU << 16 | CUs */           \
+        if (packed == 0) {                                                                                             \
             int per_cu = 0;                                                                                            \
             hipDeviceProp_t prop;                                                                                      \
             (void)hipGetDeviceProperties(&prop, dev);                                                                  \
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); \
             (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, SL_WAVES * 64, lds_bytes);                \
-            resident = (per_cu > 0 ? per_cu : 1) * (prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);    \
-            resident_slot.store(resident, std::memory_order_relaxed);                                                  \
+            packed = ((per_cu > 0 ? per_cu : 1) << 16) | (prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256); \
+            resident_slot.store(packed, std::memory_order_relaxed);                                                    \
         }                                                                                                              \
+        /* (captra_set_reserved_cus: CUs another stream's samplers hold -- every persistent workgroup must be resident) */ \
+        const int cus_l = (packed & 0xffff) - captra_reserved_cus() > 0 ? (packed & 0xffff) - captra_reserved_cus() : 1; \
+        const int resident = (packed >> 16) * cus_l;                                                                   \
         const long long centres = (long long)b * m;            /* a wave per centre: 8 centres per workgroup round */           \
         /* fewer centres than resident waves: a wave per SLICE instead (see the kernel), output pre-zeroed for the atomic max */ \
         q.split = (g_sa_split != 0 && k > 32 && (g_sa_split == 2 || centres < (long long)resident * SL_WAVES)) ? 1 : 0;    \
         const long long units = q.split ? centres * (k / 32) : centres;                                                \
         const long long wgs = (units + SL_WAVES - 1) / SL_WAVES;                                                       \
         q.b = b;                                                                                                       \
+        q.dyn = (!q.split && k > 32 && wgs > 1) ? captra_sa_dyn_slot((hipStream_t)stream) : nullptr;                   \
         const unsigned grid_l = (unsigned)(wgs < resident ? wgs : resident);                                           \
         if (q.split) (void)hipMemset2DAsync(out + (size_t)co_off * m, (size_t)out_ctotal * m * 4, 0, (size_t)c3 * m * 4, b, (hipStream_t)stream); \
         CAPTRA_LAUNCH("sa_scale_fused", kern, dim3(grid_l), dim3(SL_WAVES * 64), lds_bytes, (hipStream_t)stream, q);  \
@@ -881,7 +915,7 @@ extern "C" int captra_sa_scale_pre(int b, int n, int m, int k, int cfeat, int c1
     SwParams q;
     q.b = b; q.n = n; q.m = m; q.k = k; q.feat = nullptr; q.xyz_cn = xyz_cn; q.new_xyz = new_xyz; q.idx = idx;
     q.w1 = w1; q.b1 = b2 /* unused by the PRE kernels: any valid packed bias */; q.w2 = w2; q.b2 = b2; q.w3 = w3; q.b3 = b3;
-    q.out = out; q.out_ctotal = out_ctotal; q.co_off = co_off; q.v1 = v1; q.prof = g_sa_prof; q.split = 0;
+    q.out = out; q.out_ctotal = out_ctotal; q.co_off = co_off; q.v1 = v1; q.prof = g_sa_prof; q.split = 0; q.dyn = nullptr;
     const long long Lw = (long long)m * k;
     dim3 gridw((unsigned)((Lw + SF_POS - 1) / SF_POS), b);
 #define SWP_CASE(CF_, C1_, C2_, C3_)                                                                                       \

@@ -40,6 +40,7 @@ struct SpParams {
     int out_ctotal, co_off;
     unsigned long long *prof;  // debug: per-phase wave-cycle totals of a sample of workgroups (captra_sa_fused_set_prof), or null
     int split;                 // a wave owns ONE 32-neighbour slice of a centre (small batches); maxima combined by atomic max on the zeroed output
+    int *dyn;                  // zeroed counter: centres beyond a wave's first are handed out through it (sa_fused.hip, captra_sa_set_dynamic)
 };
 
 #define SP_TICK(slot)                                                           \
@@ -277,6 +278,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int ssh = __builtin_ctz((unsigned)nslices);
     int task = gid;
     int c = split ? gid >> ssh : gid, sl = split ? gid & (nslices - 1) : 0;
+    // dynamic hand-out of the centres after a wave's first (as in sa_wave_lds_kernel): asked for at a centre's first slice, read
+    // at its last
+    const bool dyn = p.dyn != nullptr && !split && nslices > 1;
+    int dyn_raw = 0, c_next = gid + nwaves;
+    if (dyn) {
+        if (lane == 0) dyn_raw = atomicAdd(p.dyn, 1);
+        c = __builtin_amdgcn_readfirstlane(dyn_raw);
+    }
     if (c < ncentres) {
         sw_first_set<C1, C2>(s[NEXT2], p.w2, lane);
         id = load_id(c, sl);
@@ -289,7 +298,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
         // ---- what comes after this slice (wave-uniform) ----
         const bool last_slice = split || sl + 1 == nslices;
-        const int cn = split ? (task + nwaves) >> ssh : (last_slice ? c + nwaves : c), sn = split ? (task + nwaves) & (nslices - 1) : (last_slice ? 0 : sl + 1);
+        if (dyn) {
+            if (sl == 0 && lane == 0) dyn_raw = atomicAdd(p.dyn, 1);
+            if (last_slice) c_next = __builtin_amdgcn_readfirstlane(dyn_raw);
+        } else {
+            c_next = c + nwaves;
+        }
+        const int cn = split ? (task + nwaves) >> ssh : (last_slice ? c_next : c), sn = split ? (task + nwaves) & (nslices - 1) : (last_slice ? 0 : sl + 1);
         const bool has_next = cn < ncentres;
         int id_n = 0;
 
@@ -355,6 +370,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
 extern unsigned long long *captra_sa_prof_ptr();   // sa_fused.hip: the debug counters set by captra_sa_fused_set_prof
 extern int captra_sa_split_knob();                  // sa_fused.hip: captra_sa_fused_set_split
+extern int *captra_sa_dyn_slot(hipStream_t stream); // sa_fused.hip: captra_sa_set_dynamic
 
 // SA scale with a pre-transformed, POINT-major first layer (see include/captra_hip.h): v1pm (B,N,c1).
 // -2: shape not instantiated / not tileable (the caller takes captra_sa_scale_pre).
@@ -381,6 +397,7 @@ extern "C" int captra_sa_scale_pre_pm(int b, int n, int m, int k, int cfeat, int
         cus = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
         cus_of[dev & 127].store(cus, std::memory_order_relaxed);
     }
+    cus = cus - captra_reserved_cus() > 0 ? cus - captra_reserved_cus() : 1;     // (captra_set_reserved_cus)
     // one workgroup (4 waves, one per SIMD) per CU; a wave per centre
     const long long centres = (long long)b * m;
     if (centres >= (1ll << 30)) return -2;
@@ -388,6 +405,7 @@ extern "C" int captra_sa_scale_pre_pm(int b, int n, int m, int k, int cfeat, int
     q.split = (split_knob != 0 && k > 32 && (split_knob == 2 || centres < 4ll * cus)) ? 1 : 0;     // fewer centres than resident waves
     const long long wgs = ((q.split ? centres * (k / 32) : centres) + 3) / 4;
     const unsigned grid = (unsigned)(wgs < cus ? wgs : cus);
+    q.dyn = (!q.split && k > 32 && wgs > 1) ? captra_sa_dyn_slot((hipStream_t)stream) : nullptr;
     if (q.split) (void)hipMemset2DAsync(out + (size_t)co_off * m, (size_t)out_ctotal * m * 4, 0, (size_t)c3 * m * 4, b, (hipStream_t)stream);
 #define SPP_CASE(CF_, C1_, C2_, C3_)                                                                                  \
     if (cfeat == CF_ && c1 == C1_ && c2 == C2_ && c3 == C3_) {                                                        \

@@ -841,7 +841,8 @@ extern "C" int captra_head12_bf16(int b, int cin, long long l, const void *x, co
         cus_of[dev & 127].store((hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256);
         once.done();
     }
-    const int cus = cus_of[dev & 127].load() > 0 ? cus_of[dev & 127].load() : 256;
+    const int cus_dev = cus_of[dev & 127].load() > 0 ? cus_of[dev & 127].load() : 256;
+    const int cus = cus_dev - captra_reserved_cus() > 0 ? cus_dev - captra_reserved_cus() : 1;      // (captra_set_reserved_cus)
     const long long tpc = (l + TB_P - 1) / TB_P, ntiles = (long long)b * tpc;
     if (g_tb_persist && ntiles > cus && ntiles < (1ll << 30)) {
         // persistent: one workgroup per CU, contiguous runs of tiles

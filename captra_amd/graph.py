@@ -273,3 +273,126 @@ class TrackLanes:
             ev.record(st)
             self.consumed[slot] = ev
             self._pending = None
+
+
+class BackbonePipe:
+    """`PointNet2Msg.forward` over a STREAM of independent batches, as a two-stage pipeline on two streams: everything of a
+    batch that depends on the coordinates only -- both furthest-point samplings, both ball queries, the 3-NN weights
+    (`precompute_geometry`, backbones.py:30-69 of the reference run them inside forward) -- is one captured graph on the
+    geometry stream, the shared MLPs / feature propagation (`forward(geom=...)`) another on the MLP stream, and batch
+    t + 1's geometry runs beside batch t's MLPs.  The samplers are one workgroup per cloud (8 clouds of BASELINE.json
+    configs[4]: 8 of 256 CUs for 1.9 of the step's 4.6 ms), the MLP kernels fill the chip: side by side a batch costs
+    max(geometry, MLPs) instead of their sum.  Batches are independent (no pose feedback in the backbone), so every output
+    is the one `net(x)` returns, bit for bit.  `depth` slots of static buffers; `push` enqueues a batch and returns its slot,
+    `output(slot)` makes the caller's stream wait for it.
+
+    Not for the tracking step: there frame t + 1's cloud is canonicalised with pose t (model.py:422,454-461)."""
+
+    def __init__(self, net, x: torch.Tensor, depth: int = 2, warmup: int = 2, reserve: int | None = None):
+        if depth < 2:
+            raise ValueError("a pipeline needs at least two slots")
+        if net.training or not x.is_cuda:
+            raise ValueError("BackbonePipe: eval-mode network on the GPU")
+        dev = x.device
+        self.net, self.depth, self.t = net, depth, 0
+        # The MLP graph's PERSISTENT kernels (the fp32 SA scales: one workgroup per CU slot, centres walked statically) are sized
+        # for `reserve` CUs fewer (default: one per cloud; A/B: CAPTRA_PIPE_RESERVE): a sampler workgroup of the other stream holds
+        # its CU for the whole 1.5 ms of its rounds, and a persistent workgroup that finds its CU taken starts when another one
+        # ENDS -- the launch takes twice as long (configs[4]: the pipelined batch 3.23 ms against max(2.30, 2.05); a
+        # high-priority geometry stream does not change that, a CU-masked MLP stream makes it worse: 3.86 ms, the masked
+        # kernels run 2.05 -> 3.38 ms because every grid sized for 256 CUs then takes a second round).
+        # What the MLP graph does instead (CAPTRA_PIPE_DYNAMIC, default on): its SA kernels hand their centres out through a
+        # counter (captra_sa_set_dynamic), so a workgroup that becomes resident late finds the work done; `reserve` then
+        # defaults to 0.
+        B, _, N = x.shape
+        self.dynamic = os.environ.get("CAPTRA_PIPE_DYNAMIC", "1") != "0"
+        self.reserve = int(os.environ.get("CAPTRA_PIPE_RESERVE", str(reserve if reserve is not None else (0 if self.dynamic else B))))
+        self._dyn_pool = torch.zeros(depth, 64, dtype=torch.int32, device=dev)
+        self.geom_stream = torch.cuda.Stream(device=dev)
+        self.mlp_stream = torch.cuda.Stream(device=dev)
+        self.x = [x.clone() for _ in range(depth)]
+        self.x_n3 = [torch.empty(B, N, 3, dtype=x.dtype, device=dev) for _ in range(depth)]
+        cur = torch.cuda.current_stream(dev)
+        self.mlp_stream.wait_stream(cur)
+        with torch.cuda.stream(self.mlp_stream), torch.no_grad():
+            for _ in range(warmup):                    # folds weights, sets kernel attributes, warms the allocator
+                self._geometry(0)
+                net(self.x[0], input_n3=self.x_n3[0], geom=self._geometry(0))
+        cur.wait_stream(self.mlp_stream)
+        torch.cuda.synchronize(dev)
+        if self._geometry(0) is None:
+            raise ValueError("BackbonePipe: the fused samplers do not cover this cloud size")
+        from .fold import collect_folded, weights_version
+        self.weights = collect_folded(net)             # the captured kernels read the folded weights through raw pointers
+        self.weights_version = weights_version()
+        self.g_geom, self.g_mlp, self.geom, self.out = [], [], [], []
+        import ctypes
+        from . import _lib
+        cap = torch.cuda.Stream(device=dev)
+        for s in range(depth):
+            gg, gm = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gg, stream=cap, capture_error_mode="thread_local"), torch.no_grad():
+                geom = self._geometry(s)
+            _lib.lib().captra_set_reserved_cus(ctypes.c_int(self.reserve))
+            if self.dynamic:
+                _lib.lib().captra_sa_set_dynamic(ctypes.c_void_p(self._dyn_pool[s].data_ptr()), ctypes.c_int(64))
+            try:
+                with torch.cuda.graph(gm, stream=cap, capture_error_mode="thread_local"), torch.no_grad():
+                    out = net(self.x[s], input_n3=self.x_n3[s], geom=geom)
+            finally:
+                _lib.lib().captra_set_reserved_cus(ctypes.c_int(0))
+                _lib.lib().captra_sa_set_dynamic(ctypes.c_void_p(0), ctypes.c_int(0))
+            self.g_geom.append(gg); self.g_mlp.append(gm); self.geom.append(geom); self.out.append(out)
+        self.geom_ready = [torch.cuda.Event() for _ in range(depth)]
+        self.mlp_done = [None] * depth
+        self.consumed = [None] * depth                 # recorded on the consumer's stream at the next push after `output(slot)`
+        self._pending = []                             # (slot, stream) handed out since the last push
+
+    def _geometry(self, s: int):
+        x = self.x[s]
+        xyz = x[:, :3] if x.shape[1] > 3 else x
+        self.x_n3[s].copy_(xyz.transpose(1, 2))
+        return self.net.precompute_geometry(self.x_n3[s])
+
+    def push(self, x: torch.Tensor | None = None) -> int:
+        """Enqueue one batch (x (B,C,N) as captured; None: the slot's resident input again).  Returns the slot."""
+        for slot, st in self._pending:                 # whoever took a slot's output has enqueued its reads by now
+            ev = self.consumed[slot] or torch.cuda.Event()
+            ev.record(st)
+            self.consumed[slot] = ev
+        self._pending = []
+        s = self.t % self.depth
+        self.t += 1
+        gs, ms = self.geom_stream, self.mlp_stream
+        if self.mlp_done[s] is not None:               # the slot's previous batch still reads its input / geometry
+            gs.wait_event(self.mlp_done[s])
+        if self.consumed[s] is not None:               # ... and its consumer the output (geometry first: the MLP graph follows it)
+            gs.wait_event(self.consumed[s])
+        if x is not None:
+            gs.wait_stream(torch.cuda.current_stream(x.device))
+        with torch.cuda.stream(gs):
+            if x is not None:
+                self.x[s].copy_(x)
+            self.g_geom[s].replay()
+            self.geom_ready[s].record(gs)
+        ms.wait_event(self.geom_ready[s])
+        with torch.cuda.stream(ms):
+            self.g_mlp[s].replay()
+            ev = self.mlp_done[s] or torch.cuda.Event()
+            ev.record(ms)
+            self.mlp_done[s] = ev
+        return s
+
+    def output(self, slot: int) -> torch.Tensor:
+        """The slot's output (B,out_dim,N), valid on the current stream; overwritten `depth` pushes later."""
+        cur = torch.cuda.current_stream(self.out[slot].device)
+        if self.mlp_done[slot] is not None:
+            cur.wait_event(self.mlp_done[slot])
+        self._pending.append((slot, cur))
+        return self.out[slot]
+
+    def drain(self) -> None:
+        """The caller's stream waits for everything pushed so far."""
+        cur = torch.cuda.current_stream(self.x[0].device)
+        cur.wait_stream(self.geom_stream)
+        cur.wait_stream(self.mlp_stream)

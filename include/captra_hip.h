@@ -457,6 +457,15 @@ int captra_procrustes_rot3(int nb, int n, const float *src, const float *tgt, fl
  * ---------------------------------------------------------------------------------------- */
 const char *captra_error_string(int err);
 const char *captra_version(void);
+/* Host-side helper of the pipelined schedules (captra_amd/graph.py): the calling thread's launches of PERSISTENT kernels (grid =
+ * CU slots, static work split: the fp32 SA scales, the fused bf16 head pair) are sized for n CUs fewer, so that all of their
+ * workgroups are resident while another stream's one-workgroup-per-cloud samplers hold n CUs.  Thread-local; 0 = whole device. */
+void captra_set_reserved_cus(int n);
+/* Dynamic centre hand-out of the persistent SA kernels: pool = a caller-owned DEVICE buffer of nslots ints; every launch of the
+ * calling thread takes the next slot (round robin), zeroes it on its stream and hands its centres out through it instead of the
+ * static walk -- workgroups that become resident late (another stream's samplers hold their CUs) then find the work done instead
+ * of doubling the launch's time.  Same bits.  (NULL, 0) = static (default).  Thread-local. */
+void captra_sa_set_dynamic(int *pool, int nslots);
 /* Per-kernel HIP-event timing: when enabled every launcher brackets its kernel with events on
  * its own stream.  captra_prof_read synchronises the recorded events and returns accumulated
  * milliseconds / launch count for `name` (the kernel family, e.g. "ball_query"). */
@@ -481,6 +490,10 @@ void captra_pw_set_direct(int on);          /* dense layers: 1 = direct-operand 
 void captra_ball_query_set_prune(int on);   /* ball query: 1 = small radii of 1024..4096-point clouds from a cell grid (exact; measured slower, off by default), 0 = index-order scan */
 void captra_pw_set_occupancy(int occ);      /* dense layers, 64x64 wave tiles: workgroups per CU, 0 / 4 = as built (default), 3 / 2 = fewer (measurements) */
 void captra_pw_set_pair(int on);            /* dense layers: 1 = paired column tiles where L is even (default), 0 = never */
+void captra_sa_bf16_set_variant(int v);     /* bf16 SA scales: bit 0 = small-input scales without gather prefetch / fragment ring, bits 1-2 = ring depth
+                                               4 / 2 / 3 / 6, bits 4.. = ablations (coalesced gather, eight fragments only, no stores: WRONG results, timing only) */
+void captra_group_set_shape(int lds_kb, int ccmax, int ppb); /* group_points: staging budget (KiB, <= 64), channels per workgroup, positions per
+                                               workgroup (0 = default); tools/bench_group.py --sweep */
 
 #ifdef __cplusplus
 }

@@ -228,6 +228,49 @@ def test_pointwise_mlp_two_sources_equals_concat_bit_for_bit(device, c1, c2, cou
     np.testing.assert_array_equal(got.cpu().numpy(), O.pointwise_mlp(cat, w, b, 1))
 
 
+@pytest.mark.parametrize("cfeat,chans,n,m,k,B", [(0, (64, 96, 128), 4096, 512, 128, 9), (3, (64, 64, 128), 4096, 512, 64, 5),
+                                                  (320, (128, 196, 256), 512, 128, 128, 33), (320, (128, 128, 256), 512, 128, 64, 17),
+                                                  (0, (64, 96, 128), 700, 41, 128, 1)])
+def test_sa_scale_dynamic_centre_hand_out_bit_exact(device, cfeat, chans, n, m, k, B):
+    """captra_sa_set_dynamic: the persistent SA kernels take their centres from a zeroed counter instead of the static walk
+    (a workgroup that becomes resident late finds the work done).  Which wave computes a centre changes nothing: the launch
+    with the counter, the static launch and (through the other tests) the oracle agree bit for bit; every launch takes a
+    fresh slot of the caller's pool and leaves the number of hand-outs in it (>= the centres)."""
+    import ctypes
+    from captra_amd import _lib, fused
+    rng = np.random.default_rng(cfeat + sum(chans) + k + B)
+    xyz_cn = _dev(rng.random((B, 3, n), dtype=np.float32) - 0.5, device)
+    feat = _dev(rng.standard_normal((B, cfeat, n)).astype(np.float32), device) if cfeat else None
+    new_xyz = _dev(rng.random((B, m, 3), dtype=np.float32) - 0.5, device)
+    idx = _dev(rng.integers(0, n, (B, m, k)).astype(np.int32), device)
+    dims = (cfeat + 3,) + chans
+    packed = [fused.pack(_dev((rng.standard_normal((dims[i], dims[i + 1])) / np.sqrt(dims[i])).astype(np.float32), device),
+                         _dev(rng.standard_normal(dims[i + 1]).astype(np.float32), device)) for i in range(3)]
+
+    def run():
+        out = torch.full((B, chans[2] + 9, m), -1.0, device=device)
+        if cfeat == 320:
+            v1pm = fused.sa_first_layer_pre_pm(feat, packed[0])
+            fused.sa_scale_pre_pm(v1pm, xyz_cn, new_xyz, idx, packed, out, 4, cfeat)
+        else:
+            fused.sa_scale_fused(feat, xyz_cn, new_xyz, idx, packed, out, 4)
+        return out
+
+    _lib.lib().captra_sa_fused_set_split(ctypes.c_int(0))            # (never the slice-per-wave form: it has no centre walk)
+    pool = torch.full((4,), 12345, dtype=torch.int32, device=device)
+    try:
+        want = run()
+        _lib.lib().captra_sa_set_dynamic(ctypes.c_void_p(pool.data_ptr()), ctypes.c_int(4))
+        got = [run() for _ in range(3)]
+    finally:
+        _lib.lib().captra_sa_set_dynamic(ctypes.c_void_p(0), ctypes.c_int(0))
+        _lib.lib().captra_sa_fused_set_split(ctypes.c_int(1))
+    for g in got:
+        assert torch.equal(g, want)
+    counts = pool.cpu().tolist()
+    assert counts[3] == 12345 and all(c >= B * m for c in counts[:3]), counts
+
+
 @pytest.mark.parametrize("cfeat,chans,n,m,k,B", [(0, (64, 96, 128), 4096, 512, 128, 1), (3, (64, 64, 128), 4096, 512, 64, 1),
                                                   (3, (64, 96, 128), 700, 41, 128, 3), (320, (128, 196, 256), 512, 128, 128, 1),
                                                   (320, (128, 128, 256), 512, 128, 64, 1), (320, (128, 196, 256), 200, 6, 64, 3)])

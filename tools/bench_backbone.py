@@ -43,6 +43,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-pipe", action="store_true", help="one graph per step (geometry, then MLPs) instead of captra_amd.graph.BackbonePipe "
+                    "(batch t + 1's samplers / ball queries beside batch t's MLPs)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--xyz-feat", action="store_true", help="CoordNet's backbone (xyz as input features) instead of RotationNet's")
     args = ap.parse_args()
@@ -80,7 +82,7 @@ def main():
             for _ in range(3):
                 out = net(x)
         torch.cuda.synchronize()
-        graph = None
+        graph = pipe = None
         if not args.no_graph:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -90,13 +92,33 @@ def main():
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph), torch.no_grad():
                 out = net(x)
+            if not args.no_pipe:
+                from captra_amd.graph import BackbonePipe
+                pipe = BackbonePipe(net, x)
+                graph.replay()
+                ref = out.clone()
+                for _ in range(3):
+                    slot = pipe.push()
+                assert torch.equal(pipe.output(slot), ref), "pipelined backbone differs from the one-graph step"
 
         def step():
-            if graph is not None:
+            if pipe is not None:
+                pipe.push()
+            elif graph is not None:
                 graph.replay()
             else:
                 with torch.no_grad():
                     net(x)
+
+        def timed(fn):
+            for _ in range(args.warmup):
+                fn()
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                fn()
+            sync()
+            return time.perf_counter() - t0
 
         def sync():
             torch.cuda.synchronize()
@@ -104,14 +126,10 @@ def main():
                 dist.barrier()
             torch.cuda.synchronize()
 
-        for _ in range(args.warmup):
-            step()
-        sync()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        sync()
-        elapsed = time.perf_counter() - t0
+        elapsed = timed(step)
+        one_graph_ms = 1e3 * timed(graph.replay) / args.steps if pipe is not None else None
+        if pipe is not None:
+            out = pipe.output((pipe.t - 1) % pipe.depth)
         if dist is not None:
             t = torch.tensor([elapsed], dtype=torch.float64, device=device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -142,8 +160,13 @@ def main():
             "scaling": "weak", "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"S-uni16k, {N} pts/cloud, {B} clouds per GPU, sa1.npoint={s1}, sa2.npoint={s2}, "
                                    f"{'CoordNet' if args.xyz_feat else 'RotationNet'} backbone (BASELINE.json configs[4])",
-                       "launch": "hipGraph replay" if graph is not None else "eager", "parallelism": f"{world} replicas, no collective"},
+                       "launch": ("two-stage pipeline of hipGraphs (BackbonePipe: geometry of batch t + 1 beside the MLPs of batch t)" if pipe is not None
+                                  else "hipGraph replay" if graph is not None else "eager"),
+                       "parallelism": f"{world} replicas, no collective"},
         }
+        if one_graph_ms is not None:
+            line["one_graph"] = {"ms_per_step": round(one_graph_ms, 3), "clouds/s": round(B * world / (one_graph_ms * 1e-3), 1),
+                                 "note": "the same forward as ONE graph per batch (a batch's latency; samplers, then MLPs)"}
         if fams:
             mlp = [k for k in ("sa_scale_fused", "pointwise_mlp", "mlp_chain3", "coord_tail", "sa_group_mlp", "mlp_max") if k in fams]
             flops = sum(fused.WORK["flops"].get(k, 0.0) for k in mlp) / args.steps
