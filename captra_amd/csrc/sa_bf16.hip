@@ -27,6 +27,8 @@
 //    2^-17 relative), so its accumulators start from the inline constant 0.
 #include "common.h"
 
+unsigned long long *captra_sa_prof_ptr();   // sa_fused.hip: the debug counters set by captra_sa_fused_set_prof
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -160,6 +162,7 @@ struct SbParams {
     float *out;             // (B,out_ctotal,M)
     int out_ctotal, co_off;
     int jobs_per_cloud, njobs;
+    unsigned long long *prof;   // sa2_bf16_kernel: phase timers of a sample of waves (captra_sa_fused_set_prof), or null
 };
 
 // output tile (rows 32t.., this wave's 32 columns) -> next layer's B operands hout[2t], hout[2t+1]: ReLU + round + pack
@@ -466,7 +469,231 @@ __global__ __launch_bounds__(256, OCC) void sa_bf16_kernel(SbParams p) {
     }
 }
 
-CAPTRA_KNOB int g_sb_variant = 0;      // A/B: bit 0 = small-input scales as before (no gather prefetch, no fragment ring); bits 1-2: ring depth 4 / 2 / 3 / 6; bits 4..: ablations
+// ---- SA2 scales, second form: the epilogues UNDER the MFMAs ------------------------------------------------------------
+// sa_bf16_kernel<320, ...> runs one wave per SIMD (its 4 x 128 positions of activations fill the register file), so nothing but
+// the wave's own instruction stream can cover anything -- and that stream, as the compiler schedules it, is blocks of MFMAs
+// (a weight fragment, four MFMAs, ...) followed by blocks of 110-130 accumulator reads / conversions / maxima: per pass 656
+// MFMAs (21 k cycles) and ~2450 single-issue instructions nothing overlaps (~10 k cycles); ablations (captra_sa_bf16_set_variant,
+// bits 4..: coalesced gather, eight fragments only, no stores) move the launch by 1-6 %: it is the stream, not the memory.
+// Here every accumulator group exists TWICE: while row-tile group g + 1 accumulates, group g is read out -- one unit of four
+// instructions (two accumulator reads, a conversion or a max3, a ReLU) behind each MFMA, the order pinned with
+// sched_barrier(0) (an in-order wave hides at most ~5 single-issue instructions under a 32-cycle MFMA, MI355X_MICROARCH.md).
+// Layer 2's last read-out runs under layer 3's first group, whose early k-steps do not need it.  The neighbour ids are
+// requested before the biases are staged (one latency instead of two in front of the first MFMA).  Same MFMA sequence per
+// position, same conversions: bit-identical to sa_bf16_kernel (tests/test_model_gpu.py).  Measured (v1 launch included): 123.2 ->
+// 112.4 us (K = 128, 196 wide), 64.7 -> 58.2 us (K = 64) at 32 clouds; 67.2 -> 61.7 and 38.3 -> 35.3 at 16.  Less than the
+// instruction count promised: the slots between MFMAs are not free on this part (MI355X_MICROARCH.md: a filler between two
+// MFMAs costs 6 ... 20 cycles depending on where it lands), and a quarter of a wave's life is still the v1 gather in front of
+// layer 1 (64 16-byte loads per lane, 32 cache lines each).
+template <int C2, int K, int CG, int ILV = 1, bool PROF = false>
+__global__ __launch_bounds__(256, 1) void sa2_bf16_kernel(SbParams p) {
+    using S = SbShape<320, 128, C2, 256, true>;
+    constexpr int C1 = 128, C3 = 256, TN = 4;
+    constexpr int TPC = K / 32, CPP = TN / TPC;        // tiles per centre, centres per pass (K = 128: 1, K = 64: 2)
+    static_assert(CG * TPC == TN && (K == 64 || K == 128), "one pass of four tiles per job");
+    constexpr int RD = 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *bias_lds = reinterpret_cast<float *>(smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, col = lane & 31;
+    int job = blockIdx.x * 4 + wave;
+    const bool live = job < p.njobs;
+    job = live ? job : p.njobs - 1;                    // (a spare wave computes the last job again and stores nothing)
+    // (PROF: phase timers of a sample of waves -- an instantiation of its own: the disabled timers alone cost the kernel a third)
+    const bool sampled = PROF && blockIdx.x % 16 == 0 && lane == 0;
+    const unsigned long long t_first = PROF ? __builtin_amdgcn_s_memtime() : 0ull, r_first = PROF ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    unsigned long long t_last = t_first;
+#define SB2_TICK(slot)                                                                     \
+    if constexpr (PROF) {                                                                  \
+        const unsigned long long t_now = __builtin_amdgcn_s_memtime();                     \
+        if (sampled) atomicAdd(p.prof + (slot), t_now - t_last);                           \
+        t_last = t_now;                                                                    \
+    }
+    const int b = job / p.jobs_per_cloud;
+    const int centre0 = (job % p.jobs_per_cloud) * CG;
+    const size_t cloud_idx = (size_t)b * p.m * K;
+    const float *xb = p.xyz_cn + (size_t)b * 3 * p.n;
+    // ---- neighbour ids and centres first, the biases behind them --------------------------------------------------------------
+    int ids[TN];
+    float ctr[TN][3];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        int c = centre0 + j / TPC;
+        c = c < p.m ? c : p.m - 1;
+        ids[j] = p.idx[cloud_idx + (size_t)c * K + (j % TPC) * 32 + col];
+        const float *cp = p.new_xyz + ((size_t)b * p.m + c) * 3;
+        ctr[j][0] = cp[0]; ctr[j][1] = cp[1]; ctr[j][2] = cp[2];
+    }
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(p.img + S::WBYTES);
+        uint4 *dst = reinterpret_cast<uint4 *>(smem);
+        constexpr int N16 = S::NBIAS * 4 / 16;
+        for (int e = tid; e < N16; e += 256) dst[e] = src[e];
+    }
+    const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc((void *)p.img, 0, S::WBYTES, 0x00020000);
+    constexpr SbUseOrder<S, 1> ORDER{};
+    u32x4 ring[RD];
+    auto wload = [&](int f) -> u32x4 { return __builtin_amdgcn_raw_buffer_load_b128(wsrc, lane * 16, f * 1024, 0); };
+    int use = 0;
+    auto wfrag = [&]() -> u32x4 {                       // the fragments in ORDER (k-step major inside a row tile), RD - 1 uses ahead
+        const u32x4 w = ring[use % RD];
+        if (use + RD - 1 < S::NFRAG) ring[(use + RD - 1) % RD] = wload(ORDER.f[use + RD - 1]);
+        ++use;
+        return w;
+    };
+#pragma unroll
+    for (int i = 0; i < RD - 1; ++i) ring[i] = wload(ORDER.f[i]);
+    u32x4 x1[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int id = ids[j];
+        const float r0 = xb[id] - ctr[j][0], r1 = xb[(size_t)p.n + id] - ctr[j][1], r2 = xb[(size_t)2 * p.n + id] - ctr[j][2];
+        x1[j][0] = h ? 0u : sb_pack(r0, r1);
+        x1[j][1] = h ? 0u : sb_pack(r2, 0.f);
+        x1[j][2] = 0u;
+        x1[j][3] = 0u;
+    }
+    __syncthreads();
+    SB2_TICK(0)
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    u32x4 h1[TN][S::KST2], h2[TN][S::KST3];
+    // ---- layer 1: accumulators start from the gathered v1 rows, one k-step (the relative coordinates) ------------------------
+#pragma unroll
+    for (int t = 0; t < S::NT1; ++t) {
+        const u32x4 w = wfrag();
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            f32x16 acc;
+            const float *vp = p.v1pm + ((size_t)b * p.n + ids[j]) * C1 + 32 * t + 4 * h;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = *reinterpret_cast<const float4 *>(vp + 8 * q);
+                acc[4 * q + 0] = v.x; acc[4 * q + 1] = v.y; acc[4 * q + 2] = v.z; acc[4 * q + 3] = v.w;
+            }
+            acc = sb_mfma(w, x1[j], acc);
+            sb_mid_epilogue<S::KST2>(acc, t, h1[j]);
+        }
+    }
+    SB2_TICK(1)
+    // ---- layers 2 and 3, two accumulator groups in flight -------------------------------------------------------------------------
+    f32x16 acc[2][TN];
+    float z[S::NT3][CPP];
+#pragma unroll
+    for (int t = 0; t < S::NT3; ++t)
+#pragma unroll
+        for (int c = 0; c < CPP; ++c) z[t][c] = -__builtin_inff();
+    auto bias2 = [&](int tg) -> f32x16 {
+        f32x16 bv;
+        const float4 *bp = reinterpret_cast<const float4 *>(bias_lds + S::B2OFF + 32 * tg + 4 * h);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 v = bp[2 * q];
+            bv[4 * q + 0] = v.x; bv[4 * q + 1] = v.y; bv[4 * q + 2] = v.z; bv[4 * q + 3] = v.w;
+        }
+        return bv;
+    };
+    // read-out element i (0..3) of unit u = (tile u >> 1, half u & 1) of layer-2 group tg: two accumulator registers -> one packed pair
+    auto epi2 = [&](int tg, int u, int i, const f32x16 (&a)[TN]) {
+        const int j = u >> 1, jj = u & 1;
+        if (2 * tg + jj < S::KST3) h2[j][2 * tg + jj][i] = sb_relu2(sb_pack(a[j][8 * jj + 2 * i], a[j][8 * jj + 2 * i + 1]));
+    };
+    // the same of layer-3 group tg: two registers of tile j into the running maximum of its centre
+    auto epi3 = [&](int tg, int u, int i, const f32x16 (&a)[TN]) {
+        const int j = u >> 1, hf = u & 1, c = CPP > 1 ? j / (TN / CPP) : 0;
+        z[tg][c] = sb_max3<true>(z[tg][c], a[j][8 * hf + 2 * i], a[j][8 * hf + 2 * i + 1]);
+    };
+#pragma unroll
+    for (int tg = 0; tg < S::NT2; ++tg) {
+        const f32x16 bv = bias2(tg);
+#pragma unroll
+        for (int kk = 0; kk < S::KST2; ++kk) {
+            const u32x4 w = wfrag();
+#pragma unroll
+            for (int j0 = 0; j0 < TN; j0 += ILV) {      // ILV MFMAs, then their ILV read-out units (ILV 1 / 2 / 4: 112.4 / 113.6 / 118.2 us at 32 clouds)
+#pragma unroll
+                for (int j = j0; j < j0 + ILV; ++j) acc[tg & 1][j] = sb_mfma(w, h1[j][kk], kk == 0 ? bv : acc[tg & 1][j]);
+#pragma unroll
+                for (int j = j0; j < j0 + ILV; ++j)
+                    if (tg > 0 && kk < 8) epi2(tg - 1, kk, j, acc[(tg - 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    SB2_TICK(2)
+    constexpr int P3 = S::NT2 & 1;                      // layer-3 group tg accumulates in acc[(tg + P3) & 1]: group 0 beside layer 2's last
+    // layer 2's last group is read out under layer 3's first one -- when the k-steps it produces (2 NT2 - 2, 2 NT2 - 1) come after
+    // the eight k-steps the read-out takes; otherwise (C2 = 128: k-steps 6, 7) before it
+    constexpr bool DEFER_LAST = 2 * (S::NT2 - 1) >= 8;
+    if constexpr (!DEFER_LAST) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) epi2(S::NT2 - 1, u, i, acc[(S::NT2 - 1) & 1]);
+    }
+#pragma unroll
+    for (int tg = 0; tg < S::NT3; ++tg) {
+#pragma unroll
+        for (int kk = 0; kk < S::KST3; ++kk) {
+            const u32x4 w = wfrag();
+#pragma unroll
+            for (int j0 = 0; j0 < TN; j0 += ILV) {
+#pragma unroll
+                for (int j = j0; j < j0 + ILV; ++j) acc[(tg + P3) & 1][j] = sb_mfma(h2[j][kk], w, kk == 0 ? zero16 : acc[(tg + P3) & 1][j]);
+#pragma unroll
+                for (int j = j0; j < j0 + ILV; ++j)
+                    if (kk < 8) {
+                        if (tg == 0) { if constexpr (DEFER_LAST) epi2(S::NT2 - 1, kk, j, acc[(S::NT2 - 1) & 1]); }
+                        else epi3(tg - 1, kk, j, acc[(tg - 1 + P3) & 1]);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) epi3(S::NT3 - 1, u, i, acc[(S::NT3 - 1 + P3) & 1]);
+    SB2_TICK(3)
+    // ---- the centres' maxima: join the half-waves, bias, ReLU, store -------------------------------------------------------------
+#pragma unroll
+    for (int c = 0; c < CPP; ++c)
+#pragma unroll
+        for (int t = 0; t < S::NT3; ++t) {
+            const unsigned u = __float_as_uint(z[t][c]);
+            const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+            float v = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1])) + bias_lds[S::B3OFF + 32 * t + col];
+            v = v > 0.f ? v : 0.f;
+            const int ch = 32 * t + col;
+            if (live && h == 0 && ch < C3 && centre0 + c < p.m)
+                p.out[((size_t)b * p.out_ctotal + p.co_off + ch) * p.m + centre0 + c] = v;
+        }
+    SB2_TICK(4)
+    if (PROF && sampled) {
+        atomicAdd(p.prof + 9, 1ull);
+        atomicAdd(p.prof + 5, t_last - t_first);
+        atomicAdd(p.prof + 6, __builtin_amdgcn_s_memrealtime() - r_first);
+    }
+#undef SB2_TICK
+}
+
+template <int C2, int K, int CG, int ILV = 1>
+int sb2_launch(int b, SbParams p, hipStream_t stream) {
+    if (p.prof != nullptr && ILV == 1) {
+        using S = SbShape<320, 128, C2, 256, true>;
+        p.jobs_per_cloud = (p.m + CG - 1) / CG;
+        p.njobs = b * p.jobs_per_cloud;
+        CAPTRA_LAUNCH("sa_scale_fused", (sa2_bf16_kernel<C2, K, CG, 1, true>), dim3((p.njobs + 3) / 4), dim3(256), S::NBIAS * 4, stream, p);
+        return captra_last_error();
+    }
+    using S = SbShape<320, 128, C2, 256, true>;
+    p.jobs_per_cloud = (p.m + CG - 1) / CG;
+    p.njobs = b * p.jobs_per_cloud;
+    CAPTRA_LAUNCH("sa_scale_fused", (sa2_bf16_kernel<C2, K, CG, ILV>), dim3((p.njobs + 3) / 4), dim3(256), S::NBIAS * 4, stream, p);
+    return captra_last_error();
+}
+
+CAPTRA_KNOB int g_sb_variant = 0;      // A/B: bit 0 = small-input scales as before (no gather prefetch, no fragment ring); bits 1-2: ring depth 4 / 2 / 3 / 6; bit 3 = SA2 scales as before (sa_bf16_kernel); bits 4..: ablations
 
 template <int CF, int C1, int C2, int C3, int K, bool PRE, int TN, int CG, bool WLDS, int OCC = (WLDS ? 2 : 1), int RGS = 0, bool PF = false, int DBG = 0, int LRD = 1>
 int sb_launch(int b, SbParams p, hipStream_t stream) {
@@ -523,6 +750,7 @@ extern "C" int captra_sa_scale_bf16(int b, int n, int m, int k, int cfeat, int c
     p.n = n; p.m = m; p.feat = pre ? nullptr : feat_or_v1; p.v1pm = pre ? feat_or_v1 : nullptr;
     p.xyz_cn = xyz_cn; p.new_xyz = new_xyz; p.idx = idx; p.img = img; p.out = out; p.out_ctotal = out_ctotal; p.co_off = co_off;
     p.jobs_per_cloud = p.njobs = 0;
+    p.prof = captra_sa_prof_ptr();
     hipStream_t s = (hipStream_t)stream;
 #define SB_MATCH(CF_, C1_, C2_, C3_, K_, PRE_) (cfeat == CF_ && c1 == C1_ && c2 == C2_ && c3 == C3_ && k == K_ && (pre != 0) == PRE_)
     // PF_: the gather prefetch pays from 64 neighbours on (sa1s3 82 -> 79 us at 32 clouds, 54 -> 50 at 16; sa1s2 26 -> 23 at 16); the
@@ -551,7 +779,10 @@ extern "C" int captra_sa_scale_bf16(int b, int n, int m, int k, int cfeat, int c
     SB_CASE1(3, 32, 32, 64, 32, false) SB_CASE1(3, 64, 64, 128, 64, true) SB_CASE1(3, 64, 96, 128, 128, true)
     // (two tiles per wave on two waves per SIMD was measured for the SA2 scales: 63 -> 59 us for K = 64, and the 196-wide scale
     // does not fit 256 registers -- 500 bytes of scratch, 122 -> 155 us)
-    if (SB_MATCH(320, 128, 128, 256, 64, true)) return sb_launch<320, 128, 128, 256, 64, true, 4, 2, false>(b, p, s);
+    if (SB_MATCH(320, 128, 128, 256, 64, true)) {
+        if (!(g_sb_variant & 8)) return sb2_launch<128, 64, 2>(b, p, s);
+        return sb_launch<320, 128, 128, 256, 64, true, 4, 2, false>(b, p, s);
+    }
     if (SB_MATCH(320, 128, 196, 256, 128, true)) {
         switch (g_sb_variant >> 4) {      // ablations (results wrong by construction): 1 coalesced gather, 2 eight fragments only, 4 no stores
         case 1: return sb_launch<320, 128, 196, 256, 128, true, 4, 1, false, 1, 0, false, 1>(b, p, s);
@@ -561,6 +792,7 @@ extern "C" int captra_sa_scale_bf16(int b, int n, int m, int k, int cfeat, int c
         case 7: return sb_launch<320, 128, 196, 256, 128, true, 4, 1, false, 1, 0, false, 7>(b, p, s);
         default: break;
         }
+        if (!(g_sb_variant & 8)) return sb2_launch<196, 128, 1>(b, p, s);
         return sb_launch<320, 128, 196, 256, 128, true, 4, 1, false>(b, p, s);
     }
 #undef SB_CASE1

@@ -1078,8 +1078,9 @@ def test_bf16_sa_scale(device, cfeat, chans, n, m, k):
                                                   (0, (64, 96, 128), 1000, 9, 128, 1), (320, (128, 196, 256), 512, 128, 128, 2),
                                                   (320, (128, 128, 256), 200, 5, 64, 3), (320, (128, 128, 256), 512, 128, 64, 2)])
 def test_bf16_sa_scale_forms_bit_identical(device, cfeat, chans, n, m, k, b):
-    """The launch forms of captra_sa_scale_bf16 (gather of the next pass prefetched or not) run the same MFMA sequence per
-    position: identical bits."""
+    """The launch forms of captra_sa_scale_bf16 (small-input scales: gather of the next pass prefetched or not, weight fragments
+    through a ring or not; SA2 scales: sa_bf16_kernel or the two-accumulator-group kernel with the read-outs under the MFMAs) run
+    the same MFMA sequence per position: identical bits."""
     import ctypes
     from captra_amd import _lib, fused
     rng = np.random.default_rng(7 * cfeat + sum(chans) + k + m)
@@ -1093,7 +1094,7 @@ def test_bf16_sa_scale_forms_bit_identical(device, cfeat, chans, n, m, k, b):
     outs = {}
     fused.set_mlp_dtype("bf16")
     try:
-        for variant in (1, 0):
+        for variant in (9, 0):
             _lib.lib().captra_sa_bf16_set_variant(ctypes.c_int(variant))
             out = torch.full((b, chans[2], m), -7.0, device=device)
             fused.sa_scale_bf16(feat, xyz_cn, new_xyz, idx, packed, out, 0)
@@ -1101,7 +1102,7 @@ def test_bf16_sa_scale_forms_bit_identical(device, cfeat, chans, n, m, k, b):
     finally:
         _lib.lib().captra_sa_bf16_set_variant(ctypes.c_int(0))
         fused.set_mlp_dtype("fp32")
-    assert torch.equal(outs[1], outs[0])
+    assert torch.equal(outs[9], outs[0])
 
 
 _SLOT_PERM = np.array([0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15])

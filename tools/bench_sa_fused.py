@@ -95,7 +95,8 @@ def main():
             _lib.lib().captra_sa_fused_set_prof(ctypes.c_void_p(0))
             c = cnt.tolist()
             waves = max(c[9], 1)
-            labels = (["loop top", "L1", "L2", "L3", "store (per centre)"] if a.pipe else      # sa_wave_pipe_kernel: per tile
+            labels = (["ids + bias staging + barrier", "L1 (v1 gather)", "L2", "L3", "maxima + store"] if a.bf16 else      # sa2_bf16_kernel: per pass
+                      ["loop top", "L1", "L2", "L3", "store (per centre)"] if a.pipe else      # sa_wave_pipe_kernel: per tile
                       ["loop top", "L1", "L2 + next gather", "L3 + max", "store (per centre)"] if cfeat <= 3 else   # sa_wave_lds_kernel: per tile
                       ["start", "L1", "L2", "L3", "end-barrier"])                 # sa_wave_kernel's timers (streamed-weight scales)
             tot = sum(c[:len(labels)]) / waves
