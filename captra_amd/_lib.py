@@ -8,12 +8,13 @@ which is what the reference's glue does with `at::cuda::getCurrentCUDAStream()`
 from __future__ import annotations
 
 import ctypes as C
+import os
 from pathlib import Path
 
 import torch
 
 _PKG = Path(__file__).resolve().parent
-LIB_PATH = _PKG / "lib" / "libcaptra_hip.so"
+LIB_PATH = Path(os.environ["CAPTRA_LIB"]) if os.environ.get("CAPTRA_LIB") else _PKG / "lib" / "libcaptra_hip.so"   # (CAPTRA_LIB: same-box A/B of two builds)
 
 _lib = None
 

@@ -23,6 +23,15 @@ struct CaptraProfScope {
         hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);             \
     } while (0)
 
+// In-kernel phase timers of the SA kernels (captra_sa_fused_set_prof, tools/bench_sa_fused.py --phases) exist only in a build with
+// -DCAPTRA_SA_PROF=1 (CAPTRA_HIPCC_EXTRA): the runtime test `p.prof != nullptr` alone -- a branch at every phase boundary, which
+// the scheduler cannot move anything across -- costs the fp32 SA1 scales 2.7 %, the SA2 scales 1-2 % and cost the bf16 SA2 kernel
+// a third (same-box A/B of two builds, CAPTRA_LIB).
+#ifndef CAPTRA_SA_PROF
+#define CAPTRA_SA_PROF 0
+#endif
+#define CAPTRA_PROF_ON(ptr) (CAPTRA_SA_PROF != 0 && (ptr) != nullptr)
+
 // prof.cpp: CUs the calling thread's persistent launches leave free (captra_set_reserved_cus)
 int captra_reserved_cus();
 

@@ -679,7 +679,7 @@ __global__ __launch_bounds__(256, 1) void sa2_bf16_kernel(SbParams p) {
 
 template <int C2, int K, int CG, int ILV = 1>
 int sb2_launch(int b, SbParams p, hipStream_t stream) {
-    if (p.prof != nullptr && ILV == 1) {
+    if (CAPTRA_PROF_ON(p.prof) && ILV == 1) {
         using S = SbShape<320, 128, C2, 256, true>;
         p.jobs_per_cloud = (p.m + CG - 1) / CG;
         p.njobs = b * p.jobs_per_cloud;

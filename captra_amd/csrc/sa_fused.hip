@@ -333,7 +333,7 @@ struct SwParams {
 };
 
 #define SW_TICK(slot)                                                         \
-    if (p.prof != nullptr) {                                                  \
+    if (CAPTRA_PROF_ON(p.prof)) {                                                  \
         const unsigned long long t_now = __builtin_amdgcn_s_memtime();        \
         if (lane == 0 && sampled) atomicAdd(p.prof + (slot), t_now - t_last); \
         t_last = t_now;                                                       \
@@ -473,9 +473,9 @@ void sa_wave_kernel(SwParams p) {
     int id = 0;
     float ctr[3] = {0.f, 0.f, 0.f};
     const bool sampled = (blockIdx.x + blockIdx.y) % 61 == 0;
-    unsigned long long t_last = p.prof != nullptr ? __builtin_amdgcn_s_memtime() : 0ull;
+    unsigned long long t_last = CAPTRA_PROF_ON(p.prof) ? __builtin_amdgcn_s_memtime() : 0ull;
     const unsigned long long t_first = t_last;
-    const unsigned long long r_first = p.prof != nullptr ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    const unsigned long long r_first = CAPTRA_PROF_ON(p.prof) ? __builtin_amdgcn_s_memrealtime() : 0ull;
     if (active) {
         id = p.idx[(size_t)b * L + wpos + (lane & 31)];
         const float *cp = p.new_xyz + ((size_t)b * p.m + (int)(wpos / p.k)) * 3;
@@ -522,7 +522,7 @@ void sa_wave_kernel(SwParams p) {
     }
     __syncthreads();
     SW_TICK(4)
-    if (p.prof != nullptr && lane == 0 && sampled) {
+    if (CAPTRA_PROF_ON(p.prof) && lane == 0 && sampled) {
         atomicAdd(p.prof + 9, 1ull);
         atomicAdd(p.prof + 5, t_last - t_first);                                  // shader cycles of this wave's life
         atomicAdd(p.prof + 6, __builtin_amdgcn_s_memrealtime() - r_first);        // same span in 100 MHz ticks
@@ -711,7 +711,7 @@ __global__ __launch_bounds__(SL_WAVES * 64) __attribute__((amdgpu_waves_per_eu(4
     if (c < ncentres) gather_x1(c, id, ctr, x1);
     int zrun[S3::NT];
     const bool sampled = blockIdx.x % 16 == 0;            // phase timers (captra_sa_fused_set_prof): a sample of workgroups
-    unsigned long long t_last = p.prof != nullptr ? __builtin_amdgcn_s_memtime() : 0ull;
+    unsigned long long t_last = CAPTRA_PROF_ON(p.prof) ? __builtin_amdgcn_s_memtime() : 0ull;
     while (c < ncentres) {
         if (sl == 0 || split) {
 #pragma unroll
@@ -745,7 +745,7 @@ __global__ __launch_bounds__(SL_WAVES * 64) __attribute__((amdgpu_waves_per_eu(4
         SW_TICK(2)
         sl_layer<C2, C3, true>(wl3, bias3, h2, none, zrun, lane);
         SW_TICK(3)
-        if (p.prof != nullptr && lane == 0 && sampled) atomicAdd(p.prof + 9, 1ull);
+        if (CAPTRA_PROF_ON(p.prof) && lane == 0 && sampled) atomicAdd(p.prof + 9, 1ull);
         if (last_slice) {
             // the centre's maxima: lane l with (l & 16) == 0 holds row 32 t + 8 ((l & 15) >> 2) + (l & 3) + 4 (l >> 5) of tile t
             const int tb = c / p.m, centre = c - tb * p.m;

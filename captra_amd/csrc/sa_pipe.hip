@@ -44,7 +44,7 @@ struct SpParams {
 };
 
 #define SP_TICK(slot)                                                           \
-    if (p.prof != nullptr) {                                                    \
+    if (CAPTRA_PROF_ON(p.prof)) {                                                    \
         const unsigned long long t_now = __builtin_amdgcn_s_memtime();          \
         if (lane == 0 && sampled) atomicAdd(p.prof + (slot), t_now - t_last);   \
         t_last = t_now;                                                         \
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     };
 
     const bool sampled = blockIdx.x % 16 == 0;
-    unsigned long long t_last = p.prof != nullptr ? __builtin_amdgcn_s_memtime() : 0ull;
+    unsigned long long t_last = CAPTRA_PROF_ON(p.prof) ? __builtin_amdgcn_s_memtime() : 0ull;
     float s[3][16];
     constexpr int START3 = S2::STEPS % 3;                     // ring slot of layer 3's first set (layer 2 starts in slot 0)
     constexpr int NEXT2 = (START3 + S3::STEPS) % 3;            // slot in which layer 3 leaves the NEXT slice's first layer-2 set
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                                        [&](int g) { if (g == 2 && has_next) load_rest(cn, id_n, bt, g4); });
         id = id_n;
         SP_TICK(3)
-        if (p.prof != nullptr && lane == 0 && sampled) atomicAdd(p.prof + 9, 1ull);
+        if (CAPTRA_PROF_ON(p.prof) && lane == 0 && sampled) atomicAdd(p.prof + 9, 1ull);
         if (last_slice) {
             // the centre's maxima: lane l with (l & 16) == 0 holds row 32 t + 8 ((l & 15) >> 2) + (l & 3) + 4 (l >> 5) of tile t
             const int tb = c / p.m, centre = c - tb * p.m;

@@ -29,7 +29,7 @@ def main():
     ap.add_argument("--bf16", action="store_true", help="the bf16-native kernel (csrc/sa_bf16.hip); time includes the point-major v1 launch of the SA2 scales")
     ap.add_argument("--zeros", action="store_true", help="all-zero features / weights: same instruction stream at lower power (DVFS probe)")
     ap.add_argument("--mode", type=int, default=0, help="0 = register-resident kernels where instantiated, 1 = generic LDS kernel")
-    ap.add_argument("--phases", action="store_true", help="debug: in-kernel s_memtime phase breakdown of sa_wave_kernel")
+    ap.add_argument("--phases", action="store_true", help="debug: in-kernel s_memtime phase breakdown (needs a library built with CAPTRA_HIPCC_EXTRA=-DCAPTRA_SA_PROF=1)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     import ctypes
