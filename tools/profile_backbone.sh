@@ -7,7 +7,7 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
-CMD="python $ROOT/tools/bench_backbone.py --npoint 2048 512 --steps 5 --warmup 2 --no-kernel-timing"
+CMD="python $ROOT/tools/bench_backbone.py --npoint 2048 512 --steps 5 --warmup 2 --no-kernel-timing --no-pipe"
 CMD_EAGER="python $ROOT/tools/bench_backbone.py --npoint 2048 512 --steps 2 --warmup 1 --no-kernel-timing --no-graph"
 cd /tmp
 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_bb_trace -o bench -- $CMD > $OUT/${TAG}_bb_trace.log 2>&1
