@@ -1,4 +1,6 @@
-"""Stage times of BackbonePipe on configs[4]: geometry graph alone, MLP graph alone, both pipelined."""
+"""Stage times of captra_amd.graph.BackbonePipe on BASELINE.json configs[4] (8 clouds of 16384 points): the geometry graph alone, the MLP
+graph alone, both pipelined, and each stage's time INSIDE the pipeline (events around every replay on its own stream).
+    python tools/bench_pipe_stages.py [clouds]        CAPTRA_PIPE_DYNAMIC=0 / CAPTRA_PIPE_RESERVE=n: the A/B switches of DESIGN.md 3.4"""
 import copy, sys, time
 from pathlib import Path
 import numpy as np, torch
