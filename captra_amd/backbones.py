@@ -18,6 +18,18 @@ from .pointnet_utils import (PointNetFeaturePropagation, PointNetSetAbstraction,
                              _FoldCache)
 
 
+def _geom_tensors(geom):
+    for v in geom.values():
+        if torch.is_tensor(v):
+            yield v
+        elif isinstance(v, dict):
+            yield from _geom_tensors(v)
+        elif isinstance(v, (list, tuple)):
+            for t in v:
+                if torch.is_tensor(t):
+                    yield t
+
+
 class PointNet2Msg(_FoldCache, nn.Module):
     def __init__(self, cfg, out_dim, net_type="camera", use_xyz_feat=False):
         super().__init__()
@@ -80,6 +92,49 @@ class PointNet2Msg(_FoldCache, nn.Module):
         if level1_only:
             return geom
         return self.precompute_geometry_rest(geom, xyz_n3)
+
+    def precompute_geometry_streamed(self, xyz_n3, chunks: int, gstream, consumers=()):
+        """`precompute_geometry` with the first level's sampling STREAMED: the 4096 -> 512 sampler is `chunks` launches of
+        npoint / chunks picks each on `gstream` (captra_fps_gather_part: the same loop, cut), every part followed by the ball
+        query of its centres and an event; `geom["sa1"]["chunks"]` = [(first centre, count, event)] is what `sa1` walks --
+        a window's shared MLPs start when its picks and neighbour lists are there, while the sampler (one workgroup per cloud,
+        511 dependent rounds: a quarter of a frame with nothing else able to run) picks the next ones.  Level 2 and the
+        interpolation weights follow on `gstream`; `geom["_ready"]` is recorded behind them (forward waits for it before
+        `sa2`).  Returns at once; None when a shape is outside the streamed kernels (caller: `precompute_geometry`).
+        `gstream` must not be the current stream; `consumers`: the streams that will read the geometry (record_stream)."""
+        if self.training or not xyz_n3.is_cuda or self.sa1.knn or self.sa2.knn or chunks < 2:
+            return None
+        M = self.sa1.npoint
+        self.sa1._fold(xyz_n3.device)
+        if M % chunks or (M // chunks) % 8 or not self.sa1.window_ok(self.in_dim):
+            return None
+        xyz_n3 = xyz_n3.contiguous()
+        bufs = fused.fps_gather_parts(xyz_n3, M)
+        if bufs is None:
+            return None
+        B = xyz_n3.shape[0]
+        idx1 = [torch.empty(B, M, int(k), dtype=torch.int32, device=xyz_n3.device) for k in self.sa1.nsample_list]
+        main = torch.cuda.current_stream(xyz_n3.device)
+        gstream.wait_stream(main)
+        step = M // chunks
+        marks = []
+        with torch.cuda.stream(gstream):
+            for c in range(chunks):
+                fused.fps_gather_part(xyz_n3, M, c * step, (c + 1) * step, bufs)
+                with fused.centre_window(c * step, step):
+                    fused.ball_query_multi(self.sa1.radius_list, self.sa1.nsample_list, xyz_n3, bufs[1], outs=idx1)
+                ev = torch.cuda.Event()
+                ev.record(gstream)
+                marks.append((c * step, step, ev))
+            geom = {"sa1": {"new_xyz_n3": bufs[1], "new_xyz": bufs[2], "idx_list": idx1, "chunks": marks}}
+            geom = self.precompute_geometry_rest(geom, xyz_n3)
+            ready = torch.cuda.Event()
+            ready.record(gstream)
+            geom["_ready"] = ready
+        for t in _geom_tensors(geom):
+            for st in (main,) + tuple(consumers):
+                t.record_stream(st)
+        return geom
 
     def precompute_geometry_rest(self, geom, xyz_n3):
         """Level 2 and the interpolation weights, given level 1 (`precompute_geometry(..., level1_only=True)`)."""

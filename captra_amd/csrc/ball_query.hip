@@ -47,6 +47,7 @@ struct BqParams {
     float rad[BQ_MAXR];
     int ns[BQ_MAXR];
     int *idx[BQ_MAXR];
+    int m0, mhi;          // centres [m0, mhi) of every cloud (captra_set_centre_window; default 0, m)
 };
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(BQ_WAVES * 64) void ball_query_kernel(int n, int m,
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const float *xyz = xyz_all + (size_t)b * n * 3;
     const float *new_xyz = new_xyz_all + (size_t)b * m * 3;
-    const int c_base = (blockIdx.x * BQ_WAVES + wave) * CPW;
+    const int c_base = prm.m0 + (blockIdx.x * BQ_WAVES + wave) * CPW;
     int cnt[CPW][NR];
     int first[CPW][NR];
 #pragma unroll
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(BQ_WAVES * 64) void ball_query_kernel(int n, int m,
 #pragma unroll
         for (int ci = 0; ci < CPW; ++ci) {
             const int c = c_base + ci;
-            if (c >= m) continue;
+            if (c >= prm.mhi) continue;
             if (PRUNE && any_pruned) {
                 // ---- the grid's radii: candidates of the 27 cells, hits into bitmaps over original indices ----
                 const float cx = new_xyz[(size_t)c * 3 + 0];
@@ -377,7 +378,7 @@ __global__ __launch_bounds__(BQ_WAVES * 64) void ball_query_kernel(int n, int m,
 #pragma unroll
     for (int ci = 0; ci < CPW; ++ci) {
         const int c = c_base + ci;
-        if (c >= m) continue;
+        if (c >= prm.mhi) continue;
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             if (PRUNE && first[ci][r] < 0) continue;          // answered (and padded) from the grid
@@ -419,7 +420,11 @@ int launch_ball_query(int b, int n, int m, int nr, const float *radius, const in
     // workgroup costs less than the second walk.  The grid path (opt-in) keeps two.
     const bool one = !prune && g_bq_cpw != 2;
     const int cpw = one ? 1 : BQ_CPW;
-    dim3 grid((m + BQ_WAVES * cpw - 1) / (BQ_WAVES * cpw), b);
+    int wm0, wmc;
+    (void)captra_centre_window(m, &wm0, &wmc);
+    if (wmc == 0) return 0;
+    prm.m0 = wm0; prm.mhi = wm0 + wmc;
+    dim3 grid((wmc + BQ_WAVES * cpw - 1) / (BQ_WAVES * cpw), b);
     dim3 block(BQ_WAVES * 64);
 #define BQ_LAUNCH(NR)                                                                            \
     if (prune) {                                                                                 \

@@ -34,6 +34,8 @@ struct CaptraProfScope {
 
 // prof.cpp: CUs the calling thread's persistent launches leave free (captra_set_reserved_cus)
 int captra_reserved_cus();
+// prof.cpp: the calling thread's centre window (captra_set_centre_window); true when one is set
+bool captra_centre_window(int m, int *m0, int *mc);
 
 static inline int captra_last_error() { return (int)hipGetLastError(); }
 

@@ -181,7 +181,10 @@ template <int NWAVES, int PPT, bool XYZ_LDS>
 __global__ __launch_bounds__(NWAVES * 64) void fps_kernel_blocked(int n_stride, int m, const float *__restrict__ xyz_all,
                                                                   float *__restrict__ temp_all, int *__restrict__ idx_all,
                                                                   float *__restrict__ new_n3, float *__restrict__ new_cn,
-                                                                  const int *__restrict__ n_per_cloud, int defer) {
+                                                                  const int *__restrict__ n_per_cloud, int defer, int j0, int j1) {
+    // picks [j0, j1) of the m (captra_fps_gather_part): j0 > 0 continues a cloud's sampling -- the running minima come from `temp`
+    // (what the previous part left there: distances to every pick before idx[j0 - 1]) and the round of pick j0 starts from idx[j0 - 1];
+    // a part that starts at 0 with `temp` given initialises it itself.  The whole sampling is (0, m).
     static_assert(PPT % 2 == 0, "two points per packed instruction");
     constexpr int H = PPT / 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -203,6 +206,7 @@ __global__ __launch_bounds__(NWAVES * 64) void fps_kernel_blocked(int n_stride, 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int base = tid * PPT;
+    const bool part = !(j0 == 0 && j1 == m);
     // optional gather of the sampled coordinates (pointnet_utils.py:222-223 index_points(xyz, fps_idx)): both layouts
     auto emit = [&](int j, float x, float y, float z) {
         if (new_n3 != nullptr) {
@@ -224,23 +228,23 @@ __global__ __launch_bounds__(NWAVES * 64) void fps_kernel_blocked(int n_stride, 
         unsigned d0 = 0u;                      // slots beyond n: distance 0 forever, highest indices -> never preferred
         if (k < n) {
             x = xyz[(size_t)k * 3 + 0]; y = xyz[(size_t)k * 3 + 1]; z = xyz[(size_t)k * 3 + 2];
-            d0 = __float_as_uint(temp != nullptr ? temp[k] : 1e10f);
+            d0 = __float_as_uint(temp != nullptr && !(part && j0 == 0) ? temp[k] : 1e10f);
             if (XYZ_LDS) { xs[k] = x; ys[k] = y; zs[k] = z; }
         }
         px[i / 2][i & 1] = x; py[i / 2][i & 1] = y; pz[i / 2][i & 1] = z;
         dmin[i] = d0;
     }
-    if (tid == 0) {
+    if (tid == 0 && j0 == 0) {
         if (XYZ_LDS && defer) picks[0] = 0;
         else idx[0] = 0;
     }
     __syncthreads();
 
-    int old = 0;
+    int old = j0 > 0 ? idx[j0 - 1] : 0;
     // clouds beyond the LDS budget: the winner's coordinates travel with its (distance, index) through the wave slots
     // (picked out of the owner lane's registers with a uniform slot switch + v_readlane), so a round reads no memory at all
-    float nx = xyz[0], ny = xyz[1], nz = xyz[2];
-    for (int j = 1; j < m; ++j) {
+    float nx = xyz[(size_t)old * 3 + 0], ny = xyz[(size_t)old * 3 + 1], nz = xyz[(size_t)old * 3 + 2];
+    for (int j = j0 > 0 ? j0 : 1; j < j1; ++j) {
         // the last pick's coordinates: broadcast read of the LDS mirror, or the values carried over from the last round
         const float ox = XYZ_LDS ? xs[old] : nx;
         const float oy = XYZ_LDS ? ys[old] : ny;
@@ -302,17 +306,17 @@ __global__ __launch_bounds__(NWAVES * 64) void fps_kernel_blocked(int n_stride, 
         }
         old = (int)sel;
         if (XYZ_LDS && defer) {
-            if (wave == 0) picks[j] = old;                      // (uniform branch; the 64 lanes store one word)
+            if (wave == 0) picks[j - j0] = old;                 // (uniform branch; the 64 lanes store one word)
         } else if (tid == 0) idx[j] = old;
     }
     if (XYZ_LDS && defer) {
         __syncthreads();
-        for (int j = tid; j < m; j += NWAVES * 64) {
-            const int id = picks[j];
+        for (int j = j0 + tid; j < j1; j += NWAVES * 64) {
+            const int id = picks[j - j0];
             idx[j] = id;
             emit(j, xs[id], ys[id], zs[id]);
         }
-    } else if (tid == 0) emit(m - 1, xyz[(size_t)old * 3 + 0], xyz[(size_t)old * 3 + 1], xyz[(size_t)old * 3 + 2]);
+    } else if (tid == 0) emit(j1 - 1, xyz[(size_t)old * 3 + 0], xyz[(size_t)old * 3 + 1], xyz[(size_t)old * 3 + 2]);
     if (temp != nullptr) {
 #pragma unroll
         for (int i = 0; i < PPT; ++i) {
@@ -366,7 +370,8 @@ static CAPTRA_KNOB int g_fps_variant = 0;  // 0 = blocked / ballot / packed-math
 
 template <int NWAVES, int PPT>
 int launch_fps(int b, int n, int m, const float *xyz, float *temp, int *idx, hipStream_t s, float *new_n3 = nullptr,
-               float *new_cn = nullptr, bool need_blocked = false, const int *ns = nullptr) {
+               float *new_cn = nullptr, bool need_blocked = false, const int *ns = nullptr, int j0 = 0, int j1 = -1) {
+    if (j1 < 0) j1 = m;
     size_t slots = 2 * 16 * sizeof(uint2);
     size_t lds_xyz = (size_t)n * 3 * sizeof(float);
     if constexpr (PPT % 2 == 0) {
@@ -377,18 +382,18 @@ int launch_fps(int b, int n, int m, const float *xyz, float *temp, int *idx, hip
                 hipFuncSetAttribute(reinterpret_cast<const void *>(kern2), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
                 once2.done();
             }
-            const size_t picks_b = (size_t)m * sizeof(int);
+            const size_t picks_b = (size_t)(j1 - j0) * sizeof(int);
             const int defer = (g_fps_defer && slots + lds_xyz + picks_b <= 150 * 1024) ? 1 : 0;
-            CAPTRA_LAUNCH("fps", kern2, dim3(b), dim3(NWAVES * 64), slots + lds_xyz + (defer ? picks_b : 0), s, n, m, xyz, temp, idx, new_n3, new_cn, ns, defer);
+            CAPTRA_LAUNCH("fps", kern2, dim3(b), dim3(NWAVES * 64), slots + lds_xyz + (defer ? picks_b : 0), s, n, m, xyz, temp, idx, new_n3, new_cn, ns, defer, j0, j1);
             return captra_last_error();
         }
         if (g_fps_variant == 0) {  // cloud larger than the LDS mirror: same kernel, winner coordinates from global memory
             CAPTRA_LAUNCH("fps", (fps_kernel_blocked<NWAVES, PPT, false>), dim3(b), dim3(NWAVES * 64),
-                          slots + 2 * 16 * sizeof(float4), s, n, m, xyz, temp, idx, new_n3, new_cn, ns, 0);
+                          slots + 2 * 16 * sizeof(float4), s, n, m, xyz, temp, idx, new_n3, new_cn, ns, 0, j0, j1);
             return captra_last_error();
         }
     }
-    if (need_blocked || ns != nullptr) return -2;  // the fused sample + gather entry exists on the blocked kernel only
+    if (need_blocked || ns != nullptr || j0 != 0 || j1 != m) return -2;  // the fused sample + gather entry (and its parts) exist on the blocked kernel only
     if (slots + lds_xyz <= 150 * 1024) {
         auto kern = fps_kernel<NWAVES, PPT, true>;
         static CaptraDeviceOnce once;
@@ -454,11 +459,15 @@ extern "C" int captra_furthest_point_sampling(int b, int n, int m, const float *
 // FPS + gather of the sampled coordinates in one launch (see include/captra_hip.h).  -2 when the cloud does not fit the
 // register-resident kernel (use captra_furthest_point_sampling + captra_gather_points then).
 static int fps_gather_dispatch(int b, int n, const int *ns, int m, const float *xyz, int *idx, float *new_xyz_n3,
-                               float *new_xyz_cn, hipStream_t s) {
+                               float *new_xyz_cn, hipStream_t s, float *temp = nullptr, int j0 = 0, int j1 = -1) {
     if (b < 0 || n < 1 || m < 1) return -1;
     if (b == 0) return 0;
     if (g_fps_variant != 0) return -2;
+    if (j1 < 0) j1 = m;
+    const bool part = !(j0 == 0 && j1 == m);
+    if (part && (temp == nullptr || j0 < 0 || j1 > m || j0 >= j1 || ns != nullptr)) return -1;
     if (g_fps_pruned_min > 0 && n >= g_fps_pruned_min && m > 1) {
+        if (part) return -2;                       // parts: the register-resident kernel only
         const int rc = captra_fps_pruned_launch(b, n, ns, m, xyz, nullptr, idx, new_xyz_n3, new_xyz_cn, s);
         if (rc != -2) return rc;
     }
@@ -473,7 +482,7 @@ static int fps_gather_dispatch(int b, int n, const int *ns, int m, const float *
     }
     const int ppt = (n + waves * 64 - 1) / (waves * 64);
 #define FPSG_CASE(W, P) \
-    if (waves == W && ppt <= P) return launch_fps<W, P>(b, n, m, xyz, nullptr, idx, s, new_xyz_n3, new_xyz_cn, true, ns);
+    if (waves == W && ppt <= P) return launch_fps<W, P>(b, n, m, xyz, temp, idx, s, new_xyz_n3, new_xyz_cn, true, ns, j0, j1);
     FPSG_CASE(1, 2) FPSG_CASE(1, 4) FPSG_CASE(1, 8)
     FPSG_CASE(2, 8) FPSG_CASE(4, 8) FPSG_CASE(8, 8) FPSG_CASE(4, 16) FPSG_CASE(2, 32) FPSG_CASE(16, 4)   /* (the last three: captra_fps_set_waves experiments; 4 x 16 is the default for 2049..4096 points) */
     FPSG_CASE(16, 8) FPSG_CASE(16, 12) FPSG_CASE(16, 16) FPSG_CASE(16, 20)
@@ -485,6 +494,17 @@ static int fps_gather_dispatch(int b, int n, const int *ns, int m, const float *
 extern "C" int captra_fps_gather(int b, int n, int m, const float *xyz, int *idx, float *new_xyz_n3, float *new_xyz_cn,
                                  captra_stream_t stream) {
     return fps_gather_dispatch(b, n, nullptr, m, xyz, idx, new_xyz_n3, new_xyz_cn, (hipStream_t)stream);
+}
+
+// Picks [j0, j1) of captra_fps_gather's m, as a launch of its own: state (B,N) fp32 carries a cloud's running minima from part
+// to part (written by every part, read by every part but the one that starts at 0), idx / new_xyz_* are the whole sampling's
+// buffers.  Parts launched in order on one stream produce what the one launch produces, bit for bit; what is between them is the
+// caller's -- e.g. the ball query and shared MLPs of the centres picked so far, on other streams.  -2: cloud outside the
+// register-resident kernel.
+extern "C" int captra_fps_gather_part(int b, int n, int m, int j0, int j1, const float *xyz, float *state, int *idx, float *new_xyz_n3,
+                                      float *new_xyz_cn, captra_stream_t stream) {
+    if (j0 == 0 && j1 == m) return fps_gather_dispatch(b, n, nullptr, m, xyz, idx, new_xyz_n3, new_xyz_cn, (hipStream_t)stream);
+    return fps_gather_dispatch(b, n, nullptr, m, xyz, idx, new_xyz_n3, new_xyz_cn, (hipStream_t)stream, state, j0, j1);
 }
 
 // Ragged batch: clouds padded to n_stride points each, cloud i samples from its first n_per_cloud[i] (device array).

@@ -162,6 +162,7 @@ struct SbParams {
     float *out;             // (B,out_ctotal,M)
     int out_ctotal, co_off;
     int jobs_per_cloud, njobs;
+    int m0, mhi;                // centres [m0, mhi) of every cloud (captra_set_centre_window; default 0, m)
     unsigned long long *prof;   // sa2_bf16_kernel: phase timers of a sample of waves (captra_sa_fused_set_prof), or null
 };
 
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(256, OCC) void sa_bf16_kernel(SbParams p) {
     const int job = blockIdx.x * 4 + wave;
     if (job >= p.njobs) return;                        // (no barrier below)
     const int b = job / p.jobs_per_cloud;
-    const int centre0 = (job % p.jobs_per_cloud) * CG;
+    const int centre0 = p.m0 + (job % p.jobs_per_cloud) * CG;
     const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc((void *)p.img, 0, S::WBYTES, 0x00020000);
     // streamed weights: a ring of RD fragments, loaded RD - 1 uses ahead of the MFMAs that read them (a fragment feeds TN
     // MFMAs = TN x 32 cycles; an L2 hit takes 500+ cycles under this load)
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(256, OCC) void sa_bf16_kernel(SbParams p) {
     auto gather_id = [&](int ps) -> int {
         const int tile = ps * 2 + h;
         int c = centre0 + tile / TPC;
-        c = c < p.m ? c : p.m - 1;
+        c = c < p.mhi ? c : p.mhi - 1;
         if constexpr (DBG & 1) return col + 32 * (tile & 3);
         return p.idx[cloud_idx + (size_t)c * K + (tile % TPC) * 32 + col];
     };
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(256, OCC) void sa_bf16_kernel(SbParams p) {
     auto gather_raw = [&](int ps, int id, float (&raw)[CF + 6]) {
         const int tile = ps * 2 + h;
         int c = centre0 + tile / TPC;
-        c = c < p.m ? c : p.m - 1;
+        c = c < p.mhi ? c : p.mhi - 1;
         const float *cp = p.new_xyz + ((size_t)b * p.m + c) * 3;
         if constexpr (!PRE) {
 #pragma unroll
@@ -330,7 +331,7 @@ __global__ __launch_bounds__(256, OCC) void sa_bf16_kernel(SbParams p) {
             for (int j = 0; j < TN; ++j) {
                 const int tile = ps * TN + j;
                 int c = centre0 + tile / TPC;
-                c = c < p.m ? c : p.m - 1;
+                c = c < p.mhi ? c : p.mhi - 1;
                 const int id = (DBG & 1) ? col + 32 * j : p.idx[cloud_idx + (size_t)c * K + (tile % TPC) * 32 + col];
                 const float *cp = p.new_xyz + ((size_t)b * p.m + c) * 3;
                 const float r0 = xb[id] - cp[0], r1 = xb[(size_t)p.n + id] - cp[1], r2 = xb[(size_t)2 * p.n + id] - cp[2];
@@ -436,7 +437,7 @@ __global__ __launch_bounds__(256, OCC) void sa_bf16_kernel(SbParams p) {
                     if constexpr (STAGE_OUT) {
                         if (h == 0 && ch < C3) ost[cl * C3 + ch] = v;
                     } else {
-                        if (h == 0 && ch < C3 && centre0 + cl < p.m && (!(DBG & 4) || v == 12345.f))
+                        if (h == 0 && ch < C3 && centre0 + cl < p.mhi && (!(DBG & 4) || v == 12345.f))
                             p.out[((size_t)b * p.out_ctotal + p.co_off + ch) * p.m + centre0 + cl] = v;
                     }
                 }
@@ -448,7 +449,7 @@ __global__ __launch_bounds__(256, OCC) void sa_bf16_kernel(SbParams p) {
         constexpr int QPC = CG / 4;                    // 16-byte segments per channel row
         constexpr int CHS = 64 / QPC;                  // channels per sweep
         float *ob = p.out + ((size_t)b * p.out_ctotal + p.co_off) * p.m + centre0;
-        const bool vec_ok = (p.m % 4) == 0 && centre0 + CG <= p.m;
+        const bool vec_ok = (p.m % 4) == 0 && (centre0 % 4) == 0 && centre0 + CG <= p.mhi;
 #pragma unroll 1
         for (int c0 = 0; c0 < C3; c0 += CHS) {
             const int ch = c0 + lane / QPC, cq = (lane % QPC) * 4;
@@ -459,10 +460,10 @@ __global__ __launch_bounds__(256, OCC) void sa_bf16_kernel(SbParams p) {
                 float *dst = ob + (size_t)ch * p.m + cq;
                 if (vec_ok) *reinterpret_cast<float4 *>(dst) = v;
                 else {
-                    if (centre0 + cq + 0 < p.m) dst[0] = v.x;
-                    if (centre0 + cq + 1 < p.m) dst[1] = v.y;
-                    if (centre0 + cq + 2 < p.m) dst[2] = v.z;
-                    if (centre0 + cq + 3 < p.m) dst[3] = v.w;
+                    if (centre0 + cq + 0 < p.mhi) dst[0] = v.x;
+                    if (centre0 + cq + 1 < p.mhi) dst[1] = v.y;
+                    if (centre0 + cq + 2 < p.mhi) dst[2] = v.z;
+                    if (centre0 + cq + 3 < p.mhi) dst[3] = v.w;
                 }
             }
         }
@@ -511,7 +512,7 @@ __global__ __launch_bounds__(256, 1) void sa2_bf16_kernel(SbParams p) {
         t_last = t_now;                                                                    \
     }
     const int b = job / p.jobs_per_cloud;
-    const int centre0 = (job % p.jobs_per_cloud) * CG;
+    const int centre0 = p.m0 + (job % p.jobs_per_cloud) * CG;
     const size_t cloud_idx = (size_t)b * p.m * K;
     const float *xb = p.xyz_cn + (size_t)b * 3 * p.n;
     // ---- neighbour ids and centres first, the biases behind them --------------------------------------------------------------
@@ -520,7 +521,7 @@ __global__ __launch_bounds__(256, 1) void sa2_bf16_kernel(SbParams p) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         int c = centre0 + j / TPC;
-        c = c < p.m ? c : p.m - 1;
+        c = c < p.mhi ? c : p.mhi - 1;
         ids[j] = p.idx[cloud_idx + (size_t)c * K + (j % TPC) * 32 + col];
         const float *cp = p.new_xyz + ((size_t)b * p.m + c) * 3;
         ctr[j][0] = cp[0]; ctr[j][1] = cp[1]; ctr[j][2] = cp[2];
@@ -698,8 +699,9 @@ CAPTRA_KNOB int g_sb_variant = 0;      // A/B: bit 0 = small-input scales as bef
 template <int CF, int C1, int C2, int C3, int K, bool PRE, int TN, int CG, bool WLDS, int OCC = (WLDS ? 2 : 1), int RGS = 0, bool PF = false, int DBG = 0, int LRD = 1>
 int sb_launch(int b, SbParams p, hipStream_t stream) {
     using S = SbShape<CF, C1, C2, C3, PRE>;
-    p.jobs_per_cloud = (p.m + CG - 1) / CG;
+    p.jobs_per_cloud = (p.mhi - p.m0 + CG - 1) / CG;
     p.njobs = b * p.jobs_per_cloud;
+    if (p.njobs == 0) return 0;
     const int lds = (WLDS ? S::WBYTES : 0) + S::NBIAS * 4 + (CG >= 4 ? 4 * CG * C3 * 4 : 0);
     auto kern = sa_bf16_kernel<CF, C1, C2, C3, K, PRE, TN, CG, WLDS, OCC, RGS, PF, DBG, LRD>;
     static CaptraDeviceOnce once;
@@ -751,6 +753,12 @@ extern "C" int captra_sa_scale_bf16(int b, int n, int m, int k, int cfeat, int c
     p.xyz_cn = xyz_cn; p.new_xyz = new_xyz; p.idx = idx; p.img = img; p.out = out; p.out_ctotal = out_ctotal; p.co_off = co_off;
     p.jobs_per_cloud = p.njobs = 0;
     p.prof = captra_sa_prof_ptr();
+    {
+        int wm0, wmc;
+        const bool win = captra_centre_window(m, &wm0, &wmc);
+        if (win && pre) return -2;            // a centre window is the small-input scales' only (sa_bf16_kernel)
+        p.m0 = wm0; p.mhi = wm0 + wmc;
+    }
     hipStream_t s = (hipStream_t)stream;
 #define SB_MATCH(CF_, C1_, C2_, C3_, K_, PRE_) (cfeat == CF_ && c1 == C1_ && c2 == C2_ && c3 == C3_ && k == K_ && (pre != 0) == PRE_)
     // PF_: the gather prefetch pays from 64 neighbours on (sa1s3 82 -> 79 us at 32 clouds, 54 -> 50 at 16; sa1s2 26 -> 23 at 16); the

@@ -328,6 +328,7 @@ struct SwParams {
     const float *v1;           // PRE kernels: (B,C1,N) = b1 + W1[feature rows] * feat per source point, else null
     unsigned long long *prof;  // debug: per-phase wave-cycle totals of a sample of waves (sa_wave_kernel), else null
     int split;                 // sa_wave_lds_kernel: a wave owns ONE 32-neighbour slice of a centre (small batches), maxima combined by atomic max
+    int m0, mc;                // sa_wave_lds_kernel: centres [m0, m0 + mc) of every cloud (captra_set_centre_window; default 0, m)
     int *dyn;                  // sa_wave_lds_kernel: a zeroed counter -> centres beyond every wave's first are handed out through it
                                // (captra_sa_set_dynamic), null = static walk gid, gid + nwaves, ...
 };
@@ -650,16 +651,17 @@ __global__ __launch_bounds__(SL_WAVES * 64) __attribute__((amdgpu_waves_per_eu(4
     // ends up to a whole centre (4 slices, ~150 us with four waves per SIMD) late, and the atomic's return is waited for
     // at every centre end (674 / 298 / 210 us).
     const int nwaves = (int)gridDim.x * SL_WAVES, gid = (int)blockIdx.x * SL_WAVES + wave;
-    const int ncentres = p.b * p.m;                       // < 2^30 (launcher)
+    const int ncentres = p.b * p.mc;                      // < 2^30 (launcher); centre c of the window = row crow(c) of (B, M)
+    auto crow = [&](int c) { const int tb = c / p.mc; return tb * p.m + p.m0 + (c - tb * p.mc); };
     const int nslices = p.k / 32;
-    auto load_ids = [&](int c, int sl) { return p.idx[(size_t)c * p.k + sl * 32 + (lane & 31)]; };
+    auto load_ids = [&](int c, int sl) { return p.idx[(size_t)crow(c) * p.k + sl * 32 + (lane & 31)]; };
     auto load_ctr = [&](int c, float (&o)[3]) {
-        const float *cp = p.new_xyz + (size_t)c * 3;
+        const float *cp = p.new_xyz + (size_t)crow(c) * 3;
         o[0] = cp[0]; o[1] = cp[1]; o[2] = cp[2];
     };
     // first-layer B operand of a slice (k-step j = rows 2j, 2j+1: feature rows, then centre-relative xyz), gathered per lane
     auto gather_x1 = [&](int c, int id_, const float (&c_)[3], float (&x_)[S1::KST]) {
-        const int tb = c / p.m;
+        const int tb = c / p.mc;
 #pragma unroll
         for (int j = 0; j < S1::KST; ++j) {
             const int row = 2 * j + (lane >> 5);
@@ -748,7 +750,7 @@ __global__ __launch_bounds__(SL_WAVES * 64) __attribute__((amdgpu_waves_per_eu(4
         if (CAPTRA_PROF_ON(p.prof) && lane == 0 && sampled) atomicAdd(p.prof + 9, 1ull);
         if (last_slice) {
             // the centre's maxima: lane l with (l & 16) == 0 holds row 32 t + 8 ((l & 15) >> 2) + (l & 3) + 4 (l >> 5) of tile t
-            const int tb = c / p.m, centre = c - tb * p.m;
+            const int tb = c / p.mc, centre = p.m0 + c - tb * p.mc;
             const int r = lane & 15;
             const int row0 = 8 * (r >> 2) + (r & 3) + 4 * (lane >> 5);
             float *op = p.out + ((size_t)tb * p.out_ctotal + p.co_off + row0) * p.m + centre;
@@ -781,6 +783,15 @@ extern "C" void captra_sa_fused_set_mode(int mode) { g_sa_mode = mode; }
 static CAPTRA_KNOB int g_sa_split = 1;  // a wave per slice for small batches: 0 = never, 1 = heuristic, 2 = always (tests)
 extern "C" void captra_sa_fused_set_split(int v) { g_sa_split = v; }
 int captra_sa_split_knob() { return g_sa_split; }
+// the slice-per-wave form's zeroed output: channels [co_off, co_off + c3), centres [m0, m0 + mc) of every cloud
+static void sl_zero_window(float *out, int b, int m, int out_ctotal, int co_off, int c3, int m0, int mc, hipStream_t stream) {
+    if (m0 == 0 && mc == m) {
+        (void)hipMemset2DAsync(out + (size_t)co_off * m, (size_t)out_ctotal * m * 4, 0, (size_t)c3 * m * 4, b, stream);
+        return;
+    }
+    for (int bb = 0; bb < b; ++bb)
+        (void)hipMemset2DAsync(out + ((size_t)bb * out_ctotal + co_off) * m + m0, (size_t)m * 4, 0, (size_t)mc * 4, c3, stream);
+}
 // Dynamic centre hand-out of the persistent SA kernels (sa_wave_lds_kernel, sa_wave_pipe_kernel): a caller-owned device buffer
 // of `nslots` ints; every launch of the calling thread takes the next slot (round robin), zeroes it on its stream and counts
 // its centres through it.  (nullptr, 0) = static walk (default).  A captured graph owns the slots its launches were given.
@@ -843,7 +854,11 @@ extern "C" int captra_sa_scale_fused(int b, int n, int m, int k, int cfeat, int 
         /* (captra_set_reserved_cus: CUs another stream's samplers hold -- every persistent workgroup must be resident) */ \
         const int cus_l = (packed & 0xffff) - captra_reserved_cus() > 0 ? (packed & 0xffff) - captra_reserved_cus() : 1; \
         const int resident = (packed >> 16) * cus_l;                                                                   \
-        const long long centres = (long long)b * m;            /* a wave per centre: 8 centres per workgroup round */           \
+        int wm0, wmc;                                                                                                  \
+        (void)captra_centre_window(m, &wm0, &wmc);                                                                     \
+        if (wmc == 0) return 0;                                                                                        \
+        q.m0 = wm0; q.mc = wmc;                                                                                        \
+        const long long centres = (long long)b * wmc;          /* a wave per centre: 8 centres per workgroup round */           \
         /* fewer centres than resident waves: a wave per SLICE instead (see the kernel), output pre-zeroed for the atomic max */ \
         q.split = (g_sa_split != 0 && k > 32 && (g_sa_split == 2 || centres < (long long)resident * SL_WAVES)) ? 1 : 0;    \
         const long long units = q.split ? centres * (k / 32) : centres;                                                \
@@ -851,7 +866,7 @@ extern "C" int captra_sa_scale_fused(int b, int n, int m, int k, int cfeat, int 
         q.b = b;                                                                                                       \
         q.dyn = (!q.split && k > 32 && wgs > 1) ? captra_sa_dyn_slot((hipStream_t)stream) : nullptr;                   \
         const unsigned grid_l = (unsigned)(wgs < resident ? wgs : resident);                                           \
-        if (q.split) (void)hipMemset2DAsync(out + (size_t)co_off * m, (size_t)out_ctotal * m * 4, 0, (size_t)c3 * m * 4, b, (hipStream_t)stream); \
+        if (q.split) sl_zero_window(out, b, m, out_ctotal, co_off, c3, wm0, wmc, (hipStream_t)stream);                  \
         CAPTRA_LAUNCH("sa_scale_fused", kern, dim3(grid_l), dim3(SL_WAVES * 64), lds_bytes, (hipStream_t)stream, q);  \
         return captra_last_error();                                                                                    \
     }
@@ -862,6 +877,7 @@ extern "C" int captra_sa_scale_fused(int b, int n, int m, int k, int cfeat, int 
         SL_CASE(3, 64, 64, 128)
         SL_CASE(3, 64, 96, 128)
 #undef SL_CASE
+        { int a0, ac; if (captra_centre_window(m, &a0, &ac)) return -2; }   // a centre window is the LDS-weights kernels' only
 #define SW_CASE(CF_, C1_, C2_, C3_)                                                                                  \
     if (cfeat == CF_ && c1 == C1_ && c2 == C2_ && c3 == C3_ && (long long)cfeat * n * 4 < (1ll << 31)) {             \
         CAPTRA_LAUNCH("sa_scale_fused", (sa_wave_kernel<CF_, C1_, C2_, C3_>), gridw, dim3(256), 0, (hipStream_t)stream, q); \

@@ -52,13 +52,26 @@ def canonicalize(pts, mean, rot, trans, scale, num_parts: int = 1, want_cn=True,
     return out_cn, out_n3
 
 
-def ball_query_multi(radii, nsamples, xyz_n3, new_xyz_n3):
-    """One scan of xyz for all radii -> [idx_r (B,M,K_r) int32]."""
+@contextlib.contextmanager
+def centre_window(m0: int, mc: int):
+    """The set-abstraction launches inside process centres [m0, m0 + mc) of every cloud only (captra_set_centre_window): the
+    ball query and the small-input SA scales of the centres a streamed sampler (`fps_gather_part`) has picked so far."""
+    L.lib().captra_set_centre_window(C.c_int(int(m0)), C.c_int(int(mc)))
+    try:
+        yield
+    finally:
+        L.lib().captra_set_centre_window(C.c_int(0), C.c_int(0))
+
+
+def ball_query_multi(radii, nsamples, xyz_n3, new_xyz_n3, outs=None):
+    """One scan of xyz for all radii -> [idx_r (B,M,K_r) int32] (`outs`: the lists to fill -- under `centre_window` a launch
+    fills its window of them)."""
     L.require_device(xyz_n3, new_xyz_n3)
     B, N, _ = xyz_n3.shape
     M = new_xyz_n3.shape[1]
     nr = len(radii)
-    outs = [torch.empty(B, M, int(k), dtype=torch.int32, device=xyz_n3.device) for k in nsamples]
+    if outs is None:
+        outs = [torch.empty(B, M, int(k), dtype=torch.int32, device=xyz_n3.device) for k in nsamples]
     c_r = (C.c_float * nr)(*[float(r) for r in radii])
     c_k = (C.c_int * nr)(*[int(k) for k in nsamples])
     c_p = (C.c_void_p * nr)(*[o.data_ptr() for o in outs])
@@ -482,6 +495,26 @@ def fps_gather(xyz_n3, m: int, n_per_cloud=None):
     return idx, n3, cn
 
 
+def fps_gather_parts(xyz_n3, m: int):
+    """Buffers of a STREAMED sampling (captra_fps_gather_part): (idx (B,m), new_xyz (B,m,3), new_xyz (B,3,m), state (B,N)); None
+    when the cloud is outside the register-resident kernel."""
+    B, N, _ = xyz_n3.shape
+    if N >= 8192 or N > 16 * 64 * 32:
+        return None
+    dev = xyz_n3.device
+    return (torch.empty(B, m, dtype=torch.int32, device=dev), torch.empty(B, m, 3, dtype=torch.float32, device=dev),
+            torch.empty(B, 3, m, dtype=torch.float32, device=dev), torch.empty(B, N, dtype=torch.float32, device=dev))
+
+
+def fps_gather_part(xyz_n3, m: int, j0: int, j1: int, bufs):
+    """Picks [j0, j1) of the m into `bufs` (fps_gather_parts); parts in order on one stream == fps_gather, bit for bit."""
+    idx, n3, cn, state = bufs
+    L.require_device(xyz_n3, idx, n3, cn, state)
+    B, N, _ = xyz_n3.shape
+    with torch.cuda.device(xyz_n3.device):
+        L.call("captra_fps_gather_part", B, N, m, j0, j1, L.ptr(xyz_n3), L.ptr(state), L.ptr(idx), L.ptr(n3), L.ptr(cn))
+
+
 USE_SA_PRE = True        # SA scales with many feature channels: first layer's feature part once per source point
 _SA_PRE_SHAPES = {(320, 128, 128, 256), (320, 128, 196, 256)}   # csrc/sa_fused.hip SWP_CASE list
 
@@ -493,6 +526,10 @@ def sa_scale_pre_supported(cfeat, layers, k) -> bool:
 
 _SA_BF16_SHAPES = {(0, 32, 32, 64, 32), (0, 64, 64, 128, 64), (0, 64, 96, 128, 128), (3, 32, 32, 64, 32), (3, 64, 64, 128, 64),
                    (3, 64, 96, 128, 128), (320, 128, 128, 256, 64), (320, 128, 196, 256, 128)}      # csrc/sa_bf16.hip SB_CASE list
+
+
+# small-input scales whose kernels (sa_wave_lds_kernel / sa_bf16_kernel) process a centre window: (cfeat, c1, c2, c3, k)
+SA_WINDOW_SHAPES = {s for s in _SA_BF16_SHAPES if s[0] <= 3}
 
 
 def sa_scale_bf16_supported(cfeat, layers, k) -> bool:

@@ -85,6 +85,10 @@ class EvalTrackModel(BaseModel):
         self.share_geometry = True
         self.overlap_geometry = os.environ.get("CAPTRA_OVERLAP_GEOM", "1") != "0"   # the shared geometry's two levels side by side
         self.overlap_nets = True     # CoordinateNet and RotationNet side by side on two streams (one part: they share the cloud)
+        # STREAMED level-1 sampling (backbones.precompute_geometry_streamed): the 4096 -> 512 sampler as this many launches on a
+        # stream of its own, the networks' first level walking the centres as they are picked; 0 / 1 = the sampler, then the
+        # networks.  Same picks, same neighbour lists, same bits.
+        self.sampler_chunks = int(cfg.get("sampler_chunks", os.environ.get("CAPTRA_SAMPLER_CHUNKS", "0")))
         # replay one captured hipGraph per frame instead of launching the ~140 kernels of a step one by one
         # (captra_amd/graph.py); opt-in: `--hipgraph` of captra_amd.track / cfg['hipgraph'].  Same kernels, same bits.
         self.use_graph = bool(cfg.get("hipgraph", False))
@@ -243,15 +247,29 @@ class EvalTrackModel(BaseModel):
         if getattr(self, "_side", None) is None:
             self._side = torch.cuda.Stream(device=dev)
         side = self._side
-        if not self._step_prep(input, npcs_input, last_pose, level1_only=small, side=side if self.overlap_geometry else None):
-            return None
         main = torch.cuda.current_stream(dev)
+        gstream = None
+        if self.sampler_chunks > 1 and self.num_parts == 1 and self.share_geometry:
+            # the geometry on a stream of its own, both networks forked right behind the canonicalisation: their first level
+            # waits for the sampler's parts one by one, their second level for the rest of the geometry
+            from .networks import _canonicalize
+            if getattr(self, "_gstream", None) is None:
+                self._gstream = torch.cuda.Stream(device=dev)
+            cam = _canonicalize(npcs_input["points"], npcs_input["points_mean"], npcs_input["canon_pose"])
+            geom = self.npcs_net.backbone.precompute_geometry_streamed(cam[1], self.sampler_chunks, self._gstream, consumers=(side,))
+            if geom is not None:
+                npcs_input["_canon"], npcs_input["_geom"] = cam, geom
+                gstream = self._gstream
+        if gstream is None and not self._step_prep(input, npcs_input, last_pose, level1_only=small, side=side if self.overlap_geometry else None):
+            return None
         side.wait_stream(main)
         with torch.cuda.stream(side):
             raw = self._step_rot(input, npcs_input, last_pose)
 
         def join():
             main.wait_stream(side)
+            if gstream is not None:
+                main.wait_stream(gstream)
             raw.record_stream(main)
             input["_raw"] = raw
         return join

@@ -158,6 +158,14 @@ class PointNetSetAbstractionMsg(_FoldCache, nn.Module):
                             for convs, bns in zip(self.conv_blocks, self.bn_blocks)]
         return self._folded
 
+    def window_ok(self, cfeat: int) -> bool:
+        """Every scale of this level runs on a kernel that honours a centre window (the small-input scales of the CAPTRA
+        backbone: fused.SA_WINDOW_SHAPES)."""
+        folded = self._folded
+        if folded is None or cfeat > 3:
+            return False
+        return all((cfeat, l[0].cout, l[1].cout, l[2].cout, k) in fused.SA_WINDOW_SHAPES for l, k in zip(folded, self.nsample_list))
+
     def _can_fuse(self, xyz):
         return (not self.training) and (not self.knn) and xyz.is_cuda and \
             all(k % 32 == 0 and 128 % k == 0 for k in self.nsample_list)
@@ -196,6 +204,22 @@ class PointNetSetAbstractionMsg(_FoldCache, nn.Module):
         idx_list = geom["idx_list"]
         out = torch.empty(B, self.out_channel, S, dtype=torch.float32, device=xyz_cn.device)
         feat = points.contiguous() if points is not None else None
+        if geom.get("chunks"):
+            # STREAMED sampling (backbones.precompute_geometry_streamed): the sampler is still picking the later centres on its
+            # own stream; every window of centres runs its scales as soon as its picks and neighbour lists are there
+            cur = torch.cuda.current_stream(xyz_cn.device)
+            cfeat = 0 if feat is None else feat.shape[1]
+            for m0, mc, ev in geom["chunks"]:
+                cur.wait_event(ev)
+                off = 0
+                with fused.centre_window(m0, mc):
+                    for layers, idx in zip(folded, idx_list):
+                        if fused.sa_scale_bf16_supported(cfeat, layers, idx.shape[2]):
+                            fused.sa_scale_bf16(feat, xyz_cn, new_xyz_n3, idx, layers, out, off)
+                        else:
+                            fused.sa_scale_fused(feat, xyz_cn, new_xyz_n3, idx, layers, out, off)
+                        off += layers[-1].cout
+            return out
         off = 0
         for layers, idx in zip(folded, idx_list):
             if fused.sa_scale_bf16_supported(0 if feat is None else feat.shape[1], layers, idx.shape[2]):

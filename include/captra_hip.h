@@ -328,6 +328,21 @@ int captra_crop_ball(int b, int h, int w, int cap, const int *depth, const unsig
 int captra_fps_gather_ragged(int b, int n_stride, const int *n_per_cloud, int m, const float *xyz, int *idx,
                              float *new_xyz_n3, float *new_xyz_cn, captra_stream_t stream);
 
+/* STREAMED sampling: picks [j0, j1) of captra_fps_gather's m as a launch of its own.  state (B,N) fp32 carries a cloud's running
+ * minima from part to part (every part writes it; every part but the one starting at 0 reads it); idx / new_xyz_* are the whole
+ * sampling's buffers.  Parts launched in order on one stream produce the one launch's picks bit for bit (sampling_gpu.cu:93-209
+ * is one loop; this cuts it at j0).  Between two parts the caller may run whatever needs only the centres picked so far -- the
+ * ball query and the shared MLPs of those centres, with captra_set_centre_window -- on other streams, so that the sampler's
+ * dependent rounds, one workgroup per cloud, no longer stand alone at the head of a frame.  -2: cloud outside the
+ * register-resident kernel (> 8191 points). */
+int captra_fps_gather_part(int b, int n, int m, int j0, int j1, const float *xyz, float *state, int *idx, float *new_xyz_n3,
+                           float *new_xyz_cn, captra_stream_t stream);
+/* The next captra_ball_query[_multi] / captra_sa_scale_fused (LDS-weights kernels: the small-input scales) / captra_sa_scale_bf16
+ * (small-input scales) launches of the calling thread process centres [m0, m0 + mc) of every cloud only and leave the rest of
+ * their (B, M, ...) outputs untouched; mc <= 0 = all centres (default).  Entry points that cannot honour a window return -2 while
+ * one is set.  Thread-local. */
+void captra_set_centre_window(int m0, int mc);
+
 /* SA scale with a pre-transformed first layer.  Layer 1's k-ascending chain runs over the cfeat feature rows first and the
  * three relative-xyz rows last (pointnet_utils.py:234-240), and its first cfeat steps depend on the SOURCE point only:
  *   v1 (B,c1,N) = captra_pointwise_mlp(feat (B,cfeat,N), w1 rows 0..cfeat-1, b1, CAPTRA_ACT_NONE)      (once per source point)
