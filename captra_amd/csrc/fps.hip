@@ -252,6 +252,7 @@ __global__ __launch_bounds__(NWAVES * 64) void fps_kernel_blocked(int n_stride, 
         if (!(XYZ_LDS && defer) && tid == 0) emit(j - 1, ox, oy, oz);
         const f32x2 o2x = {ox, ox}, o2y = {oy, oy}, o2z = {oz, oz};
         unsigned best = 0u;
+        unsigned q8[H];                         // pairwise maxima of the updated minima
 #pragma unroll
         for (int h = 0; h < H; ++h) {
             const f32x2 dx = px[h] - o2x, dy = py[h] - o2y, dz = pz[h] - o2z;
@@ -259,11 +260,32 @@ __global__ __launch_bounds__(NWAVES * 64) void fps_kernel_blocked(int n_stride, 
             const unsigned b0 = __float_as_uint(d[0]), b1 = __float_as_uint(d[1]);
             dmin[2 * h] = b0 < dmin[2 * h] ? b0 : dmin[2 * h];
             dmin[2 * h + 1] = b1 < dmin[2 * h + 1] ? b1 : dmin[2 * h + 1];
-            best = max(best, max(dmin[2 * h], dmin[2 * h + 1]));
+            q8[h] = max(dmin[2 * h], dmin[2 * h + 1]);
+            if constexpr (PPT != 16) best = max(best, q8[h]);
         }
         int li = PPT - 1;                       // lowest slot of this lane holding `best`
+        if constexpr (PPT == 16) {
+            // the maximum through a tree of pairwise maxima, and its lowest slot as a descent through that tree instead of
+            // fifteen compare + select pairs: at every level the LEFT half wins when it holds `best` (lowest slot among equals)
+            unsigned q4[4], q2[2];
 #pragma unroll
-        for (int i = PPT - 2; i >= 0; --i) li = dmin[i] == best ? i : li;
+            for (int i = 0; i < 4; ++i) q4[i] = max(q8[2 * i], q8[2 * i + 1]);
+            q2[0] = max(q4[0], q4[1]); q2[1] = max(q4[2], q4[3]);
+            best = max(q2[0], q2[1]);
+            const bool h3 = q2[0] != best;                                   // the maximum is in slots 8..15 only
+            const unsigned a4 = h3 ? q4[2] : q4[0];
+            const bool h2 = a4 != best;
+            const unsigned a8l = h3 ? (h2 ? q8[6] : q8[4]) : (h2 ? q8[2] : q8[0]);
+            const bool h1 = a8l != best;
+            const int p = (h3 ? 4 : 0) + (h2 ? 2 : 0) + (h1 ? 1 : 0);          // pair index 0..7
+            unsigned dl = dmin[0];
+#pragma unroll
+            for (int i = 1; i < 8; ++i) dl = p == i ? dmin[2 * i] : dl;
+            li = 2 * p + (dl != best ? 1 : 0);
+        } else {
+#pragma unroll
+            for (int i = PPT - 2; i >= 0; --i) li = dmin[i] == best ? i : li;
+        }
         const unsigned wmax = wave_max_u32_fold(best);
         const unsigned long long hit = __ballot(best == wmax);
         const int wl = __ffsll((long long)hit) - 1;            // lowest lane = lowest indices of the wave
@@ -291,6 +313,21 @@ __global__ __launch_bounds__(NWAVES * 64) void fps_kernel_blocked(int n_stride, 
                 if (!XYZ_LDS) sc[wave] = make_float4(wx, wy, wz, 0.f);
             }
             __syncthreads();
+            if constexpr (NWAVES == 4 && XYZ_LDS) {
+                // four waves: every lane reads the four (maximum, index) pairs as two 16-byte broadcasts and picks the winner
+                // with three strict compares in wave order (ties: the lower wave = the lower indices) -- no cross-lane
+                // reduction, ballot or readlane on the round's critical chain; the pick stays in a (uniform) vector register
+                const uint4 s01 = *reinterpret_cast<const uint4 *>(slot), s23 = *reinterpret_cast<const uint4 *>(slot + 2);
+                unsigned bv = s01.x, bi = s01.y;
+                bi = s01.z > bv ? s01.w : bi; bv = s01.z > bv ? s01.z : bv;
+                bi = s23.x > bv ? s23.y : bi; bv = s23.x > bv ? s23.x : bv;
+                bi = s23.z > bv ? s23.w : bi;
+                old = (int)bi;
+                if (defer) {
+                    if (wave == 0) picks[j - j0] = old;
+                } else if (tid == 0) idx[j] = old;
+                continue;
+            }
             const uint2 kv = slot[lane & (NWAVES - 1)];
             float4 kc = make_float4(0.f, 0.f, 0.f, 0.f);
             if (!XYZ_LDS) kc = sc[lane & (NWAVES - 1)];
