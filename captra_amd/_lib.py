@@ -64,6 +64,8 @@ _SIGNATURES = {
     "captra_mlp_chain_bf16": [_INT, _INT, _LL, _INT, _INT, _INT, _P, _P, _P, _P, _P, _P],
     "captra_pack_sa_bf16": [_INT] * 5 + [_P] * 7 + [_P],
     "captra_sa_scale_bf16": [_INT] * 9 + [_P] * 6 + [_INT, _INT, _P],
+    "captra_bq_planes": [_INT, _INT, _P, _P, _P],
+    "captra_sa1_stream_bf16": [_INT, _INT, _INT, _P, _P, _P, _P, _P, _P, _P, _P, _INT, _P, _P, _P, _INT, _P, _P, _P, _P, _P],
     "captra_coord_tail": [_INT, _INT, _INT, _INT, _LL, _P, _P, _P, _INT, _P, _P, _P],
     "captra_fps_gather": [_INT, _INT, _INT, _P, _P, _P, _P, _P],
     "captra_fps_gather_ragged": [_INT, _INT, _P, _INT, _P, _P, _P, _P, _P],
@@ -141,6 +143,13 @@ def lib():
         if hasattr(l, "captra_sa_bf16_image_bytes"):
             l.captra_sa_bf16_image_bytes.argtypes = [_INT] * 4
             l.captra_sa_bf16_image_bytes.restype = _LL
+        if hasattr(l, "captra_sa1_stream_scratch_bytes"):
+            l.captra_sa1_stream_scratch_bytes.argtypes = [_INT, _INT]
+            l.captra_sa1_stream_scratch_bytes.restype = _LL
+            l.captra_sa1_stream_set_grid.argtypes = [_INT, _INT]
+            l.captra_sa1_stream_set_grid.restype = None
+            l.captra_sa1_stream_set_fine.argtypes = [_INT]
+            l.captra_sa1_stream_set_fine.restype = None
         if hasattr(l, "captra_pointwise_mlp_gn_tiles"):
             l.captra_pointwise_mlp_gn_tiles.argtypes = [_INT, _INT, _LL]
             l.captra_pointwise_mlp_gn_tiles.restype = _INT

@@ -74,7 +74,9 @@ def _stale(target: Path, deps: list[Path]) -> bool:
 # 0.327), the dense-layer kernels (pointwise_mlp.hip: 1.636 -> 1.657) and the pruned sampler (+4 %) lose and stay on the default.
 # bf16_mlp.hip loses 5 % with it, interpolate.hip / ball_query.hip do not move.  Instruction order only: every result is bit-identical.
 MAX_ILP = ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]
-PER_SOURCE_FLAGS = {"sa_fused.hip": MAX_ILP, "mlp_chain.hip": MAX_ILP, "fps.hip": MAX_ILP}
+# sa_bf16.hip (round 5): the level-1 stream kernel's sampler rounds are 173 instructions with it and 200 (31 s_nop) without: 250 vs 274 us
+# for the 511 rounds; the bf16 SA scales in the same file do not move (same-box A/B of two builds)
+PER_SOURCE_FLAGS = {"sa_fused.hip": MAX_ILP, "mlp_chain.hip": MAX_ILP, "fps.hip": MAX_ILP, "sa_bf16.hip": MAX_ILP}
 
 
 def _compile_one(src: Path, force: bool, verbose: bool) -> Path:

@@ -29,6 +29,7 @@
 //     once per cloud by its own launch into a caller-provided workspace (an ABI addition) and candidates read from L2.
 // Distance: ((cx-x)^2 + (cy-y)^2) + (cz-z)^2, unfused fp32, strict '<' against radius*radius.
 #include "common.h"
+#include "bq_scan.h"
 
 namespace {
 
@@ -50,9 +51,6 @@ struct BqParams {
     int m0, mhi;          // centres [m0, mhi) of every cloud (captra_set_centre_window; default 0, m)
 };
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-__host__ __device__ constexpr int bq_pad(int v) { return (v + 255) & ~255; }
 
 template <int NR, bool PRUNE, int CPW = BQ_CPW>
 __global__ __launch_bounds__(BQ_WAVES * 64) void ball_query_kernel(int n, int m,
@@ -102,16 +100,7 @@ __global__ __launch_bounds__(BQ_WAVES * 64) void ball_query_kernel(int n, int m,
         const int tn = (n - t0) < BQ_TILE ? (n - t0) : BQ_TILE;
         const int tn_pad = bq_pad(tn);
         if (t0 > 0) __syncthreads();
-        for (int p = tid; p < tn_pad; p += BQ_WAVES * 64) {
-            const bool inb = p < tn;
-            const float *q = xyz + (size_t)(t0 + (inb ? p : 0)) * 3;
-            const float inf = __builtin_inff();
-            const int chunk = p >> 6;
-            const int a = (((chunk >> 2) << 6) + (p & 63)) * 4 + (chunk & 3);
-            xs[a] = inb ? q[0] : inf;
-            ys[a] = inb ? q[1] : inf;
-            zs[a] = inb ? q[2] : inf;
-        }
+        bq_stage_tile(xyz, t0, tn, xs, ys, zs, tid, BQ_WAVES * 64);
         __syncthreads();
 
         if (PRUNE) {
@@ -332,45 +321,17 @@ __global__ __launch_bounds__(BQ_WAVES * 64) void ball_query_kernel(int n, int m,
                     first[ci][r] = -1;
                 }
             }
-            bool open = false;
+            float r2[NR];
+            int ns[NR];
+            int *row[NR];
 #pragma unroll
-            for (int r = 0; r < NR; ++r) open = open || (cnt[ci][r] < prm.ns[r]);
-            if (!open) continue;
-            const float cx = new_xyz[(size_t)c * 3 + 0];
-            const float cy = new_xyz[(size_t)c * 3 + 1];
-            const float cz = new_xyz[(size_t)c * 3 + 2];
-            const f32x4 cx4 = {cx, cx, cx, cx}, cy4 = {cy, cy, cy, cy}, cz4 = {cz, cz, cz, cz};
-            for (int g = 0; g < (tn_pad >> 8) && open; ++g) {
-                const f32x4 dx = cx4 - reinterpret_cast<const f32x4 *>(xs)[g * 64 + lane];
-                const f32x4 dy = cy4 - reinterpret_cast<const f32x4 *>(ys)[g * 64 + lane];
-                const f32x4 dz = cz4 - reinterpret_cast<const f32x4 *>(zs)[g * 64 + lane];
-                const f32x4 d2 = (dx * dx + dy * dy) + dz * dz;  // unfused: the build runs with -ffp-contract=off
-#pragma unroll
-                for (int h = 0; h < 4; ++h) {
-                    if (!open) break;
-                    const int k0 = t0 + g * 256 + h * 64;
-                    bool any_open = false;
-#pragma unroll
-                    for (int r = 0; r < NR; ++r) {
-                        if (cnt[ci][r] < prm.ns[r]) {
-                            const bool hit = d2[h] < prm.r2[r];
-                            const unsigned long long mask = __ballot(hit);
-                            if (mask) {
-                                // rank of this lane among the hits = hits in lower lanes (v_mbcnt), written through a
-                                // uniform row pointer + unsigned 32-bit slot (scalar base + VGPR offset addressing)
-                                const unsigned pos = (unsigned)cnt[ci][r] +
-                                                     __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                                if (cnt[ci][r] == 0) first[ci][r] = k0 + (__ffsll((long long)mask) - 1);
-                                int *row = prm.idx[r] + ((size_t)b * m + c) * prm.ns[r];
-                                if (hit && pos < (unsigned)prm.ns[r]) row[pos] = k0 + lane;
-                                cnt[ci][r] += __popcll(mask);
-                            }
-                            any_open = any_open || (cnt[ci][r] < prm.ns[r]);
-                        }
-                    }
-                    open = any_open;
-                }
+            for (int r = 0; r < NR; ++r) {
+                r2[r] = prm.r2[r];
+                ns[r] = prm.ns[r];
+                row[r] = prm.idx[r] + ((size_t)b * m + c) * prm.ns[r];
             }
+            bq_scan_centre<NR>(xs, ys, zs, tn_pad >> 8, t0, new_xyz[(size_t)c * 3 + 0], new_xyz[(size_t)c * 3 + 1], new_xyz[(size_t)c * 3 + 2],
+                               r2, ns, row, cnt[ci], first[ci], lane);
         }
     }
 
@@ -382,10 +343,7 @@ __global__ __launch_bounds__(BQ_WAVES * 64) void ball_query_kernel(int n, int m,
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             if (PRUNE && first[ci][r] < 0) continue;          // answered (and padded) from the grid
-            const int have = cnt[ci][r] < prm.ns[r] ? cnt[ci][r] : prm.ns[r];
-            const int fill = first[ci][r];
-            int *row = prm.idx[r] + ((size_t)b * m + c) * prm.ns[r];
-            for (int s = have + lane; s < prm.ns[r]; s += 64) row[s] = fill;
+            bq_pad_row(prm.idx[r] + ((size_t)b * m + c) * prm.ns[r], cnt[ci][r], first[ci][r], prm.ns[r], lane);
         }
     }
 }

@@ -13,6 +13,7 @@
 // index among equal maxima.  Distances are >= 0, so their IEEE bit patterns order like unsigned
 // integers and the reductions run on u32.
 #include "common.h"
+#include "fps_round.h"
 
 namespace {
 
@@ -148,34 +149,13 @@ __global__ __launch_bounds__(NWAVES * 64) void fps_kernel(int n, int m,
     }
 }
 
-// u32 max reductions whose DPP move folds into the max (v_max_u32_dpp): 0 is the identity, so lanes without a valid
-// source (bound_ctrl) or in masked-off rows simply contribute 0
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ unsigned dpp_max_u32(unsigned v) {
-    const unsigned o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, true);
-    return max(v, o);
-}
-__device__ __forceinline__ unsigned row_max_u32_fold(unsigned v) {
-    v = dpp_max_u32<0xB1, 0xF>(v);
-    v = dpp_max_u32<0x4E, 0xF>(v);
-    v = dpp_max_u32<0x141, 0xF>(v);
-    v = dpp_max_u32<0x140, 0xF>(v);
-    return v;
-}
-__device__ __forceinline__ unsigned wave_max_u32_fold(unsigned v) {
-    v = row_max_u32_fold(v);
-    v = dpp_max_u32<0x142, 0xA>(v);  // row_bcast15 -> rows 1,3
-    v = dpp_max_u32<0x143, 0xC>(v);  // row_bcast31 -> rows 2,3
-    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
-}
-
 // Second generation of the register-resident kernel (the default): BLOCKED ownership -- lane l of wave w holds the PPT
 // consecutive points starting at (64w + l) * PPT -- so that "lowest index among equal maxima" is "lowest wave, then
 // lowest lane, then lowest slot": after one DPP max reduction the winner is picked with a ballot + find-first-set +
 // v_readlane instead of a second 6-step reduction (and likewise across waves).  Distances are computed two points
 // per instruction (v_pk_add_f32 / v_pk_mul_f32: same IEEE single operations, unfused), the running minimum and the
 // argmax run on the non-negative floats' bit patterns (v_min_u32 / v_max3_u32: no NaN-canonicalising extras).
-typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef fps_f32x2 f32x2;
 
 template <int NWAVES, int PPT, bool XYZ_LDS>
 __global__ __launch_bounds__(NWAVES * 64) void fps_kernel_blocked(int n_stride, int m, const float *__restrict__ xyz_all,
@@ -250,39 +230,21 @@ __global__ __launch_bounds__(NWAVES * 64) void fps_kernel_blocked(int n_stride, 
         const float oy = XYZ_LDS ? ys[old] : ny;
         const float oz = XYZ_LDS ? zs[old] : nz;
         if (!(XYZ_LDS && defer) && tid == 0) emit(j - 1, ox, oy, oz);
-        const f32x2 o2x = {ox, ox}, o2y = {oy, oy}, o2z = {oz, oz};
         unsigned best = 0u;
-        unsigned q8[H];                         // pairwise maxima of the updated minima
-#pragma unroll
-        for (int h = 0; h < H; ++h) {
-            const f32x2 dx = px[h] - o2x, dy = py[h] - o2y, dz = pz[h] - o2z;
-            const f32x2 d = (dx * dx + dy * dy) + dz * dz;
-            const unsigned b0 = __float_as_uint(d[0]), b1 = __float_as_uint(d[1]);
-            dmin[2 * h] = b0 < dmin[2 * h] ? b0 : dmin[2 * h];
-            dmin[2 * h + 1] = b1 < dmin[2 * h + 1] ? b1 : dmin[2 * h + 1];
-            q8[h] = max(dmin[2 * h], dmin[2 * h + 1]);
-            if constexpr (PPT != 16) best = max(best, q8[h]);
-        }
         int li = PPT - 1;                       // lowest slot of this lane holding `best`
         if constexpr (PPT == 16) {
-            // the maximum through a tree of pairwise maxima, and its lowest slot as a descent through that tree instead of
-            // fifteen compare + select pairs: at every level the LEFT half wins when it holds `best` (lowest slot among equals)
-            unsigned q4[4], q2[2];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) q4[i] = max(q8[2 * i], q8[2 * i + 1]);
-            q2[0] = max(q4[0], q4[1]); q2[1] = max(q4[2], q4[3]);
-            best = max(q2[0], q2[1]);
-            const bool h3 = q2[0] != best;                                   // the maximum is in slots 8..15 only
-            const unsigned a4 = h3 ? q4[2] : q4[0];
-            const bool h2 = a4 != best;
-            const unsigned a8l = h3 ? (h2 ? q8[6] : q8[4]) : (h2 ? q8[2] : q8[0]);
-            const bool h1 = a8l != best;
-            const int p = (h3 ? 4 : 0) + (h2 ? 2 : 0) + (h1 ? 1 : 0);          // pair index 0..7
-            unsigned dl = dmin[0];
-#pragma unroll
-            for (int i = 1; i < 8; ++i) dl = p == i ? dmin[2 * i] : dl;
-            li = 2 * p + (dl != best ? 1 : 0);
+            fps_lane_round16(px, py, pz, dmin, ox, oy, oz, best, li);      // (fps_round.h: shared with the level-1 stream kernel)
         } else {
+            const f32x2 o2x = {ox, ox}, o2y = {oy, oy}, o2z = {oz, oz};
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                const f32x2 dx = px[h] - o2x, dy = py[h] - o2y, dz = pz[h] - o2z;
+                const f32x2 d = (dx * dx + dy * dy) + dz * dz;
+                const unsigned b0 = __float_as_uint(d[0]), b1 = __float_as_uint(d[1]);
+                dmin[2 * h] = b0 < dmin[2 * h] ? b0 : dmin[2 * h];
+                dmin[2 * h + 1] = b1 < dmin[2 * h + 1] ? b1 : dmin[2 * h + 1];
+                best = max(best, max(dmin[2 * h], dmin[2 * h + 1]));
+            }
 #pragma unroll
             for (int i = PPT - 2; i >= 0; --i) li = dmin[i] == best ? i : li;
         }
@@ -317,12 +279,7 @@ __global__ __launch_bounds__(NWAVES * 64) void fps_kernel_blocked(int n_stride, 
                 // four waves: every lane reads the four (maximum, index) pairs as two 16-byte broadcasts and picks the winner
                 // with three strict compares in wave order (ties: the lower wave = the lower indices) -- no cross-lane
                 // reduction, ballot or readlane on the round's critical chain; the pick stays in a (uniform) vector register
-                const uint4 s01 = *reinterpret_cast<const uint4 *>(slot), s23 = *reinterpret_cast<const uint4 *>(slot + 2);
-                unsigned bv = s01.x, bi = s01.y;
-                bi = s01.z > bv ? s01.w : bi; bv = s01.z > bv ? s01.z : bv;
-                bi = s23.x > bv ? s23.y : bi; bv = s23.x > bv ? s23.x : bv;
-                bi = s23.z > bv ? s23.w : bi;
-                old = (int)bi;
+                old = fps_winner_of_four(slot);
                 if (defer) {
                     if (wave == 0) picks[j - j0] = old;
                 } else if (tid == 0) idx[j] = old;

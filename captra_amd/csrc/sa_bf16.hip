@@ -192,8 +192,11 @@ __device__ __forceinline__ float sb_reduce16(float z, const f32x16 &a) {
 // PF (small-input scales): the NEXT pass's gather in flight under this pass's MFMAs -- neighbour ids two passes ahead, raw
 // coordinates / features one pass ahead (a pass of the SA1 scales is 1-2 us of MFMA work behind two dependent global-memory
 // latencies; same arithmetic, same bits)
-template <int CF, int C1, int C2, int C3, int K, bool PRE, int TN, int CG, bool WLDS, int OCC = (WLDS ? 2 : 1), int RGS = 0, bool PF = false, int DBG = 0, int LRD = 1>
-__global__ __launch_bounds__(256, OCC) void sa_bf16_kernel(SbParams p) {
+// The kernel's body as a device function: `job0` = the workgroup's first job (its four waves take job0 .. job0 + 3).  The one-shot
+// kernel below passes blockIdx.x * 4; the level-1 stream kernel (end of this file) calls it once per (window, scale, network)
+// ticket with the window's four jobs.  Ends without a trailing barrier: a caller that re-uses the LDS synchronises first.
+template <int CF, int C1, int C2, int C3, int K, bool PRE, int TN, int CG, bool WLDS, int RGS = 0, bool PF = false, int DBG = 0, int LRD = 1>
+__device__ __forceinline__ void sb_body(const SbParams &p, unsigned char *smem, int job0) {
     using S = SbShape<CF, C1, C2, C3, PRE>;
     constexpr int TPC = K / 32;                        // 32-position tiles per centre
     constexpr int CPP = TN > TPC ? TN / TPC : 1;       // centres per pass
@@ -203,7 +206,6 @@ __global__ __launch_bounds__(256, OCC) void sa_bf16_kernel(SbParams p) {
     constexpr bool STAGE_OUT = CG >= 4;                // results through a wave-private LDS strip, written as 16-byte segments
     static_assert((CG * TPC) % TN == 0 && (PRE || TN == 2) && K % 32 == 0, "shape");
     static_assert(PRE || S::CIN1 + 2 <= 8, "first layer: inputs + two bias rows fit the lower half-wave's eight k-slots");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int WL = WLDS ? S::WBYTES : 0;
     float *bias_lds = reinterpret_cast<float *>(smem + WL);
     float *ost_all = bias_lds + S::NBIAS;
@@ -219,7 +221,7 @@ __global__ __launch_bounds__(256, OCC) void sa_bf16_kernel(SbParams p) {
         for (int e = tid; e < N16; e += 256) dst[e] = src[e];
     }
     __syncthreads();
-    const int job = blockIdx.x * 4 + wave;
+    const int job = job0 + wave;
     if (job >= p.njobs) return;                        // (no barrier below)
     const int b = job / p.jobs_per_cloud;
     const int centre0 = p.m0 + (job % p.jobs_per_cloud) * CG;
@@ -468,6 +470,12 @@ __global__ __launch_bounds__(256, OCC) void sa_bf16_kernel(SbParams p) {
             }
         }
     }
+}
+
+template <int CF, int C1, int C2, int C3, int K, bool PRE, int TN, int CG, bool WLDS, int OCC = (WLDS ? 2 : 1), int RGS = 0, bool PF = false, int DBG = 0, int LRD = 1>
+__global__ __launch_bounds__(256, OCC) void sa_bf16_kernel(SbParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    sb_body<CF, C1, C2, C3, K, PRE, TN, CG, WLDS, RGS, PF, DBG, LRD>(p, smem, blockIdx.x * 4);
 }
 
 // ---- SA2 scales, second form: the epilogues UNDER the MFMAs ------------------------------------------------------------
@@ -809,6 +817,366 @@ extern "C" int captra_sa_scale_bf16(int b, int n, int m, int k, int cfeat, int c
 }
 
 extern "C" void captra_sa_bf16_set_variant(int v) { g_sb_variant = v; }
+
+// ======================================================================================================================
+// LEVEL-1 STREAM KERNEL: the 4096 -> 512 sampler, the ball query and the SA1 scales of the networks that share the cloud in ONE
+// launch (reference pointnet_utils.py:214-249 PointNetSetAbstractionMsg.forward + sampling_gpu.cu:93-209 + ball_query_gpu.cu:9-45).
+//
+// The sampler is 511 dependent rounds on ONE workgroup per cloud: at 32 clouds, 0.24 ms with 224 of 256 CUs idle, and a fifth of
+// the bf16 step (no schedule of separate launches hides it -- a window of centres is one round of work for kernels
+// that lose B CUs to the sampler).  Here workgroups 0 .. B-1 run the sampler's loop (fps_round.h: the same rounds as
+// fps_kernel_blocked<4, 16>) and PUBLISH every 8 picks as 8-byte {tag, pick} granules (one write-through store per lane: the data
+// is the flag, MI355X_MICROARCH.md "R2"); every other workgroup -- and the sampler workgroups once they are done -- pulls TICKETS
+// (window of 32 centres, scale, cloud) from one counter in window order, polls the window's granules, stages the cloud in LDS,
+// runs the ball query of its scale for the window's centres (bq_scan.h: the same scan as ball_query_kernel) and then the scale's
+// shared MLPs of every network on the lists it just wrote (sb_body: the same code as sa_bf16_kernel).  Nothing crosses workgroups
+// but the granules: lists and centre coordinates are read back by the workgroup that wrote them.  Samplers have the lowest block
+// ids (dispatched first) and wait for nobody, a ticket holder waits only for a sampler: no circular wait whatever the residency;
+// every spin is bounded (ctl[1] != 0 afterwards = a consumer gave up).  Picks, lists and pooled features are bit-identical to
+// captra_fps_gather + captra_ball_query_multi + 3 x captra_sa_scale_bf16 per network (tests/test_l1_stream_gpu.py).
+// ======================================================================================================================
+#include "bq_scan.h"
+#include "fps_round.h"
+
+namespace {
+
+typedef __attribute__((address_space(1))) unsigned long long l1_gu64;
+typedef __attribute__((address_space(1))) unsigned l1_gu32;
+
+struct L1Net {
+    const float *feat;                  // (B,CF,N) fp32, or null (CF = 0)
+    const unsigned char *img[3];        // captra_pack_sa_bf16 images of the three scales
+    float *out;                         // (B,out_ctotal,M)
+    int out_ctotal, co_off[3];
+};
+struct L1Params {
+    int b, n, m;
+    const float *xyz_n3, *xyz_cn;
+    const float *planes;                // (B,3,pad256(N)) the clouds in the ball query's LDS plane order (captra_bq_planes), or null
+    int *fps_idx;
+    float *new_n3, *new_cn;
+    int *idx[3];
+    float r2[3];
+    unsigned long long *gran;           // (B,M) granules {1, pick}; zeroed before the launch
+    unsigned *ctl;                      // [0] ticket counter, [1] give-up flag; zeroed before the launch
+    unsigned long long spin_limit;      // s_memrealtime ticks (100 MHz) a consumer waits for one window
+    int prio;                           // s_setprio of the sampler's waves
+    int nfine;                          // trailing centres handed out as fine windows of 8 (multiple of 32)
+    int dbg;                            // timing experiments (results wrong): 1 = no ball-query scan, 2 = no MLPs, 4 = no cloud staging, 8 = no consumers, 16 = no sampling (picks of an earlier launch)
+    L1Net net[2];
+};
+
+constexpr int L1_REGION_A = 57344;      // SA body (image + biases + strips <= 56192) | cloud planes (49152) | sampler (51456)
+constexpr int L1_LDS = L1_REGION_A + 1024;
+
+// one network's scale s on the window's four jobs (a wave = CG consecutive centres from c0 + CG * wave)
+template <int CF, int C1, int C2, int C3, int K, bool PF, int CG>
+__device__ __forceinline__ void l1_scale(const L1Params &p, const L1Net &net, int s, int b, int c0, int nc, unsigned char *smem) {
+    SbParams q;
+    q.n = p.n; q.m = p.m; q.feat = net.feat; q.v1pm = nullptr; q.xyz_cn = p.xyz_cn; q.new_xyz = p.new_n3; q.idx = p.idx[s];
+    q.img = net.img[s]; q.out = net.out; q.out_ctotal = net.out_ctotal; q.co_off = net.co_off[s];
+    q.jobs_per_cloud = 4; q.njobs = b * 4 + nc / CG; q.m0 = c0; q.mhi = p.m; q.prof = nullptr;      // (waves beyond the jobs leave after staging)
+    sb_body<CF, C1, C2, C3, K, false, 2, CG, true, 0, PF, 0, 4>(q, smem, b * 4);
+}
+
+// a ticket's work: the ball query of centres [c0, c0 + nc) at scale s (nc / 4 per wave), then the scale's shared MLPs of the
+// networks in `nets` (bit 0 / bit 1) on the lists just written (CG centres per wave: nc / CG waves work)
+template <int CFA, int CFB, int C1, int C2, int C3, int K, bool PF, int CG>
+__device__ __forceinline__ void l1_item(const L1Params &p, int s, int b, int c0, int nc, int nets, unsigned char *smem, const float *ctr, int *next_ticket, int tid, int lane, int wave) {
+    float *xs = reinterpret_cast<float *>(smem), *ys = xs + bq_pad(p.n), *zs = ys + bq_pad(p.n);
+    // (a wave's centres four at a time against every group of the cloud: bq_scan.h)
+    const int per_wave = (p.dbg & 1) ? 0 : nc / 4;
+#pragma unroll 1
+    for (int ci = 0; ci < per_wave; ci += 4) {
+        float cx[4], cy[4], cz[4];
+        int *row[4];
+        int cnt[4], first[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool live = ci + u < per_wave;
+            const int cl = per_wave * wave + (live ? ci + u : ci);
+            cx[u] = ctr[3 * cl + 0]; cy[u] = ctr[3 * cl + 1]; cz[u] = ctr[3 * cl + 2];
+            row[u] = p.idx[s] + ((size_t)b * p.m + c0 + cl) * K;
+            cnt[u] = live ? 0 : K;                     // (a slot beyond the wave's centres: closed from the start, writes nothing)
+            first[u] = 0;
+        }
+        bq_scan_centres<4>(xs, ys, zs, bq_pad(p.n) >> 8, 0, cx, cy, cz, p.r2[s], K, row, cnt, first, lane);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (ci + u < per_wave) bq_pad_row(row[u], cnt[u], first[u], K, lane);
+    }
+    __syncthreads();                                   // the lists are written (vmcnt drained), the planes are free
+    // the NEXT ticket is fetched in front of the ticket's last MLP run and handed over behind it: the fetch's latency is off the
+    // path, and the ticket waits for this workgroup for one run only (fetched at the ticket's start it sat out the whole ticket while
+    // other workgroups idled at the end: consumers alone 350 -> 381 us at 32 clouds)
+    l1_gu32 *ctl = (l1_gu32 *)p.ctl;
+    unsigned tn = 0u;
+    const bool fetcher = tid == 0;
+    if ((p.dbg & 2) || !(CFB >= 0 && nets == 3)) {
+        if (fetcher) tn = __hip_atomic_fetch_add(ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (!(p.dbg & 2)) {
+        if (nets & 1) l1_scale<CFA, C1, C2, C3, K, PF, CG>(p, p.net[0], s, b, c0, nc, smem);
+        if constexpr (CFB >= 0) {
+            if (nets == 3) {
+                __syncthreads();
+                if (fetcher) tn = __hip_atomic_fetch_add(ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (nets & 2) l1_scale<CFB, C1, C2, C3, K, PF, CG>(p, p.net[1], s, b, c0, nc, smem);
+        }
+    }
+    if (fetcher) *next_ticket = (int)tn;
+}
+
+template <int CFA, int CFB>
+__global__ __launch_bounds__(256, 2) void l1_stream_kernel(L1Params p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int *s_word = reinterpret_cast<int *>(smem + L1_REGION_A);          // [0], [1] tickets, [2] window ok
+    float *ctr = reinterpret_cast<float *>(s_word + 4);                 // [32][3]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    l1_gu64 *gran = (l1_gu64 *)p.gran;
+    l1_gu32 *ctl = (l1_gu32 *)p.ctl;
+
+    if ((int)blockIdx.x < p.b && (p.dbg & 16)) {
+        // (timing experiment: the picks of an earlier launch, published at once -- the consumers' own throughput)
+        for (int j = tid; j < p.m; j += 256)
+            __hip_atomic_store(gran + (size_t)blockIdx.x * p.m + j, (1ull << 32) | (unsigned)p.fps_idx[(size_t)blockIdx.x * p.m + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if ((int)blockIdx.x < p.b) {
+        // ---- sampler: cloud blockIdx.x, four waves x 16 points per lane, the rounds of fps_kernel_blocked<4, 16, true> --------------
+        const int b = blockIdx.x, n = p.n, m = p.m;
+        uint2 *slots = reinterpret_cast<uint2 *>(smem);                 // [2][16] ping-pong
+        float *xs = reinterpret_cast<float *>(smem + 2 * 16 * sizeof(uint2));
+        float *ys = xs + 4096, *zs = ys + 4096;
+        int *picks = reinterpret_cast<int *>(zs + 4096);
+        const float *xyz = p.xyz_n3 + (size_t)b * n * 3;
+        const int base = tid * 16;
+        fps_f32x2 px[8], py[8], pz[8];
+        unsigned dmin[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int k = base + i;
+            float x = 0.f, y = 0.f, z = 0.f;
+            unsigned d0 = 0u;                  // slots beyond n: distance 0 forever, highest indices -> never preferred
+            if (k < n) {
+                x = xyz[(size_t)k * 3 + 0]; y = xyz[(size_t)k * 3 + 1]; z = xyz[(size_t)k * 3 + 2];
+                d0 = __float_as_uint(1e10f);
+                xs[k] = x; ys[k] = y; zs[k] = z;
+            }
+            px[i / 2][i & 1] = x; py[i / 2][i & 1] = y; pz[i / 2][i & 1] = z;
+            dmin[i] = d0;
+        }
+        if (tid == 0) picks[0] = 0;
+        __syncthreads();
+        if (p.prio > 0) __builtin_amdgcn_s_setprio(3);
+        int old = 0;
+        // eight rounds, then their picks as one granule per lane (the wave's own LDS writes: in order): the round itself carries no
+        // publishing code (inside the round it compiled to exec-masked LDS reads and a store on every round: 213 instructions for 171)
+#pragma unroll 1
+        for (int j8 = 0; j8 < m; j8 += 8) {
+#pragma unroll 1
+            for (int j = j8 > 0 ? j8 : 1; j < j8 + 8; ++j) {
+                const float ox = xs[old], oy = ys[old], oz = zs[old];
+                unsigned best, wmax, widx;
+                int li;
+                fps_lane_round16(px, py, pz, dmin, ox, oy, oz, best, li);
+                fps_wave_winner(best, li, base, wmax, widx);
+                uint2 *slot = slots + (j & 1) * 16;
+                if (lane == 0) slot[wave] = make_uint2(wmax, widx);
+                __syncthreads();
+                old = fps_winner_of_four(slot);
+                if (wave == 0) picks[j] = old;
+            }
+            if (wave == 0 && lane < 8)
+                __hip_atomic_store(gran + (size_t)b * m + j8 + lane, (1ull << 32) | (unsigned)picks[j8 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (p.prio > 0) __builtin_amdgcn_s_setprio(0);
+        __syncthreads();
+        for (int j = tid; j < m; j += 256) p.fps_idx[(size_t)b * m + j] = picks[j];
+        __syncthreads();
+    }
+
+    // ---- consumer: tickets in window order -------------------------------------------------------------------------------------
+    // COARSE windows of 32 centres (a ticket = window, scale, cloud: ball query once, every network's MLPs) for all but the last 32
+    // centres, then FINE windows of 8 (a ticket = window, scale, network, cloud; two waves x 4 centres in the MLPs): what is left when the sampler
+    // ends -- the backlog and the last window -- is many short tickets for the whole chip instead of a few long ones (a coarse
+    // K = 128 ticket is 110 us of one workgroup: 8 centres per wave through the scan, then 16 MLP passes per wave and network)
+    constexpr int NNET = CFB >= 0 ? 2 : 1;
+    const int wc = (p.m - p.nfine) / 32;               // coarse windows
+    const int coarse = wc * 3 * p.b, total = (p.dbg & 8) ? 0 : coarse + (p.nfine / 8) * 3 * NNET * p.b;
+    // s_word[0 / 1]: this ticket / the next one (l1_item fetches it); s_word[2]: window ok
+    if (tid == 0) s_word[0] = total > 0 ? (int)__hip_atomic_fetch_add(ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    for (int it = 0;; ++it) {
+        __syncthreads();                               // (every wave is out of the previous ticket's LDS; the ticket word is there)
+        const int t = s_word[it & 1];
+        if (t >= total) break;
+        const bool fine = t >= coarse;
+        int c0, nc, s, b, nets;                        // first centre, centres, scale (the widest of a window first), cloud, networks
+        if (!fine) {
+            const int w = t / (3 * p.b), r = t % (3 * p.b);
+            c0 = 32 * w; nc = 32; s = 2 - r / p.b; b = r % p.b; nets = NNET == 2 ? 3 : 1;
+        } else {
+            const int tf = t - coarse, per = 3 * NNET * p.b;
+            const int w = tf / per, r = tf % per;
+            c0 = 32 * wc + 8 * w; nc = 8; s = 2 - r / (NNET * p.b);
+            const int r2 = r % (NNET * p.b);
+            nets = 1 << (r2 / p.b); b = r2 % p.b;
+        }
+        if (wave == 0) {
+            // wave 0: this window's granules -- one relaxed device-scope load per lane until every tag is there --, then the centres: coordinates into LDS (ball query) and into new_xyz in both layouts
+            // (the SA body and everything behind this launch read them there; the tickets of a window write the same values)
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            unsigned long long g = 1ull << 32;
+            bool ok;
+            for (;;) {
+                if (lane < nc) g = __hip_atomic_load(gran + (size_t)b * p.m + c0 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = __all((g >> 32) == 1ull);
+                if (ok || __builtin_amdgcn_s_memrealtime() - t0 > p.spin_limit) break;
+                __builtin_amdgcn_s_sleep(16);
+            }
+            if (lane == 0) s_word[2] = ok ? 1 : 0;
+            if (ok && lane < nc) {
+                const int id = (int)(unsigned)g, c = c0 + lane;
+                const float *q = p.xyz_n3 + ((size_t)b * p.n + id) * 3;
+                const float x = q[0], y = q[1], z = q[2];
+                ctr[3 * lane + 0] = x; ctr[3 * lane + 1] = y; ctr[3 * lane + 2] = z;
+                float *d3 = p.new_n3 + ((size_t)b * p.m + c) * 3;
+                d3[0] = x; d3[1] = y; d3[2] = z;
+                float *dc = p.new_cn + (size_t)b * 3 * p.m + c;
+                dc[0] = x; dc[p.m] = y; dc[2 * (size_t)p.m] = z;
+            }
+        } else if (!(p.dbg & 4)) {
+            // waves 1-3: the cloud into the LDS planes (from the caller's plane image when there is one: straight 16-byte copies)
+            float *xs = reinterpret_cast<float *>(smem), *ys = xs + bq_pad(p.n), *zs = ys + bq_pad(p.n);
+            if (p.planes != nullptr) {
+                const float4 *src = reinterpret_cast<const float4 *>(p.planes + (size_t)b * 3 * bq_pad(p.n));
+                float4 *dst = reinterpret_cast<float4 *>(smem);
+                const int n16 = 3 * bq_pad(p.n) / 4;
+                for (int e = tid - 64; e < n16; e += 192) dst[e] = src[e];
+            } else {
+                bq_stage_tile(p.xyz_n3 + (size_t)b * p.n * 3, 0, p.n, xs, ys, zs, tid - 64, 192);
+            }
+        }
+        __syncthreads();
+        if (!s_word[2]) {
+            // gave up: flag it and push the ticket counter past the end, so that every other workgroup leaves at its next fetch
+            if (tid == 0) {
+                __hip_atomic_fetch_or(ctl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(ctl, 1u << 30, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            break;
+        }
+        if (!fine) {
+            if (s == 2) l1_item<CFA, CFB, 64, 96, 128, 128, true, 8>(p, s, b, c0, nc, nets, smem, ctr, s_word + ((it & 1) ^ 1), tid, lane, wave);
+            else if (s == 1) l1_item<CFA, CFB, 64, 64, 128, 64, true, 8>(p, s, b, c0, nc, nets, smem, ctr, s_word + ((it & 1) ^ 1), tid, lane, wave);
+            else l1_item<CFA, CFB, 32, 32, 64, 32, false, 8>(p, s, b, c0, nc, nets, smem, ctr, s_word + ((it & 1) ^ 1), tid, lane, wave);
+        } else {
+            if (s == 2) l1_item<CFA, CFB, 64, 96, 128, 128, true, 4>(p, s, b, c0, nc, nets, smem, ctr, s_word + ((it & 1) ^ 1), tid, lane, wave);
+            else if (s == 1) l1_item<CFA, CFB, 64, 64, 128, 64, true, 4>(p, s, b, c0, nc, nets, smem, ctr, s_word + ((it & 1) ^ 1), tid, lane, wave);
+            else l1_item<CFA, CFB, 32, 32, 64, 32, false, 4>(p, s, b, c0, nc, nets, smem, ctr, s_word + ((it & 1) ^ 1), tid, lane, wave);
+        }
+    }
+}
+
+// the clouds in the ball query's LDS plane order (bq_scan.h), once per cloud instead of once per ticket
+__global__ __launch_bounds__(256) void bq_planes_kernel(int n, const float *__restrict__ xyz_n3, float *__restrict__ planes) {
+    const int b = blockIdx.y, npad = bq_pad(n);
+    const int pt = blockIdx.x * 256 + threadIdx.x;
+    if (pt >= npad) return;
+    const bool inb = pt < n;
+    const float *q = xyz_n3 + ((size_t)b * n + (inb ? pt : 0)) * 3;
+    const float inf = __builtin_inff();
+    const int chunk = pt >> 6;
+    const int a = (((chunk >> 2) << 6) + (pt & 63)) * 4 + (chunk & 3);
+    float *d = planes + (size_t)b * 3 * npad;
+    d[a] = inb ? q[0] : inf;
+    d[npad + a] = inb ? q[1] : inf;
+    d[2 * npad + a] = inb ? q[2] : inf;
+}
+
+template <int CFA, int CFB>
+int l1_launch(const L1Params &p, int grid, hipStream_t stream) {
+    auto kern = l1_stream_kernel<CFA, CFB>;
+    static CaptraDeviceOnce once;
+    if (once.first_use()) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, L1_LDS) != hipSuccess) return (int)hipGetLastError();
+        once.done();
+    }
+    CAPTRA_LAUNCH("l1_stream", kern, dim3(grid), dim3(256), L1_LDS, stream, p);
+    return captra_last_error();
+}
+
+CAPTRA_KNOB int g_l1_grid = 0;          // experiment knob: workgroups of the stream kernel (0 = two per CU)
+CAPTRA_KNOB int g_l1_prio = 1;
+CAPTRA_KNOB int g_l1_fine = 32;
+CAPTRA_KNOB int g_l1_dbg = 0;
+
+}  // namespace
+
+extern "C" void captra_sa1_stream_set_grid(int grid, int prio) { g_l1_grid = grid; g_l1_prio = prio; }
+extern "C" void captra_sa1_stream_set_fine(int centres) { g_l1_fine = centres & 0xFFFF; g_l1_dbg = centres >> 16; }   // (bits 16..: timing ablations, results wrong)
+
+// planes (B,3,pad256(N)) <- xyz_n3 (B,N,3): element ((chunk / 4) * 64 + lane) * 4 + chunk % 4 of plane a = coordinate a of point
+// 64 chunk + lane; slots beyond N hold +inf
+extern "C" int captra_bq_planes(int b, int n, const float *xyz_n3, float *planes, captra_stream_t stream) {
+    if (b < 0 || n < 1) return -1;
+    if (b == 0) return 0;
+    CAPTRA_LAUNCH("bq_planes", bq_planes_kernel, dim3((bq_pad(n) + 255) / 256, b), dim3(256), 0, (hipStream_t)stream, n, xyz_n3, planes);
+    return captra_last_error();
+}
+
+extern "C" long long captra_sa1_stream_scratch_bytes(int b, int m) {
+    if (b < 0 || m < 0) return -1;
+    return (long long)b * m * 8 + 64;
+}
+
+// Level 1 of PointNet2Msg for the networks that share a cloud, in one launch: sampling (fps_idx, new_xyz in both layouts), the three
+// ball queries (idx3[s] (B,M,K_s), K = 32 / 64 / 128) and the pooled features out_a / out_b (B,320,M) of the CAPTRA SA1 shapes
+// [CF+3 -> 32 -> 32 -> 64], [-> 64 -> 64 -> 128], [-> 64 -> 96 -> 128] for input features feat_a (B,cfa,N) / feat_b (B,cfb,N), cf in {0, 3}
+// (feat null for 0); cfb < 0: one network.  img_*: the scales' captra_pack_sa_bf16 images (pre = 0).  scratch:
+// captra_sa1_stream_scratch_bytes(b, m) bytes, zeroed here on `stream`; after completion ((unsigned *)(scratch + b*m*8))[1] != 0
+// means a consumer gave up waiting for the sampler (outputs incomplete).  -2: shape outside the kernel (n <= 4096, m <= 512, m % 32 == 0).
+extern "C" int captra_sa1_stream_bf16(int b, int n, int m, const float *xyz_n3, const float *xyz_cn, const float *planes, const float *radius3, int *fps_idx,
+                                      float *new_n3, float *new_cn, int *const *idx3, int cfa, const float *feat_a,
+                                      const unsigned char *const *img_a3, float *out_a, int cfb, const float *feat_b,
+                                      const unsigned char *const *img_b3, float *out_b, void *scratch, captra_stream_t stream) {
+    if (b < 0 || n < 1 || m < 1) return -1;
+    if (n > 4096 || m > 512 || m % 32 || m > n) return -2;
+    if (!((cfa == 0 || cfa == 3) && (cfb < 0 || cfb == 0 || cfb == 3))) return -2;
+    if (b == 0) return 0;
+    if (b > 256) return -2;
+    hipStream_t st = (hipStream_t)stream;
+    const long long sbytes = captra_sa1_stream_scratch_bytes(b, m);
+    if (hipMemsetAsync(scratch, 0, (size_t)sbytes, st) != hipSuccess) return (int)hipGetLastError();
+    L1Params p;
+    p.b = b; p.n = n; p.m = m; p.xyz_n3 = xyz_n3; p.xyz_cn = xyz_cn; p.planes = planes; p.fps_idx = fps_idx; p.new_n3 = new_n3; p.new_cn = new_cn;
+    for (int s = 0; s < 3; ++s) { p.idx[s] = idx3[s]; p.r2[s] = radius3[s] * radius3[s]; }
+    p.gran = reinterpret_cast<unsigned long long *>(scratch);
+    p.ctl = reinterpret_cast<unsigned *>(reinterpret_cast<unsigned char *>(scratch) + (size_t)b * m * 8);
+    p.spin_limit = 2000000ull;          // 20 ms of the 100 MHz counter: a sampler takes 0.25 ms
+    p.prio = g_l1_prio;
+    p.dbg = g_l1_dbg;
+    p.nfine = g_l1_fine < 0 ? 0 : (g_l1_fine > m ? m : g_l1_fine) / 32 * 32;
+    const int coff[3] = {0, 64, 192};
+    for (int s = 0; s < 3; ++s) {
+        p.net[0].img[s] = img_a3[s]; p.net[0].co_off[s] = coff[s];
+        p.net[1].img[s] = cfb >= 0 ? img_b3[s] : nullptr; p.net[1].co_off[s] = coff[s];
+    }
+    p.net[0].feat = cfa ? feat_a : nullptr; p.net[0].out = out_a; p.net[0].out_ctotal = 320;
+    p.net[1].feat = cfb > 0 ? feat_b : nullptr; p.net[1].out = out_b; p.net[1].out_ctotal = 320;
+    int grid = g_l1_grid;
+    if (grid <= 0) {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        grid = 2 * cus;
+    }
+    if (grid < b + 1) grid = b + 1;
+    if (cfa == 0 && cfb == 3) return l1_launch<0, 3>(p, grid, st);
+    if (cfa == 3 && cfb == 0) return l1_launch<3, 0>(p, grid, st);
+    if (cfa == 0 && cfb < 0) return l1_launch<0, -1>(p, grid, st);
+    if (cfa == 3 && cfb < 0) return l1_launch<3, -1>(p, grid, st);
+    return -2;
+}
 
 // ======================================================================================================================
 // Dense CHAIN, register-resident: FP1's shared MLP + the backbone's conv1 (pointnet_utils.py:296-298, backbones.py:66-68) and,

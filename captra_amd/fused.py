@@ -515,6 +515,78 @@ def fps_gather_part(xyz_n3, m: int, j0: int, j1: int, bufs):
         L.call("captra_fps_gather_part", B, N, m, j0, j1, L.ptr(xyz_n3), L.ptr(state), L.ptr(idx), L.ptr(n3), L.ptr(cn))
 
 
+# CAPTRA's first set-abstraction level (configs/pointnet_config/pointnet2_*.yml sa1): what the level-1 stream kernel is built for
+_L1_STREAM_WIDTHS = ((32, 32, 64), (64, 64, 128), (64, 96, 128))
+_L1_STREAM_K = (32, 64, 128)
+USE_L1_STREAM = os.environ.get("CAPTRA_L1_STREAM", "1") != "0"
+
+
+def sa1_stream_supported(n: int, sa_modules, cfeats) -> bool:
+    """`sa_modules`: the PointNetSetAbstractionMsg modules (one or two) whose level runs in the stream kernel, `cfeats` their
+    feature-channel counts.  bf16 mode, CAPTRA's SA1 shapes, clouds of <= 4096 points."""
+    if not (USE_L1_STREAM and mlp_dtype() == "bf16" and 1 <= len(sa_modules) <= 2 and n <= 4096):
+        return False
+    first = sa_modules[0]
+    for mod, cf in zip(sa_modules, cfeats):
+        if mod.training or mod.knn or cf not in (0, 3) or tuple(mod.nsample_list) != _L1_STREAM_K or mod.npoint > 512 or mod.npoint % 32:
+            return False
+        if mod.npoint != first.npoint or tuple(mod.radius_list) != tuple(first.radius_list):
+            return False
+        folded = mod._folded
+        if folded is None or tuple(tuple(l.cout for l in layers) for layers in folded) != _L1_STREAM_WIDTHS:
+            return False
+    return True
+
+
+def bq_planes(xyz_n3):
+    """(B,N,3) -> (B,3,pad256(N)): the clouds in the ball query's LDS plane order (captra_bq_planes)."""
+    L.require_device(xyz_n3)
+    B, N, _ = xyz_n3.shape
+    out = torch.empty(B, 3, (N + 255) // 256 * 256, dtype=torch.float32, device=xyz_n3.device)
+    with torch.cuda.device(xyz_n3.device):
+        L.call("captra_bq_planes", B, N, L.ptr(xyz_n3), L.ptr(out))
+    return out
+
+
+def sa1_stream_bf16(xyz_n3, xyz_cn, sa_modules, feats, planes=None):
+    """Level 1 of the backbones in `sa_modules` on the SAME cloud in one launch (captra_sa1_stream_bf16): sampling, the three ball
+    queries and every network's pooled SA1 features.  feats[i]: (B,cf,N) or None.  -> (fps_idx, new_xyz (B,M,3), new_xyz (B,3,M),
+    [idx (B,M,K)] * 3, [out (B,320,M)] per network, scratch).  scratch[-16:].view(int32)[1] != 0 after completion = a consumer gave up."""
+    L.require_device(xyz_n3, xyz_cn, *[f for f in feats if f is not None])
+    B, N, _ = xyz_n3.shape
+    first = sa_modules[0]
+    M = first.npoint
+    dev = xyz_n3.device
+    idx = torch.empty(B, M, dtype=torch.int32, device=dev)
+    n3 = torch.empty(B, M, 3, dtype=torch.float32, device=dev)
+    cn = torch.empty(B, 3, M, dtype=torch.float32, device=dev)
+    lists = [torch.empty(B, M, k, dtype=torch.int32, device=dev) for k in _L1_STREAM_K]
+    outs = [torch.empty(B, 320, M, dtype=torch.float32, device=dev) for _ in sa_modules]
+    nbytes = L.lib().captra_sa1_stream_scratch_bytes(B, M)
+    scratch = torch.empty(nbytes // 8, dtype=torch.int64, device=dev)
+    cfs = [0 if f is None else f.shape[1] for f in feats]
+    imgs = [[sa_bf16_image(layers, cf, False) for layers in mod._folded] for mod, cf in zip(sa_modules, cfs)]
+    P = C.c_void_p
+    lp = (P * 3)(*[t.data_ptr() for t in lists])
+    ia = (P * 3)(*[t.data_ptr() for t in imgs[0]])
+    ib = (P * 3)(*[t.data_ptr() for t in imgs[1]]) if len(imgs) > 1 else (P * 3)()
+    rad = (C.c_float * 3)(*[float(r) for r in first.radius_list])
+    with torch.cuda.device(dev):
+        L.call("captra_sa1_stream_bf16", B, N, M, L.ptr(xyz_n3), L.ptr(xyz_cn), L.ptr(planes), rad, L.ptr(idx), L.ptr(n3), L.ptr(cn), lp,
+               cfs[0], L.ptr(feats[0]), ia, L.ptr(outs[0]), cfs[1] if len(cfs) > 1 else -1, L.ptr(feats[1]) if len(feats) > 1 else None,
+               ib, L.ptr(outs[1]) if len(outs) > 1 else None, L.ptr(scratch))
+    for mod, cf in zip(sa_modules, cfs):
+        for (l1, l2, l3), k in zip(mod._folded, _L1_STREAM_K):
+            _work("sa_scale_fused", flops=2.0 * B * M * k * ((cf + 3) * l1.cout + l1.cout * l2.cout + l2.cout * l3.cout),
+                  nbytes=4.0 * B * (cf * N + 3 * N + M * k + 3 * M + l3.cout * M))
+    return idx, n3, cn, lists, outs, scratch
+
+
+def sa1_stream_gave_up(scratch) -> bool:
+    """True when a consumer of the stream kernel's launch that used `scratch` gave up waiting (synchronises)."""
+    return bool(scratch.view(torch.int32)[-15].item())
+
+
 USE_SA_PRE = True        # SA scales with many feature channels: first layer's feature part once per source point
 _SA_PRE_SHAPES = {(320, 128, 128, 256), (320, 128, 196, 256)}   # csrc/sa_fused.hip SWP_CASE list
 

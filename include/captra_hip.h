@@ -343,6 +343,28 @@ int captra_fps_gather_part(int b, int n, int m, int j0, int j1, const float *xyz
  * one is set.  Thread-local. */
 void captra_set_centre_window(int m0, int mc);
 
+/* LEVEL-1 STREAM (csrc/sa_bf16.hip, bf16 mode): everything PointNetSetAbstractionMsg.forward (pointnet_utils.py:214-249) does at the
+ * first level of PointNet2Msg, for the (one or two) networks that share a cloud, in ONE launch -- furthest point sampling
+ * (sampling_gpu.cu:93-209; fps_idx (B,M), new_xyz in both layouts), the three ball queries (ball_query_gpu.cu:9-45; idx3[s]
+ * (B,M,K_s), K = 32 / 64 / 128, radius3[s]) and the pooled features out_a / out_b (B,320,M) of the CAPTRA SA1 shapes
+ * [cf+3 -> 32 -> 32 -> 64], [-> 64 -> 64 -> 128], [-> 64 -> 96 -> 128] on feat_a (B,cfa,N) / feat_b (B,cfb,N), cf in {0, 3} (feat NULL for
+ * 0; cfb < 0: one network).  B workgroups run the sampler's dependent rounds and publish every 32 picks; all other workgroups
+ * consume (window, scale, cloud) tickets -- ball query of the window's centres, then the scale's shared MLPs -- while the sampler
+ * picks on, so the 0.24 ms it used to hold the step alone are filled.  Every output equals captra_fps_gather +
+ * captra_ball_query_multi + 3 x captra_sa_scale_bf16 per network, bit for bit.  img_*3[s]: the scales' captra_pack_sa_bf16 images
+ * (pre = 0).  scratch: captra_sa1_stream_scratch_bytes(b, m) bytes, zeroed by the call on `stream`; once the launch completed,
+ * word 1 of the 16 unsigned words at scratch + 8*b*m is non-zero iff a consumer gave up waiting (bounded spins; outputs incomplete
+ * then).  planes (optional, NULL = staged from xyz_n3 by every ticket): the clouds once more, (B,3,pad256(N)) in the ball query's LDS
+ * plane order (captra_bq_planes: element ((chunk / 4) * 64 + lane) * 4 + chunk % 4 of plane a = coordinate a of point 64 chunk + lane, +inf
+ * beyond N), so that a ticket's staging is straight 16-byte copies.  -2: n > 4096, m > 512, m % 32 != 0, b > 256 or feature counts
+ * outside {0, 3}. */
+long long captra_sa1_stream_scratch_bytes(int b, int m);
+int captra_bq_planes(int b, int n, const float *xyz_n3, float *planes, captra_stream_t stream);
+int captra_sa1_stream_bf16(int b, int n, int m, const float *xyz_n3, const float *xyz_cn, const float *planes, const float *radius3, int *fps_idx,
+                           float *new_xyz_n3, float *new_xyz_cn, int *const *idx3, int cfa, const float *feat_a,
+                           const unsigned char *const *img_a3, float *out_a, int cfb, const float *feat_b,
+                           const unsigned char *const *img_b3, float *out_b, void *scratch, captra_stream_t stream);
+
 /* SA scale with a pre-transformed first layer.  Layer 1's k-ascending chain runs over the cfeat feature rows first and the
  * three relative-xyz rows last (pointnet_utils.py:234-240), and its first cfeat steps depend on the SOURCE point only:
  *   v1 (B,c1,N) = captra_pointwise_mlp(feat (B,cfeat,N), w1 rows 0..cfeat-1, b1, CAPTRA_ACT_NONE)      (once per source point)
@@ -505,6 +527,8 @@ void captra_pw_set_direct(int on);          /* dense layers: 1 = direct-operand 
 void captra_ball_query_set_prune(int on);   /* ball query: 1 = small radii of 1024..4096-point clouds from a cell grid (exact; measured slower, off by default), 0 = index-order scan */
 void captra_pw_set_occupancy(int occ);      /* dense layers, 64x64 wave tiles: workgroups per CU, 0 / 4 = as built (default), 3 / 2 = fewer (measurements) */
 void captra_pw_set_pair(int on);            /* dense layers: 1 = paired column tiles where L is even (default), 0 = never */
+void captra_sa1_stream_set_grid(int grid, int prio); /* level-1 stream kernel: workgroups (0 = two per CU), 1 = samplers at s_setprio 3 (default) */
+void captra_sa1_stream_set_fine(int centres); /* level-1 stream kernel: trailing centres handed out as fine tickets of 8 (multiple of 32, default 32) */
 void captra_sa_bf16_set_variant(int v);     /* bf16 SA scales: bit 0 = small-input scales without gather prefetch / fragment ring, bits 1-2 = ring depth
                                                4 / 2 / 3 / 6, bits 4.. = ablations (coalesced gather, eight fragments only, no stores: WRONG results, timing only) */
 void captra_group_set_shape(int lds_kb, int ccmax, int ppb); /* group_points: staging budget (KiB, <= 64), channels per workgroup, positions per
