@@ -443,7 +443,7 @@ def config_leg(name: str, extra: list, timeout_s: int = 120):
     if res.returncode != 0 or not lines:
         return {"error": (res.stderr or res.stdout)[-500:], "command": " ".join(cmd[1:])}
     d = json.loads(lines[-1])
-    keep = ("metric", "value", "unit", "ms_per_step", "dtype", "steps", "roofline", "kernel_ms_per_step", "timed_blocks", "config", "one_graph")
+    keep = ("metric", "value", "unit", "ms_per_step", "dtype", "steps", "roofline", "kernel_ms_per_step", "timed_blocks", "config", "one_graph", "l1_stream")
     out = {k: d[k] for k in keep if k in d}
     if isinstance(out.get("config"), dict):
         out["config"] = {k: out["config"].get(k) for k in ("workload", "launch") if out["config"].get(k)}
@@ -731,6 +731,12 @@ def main():
         last_pose = {k: v.clone() for k, v in step(done, prev_pose).items()}
     last_frame = frame_of(done)
     torch.cuda.synchronize()
+    # the level-1 stream kernel's own stamps of the step just replayed (100 MHz counter): where the sampler ended inside the launch
+    l1_spans = None
+    if getattr(model, "_l1_scratch", None) is not None:
+        model.check_l1_stream()
+        sp = fused.sa1_stream_spans(model._l1_scratch)
+        l1_spans = {"sampler_us": round(sp[0], 1), "launch_us": round(sp[1], 1)}
     timed_steps = args.steps
     if timing and not eager_timing:
         # the timed blocks replayed a hipGraph; the per-kernel HIP events come from the same steps
@@ -798,6 +804,7 @@ def main():
                          "ms_per_step_p90": round(1e3 * order[(9 * len(order)) // 10 if len(order) > 1 else 0] / args.steps, 3),
                          "bimodal": bool(len(order) >= 5 and order[(9 * len(order)) // 10] > 1.05 * order[len(order) // 10])},
         "rccl_world_size": rccl_world,
+        "l1_stream": l1_spans,
         "rank0_cpu_affinity": (f"{len(bound_cpus)} cores next to its GPU ({bound_cpus[0]}..{bound_cpus[-1]}); every rank binds to its own share "
                                "(captra_amd.parallel.bind_rank_cpus)") if bound_cpus else "unbound (single rank)",
         "collective_backend": ("none (single rank)" if dist is None else "nccl (RCCL)" if backend == "nccl" else

@@ -37,6 +37,7 @@ _SIGNATURES = {
     "captra_three_interpolate": [_INT, _INT, _INT, _INT, _P, _P, _P, _P, _P],
     "captra_three_interpolate_grad": [_INT, _INT, _INT, _INT, _P, _P, _P, _P, _P],
     "captra_canonicalize": [_INT, _INT, _INT, _P, _P, _P, _P, _P, _P, _P, _P],
+    "captra_canonicalize_planes": [_INT, _INT, _INT, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "captra_ball_query_multi": [_INT, _INT, _INT, _INT, _P, _P, _P, _P, _P, _P],
     "captra_pack_weights": [_INT, _INT, _P, _P, _P, _P, _P],
     "captra_pointwise_mlp": [_INT, _INT, _INT, _LL, _P, _P, _P, _INT, _P, _P],
@@ -65,7 +66,7 @@ _SIGNATURES = {
     "captra_pack_sa_bf16": [_INT] * 5 + [_P] * 7 + [_P],
     "captra_sa_scale_bf16": [_INT] * 9 + [_P] * 6 + [_INT, _INT, _P],
     "captra_bq_planes": [_INT, _INT, _P, _P, _P],
-    "captra_sa1_stream_bf16": [_INT, _INT, _INT, _P, _P, _P, _P, _P, _P, _P, _P, _INT, _P, _P, _P, _INT, _P, _P, _P, _P, _P],
+    "captra_sa1_stream_bf16": [_INT, _INT, _INT, _P, _P, _P, _P, _P, _P, _P, _P, _INT, _P, _P, _P, _INT, _P, _P, _P, _INT, _P, _P, _P, _P, _P],
     "captra_coord_tail": [_INT, _INT, _INT, _INT, _LL, _P, _P, _P, _INT, _P, _P, _P],
     "captra_fps_gather": [_INT, _INT, _INT, _P, _P, _P, _P, _P],
     "captra_fps_gather_ragged": [_INT, _INT, _P, _INT, _P, _P, _P, _P, _P],
@@ -150,6 +151,8 @@ def lib():
             l.captra_sa1_stream_set_grid.restype = None
             l.captra_sa1_stream_set_fine.argtypes = [_INT]
             l.captra_sa1_stream_set_fine.restype = None
+            l.captra_sa1_stream_set_whole.argtypes = [_INT]
+            l.captra_sa1_stream_set_whole.restype = None
         if hasattr(l, "captra_pointwise_mlp_gn_tiles"):
             l.captra_pointwise_mlp_gn_tiles.argtypes = [_INT, _INT, _LL]
             l.captra_pointwise_mlp_gn_tiles.restype = _INT
@@ -162,6 +165,8 @@ def lib():
                         ("CAPTRA_HEAD_PERSIST", "captra_tile_bf16_set_persistent")):
             if env in os.environ and hasattr(l, fn):
                 getattr(l, fn)(C.c_int(int(os.environ[env])))
+        if "CAPTRA_L1_GRID" in os.environ and hasattr(l, "captra_sa1_stream_set_grid"):
+            l.captra_sa1_stream_set_grid(int(os.environ["CAPTRA_L1_GRID"]), 1)
     return _lib
 
 

@@ -61,16 +61,51 @@ class PointNet2Msg(_FoldCache, nn.Module):
         self.device = cfg["device"]
         self._folded = None
 
-    def precompute_geometry(self, xyz_n3, level1_only=False, side=None):
+    def precompute_geometry(self, xyz_n3, level1_only=False, side=None, stream_level1=None):
         """Everything that depends on the coordinates only, in the layout `forward(geom=...)` takes: the two samplings, the
         ball-query lists of both levels, the 3-NN weights of FP1 / FP2.  Lets a caller run the MLP work of two networks
-        that share a cloud on two streams (EvalTrackModel at small batch).  None when the fused samplers do not apply."""
+        that share a cloud on two streams (EvalTrackModel at small batch).  None when the fused samplers do not apply.
+        `stream_level1` = (xyz_cn, planes or None, [(backbone, features (B,cf,N) or None), ...]): the backbones (one or two, this one
+        among them) whose FIRST LEVEL runs inside the sampler's launch (fused.sa1_stream_bf16: ball query and shared MLPs of the
+        centres picked so far on the CUs the sampler leaves idle); their pooled features ride in geom["sa1"]["pooled"]."""
         if self.training or not xyz_n3.is_cuda or self.sa1.knn or self.sa2.knn:
             return None
-        first = fused.fps_gather(xyz_n3.contiguous(), self.sa1.npoint)
+        pooled = lists = None
+        if stream_level1 is not None:
+            xyz_cn, planes, nets = stream_level1
+            mods = [bb.sa1 for bb, _ in nets]
+            for mod in mods:
+                mod._fold(xyz_n3.device)
+            cfs = [0 if f is None else f.shape[1] for _, f in nets]
+            if fused.sa1_stream_supported(xyz_n3.shape[1], mods, cfs):
+                m2 = self.sa2.npoint if (not level1_only and self.sa2.npoint <= 256) else 0
+                res = fused.sa1_stream_bf16(xyz_n3.contiguous(), xyz_cn.contiguous(), mods, [f for _, f in nets], planes=planes, m2=m2)
+                _, n1_n3, n1_cn, lists, outs, scratch = res[:6]
+                pooled = {id(mod): out for mod, out in zip(mods, outs)}
+                pooled["_scratch"] = scratch
+                if m2:
+                    pooled["_level2"] = res[6]
+                first = (None, n1_n3, n1_cn)
+        if pooled is None:
+            first = fused.fps_gather(xyz_n3.contiguous(), self.sa1.npoint)
         if first is None:
             return None
         _, n1_n3, n1_cn = first
+        if pooled is not None:
+            g1 = {"new_xyz_n3": n1_n3, "new_xyz": n1_cn, "idx_list": lists, "pooled": pooled}
+            if level1_only:
+                return {"sa1": g1}
+            if side is not None:
+                main = torch.cuda.current_stream(xyz_n3.device)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    nn1 = fused.three_nn_weights(xyz_n3, n1_n3)
+                geom = self.precompute_geometry_rest({"sa1": g1, "fp1": nn1}, xyz_n3)
+                main.wait_stream(side)
+                for t in nn1:
+                    t.record_stream(main)
+                return geom
+            return self.precompute_geometry_rest({"sa1": g1}, xyz_n3)
         if side is not None and not level1_only:
             # everything below depends on the first sampling only: level 1's ball query and interpolation weights on `side`,
             # level 2's sampling, ball query and weights on this stream (a plain fork / join: ~0.06 ms off the serial prefix
@@ -139,7 +174,8 @@ class PointNet2Msg(_FoldCache, nn.Module):
     def precompute_geometry_rest(self, geom, xyz_n3):
         """Level 2 and the interpolation weights, given level 1 (`precompute_geometry(..., level1_only=True)`)."""
         n1_n3 = geom["sa1"]["new_xyz_n3"]
-        _, n2_n3, n2_cn = fused.fps_gather(n1_n3, self.sa2.npoint)
+        lvl2 = (geom["sa1"].get("pooled") or {}).get("_level2")     # the level-1 stream kernel's samplers went on to level 2
+        _, n2_n3, n2_cn = lvl2 if lvl2 is not None else fused.fps_gather(n1_n3, self.sa2.npoint)
         geom["sa2"] = {"new_xyz_n3": n2_n3, "new_xyz": n2_cn,
                        "idx_list": fused.ball_query_multi(self.sa2.radius_list, self.sa2.nsample_list, n1_n3, n2_n3)}
         if "fp1" not in geom:

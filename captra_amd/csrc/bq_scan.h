@@ -71,17 +71,20 @@ __device__ __forceinline__ void bq_scan_centre(const float *xs, const float *ys,
     }
 }
 
-// One wave, NC centres at ONE radius, one staged tile: every 256-point group is read once (three ds_read_b128) and tested against
-// all NC centres -- NC independent chains of packed arithmetic behind one LDS latency -- then each centre's four chunks are
-// compacted in index order exactly as in bq_scan_centre.  For a wave that owns several centres and shares its SIMD with few other
-// waves (the level-1 stream kernel's consumers: two waves per SIMD), where one centre at a time waits out every LDS read.
-template <int NC>
+// One wave, NC centres x NR radii, one staged tile: every 256-point group is read once (three ds_read_b128) and tested against all
+// NC centres -- NC independent chains of packed arithmetic behind one LDS latency -- then each (centre, radius) list takes its four
+// chunks' hits in index order exactly as in bq_scan_centre.  For a wave that owns several centres and shares its SIMD with few
+// other waves (the level-1 stream kernel's consumers: two waves per SIMD), where one centre at a time waits out every LDS read.
+// List (c, r) = rows[r] + c * ns[r] (consecutive centres: consecutive rows); cnt = ns closes a slot from the start.
+template <int NC, int NR>
 __device__ __forceinline__ void bq_scan_centres(const float *xs, const float *ys, const float *zs, int groups, int t0, const float (&cx)[NC],
-                                                const float (&cy)[NC], const float (&cz)[NC], float r2, int ns, int *const (&row)[NC],
-                                                int (&cnt)[NC], int (&first)[NC], int lane) {
+                                                const float (&cy)[NC], const float (&cz)[NC], const float (&r2)[NR], const int (&ns)[NR],
+                                                int *const (&rows)[NR], int (&cnt)[NC][NR], int (&first)[NC][NR], int lane) {
     bool any = false;
 #pragma unroll
-    for (int c = 0; c < NC; ++c) any = any || (cnt[c] < ns);
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int r = 0; r < NR; ++r) any = any || (cnt[c][r] < ns[r]);
     for (int g = 0; g < groups && any; ++g) {
         const bq_f32x4 X = reinterpret_cast<const bq_f32x4 *>(xs)[g * 64 + lane];
         const bq_f32x4 Y = reinterpret_cast<const bq_f32x4 *>(ys)[g * 64 + lane];
@@ -97,20 +100,24 @@ __device__ __forceinline__ void bq_scan_centres(const float *xs, const float *ys
         for (int c = 0; c < NC; ++c) {
 #pragma unroll
             for (int h = 0; h < 4; ++h) {
-                if (cnt[c] < ns) {
-                    const bool hit = d2[c][h] < r2;
-                    const unsigned long long mask = __ballot(hit);
-                    if (mask) {
-                        const int k0 = t0 + g * 256 + h * 64;
-                        const unsigned pos = (unsigned)cnt[c] +
-                                             __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                        if (cnt[c] == 0) first[c] = k0 + (__ffsll((long long)mask) - 1);
-                        if (hit && pos < (unsigned)ns) row[c][pos] = k0 + lane;
-                        cnt[c] += __popcll(mask);
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    if (cnt[c][r] < ns[r]) {
+                        const bool hit = d2[c][h] < r2[r];
+                        const unsigned long long mask = __ballot(hit);
+                        if (mask) {
+                            const int k0 = t0 + g * 256 + h * 64;
+                            const unsigned pos = (unsigned)cnt[c][r] +
+                                                 __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                            if (cnt[c][r] == 0) first[c][r] = k0 + (__ffsll((long long)mask) - 1);
+                            if (hit && pos < (unsigned)ns[r]) (rows[r] + (size_t)c * ns[r])[pos] = k0 + lane;
+                            cnt[c][r] += __popcll(mask);
+                        }
                     }
                 }
             }
-            any = any || (cnt[c] < ns);
+#pragma unroll
+            for (int r = 0; r < NR; ++r) any = any || (cnt[c][r] < ns[r]);
         }
     }
 }

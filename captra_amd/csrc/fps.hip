@@ -235,18 +235,7 @@ __global__ __launch_bounds__(NWAVES * 64) void fps_kernel_blocked(int n_stride, 
         if constexpr (PPT == 16) {
             fps_lane_round16(px, py, pz, dmin, ox, oy, oz, best, li);      // (fps_round.h: shared with the level-1 stream kernel)
         } else {
-            const f32x2 o2x = {ox, ox}, o2y = {oy, oy}, o2z = {oz, oz};
-#pragma unroll
-            for (int h = 0; h < H; ++h) {
-                const f32x2 dx = px[h] - o2x, dy = py[h] - o2y, dz = pz[h] - o2z;
-                const f32x2 d = (dx * dx + dy * dy) + dz * dz;
-                const unsigned b0 = __float_as_uint(d[0]), b1 = __float_as_uint(d[1]);
-                dmin[2 * h] = b0 < dmin[2 * h] ? b0 : dmin[2 * h];
-                dmin[2 * h + 1] = b1 < dmin[2 * h + 1] ? b1 : dmin[2 * h + 1];
-                best = max(best, max(dmin[2 * h], dmin[2 * h + 1]));
-            }
-#pragma unroll
-            for (int i = PPT - 2; i >= 0; --i) li = dmin[i] == best ? i : li;
+            fps_lane_round<PPT>(px, py, pz, dmin, ox, oy, oz, best, li);
         }
         const unsigned wmax = wave_max_u32_fold(best);
         const unsigned long long hit = __ballot(best == wmax);

@@ -82,3 +82,23 @@ __device__ __forceinline__ int fps_winner_of_four(const uint2 *slot) {
     bi = s23.z > bv ? s23.w : bi;
     return (int)bi;
 }
+
+// The same for a lane holding PPT (even, != 16) points: maximum by a linear walk, lowest slot by a descending select chain.
+template <int PPT>
+__device__ __forceinline__ void fps_lane_round(const fps_f32x2 (&px)[PPT / 2], const fps_f32x2 (&py)[PPT / 2], const fps_f32x2 (&pz)[PPT / 2],
+                                               unsigned (&dmin)[PPT], float ox, float oy, float oz, unsigned &best, int &li) {
+    const fps_f32x2 o2x = {ox, ox}, o2y = {oy, oy}, o2z = {oz, oz};
+    best = 0u;
+#pragma unroll
+    for (int h = 0; h < PPT / 2; ++h) {
+        const fps_f32x2 dx = px[h] - o2x, dy = py[h] - o2y, dz = pz[h] - o2z;
+        const fps_f32x2 d = (dx * dx + dy * dy) + dz * dz;
+        const unsigned b0 = __float_as_uint(d[0]), b1 = __float_as_uint(d[1]);
+        dmin[2 * h] = b0 < dmin[2 * h] ? b0 : dmin[2 * h];
+        dmin[2 * h + 1] = b1 < dmin[2 * h + 1] ? b1 : dmin[2 * h + 1];
+        best = max(best, max(dmin[2 * h], dmin[2 * h + 1]));
+    }
+    li = PPT - 1;
+#pragma unroll
+    for (int i = PPT - 2; i >= 0; --i) li = dmin[i] == best ? i : li;
+}

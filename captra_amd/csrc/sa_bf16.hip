@@ -855,6 +855,9 @@ struct L1Params {
     const float *planes;                // (B,3,pad256(N)) the clouds in the ball query's LDS plane order (captra_bq_planes), or null
     int *fps_idx;
     float *new_n3, *new_cn;
+    int m2;                             // level 2: the sampler workgroups go on to pick m2 of their m centres (0: not asked for)
+    int *fps2_idx;                      // (B,m2) indices into the level-1 centres
+    float *new2_n3, *new2_cn;           // (B,m2,3), (B,3,m2)
     int *idx[3];
     float r2[3];
     unsigned long long *gran;           // (B,M) granules {1, pick}; zeroed before the launch
@@ -862,12 +865,16 @@ struct L1Params {
     unsigned long long spin_limit;      // s_memrealtime ticks (100 MHz) a consumer waits for one window
     int prio;                           // s_setprio of the sampler's waves
     int nfine;                          // trailing centres handed out as fine windows of 8 (multiple of 32)
+    int nwhole;                         // leading windows of 32 handed out whole (all three scales in one ticket)
+    int pair;                           // scale tickets: 1 = two per window and cloud (scale 2 | scales 1 + 0 behind one scan), 0 = three
     int dbg;                            // timing experiments (results wrong): 1 = no ball-query scan, 2 = no MLPs, 4 = no cloud staging, 8 = no consumers, 16 = no sampling (picks of an earlier launch)
     L1Net net[2];
 };
 
 constexpr int L1_REGION_A = 57344;      // SA body (image + biases + strips <= 56192) | cloud planes (49152) | sampler (51456)
-constexpr int L1_LDS = L1_REGION_A + 1024;
+constexpr int L1_CTL = 1024;             // ticket words + the window's centres
+constexpr int L1_LEVEL2 = 3 * 512 * 4 + 1024;   // the sampler's second level: its 512 centres' coordinates + 256 picks
+constexpr int L1_LDS = L1_REGION_A + L1_CTL + L1_LEVEL2;
 
 // one network's scale s on the window's four jobs (a wave = CG consecutive centres from c0 + CG * wave)
 template <int CF, int C1, int C2, int C3, int K, bool PF, int CG>
@@ -879,46 +886,60 @@ __device__ __forceinline__ void l1_scale(const L1Params &p, const L1Net &net, in
     sb_body<CF, C1, C2, C3, K, false, 2, CG, true, 0, PF, 0, 4>(q, smem, b * 4);
 }
 
-// a ticket's work: the ball query of centres [c0, c0 + nc) at scale s (nc / 4 per wave), then the scale's shared MLPs of the
-// networks in `nets` (bit 0 / bit 1) on the lists just written (CG centres per wave: nc / CG waves work)
-template <int CFA, int CFB, int C1, int C2, int C3, int K, bool PF, int CG>
-__device__ __forceinline__ void l1_item(const L1Params &p, int s, int b, int c0, int nc, int nets, unsigned char *smem, const float *ctr, int *next_ticket, int tid, int lane, int wave) {
-    float *xs = reinterpret_cast<float *>(smem), *ys = xs + bq_pad(p.n), *zs = ys + bq_pad(p.n);
-    // (a wave's centres four at a time against every group of the cloud: bq_scan.h)
+// the ball query of a ticket's centres [c0, c0 + nc) (nc / 4 per wave, four at a time against every group of the cloud: bq_scan.h) at
+// the NR radii s0 .. s0 + NR - 1: one scan of the staged cloud whatever NR
+template <int NR>
+__device__ __forceinline__ void l1_ball_query(const L1Params &p, int s0, int b, int c0, int nc, unsigned char *smem, const float *ctr, int lane, int wave) {
+    const float *xs = reinterpret_cast<const float *>(smem), *ys = xs + bq_pad(p.n), *zs = ys + bq_pad(p.n);
+    constexpr int KS[3] = {32, 64, 128};
+    float r2[NR];
+    int ns[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) { r2[r] = p.r2[s0 + r]; ns[r] = KS[0] << (s0 + r); }
     const int per_wave = (p.dbg & 1) ? 0 : nc / 4;
 #pragma unroll 1
     for (int ci = 0; ci < per_wave; ci += 4) {
         float cx[4], cy[4], cz[4];
-        int *row[4];
-        int cnt[4], first[4];
+        int cnt[4][NR], first[4][NR];
+        int *rows[NR];
+        const int cl0 = per_wave * wave + ci;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) rows[r] = p.idx[s0 + r] + ((size_t)b * p.m + c0 + cl0) * ns[r];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const bool live = ci + u < per_wave;
-            const int cl = per_wave * wave + (live ? ci + u : ci);
+            const int cl = live ? cl0 + u : cl0;
             cx[u] = ctr[3 * cl + 0]; cy[u] = ctr[3 * cl + 1]; cz[u] = ctr[3 * cl + 2];
-            row[u] = p.idx[s] + ((size_t)b * p.m + c0 + cl) * K;
-            cnt[u] = live ? 0 : K;                     // (a slot beyond the wave's centres: closed from the start, writes nothing)
-            first[u] = 0;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                cnt[u][r] = live ? 0 : ns[r];          // (a slot beyond the wave's centres: closed from the start, writes nothing)
+                first[u][r] = 0;
+            }
         }
-        bq_scan_centres<4>(xs, ys, zs, bq_pad(p.n) >> 8, 0, cx, cy, cz, p.r2[s], K, row, cnt, first, lane);
+        bq_scan_centres<4, NR>(xs, ys, zs, bq_pad(p.n) >> 8, 0, cx, cy, cz, r2, ns, rows, cnt, first, lane);
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-            if (ci + u < per_wave) bq_pad_row(row[u], cnt[u], first[u], K, lane);
+#pragma unroll
+            for (int r = 0; r < NR; ++r)
+                if (ci + u < per_wave) bq_pad_row(rows[r] + (size_t)u * ns[r], cnt[u][r], first[u][r], ns[r], lane);
     }
-    __syncthreads();                                   // the lists are written (vmcnt drained), the planes are free
-    // the NEXT ticket is fetched in front of the ticket's last MLP run and handed over behind it: the fetch's latency is off the
-    // path, and the ticket waits for this workgroup for one run only (fetched at the ticket's start it sat out the whole ticket while
-    // other workgroups idled at the end: consumers alone 350 -> 381 us at 32 clouds)
+}
+
+// the shared MLPs of scale s for the networks in `nets` (bit 0 / bit 1) on centres [c0, c0 + nc), CG centres per wave.  `next_ticket`
+// non-null: this is the ticket's LAST scale -- the NEXT ticket is fetched in front of its last run and handed over behind it: the
+// fetch's latency is off the path, and the ticket waits for this workgroup for one run only (fetched at the ticket's start it sat
+// out the whole ticket while other workgroups idled at the end: consumers alone 350 -> 381 us at 32 clouds)
+template <int CFA, int CFB, int C1, int C2, int C3, int K, bool PF, int CG>
+__device__ __forceinline__ void l1_mlps(const L1Params &p, int s, int b, int c0, int nc, int nets, unsigned char *smem, int *next_ticket, int tid) {
     l1_gu32 *ctl = (l1_gu32 *)p.ctl;
     unsigned tn = 0u;
-    const bool fetcher = tid == 0;
-    if ((p.dbg & 2) || !(CFB >= 0 && nets == 3)) {
-        if (fetcher) tn = __hip_atomic_fetch_add(ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    const bool fetcher = tid == 0 && next_ticket != nullptr;
+    const bool both = CFB >= 0 && nets == 3;
+    if (((p.dbg & 2) || !both) && fetcher) tn = __hip_atomic_fetch_add(ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (!(p.dbg & 2)) {
         if (nets & 1) l1_scale<CFA, C1, C2, C3, K, PF, CG>(p, p.net[0], s, b, c0, nc, smem);
         if constexpr (CFB >= 0) {
-            if (nets == 3) {
+            if (both) {
                 __syncthreads();
                 if (fetcher) tn = __hip_atomic_fetch_add(ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -937,6 +958,9 @@ __global__ __launch_bounds__(256, 2) void l1_stream_kernel(L1Params p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     l1_gu64 *gran = (l1_gu64 *)p.gran;
     l1_gu32 *ctl = (l1_gu32 *)p.ctl;
+    // ctl[2] / [3] / [4]: earliest workgroup start (complemented), latest sampler end, latest workgroup end, in ticks of the 100 MHz counter
+    // (read back by tools / tests: the sampler's span inside the launch, and the consumers' tail behind it)
+    if (tid == 0) __hip_atomic_fetch_max(ctl + 2, ~(unsigned)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (max of the complement = the earliest)
 
     if ((int)blockIdx.x < p.b && (p.dbg & 16)) {
         // (timing experiment: the picks of an earlier launch, published at once -- the consumers' own throughput)
@@ -993,37 +1017,89 @@ __global__ __launch_bounds__(256, 2) void l1_stream_kernel(L1Params p) {
         if (p.prio > 0) __builtin_amdgcn_s_setprio(0);
         __syncthreads();
         for (int j = tid; j < m; j += 256) p.fps_idx[(size_t)b * m + j] = picks[j];
+        if (tid == 0) __hip_atomic_fetch_max(ctl + 3, (unsigned)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (p.m2 > 0) {
+            // ---- level 2 (PointNet2Msg.sa2's sampling: m2 of the m centres just picked), while the consumers work off their backlog:
+            // the rounds of fps_kernel_blocked<1, 8, true> on wave 0 (lane l holds centres 8l .. 8l + 7), the other waves wait ----
+            float *c2x = reinterpret_cast<float *>(smem + L1_REGION_A + L1_CTL), *c2y = c2x + 512, *c2z = c2y + 512;
+            int *picks2 = reinterpret_cast<int *>(c2z + 512);
+            for (int j = tid; j < 512; j += 256) {
+                const int id = j < m ? picks[j] : 0;
+                c2x[j] = j < m ? xs[id] : 0.f; c2y[j] = j < m ? ys[id] : 0.f; c2z[j] = j < m ? zs[id] : 0.f;
+            }
+            __syncthreads();
+            if (wave == 0) {
+                fps_f32x2 qx[4], qy[4], qz[4];
+                unsigned d2min[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int k = lane * 8 + i;
+                    qx[i / 2][i & 1] = c2x[k]; qy[i / 2][i & 1] = c2y[k]; qz[i / 2][i & 1] = c2z[k];
+                    d2min[i] = k < m ? __float_as_uint(1e10f) : 0u;
+                }
+                if (lane == 0) picks2[0] = 0;
+                int old2 = 0;
+#pragma unroll 1
+                for (int j = 1; j < p.m2; ++j) {
+                    unsigned best, wmax, widx;
+                    int li;
+                    fps_lane_round<8>(qx, qy, qz, d2min, c2x[old2], c2y[old2], c2z[old2], best, li);
+                    fps_wave_winner(best, li, lane * 8, wmax, widx);
+                    old2 = (int)widx;
+                    picks2[j] = old2;
+                }
+            }
+            __syncthreads();
+            for (int j = tid; j < p.m2; j += 256) {
+                const int id = picks2[j];
+                p.fps2_idx[(size_t)b * p.m2 + j] = id;
+                float *d3 = p.new2_n3 + ((size_t)b * p.m2 + j) * 3;
+                d3[0] = c2x[id]; d3[1] = c2y[id]; d3[2] = c2z[id];
+                float *dc = p.new2_cn + (size_t)b * 3 * p.m2 + j;
+                dc[0] = c2x[id]; dc[p.m2] = c2y[id]; dc[2 * (size_t)p.m2] = c2z[id];
+            }
+        }
         __syncthreads();
     }
 
     // ---- consumer: tickets in window order -------------------------------------------------------------------------------------
-    // COARSE windows of 32 centres (a ticket = window, scale, cloud: ball query once, every network's MLPs) for all but the last 32
-    // centres, then FINE windows of 8 (a ticket = window, scale, network, cloud; two waves x 4 centres in the MLPs): what is left when the sampler
-    // ends -- the backlog and the last window -- is many short tickets for the whole chip instead of a few long ones (a coarse
-    // K = 128 ticket is 110 us of one workgroup: 8 centres per wave through the scan, then 16 MLP passes per wave and network)
+    // Three kinds, so that the work is in few long tickets while the sampler has a long way to go and in many short ones at the end:
+    //   WHOLE windows (the first p.nwhole windows of 32 centres): ticket = (window, cloud) -- ONE scan of the cloud for the three
+    //     radii (the small ones never fill and walk all of it anyway), then the six MLP runs; one poll / staging per 32 x 3 lists;
+    //   SCALE tickets (window, scale, cloud) for the windows behind them: a scan per scale, that scale's MLPs of every network;
+    //   FINE tickets (window of 8, scale, network, cloud) for the last p.nfine centres: what is left when the sampler ends -- the
+    //     backlog and the last window -- is many short tickets for the whole chip (a scale ticket at K = 128 is 110 us of one
+    //     workgroup on an idle chip: 8 centres per wave through the scan, then 16 MLP passes per wave and network).
     constexpr int NNET = CFB >= 0 ? 2 : 1;
-    const int wc = (p.m - p.nfine) / 32;               // coarse windows
-    const int coarse = wc * 3 * p.b, total = (p.dbg & 8) ? 0 : coarse + (p.nfine / 8) * 3 * NNET * p.b;
-    // s_word[0 / 1]: this ticket / the next one (l1_item fetches it); s_word[2]: window ok
+    const int wc = (p.m - p.nfine) / 32;               // windows of 32
+    const int wa = p.nwhole < wc ? p.nwhole : wc;
+    const int tpw = p.pair ? 2 : 3;                    // scale tickets per window and cloud: {2, 1, 0} or {2, 1 + 0}
+    const int n_whole = wa * p.b, n_scale = n_whole + (wc - wa) * tpw * p.b;
+    const int total = (p.dbg & 8) ? 0 : n_scale + (p.nfine / 8) * 3 * NNET * p.b;
+    // s_word[0 / 1]: this ticket / the next one (l1_mlps fetches it); s_word[2]: window ok
     if (tid == 0) s_word[0] = total > 0 ? (int)__hip_atomic_fetch_add(ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
     for (int it = 0;; ++it) {
         __syncthreads();                               // (every wave is out of the previous ticket's LDS; the ticket word is there)
         const int t = s_word[it & 1];
         if (t >= total) break;
-        const bool fine = t >= coarse;
-        int c0, nc, s, b, nets;                        // first centre, centres, scale (the widest of a window first), cloud, networks
-        if (!fine) {
-            const int w = t / (3 * p.b), r = t % (3 * p.b);
-            c0 = 32 * w; nc = 32; s = 2 - r / p.b; b = r % p.b; nets = NNET == 2 ? 3 : 1;
+        int c0, nc, smask, b, nets;                    // first centre, centres, scales (bit s; the widest first), cloud, networks
+        if (t < n_whole) {
+            c0 = 32 * (t / p.b); nc = 32; smask = 7; b = t % p.b; nets = NNET == 2 ? 3 : 1;
+        } else if (t < n_scale) {
+            const int ts = t - n_whole;
+            const int w = ts / (tpw * p.b), r = ts % (tpw * p.b), q = r / p.b;
+            c0 = 32 * (wa + w); nc = 32; b = r % p.b; nets = NNET == 2 ? 3 : 1;
+            smask = p.pair ? (q == 0 ? 4 : 3) : 1 << (2 - q);      // (pair: the two narrow scales share ONE scan of the cloud -- both walk all of it)
         } else {
-            const int tf = t - coarse, per = 3 * NNET * p.b;
+            const int tf = t - n_scale, per = 3 * NNET * p.b;
             const int w = tf / per, r = tf % per;
-            c0 = 32 * wc + 8 * w; nc = 8; s = 2 - r / (NNET * p.b);
+            c0 = 32 * wc + 8 * w; nc = 8; smask = 1 << (2 - r / (NNET * p.b));
             const int r2 = r % (NNET * p.b);
             nets = 1 << (r2 / p.b); b = r2 % p.b;
         }
         if (wave == 0) {
-            // wave 0: this window's granules -- one relaxed device-scope load per lane until every tag is there --, then the centres: coordinates into LDS (ball query) and into new_xyz in both layouts
+            // wave 0: this window's granules -- one relaxed device-scope load per lane until every tag is there --, then the centres:
+            // coordinates into LDS (ball query) and into new_xyz in both layouts
             // (the SA body and everything behind this launch read them there; the tickets of a window write the same values)
             const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
             unsigned long long g = 1ull << 32;
@@ -1066,16 +1142,27 @@ __global__ __launch_bounds__(256, 2) void l1_stream_kernel(L1Params p) {
             }
             break;
         }
-        if (!fine) {
-            if (s == 2) l1_item<CFA, CFB, 64, 96, 128, 128, true, 8>(p, s, b, c0, nc, nets, smem, ctr, s_word + ((it & 1) ^ 1), tid, lane, wave);
-            else if (s == 1) l1_item<CFA, CFB, 64, 64, 128, 64, true, 8>(p, s, b, c0, nc, nets, smem, ctr, s_word + ((it & 1) ^ 1), tid, lane, wave);
-            else l1_item<CFA, CFB, 32, 32, 64, 32, false, 8>(p, s, b, c0, nc, nets, smem, ctr, s_word + ((it & 1) ^ 1), tid, lane, wave);
-        } else {
-            if (s == 2) l1_item<CFA, CFB, 64, 96, 128, 128, true, 4>(p, s, b, c0, nc, nets, smem, ctr, s_word + ((it & 1) ^ 1), tid, lane, wave);
-            else if (s == 1) l1_item<CFA, CFB, 64, 64, 128, 64, true, 4>(p, s, b, c0, nc, nets, smem, ctr, s_word + ((it & 1) ^ 1), tid, lane, wave);
-            else l1_item<CFA, CFB, 32, 32, 64, 32, false, 4>(p, s, b, c0, nc, nets, smem, ctr, s_word + ((it & 1) ^ 1), tid, lane, wave);
+        if (smask == 7) l1_ball_query<3>(p, 0, b, c0, nc, smem, ctr, lane, wave);
+        else if (smask == 3) l1_ball_query<2>(p, 0, b, c0, nc, smem, ctr, lane, wave);
+        else l1_ball_query<1>(p, smask == 4 ? 2 : (smask == 2 ? 1 : 0), b, c0, nc, smem, ctr, lane, wave);
+        int *next = s_word + ((it & 1) ^ 1);
+#pragma unroll 1
+        for (int s = 2; s >= 0; --s) {
+            if (!((smask >> s) & 1)) continue;
+            __syncthreads();                           // the lists are written (vmcnt drained), the planes / the last run's weights are free
+            int *nx = (smask & ((1 << s) - 1)) == 0 ? next : nullptr;      // the ticket's last scale
+            if (nc == 32) {
+                if (s == 2) l1_mlps<CFA, CFB, 64, 96, 128, 128, true, 8>(p, s, b, c0, nc, nets, smem, nx, tid);
+                else if (s == 1) l1_mlps<CFA, CFB, 64, 64, 128, 64, true, 8>(p, s, b, c0, nc, nets, smem, nx, tid);
+                else l1_mlps<CFA, CFB, 32, 32, 64, 32, false, 8>(p, s, b, c0, nc, nets, smem, nx, tid);
+            } else {
+                if (s == 2) l1_mlps<CFA, CFB, 64, 96, 128, 128, true, 4>(p, s, b, c0, nc, nets, smem, nx, tid);
+                else if (s == 1) l1_mlps<CFA, CFB, 64, 64, 128, 64, true, 4>(p, s, b, c0, nc, nets, smem, nx, tid);
+                else l1_mlps<CFA, CFB, 32, 32, 64, 32, false, 4>(p, s, b, c0, nc, nets, smem, nx, tid);
+            }
         }
     }
+    if (tid == 0) __hip_atomic_fetch_max(ctl + 4, (unsigned)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // the clouds in the ball query's LDS plane order (bq_scan.h), once per cloud instead of once per ticket
@@ -1106,15 +1193,18 @@ int l1_launch(const L1Params &p, int grid, hipStream_t stream) {
     return captra_last_error();
 }
 
-CAPTRA_KNOB int g_l1_grid = 0;          // experiment knob: workgroups of the stream kernel (0 = two per CU)
+CAPTRA_KNOB int g_l1_grid = 0;          // experiment knob: workgroups of the stream kernel (0 = one per CU up to 16 clouds, two beyond)
 CAPTRA_KNOB int g_l1_prio = 1;
 CAPTRA_KNOB int g_l1_fine = 32;
+CAPTRA_KNOB int g_l1_whole = 0;
+CAPTRA_KNOB int g_l1_pair = 1;
 CAPTRA_KNOB int g_l1_dbg = 0;
 
 }  // namespace
 
 extern "C" void captra_sa1_stream_set_grid(int grid, int prio) { g_l1_grid = grid; g_l1_prio = prio; }
 extern "C" void captra_sa1_stream_set_fine(int centres) { g_l1_fine = centres & 0xFFFF; g_l1_dbg = centres >> 16; }   // (bits 16..: timing ablations, results wrong)
+extern "C" void captra_sa1_stream_set_whole(int windows) { g_l1_whole = windows & 0xFF; g_l1_pair = (windows >> 8) & 1 ? 0 : 1; }   // (bit 8: three scale tickets per window)
 
 // planes (B,3,pad256(N)) <- xyz_n3 (B,N,3): element ((chunk / 4) * 64 + lane) * 4 + chunk % 4 of plane a = coordinate a of point
 // 64 chunk + lane; slots beyond N hold +inf
@@ -1139,9 +1229,10 @@ extern "C" long long captra_sa1_stream_scratch_bytes(int b, int m) {
 extern "C" int captra_sa1_stream_bf16(int b, int n, int m, const float *xyz_n3, const float *xyz_cn, const float *planes, const float *radius3, int *fps_idx,
                                       float *new_n3, float *new_cn, int *const *idx3, int cfa, const float *feat_a,
                                       const unsigned char *const *img_a3, float *out_a, int cfb, const float *feat_b,
-                                      const unsigned char *const *img_b3, float *out_b, void *scratch, captra_stream_t stream) {
-    if (b < 0 || n < 1 || m < 1) return -1;
-    if (n > 4096 || m > 512 || m % 32 || m > n) return -2;
+                                      const unsigned char *const *img_b3, float *out_b, int m2, int *fps2_idx, float *new2_n3, float *new2_cn,
+                                      void *scratch, captra_stream_t stream) {
+    if (b < 0 || n < 1 || m < 1 || m2 < 0) return -1;
+    if (n > 4096 || m > 512 || m % 32 || m > n || m2 > 256 || m2 > m) return -2;
     if (!((cfa == 0 || cfa == 3) && (cfb < 0 || cfb == 0 || cfb == 3))) return -2;
     if (b == 0) return 0;
     if (b > 256) return -2;
@@ -1149,6 +1240,7 @@ extern "C" int captra_sa1_stream_bf16(int b, int n, int m, const float *xyz_n3, 
     const long long sbytes = captra_sa1_stream_scratch_bytes(b, m);
     if (hipMemsetAsync(scratch, 0, (size_t)sbytes, st) != hipSuccess) return (int)hipGetLastError();
     L1Params p;
+    p.m2 = m2; p.fps2_idx = fps2_idx; p.new2_n3 = new2_n3; p.new2_cn = new2_cn;
     p.b = b; p.n = n; p.m = m; p.xyz_n3 = xyz_n3; p.xyz_cn = xyz_cn; p.planes = planes; p.fps_idx = fps_idx; p.new_n3 = new_n3; p.new_cn = new_cn;
     for (int s = 0; s < 3; ++s) { p.idx[s] = idx3[s]; p.r2[s] = radius3[s] * radius3[s]; }
     p.gran = reinterpret_cast<unsigned long long *>(scratch);
@@ -1156,6 +1248,8 @@ extern "C" int captra_sa1_stream_bf16(int b, int n, int m, const float *xyz_n3, 
     p.spin_limit = 2000000ull;          // 20 ms of the 100 MHz counter: a sampler takes 0.25 ms
     p.prio = g_l1_prio;
     p.dbg = g_l1_dbg;
+    p.nwhole = g_l1_whole < 0 ? 0 : g_l1_whole;
+    p.pair = g_l1_pair;
     p.nfine = g_l1_fine < 0 ? 0 : (g_l1_fine > m ? m : g_l1_fine) / 32 * 32;
     const int coff[3] = {0, 64, 192};
     for (int s = 0; s < 3; ++s) {
@@ -1168,7 +1262,9 @@ extern "C" int captra_sa1_stream_bf16(int b, int n, int m, const float *xyz_n3, 
     if (grid <= 0) {
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        grid = 2 * cus;
+        // up to 16 clouds one workgroup per CU: the launch then leaves room for whatever else runs (the other lane's networks), and
+        // its own consumers, each alone on a CU, are not behind (bf16 step, two lanes of 16: 1.277 -> 1.23 ms; 512 workgroups: 1.43)
+        grid = (b <= 16 ? 1 : 2) * cus;
     }
     if (grid < b + 1) grid = b + 1;
     if (cfa == 0 && cfb == 3) return l1_launch<0, 3>(p, grid, st);

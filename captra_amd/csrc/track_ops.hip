@@ -18,11 +18,21 @@ __global__ __launch_bounds__(256) void canonicalize_kernel(int p, int n, const f
                                                            const float *__restrict__ trans,
                                                            const float *__restrict__ scale,
                                                            float *__restrict__ out_cn,
-                                                           float *__restrict__ out_n3) {
+                                                           float *__restrict__ out_n3,
+                                                           float *__restrict__ out_planes) {
     const int q = blockIdx.y;  // cloud index b*P + part
     const int bi = q / p;
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+    // out_planes: the cloud a third time, in the ball query's LDS plane order (csrc/bq_scan.h; slots beyond n hold +inf)
+    const int npad = (n + 255) & ~255;
+    const int pa = ((((i >> 6) >> 2) << 6) + (i & 63)) * 4 + ((i >> 6) & 3);
+    if (i >= n) {
+        if (out_planes != nullptr && i < npad) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) out_planes[((size_t)q * 3 + a) * npad + pa] = __builtin_inff();
+        }
+        return;
+    }
     const float *R = rot + (size_t)q * 9;
     const float *t = trans + (size_t)q * 3;
     const float s = scale[q];
@@ -35,6 +45,7 @@ __global__ __launch_bounds__(256) void canonicalize_kernel(int p, int n, const f
         const float o = acc / s;
         if (out_cn) out_cn[((size_t)q * 3 + a) * n + i] = o;
         if (out_n3) out_n3[((size_t)q * n + i) * 3 + a] = o;
+        if (out_planes) out_planes[((size_t)q * 3 + a) * npad + pa] = o;
     }
 }
 
@@ -452,15 +463,21 @@ __global__ __launch_bounds__(256) void pack_pose_kernel(int n, const float *__re
 
 }  // namespace
 
-extern "C" int captra_canonicalize(int b, int p, int n, const float *pts, const float *mean, const float *rot,
-                                   const float *trans, const float *scale, float *out_cn, float *out_n3,
-                                   captra_stream_t stream) {
+extern "C" int captra_canonicalize_planes(int b, int p, int n, const float *pts, const float *mean, const float *rot,
+                                          const float *trans, const float *scale, float *out_cn, float *out_n3,
+                                          float *out_planes, captra_stream_t stream) {
     if (b < 0 || p < 1 || n < 0) return -1;
     if (b == 0 || n == 0) return 0;
     dim3 grid((n + 255) / 256, b * p);
     CAPTRA_LAUNCH("canonicalize", canonicalize_kernel, grid, dim3(256), 0, (hipStream_t)stream, p, n, pts, mean,
-                  rot, trans, scale, out_cn, out_n3);
+                  rot, trans, scale, out_cn, out_n3, out_planes);
     return captra_last_error();
+}
+
+extern "C" int captra_canonicalize(int b, int p, int n, const float *pts, const float *mean, const float *rot,
+                                   const float *trans, const float *scale, float *out_cn, float *out_n3,
+                                   captra_stream_t stream) {
+    return captra_canonicalize_planes(b, p, n, pts, mean, rot, trans, scale, out_cn, out_n3, nullptr, stream);
 }
 
 static CAPTRA_KNOB int g_nn_split = 1;     // experiment knob: 0 = one lane per unknown point (the first form)

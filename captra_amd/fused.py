@@ -34,9 +34,10 @@ def _work(name: str, flops: float = 0.0, nbytes: float = 0.0) -> None:
         WORK["bytes"][name] = WORK["bytes"].get(name, 0.0) + nbytes
 
 
-def canonicalize(pts, mean, rot, trans, scale, num_parts: int = 1, want_cn=True, want_n3=True):
+def canonicalize(pts, mean, rot, trans, scale, num_parts: int = 1, want_cn=True, want_n3=True, want_planes=False):
     """pts (B,3,N), mean (B,3[,1]), rot (B*P,3,3), trans (B*P,3[,1]), scale (B*P) ->
-    (out_cn (B*P,3,N), out_n3 (B*P,N,3)) = R^T((pts+mean)-t)/s  (networks.py:38-41, 184-187)."""
+    (out_cn (B*P,3,N), out_n3 (B*P,N,3)) = R^T((pts+mean)-t)/s  (networks.py:38-41, 184-187).
+    want_planes: a third element, the clouds in the ball query's LDS plane order (B*P,3,pad256(N)) for the level-1 stream kernel."""
     B, _, N = pts.shape
     Q = B * num_parts
     mean = mean.reshape(B, 3).contiguous()
@@ -46,6 +47,12 @@ def canonicalize(pts, mean, rot, trans, scale, num_parts: int = 1, want_cn=True,
     L.require_device(pts, mean, rot, trans, scale)
     out_cn = torch.empty(Q, 3, N, dtype=torch.float32, device=pts.device) if want_cn else None
     out_n3 = torch.empty(Q, N, 3, dtype=torch.float32, device=pts.device) if want_n3 else None
+    if want_planes:
+        planes = torch.empty(Q, 3, (N + 255) // 256 * 256, dtype=torch.float32, device=pts.device)
+        with torch.cuda.device(pts.device):
+            L.call("captra_canonicalize_planes", B, num_parts, N, L.ptr(pts), L.ptr(mean), L.ptr(rot), L.ptr(trans), L.ptr(scale),
+                   L.ptr(out_cn), L.ptr(out_n3), L.ptr(planes))
+        return out_cn, out_n3, planes
     with torch.cuda.device(pts.device):
         L.call("captra_canonicalize", B, num_parts, N, L.ptr(pts), L.ptr(mean), L.ptr(rot), L.ptr(trans), L.ptr(scale),
                L.ptr(out_cn), L.ptr(out_n3))
@@ -519,6 +526,9 @@ def fps_gather_part(xyz_n3, m: int, j0: int, j1: int, bufs):
 _L1_STREAM_WIDTHS = ((32, 32, 64), (64, 64, 128), (64, 96, 128))
 _L1_STREAM_K = (32, 64, 128)
 USE_L1_STREAM = os.environ.get("CAPTRA_L1_STREAM", "1") != "0"
+# clouds per launch up to which the stream kernel pays (same-box A/B, bf16 step: 16 per lane 1.277 -> 1.23 ms, 32 in one lane 1.28 ->
+# 1.265; two lanes of 32 lose 2 %: the consumers' backlog behind the sampler grows with the batch while the sampler's time does not)
+L1_STREAM_MAX_CLOUDS = int(os.environ.get("CAPTRA_L1_STREAM_MAX", "32"))
 
 
 def sa1_stream_supported(n: int, sa_modules, cfeats) -> bool:
@@ -548,10 +558,11 @@ def bq_planes(xyz_n3):
     return out
 
 
-def sa1_stream_bf16(xyz_n3, xyz_cn, sa_modules, feats, planes=None):
+def sa1_stream_bf16(xyz_n3, xyz_cn, sa_modules, feats, planes=None, m2: int = 0):
     """Level 1 of the backbones in `sa_modules` on the SAME cloud in one launch (captra_sa1_stream_bf16): sampling, the three ball
     queries and every network's pooled SA1 features.  feats[i]: (B,cf,N) or None.  -> (fps_idx, new_xyz (B,M,3), new_xyz (B,3,M),
-    [idx (B,M,K)] * 3, [out (B,320,M)] per network, scratch).  scratch[-16:].view(int32)[1] != 0 after completion = a consumer gave up."""
+    [idx (B,M,K)] * 3, [out (B,320,M)] per network, scratch[, level 2]).  scratch[-16:].view(int32)[1] != 0 after completion = a consumer
+    gave up.  m2 > 0: the second level's sampling too -- (idx2 (B,m2), new_xyz2 (B,m2,3), new_xyz2 (B,3,m2)) as the last element."""
     L.require_device(xyz_n3, xyz_cn, *[f for f in feats if f is not None])
     B, N, _ = xyz_n3.shape
     first = sa_modules[0]
@@ -566,6 +577,10 @@ def sa1_stream_bf16(xyz_n3, xyz_cn, sa_modules, feats, planes=None):
     scratch = torch.empty(nbytes // 8, dtype=torch.int64, device=dev)
     cfs = [0 if f is None else f.shape[1] for f in feats]
     imgs = [[sa_bf16_image(layers, cf, False) for layers in mod._folded] for mod, cf in zip(sa_modules, cfs)]
+    lvl2 = None
+    if m2 > 0:
+        lvl2 = (torch.empty(B, m2, dtype=torch.int32, device=dev), torch.empty(B, m2, 3, dtype=torch.float32, device=dev),
+                torch.empty(B, 3, m2, dtype=torch.float32, device=dev))
     P = C.c_void_p
     lp = (P * 3)(*[t.data_ptr() for t in lists])
     ia = (P * 3)(*[t.data_ptr() for t in imgs[0]])
@@ -574,12 +589,22 @@ def sa1_stream_bf16(xyz_n3, xyz_cn, sa_modules, feats, planes=None):
     with torch.cuda.device(dev):
         L.call("captra_sa1_stream_bf16", B, N, M, L.ptr(xyz_n3), L.ptr(xyz_cn), L.ptr(planes), rad, L.ptr(idx), L.ptr(n3), L.ptr(cn), lp,
                cfs[0], L.ptr(feats[0]), ia, L.ptr(outs[0]), cfs[1] if len(cfs) > 1 else -1, L.ptr(feats[1]) if len(feats) > 1 else None,
-               ib, L.ptr(outs[1]) if len(outs) > 1 else None, L.ptr(scratch))
+               ib, L.ptr(outs[1]) if len(outs) > 1 else None, m2, L.ptr(lvl2[0]) if lvl2 else None, L.ptr(lvl2[1]) if lvl2 else None,
+               L.ptr(lvl2[2]) if lvl2 else None, L.ptr(scratch))
     for mod, cf in zip(sa_modules, cfs):
         for (l1, l2, l3), k in zip(mod._folded, _L1_STREAM_K):
             _work("sa_scale_fused", flops=2.0 * B * M * k * ((cf + 3) * l1.cout + l1.cout * l2.cout + l2.cout * l3.cout),
                   nbytes=4.0 * B * (cf * N + 3 * N + M * k + 3 * M + l3.cout * M))
+    if lvl2 is not None:
+        return idx, n3, cn, lists, outs, scratch, lvl2
     return idx, n3, cn, lists, outs, scratch
+
+
+def sa1_stream_spans(scratch):
+    """(sampler span, whole span) in us of the launch that used `scratch`, from the kernel's own 100 MHz stamps (synchronises)."""
+    w = scratch.view(torch.int32)[-16:].cpu().numpy().astype("uint32")
+    start = (~w[2]) & 0xFFFFFFFF
+    return float((int(w[3]) - int(start)) & 0xFFFFFFFF) / 100.0, float((int(w[4]) - int(start)) & 0xFFFFFFFF) / 100.0
 
 
 def sa1_stream_gave_up(scratch) -> bool:

@@ -89,6 +89,10 @@ class EvalTrackModel(BaseModel):
         # stream of its own, the networks' first level walking the centres as they are picked; 0 / 1 = the sampler, then the
         # networks.  Same picks, same neighbour lists, same bits.
         self.sampler_chunks = int(cfg.get("sampler_chunks", os.environ.get("CAPTRA_SAMPLER_CHUNKS", "0")))
+        # bf16 mode, one part: the first level of BOTH networks inside the sampler's launch (csrc/sa_bf16.hip level-1 stream kernel:
+        # sampler workgroups publish their picks, the other workgroups run ball query + shared MLPs of the published centres).
+        # Same picks, lists and features, bit for bit (tests/test_l1_stream_gpu.py); cfg['l1_stream'] = False / CAPTRA_L1_STREAM=0: off
+        self.l1_stream = bool(cfg.get("l1_stream", True))
         # replay one captured hipGraph per frame instead of launching the ~140 kernels of a step one by one
         # (captra_amd/graph.py); opt-in: `--hipgraph` of captra_amd.track / cfg['hipgraph'].  Same kernels, same bits.
         self.use_graph = bool(cfg.get("hipgraph", False))
@@ -189,13 +193,39 @@ class EvalTrackModel(BaseModel):
     def _step_prep(self, input, npcs_input, last_pose, level1_only=False, side=None) -> bool:
         """The part both networks wait for: CoordinateNet's canonicalised cloud and its geometry (sampling, neighbour lists,
         interpolation weights).  False when the cloud does not fit the one-launch sampler (no side-by-side schedule then)."""
+        from . import fused
         from .networks import _canonicalize
-        cam = _canonicalize(npcs_input["points"], npcs_input["points_mean"], npcs_input["canon_pose"])
-        geom = self.npcs_net.backbone.precompute_geometry(cam[1], level1_only=level1_only, side=side)
+        coord_bb = self.npcs_net.backbone
+        # bf16 mode, one part: both networks' first level inside the sampler's launch (the level-1 stream kernel)
+        stream = (self.l1_stream and self.num_parts == 1 and self.share_geometry and fused.USE_L1_STREAM and fused.mlp_dtype() == "bf16"
+                  and not self.training and npcs_input["points"].is_cuda and npcs_input["points"].shape[2] <= 4096
+                  and npcs_input["points"].shape[0] <= fused.L1_STREAM_MAX_CLOUDS)
+        cam = _canonicalize(npcs_input["points"], npcs_input["points_mean"], npcs_input["canon_pose"], want_planes=stream)
+        stream_level1 = None
+        if stream:
+            # RotationNet's backbone sees the bare coordinates, CoordinateNet's the coordinates as features too (use_xyz_feat)
+            # RotationNet's backbone sees the bare coordinates, CoordinateNet's the coordinates as features too.  CAPTRA_L1_NETS=rot
+            # (A/B): RotationNet's level only, CoordinateNet's three scales as launches of its own branch -- measured equal at 32
+            # trajectories (1.27 ms per step either way: the step is bound by the chip's work, not by the sampler's latency)
+            nets = [(self.net.regress_net.encoder, None)]
+            if os.environ.get("CAPTRA_L1_NETS", "both") == "both":
+                nets.append((coord_bb, cam[0]))
+            stream_level1 = (cam[0], cam[2], nets)
+        geom = coord_bb.precompute_geometry(cam[1], level1_only=level1_only, side=side, stream_level1=stream_level1)
         if geom is None:
             return False
-        npcs_input["_canon"], npcs_input["_geom"] = cam, geom
+        npcs_input["_canon"], npcs_input["_geom"] = (cam[0], cam[1]), geom
+        scratch = (geom["sa1"].get("pooled") or {}).get("_scratch")
+        if scratch is not None:
+            self._l1_scratch = scratch
         return True
+
+    def check_l1_stream(self) -> None:
+        """Raises when a consumer of the last level-1 stream launch gave up waiting for its sampler (bounded spins; synchronises)."""
+        from . import fused
+        scratch = getattr(self, "_l1_scratch", None)
+        if scratch is not None and fused.sa1_stream_gave_up(scratch):
+            raise RuntimeError("level-1 stream kernel: a consumer workgroup gave up waiting for the sampler; the step's outputs are incomplete")
 
     def _step_rot(self, input, npcs_input, last_pose):
         """RotationNet up to its heads' raw per-point output (needs nothing of CoordinateNet's but, for one part, its geometry)."""
@@ -480,6 +510,7 @@ class EvalTrackModel(BaseModel):
                 if self.frame_hook is not None:
                     self.frame_hook(i, pose)
         self.pred_dict = {"poses": pred_poses, "npcs_pred": npcs_pred}
+        self.check_l1_stream()
         if save:
             self._save(frame_nums)
 

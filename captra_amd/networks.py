@@ -22,11 +22,11 @@ from .pose_utils.procrustes import (rot_around_yaxis_to_3d, scale_pts_mask, tran
                                     translate_pts_mask)
 
 
-def _canonicalize(points, points_mean, pose, num_parts=1):
-    """R^T((points + mean) - t)/s for B*num_parts clouds -> (cn (Q,3,N), n3 (Q,N,3))."""
+def _canonicalize(points, points_mean, pose, num_parts=1, want_planes=False):
+    """R^T((points + mean) - t)/s for B*num_parts clouds -> (cn (Q,3,N), n3 (Q,N,3)[, planes (Q,3,pad256(N))])."""
     if points.is_cuda:
         return fused.canonicalize(points.float().contiguous(), points_mean.float(), pose["rotation"].float(),
-                                  pose["translation"].float(), pose["scale"].float(), num_parts)
+                                  pose["translation"].float(), pose["scale"].float(), num_parts, want_planes=want_planes)
     raise RuntimeError("captra_amd networks run on the GPU only (no CPU path)")
 
 

@@ -191,6 +191,10 @@ class PointNetSetAbstractionMsg(_FoldCache, nn.Module):
         new_xyz_n3, new_xyz = geom["new_xyz_n3"], geom["new_xyz"]
         self.last_new_xyz_n3 = new_xyz_n3
         self.last_geom = geom
+        pooled = geom.get("pooled")
+        if pooled is not None and id(self) in pooled:
+            # the level-1 stream kernel (fused.sa1_stream_bf16) ran this level beside the sampler: nothing left to launch
+            return new_xyz, pooled[id(self)]
         if self._can_fuse(xyz):
             return new_xyz, self._forward_fused(xyz.contiguous(), xyz_n3, points, new_xyz_n3, geom)
         return new_xyz, self._forward_layers(xyz, xyz_n3, points, new_xyz, new_xyz_n3)

@@ -123,6 +123,11 @@ int captra_three_interpolate_grad_ws(int b, int c, int n, int m, const float *gr
 int captra_canonicalize(int b, int p, int n, const float *pts, const float *mean, const float *rot,
                         const float *trans, const float *scale, float *out_cn, float *out_n3,
                         captra_stream_t stream);
+/* The same with a third layout: out_planes (B*P,3,pad256(N)), the clouds in the ball query's LDS plane order (captra_bq_planes),
+ * which the level-1 stream kernel's tickets copy into LDS as they are.  Any output may be NULL. */
+int captra_canonicalize_planes(int b, int p, int n, const float *pts, const float *mean, const float *rot,
+                               const float *trans, const float *scale, float *out_cn, float *out_n3,
+                               float *out_planes, captra_stream_t stream);
 
 /* Ball query for up to 4 radii in ONE scan of xyz (PointNetSetAbstractionMsg's loop over
  * radius_list, pointnet_utils.py:228-233).  idx_r (r = 0..nr-1) is (B,M,nsample[r]) i32 with
@@ -354,7 +359,9 @@ void captra_set_centre_window(int m0, int mc);
  * captra_ball_query_multi + 3 x captra_sa_scale_bf16 per network, bit for bit.  img_*3[s]: the scales' captra_pack_sa_bf16 images
  * (pre = 0).  scratch: captra_sa1_stream_scratch_bytes(b, m) bytes, zeroed by the call on `stream`; once the launch completed,
  * word 1 of the 16 unsigned words at scratch + 8*b*m is non-zero iff a consumer gave up waiting (bounded spins; outputs incomplete
- * then).  planes (optional, NULL = staged from xyz_n3 by every ticket): the clouds once more, (B,3,pad256(N)) in the ball query's LDS
+ * then).  m2 > 0 (<= 256): the sampler workgroups go on to pick m2 of their m centres -- the second level's sampling
+ * (captra_fps_gather on new_xyz_n3, bit for bit: fps2_idx (B,m2) indexes the level-1 centres, new2_xyz_* their coordinates) -- while
+ * the consumers work off their backlog.  planes (optional, NULL = staged from xyz_n3 by every ticket): the clouds once more, (B,3,pad256(N)) in the ball query's LDS
  * plane order (captra_bq_planes: element ((chunk / 4) * 64 + lane) * 4 + chunk % 4 of plane a = coordinate a of point 64 chunk + lane, +inf
  * beyond N), so that a ticket's staging is straight 16-byte copies.  -2: n > 4096, m > 512, m % 32 != 0, b > 256 or feature counts
  * outside {0, 3}. */
@@ -363,7 +370,8 @@ int captra_bq_planes(int b, int n, const float *xyz_n3, float *planes, captra_st
 int captra_sa1_stream_bf16(int b, int n, int m, const float *xyz_n3, const float *xyz_cn, const float *planes, const float *radius3, int *fps_idx,
                            float *new_xyz_n3, float *new_xyz_cn, int *const *idx3, int cfa, const float *feat_a,
                            const unsigned char *const *img_a3, float *out_a, int cfb, const float *feat_b,
-                           const unsigned char *const *img_b3, float *out_b, void *scratch, captra_stream_t stream);
+                           const unsigned char *const *img_b3, float *out_b, int m2, int *fps2_idx, float *new2_xyz_n3,
+                           float *new2_xyz_cn, void *scratch, captra_stream_t stream);
 
 /* SA scale with a pre-transformed first layer.  Layer 1's k-ascending chain runs over the cfeat feature rows first and the
  * three relative-xyz rows last (pointnet_utils.py:234-240), and its first cfeat steps depend on the SOURCE point only:
@@ -529,6 +537,7 @@ void captra_pw_set_occupancy(int occ);      /* dense layers, 64x64 wave tiles: w
 void captra_pw_set_pair(int on);            /* dense layers: 1 = paired column tiles where L is even (default), 0 = never */
 void captra_sa1_stream_set_grid(int grid, int prio); /* level-1 stream kernel: workgroups (0 = two per CU), 1 = samplers at s_setprio 3 (default) */
 void captra_sa1_stream_set_fine(int centres); /* level-1 stream kernel: trailing centres handed out as fine tickets of 8 (multiple of 32, default 32) */
+void captra_sa1_stream_set_whole(int windows); /* level-1 stream kernel: bits 0-7 = leading windows of 32 centres handed out as one ticket for all three scales (default 0), bit 8 = three scale tickets per window instead of two */
 void captra_sa_bf16_set_variant(int v);     /* bf16 SA scales: bit 0 = small-input scales without gather prefetch / fragment ring, bits 1-2 = ring depth
                                                4 / 2 / 3 / 6, bits 4.. = ablations (coalesced gather, eight fragments only, no stores: WRONG results, timing only) */
 void captra_group_set_shape(int lds_kb, int ccmax, int ppb); /* group_points: staging budget (KiB, <= 64), channels per workgroup, positions per

@@ -83,10 +83,15 @@ def test_stream_kernel_equals_three_launches(device, B, N, M, cfs):
         assert fused.sa1_stream_supported(N, mods, cfs)
         want = _reference(x_n3, x_cn, mods, feats)
         planes = fused.bq_planes(x_n3)
+        m2 = min(128, M // 2)
+        want2 = fused.fps_gather(want[1], m2)
         for rep in range(3):
-            got = fused.sa1_stream_bf16(x_n3, x_cn, mods, feats, planes=planes if rep else None)
+            got = fused.sa1_stream_bf16(x_n3, x_cn, mods, feats, planes=planes if rep else None, m2=m2 if rep != 1 else 0)
             torch.cuda.synchronize()
-            _check(got, want, f"rep {rep}")
+            _check(got[:6], want, f"rep {rep}")
+            if rep != 1:
+                for g, w, what in zip(got[6], want2, ("picks", "coordinates (B,m2,3)", "coordinates (B,3,m2)")):
+                    assert torch.equal(g, w), f"rep {rep}: level-2 {what} differ"
     finally:
         fused.set_mlp_dtype("fp32")
 
@@ -106,9 +111,10 @@ def test_stream_kernel_under_uneven_load_and_small_grids(device):
         want = _reference(x_n3, x_cn, mods, feats)
         side = torch.cuda.Stream()
         a = torch.randn(4096, 4096, device=device)
-        for grid, prio, fine in ((0, 1, 32), (B + 1, 1, 0), (B + 7, 0, 64), (300, 1, 512), (1024, 1, 32)):
+        for grid, prio, fine, whole in ((0, 1, 32, 0), (B + 1, 1, 0, 16), (B + 7, 0, 64, 256), (300, 1, 512, 3), (1024, 1, 32, 256 + 12)):
             L.lib().captra_sa1_stream_set_grid(grid, prio)
             L.lib().captra_sa1_stream_set_fine(fine)
+            L.lib().captra_sa1_stream_set_whole(whole)
             for rep in range(4):
                 with torch.cuda.stream(side):
                     for _ in range(3):
@@ -119,4 +125,51 @@ def test_stream_kernel_under_uneven_load_and_small_grids(device):
     finally:
         L.lib().captra_sa1_stream_set_grid(0, 1)
         L.lib().captra_sa1_stream_set_fine(32)
+        L.lib().captra_sa1_stream_set_whole(0)
         fused.set_mlp_dtype("fp32")
+
+
+@pytest.mark.parametrize("tag", ["bottle", "camera"])
+def test_track_step_with_level1_stream_equals_plain_step(device, tag):
+    """EvalTrackModel in bf16 mode with both networks' first level inside the sampler's launch (model.l1_stream): every frame's
+    pose equals the plain step's (sampler, ball query and SA1 scales as launches of their own) bit for bit, eager and as a captured
+    graph, chained over the frames of a trajectory -- and no consumer gave up."""
+    from captra_amd.graph import TrackStepGraph
+    from tests.test_model_gpu import _trainer
+    trainer, cfg, sd, data = _trainer(tag, device)
+    model = trainer.model.eval()
+    model.track_cfg["gt_label"] = False
+    model.mlp_dtype = "bf16"
+    model.set_data(data)
+    pose0 = {k: v.clone() for k, v in model.feed_dict[0]["gt_part"].items()}
+
+    def loop(step):
+        pe, out = pose0, []
+        for i in range(1, len(data)):
+            pe = step(i, pe)
+            out.append({k: v.clone() for k, v in pe.items()})
+        torch.cuda.synchronize()
+        return out
+
+    def eager(i, pe):
+        with torch.no_grad():
+            return model.track_step(model.feed_dict[i], model.npcs_feed_dict[i], pe)[1]
+
+    try:
+        model.l1_stream = False
+        want = loop(eager)
+        model.l1_stream = True
+        model._l1_scratch = None
+        got = loop(eager)
+        assert model._l1_scratch is not None, "the level-1 stream kernel did not run"
+        model.check_l1_stream()
+        graph = TrackStepGraph(model, model.feed_dict[1]["points"], model.feed_dict[1]["points_mean"], pose0)
+        got_g = loop(lambda i, pe: graph.replay(model.feed_dict[i]["points"], model.feed_dict[i]["points_mean"], pe))
+        model.check_l1_stream()
+    finally:
+        model.l1_stream = True
+        model.mlp_dtype = None
+    for i, (a, b, c) in enumerate(zip(want, got, got_g)):
+        for k in a:
+            assert torch.equal(a[k], b[k]), (i, k, "eager")
+            assert torch.equal(a[k], c[k]), (i, k, "graph")

@@ -46,11 +46,15 @@ def timed(fn, reps=20):
 
 fused.set_mlp_dtype("bf16")
 mods = [module(0, 1), module(3, 2)]
+one_net = "--one" in sys.argv
+if one_net:
+    sys.argv.remove("--one")
+    mods = mods[:1]
 batches = [int(a) for a in sys.argv[1:]] or [1, 16, 32, 64]
 for B in batches:
     x_n3 = torch.from_numpy(np.stack([clouds.s_nocs(1000 + i)[0] for i in range(B)]).astype(np.float32)).to(dev).contiguous()
     x_cn = x_n3.transpose(1, 2).contiguous()
-    feats = [None, x_cn]
+    feats = [None, x_cn][:len(mods)]
 
     def sampler():
         return fused.fps_gather(x_n3, 512)
@@ -69,18 +73,25 @@ for B in batches:
     use_planes = [True]
 
     def stream():
-        return fused.sa1_stream_bf16(x_n3, x_cn, mods, feats, planes=planes if use_planes[0] else None)
+        return fused.sa1_stream_bf16(x_n3, x_cn, mods, feats, planes=planes if use_planes[0] else None, m2=128)
 
     t_s, t_3 = timed(sampler), timed(three)
     line = f"B={B:3d}: sampler alone {t_s:7.1f} us, seven launches {t_3:7.1f} us"
-    for grid, prio, fine in ((0, 1, 32), (0, 1, 32 + (8 << 16)), (0, 1, 32 + (16 << 16)), (0, 1, 32 + (17 << 16)), (0, 1, 32 + (18 << 16)), (0, 1, 32 + (19 << 16)), (0, 1, 32 + (23 << 16))):
-        _lib.lib().captra_sa1_stream_set_grid(grid, prio)
-        _lib.lib().captra_sa1_stream_set_fine(fine)
-        line += f", stream[grid {grid or 512}, prio {prio}, fine {fine & 0xFFFF} dbg {fine >> 16}] {timed(stream):7.1f} us"
-    _lib.lib().captra_sa1_stream_set_grid(0, 1)
-    _lib.lib().captra_sa1_stream_set_fine(32)
+    lib = _lib.lib()
+    for whole, fine, dbg in ((0, 32, 0), (256, 32, 0), (0, 64, 0), (0, 0, 0), (4, 32, 0), (0, 32, 8), (0, 32, 16), (256, 32, 16)):  # (dbg & 1 reads lists nobody wrote: not in a sweep)
+        lib.captra_sa1_stream_set_whole(whole)
+        lib.captra_sa1_stream_set_fine(fine + (dbg << 16))
+        print(f"  B={B} whole {whole} fine {fine} dbg {dbg} ...", end="", flush=True)
+        t_ = timed(stream)
+        got_ = stream()
+        torch.cuda.synchronize()
+        sp_ = fused.sa1_stream_spans(got_[5])
+        print(f" {t_:6.1f} us (in-kernel: sampler {sp_[0]:6.1f}, all {sp_[1]:6.1f})", flush=True)
+        line += f", [whole {whole} fine {fine} dbg {dbg}] {t_:6.1f}"
+    lib.captra_sa1_stream_set_whole(0)
+    lib.captra_sa1_stream_set_fine(32)
     use_planes[0] = False
     line += f", no plane image {timed(stream):7.1f} us"
     got = stream()
     torch.cuda.synchronize()
-    print(line + f", gave up: {fused.sa1_stream_gave_up(got[-1])}", flush=True)
+    print(line + f", gave up: {fused.sa1_stream_gave_up(got[5])}", flush=True)
