@@ -65,6 +65,7 @@ _SIGNATURES = {
     "captra_mlp_chain_bf16": [_INT, _INT, _LL, _INT, _INT, _INT, _P, _P, _P, _P, _P, _P],
     "captra_pack_sa_bf16": [_INT] * 5 + [_P] * 7 + [_P],
     "captra_sa_scale_bf16": [_INT] * 9 + [_P] * 6 + [_INT, _INT, _P],
+    "captra_query_and_group": [_INT, _INT, _INT, _F, _INT, _INT, _INT, _P, _P, _P, _P, _P, _P],
     "captra_bq_planes": [_INT, _INT, _P, _P, _P],
     "captra_sa1_stream_bf16": [_INT, _INT, _INT, _P, _P, _P, _P, _P, _P, _P, _P, _INT, _P, _P, _P, _INT, _P, _P, _P, _INT, _P, _P, _P, _P, _P],
     "captra_coord_tail": [_INT, _INT, _INT, _INT, _LL, _P, _P, _P, _INT, _P, _P, _P],
@@ -153,6 +154,9 @@ def lib():
             l.captra_sa1_stream_set_fine.restype = None
             l.captra_sa1_stream_set_whole.argtypes = [_INT]
             l.captra_sa1_stream_set_whole.restype = None
+        if hasattr(l, "captra_query_and_group_set_shape"):
+            l.captra_query_and_group_set_shape.argtypes = [_INT, _INT]
+            l.captra_query_and_group_set_shape.restype = None
         if hasattr(l, "captra_pointwise_mlp_gn_tiles"):
             l.captra_pointwise_mlp_gn_tiles.argtypes = [_INT, _INT, _LL]
             l.captra_pointwise_mlp_gn_tiles.restype = _INT

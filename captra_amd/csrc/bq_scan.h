@@ -75,7 +75,8 @@ __device__ __forceinline__ void bq_scan_centre(const float *xs, const float *ys,
 // NC centres -- NC independent chains of packed arithmetic behind one LDS latency -- then each (centre, radius) list takes its four
 // chunks' hits in index order exactly as in bq_scan_centre.  For a wave that owns several centres and shares its SIMD with few
 // other waves (the level-1 stream kernel's consumers: two waves per SIMD), where one centre at a time waits out every LDS read.
-// List (c, r) = rows[r] + c * ns[r] (consecutive centres: consecutive rows); cnt = ns closes a slot from the start.
+// List (c, r) = rows[r] + c * ns[r] (consecutive centres: consecutive rows); cnt = ns closes a slot from the start.  Radii ascending
+// (r2[NR - 1] the largest: the quick reject tests against it).
 template <int NC, int NR>
 __device__ __forceinline__ void bq_scan_centres(const float *xs, const float *ys, const float *zs, int groups, int t0, const float (&cx)[NC],
                                                 const float (&cy)[NC], const float (&cz)[NC], const float (&r2)[NR], const int (&ns)[NR],
@@ -98,6 +99,14 @@ __device__ __forceinline__ void bq_scan_centres(const float *xs, const float *ys
         any = false;
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
+            // quick reject: none of the centre's 256 tests of this group is inside the largest radius (the small radii of a level
+            // hit in a handful of the cloud's 64-point chunks: one min3 pair + one compare instead of four compare / branch pairs)
+            const float dmin4 = fminf(fminf(d2[c][0], d2[c][1]), fminf(d2[c][2], d2[c][3]));
+            if (__ballot(dmin4 < r2[NR - 1]) == 0ull) {
+#pragma unroll
+                for (int r = 0; r < NR; ++r) any = any || (cnt[c][r] < ns[r]);
+                continue;
+            }
 #pragma unroll
             for (int h = 0; h < 4; ++h) {
 #pragma unroll

@@ -7,6 +7,7 @@
 // `cc` channel rows of points[b] (contiguous cc*N floats) into LDS with 16-byte coalesced loads,
 // reads each idx quad ONCE, gathers the cc rows from LDS and writes 16-byte coalesced stores.
 #include "common.h"
+#include "bq_scan.h"
 
 // scatter_reduce.hip: CSR inversion of an index list + per-source-point sums (-2: shape outside that path)
 int captra_scatter_reduce(bool interp, int b, int c, int n_src, long long npos, const float *grad_out, const float *weight,
@@ -140,6 +141,132 @@ __global__ __launch_bounds__(GP_THREADS) void group_points_grad_kernel(int c, in
         atomicAdd(grad_points + ((size_t)b * c + ch) * n + id, grad_out[((size_t)b * c + ch) * npos + p]);
 }
 
+
+// ======================================================================================================================
+// QueryAndGroup in ONE launch (reference pointnet_lib/pointnet2_utils.py:274-310: ball_query -> grouping_operation(xyz) -> centre
+// subtraction -> grouping_operation(features) -> cat([features, xyz])).  A workgroup owns MCB consecutive centres of a cloud and a
+// chunk of the output's channels: it stages the cloud in LDS as the ball query's coordinate planes, its waves scan for their
+// centres four at a time (bq_scan.h: the same index-order scan as captra_ball_query), the lists stay in LDS -- and are written out
+// once when the caller wants them --, then the workgroup writes its channels position-major exactly as group_points_body does
+// (16-byte streaming stores, a channel's MCB x K positions contiguous): feature channels gathered from LDS-staged rows (or from
+// L2 when a row chunk does not fit), the three coordinate channels straight from the planes minus the centre.  Neither the index
+// list nor the grouped coordinates make a round trip through HBM between two launches.
+// ======================================================================================================================
+struct QgParams {
+    int n, m, k, c, use_xyz, cc, cs, mcb, stage_rows;      // cc: channels staged at a time, cs: channels per workgroup (a multiple of cc)
+    float r2;
+    const float *xyz_n3, *new_xyz, *feat;
+    float *out;
+    int *idx_out;
+};
+
+__device__ __forceinline__ int qg_plane_slot(int p) { return ((p >> 8) << 8) + ((p & 63) << 2) + ((p >> 6) & 3); }
+
+template <int NT>
+__global__ __launch_bounds__(NT) void query_and_group_kernel(QgParams q) {
+    extern __shared__ __attribute__((aligned(16))) float qg_lds[];
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const int npad = bq_pad(q.n);
+    float *xs = qg_lds, *ys = xs + npad, *zs = ys + npad;
+    int *lists = reinterpret_cast<int *>(zs + npad);            // [mcb][k]
+    float *ctr = reinterpret_cast<float *>(lists + q.mcb * q.k);   // [mcb][3]
+    float *rows = ctr + ((q.mcb * 3 + 3) & ~3);                 // [cc][n] (stage_rows)
+    const int b = blockIdx.z, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c0 = blockIdx.x * q.mcb;
+    const int ncen = (q.m - c0) < q.mcb ? (q.m - c0) : q.mcb;
+    const int ct = (q.feat != nullptr ? q.c : 0) + (q.use_xyz || q.feat == nullptr ? 3 : 0);   // channels of the output
+    const int cf = q.feat != nullptr ? q.c : 0;                 // of which features (first)
+    const int cs0 = blockIdx.y * q.cs;
+    const int cs1 = (cs0 + q.cs) < ct ? (cs0 + q.cs) : ct;      // this workgroup's channels [cs0, cs1), cc at a time
+    bq_stage_tile(q.xyz_n3 + (size_t)b * q.n * 3, 0, q.n, xs, ys, zs, tid, NT);
+    for (int e = tid; e < ncen * 3; e += NT) ctr[e] = q.new_xyz[((size_t)b * q.m + c0) * 3 + e];
+    __syncthreads();
+    // ---- the ball query of this workgroup's centres: wave w takes every (NT / 64)-th group of four ----------------------------
+    {
+        const float r2[1] = {q.r2};
+        const int ns[1] = {q.k};
+        for (int g0 = 4 * wave; g0 < ncen; g0 += NT / 16) {
+            float cx[4], cy[4], cz[4];
+            int cnt[4][1], first[4][1];
+            int *rws[1] = {lists + (size_t)g0 * q.k};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool live = g0 + u < ncen;
+                const int cl = live ? g0 + u : g0;
+                cx[u] = ctr[3 * cl + 0]; cy[u] = ctr[3 * cl + 1]; cz[u] = ctr[3 * cl + 2];
+                cnt[u][0] = live ? 0 : q.k;
+                first[u][0] = 0;
+            }
+            bq_scan_centres<4, 1>(xs, ys, zs, npad >> 8, 0, cx, cy, cz, r2, ns, rws, cnt, first, lane);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (g0 + u < ncen) bq_pad_row(rws[0] + (size_t)u * q.k, cnt[u][0], first[u][0], q.k, lane);
+        }
+    }
+    __syncthreads();
+    const int npos = ncen * q.k;                                // this workgroup's positions (k % 4 == 0)
+    if (q.idx_out != nullptr && blockIdx.y == 0) {
+        int4 *dst = reinterpret_cast<int4 *>(q.idx_out + ((size_t)b * q.m + c0) * q.k);
+        const int4 *src = reinterpret_cast<const int4 *>(lists);
+        for (int e = tid; e < npos / 4; e += NT) dst[e] = src[e];
+    }
+    // ---- the workgroup's channels, cc at a time: stage the chunk's feature rows, then channel after channel over the positions ---
+    const long long mk = (long long)q.m * q.k;
+    float *out_b = q.out + (size_t)b * ct * mk + (size_t)c0 * q.k;
+    for (int ch0 = cs0; ch0 < cs1; ch0 += q.cc) {
+        const int ch1 = (ch0 + q.cc) < cs1 ? (ch0 + q.cc) : cs1;
+        const int f1 = ch1 < cf ? ch1 : cf;                     // feature channels [ch0, f1) of this chunk
+        if (q.stage_rows && f1 > ch0) {
+            if (ch0 > cs0) __syncthreads();                     // (the last chunk's rows have been read)
+            const float *src = q.feat + ((size_t)b * q.c + ch0) * q.n;
+            const size_t nstage = (size_t)(f1 - ch0) * q.n;
+            if ((nstage & 3) == 0 && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
+                const float4 *s4 = reinterpret_cast<const float4 *>(src);
+                float4 *d4 = reinterpret_cast<float4 *>(rows);
+                for (size_t e = tid; e < nstage / 4; e += NT) d4[e] = s4[e];
+            } else {
+                for (size_t e = tid; e < nstage; e += NT) rows[e] = src[e];
+            }
+            __syncthreads();
+        }
+        for (int pb = 0; pb < npos; pb += NT * 16) {
+            int4 id[4];
+            int cen[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int p = pb + (u * NT + tid) * 4;
+                id[u] = p < npos ? *reinterpret_cast<const int4 *>(lists + p) : make_int4(0, 0, 0, 0);
+                cen[u] = p < npos ? p / q.k : 0;                // (a quad never straddles two centres: k % 4 == 0)
+            }
+            for (int ch = ch0; ch < ch1; ++ch) {
+                float *orow = out_b + (size_t)ch * mk;
+                if (ch < cf) {
+                    const float *row = q.stage_rows ? rows + (size_t)(ch - ch0) * q.n : q.feat + ((size_t)b * q.c + ch) * q.n;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int p = pb + (u * NT + tid) * 4;
+                        const f32x4 vv = {row[id[u].x], row[id[u].y], row[id[u].z], row[id[u].w]};
+                        if (p < npos) __builtin_nontemporal_store(vv, reinterpret_cast<f32x4 *>(orow + p));
+                    }
+                } else {
+                    const float *plane = xs + (size_t)(ch - cf) * npad;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int p = pb + (u * NT + tid) * 4;
+                        const float cc0 = ctr[3 * cen[u] + (ch - cf)];
+                        const f32x4 vv = {plane[qg_plane_slot(id[u].x)] - cc0, plane[qg_plane_slot(id[u].y)] - cc0,
+                                          plane[qg_plane_slot(id[u].z)] - cc0, plane[qg_plane_slot(id[u].w)] - cc0};
+                        if (p < npos) __builtin_nontemporal_store(vv, reinterpret_cast<f32x4 *>(orow + p));
+                    }
+                }
+            }
+        }
+    }
+}
+
+CAPTRA_KNOB int g_qg_mcb = 0, g_qg_cc = 0, g_qg_cs = 0, g_qg_nt = 0;     // measurement knobs: centres per workgroup, channels per staging chunk / per workgroup, threads (0 = heuristic)
+
 // channel-chunk size, positions per workgroup and position blocks of one job (rows fit the LDS budget)
 void gp_shape(int b, int c, int n, long long npos, int &cc, int &ppb, long long &pos_blocks) {
     const size_t row_bytes = (size_t)n * sizeof(float);
@@ -211,6 +338,70 @@ int launch_group_grad(int b, int c, int n, long long npos, const float *grad_out
 }
 
 }  // namespace
+
+extern "C" void captra_query_and_group_set_shape(int mcb, int cc) { g_qg_mcb = mcb & 0xFF; g_qg_nt = (mcb >> 8) & 0xFFF; g_qg_cc = cc & 0xFF; g_qg_cs = (cc >> 8) & 0xFFF; }   // (bits 8..: threads / channels per workgroup)
+
+// QueryAndGroup(radius, nsample, use_xyz)(xyz, new_xyz, features) of the reference (pointnet2_utils.py:274-310) in one launch:
+// out (B, C + 3, M, K) = cat([features[:, :, idx], xyz[idx] - new_xyz]) (features first; (B,3,M,K) when features == NULL; (B,C,M,K)
+// when use_xyz == 0), idx = the ball query's lists (also written to idx_out (B,M,K) when non-NULL).  xyz (B,N,3), new_xyz (B,M,3),
+// features (B,C,N) or NULL.  -2: nsample % 4 != 0, unaligned out / idx_out, or a cloud whose planes do not fit the LDS (N > 8192):
+// the caller runs captra_ball_query + captra_group_points then.
+extern "C" int captra_query_and_group(int b, int n, int m, float radius, int nsample, int c, int use_xyz, const float *xyz, const float *new_xyz,
+                                      const float *features, float *out, int *idx_out, captra_stream_t stream) {
+    if (b < 0 || n < 1 || m < 0 || nsample < 1 || c < 0) return -1;
+    if (features == nullptr && !use_xyz) return -1;
+    if (b == 0 || m == 0) return 0;
+    if (nsample % 4 || (reinterpret_cast<uintptr_t>(out) & 15) || (reinterpret_cast<uintptr_t>(idx_out) & 15) || n > 8192) return -2;
+    if ((long long)m * nsample * (c + 3) >= (1ll << 31)) return -2;
+    QgParams q;
+    q.n = n; q.m = m; q.k = nsample; q.c = features != nullptr ? c : 0; q.use_xyz = use_xyz; q.r2 = radius * radius;
+    q.xyz_n3 = xyz; q.new_xyz = new_xyz; q.feat = features; q.out = out; q.idx_out = idx_out;
+    const int ct = q.c + ((use_xyz || features == nullptr) ? 3 : 0);
+    // Threads: a long scan with few channels behind it (SA1: 4096 points, <= 6 channels) is bound by the search -- 512 threads, so that
+    // two workgroups keep 16 waves on a CU; a short scan with hundreds of channels (SA2) by the stores -- 256 threads as group_points.
+    // Centres per workgroup: 4096 positions at most (16 KiB of lists).  Feature rows staged in LDS cc at a time when a chunk of at
+    // least 8 fits beside the planes and the lists in 64 KiB (two workgroups per CU), else gathered from L2; a workgroup takes cs
+    // channels (a multiple of cc), i.e. repeats the search ceil(ct / cs) times per centre block: as few as still cover the chip.
+    int nt = (n >= 2048 && ct <= 16) ? 512 : 256;
+    if (g_qg_nt == 256 || g_qg_nt == 512) nt = g_qg_nt;
+    // (sweep on the CAPTRA shapes at 32 clouds, tools/bench_qg.py --sweep: SA1 calls 45 -> 34-40 us with 512 threads and 32 centres per
+    // workgroup; SA2 K = 64: 32 centres, rows 8 at a time, 48 channels per workgroup 78-82 us (one search per 8 channels: 88-106);
+    // K = 128: 16 centres, 8 channels per workgroup 124 us = 5.7 TB/s (48 and more: 140-150))
+    const bool many = ct > 16;
+    int mcb = (many ? 2048 : 4096) / nsample;
+    if (mcb > 32) mcb = 32;
+    mcb = (mcb + 3) & ~3;
+    if (mcb < 4) mcb = 4;
+    if (g_qg_mcb > 0) mcb = (g_qg_mcb + 3) & ~3;
+    if (mcb * nsample > 8192) return -2;
+    const size_t fixed = (size_t)3 * bq_pad(n) * 4 + (size_t)mcb * nsample * 4 + (size_t)((mcb * 3 + 3) & ~3) * 4;
+    int cc = ct;
+    q.stage_rows = 0;
+    if (q.c > 0) {
+        const long long room = 64 * 1024 - (long long)fixed;
+        const int fit = room > 0 ? (int)(room / ((long long)n * 4)) : 0;
+        if (fit >= 8 || fit >= q.c) { q.stage_rows = 1; cc = fit < 8 ? fit : 8; }
+        else cc = 8;
+    }
+    if (g_qg_cc > 0) cc = g_qg_cc;
+    if (cc > ct) cc = ct;
+    int cs = !many ? ct : (nsample <= 64 ? 6 * cc : cc);
+    if (g_qg_cs > 0) cs = (g_qg_cs + cc - 1) / cc * cc;
+    if (cs < cc) cs = cc;
+    q.mcb = mcb; q.cc = cc; q.cs = cs;
+    const size_t lds = fixed + (q.stage_rows ? (size_t)cc * n * 4 : 0);
+    if (lds > 160 * 1024) return -2;
+    dim3 grid((m + mcb - 1) / mcb, (ct + cs - 1) / cs, b);
+    static CaptraDeviceOnce once;
+    if (once.first_use()) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(query_and_group_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return (int)hipGetLastError();
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(query_and_group_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return (int)hipGetLastError();
+        once.done();
+    }
+    if (nt == 512) { CAPTRA_LAUNCH("query_and_group", query_and_group_kernel<512>, grid, dim3(512), lds, (hipStream_t)stream, q); }
+    else { CAPTRA_LAUNCH("query_and_group", query_and_group_kernel<256>, grid, dim3(256), lds, (hipStream_t)stream, q); }
+    return captra_last_error();
+}
 
 extern "C" void captra_group_set_shape(int lds_kb, int ccmax, int ppb) {
     g_gp_lds_kb = lds_kb < 1 ? 1 : (lds_kb > 64 ? 64 : lds_kb);

@@ -110,6 +110,26 @@ def group_points_multi(points_list, idx_list, outs=None):
     return outs
 
 
+def query_and_group(radius: float, nsample: int, xyz_n3, new_xyz_n3, features=None, use_xyz: bool = True, want_idx: bool = False):
+    """The reference's QueryAndGroup module (pointnet_lib/pointnet2_utils.py:274-310) as ONE launch (captra_query_and_group): ball
+    query, grouping of the coordinates, centre subtraction, grouping of the features and the concat.  xyz (B,N,3), new_xyz (B,M,3),
+    features (B,C,N) or None -> (B, C + 3, M, K) (features first), [(B,M,K) int32 lists].  None when the shape is outside the
+    kernel (nsample % 4, N > 8192): the caller runs the two ops."""
+    L.require_device(xyz_n3, new_xyz_n3, features)
+    B, N, _ = xyz_n3.shape
+    M = new_xyz_n3.shape[1]
+    C = 0 if features is None else features.shape[1]
+    if nsample % 4 or N > 8192 or (features is None and not use_xyz):
+        return None
+    ct = C + (3 if (use_xyz or features is None) else 0)
+    out = torch.empty(B, ct, M, nsample, dtype=torch.float32, device=xyz_n3.device)
+    idx = torch.empty(B, M, nsample, dtype=torch.int32, device=xyz_n3.device) if want_idx else None
+    with torch.cuda.device(xyz_n3.device):
+        L.call("captra_query_and_group", B, N, M, float(radius), nsample, C, 1 if use_xyz else 0, L.ptr(xyz_n3), L.ptr(new_xyz_n3),
+               L.ptr(features), L.ptr(out), L.ptr(idx))
+    return (out, idx) if want_idx else out
+
+
 def seg_softmax_argmax(logits):
     """logits (B,S,N) -> (softmax over S (B,S,N), labels (B,N) int32 = first index of the largest logit): CoordinateNet's
     read-out (networks.py:50 + model.py:466) in one launch."""

@@ -174,6 +174,10 @@ class EvalTrackModel(BaseModel):
     def _track_step(self, input, npcs_input, last_pose):
         self._step_begin(input, npcs_input, last_pose)
         join = self._fork_rotation_net(input, npcs_input, last_pose) if self._overlap_nets(input) else None
+        if join is None and "_geom" not in npcs_input and self._l1_stream_on(npcs_input):
+            # networks one after the other (no fork): the shared prefix with the level-1 stream kernel all the same -- CoordinateNet
+            # takes it from `_geom`, RotationNet through the shared geometry
+            self._step_prep(input, npcs_input, last_pose)
         npcs_pred = self._step_coord(npcs_input)
         if join is not None:
             join()
@@ -197,9 +201,7 @@ class EvalTrackModel(BaseModel):
         from .networks import _canonicalize
         coord_bb = self.npcs_net.backbone
         # bf16 mode, one part: both networks' first level inside the sampler's launch (the level-1 stream kernel)
-        stream = (self.l1_stream and self.num_parts == 1 and self.share_geometry and fused.USE_L1_STREAM and fused.mlp_dtype() == "bf16"
-                  and not self.training and npcs_input["points"].is_cuda and npcs_input["points"].shape[2] <= 4096
-                  and npcs_input["points"].shape[0] <= fused.L1_STREAM_MAX_CLOUDS)
+        stream = self._l1_stream_on(npcs_input)
         cam = _canonicalize(npcs_input["points"], npcs_input["points_mean"], npcs_input["canon_pose"], want_planes=stream)
         stream_level1 = None
         if stream:
@@ -219,6 +221,14 @@ class EvalTrackModel(BaseModel):
         if scratch is not None:
             self._l1_scratch = scratch
         return True
+
+    def _l1_stream_on(self, npcs_input) -> bool:
+        """bf16 mode, one part: both networks' first level inside the sampler's launch (the level-1 stream kernel)."""
+        from . import fused
+        pts = npcs_input["points"]
+        return (self.l1_stream and self.num_parts == 1 and self.share_geometry and fused.USE_L1_STREAM and fused.mlp_dtype() == "bf16"
+                and not self.training and pts.is_cuda and pts.shape[2] <= 4096 and pts.shape[0] <= fused.L1_STREAM_MAX_CLOUDS
+                and not (self.track_cfg["gt_label"] or self.track_cfg["nocs2d_label"]))
 
     def check_l1_stream(self) -> None:
         """Raises when a consumer of the last level-1 stream launch gave up waiting for its sampler (bounded spins; synchronises)."""

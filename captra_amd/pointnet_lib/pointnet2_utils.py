@@ -188,6 +188,15 @@ class QueryAndGroup(nn.Module):
         self.radius, self.nsample, self.use_xyz = radius, nsample, use_xyz
 
     def forward(self, xyz: torch.Tensor, new_xyz: torch.Tensor, features: torch.Tensor = None) -> torch.Tensor:
+        needs_grad = torch.is_grad_enabled() and (xyz.requires_grad or new_xyz.requires_grad or (features is not None and features.requires_grad))
+        if xyz.is_cuda and not needs_grad:
+            # inference: the whole module as ONE launch (captra_query_and_group) -- the lists never leave LDS, the cloud is staged
+            # once for the search and for the coordinate channels; same values as the ops below, bit for bit
+            from .. import fused
+            out = fused.query_and_group(self.radius, self.nsample, xyz.contiguous(), new_xyz.contiguous(),
+                                        None if features is None else features.contiguous(), self.use_xyz)
+            if out is not None:
+                return out
         idx = ball_query(self.radius, self.nsample, xyz, new_xyz)
         grouped_xyz = grouping_operation(xyz.transpose(1, 2).contiguous(), idx)
         grouped_xyz = grouped_xyz - new_xyz.transpose(1, 2).unsqueeze(-1)

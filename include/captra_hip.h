@@ -348,6 +348,16 @@ int captra_fps_gather_part(int b, int n, int m, int j0, int j1, const float *xyz
  * one is set.  Thread-local. */
 void captra_set_centre_window(int m0, int mc);
 
+/* QueryAndGroup(radius, nsample, use_xyz)(xyz, new_xyz, features) of the reference (pointnet_lib/pointnet2_utils.py:274-310: ball_query
+ * -> grouping_operation -> centre subtraction -> cat) in ONE launch: out (B, C + 3, M, K) = cat([features[:, :, idx], xyz[idx] -
+ * new_xyz]) -- features first; (B,3,M,K) when features == NULL, (B,C,M,K) when use_xyz == 0 -- with idx the ball query's lists
+ * (captra_ball_query, bit for bit; also written to idx_out (B,M,K) when non-NULL).  xyz (B,N,3), new_xyz (B,M,3), features (B,C,N).
+ * The lists stay in LDS and the cloud is staged once per workgroup for the search AND the coordinate channels: nothing goes through
+ * HBM between the two ops.  -2: nsample % 4 != 0, out / idx_out not 16-byte aligned, N > 8192 (captra_ball_query +
+ * captra_group_points then). */
+int captra_query_and_group(int b, int n, int m, float radius, int nsample, int c, int use_xyz, const float *xyz, const float *new_xyz,
+                           const float *features, float *out, int *idx_out, captra_stream_t stream);
+
 /* LEVEL-1 STREAM (csrc/sa_bf16.hip, bf16 mode): everything PointNetSetAbstractionMsg.forward (pointnet_utils.py:214-249) does at the
  * first level of PointNet2Msg, for the (one or two) networks that share a cloud, in ONE launch -- furthest point sampling
  * (sampling_gpu.cu:93-209; fps_idx (B,M), new_xyz in both layouts), the three ball queries (ball_query_gpu.cu:9-45; idx3[s]
@@ -540,6 +550,7 @@ void captra_sa1_stream_set_fine(int centres); /* level-1 stream kernel: trailing
 void captra_sa1_stream_set_whole(int windows); /* level-1 stream kernel: bits 0-7 = leading windows of 32 centres handed out as one ticket for all three scales (default 0), bit 8 = three scale tickets per window instead of two */
 void captra_sa_bf16_set_variant(int v);     /* bf16 SA scales: bit 0 = small-input scales without gather prefetch / fragment ring, bits 1-2 = ring depth
                                                4 / 2 / 3 / 6, bits 4.. = ablations (coalesced gather, eight fragments only, no stores: WRONG results, timing only) */
+void captra_query_and_group_set_shape(int mcb, int cc); /* captra_query_and_group: centres per workgroup, channels per chunk (0 = heuristic) */
 void captra_group_set_shape(int lds_kb, int ccmax, int ppb); /* group_points: staging budget (KiB, <= 64), channels per workgroup, positions per
                                                workgroup (0 = default); tools/bench_group.py --sweep */
 

@@ -661,3 +661,37 @@ def test_gather_points_grad_takes_the_csr_path_bit_reproducibly(device):
     ref = torch.zeros(B, C, N, dtype=torch.float64)
     ref.scatter_add_(2, idx.cpu().long().unsqueeze(1).expand(-1, C, -1), grad_out.cpu().double())
     np.testing.assert_allclose(outs[0].numpy(), ref.numpy(), atol=4e-6 * float(ref.abs().max()), rtol=0)
+
+
+@pytest.mark.parametrize("B,N,M,r,K,C,use_xyz", [(2, 4096, 512, 0.05, 32, 0, True), (2, 4096, 512, 0.1, 64, 3, True), (1, 4096, 512, 0.2, 128, 3, True),
+                                                  (2, 512, 128, 0.2, 64, 320, True), (2, 512, 128, 0.4, 128, 320, True), (3, 300, 45, 0.2, 16, 5, True),
+                                                  (2, 700, 33, 0.3, 20, 7, False), (1, 6000, 100, 0.1, 32, 2, True)])
+def test_query_and_group_one_launch_equals_the_two_ops_and_the_oracle(device, B, N, M, r, K, C, use_xyz):
+    """captra_query_and_group (the reference's QueryAndGroup module, pointnet2_utils.py:274-310, as ONE launch) against
+    captra_ball_query + captra_group_points + the torch centre subtraction / concat, and against the oracle's ball query: the lists
+    and every grouped value bit for bit, on the workload's SA1 / SA2 shapes and on ragged ones (centres not a multiple of the
+    workgroup's block, K = 16 / 20, clouds beyond one 4096-point tile)."""
+    from captra_amd import fused
+    from captra_amd import synthetic as clouds
+    from captra_amd.pointnet_lib import pointnet2_utils as pn
+    rng = np.random.default_rng(B * 1000 + N + K)
+    if N == 4096:
+        xyz = np.stack([clouds.s_nocs(70 + i)[0] for i in range(B)]).astype(np.float32)
+    else:
+        xyz = (rng.random((B, N, 3), dtype=np.float32) - 0.5).astype(np.float32)
+    new_xyz = np.ascontiguousarray(xyz[:, ::max(N // M, 1)][:, :M])
+    feat = rng.standard_normal((B, C, N)).astype(np.float32) if C else None
+    x, nx = _dev(xyz, device), _dev(new_xyz, device)
+    f = _dev(feat, device) if C else None
+    idx = pn.ball_query(r, K, x, nx)
+    np.testing.assert_array_equal(idx.cpu().numpy(), O.ball_query(r, K, xyz, new_xyz))
+    gx = pn.grouping_operation(x.transpose(1, 2).contiguous(), idx) - nx.transpose(1, 2).unsqueeze(-1)
+    want = gx if f is None else (torch.cat([pn.grouping_operation(f, idx), gx], dim=1) if use_xyz else pn.grouping_operation(f, idx))
+    got, got_idx = fused.query_and_group(r, K, x, nx, f, use_xyz, want_idx=True)
+    torch.cuda.synchronize()
+    assert torch.equal(got_idx, idx)
+    assert torch.equal(got, want)
+    assert torch.equal(fused.query_and_group(r, K, x, nx, f, use_xyz), want)       # (no list output)
+    # the module itself (inference: the one launch; a K the kernel does not take falls back to the ops)
+    assert torch.equal(pn.QueryAndGroup(r, K, use_xyz)(x, nx, f), want)
+    assert fused.query_and_group(r, 18, x, nx, f, use_xyz) is None
