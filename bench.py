@@ -162,8 +162,7 @@ def otf_leg(batch: int, device, frames: int = 10, reps: int = 5):
     data = make_otf_trajectory(batch, frames, seed=1)
     for f in data:
         f["meta"]["pre_fetched"] = {k: v.to(device) for k, v in f["meta"]["pre_fetched"].items()}
-    out = {"workload": f"EvalTrackModel.test, nocs_otf=True, bottle, {batch} trajectories x {frames} frames, each watching its own 480x640 "
-                       f"depth image with a drifting object, ~15 k candidate points per crop resampled to 4096", "unit": "frames/s"}
+    out = {"workload": f"EvalTrackModel.test, nocs_otf=True, bottle, {batch} trajectories x {frames} frames, ~15 k candidates per crop -> 4096", "unit": "frames/s"}
     for key, lanes in (("two_lanes", True), ("single_batch", False)):
         cfg = make_config("1", experiment_dir=tempfile.mkdtemp(prefix="captra_bench_otf_"), nocs_otf=True, **{"init_frame/gt": True})
         cfg["device"] = device
@@ -233,7 +232,7 @@ def b1_leg(device, steps: int = 200, otf_frames: int = 24, reps: int = 5):
     fams = {n: _lib.prof_read(n)[0] / 20 for n in _lib.prof_names() if _lib.prof_read(n)[1]}
     out = {"unit": "ms per frame", "convention": "reference README.md:267 (--batch_size=1), model.py:319",
            "pre_cropped": {"ms_per_frame": round(pre * 1e3, 4), "frames_per_s": round(1.0 / pre, 1), "launch": "hipGraph replay of the step, pose chained",
-                           "kernel_ms_per_frame_networks_in_sequence": {k: round(v, 4) for k, v in sorted(fams.items(), key=lambda kv: -kv[1])}}}
+                           "kernel_ms_per_frame_networks_in_sequence": {k: round(v, 3) for k, v in sorted(fams.items(), key=lambda kv: -kv[1])[:8]}}}
     del graph, model
     cfg = make_config("1", experiment_dir=tempfile.mkdtemp(prefix="captra_bench_b1_"), nocs_otf=True, **{"init_frame/gt": True})
     cfg["device"] = device
@@ -266,7 +265,7 @@ def b1_leg(device, steps: int = 200, otf_frames: int = 24, reps: int = 5):
     out["nocs_otf"] = {"ms_per_frame": round(med * 1e3, 4), "frames_per_s": round(1.0 / med, 1),
                        "launch": "EvalTrackModel.test, nocs_otf=True: re-crop + captured step per frame, Python included",
                        "kernel_ms_per_frame": {"crop_ball": round(crop["crop_ball"], 4),
-                                               "fps (re-crop sampler + the step's two levels, eager passes only)": round(crop["fps"], 4)}}
+                                               "fps": round(crop["fps"], 4)}}
     out["note"] = f"median of {reps} runs each"
     return out
 
@@ -470,11 +469,18 @@ def config_leg(name: str, extra: list, timeout_s: int = 120):
     d = json.loads(lines[-1])
     keep = ("metric", "value", "unit", "ms_per_step", "dtype", "steps", "roofline", "kernel_ms_per_step", "timed_blocks", "config", "one_graph", "l1_stream")
     out = {k: d[k] for k in keep if k in d}
+    # compact (the main line has to fit the driver's 8 KB tail): what the leg ran is its command; the numbers stay
     if isinstance(out.get("config"), dict):
-        out["config"] = {k: out["config"].get(k) for k in ("workload", "launch") if out["config"].get(k)}
+        out["config"] = {"workload": (out["config"].get("workload") or "")[:60]}
     if isinstance(out.get("timed_blocks"), dict):
-        out["timed_blocks"] = {k: out["timed_blocks"][k] for k in ("n", "ms_per_step_median", "ms_per_step_min", "ms_per_step_max") if k in out["timed_blocks"]}
-    out["command"] = "python " + " ".join(os.path.relpath(c, here) if c.startswith(here) else c for c in cmd[1:])
+        out["timed_blocks"] = {k: out["timed_blocks"][k] for k in ("n", "ms_per_step_min", "ms_per_step_max") if k in out["timed_blocks"]}
+    if isinstance(out.get("roofline"), dict):
+        out["roofline"] = {k: out["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us", "flops_per_launch", "share_of_kernel_time") if k in out["roofline"]}
+    if isinstance(out.get("kernel_ms_per_step"), dict):
+        top = sorted(((k, v) for k, v in out["kernel_ms_per_step"].items() if not k.startswith("_")), key=lambda kv: -kv[1])[:5]
+        out["kernel_ms_per_step"] = dict(top, _sum=out["kernel_ms_per_step"].get("_sum_captra_kernels"))
+    out.pop("metric", None)
+    out["command"] = " ".join(os.path.relpath(c, here) if c.startswith(here) else c for c in cmd[1:])
     out["leg_wall_s"] = round(time.perf_counter() - t0, 1)
     return out
 
@@ -813,12 +819,10 @@ def main():
                                   else " (BASELINE.json configs[1])" if args.category == "bottle" and args.mlp_dtype == "fp32" else " (BASELINE.json configs[3]: drawers)" if args.category == "drawers" else ""),
                    "points": 4096, "trajectories_per_gpu": B, "distinct_clouds_per_gpu": B,
                    "parallelism": f"dp{world} (trajectory-sharded, RCCL all-gather of poses)",
-                   "weights": f"seeded default_rng(7) on the real architecture ({sum(v.numel() for v in sd.values()) / 1e6:.2f} M params incl. BN statistics), "
-                              "physical-regime plants (captra_amd/synthetic.make_physical_state_dict)",
+                   "weights": f"seeded default_rng(7), real architecture ({sum(v.numel() for v in sd.values()) / 1e6:.2f} M params), physical-regime plants",
                    "launch": (f"{args.lanes} free-running lanes of {B // args.lanes} trajectories, each a hipGraph replay of the step on its own stream" if lanes is not None
                               else "hipGraph replay of the step" if graph is not None else "eager launches")
-                             + (", CoordinateNet and RotationNet side by side on two streams" + (" (two branches of the graph)" if graph is not None else "")
-                                if not args.no_overlap else "")},
+                             + (", the two networks side by side" if not args.no_overlap else "")},
         "timed_blocks": {"n": len(blocks), "steps_each": args.steps, "ms_per_step_median": round(1e3 * elapsed / args.steps, 3),
                          "ms_per_step_min": round(1e3 * order[0] / args.steps, 3), "ms_per_step_max": round(1e3 * order[-1] / args.steps, 3),
                          "value_from": "median block of exactly `steps` steps (barrier + synchronize on both sides, max over ranks)",
@@ -834,7 +838,8 @@ def main():
                                "(captra_amd.parallel.bind_rank_cpus)") if bound_cpus else "unbound (single rank)",
         "collective_backend": ("none (single rank)" if dist is None else "nccl (RCCL)" if backend == "nccl" else
                                "gloo -- CAPTRA_BENCH_SHARE_GPU functional test mode: ranks share GPUs, NOT a scaling measurement"),
-        "per_rank_ms_per_step": [[round(x, 3) for x in row] for row in per_rank_ms],
+        # (every block of every rank only when there is more than one rank: at world 1 it is `timed_blocks`)
+        "per_rank_ms_per_step": [[round(x, 3) for x in row] for row in per_rank_ms] if world > 1 else [[round(sorted(per_rank_ms[0])[len(per_rank_ms[0]) // 2], 3)]],
     }
     if timing:
         fams = {}

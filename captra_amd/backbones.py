@@ -128,7 +128,7 @@ class PointNet2Msg(_FoldCache, nn.Module):
             return geom
         return self.precompute_geometry_rest(geom, xyz_n3)
 
-    def precompute_geometry_streamed(self, xyz_n3, chunks: int, gstream, consumers=()):
+    def precompute_geometry_streamed(self, xyz_n3, chunks: int, gstream, consumers=(), backbones=()):
         """`precompute_geometry` with the first level's sampling STREAMED: the 4096 -> 512 sampler is `chunks` launches of
         npoint / chunks picks each on `gstream` (captra_fps_gather_part: the same loop, cut), every part followed by the ball
         query of its centres and an event; `geom["sa1"]["chunks"]` = [(first centre, count, event)] is what `sa1` walks --
@@ -143,6 +143,10 @@ class PointNet2Msg(_FoldCache, nn.Module):
         self.sa1._fold(xyz_n3.device)
         if M % chunks or (M // chunks) % 8 or not self.sa1.window_ok(self.in_dim):
             return None
+        for bb in backbones:         # every backbone that will walk the windows (RotationNet's shares this geometry)
+            bb.sa1._fold(xyz_n3.device)
+            if not bb.sa1.window_ok(bb.in_dim) or bb.sa1.npoint != M:
+                return None
         xyz_n3 = xyz_n3.contiguous()
         bufs = fused.fps_gather_parts(xyz_n3, M)
         if bufs is None:
@@ -166,6 +170,12 @@ class PointNet2Msg(_FoldCache, nn.Module):
             ready = torch.cuda.Event()
             ready.record(gstream)
             geom["_ready"] = ready
+        # the sampler's own buffers (picks, running minima: read and written by every later part) were allocated on the calling
+        # stream and are used on `gstream` only: they stay alive with the geometry and are recorded on `gstream`, or the caching
+        # allocator could hand them to the next allocation of the calling stream while the remaining parts are still queued
+        geom["_keep"] = tuple(bufs) + tuple(idx1)
+        for t in geom["_keep"]:
+            t.record_stream(gstream)
         for t in _geom_tensors(geom):
             for st in (main,) + tuple(consumers):
                 t.record_stream(st)

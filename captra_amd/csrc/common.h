@@ -32,6 +32,12 @@ struct CaptraProfScope {
 #endif
 #define CAPTRA_PROF_ON(ptr) (CAPTRA_SA_PROF != 0 && (ptr) != nullptr)
 
+// Ablation instantiations and timing modes whose RESULTS ARE WRONG BY CONSTRUCTION (measurement only: tools/bench_l1_stream.py,
+// tools/bf16_variants.sh) exist only in a build with -DCAPTRA_ABLATIONS=1 (CAPTRA_HIPCC_EXTRA); the shipped library ignores their knobs.
+#ifndef CAPTRA_ABLATIONS
+#define CAPTRA_ABLATIONS 0
+#endif
+
 // prof.cpp: CUs the calling thread's persistent launches leave free (captra_set_reserved_cus)
 int captra_reserved_cus();
 // prof.cpp: the calling thread's centre window (captra_set_centre_window); true when one is set

@@ -702,7 +702,7 @@ int sb2_launch(int b, SbParams p, hipStream_t stream) {
     return captra_last_error();
 }
 
-CAPTRA_KNOB int g_sb_variant = 0;      // A/B: bit 0 = small-input scales as before (no gather prefetch, no fragment ring); bits 1-2: ring depth 4 / 2 / 3 / 6; bit 3 = SA2 scales as before (sa_bf16_kernel); bits 4..: ablations
+CAPTRA_KNOB int g_sb_variant = 0;      // A/B: bit 0 = small-input scales as before (no gather prefetch, no fragment ring); bit 3 = SA2 scales as before (sa_bf16_kernel); bits 4..: ablations (CAPTRA_ABLATIONS builds)
 
 template <int CF, int C1, int C2, int C3, int K, bool PRE, int TN, int CG, bool WLDS, int OCC = (WLDS ? 2 : 1), int RGS = 0, bool PF = false, int DBG = 0, int LRD = 1>
 int sb_launch(int b, SbParams p, hipStream_t stream) {
@@ -774,13 +774,9 @@ extern "C" int captra_sa_scale_bf16(int b, int n, int m, int k, int cfeat, int c
 #define SB_CASE1(CF_, C1_, C2_, C3_, K_, PF_)                                                                \
     if (SB_MATCH(CF_, C1_, C2_, C3_, K_, false)) {                                                          \
         if (g_sb_variant & 1) return sb_launch<CF_, C1_, C2_, C3_, K_, false, 2, 8, true, 2, 0, false, 0, 1>(b, p, s);   \
-        switch ((g_sb_variant >> 1) & 3) {                                                                  \
-        case 1: return sb_launch<CF_, C1_, C2_, C3_, K_, false, 2, 8, true, 2, 0, PF_, 0, 2>(b, p, s);      \
-        case 2: return sb_launch<CF_, C1_, C2_, C3_, K_, false, 2, 8, true, 2, 0, PF_, 0, 3>(b, p, s);      \
-        case 3: return sb_launch<CF_, C1_, C2_, C3_, K_, false, 2, 8, true, 2, 0, PF_, 0, 6>(b, p, s);      \
-        default: return sb_launch<CF_, C1_, C2_, C3_, K_, false, 2, 8, true, 2, 0, PF_, 0, 4>(b, p, s);     \
-        }                                                                                                   \
+        return sb_launch<CF_, C1_, C2_, C3_, K_, false, 2, 8, true, 2, 0, PF_, 0, 4>(b, p, s);              \
     }
+#if CAPTRA_ABLATIONS
     if (SB_MATCH(0, 64, 96, 128, 128, false)) {
         switch (g_sb_variant >> 4) {
         case 1: return sb_launch<0, 64, 96, 128, 128, false, 2, 8, true, 2, 0, false, 1>(b, p, s);
@@ -791,6 +787,7 @@ extern "C" int captra_sa_scale_bf16(int b, int n, int m, int k, int cfeat, int c
         default: break;
         }
     }
+#endif
     SB_CASE1(0, 32, 32, 64, 32, false) SB_CASE1(0, 64, 64, 128, 64, true) SB_CASE1(0, 64, 96, 128, 128, true)
     SB_CASE1(3, 32, 32, 64, 32, false) SB_CASE1(3, 64, 64, 128, 64, true) SB_CASE1(3, 64, 96, 128, 128, true)
     // (two tiles per wave on two waves per SIMD was measured for the SA2 scales: 63 -> 59 us for K = 64, and the 196-wide scale
@@ -800,6 +797,7 @@ extern "C" int captra_sa_scale_bf16(int b, int n, int m, int k, int cfeat, int c
         return sb_launch<320, 128, 128, 256, 64, true, 4, 2, false>(b, p, s);
     }
     if (SB_MATCH(320, 128, 196, 256, 128, true)) {
+#if CAPTRA_ABLATIONS
         switch (g_sb_variant >> 4) {      // ablations (results wrong by construction): 1 coalesced gather, 2 eight fragments only, 4 no stores
         case 1: return sb_launch<320, 128, 196, 256, 128, true, 4, 1, false, 1, 0, false, 1>(b, p, s);
         case 2: return sb_launch<320, 128, 196, 256, 128, true, 4, 1, false, 1, 0, false, 2>(b, p, s);
@@ -808,6 +806,7 @@ extern "C" int captra_sa_scale_bf16(int b, int n, int m, int k, int cfeat, int c
         case 7: return sb_launch<320, 128, 196, 256, 128, true, 4, 1, false, 1, 0, false, 7>(b, p, s);
         default: break;
         }
+#endif
         if (!(g_sb_variant & 8)) return sb2_launch<196, 128, 1>(b, p, s);
         return sb_launch<320, 128, 196, 256, 128, true, 4, 1, false>(b, p, s);
     }
@@ -816,7 +815,11 @@ extern "C" int captra_sa_scale_bf16(int b, int n, int m, int k, int cfeat, int c
     return -2;
 }
 
-extern "C" void captra_sa_bf16_set_variant(int v) { g_sb_variant = v; }
+// Only the two forms the tests compare (bit 0: the small-input scales without gather prefetch / fragment ring, bit 3: the SA2 scales on
+// sa_bf16_kernel) exist in the shipped library; the ablation instantiations (bits 4..: results wrong by construction) and the timing
+// modes of the level-1 stream kernel are compiled only with -DCAPTRA_ABLATIONS=1 (CAPTRA_HIPCC_EXTRA): a stray CAPTRA_SA_BF16_VARIANT
+// cannot select them.
+extern "C" void captra_sa_bf16_set_variant(int v) { g_sb_variant = CAPTRA_ABLATIONS ? v : (v & 9); }
 
 // ======================================================================================================================
 // LEVEL-1 STREAM KERNEL: the 4096 -> 512 sampler, the ball query and the SA1 scales of the networks that share the cloud in ONE
@@ -1203,7 +1206,7 @@ CAPTRA_KNOB int g_l1_dbg = 0;
 }  // namespace
 
 extern "C" void captra_sa1_stream_set_grid(int grid, int prio) { g_l1_grid = grid; g_l1_prio = prio; }
-extern "C" void captra_sa1_stream_set_fine(int centres) { g_l1_fine = centres & 0xFFFF; g_l1_dbg = centres >> 16; }   // (bits 16..: timing ablations, results wrong)
+extern "C" void captra_sa1_stream_set_fine(int centres) { g_l1_fine = centres & 0xFFFF; g_l1_dbg = CAPTRA_ABLATIONS ? centres >> 16 : 0; }   // (bits 16..: timing ablations, results wrong: CAPTRA_ABLATIONS builds only)
 extern "C" void captra_sa1_stream_set_whole(int windows) { g_l1_whole = windows & 0xFF; g_l1_pair = (windows >> 8) & 1 ? 0 : 1; }   // (bit 8: three scale tickets per window)
 
 // planes (B,3,pad256(N)) <- xyz_n3 (B,N,3): element ((chunk / 4) * 64 + lane) * 4 + chunk % 4 of plane a = coordinate a of point

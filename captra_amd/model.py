@@ -255,7 +255,7 @@ class EvalTrackModel(BaseModel):
     def _step_post(self, input, npcs_input, npcs_pred, last_pose):
         pred_npcs = npcs_pred["nocs"].reshape(len(npcs_pred["nocs"]), self.num_parts, 3, -1)
         input["state"] = {"part": last_pose}
-        lab32 = getattr(self.npcs_net, "last_labels_i32", None)   # CoordinateNet's fused read-out: int32 labels beside the softmax
+        lab32 = npcs_pred.pop("_labels_i32", None)   # CoordinateNet's fused read-out: the int32 labels of THIS prediction
         if lab32 is not None and not (self.track_cfg["gt_label"] or self.track_cfg["nocs2d_label"]):
             input["pred_labels_i32"] = lab32             # what the one-launch rotation read-out and pose fit take
             input["pred_labels"] = lab32 if self._overlap_nets(input) else lab32.long()
@@ -296,7 +296,8 @@ class EvalTrackModel(BaseModel):
             if getattr(self, "_gstream", None) is None:
                 self._gstream = torch.cuda.Stream(device=dev)
             cam = _canonicalize(npcs_input["points"], npcs_input["points_mean"], npcs_input["canon_pose"])
-            geom = self.npcs_net.backbone.precompute_geometry_streamed(cam[1], self.sampler_chunks, self._gstream, consumers=(side,))
+            geom = self.npcs_net.backbone.precompute_geometry_streamed(cam[1], self.sampler_chunks, self._gstream, consumers=(side,),
+                                                                       backbones=(self.net.regress_net.encoder,))
             if geom is not None:
                 npcs_input["_canon"], npcs_input["_geom"] = cam, geom
                 gstream = self._gstream

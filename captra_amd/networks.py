@@ -113,15 +113,16 @@ class CoordNet(nn.Module):
         else:
             seg_logits, nocs = self._heads(out)
             nocs_m05 = nocs - 0.5
-        # The fused read-out's int32 labels travel beside the dict (`last_labels_i32`; EvalTrackModel takes them), not in it: the
-        # dict stays the reference's (networks.py:44-52) for every other consumer.  The label is the first index of the largest
+        # The fused read-out's int32 labels travel WITH the prediction under the private key "_labels_i32" (EvalTrackModel pops it
+        # before the dict leaves the step: tied to this forward's seg / nocs whatever ran in between; `last_labels_i32` mirrors it
+        # for callers of the module alone); the dict's public keys stay the reference's (networks.py:44-52).  The label is the first index of the largest
         # LOGIT; the reference's argmax of the softmax output differs only when distinct logits round to equal probabilities
         # (lower index there) or a logit is NaN (torch.argmax returns the NaN's index).
         self.last_labels_i32 = None
         if ((not self.training) and seg_logits.is_cuda and seg_logits.dim() == 3 and seg_logits.shape[1] <= 8
                 and seg_logits.dtype == torch.float32 and not (torch.is_grad_enabled() and seg_logits.requires_grad)):
             seg, self.last_labels_i32 = fused.seg_softmax_argmax(seg_logits.contiguous())      # softmax + arg max + int32 labels: one launch
-            pred = {"seg": seg, "nocs": nocs_m05, "points": cam_cn}
+            pred = {"seg": seg, "nocs": nocs_m05, "points": cam_cn, "_labels_i32": self.last_labels_i32}
         else:
             pred = {"seg": F.softmax(seg_logits, dim=1), "nocs": nocs_m05, "points": cam_cn}
         if "gt_part" in input:

@@ -98,6 +98,14 @@ class Ranks:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return int(t.item())
 
+    def broadcast_object(self, obj):
+        """rank 0's `obj` on every rank."""
+        if self.dist is None:
+            return obj
+        box = [obj]
+        self.dist.broadcast_object_list(box, src=0)
+        return box[0]
+
     def gather_objects(self, obj):
         """-> list over ranks on rank 0 (None elsewhere)."""
         if self.dist is None:
@@ -326,24 +334,33 @@ def _write_gathered_results(cfg, ranks: Ranks, records, gathered, capacity: int)
     from .model import write_result_pickles
     from .parallel import unpack_pose
     per_rank = ranks.gather_objects(records)
+    out, error = [], None
+    if ranks.rank == 0:
+        try:
+            for r, recs in enumerate(per_rank):
+                for j, (name, rec) in enumerate(recs):
+                    for i, pose in enumerate(rec["pred"]["poses"]):
+                        got, valid = unpack_pose(gathered[i][r * capacity + j:r * capacity + j + 1].cpu())
+                        assert bool(valid.all()), f"rank {r} trajectory {j} frame {i}: record not marked valid"
+                        for key in pose:
+                            wire = got[key][0].reshape(pose[key].shape)
+                            mine = torch.as_tensor(pose[key])
+                            # bit patterns, not values: a NaN pose (diverged / empty part under --random_init) equals itself on the wire
+                            if not torch.equal(wire.float().contiguous().view(torch.int32), mine.float().contiguous().view(torch.int32)):
+                                raise RuntimeError(f"pose exchange of {name} frame {i} {key}: the all-gathered record differs from what rank {r} "
+                                                   f"computed (max |diff| {float((wire.float() - mine.float()).abs().nan_to_num(0.0).max()):.3g}); "
+                                                   "refusing to write a corrupted wire copy into the result pickles")
+                            pose[key] = wire.clone() if torch.is_tensor(pose[key]) else wire.numpy().copy()
+                    out.append((name, rec))
+        except (RuntimeError, AssertionError) as e:
+            error = str(e)
+    # every rank learns the verdict and fails together: rank 0 alone raising would leave the others in their next collective until
+    # the communicator's timeout
+    error = ranks.broadcast_object(error)
+    if error is not None:
+        raise RuntimeError(error)
     if ranks.rank != 0:
         return
-    out = []
-    for r, recs in enumerate(per_rank):
-        for j, (name, rec) in enumerate(recs):
-            for i, pose in enumerate(rec["pred"]["poses"]):
-                got, valid = unpack_pose(gathered[i][r * capacity + j:r * capacity + j + 1].cpu())
-                assert bool(valid.all()), f"rank {r} trajectory {j} frame {i}: record not marked valid"
-                for key in pose:
-                    wire = got[key][0].reshape(pose[key].shape)
-                    mine = torch.as_tensor(pose[key])
-                    # bit patterns, not values: a NaN pose (diverged / empty part under --random_init) equals itself on the wire
-                    if not torch.equal(wire.float().contiguous().view(torch.int32), mine.float().contiguous().view(torch.int32)):
-                        raise RuntimeError(f"pose exchange of {name} frame {i} {key}: the all-gathered record differs from what rank {r} "
-                                           f"computed (max |diff| {float((wire.float() - mine.float()).abs().nan_to_num(0.0).max()):.3g}); "
-                                           "refusing to write a corrupted wire copy into the result pickles")
-                    pose[key] = wire.clone() if torch.is_tensor(pose[key]) else wire.numpy().copy()
-            out.append((name, rec))
     write_result_pickles(cfg["experiment_dir"], out)
 
 

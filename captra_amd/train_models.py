@@ -116,6 +116,7 @@ class CanonCoordModel(BaseModel):
         self.loss_dict = {}
         with torch.no_grad():
             self.pred_dict = self.net(self.feed_dict, test=True)
+            self.pred_dict.pop("_labels_i32", None)      # (the track loop's private hand-over: not part of the reference's dict)
             if not no_eval:
                 self.compute_loss(test=True)
 

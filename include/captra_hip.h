@@ -548,8 +548,8 @@ void captra_pw_set_pair(int on);            /* dense layers: 1 = paired column t
 void captra_sa1_stream_set_grid(int grid, int prio); /* level-1 stream kernel: workgroups (0 = two per CU), 1 = samplers at s_setprio 3 (default) */
 void captra_sa1_stream_set_fine(int centres); /* level-1 stream kernel: trailing centres handed out as fine tickets of 8 (multiple of 32, default 32) */
 void captra_sa1_stream_set_whole(int windows); /* level-1 stream kernel: bits 0-7 = leading windows of 32 centres handed out as one ticket for all three scales (default 0), bit 8 = three scale tickets per window instead of two */
-void captra_sa_bf16_set_variant(int v);     /* bf16 SA scales: bit 0 = small-input scales without gather prefetch / fragment ring, bits 1-2 = ring depth
-                                               4 / 2 / 3 / 6, bits 4.. = ablations (coalesced gather, eight fragments only, no stores: WRONG results, timing only) */
+void captra_sa_bf16_set_variant(int v);     /* bf16 SA scales: bit 0 = small-input scales without gather prefetch / fragment ring, bit 3 = SA2 scales on
+                                               sa_bf16_kernel; bits 4.. (ablations with WRONG results, timing only) exist in -DCAPTRA_ABLATIONS=1 builds only */
 void captra_query_and_group_set_shape(int mcb, int cc); /* captra_query_and_group: centres per workgroup, channels per chunk (0 = heuristic) */
 void captra_group_set_shape(int lds_kb, int ccmax, int ppb); /* group_points: staging budget (KiB, <= 64), channels per workgroup, positions per
                                                workgroup (0 = default); tools/bench_group.py --sweep */

@@ -91,7 +91,12 @@ def test_bench_line_contract_single_gpu(device):
     b1 = out["b1"]                     # single-trajectory latency (the reference's own measuring convention, README.md:267)
     assert 0.3 < b1["pre_cropped"]["ms_per_frame"] < 5.0 and b1["pre_cropped"]["ms_per_frame"] < b1["nocs_otf"]["ms_per_frame"] < 20.0
     h = out["hbm_ops"]
-    assert h["per_level"]["frac"] > h["frac"] and h["fill_probe_GB/s"] > 1000 and "equivalent_frac" not in h["product_path"]
+    assert h["per_level"]["frac"] > h["frac"] and h["fill_probe_GB/s"] > 1000 and "equivalent_frac" not in h
+    # the reference's QueryAndGroup module, one launch per call, and the summary where the driver's parser keeps it
+    q = h["query_and_group"]
+    assert q["launches"] == 10 and q["frac"] > 0.3 and abs(q["frac"] - r["hbm_ops"]["query_and_group_frac"]) < 1e-9
+    assert r["hbm_ops"]["frac"] == h["frac"] and r["hbm_ops"]["per_level_frac"] == h["per_level"]["frac"]
+    assert len(line[0]) < 8000, f"the bench line must fit the driver's 8 KB tail: {len(line[0])} bytes"
 
 
 def test_rccl_communicator_world1_graph_lanes_and_exchange(device):
