@@ -66,6 +66,7 @@ _SIGNATURES = {
     "captra_pack_sa_bf16": [_INT] * 5 + [_P] * 7 + [_P],
     "captra_sa_scale_bf16": [_INT] * 9 + [_P] * 6 + [_INT, _INT, _P],
     "captra_query_and_group": [_INT, _INT, _INT, _F, _INT, _INT, _INT, _P, _P, _P, _P, _P, _P],
+    "captra_neck_chain_bf16": [_INT, _INT, _LL, _INT, _P, _P, _P, _INT, _P, _P, _P, _P, _INT, _P, _P, _INT, _INT, _P, _P],
     "captra_bq_planes": [_INT, _INT, _P, _P, _P],
     "captra_sa1_stream_bf16": [_INT, _INT, _INT, _P, _P, _P, _P, _P, _P, _P, _P, _INT, _P, _P, _P, _INT, _P, _P, _P, _INT, _P, _P, _P, _P, _P],
     "captra_coord_tail": [_INT, _INT, _INT, _INT, _LL, _P, _P, _P, _INT, _P, _P, _P],
@@ -154,6 +155,9 @@ def lib():
             l.captra_sa1_stream_set_fine.restype = None
             l.captra_sa1_stream_set_whole.argtypes = [_INT]
             l.captra_sa1_stream_set_whole.restype = None
+        if hasattr(l, "captra_neck_chain_set_split"):
+            l.captra_neck_chain_set_split.argtypes = [_INT]
+            l.captra_neck_chain_set_split.restype = None
         if hasattr(l, "captra_query_and_group_set_shape"):
             l.captra_query_and_group_set_shape.argtypes = [_INT, _INT]
             l.captra_query_and_group_set_shape.restype = None

@@ -377,6 +377,57 @@ def mlp_chain_bf16_tile(x, layers, acts, x2=None, out_pm: bool = False, pool: bo
     return y
 
 
+USE_NECK_CHAIN = os.environ.get("CAPTRA_NECK_CHAIN", "1") != "0"   # a neck module's layers in ONE launch (csrc/neck_bf16.hip); 0 = layer by layer (A/B, tests)
+
+
+def neck_chain_supported(c0: int, l: int, layers, csplit: int, kind: int) -> bool:
+    """The launcher's own conditions (captra_neck_chain_bf16): bf16 mode, two or three layers, hidden widths 128-multiples up to
+    256 then 512, every width a multiple of 32, whole position quads."""
+    n = len(layers)
+    if not (USE_NECK_CHAIN and USE_TILE_BF16 and mlp_dtype() == "bf16" and n in (2, 3) and l % 4 == 0 and l >= 4 and layers[0].cin == c0):
+        return False
+    w = [lin.cout for lin in layers]
+    if any(c % 32 for c in w) or w[0] > 256 or w[0] % 128 or (n == 3 and (w[1] > 512 or w[1] % 128)) or not 0 <= csplit <= c0:
+        return False
+    mt = [(c // 32 + 7) // 8 for c in w]
+    return (mt == [1, 2, 4] and kind == 0) or (mt == [1, 1] and kind in (1, 2))
+
+
+def neck_chain(kind: int, x, layers, x2=None, nn=None, v=None, v_rows=None, act_last: int = ACT_RELU):
+    """A module of the backbone's neck in one launch (captra_neck_chain_bf16).  kind 0 (SA3): x (B,c,L), x2 (B,c',L) -> (B,c_n,1) = relu(max
+    over the positions); kind 1 (FP3): x (B,c0,L), v (B,cv[,1]) the cloud's pooled vector, v_rows the PackedLinear of the first layer's
+    rows that multiply v -> (B,c_n,L); kind 2 (FP2): x (B,c,L) the skip features, x2 (B,c',S) known features, nn = (idx, weight) (B,L,3)
+    -> (B,c_n,L).  Bit-identical to the layer-by-layer route."""
+    L.require_device(x, x2, v)
+    B, csplit, l = x.shape[0], x.shape[1], x.shape[2]
+    n = len(layers)
+    chans = (C.c_int * (n + 1))(layers[0].cin, *[lin.cout for lin in layers])
+    P = C.c_void_p
+    imgs = [lin.bf16_frag(True) for lin in layers]
+    wp = (P * n)(*[t.data_ptr() for t in imgs])
+    bp = (P * n)(*[lin.bias.data_ptr() for lin in layers])
+    cout = layers[-1].cout
+    y = torch.empty((B, cout, 1) if kind == 0 else (B, cout, l), dtype=torch.float32, device=x.device)
+    idx = wgt = None
+    s_known = 0
+    if kind == 2:
+        idx, wgt = nn
+        L.require_device(idx, wgt)
+        s_known = x2.shape[2]
+    gw = None
+    if v_rows is not None:
+        # the rows that multiply the cloud's vector, rounded once (RNE: what the gemv kernels do to the fp32 rows on the fly)
+        if "gemv16" not in v_rows._bf16:
+            v_rows._bf16["gemv16"] = v_rows.wt2d[:v_rows.cin].to(torch.bfloat16).contiguous()
+        gw = v_rows._bf16["gemv16"]
+    with torch.cuda.device(x.device):
+        L.call("captra_neck_chain_bf16", kind, B, l, n, chans, L.ptr(x), L.ptr(x2), csplit, wp, bp, L.ptr(idx), L.ptr(wgt), s_known,
+               L.ptr(v), L.ptr(gw), 0 if v is None else v.shape[1], act_last, L.ptr(y))
+    flops = 2.0 * B * l * sum(lin.cin * lin.cout for lin in layers)
+    _work("neck_chain", flops=flops, nbytes=4.0 * B * l * (layers[0].cin + cout))
+    return y
+
+
 def head12_bf16_supported(x, lin1: PackedLinear, lin2: PackedLinear) -> bool:
     return (USE_TILE_BF16 and x.dtype == torch.bfloat16 and x.dim() == 3 and lin1.cin <= 128 and lin1.cout == 512 and lin2.cin == 512
             and lin2.cout == 512 and x.shape[1] * 512 * 2 < (1 << 31))

@@ -315,6 +315,10 @@ class PointNetFeaturePropagation(_FoldCache, nn.Module):
             layers = list(self._fold(xyz1.device))
             c1 = points1.shape[1]
             lin0 = layers[0]
+            if fused.neck_chain_supported(c1, N, [lin0.leading_rows(c1)] + layers[1:], c1, 1):
+                # the whole module in one launch (csrc/neck_bf16.hip): the per-cloud product first, then both layers on LDS-resident tiles
+                return fused.neck_chain(1, points1.contiguous(), [lin0.leading_rows(c1)] + layers[1:], v=points2.contiguous(),
+                                        v_rows=lin0.trailing_rows(c1)).view(B, layers[-1].cout, N)
             if fused.chain_tile_bf16_supported(c1, N, layers):
                 # LDS-tiled kernels (csrc/tile_bf16.hip): the per-cloud product as one small launch, then the layers
                 bias_bc = fused.gemv_bf16(points2.contiguous(), lin0.trailing_rows(c1))
@@ -347,6 +351,11 @@ class PointNetFeaturePropagation(_FoldCache, nn.Module):
                 if nn is None:
                     nn = fused.three_nn_weights(xyz1_n3, xyz2_n3)
                 self.last_nn = nn
+                if (points1 is not None and tail is None and finish is None and fused.mlp_dtype() == "bf16"
+                        and fused.neck_chain_supported(points1.shape[1] + points2.shape[1], N, self._fold(xyz1.device), points1.shape[1], 2)):
+                    # interpolation, skip concat and both layers in one launch (csrc/neck_bf16.hip): the interpolated channels are
+                    # formed while the first layer's operand is staged
+                    return fused.neck_chain(2, points1.contiguous(), self._fold(xyz1.device), x2=points2.contiguous(), nn=nn)
                 new_points = fused.interp_concat(None if points1 is None else points1.contiguous(),
                                                  points2.contiguous(), nn[0], nn[1])
             else:
@@ -414,6 +423,8 @@ class PointNetSetAbstraction(_FoldCache, nn.Module):
             # of 128 and the group maxima are maxed again (max is exact, so the split does not change a bit)
             folded = self._fold(xyz.device)
             groups, k = (1, N) if N <= 128 else (N // 128, 128)
+            if fused.mlp_dtype() == "bf16" and _has_points(points) and fused.neck_chain_supported(C + points.shape[1], N, folded, C, 0):
+                return new_xyz, fused.neck_chain(0, xyz.contiguous(), folded, x2=points.contiguous())
             if fused.mlp_dtype() == "bf16" and _has_points(points) and fused.chain_tile_bf16_supported(C + points.shape[1], N, folded, pool=True):
                 # LDS-tiled kernels: [xyz, feat] read as two sources (no concat), the max over the points in the last layer's epilogue
                 return new_xyz, fused.mlp_chain_bf16_tile(xyz.contiguous(), folded, [fused.ACT_RELU] * len(folded), x2=points.contiguous(), pool=True)

@@ -348,6 +348,23 @@ int captra_fps_gather_part(int b, int n, int m, int j0, int j1, const float *xyz
  * one is set.  Thread-local. */
 void captra_set_centre_window(int m0, int mc);
 
+/* A module of the backbone's NECK in the bf16 mode as ONE launch (csrc/neck_bf16.hip): nl = 2 or 3 layers act(b + W x), ReLU between them,
+ * on tiles of 64 positions with every hidden activation in LDS as the next layer's operand image and the weights streamed from the
+ * layers' captra_pack_dense_bf16(perm = 1) images wimg[i] (+ packed fp32 biases bias[i]); channel counts c[0] (input) .. c[nl], hidden
+ * widths multiples of 128 up to 256 then 512.  Layer 1's input (B,c[0],L) is never built: channels [0, csplit) come from x (B,csplit,L) and
+ *   kind 0 -- SA3, PointNetSetAbstraction with group_all (pointnet_utils.py:302-343): the rest from x2 (B,c[0]-csplit,L); y (B,c[nl]) fp32 =
+ *            act_last(max over the L positions) (zeroed by the call on `stream`; act_last must be CAPTRA_ACT_RELU);
+ *   kind 1 -- FP3, PointNetFeaturePropagation with one source vector per cloud (pointnet_utils.py:265-298): csplit = c[0]; layer 1's bias
+ *            of cloud b is bias[0] + W_v bf16(v[b]), v (B,cv) fp32, gw (cv, ceil128(c[1])) bf16 = the RNE rounding of the packed fp32 W'^T rows
+ *            that multiply v (captra_gemv_bf16 rounds the same rows on the fly: same arithmetic); y (B,c[nl],L) fp32;
+ *   kind 2 -- FP2, PointNetFeaturePropagation (pointnet_utils.py:280-298): the rest interpolated from x2 (B,c[0]-csplit,S) through nn_idx /
+ *            nn_w (B,L,3) of captra_three_nn_weights, (w0 f[j0] + w1 f[j1]) + w2 f[j2] as captra_interp_concat; y (B,c[nl],L) fp32.
+ * Bit-identical to the chain of captra_dense_bf16_tile_ex launches (+ captra_gemv_bf16 / captra_interp_concat) it replaces.  -2: shapes
+ * outside the kernel. */
+int captra_neck_chain_bf16(int kind, int b, long long l, int nl, const int *c, const float *x, const float *x2, int csplit,
+                           const unsigned char *const *wimg, const float *const *bias, const int *nn_idx, const float *nn_w, int s_known,
+                           const float *v, const unsigned short *gw, int cv, int act_last, float *y, captra_stream_t stream);
+
 /* QueryAndGroup(radius, nsample, use_xyz)(xyz, new_xyz, features) of the reference (pointnet_lib/pointnet2_utils.py:274-310: ball_query
  * -> grouping_operation -> centre subtraction -> cat) in ONE launch: out (B, C + 3, M, K) = cat([features[:, :, idx], xyz[idx] -
  * new_xyz]) -- features first; (B,3,M,K) when features == NULL, (B,C,M,K) when use_xyz == 0 -- with idx the ball query's lists
@@ -550,6 +567,7 @@ void captra_sa1_stream_set_fine(int centres); /* level-1 stream kernel: trailing
 void captra_sa1_stream_set_whole(int windows); /* level-1 stream kernel: bits 0-7 = leading windows of 32 centres handed out as one ticket for all three scales (default 0), bit 8 = three scale tickets per window instead of two */
 void captra_sa_bf16_set_variant(int v);     /* bf16 SA scales: bit 0 = small-input scales without gather prefetch / fragment ring, bit 3 = SA2 scales on
                                                sa_bf16_kernel; bits 4.. (ablations with WRONG results, timing only) exist in -DCAPTRA_ABLATIONS=1 builds only */
+void captra_neck_chain_set_split(int n); /* captra_neck_chain_bf16, three-layer modules: workgroups sharing the last layer of a position tile (1 / 2 / 4, default 4) */
 void captra_query_and_group_set_shape(int mcb, int cc); /* captra_query_and_group: centres per workgroup, channels per chunk (0 = heuristic) */
 void captra_group_set_shape(int lds_kb, int ccmax, int ppb); /* group_points: staging budget (KiB, <= 64), channels per workgroup, positions per
                                                workgroup (0 = default); tools/bench_group.py --sweep */
