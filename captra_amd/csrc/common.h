@@ -74,6 +74,12 @@ struct CaptraDeviceOnce {
 // another thread (another GPU's stream in the same process) launches; the reference boundary has no global state.
 #define CAPTRA_KNOB thread_local
 
+// Zero `nbytes` (a multiple of 16, 16-byte aligned) on `stream` with a KERNEL (prof.cpp).  Not hipMemsetAsync: inside a captured
+// hipGraph a memset node is not a kernel node, and in a graph that is ONE linear chain (the step with the networks one after the
+// other) the fill was observed to overlap the kernel behind it at 64+ KiB -- the level-1 stream kernel's granules zeroed after its
+// samplers had published them (consumers gave up waiting, garbage picks); a kernel node is ordered like every other launch.
+int captra_zero_async(void *p, size_t nbytes, hipStream_t stream);
+
 // ---- device helpers ---------------------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 

@@ -428,7 +428,7 @@ extern "C" int captra_neck_chain_bf16(int kind, int b, long long l, int nl, cons
     // row tiles per wave: eight waves share a layer's nt row tiles
     const int mt1 = (p.ly[0].nt + 7) / 8, mt2 = (p.ly[1].nt + 7) / 8, mt3 = nl == 3 ? (p.ly[2].nt + 7) / 8 : 0;
     if (kind == 0) {
-        if (hipMemsetAsync(y, 0, (size_t)b * c[nl] * sizeof(float), s) != hipSuccess) return (int)hipGetLastError();
+        if (const int zrc = captra_zero_async(y, (size_t)b * c[nl] * sizeof(float), s)) return zrc;      // (a kernel, not a memset node: common.h)
         if (nl == 3 && mt1 == 1 && mt2 == 2 && mt3 == 4) {
             if (g_nk_split == 1) return nk_launch<0, 1, 1, 2, 4>(b, p, s);
             if (g_nk_split == 2) return nk_launch<0, 1, 1, 2, 2>(b, p, s, 2);

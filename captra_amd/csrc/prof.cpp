@@ -149,3 +149,18 @@ bool captra_centre_window(int m, int *m0, int *mc) {
     return true;
 }
 
+
+// ---- zeroing as a kernel (common.h: captra_zero_async) ---------------------------------------------------------------------
+__global__ __launch_bounds__(256) void captra_zero_kernel(uint4 *p, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+
+int captra_zero_async(void *p, size_t nbytes, hipStream_t stream) {
+    if (nbytes == 0) return 0;
+    if ((nbytes & 15) != 0 || (reinterpret_cast<uintptr_t>(p) & 15) != 0) return -1;
+    const size_t n16 = nbytes / 16;
+    size_t blocks = (n16 + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    CAPTRA_LAUNCH("zero", captra_zero_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, reinterpret_cast<uint4 *>(p), n16);
+    return captra_last_error();
+}

@@ -1241,7 +1241,7 @@ extern "C" int captra_sa1_stream_bf16(int b, int n, int m, const float *xyz_n3, 
     if (b > 256) return -2;
     hipStream_t st = (hipStream_t)stream;
     const long long sbytes = captra_sa1_stream_scratch_bytes(b, m);
-    if (hipMemsetAsync(scratch, 0, (size_t)sbytes, st) != hipSuccess) return (int)hipGetLastError();
+    if (const int zrc = captra_zero_async(scratch, (size_t)sbytes, st)) return zrc;      // (a kernel, not a memset node: common.h)
     L1Params p;
     p.m2 = m2; p.fps2_idx = fps2_idx; p.new2_n3 = new2_n3; p.new2_cn = new2_cn;
     p.b = b; p.n = n; p.m = m; p.xyz_n3 = xyz_n3; p.xyz_cn = xyz_cn; p.planes = planes; p.fps_idx = fps_idx; p.new_n3 = new_n3; p.new_cn = new_cn;

@@ -786,6 +786,12 @@ int captra_sa_split_knob() { return g_sa_split; }
 // the slice-per-wave form's zeroed output: channels [co_off, co_off + c3), centres [m0, m0 + mc) of every cloud
 static void sl_zero_window(float *out, int b, int m, int out_ctotal, int co_off, int c3, int m0, int mc, hipStream_t stream) {
     if (m0 == 0 && mc == m) {
+        // (few clouds -- the only case the slice-per-wave form is chosen for -- : zeroed by a kernel per cloud, not by a memset node:
+        // common.h captra_zero_async)
+        if (b <= 8 && ((size_t)c3 * m * 4) % 16 == 0 && (reinterpret_cast<uintptr_t>(out + (size_t)co_off * m) & 15) == 0 && ((size_t)out_ctotal * m * 4) % 16 == 0) {
+            for (int bb = 0; bb < b; ++bb) (void)captra_zero_async(out + ((size_t)bb * out_ctotal + co_off) * m, (size_t)c3 * m * 4, stream);
+            return;
+        }
         (void)hipMemset2DAsync(out + (size_t)co_off * m, (size_t)out_ctotal * m * 4, 0, (size_t)c3 * m * 4, b, stream);
         return;
     }

@@ -406,7 +406,14 @@ extern "C" int captra_sa_scale_pre_pm(int b, int n, int m, int k, int cfeat, int
     const long long wgs = ((q.split ? centres * (k / 32) : centres) + 3) / 4;
     const unsigned grid = (unsigned)(wgs < cus ? wgs : cus);
     q.dyn = (!q.split && k > 32 && wgs > 1) ? captra_sa_dyn_slot((hipStream_t)stream) : nullptr;
-    if (q.split) (void)hipMemset2DAsync(out + (size_t)co_off * m, (size_t)out_ctotal * m * 4, 0, (size_t)c3 * m * 4, b, (hipStream_t)stream);
+    if (q.split) {
+        // (zeroed by a kernel per cloud where the rows allow it, not by a memset node: common.h captra_zero_async)
+        if (b <= 8 && ((size_t)c3 * m * 4) % 16 == 0 && (reinterpret_cast<uintptr_t>(out + (size_t)co_off * m) & 15) == 0 && ((size_t)out_ctotal * m * 4) % 16 == 0) {
+            for (int bb = 0; bb < b; ++bb) (void)captra_zero_async(out + ((size_t)bb * out_ctotal + co_off) * m, (size_t)c3 * m * 4, (hipStream_t)stream);
+        } else {
+            (void)hipMemset2DAsync(out + (size_t)co_off * m, (size_t)out_ctotal * m * 4, 0, (size_t)c3 * m * 4, b, (hipStream_t)stream);
+        }
+    }
 #define SPP_CASE(CF_, C1_, C2_, C3_)                                                                                  \
     if (cfeat == CF_ && c1 == C1_ && c2 == C2_ && c3 == C3_) {                                                        \
         auto kern = sa_wave_pipe_kernel<CF_, C1_, C2_, C3_>;                                                          \
