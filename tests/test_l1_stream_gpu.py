@@ -173,3 +173,39 @@ def test_track_step_with_level1_stream_equals_plain_step(device, tag):
         for k in a:
             assert torch.equal(a[k], b[k]), (i, k, "eager")
             assert torch.equal(a[k], c[k]), (i, k, "graph")
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+def test_captured_step_with_level1_stream_at_sixteen_trajectories(device, overlap):
+    """The captured step (hipGraph replay) with the level-1 stream kernel at 16 trajectories, the two networks side by side and one
+    after the other.  The second form is ONE linear chain of graph nodes: with the kernel's scratch zeroed by a hipMemsetAsync node
+    the fill overlapped the kernel from 64 KiB on (granules zeroed after the samplers had published them: consumers gave up, wild
+    gathers, memory faults) -- it is zeroed by a kernel now (common.h captra_zero_async); every replayed pose must equal the eager
+    step's, and no consumer may give up."""
+    import bench
+    from captra_amd.graph import TrackStepGraph
+    cfg, sd, model, data = bench.build_workload(16, device, category="bottle", traj_seed=0, mlp_dtype="bf16")
+    model.overlap_nets = overlap
+    pose0 = {k: v.clone() for k, v in model.feed_dict[0]["gt_part"].items()}
+    n = len(model.feed_dict)
+
+    def loop(step, k=5):
+        pe, out = pose0, []
+        for i in range(1, k):
+            pe = step(1 + (i - 1) % (n - 1), pe)
+            out.append({kk: v.clone() for kk, v in pe.items()})
+            torch.cuda.synchronize()
+            model.check_l1_stream()
+        return out
+
+    def eager(i, pe):
+        with torch.no_grad():
+            return model.track_step(model.feed_dict[i], model.npcs_feed_dict[i], pe)[1]
+
+    want = loop(eager)
+    assert model._l1_scratch is not None, "the level-1 stream kernel did not run"
+    graph = TrackStepGraph(model, model.feed_dict[1]["points"], model.feed_dict[1]["points_mean"], pose0)
+    got = loop(lambda i, pe: graph.replay(model.feed_dict[i]["points"], model.feed_dict[i]["points_mean"], pe))
+    for i, (a, b) in enumerate(zip(want, got)):
+        for k in a:
+            assert torch.equal(a[k], b[k]), (i, k)
