@@ -850,7 +850,8 @@ def main():
         total_ms = sum(v["ms_total"] for v in fams.values())
         # the fp32-MFMA shared-MLP kernels: the fused SA scale (sa_fused.hip) and the layer kernel template
         # (pointwise_mlp.hip: pointwise_mlp / sa_group_mlp / mlp_max entry points)
-        mlp = ["sa_scale_fused", "pointwise_mlp", "mlp_chain3", "coord_tail", "sa_group_mlp", "mlp_max"]
+        # (the level-1 stream kernel's MLPs are timed with its sampler -- a latency-bound launch -- and stay out of the family)
+        mlp = ["sa_scale_fused", "pointwise_mlp", "mlp_chain3", "coord_tail", "sa_group_mlp", "mlp_max", "neck_chain"]
         mlp_ms = sum(fams[k]["ms_total"] for k in mlp if k in fams)
         mlp_launches = sum(fams[k]["launches"] for k in mlp if k in fams)
         mlp_flops = sum(fused.WORK["flops"].get(k, 0.0) for k in mlp)
@@ -867,7 +868,7 @@ def main():
                                "share_of_kernel_time": round(mlp_ms / max(total_ms, 1e-9), 3), "dominant_family": dominant}
             # the counter file of THIS configuration (tools/profile_round.sh <tag> <suffix> ...): bf16 / drawers have their own
             sfx = ("_bf16" if args.mlp_dtype != "fp32" else "") + ("_drawers" if args.category == "drawers" else "")
-            traffic, src, why = pmc_traffic(["sa_bf16_kernel", "tb_layer_kernel", "tb_head12_kernel", "chain_bf16_kernel", "pw_bf16pm_kernel", "pw_bf16pm_affs_kernel", "pw_bf16_kernel"], sfx) if args.mlp_dtype != "fp32" else pmc_traffic(
+            traffic, src, why = pmc_traffic(["sa_bf16_kernel", "sa2_bf16_kernel", "tb_layer_kernel", "tb_head12_kernel", "tb_head12p_kernel", "neck_chain_kernel", "chain_bf16_kernel", "pw_bf16pm_kernel", "pw_bf16pm_affs_kernel", "pw_bf16_kernel"], sfx) if args.mlp_dtype != "fp32" else pmc_traffic(
                 ["sa_wave_kernel", "sa_wave_lds_kernel", "sa_wave_pipe_kernel", "sa_fused_kernel", "mlp_chain3_kernel", "coord_tail_kernel", "pw_direct_kernel", "pw_direct_max_kernel", "pw_mlp_kernel"], sfx)
             if traffic is not None:
                 out["roofline"]["traffic"] = round(traffic)
