@@ -63,7 +63,6 @@ _SIGNATURES = {
     "captra_gemv_bf16": [_INT, _INT, _INT, _P, _P, _P, _P, _P],
     "captra_head12_bf16": [_INT, _INT, _LL, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "captra_mlp_chain_bf16": [_INT, _INT, _LL, _INT, _INT, _INT, _P, _P, _P, _P, _P, _P],
-    "captra_mlp_chain_bf16_interp": [_INT, _INT, _LL, _INT, _INT, _INT, _P, _INT, _P, _INT, _P, _P, _P, _P, _P, _P, _P],
     "captra_pack_sa_bf16": [_INT] * 5 + [_P] * 7 + [_P],
     "captra_sa_scale_bf16": [_INT] * 9 + [_P] * 6 + [_INT, _INT, _P],
     "captra_query_and_group": [_INT, _INT, _INT, _F, _INT, _INT, _INT, _P, _P, _P, _P, _P, _P],
@@ -174,8 +173,6 @@ def lib():
                         ("CAPTRA_HEAD_PERSIST", "captra_tile_bf16_set_persistent")):
             if env in os.environ and hasattr(l, fn):
                 getattr(l, fn)(C.c_int(int(os.environ[env])))
-        if "CAPTRA_L1_FINE" in os.environ and hasattr(l, "captra_sa1_stream_set_fine"):
-            l.captra_sa1_stream_set_fine(int(os.environ["CAPTRA_L1_FINE"]))
         if "CAPTRA_L1_GRID" in os.environ and hasattr(l, "captra_sa1_stream_set_grid"):
             l.captra_sa1_stream_set_grid(int(os.environ["CAPTRA_L1_GRID"]), 1)
     return _lib

@@ -1292,11 +1292,7 @@ namespace {
 struct CbParams {
     int c0, s, no;                 // input channels, segmentation logits (0: no heads), NOCS outputs
     long long L;
-    const float *x;                // (B,c0,L) fp32; INTERP: (B,csplit,L), the skip channels
-    const float *x2;               // INTERP: (B,c0 - csplit,S) known features, interpolated through nn_idx / nn_w (B,L,3)
-    const int *nn_idx;
-    const float *nn_w;
-    int csplit, s_known;
+    const float *x;                // (B,c0,L) fp32
     const unsigned char *img;      // fragments of every layer back to back, then the biases (32 floats per row tile)
     void *feat_pm;                 // (B,L,128) bf16 slot order, or null
     float *seg, *nocs;             // (B,s,L), (B,no,L) fp32 (heads only)
@@ -1365,10 +1361,7 @@ __device__ __forceinline__ void cb_out_layer(const unsigned char *wl, const floa
     }
 }
 
-// INTERP: the input is cat([skip, interpolate(known)]) of pointnet_utils.py:280-294, never built -- channel ch >= csplit of position c is
-// (w0 f[j0] + w1 f[j1]) + w2 f[j2] (captra_interp_concat's expression, unfused), formed while the first operand is loaded: the
-// (B, c0, 4096) tensor's write + read (4 MB per cloud) and a launch are gone, the values are the same.
-template <int KST0, bool HEADS, bool INTERP = false>
+template <int KST0, bool HEADS>
 __global__ __launch_bounds__(512, 2) void chain_bf16_kernel(CbParams p) {
     constexpr int NF_TRUNK = 4 * KST0 + 32 + 32;                   // fragments of the three 128-wide layers
     constexpr int NF = NF_TRUNK + (HEADS ? 8 + 32 + 8 : 0);        // + seg (1 tile x 8), hidden (4 x 8), out (1 x 8)
@@ -1389,9 +1382,8 @@ __global__ __launch_bounds__(512, 2) void chain_bf16_kernel(CbParams p) {
     const long long pos0 = ((long long)blockIdx.x * 8 + wave) * 64;
     if (pos0 >= p.L) return;                                       // (no barrier below)
     // ---- layer 1's B operands straight from the fp32 rows: k-step kk, lane (col, h) = channels 16kk + 8h + 0..7 of its position
-    const int cx = INTERP ? p.csplit : p.c0;
-    const float *xb = p.x + (size_t)b * cx * p.L;
-    const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc((void *)xb, 0, (int)((long long)cx * p.L * 4), 0x00020000);
+    const float *xb = p.x + (size_t)b * p.c0 * p.L;
+    const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc((void *)xb, 0, (int)((long long)p.c0 * p.L * 4), 0x00020000);
     u32x4 x0[2][KST0];
     const int xrow = (int)(p.L * 4);
 #pragma unroll
@@ -1399,35 +1391,11 @@ __global__ __launch_bounds__(512, 2) void chain_bf16_kernel(CbParams p) {
         long long c = pos0 + 32 * j + col;
         if (c >= p.L) c = p.L - 1;                                 // clamped column: computed, never stored
         const int voff = (int)(((long long)(8 * h) * p.L + c) * 4); // rows >= c0 fall outside the buffer and read as 0
-        int nj[3] = {0, 0, 0};
-        float nw[3] = {0.f, 0.f, 0.f};
-        const float *kb = nullptr;
-        if constexpr (INTERP) {
-            const int *ii = p.nn_idx + ((size_t)b * p.L + c) * 3;
-            const float *ww = p.nn_w + ((size_t)b * p.L + c) * 3;
-#pragma unroll
-            for (int e = 0; e < 3; ++e) { nj[e] = ii[e]; nw[e] = ww[e]; }
-            kb = p.x2 + (size_t)b * (p.c0 - p.csplit) * p.s_known;
-        }
 #pragma unroll
         for (int kk = 0; kk < KST0; ++kk) {
             float v[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                if constexpr (INTERP) {
-                    const int ch = kk * 16 + 8 * h + i;
-                    if (ch < p.csplit) {
-                        v[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xsrc, voff + (kk * 16 + i) * xrow, 0, 0));
-                    } else if (ch < p.c0) {
-                        const float *row = kb + (size_t)(ch - p.csplit) * p.s_known;
-                        v[i] = (nw[0] * row[nj[0]] + nw[1] * row[nj[1]]) + nw[2] * row[nj[2]];
-                    } else {
-                        v[i] = 0.f;
-                    }
-                } else {
-                    v[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xsrc, voff + (kk * 16 + i) * xrow, 0, 0));
-                }
-            }
+            for (int i = 0; i < 8; ++i) v[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xsrc, voff + (kk * 16 + i) * xrow, 0, 0));
 #pragma unroll
             for (int i = 0; i < 4; ++i) x0[j][kk][i] = sb_pack(v[2 * i], v[2 * i + 1]);
         }
@@ -1454,11 +1422,11 @@ __global__ __launch_bounds__(512, 2) void chain_bf16_kernel(CbParams p) {
     }
 }
 
-template <int KST0, bool HEADS, bool INTERP = false>
+template <int KST0, bool HEADS>
 int cb_launch(int b, const CbParams &p, hipStream_t stream) {
     constexpr int NF = 4 * KST0 + 64 + (HEADS ? 48 : 0), NBT = 12 + (HEADS ? 6 : 0);
     const int lds = NF * 1024 + NBT * 32 * 4;
-    auto kern = chain_bf16_kernel<KST0, HEADS, INTERP>;
+    auto kern = chain_bf16_kernel<KST0, HEADS>;
     static CaptraDeviceOnce once;
     if (once.first_use()) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return (int)hipGetLastError();
@@ -1489,33 +1457,10 @@ extern "C" int captra_mlp_chain_bf16(int b, int c0, long long l, int heads, int 
     if (b == 0 || l == 0) return 0;
     CbParams p;
     p.c0 = c0; p.s = s; p.no = no; p.L = l; p.x = x; p.img = img; p.feat_pm = feat_pm; p.seg = seg; p.nocs = nocs;
-    p.x2 = nullptr; p.nn_idx = nullptr; p.nn_w = nullptr; p.csplit = c0; p.s_known = 0;
     const int kst0 = (c0 + 15) / 16;
     hipStream_t st = (hipStream_t)stream;
 #define CB_CASE(K_)                                                                      \
     if (kst0 == K_) return heads ? cb_launch<K_, true>(b, p, st) : cb_launch<K_, false>(b, p, st);
-    CB_CASE(9) CB_CASE(8)
-#undef CB_CASE
-    return -2;
-}
-
-// The same chain on the input cat([skip, interpolate(known)]) of PointNetFeaturePropagation (pointnet_utils.py:280-294), never built:
-// skip (B,csplit,L) fp32, known (B,c0 - csplit,S) fp32, nn_idx / nn_w (B,L,3) of captra_three_nn_weights; channel ch >= csplit of position
-// c = (w0 f[j0] + w1 f[j1]) + w2 f[j2] as captra_interp_concat forms it.  Same outputs as captra_interp_concat + captra_mlp_chain_bf16.
-extern "C" int captra_mlp_chain_bf16_interp(int b, int c0, long long l, int heads, int s, int no, const float *skip, int csplit,
-                                            const float *known, int s_known, const int *nn_idx, const float *nn_w, const unsigned char *img,
-                                            void *feat_pm, float *seg, float *nocs, captra_stream_t stream) {
-    if (b < 0 || c0 < 1 || l < 0 || csplit < 0 || csplit > c0 || s_known < 1) return -1;
-    if (c0 > 144 || (heads && (s < 1 || s > 32 || no < 1 || no > 32 || seg == nullptr || nocs == nullptr))) return -2;
-    if ((long long)c0 * l * 4 >= (1ll << 31)) return -2;
-    if (b == 0 || l == 0) return 0;
-    CbParams p;
-    p.c0 = c0; p.s = s; p.no = no; p.L = l; p.x = skip; p.img = img; p.feat_pm = feat_pm; p.seg = seg; p.nocs = nocs;
-    p.x2 = known; p.nn_idx = nn_idx; p.nn_w = nn_w; p.csplit = csplit; p.s_known = s_known;
-    const int kst0 = (c0 + 15) / 16;
-    hipStream_t st = (hipStream_t)stream;
-#define CB_CASE(K_)                                                                      \
-    if (kst0 == K_) return heads ? cb_launch<K_, true, true>(b, p, st) : cb_launch<K_, false, true>(b, p, st);
     CB_CASE(9) CB_CASE(8)
 #undef CB_CASE
     return -2;

@@ -499,31 +499,6 @@ class PMTensor:
 USE_CHAIN_BF16 = True     # FP1 + conv1 (+ CoordinateNet's heads) register-resident in one launch (captra_mlp_chain_bf16)
 
 
-USE_CHAIN_INTERP = os.environ.get("CAPTRA_CHAIN_INTERP", "1") != "0"   # FP1's interpolation + concat inside the chain's operand load
-
-
-class InterpConcat:
-    """cat([skip, interpolate(known)]) of PointNetFeaturePropagation (pointnet_utils.py:280-294) NOT built yet: what a consumer that
-    can form it while loading (captra_mlp_chain_bf16_interp) takes instead of the (B, c1 + c2, N) tensor; `materialize()` builds it."""
-    __slots__ = ("skip", "known", "idx", "weight")
-
-    def __init__(self, skip, known, idx, weight):
-        self.skip, self.known, self.idx, self.weight = skip, known, idx, weight
-
-    @property
-    def shape(self):
-        return (self.skip.shape[0], self.skip.shape[1] + self.known.shape[1], self.skip.shape[2])
-
-    def dim(self):
-        return 3
-
-    def contiguous(self):
-        return self
-
-    def materialize(self):
-        return interp_concat(self.skip, self.known, self.idx, self.weight)
-
-
 def chain_bf16_supported(x, layers, heads=None) -> bool:
     # (captra_mlp_chain_bf16 instantiates 8 and 9 input k-steps: 113 .. 144 input channels; anything else returns -2)
     if not (USE_CHAIN_BF16 and mlp_dtype() == "bf16" and len(layers) == 3 and x.dim() == 3 and (x.shape[1] + 15) // 16 in (8, 9)):
@@ -554,31 +529,19 @@ def _chain_bf16_image(layers, heads):
 def mlp_chain_bf16_fused(x, layers, heads=None):
     """x (B,c0,L) fp32 through three 128-wide Conv+BN+ReLU layers in ONE launch.  heads None -> the feature map as a PMTensor;
     heads = (seg, hidden, out) packed layers -> (seg logits (B,S,L), sigmoid(nocs) - 0.5 (B,3P,L)) fp32."""
+    L.require_device(x)
     B, c0, l = x.shape
     img = _chain_bf16_image(layers, heads)
-    dev = img.device
-    lazy = isinstance(x, InterpConcat)
-    if lazy:
-        L.require_device(x.skip, x.known, x.idx, x.weight)
-    else:
-        L.require_device(x)
-
-    def launch(nh, s_, no_, feat, seg, nocs):
-        with torch.cuda.device(dev):
-            if lazy:
-                L.call("captra_mlp_chain_bf16_interp", B, c0, l, nh, s_, no_, L.ptr(x.skip), x.skip.shape[1], L.ptr(x.known), x.known.shape[2],
-                       L.ptr(x.idx), L.ptr(x.weight), L.ptr(img), L.ptr(feat), L.ptr(seg), L.ptr(nocs))
-            else:
-                L.call("captra_mlp_chain_bf16", B, c0, l, nh, s_, no_, L.ptr(x), L.ptr(img), L.ptr(feat), L.ptr(seg), L.ptr(nocs))
-
     if heads is None:
-        feat = torch.empty(B, l, 128, dtype=torch.bfloat16, device=dev)
-        launch(0, 0, 0, feat, None, None)
+        feat = torch.empty(B, l, 128, dtype=torch.bfloat16, device=x.device)
+        with torch.cuda.device(x.device):
+            L.call("captra_mlp_chain_bf16", B, c0, l, 0, 0, 0, L.ptr(x), L.ptr(img), L.ptr(feat), None, None)
         _work("mlp_chain3", flops=2.0 * B * l * (c0 * 128 + 2 * 128 * 128), nbytes=B * l * (4.0 * c0 + 2.0 * 128))
         return PMTensor(feat, 128)
-    seg = torch.empty(B, heads[0].cout, l, dtype=torch.float32, device=dev)
-    nocs = torch.empty(B, heads[2].cout, l, dtype=torch.float32, device=dev)
-    launch(1, heads[0].cout, heads[2].cout, None, seg, nocs)
+    seg = torch.empty(B, heads[0].cout, l, dtype=torch.float32, device=x.device)
+    nocs = torch.empty(B, heads[2].cout, l, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        L.call("captra_mlp_chain_bf16", B, c0, l, 1, heads[0].cout, heads[2].cout, L.ptr(x), L.ptr(img), None, L.ptr(seg), L.ptr(nocs))
     _work("coord_tail", flops=2.0 * B * l * (c0 * 128 + 3 * 128 * 128 + 128 * (heads[0].cout + heads[2].cout)),
           nbytes=4.0 * B * l * (c0 + heads[0].cout + heads[2].cout))
     return seg, nocs

@@ -92,8 +92,6 @@ class CoordNet(nn.Module):
             head_layers = self._head_layers(cam_cn.device)
             if head_layers is not None:
                 def fused_tail(x, layers):
-                    if isinstance(x, fused.InterpConcat) and not fused.chain_bf16_supported(x, layers, head_layers):
-                        x = x.materialize()
                     all_layers = list(layers) + head_layers
                     if fused.coord_tail_supported(x, all_layers):
                         return fused.coord_tail(x, all_layers)            # (seg logits, sigmoid(nocs) - 0.5)
@@ -190,8 +188,6 @@ class RotationRegressionBackbone(nn.Module):
             def finish(x, layers):
                 if fused.chain_bf16_supported(x, layers):
                     return fused.mlp_chain_bf16_fused(x.contiguous(), layers)
-                if isinstance(x, fused.InterpConcat):
-                    x = x.materialize()
                 return fused.mlp_chain3(x, layers, fused.ACT_RELU)
         return self.pose_pred.raw_diag(self.encoder(cam, input_n3=cam_n3, geom=geom, finish=finish))
 

@@ -356,12 +356,6 @@ class PointNetFeaturePropagation(_FoldCache, nn.Module):
                     # interpolation, skip concat and both layers in one launch (csrc/neck_bf16.hip): the interpolated channels are
                     # formed while the first layer's operand is staged
                     return fused.neck_chain(2, points1.contiguous(), self._fold(xyz1.device), x2=points2.contiguous(), nn=nn)
-                if (finish is not None and points1 is not None and fused.USE_CHAIN_INTERP and fused.mlp_dtype() == "bf16"
-                        and fused.chain_bf16_supported(fused.InterpConcat(points1, points2, nn[0], nn[1]), list(self._fold(xyz1.device)) + ([tail] if tail is not None else []))):
-                    # the caller's one-launch chain forms the interpolated channels while it loads its first operand: no
-                    # (B, c1 + c2, N) tensor, no interpolation launch (the caller materialises it if its chain does not apply)
-                    layers = list(self._fold(xyz1.device)) + ([tail] if tail is not None else [])
-                    return finish(fused.InterpConcat(points1.contiguous(), points2.contiguous(), nn[0], nn[1]), layers)
                 new_points = fused.interp_concat(None if points1 is None else points1.contiguous(),
                                                  points2.contiguous(), nn[0], nn[1])
             else:

@@ -306,12 +306,6 @@ int captra_head12_bf16(int b, int cin, long long l, const void *x, const unsigne
 long long captra_chain_bf16_image_bytes(int c0, int heads);
 int captra_mlp_chain_bf16(int b, int c0, long long l, int heads, int s, int no, const float *x, const unsigned char *img,
                           void *feat_pm, float *seg, float *nocs, captra_stream_t stream);
-/* captra_mlp_chain_bf16 on the input cat([skip, interpolate(known)]) of PointNetFeaturePropagation (pointnet_utils.py:280-294), never
- * built: skip (B,csplit,L), known (B,c0-csplit,S) fp32, nn_idx / nn_w (B,L,3) of captra_three_nn_weights; the interpolated channels are
- * formed with captra_interp_concat's expression while the first operand is loaded.  Same outputs as the two launches. */
-int captra_mlp_chain_bf16_interp(int b, int c0, long long l, int heads, int s, int no, const float *skip, int csplit, const float *known,
-                                 int s_known, const int *nn_idx, const float *nn_w, const unsigned char *img, void *feat_pm, float *seg,
-                                 float *nocs, captra_stream_t stream);
 
 /* Furthest point sampling + index_points in one launch (pointnet_utils.py:222-223: new_xyz = index_points(xyz,
  * farthest_point_sample(xyz, S))): xyz (B,N,3) -> idx (B,M) i32, new_xyz_n3 (B,M,3), new_xyz_cn (B,3,M) (either output

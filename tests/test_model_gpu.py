@@ -1291,38 +1291,6 @@ def test_bf16_chain_one_launch_equals_layer_by_layer(device, c0, l):
     assert err.max() <= 3e-2 * scale and err.mean() <= 2e-4 * scale
 
 
-@pytest.mark.parametrize("c1,c2,l,s", [(3, 128, 4096, 512), (6, 128, 1000, 128), (3, 128, 77, 5)])
-def test_bf16_chain_with_interpolation_on_load_is_identical(device, c1, c2, l, s):
-    """captra_mlp_chain_bf16_interp (cat([skip, interpolate(known)]) formed while the chain loads its first operand) against
-    captra_interp_concat + captra_mlp_chain_bf16: the same expression per element, so every output bit agrees -- feature map and heads."""
-    from captra_amd import fused
-    rng = np.random.default_rng(c1 + l)
-    B = 3
-    c0 = c1 + c2
-    skip = _dev(rng.standard_normal((B, c1, l)).astype(np.float32), device)
-    known = _dev(rng.standard_normal((B, c2, s)).astype(np.float32), device)
-    xyz1 = _dev(rng.uniform(-1, 1, (B, l, 3)).astype(np.float32), device)
-    xyz2 = _dev(rng.uniform(-1, 1, (B, s, 3)).astype(np.float32), device)
-    idx, w = fused.three_nn_weights(xyz1, xyz2)
-    dims = [c0, 128, 128, 128]
-    layers = [fused.pack(_dev((rng.standard_normal((dims[i], dims[i + 1])) / np.sqrt(dims[i])).astype(np.float32), device),
-                         _dev(rng.standard_normal(dims[i + 1]).astype(np.float32), device)) for i in range(3)]
-    heads = [fused.pack(_dev((rng.standard_normal((128, c)) / np.sqrt(128)).astype(np.float32), device), _dev(rng.standard_normal(c).astype(np.float32), device))
-             for c in (2, 128, 3)]
-    with fused.use_mlp_dtype("bf16"):
-        lazy = fused.InterpConcat(skip, known, idx, w)
-        assert lazy.shape == (B, c0, l) and fused.chain_bf16_supported(lazy, layers, heads)
-        x = lazy.materialize()
-        assert tuple(x.shape) == (B, c0, l)
-        ref_feat = fused.mlp_chain_bf16_fused(x, layers)
-        ref_seg, ref_nocs = fused.mlp_chain_bf16_fused(x, layers, heads)
-        feat = fused.mlp_chain_bf16_fused(lazy, layers)
-        seg, nocs = fused.mlp_chain_bf16_fused(lazy, layers, heads)
-    torch.cuda.synchronize()
-    assert torch.equal(feat.data.view(torch.int16), ref_feat.data.view(torch.int16))
-    assert torch.equal(seg, ref_seg) and torch.equal(nocs, ref_nocs)
-
-
 def test_bf16_mode_track_step_close_to_fp32(device):
     """The whole tracking step with bf16 MFMA operands in the shared MLPs (fused.use_mlp_dtype / cfg['mlp_dtype'], BASELINE.json configs[2]) stays
     close to the exact-fp32 step on the same inputs: NOCS coordinates within bf16-level error, (almost) no label flips."""
