@@ -173,6 +173,8 @@ def lib():
                         ("CAPTRA_HEAD_PERSIST", "captra_tile_bf16_set_persistent")):
             if env in os.environ and hasattr(l, fn):
                 getattr(l, fn)(C.c_int(int(os.environ[env])))
+        if "CAPTRA_L1_FINE" in os.environ and hasattr(l, "captra_sa1_stream_set_fine"):
+            l.captra_sa1_stream_set_fine(int(os.environ["CAPTRA_L1_FINE"]))
         if "CAPTRA_L1_GRID" in os.environ and hasattr(l, "captra_sa1_stream_set_grid"):
             l.captra_sa1_stream_set_grid(int(os.environ["CAPTRA_L1_GRID"]), 1)
     return _lib
