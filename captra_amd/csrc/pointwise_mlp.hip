@@ -30,6 +30,7 @@
 // chunk c and written to LDS after them), 2 workgroups per CU.
 #include "common.h"
 #include <atomic>
+#include <type_traits>
 
 namespace {
 
@@ -66,6 +67,7 @@ struct PwParams {
     // cloud, read for every position); both tensors are addressed from ONE buffer descriptor based at the lower of the two
     const float *x2;
     int csplit, x2_bcast;
+    int dbg;              // CAPTRA_ABLATIONS builds only (timing ablations of the direct kernel, results wrong): 1 = no y stores, 2 = no statistics, 4 = every workgroup reads the first columns
 };
 
 template <int CTRL>
@@ -341,10 +343,46 @@ __device__ __forceinline__ float half_wave_sum(float v) {
     return v;
 }
 
+// Transposing reduction of the statistics epilogue: 16 per-row values per lane -> ONE value per lane, the total over the half-wave's
+// 32 lanes of the row the lane stands for.  Each step halves the registers: a lane keeps the first of a register pair where its lane
+// bit is 0 and the second where it is 1, and adds its partner's copy of the one it keeps.  Bits 2 and 3 pick whole banks of four
+// lanes, so the keep / send choice is the DPP move's bank mask (no select); bits 0 and 1 take two v_cndmask.  15 exchanges of three
+// instructions instead of 16 five-step butterflies, and one store per lane at the end instead of two two-lane stores per row.
+template <int CTRL_LO, int CTRL_HI, int BANK_LO, int BANK_HI>
+__device__ __forceinline__ float xchg_add_banked(float a, float b) {
+    const int x = __builtin_amdgcn_update_dpp(__float_as_int(b), __float_as_int(a), CTRL_LO, 0xF, BANK_LO, false);   // bit 0 lanes: the partner's a
+    const int y = __builtin_amdgcn_update_dpp(__float_as_int(a), __float_as_int(b), CTRL_HI, 0xF, BANK_HI, false);   // bit 1 lanes: the partner's b
+    return __int_as_float(x) + __int_as_float(y);
+}
+template <int CTRL>
+__device__ __forceinline__ float xchg_add_select(float a, float b, bool bit) {
+    const float keep = bit ? b : a, send = bit ? a : b;
+    return keep + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), CTRL, 0xF, 0xF, true));
+}
+// v[16] -> the half-wave total of register rr(lane) = ((lane >> 1) & 1) + 2 (lane & 1) + 4 ((lane >> 3) & 1) + 8 ((lane >> 2) & 1)
+__device__ __forceinline__ float half_wave_transpose_sum(const float (&v)[16], int lane) {
+    float w[8], u[4], t[2];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) w[k] = xchg_add_banked<0x104, 0x114, 0x5, 0xA>(v[k], v[k + 8]);      // lane ^ 4: row_shl:4 / row_shr:4
+#pragma unroll
+    for (int k = 0; k < 4; ++k) u[k] = xchg_add_banked<0x128, 0x128, 0x3, 0xC>(w[k], w[k + 4]);      // lane ^ 8: row_ror:8
+#pragma unroll
+    for (int k = 0; k < 2; ++k) t[k] = xchg_add_select<0xB1>(u[k], u[k + 2], (lane & 1) != 0);       // lane ^ 1: quad_perm [1,0,3,2]
+    float s = xchg_add_select<0x4E>(t[0], t[1], (lane & 2) != 0);                                     // lane ^ 2: quad_perm [2,3,0,1]
+    return s + __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(s), 0x401F));                // lane ^ 16 (swizzle within 32 lanes)
+}
+
 // PAIR (TN == 2, L even): the wave's 64 columns are dealt to its two column tiles ALTERNATELY (tile tn holds columns
 //      pos0 + 2i + tn), so one 8-byte load per lane and k-step feeds both tiles' B operands and one 8-byte store writes
 //      both tiles' outputs of a row -- half the vector-memory instructions of the B side.  Which column a lane's
 //      accumulator stands for changes, the per-element k-ascending chain does not: same bits per output element.
+template <int ACT>
+__device__ __forceinline__ float apply_act_c(float v) {
+    if (ACT == ACT_RELU) return relu_bits(v);
+    if (ACT == ACT_SIGMOID_M05) return 1.0f / (1.0f + expf(-v)) - 0.5f;
+    return v;
+}
+
 template <int TM, int TN, int WGM, int WGN, bool AFF = false, bool ST = false, bool PAIR = false, bool SRC2 = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void pw_direct_kernel(PwParams p) {
     static_assert(WGM * WGN == 4, "4 waves");
@@ -355,11 +393,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void p
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WGN, wn = wave % WGN;
+    const int dbg = CAPTRA_ABLATIONS ? p.dbg : 0;
     const int b = blockIdx.z;
     const int co0 = (blockIdx.y * WGM + wm) * TM * 32;
     const long long pos0 = ((long long)blockIdx.x * WGN + wn) * TN * 32;
     if (co0 >= p.cout) return;  // wave-uniform; no barriers in this kernel
-
     // A operands from the FRAGMENT image of the packed buffer (behind its row-major image): one 16-byte load per lane holds
     // four consecutive k-steps of an output tile -- a quarter of the vector-memory instructions of dword loads, which at one
     // load per MFMA kept the CU's address unit as busy as its four matrix pipes
@@ -390,6 +428,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void p
     for (int tn = 0; tn < TN; ++tn) {
         long long col = col_of(tn);
         if (col >= p.L) col = PAIR ? p.L - 2 + tn : p.L - 1;   // (PAIR: L and the pair's first column are even)
+        if (dbg & 4) col -= pos0;
         xvoff[tn] = (int)(((long long)(lane >> 5) * p.L + col) * 4);
         xcol4[tn] = (int)(col * 4);
     }
@@ -465,9 +504,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void p
 #undef PW_LOAD_SET
 #undef PW_MFMA_SET
 
+    if constexpr (ST && PAIR) {
+        // the rotation heads' layers (whole tiles, channel-major output, no activation on this path): the epilogue with nothing to
+        // decide per element.  Everything a wave issues here is time its SIMD's matrix pipe does not get back (ablations, DESIGN
+        // 3.2): 32 stores + ~280 vector instructions per 64 x 64 tile instead of 96 stores + ~1000
+        if (!p.y_pm && pos0 + 64 <= p.L && co0 + TM * 32 <= p.cout && dbg == 0) {
+            const int h = lane >> 5;
+            const int tcol = (int)(pos0 / 64);
+            const int rr = ((lane >> 1) & 1) + 2 * (lane & 1) + 4 * ((lane >> 3) & 1) + 8 * ((lane >> 2) & 1);
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                const int row0 = co0 + tm * 32 + 4 * h;
+                float *yp = p.y + ((size_t)b * p.cout + row0) * p.L + pos0 + 2 * (lane & 31);
+                float vs[16], vq[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v0 = acc[tm][0][r], v1 = acc[tm][1][r];
+                    *reinterpret_cast<float2 *>(yp + (size_t)((r & 3) + 8 * (r >> 2)) * p.L) = make_float2(v0, v1);
+                    vs[r] = v0 + v1;
+                    vq[r] = v0 * v0 + v1 * v1;
+                }
+                const float sm = half_wave_transpose_sum(vs, lane), sq = half_wave_transpose_sum(vq, lane);
+                if ((lane & 16) == 0)
+                    *reinterpret_cast<float2 *>(p.stats_out + (((size_t)b * p.cout + row0 + (rr & 3) + 8 * (rr >> 2)) * p.stats_t + tcol) * 2) =
+                        make_float2(sm, sq);
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
         const int row0 = co0 + tm * 32 + 4 * (lane >> 5);
+        if ((dbg & 1) && acc[tm][0][0] != 1.2345e-30f) continue;
         if (PAIR && !p.y_pm) {
             // both column tiles' outputs of a row are neighbours: one 8-byte store (col even, L even: aligned)
             const long long col = col_of(0);
@@ -505,7 +573,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void p
             }
         }
     }
-    if (ST) {
+    if (ST && !(dbg & 2)) {
+        float dsm = 0.f, dsq = 0.f;   // (dbg & 8: one statistics store per row tile, timing only)
         // (sum, sum of squares) of the RAW outputs (act is none on this path) of every row over this wave's TN*32 columns
         const int tcol = (int)(pos0 / (TN * 32));
 #pragma unroll
@@ -523,6 +592,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void p
                 sm = half_wave_sum(sm);
                 sq = half_wave_sum(sq);
                 const int row = row0 + (r & 3) + 8 * (r >> 2);
+                if (dbg & 8) { dsm += sm; dsq += sq; if (r < 15) continue; sm = dsm; sq = dsq; }
                 if ((lane & 31) == 16 && row < p.cout) {
                     float *d = p.stats_out + (((size_t)b * p.cout + row) * p.stats_t + tcol) * 2;
                     d[0] = sm;
@@ -676,6 +746,8 @@ static CAPTRA_KNOB int g_pw_direct = 1;  // experiment knob: 0 = LDS-staged kern
 static CAPTRA_KNOB int g_pw_occ = 0;       // experiment knob: 0 / 4 = as built, 3 / 2 = fewer workgroups per CU
 extern "C" void captra_pw_set_occupancy(int occ) { g_pw_occ = occ; }
 static inline unsigned pw_occupancy_pad() { return g_pw_occ == 2 ? 60000u : (g_pw_occ == 3 ? 45000u : 0u); }
+static CAPTRA_KNOB int g_pw_dbg = 0;     // CAPTRA_ABLATIONS builds: PwParams::dbg of captra_pointwise_mlp_gn's launches
+extern "C" void captra_pw_set_dbg(int v) { g_pw_dbg = CAPTRA_ABLATIONS ? v : 0; }
 static CAPTRA_KNOB int g_pw_pair = 1;    // experiment knob: 0 = never the paired-column variant
 extern "C" void captra_pw_set_pair(int on) { g_pw_pair = on; }
 // paired column tiles need 8-byte aligned row segments: even L, 8-byte aligned tensors
@@ -825,7 +897,7 @@ extern "C" int captra_pointwise_mlp_gn(int b, int cin, int cout, long long l, co
     if (b == 0 || l == 0) return 0;
     PwParams p = {};
     p.cin = cin; p.cout = cout; p.ldw = (cout + 127) / 128 * 128; p.L = l; p.x = x; p.wt = wt_packed; p.bias = bias_packed;
-    p.y = y; p.act = act; p.ab_in = ab_in; p.stats_out = stats_out; p.stats_t = stats_t;
+    p.y = y; p.act = act; p.ab_in = ab_in; p.stats_out = stats_out; p.stats_t = stats_t; p.dbg = g_pw_dbg;
     hipStream_t s = (hipStream_t)stream;
     const long long waves22 = ((l + 63) / 64) * ((cout + 63) / 64) * b;
     if (cout > 64 && waves22 < 2048) {

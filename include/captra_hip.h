@@ -561,6 +561,7 @@ void captra_sa_fused_set_prof(unsigned long long *dev_counters); /* sa_wave_kern
 void captra_pw_set_direct(int on);          /* dense layers: 1 = direct-operand kernel (default), 0 = LDS-staged kernel */
 void captra_ball_query_set_prune(int on);   /* ball query: 1 = small radii of 1024..4096-point clouds from a cell grid (exact; measured slower, off by default), 0 = index-order scan */
 void captra_pw_set_occupancy(int occ);      /* dense layers, 64x64 wave tiles: workgroups per CU, 0 / 4 = as built (default), 3 / 2 = fewer (measurements) */
+void captra_pw_set_dbg(int v);             /* dense layers of a GroupNorm chain: timing ablations (-DCAPTRA_ABLATIONS=1 builds only, results wrong; ignored otherwise) */
 void captra_pw_set_pair(int on);            /* dense layers: 1 = paired column tiles where L is even (default), 0 = never */
 void captra_sa1_stream_set_grid(int grid, int prio); /* level-1 stream kernel: workgroups (0 = two per CU), 1 = samplers at s_setprio 3 (default) */
 void captra_sa1_stream_set_fine(int centres); /* level-1 stream kernel: trailing centres handed out as fine tickets of 8 (multiple of 32, default 32) */

@@ -979,7 +979,35 @@ def test_rot_pool_compose_vs_reference_algebra(device, sym, P):
     np.testing.assert_allclose(rot.cpu().numpy(), r_ref.numpy(), atol=2e-6, rtol=0)
 
 
-@pytest.mark.parametrize("n,batch", [(4096, 3), (1000, 3), (4096, 1), (520, 2)])
+@pytest.mark.parametrize("cin,cout,l,batch,with_ab", [(128, 512, 4096, 5, False), (512, 256, 4096, 9, True), (128, 512, 4032, 5, False), (64, 128, 1030, 64, True)])
+def test_gn_chain_layer_statistics_epilogue_on_64x64_tiles(device, cin, cout, l, batch, with_ab):
+    """captra_pointwise_mlp_gn at launch shapes that take the 64x64 wave tiles (>= 2048 of them; the rotation heads at >= 4 clouds): y is
+    the plain layer's y bit for bit (the operand's relu(a x + b) formed by torch where coefficients are given), and the epilogue's
+    per-(row, 64-column tile) partials (transposing DPP reduction on whole tiles, the butterfly on ragged ones) are the sums of that
+    y to summation-order rounding."""
+    from captra_amd import fused
+    g = torch.Generator().manual_seed(cin + cout + l)
+    x = torch.randn(batch, cin, l, generator=g).to(device)
+    lin = fused.pack((torch.randn(cin, cout, generator=g) / cin ** 0.5).to(device), torch.randn(cout, generator=g).to(device))
+    ab = torch.stack([torch.rand(batch, cin, generator=g) + 0.5, torch.randn(batch, cin, generator=g) * 0.3], -1).to(device).contiguous() if with_ab else None
+    y, stats = fused.pointwise_mlp_gn(x, lin, ab, fused.ACT_NONE, True)
+    xin = torch.relu(ab[:, :, :1] * x + ab[:, :, 1:]) if with_ab else x
+    ref = fused.pointwise_mlp(xin.contiguous(), lin, fused.ACT_NONE)
+    t = stats.shape[2]
+    assert t == (l + 127) // 128 * 2
+    if with_ab:       # (the kernel's fmaf(a, x, b) against torch's separately rounded a x + b: operands differ by an ulp)
+        np.testing.assert_allclose(y.cpu().numpy(), ref.cpu().numpy(), atol=2e-5 * float(ref.abs().max()), rtol=0)
+    else:
+        assert torch.equal(y, ref)
+    yd = torch.zeros(batch, cout, t * 64, dtype=torch.float64, device=device)
+    yd[:, :, :l] = y.double()
+    yt = yd.reshape(batch, cout, t, 64)
+    want = torch.stack([yt.sum(-1), (yt * yt).sum(-1)], -1)
+    err = (stats.double() - want).abs()
+    assert float(err[..., 0].max()) <= 1e-5 * float(yt.abs().sum(-1).max()) and float(err[..., 1].max()) <= 1e-5 * float(want[..., 1].max())
+
+
+@pytest.mark.parametrize("n,batch", [(4096, 3), (1000, 3), (4096, 1), (520, 2), (4096, 5)])
 def test_group_norm_chain_fused_vs_separate_and_torch(device, n, batch):
     """Rotation-head MLP (Conv -> GroupNorm(C/2 groups) -> ReLU x3 -> Conv): statistics emitted by the conv epilogue and
     the normalisation applied in the next conv's operand load == the separate GroupNorm kernel == torch, to rounding."""
