@@ -67,7 +67,7 @@ struct PwParams {
     // cloud, read for every position); both tensors are addressed from ONE buffer descriptor based at the lower of the two
     const float *x2;
     int csplit, x2_bcast;
-    int dbg;              // CAPTRA_ABLATIONS builds only (timing ablations of the direct kernel, results wrong): 1 = no y stores, 2 = no statistics, 4 = every workgroup reads the first columns
+    int dbg;              // CAPTRA_ABLATIONS builds only (timing ablations of the direct kernel, results wrong; != 0 takes the general epilogue): 1 = no y stores, 2 = no statistics, 4 = every workgroup reads the first columns, 8 = one statistics store per row tile
 };
 
 template <int CTRL>
