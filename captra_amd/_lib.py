@@ -74,6 +74,7 @@ _SIGNATURES = {
     "captra_fps_gather_ragged": [_INT, _INT, _P, _INT, _P, _P, _P, _P, _P],
     "captra_fps_gather_part": [_INT, _INT, _INT, _INT, _INT, _P, _P, _P, _P, _P, _P],
     "captra_crop_ball": [_INT, _INT, _INT, _INT, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "captra_crop_box": [_INT, _INT, _INT, C.c_double, _P, _P, _P, _P, _P, _P, _P],
     "captra_sa_scale_pre": [_INT] * 8 + [_P] * 9 + [_P, _INT, _INT, _P],
     "captra_sa_scale_pre_pm": [_INT] * 8 + [_P] * 9 + [_P, _INT, _INT, _P],
     "captra_pointwise_mlp_pm": [_INT, _INT, _INT, _LL, _P, _P, _P, _INT, _P, _P],

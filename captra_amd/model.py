@@ -63,6 +63,7 @@ class BaseModel(nn.Module):
             self.per_diff_dict.setdefault(f"{instance}_{track_num}_{frame_i}", {}).update(get_ith_from_batch(per_diff, i))
 
 
+OTF_POSE_ON_DEVICE = os.environ.get("CAPTRA_OTF_POSE_ON_DEVICE", "1") != "0"   # nocs_otf: the crop box from the device-resident pose (A/B: 0 = via the host)
 _OTF_LANE_STREAMS: dict = {}      # device index -> the two lane streams of EvalTrackModel._forward_otf_lanes
 
 
@@ -360,16 +361,21 @@ class EvalTrackModel(BaseModel):
         npcs = self.npcs_feed_dict[i]
         N = input["points"].shape[2]
         b = last_pose["scale"].shape[0]
-        cs = to_host(torch.cat([last_pose["translation"][:, self.root].reshape(b, 3), last_pose["scale"][:, self.root].reshape(b, 1)], dim=1).double())
         gt = input.get("gt_root_host")
         if gt is None:
             gt = {k: to_host(v[:, self.root].double().contiguous()) for k, v in input["gt_part"].items()}
         gt = {k: v[sl] for k, v in gt.items()}
         depth, mask = pre["depth"][sl], pre["mask"][sl]
-        full = full_data_batch_arrays(depth, mask, cs[:, :3], self.radius * cs[:, 3],
-                                      {"rotation": np.asarray(gt["rotation"], np.float64).reshape(b, 3, 3),
-                                       "translation": np.asarray(gt["translation"], np.float64).reshape(b, 3),
-                                       "scale": np.asarray(gt["scale"], np.float64).reshape(b)}, N, stacked=True)
+        gt64 = {"rotation": np.asarray(gt["rotation"], np.float64).reshape(b, 3, 3),
+                "translation": np.asarray(gt["translation"], np.float64).reshape(b, 3),
+                "scale": np.asarray(gt["scale"], np.float64).reshape(b)}
+        trans_d, scale_d = last_pose["translation"][:, self.root].reshape(b, 3), last_pose["scale"][:, self.root].reshape(b)
+        if OTF_POSE_ON_DEVICE and depth.is_cuda and trans_d.dtype == torch.float32 and scale_d.dtype == torch.float32:
+            # the crop's box / centre / radius derived on the device from the pose (captra_crop_box): no round trip for the pose
+            full = full_data_batch_arrays(depth, mask, None, None, gt64, N, stacked=True, pose_dev=(trans_d, scale_d, float(self.radius)))
+        else:
+            cs = to_host(torch.cat([trans_d, scale_d.reshape(b, 1)], dim=1).double())
+            full = full_data_batch_arrays(depth, mask, cs[:, :3], self.radius * cs[:, 3], gt64, N, stacked=True)
         points = (full["points"].float() - npcs["points_mean"][sl].reshape(b, 1, 3)).transpose(1, 2).contiguous()
         return points, full["labels"].contiguous(), full["nocs"].float().transpose(1, 2).contiguous()
 

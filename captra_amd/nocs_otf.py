@@ -228,38 +228,70 @@ def full_data_batch(frames, num_points: int, intrinsics=NOCS_REAL_INTRINSICS, us
                                   np.array([float(f[3]) for f in frames], np.float64), gt, num_points, intrinsics, stacked)
 
 
-def full_data_batch_arrays(depth, mask, centers, radii_in, gt, num_points: int, intrinsics=NOCS_REAL_INTRINSICS, stacked: bool = True):
+_KMAT_DEV: dict = {}
+
+
+def _intrinsics_on_device(intrinsics, dev) -> torch.Tensor:
+    """[K (9 doubles), K^-1 (9 doubles)] on the device, uploaded once per (matrix, device)."""
+    K = np.asarray(intrinsics, np.float64)
+    key = (K.tobytes(), str(dev))
+    if key not in _KMAT_DEV:
+        _KMAT_DEV[key] = torch.from_numpy(np.concatenate([K.reshape(9), _kinv(intrinsics)])).to(dev)
+    return _KMAT_DEV[key]
+
+
+def full_data_batch_arrays(depth, mask, centers, radii_in, gt, num_points: int, intrinsics=NOCS_REAL_INTRINSICS, stacked: bool = True,
+                           pose_dev=None):
     """full_data_batch on already-stacked inputs (the track loop's form: no per-trajectory Python on the frame's critical
-    path — the host work sits between two device round trips): depth (B,H,W), mask (B,H,W) device tensors; centers (B,3),
-    radii_in (B,) float64 host arrays (radius as handed to full_data_from_depth: clamped to 0.05 inside); gt = {'rotation'
-    (B,3,3), 'translation' (B,3), 'scale' (B,)} float64 host arrays."""
+    path): depth (B,H,W), mask (B,H,W) device tensors; centers (B,3), radii_in (B,) float64 host arrays (radius as handed to
+    full_data_from_depth: clamped to 0.05 inside); gt = {'rotation' (B,3,3), 'translation' (B,3), 'scale' (B,)} float64 host arrays.
+    `pose_dev` = (translation (B,3) fp32, scale (B,) fp32, radius_factor) ON THE DEVICE instead of centers / radii_in (pass None
+    for both): the crop's box, centre and radius are then derived there (captra_crop_box: the same float64 operations) and the
+    pose never visits the host -- the stage's ONE round trip is the member counts."""
     from . import _lib as L, fused
     dev = depth.device
     B = depth.shape[0]
     depth = depth.to(torch.int32).contiguous()
     mask = mask.to(torch.uint8).contiguous()
     _, H, W = depth.shape
-    centers = np.ascontiguousarray(np.asarray(centers, np.float64).reshape(B, 3))
-    radii_in = np.asarray(radii_in, np.float64).reshape(B)
-    radii = np.maximum(radii_in, 0.05)
-    boxes = proj_corners_batch(H, W, centers, radii_in, intrinsics).reshape(B, 4).astype(np.int32)
-    kinv = _kinv(intrinsics)
-    # ONE host-to-device copy for everything the crop kernel reads from the host: the doubles (centres, radii, K^-1), then
-    # the int32 boxes (this stretch of host work sits between the pose round trip and the crop launch: the GPU waits for it)
-    ndbl = 4 * B + 9
-    blob = np.empty(8 * ndbl + 16 * B, np.uint8)
-    blob[:8 * ndbl].view(np.float64)[:] = np.concatenate([centers.reshape(-1), radii, kinv])
-    blob[8 * ndbl:].view(np.int32)[:] = boxes.reshape(-1)
-    host = to_device(blob, dev)
-    hp = host.data_ptr()
     pts = torch.empty(B, CROP_CAP, 3, dtype=torch.float64, device=dev)
     obj = torch.empty(B, CROP_CAP, dtype=torch.uint8, device=dev)
     pix = torch.empty(B, CROP_CAP, dtype=torch.int32, device=dev)
     counts = torch.empty(B, 2, dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
-        L.call("captra_crop_ball", B, H, W, CROP_CAP, L.ptr(depth), L.ptr(mask), hp + 8 * ndbl, hp,
-               hp + 8 * 3 * B, hp + 8 * 4 * B, L.ptr(pts), L.ptr(obj), L.ptr(pix), L.ptr(counts))
+    if pose_dev is not None:
+        trans_d, scale_d, factor = pose_dev
+        trans_d = trans_d.reshape(B, 3).float().contiguous()
+        scale_d = scale_d.reshape(B).float().contiguous()
+        kk = _intrinsics_on_device(intrinsics, dev)
+        box_d = torch.empty(B, 4, dtype=torch.int32, device=dev)
+        ctr_d = torch.empty(B, 3, dtype=torch.float64, device=dev)
+        rad_d = torch.empty(B, dtype=torch.float64, device=dev)
+        with torch.cuda.device(dev):
+            L.call("captra_crop_box", B, H, W, float(factor), L.ptr(trans_d), L.ptr(scale_d), kk.data_ptr(), L.ptr(box_d), L.ptr(ctr_d), L.ptr(rad_d))
+            L.call("captra_crop_ball", B, H, W, CROP_CAP, L.ptr(depth), L.ptr(mask), L.ptr(box_d), L.ptr(ctr_d), L.ptr(rad_d),
+                   kk.data_ptr() + 72, L.ptr(pts), L.ptr(obj), L.ptr(pix), L.ptr(counts))
+    else:
+        centers = np.ascontiguousarray(np.asarray(centers, np.float64).reshape(B, 3))
+        radii_in = np.asarray(radii_in, np.float64).reshape(B)
+        radii = np.maximum(radii_in, 0.05)
+        boxes = proj_corners_batch(H, W, centers, radii_in, intrinsics).reshape(B, 4).astype(np.int32)
+        kinv = _kinv(intrinsics)
+        # ONE host-to-device copy for everything the crop kernel reads from the host: the doubles (centres, radii, K^-1), then
+        # the int32 boxes (this stretch of host work sits between the pose round trip and the crop launch: the GPU waits for it)
+        ndbl = 4 * B + 9
+        blob = np.empty(8 * ndbl + 16 * B, np.uint8)
+        blob[:8 * ndbl].view(np.float64)[:] = np.concatenate([centers.reshape(-1), radii, kinv])
+        blob[8 * ndbl:].view(np.int32)[:] = boxes.reshape(-1)
+        host = to_device(blob, dev)
+        hp = host.data_ptr()
+        with torch.cuda.device(dev):
+            L.call("captra_crop_ball", B, H, W, CROP_CAP, L.ptr(depth), L.ptr(mask), hp + 8 * ndbl, hp,
+                   hp + 8 * 3 * B, hp + 8 * 4 * B, L.ptr(pts), L.ptr(obj), L.ptr(pix), L.ptr(counts))
     n_members = to_host(counts[:, 0].contiguous())                                               # the one sync of the stage
+    if pose_dev is not None and any(int(c) < 10 or int(c) > CROP_CAP for c in n_members):
+        # a rare-path instance (radius growth / more members than the table holds) takes the torch path, which wants the centre on the host
+        cs = to_host(torch.cat([ctr_d, (float(factor) * scale_d.double()).reshape(B, 1)], dim=1))
+        centers, radii_in = np.ascontiguousarray(cs[:, :3]), np.ascontiguousarray(cs[:, 3])
 
     def gt_of(b):
         return {"rotation": gt["rotation"][b], "translation": np.asarray(gt["translation"][b]).reshape(3, 1), "scale": gt["scale"][b]}

@@ -324,6 +324,13 @@ int captra_crop_ball(int b, int h, int w, int cap, const int *depth, const unsig
                      const double *center, const double *radius, const double *kinv, double *pts, unsigned char *obj,
                      int *pix, int *counts, captra_stream_t stream);
 
+/* The crop's inputs from the DEVICE-resident pose of the previous frame (reference nocs_data_process.py:136-148 `proj_corners`, model.py:425-452):
+ * trans (B,3), scale (B) fp32 -> center (B,3) = double(trans), radius (B) = max(radius_factor * double(scale), 0.05), box (B,4) = the inclusive,
+ * clamped image box {row_min, col_min, row_max, col_max} of the cube c +- r under the intrinsics kmat (9 doubles, row-major), in float64
+ * with numpy's operation order and int32 truncation.  What captra_crop_ball reads: no host round trip between the pose and the crop. */
+int captra_crop_box(int b, int h, int w, double radius_factor, const float *trans, const float *scale, const double *kmat, int *box,
+                    double *center, double *radius, captra_stream_t stream);
+
 /* Ragged batch of the same operation: the clouds are padded to n_stride points each (xyz (B,n_stride,3)) and cloud i
  * samples m of its FIRST n_per_cloud[i] points (device array of B ints, 1 <= n_per_cloud[i] <= n_stride; NULL = all
  * n_stride).  This is the re-sampling step of the on-the-fly ball crop (reference datasets/data_utils.py:138-157:

@@ -178,6 +178,49 @@ def test_batched_recrop_equals_one_call_per_trajectory(device, use_kernel):
 
 
 @pytest.mark.gpu
+def test_crop_box_on_device_equals_host_projection(device):
+    """captra_crop_box (box, centre, radius of the crop from the device-resident fp32 pose) == nocs_otf.proj_corners_batch and the
+    float64 casts the loop did on the host, bit for bit, on poses around the camera frustum (boxes clamped on every side, radius
+    clamped to 0.05) -- and the re-crop through it equals the re-crop through the host, including an instance on the rare path."""
+    from captra_amd import _lib as L
+    rng = np.random.default_rng(5)
+    B, H, W = 257, 480, 640
+    trans = np.stack([rng.uniform(-0.6, 0.6, B), rng.uniform(-0.5, 0.5, B), rng.uniform(-2.5, -0.4, B)], 1).astype(np.float32)
+    scale = rng.uniform(0.01, 0.6, B).astype(np.float32)
+    factor = 0.6
+    t_d, s_d = torch.from_numpy(trans).to(device), torch.from_numpy(scale).to(device)
+    kk = nocs_otf._intrinsics_on_device(nocs_otf.NOCS_REAL_INTRINSICS, torch.device(device))
+    box = torch.empty(B, 4, dtype=torch.int32, device=device)
+    ctr = torch.empty(B, 3, dtype=torch.float64, device=device)
+    rad = torch.empty(B, dtype=torch.float64, device=device)
+    with torch.cuda.device(device):
+        L.call("captra_crop_box", B, H, W, factor, L.ptr(t_d), L.ptr(s_d), kk.data_ptr(), L.ptr(box), L.ptr(ctr), L.ptr(rad))
+    c64, r_in = trans.astype(np.float64), factor * scale.astype(np.float64)
+    want = nocs_otf.proj_corners_batch(H, W, c64, r_in).reshape(B, 4)
+    np.testing.assert_array_equal(box.cpu().numpy(), want)
+    np.testing.assert_array_equal(ctr.cpu().numpy(), c64)
+    np.testing.assert_array_equal(rad.cpu().numpy(), np.maximum(r_in, 0.05))
+    assert (want[:, 0] == 0).any() and (want[:, 1] == 0).any() and (want[:, 2] == H - 1).any() and (want[:, 3] == W - 1).any()
+    # the re-crop: pose on the device against pose through the host (fp32 poses, as the track loop holds them)
+    n = CASES[0][3]
+    frames = [make_frame(sd) for sd in (CASES[0][1], CASES[1][1], CASES[0][1])]
+    depth = torch.stack([torch.from_numpy(f[0].astype(np.int32)) for f in frames]).to(device)
+    mask = torch.stack([torch.from_numpy(f[1]) for f in frames]).to(device)
+    tr = np.stack([np.asarray(f[2], np.float64).reshape(3) for f in frames]).astype(np.float32)
+    sc = np.array([CASES[0][2], CASES[1][2], 0.004], np.float32)              # (the third: fewer than 10 members -> the torch path)
+    gt = {"rotation": np.stack([np.asarray(f[3]["rotation"], np.float64).reshape(3, 3) for f in frames]),
+          "translation": np.stack([np.asarray(f[3]["translation"], np.float64).reshape(3) for f in frames]),
+          "scale": np.array([float(np.asarray(f[3]["scale"]).reshape(-1)[0]) for f in frames])}
+    np.random.seed(3)
+    via_host = nocs_otf.full_data_batch_arrays(depth, mask, tr.astype(np.float64), 1.0 * sc.astype(np.float64), gt, n)
+    np.random.seed(3)
+    via_dev = nocs_otf.full_data_batch_arrays(depth, mask, None, None, gt, n,
+                                              pose_dev=(torch.from_numpy(tr).to(device), torch.from_numpy(sc).to(device), 1.0))
+    for k in ("points", "labels", "nocs"):
+        assert torch.equal(via_host[k], via_dev[k])
+
+
+@pytest.mark.gpu
 def test_batched_recrop_rare_paths_and_golden(device):
     """A batch mixing a normal crop with one whose ball holds fewer than 10 pixels at first (radius growth: that instance
     takes the torch path) and one thinned by the permutation; each equals its own single call, and the sparse case equals
