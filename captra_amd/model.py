@@ -139,6 +139,7 @@ class EvalTrackModel(BaseModel):
             # the values of the float32 device copy), so that the loop does not fetch it back from the device every frame
             root = frame["meta"]["nocs2camera"][self.root]
             out["gt_root_host"] = {k: np.asarray(torch.as_tensor(root[k]).float().double().cpu().numpy()) for k in ("rotation", "translation", "scale")}
+            out["gt_root_dev"] = {k: torch.from_numpy(v).to(self.device) for k, v in out["gt_root_host"].items()}   # (and on the device: no upload per frame)
         return out
 
     def _convert_npcs_frame(self, frame):
@@ -369,10 +370,12 @@ class EvalTrackModel(BaseModel):
         gt64 = {"rotation": np.asarray(gt["rotation"], np.float64).reshape(b, 3, 3),
                 "translation": np.asarray(gt["translation"], np.float64).reshape(b, 3),
                 "scale": np.asarray(gt["scale"], np.float64).reshape(b)}
+        gtd = input.get("gt_root_dev")
+        gtd = None if gtd is None else {k: v[sl] for k, v in gtd.items()}
         trans_d, scale_d = last_pose["translation"][:, self.root].reshape(b, 3), last_pose["scale"][:, self.root].reshape(b)
         if OTF_POSE_ON_DEVICE and depth.is_cuda and trans_d.dtype == torch.float32 and scale_d.dtype == torch.float32:
             # the crop's box / centre / radius derived on the device from the pose (captra_crop_box): no round trip for the pose
-            full = full_data_batch_arrays(depth, mask, None, None, gt64, N, stacked=True, pose_dev=(trans_d, scale_d, float(self.radius)))
+            full = full_data_batch_arrays(depth, mask, None, None, gt64, N, stacked=True, pose_dev=(trans_d, scale_d, float(self.radius)), gt_dev=gtd)
         else:
             cs = to_host(torch.cat([trans_d, scale_d.reshape(b, 1)], dim=1).double())
             full = full_data_batch_arrays(depth, mask, cs[:, :3], self.radius * cs[:, 3], gt64, N, stacked=True)

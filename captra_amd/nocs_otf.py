@@ -241,13 +241,14 @@ def _intrinsics_on_device(intrinsics, dev) -> torch.Tensor:
 
 
 def full_data_batch_arrays(depth, mask, centers, radii_in, gt, num_points: int, intrinsics=NOCS_REAL_INTRINSICS, stacked: bool = True,
-                           pose_dev=None):
+                           pose_dev=None, gt_dev=None):
     """full_data_batch on already-stacked inputs (the track loop's form: no per-trajectory Python on the frame's critical
     path): depth (B,H,W), mask (B,H,W) device tensors; centers (B,3), radii_in (B,) float64 host arrays (radius as handed to
     full_data_from_depth: clamped to 0.05 inside); gt = {'rotation' (B,3,3), 'translation' (B,3), 'scale' (B,)} float64 host arrays.
     `pose_dev` = (translation (B,3) fp32, scale (B,) fp32, radius_factor) ON THE DEVICE instead of centers / radii_in (pass None
     for both): the crop's box, centre and radius are then derived there (captra_crop_box: the same float64 operations) and the
-    pose never visits the host -- the stage's ONE round trip is the member counts."""
+    pose never visits the host -- the stage's ONE round trip is the member counts.  `gt_dev`: the same three arrays as float64 DEVICE
+    tensors (uploaded once with the trajectory), used instead of three uploads per frame."""
     from . import _lib as L, fused
     dev = depth.device
     B = depth.shape[0]
@@ -333,9 +334,13 @@ def full_data_batch_arrays(depth, mask, centers, radii_in, gt, num_points: int, 
         P = torch.gather(pts_f, 1, sel.unsqueeze(-1).expand(-1, -1, 3))                            # (F, N, 3) float64
         O = torch.gather(obj_f, 1, sel).bool()
         sub = slice(None) if len(fast) == B else np.asarray(fast)
-        rot = to_device(np.ascontiguousarray(np.asarray(gt["rotation"], np.float64).reshape(B, 3, 3)[sub]), dev)
-        trans = to_device(np.ascontiguousarray(np.asarray(gt["translation"], np.float64).reshape(B, 1, 3)[sub]), dev)
-        scale = to_device(np.ascontiguousarray(np.asarray(gt["scale"], np.float64).reshape(B)[sub]), dev)
+        if gt_dev is not None:
+            pick = (lambda t: t) if len(fast) == B else (lambda t: t[fidx])
+            rot, trans, scale = pick(gt_dev["rotation"].reshape(B, 3, 3)), pick(gt_dev["translation"].reshape(B, 1, 3)), pick(gt_dev["scale"].reshape(B))
+        else:
+            rot = to_device(np.ascontiguousarray(np.asarray(gt["rotation"], np.float64).reshape(B, 3, 3)[sub]), dev)
+            trans = to_device(np.ascontiguousarray(np.asarray(gt["translation"], np.float64).reshape(B, 1, 3)[sub]), dev)
+            scale = to_device(np.ascontiguousarray(np.asarray(gt["scale"], np.float64).reshape(B)[sub]), dev)
         nocs = torch.where(O.unsqueeze(-1), torch.bmm((P - trans) / scale.reshape(-1, 1, 1), rot), torch.zeros_like(P))
         labels = 1 - O.long()
         if stacked and len(fast) == B:
