@@ -783,6 +783,11 @@ extern "C" void captra_sa_fused_set_mode(int mode) { g_sa_mode = mode; }
 static CAPTRA_KNOB int g_sa_split = 1;  // a wave per slice for small batches: 0 = never, 1 = heuristic, 2 = always (tests)
 extern "C" void captra_sa_fused_set_split(int v) { g_sa_split = v; }
 int captra_sa_split_knob() { return g_sa_split; }
+// the caller zeroed the whole output tensor itself (one fill for every scale of a level instead of one per scale and cloud): the
+// slice-per-wave form then launches straight away
+static CAPTRA_KNOB int g_sa_prezeroed = 0;
+extern "C" void captra_sa_set_prezeroed(int on) { g_sa_prezeroed = on; }
+int captra_sa_prezeroed() { return g_sa_prezeroed; }
 // the slice-per-wave form's zeroed output: channels [co_off, co_off + c3), centres [m0, m0 + mc) of every cloud
 static void sl_zero_window(float *out, int b, int m, int out_ctotal, int co_off, int c3, int m0, int mc, hipStream_t stream) {
     if (m0 == 0 && mc == m) {
@@ -872,7 +877,7 @@ extern "C" int captra_sa_scale_fused(int b, int n, int m, int k, int cfeat, int 
         q.b = b;                                                                                                       \
         q.dyn = (!q.split && k > 32 && wgs > 1) ? captra_sa_dyn_slot((hipStream_t)stream) : nullptr;                   \
         const unsigned grid_l = (unsigned)(wgs < resident ? wgs : resident);                                           \
-        if (q.split) sl_zero_window(out, b, m, out_ctotal, co_off, c3, wm0, wmc, (hipStream_t)stream);                  \
+        if (q.split && !g_sa_prezeroed) sl_zero_window(out, b, m, out_ctotal, co_off, c3, wm0, wmc, (hipStream_t)stream);                  \
         CAPTRA_LAUNCH("sa_scale_fused", kern, dim3(grid_l), dim3(SL_WAVES * 64), lds_bytes, (hipStream_t)stream, q);  \
         return captra_last_error();                                                                                    \
     }

@@ -370,6 +370,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
 extern unsigned long long *captra_sa_prof_ptr();   // sa_fused.hip: the debug counters set by captra_sa_fused_set_prof
 extern int captra_sa_split_knob();                  // sa_fused.hip: captra_sa_fused_set_split
+extern int captra_sa_prezeroed();                   // sa_fused.hip: captra_sa_set_prezeroed
 extern int *captra_sa_dyn_slot(hipStream_t stream); // sa_fused.hip: captra_sa_set_dynamic
 
 // SA scale with a pre-transformed, POINT-major first layer (see include/captra_hip.h): v1pm (B,N,c1).
@@ -406,7 +407,7 @@ extern "C" int captra_sa_scale_pre_pm(int b, int n, int m, int k, int cfeat, int
     const long long wgs = ((q.split ? centres * (k / 32) : centres) + 3) / 4;
     const unsigned grid = (unsigned)(wgs < cus ? wgs : cus);
     q.dyn = (!q.split && k > 32 && wgs > 1) ? captra_sa_dyn_slot((hipStream_t)stream) : nullptr;
-    if (q.split) {
+    if (q.split && !captra_sa_prezeroed()) {
         // (zeroed by a kernel per cloud where the rows allow it, not by a memset node: common.h captra_zero_async)
         if (b <= 8 && ((size_t)c3 * m * 4) % 16 == 0 && (reinterpret_cast<uintptr_t>(out + (size_t)co_off * m) & 15) == 0 && ((size_t)out_ctotal * m * 4) % 16 == 0) {
             for (int bb = 0; bb < b; ++bb) (void)captra_zero_async(out + ((size_t)bb * out_ctotal + co_off) * m, (size_t)c3 * m * 4, (hipStream_t)stream);

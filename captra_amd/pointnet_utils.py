@@ -225,6 +225,19 @@ class PointNetSetAbstractionMsg(_FoldCache, nn.Module):
                         off += layers[-1].cout
             return out
         off = 0
+        prezero = B <= 8 and fused.mlp_dtype() == "fp32" and len(folded) > 1
+        if prezero:
+            # few clouds: the fp32 scales run a wave per neighbour slice and combine a centre's slices by an atomic max on a zeroed
+            # output -- ONE fill of the level's tensor here instead of a fill per scale and cloud in the launchers
+            out.zero_()
+            fused.L.lib().captra_sa_set_prezeroed(1)
+        try:
+            return self._forward_scales(folded, idx_list, feat, xyz_cn, new_xyz_n3, out, off, B)
+        finally:
+            if prezero:
+                fused.L.lib().captra_sa_set_prezeroed(0)
+
+    def _forward_scales(self, folded, idx_list, feat, xyz_cn, new_xyz_n3, out, off, B):
         for layers, idx in zip(folded, idx_list):
             if fused.sa_scale_bf16_supported(0 if feat is None else feat.shape[1], layers, idx.shape[2]):
                 fused.sa_scale_bf16(feat, xyz_cn, new_xyz_n3, idx, layers, out, off)
