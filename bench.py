@@ -485,7 +485,7 @@ def config_leg(name: str, extra: list, timeout_s: int = 120):
     return out
 
 
-def pmc_traffic(kernel_prefixes, suffix: str = ""):
+def pmc_traffic(kernel_prefixes, suffix: str = "", stem: str = "bench"):
     """HBM bytes per launch of the MFMA family from the newest committed PMC summary (profiles/*_bench_pmc.json,
     written by tools/profile_round.sh from separate rocprofv3 --pmc passes): 2 x FETCH_SIZE (gfx950 correction,
     MI355X_MICROARCH.md) + WRITE_SIZE, KiB -> bytes, averaged over the family's launches.  The file carries the fingerprint
@@ -494,9 +494,10 @@ def pmc_traffic(kernel_prefixes, suffix: str = ""):
     import glob
     # suffix: the counter file of another configuration of the same command (tools/profile_round.sh <tag> _bf16 --mlp-dtype bf16
     # writes profiles/<tag>_bench_bf16_pmc.json)
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"*_bench{suffix}_pmc.json")))
+    # stem: "backbone16k" for tools/profile_backbone.sh's file (profiles/<tag>_backbone16k_pmc.json)
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"*_{stem}{suffix}_pmc.json")))
     if not files:
-        return None, None, f"no profiles/*_bench{suffix}_pmc.json"
+        return None, None, f"no profiles/*_{stem}{suffix}_pmc.json"
     with open(files[-1]) as fh:
         data = json.load(fh)
     name = os.path.basename(files[-1])

@@ -178,6 +178,13 @@ def main():
                                     "frac": round(flops / (mlp_us * 1e-6) / 1e12 / PEAK_MFMA_F32, 3),
                                     "families": mlp, "us_per_step": round(mlp_us, 1),
                                     "share_of_kernel_time": round(mlp_us / sum(v["us_per_step"] for v in fams.values()), 3)}
+                # HBM bytes per launch of the family from the committed counter passes of THIS workload (tools/profile_backbone.sh ->
+                # profiles/<tag>_backbone16k_pmc.json), used only when taken on this tree's kernel sources (bench.pmc_traffic)
+                import bench as _bench
+                traffic, src, why = _bench.pmc_traffic(["sa_wave_kernel", "sa_wave_lds_kernel", "sa_wave_pipe_kernel", "sa_fused_kernel", "mlp_chain3_kernel",
+                                                        "pw_direct_kernel", "pw_direct_max_kernel", "pw_mlp_kernel"], stem="backbone16k")
+                line["roofline"]["traffic"] = None if traffic is None else round(traffic)
+                line["roofline"]["traffic_source"] = f"profiles/{src}" if traffic is not None else f"null: {why}"
             # geometry ops of the fused path, §8(d) byte definitions at this shape (per step, all clouds)
             ks1, ks2 = (32, 64, 128), (64, 128)
             bq = B * (sum(12 * N + 12 * s1 + 4 * s1 * k for k in ks1) + sum(12 * s1 + 12 * s2 + 4 * s2 * k for k in ks2))
