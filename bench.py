@@ -514,6 +514,64 @@ def pmc_traffic(kernel_prefixes, suffix: str = "", stem: str = "bench"):
     return (tot / n if n else None), name, None
 
 
+def live_pmc_traffic(kernel_prefixes, extra_args, timeout_s: int = 150):
+    """HBM bytes per launch of the MFMA family MEASURED IN THIS RUN: two rocprofv3 counter passes (FETCH_SIZE, then WRITE_SIZE; counters
+    only, with --kernel-trace -- the combination MI355X_MICROARCH.md prescribes) over a child of this script running 2 eager steps
+    of the same workload, parsed like tools/pmc_summary.py, corrected like pmc_traffic (2 x FETCH_SIZE on gfx950).
+    -> (bytes or None, note).  Any failure (no rocprofv3, a pass that times out or exits non-zero, nothing parsed) returns None and
+    the caller keeps the committed profile's figure."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    here = os.path.dirname(os.path.abspath(__file__))
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, "rocprofv3 not found"
+    sys.path.insert(0, os.path.join(here, "tools"))
+    try:
+        from pmc_summary import short
+    finally:
+        sys.path.pop(0)
+    child = [sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--repeats", "1", "--min-timed-s", "0", "--min-warmup", "1",
+             "--no-pose-match", "--no-cpu-baseline", "--no-kernel-timing", "--no-otf", "--no-b1", "--no-legs", "--no-graph", "--no-overlap",
+             "--no-live-traffic"] + list(extra_args)
+    table = {}
+    try:
+        with tempfile.TemporaryDirectory(dir="/tmp") as td:
+            env = dict(os.environ, TMPDIR="/tmp")
+            for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+                out = os.path.join(td, counter)
+                res = subprocess.run([exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "p", "--"] + child,
+                                     cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+                if res.returncode != 0:
+                    return None, f"rocprofv3 --pmc {counter} exited {res.returncode}"
+                per = {}
+                for f in glob.glob(out + "/**/*counter_collection.csv", recursive=True):
+                    with open(f) as fh:
+                        for row in csv.DictReader(fh):
+                            if row["Counter_Name"] != counter:
+                                continue
+                            cell = per.setdefault(row["Dispatch_Id"], [short(row["Kernel_Name"]), 0.0])
+                            cell[1] += float(row["Counter_Value"])
+                for name, v in per.values():
+                    c = table.setdefault(name, {}).setdefault(counter, [0.0, 0])
+                    c[0] += v
+                    c[1] += 1
+    except Exception as e:          # (a timeout, a parse error: the committed figure stays)
+        return None, f"{type(e).__name__}: {e}"
+    tot, n = 0.0, 0
+    for kname, c in table.items():
+        if kname.startswith(tuple(kernel_prefixes)) and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            k = min(c["FETCH_SIZE"][1], c["WRITE_SIZE"][1])
+            tot += k * 1024.0 * (2.0 * c["FETCH_SIZE"][0] / c["FETCH_SIZE"][1] + c["WRITE_SIZE"][0] / c["WRITE_SIZE"][1])
+            n += k
+    if not n:
+        return None, "no dispatch of the family in the counter passes"
+    return tot / n, f"{n} dispatches"
+
+
 def pose_match(cfg, sd, frame_cpu, prev_pose, new_pose, which=(0, 1)):
     """Accuracy of the timed trajectories themselves (outside the timed region): the LAST step of the run, for trajectories
     `which` of this rank, redone by the CPU oracle (oracle/model.py track_step: C geometry + torch-CPU shared MLPs) from the
@@ -597,6 +655,8 @@ def main():
     ap.add_argument("--otf-only", action="store_true", help=argparse.SUPPRESS)          # the `otf` leg's own process: prints that object only
     ap.add_argument("--b1-only", action="store_true", help=argparse.SUPPRESS)           # the `b1` leg's own process
     ap.add_argument("--no-b1", action="store_true", help="skip the `b1` leg (single-trajectory latency, pre-cropped and nocs_otf)")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not measure roofline.traffic in this run (two rocprofv3 counter passes over a 2-step child, ~40 s): keep the committed profile's figure")
     ap.add_argument("--no-legs", action="store_true",
                     help="skip the `bf16` (BASELINE.json configs[2]'s arithmetic), `drawers` (configs[3]) and `backbone16k` (configs[4]) legs")
     ap.add_argument("--leg", action="store_true", help=argparse.SUPPRESS)               # a configuration leg's own process: short timed region, the line only
@@ -869,14 +929,17 @@ def main():
                                "share_of_kernel_time": round(mlp_ms / max(total_ms, 1e-9), 3), "dominant_family": dominant}
             # the counter file of THIS configuration (tools/profile_round.sh <tag> <suffix> ...): bf16 / drawers have their own
             sfx = ("_bf16" if args.mlp_dtype != "fp32" else "") + ("_drawers" if args.category == "drawers" else "")
-            traffic, src, why = pmc_traffic(["sa_bf16_kernel", "sa2_bf16_kernel", "tb_layer_kernel", "tb_head12_kernel", "tb_head12p_kernel", "neck_chain_kernel", "chain_bf16_kernel", "pw_bf16pm_kernel", "pw_bf16pm_affs_kernel", "pw_bf16_kernel"], sfx) if args.mlp_dtype != "fp32" else pmc_traffic(
-                ["sa_wave_kernel", "sa_wave_lds_kernel", "sa_wave_pipe_kernel", "sa_fused_kernel", "mlp_chain3_kernel", "coord_tail_kernel", "pw_direct_kernel", "pw_direct_max_kernel", "pw_mlp_kernel"], sfx)
+            mlp_prefixes = (["sa_bf16_kernel", "sa2_bf16_kernel", "tb_layer_kernel", "tb_head12_kernel", "tb_head12p_kernel", "neck_chain_kernel", "chain_bf16_kernel", "pw_bf16pm_kernel", "pw_bf16pm_affs_kernel", "pw_bf16_kernel"]
+                            if args.mlp_dtype != "fp32" else
+                            ["sa_wave_kernel", "sa_wave_lds_kernel", "sa_wave_pipe_kernel", "sa_fused_kernel", "mlp_chain3_kernel", "coord_tail_kernel", "pw_direct_kernel", "pw_direct_max_kernel", "pw_mlp_kernel"])
+            traffic, src, why = pmc_traffic(mlp_prefixes, sfx)
             if traffic is not None:
                 out["roofline"]["traffic"] = round(traffic)
                 out["roofline"]["traffic_source"] = f"profiles/{src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes per launch, kernel sources {csrc_fingerprint()} = this tree)"
             else:
                 out["roofline"]["traffic_source"] = f"null: {why}"
                 print(f"bench.py: roofline.traffic dropped -- {why}", file=sys.stderr)
+            out["_traffic_family"] = (mlp_prefixes, sfx)
         if "ball_query" in fams:
             # the scan is N x M distance tests per cloud (VALU work: 8 packed-fp32 instructions per 128 tests + the ordered
             # compaction), not a byte stream: reported as pair tests per second against the packed-fp32 VALU rate, with the
@@ -927,6 +990,20 @@ def main():
         out["legs"] = {"bf16": config_leg("bf16", ["--mlp-dtype", "bf16", "--batch", str(B)]),
                        "drawers": config_leg("drawers", ["--category", "drawers", "--batch", str(B)]),
                        "backbone16k": config_leg("backbone16k", [])}
+    fam = out.pop("_traffic_family", None)
+    if fam is not None and world == 1 and not args.leg and not args.no_live_traffic:
+        # roofline.traffic measured in THIS run (two counter passes over a 2-step child of the same workload); the committed
+        # profile's figure stays beside it, and stays the value if the passes cannot run here
+        extra = ["--batch", str(B)] + (["--mlp-dtype", args.mlp_dtype] if args.mlp_dtype != "fp32" else []) + (["--category", args.category] if args.category != "bottle" else [])
+        t0 = time.perf_counter()
+        live, note = live_pmc_traffic(fam[0], extra)
+        if live is not None:
+            out["roofline"]["traffic_committed_profile"] = out["roofline"].get("traffic")
+            out["roofline"]["traffic"] = round(live)
+            out["roofline"]["traffic_source"] = (f"measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over a 2-step eager child of this workload, "
+                                                 f"per launch of the family ({note}; {time.perf_counter() - t0:.0f} s)")
+        else:
+            out["roofline"]["traffic_live"] = f"not measured here ({note}): the committed profile's figure"
     if world == 1 and not args.no_cpu_baseline and args.category == "bottle":
         out["cpu_baseline"] = cpu_baseline(cfg, sd, args.cpu_budget)
         out["cpu_baseline"]["reference_cpu_path_in_authoring_container"] = {

@@ -84,6 +84,10 @@ def test_bench_line_contract_single_gpu(device):
     r = out["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0.3 < r["frac"] < 1.0
     assert "traffic" in r and (r["traffic"] is None or r["traffic"] > 0)
+    # measured in the run itself where rocprofv3 is there (two counter passes over a child), else the committed profile's figure
+    assert r["traffic_source"].startswith("measured in this run") or "traffic_live" in r
+    if "traffic_committed_profile" in r and r["traffic_committed_profile"]:
+        assert 0.7 < r["traffic"] / r["traffic_committed_profile"] < 1.4
     c = out["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == out["unit"] and c["sample"]
     assert out["pose_match"]["within_1e-4"] and out["pose_match"]["agree_5deg5cm"] == 1.0
