@@ -467,15 +467,14 @@ def config_leg(name: str, extra: list, timeout_s: int = 120):
     if res.returncode != 0 or not lines:
         return {"error": (res.stderr or res.stdout)[-500:], "command": " ".join(cmd[1:])}
     d = json.loads(lines[-1])
-    keep = ("metric", "value", "unit", "ms_per_step", "dtype", "steps", "roofline", "kernel_ms_per_step", "timed_blocks", "config", "one_graph", "l1_stream")
+    keep = ("metric", "value", "unit", "ms_per_step", "dtype", "steps", "roofline", "kernel_ms_per_step", "timed_blocks", "one_graph", "l1_stream")
     out = {k: d[k] for k in keep if k in d}
     # compact (the main line has to fit the driver's 8 KB tail): what the leg ran is its command; the numbers stay
-    if isinstance(out.get("config"), dict):
-        out["config"] = {"workload": (out["config"].get("workload") or "")[:60]}
+    out.pop("config", None)
     if isinstance(out.get("timed_blocks"), dict):
         out["timed_blocks"] = {k: out["timed_blocks"][k] for k in ("n", "ms_per_step_min", "ms_per_step_max") if k in out["timed_blocks"]}
     if isinstance(out.get("roofline"), dict):
-        out["roofline"] = {k: out["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us", "flops_per_launch", "share_of_kernel_time") if k in out["roofline"]}
+        out["roofline"] = {k: out["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_measured", "avg_launch_us", "flops_per_launch", "share_of_kernel_time") if k in out["roofline"]}
     if isinstance(out.get("kernel_ms_per_step"), dict):
         top = sorted(((k, v) for k, v in out["kernel_ms_per_step"].items() if not k.startswith("_")), key=lambda kv: -kv[1])[:5]
         out["kernel_ms_per_step"] = dict(top, _sum=out["kernel_ms_per_step"].get("_sum_captra_kernels"))
@@ -991,7 +990,7 @@ def main():
                        "drawers": config_leg("drawers", ["--category", "drawers", "--batch", str(B)]),
                        "backbone16k": config_leg("backbone16k", [])}
     fam = out.pop("_traffic_family", None)
-    if fam is not None and world == 1 and not args.leg and not args.no_live_traffic:
+    if fam is not None and world == 1 and not args.no_live_traffic:
         # roofline.traffic measured in THIS run (two counter passes over a 2-step child of the same workload); the committed
         # profile's figure stays beside it, and stays the value if the passes cannot run here
         extra = ["--batch", str(B)] + (["--mlp-dtype", args.mlp_dtype] if args.mlp_dtype != "fp32" else []) + (["--category", args.category] if args.category != "bottle" else [])
@@ -1000,6 +999,8 @@ def main():
         if live is not None:
             out["roofline"]["traffic_committed_profile"] = out["roofline"].get("traffic")
             out["roofline"]["traffic"] = round(live)
+            if args.leg:
+                out["roofline"]["traffic_measured"] = "in this run"     # (a leg's record keeps this flag instead of the source text)
             out["roofline"]["traffic_source"] = (f"measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over a 2-step eager child of this workload, "
                                                  f"per launch of the family ({note}; {time.perf_counter() - t0:.0f} s)")
         else:
