@@ -103,6 +103,13 @@ def test_bench_line_contract_single_gpu(device):
     assert len(line[0]) < 8000, f"the bench line must fit the driver's 8 KB tail: {len(line[0])} bytes"
 
 
+def test_build_then_smoke_in_one_process(device):
+    """`__graft_entry__.build()` followed by `smoke()` in the SAME process (a driver may do that on the GPU box): build() must not load
+    libcaptra_hip.so before torch -- that leaves the process with two HIP runtimes and every launch fails with hipErrorNoDevice."""
+    res = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build(); g.smoke()"], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0 and "smoke ok" in res.stdout, res.stdout[-1500:] + res.stderr[-3000:]
+
+
 def test_rccl_communicator_world1_graph_lanes_and_exchange(device):
     """What a 1-GPU box can exercise of the RCCL path, in a process of its own (tools/check_dist_graph.py):
     init_process_group("nccl", world_size=1, device_id=...), the step captured AFTER the communicator is up, five replays and
