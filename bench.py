@@ -528,6 +528,8 @@ def live_pmc_traffic(kernel_prefixes, extra_args, timeout_s: int = 150):
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if exe is None:
         return None, "rocprofv3 not found"
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        return None, "this process is itself under a profiler"
     sys.path.insert(0, os.path.join(here, "tools"))
     try:
         from pmc_summary import short
