@@ -179,6 +179,8 @@ def lib():
                 getattr(l, fn)(C.c_int(int(os.environ[env])))
         if "CAPTRA_L1_FINE" in os.environ and hasattr(l, "captra_sa1_stream_set_fine"):
             l.captra_sa1_stream_set_fine(int(os.environ["CAPTRA_L1_FINE"]))
+        if "CAPTRA_L1_WHOLE" in os.environ and hasattr(l, "captra_sa1_stream_set_whole"):
+            l.captra_sa1_stream_set_whole(int(os.environ["CAPTRA_L1_WHOLE"]))
         if "CAPTRA_L1_GRID" in os.environ and hasattr(l, "captra_sa1_stream_set_grid"):
             l.captra_sa1_stream_set_grid(int(os.environ["CAPTRA_L1_GRID"]), 1)
     return _lib
