@@ -156,6 +156,9 @@ def lib():
             l.captra_sa1_stream_set_fine.restype = None
             l.captra_sa1_stream_set_whole.argtypes = [_INT]
             l.captra_sa1_stream_set_whole.restype = None
+        if hasattr(l, "captra_pw_set_splitk"):
+            l.captra_pw_set_splitk.argtypes = [_INT]
+            l.captra_pw_set_splitk.restype = None
         if hasattr(l, "captra_sa_set_prezeroed"):
             l.captra_sa_set_prezeroed.argtypes = [_INT]
             l.captra_sa_set_prezeroed.restype = None

@@ -603,6 +603,96 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void p
     }
 }
 
+// SPLIT-K form of the direct kernel for launches with FEW positions (one or two trajectories: the 128- / 512-point levels are 4-16
+// position tiles per cloud, and a 32x32 wave tile is ONE dependent MFMA chain of cin / 2 steps -- 768 of them, 23 us of matrix
+// pipe, for FP3's first layer -- on a chip that is otherwise idle).  The four waves of a workgroup own the SAME 32 x 32 output tile
+// and a quarter of the k-steps each (whole quads of the fragment image); partial tiles meet in LDS and are added in wave order,
+// ((p0 + p1) + p2) + p3 with the bias in p0: a fixed order, but not the single k-ascending chain -- results differ from the
+// bit-exact form in the last bits (tested at 1e-5 relative against it), so the launchers take this form only where the caller
+// asked for it (captra_pw_set_splitk: EvalTrackModel at <= 2 trajectories; north_star's tolerance is 1e-4 on the poses).
+template <bool SRC2>
+__global__ __launch_bounds__(256) void pw_splitk_kernel(PwParams p) {
+    __shared__ float red[4][16][64];
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.z, co0 = blockIdx.y * 32;
+    const long long pos0 = (long long)blockIdx.x * 32;
+    const int kp = (p.cin + 31) / 32 * 32;
+    const int kq = ((p.cin + 1) / 2 + 3) / 4;
+    const int ntile = (p.cout + 31) / 32;
+    const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(p.wt + (size_t)kp * p.ldw), 0, ntile * kq * 1024, 0x00020000);
+    const float *xb = p.x + (size_t)b * (SRC2 ? p.csplit : p.cin) * p.L;
+    const float *x2b = SRC2 ? p.x2 + (size_t)b * (p.cin - p.csplit) * (p.x2_bcast ? 1 : p.L) : nullptr;
+    const float *xbase = SRC2 && x2b < xb ? x2b : xb;
+    const int off1 = SRC2 ? (int)((const char *)xb - (const char *)xbase) : 0, off2 = SRC2 ? (int)((const char *)x2b - (const char *)xbase) : 0;
+    const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc((void *)xbase, 0, SRC2 ? 0x7ffffff0 : (int)((long long)p.cin * p.L * 4), 0x00020000);
+    long long col = pos0 + (lane & 31);
+    const bool col_ok = col < p.L;
+    if (!col_ok) col = p.L - 1;                                   // clamped column: computed, never stored
+    const int col4 = (int)(col * 4), rowb = (int)(p.L * 4);
+    auto xoff = [&](int ks) {                                     // byte offset of operand row 2 ks + h, this lane's column
+        const int r = 2 * ks + h;
+        if (!SRC2) return r * rowb + col4;                        // rows >= cin lie beyond the descriptor: read as 0
+        if (r >= p.cin) return 0x7ffffffc;
+        return r < p.csplit ? off1 + r * rowb + col4 : off2 + (r - p.csplit) * (p.x2_bcast ? 4 : rowb) + (p.x2_bcast ? 0 : col4);
+    };
+    const int q0 = (int)((long long)wave * kq / 4), q1 = (int)((long long)(wave + 1) * kq / 4);
+    const int woff = blockIdx.y * kq * 1024 + lane * 16;
+    f32x16 acc;
+    {
+        const float *bp = p.bias + co0 + 4 * h;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = wave == 0 ? bp[(r & 3) + 8 * (r >> 2)] : 0.f;
+    }
+    float4 a[2];
+    float bv[2][4];
+#define SK_LOAD(s, q)                                                                                                    \
+    a[s] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wsrc, woff, (q) * 1024, 0));                 \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) bv[s][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xsrc, xoff(4 * (q) + j), 0, 0));
+#define SK_MFMA(s)                                                                                                       \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s].x, bv[s][0], acc, 0, 0, 0);                                          \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s].y, bv[s][1], acc, 0, 0, 0);                                          \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s].z, bv[s][2], acc, 0, 0, 0);                                          \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s].w, bv[s][3], acc, 0, 0, 0);
+    if (q0 < q1) {
+        SK_LOAD(0, q0)
+        int q = q0;
+        for (; q + 1 < q1; q += 2) {
+            SK_LOAD(1, q + 1)
+            SK_MFMA(0)
+            SK_LOAD(0, (q + 2 < q1 ? q + 2 : q1 - 1))
+            SK_MFMA(1)
+        }
+        if (q < q1) { SK_MFMA(0) }
+    }
+#undef SK_LOAD
+#undef SK_MFMA
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
+    __syncthreads();
+    // wave w finishes accumulator registers 4 w .. 4 w + 3 = rows co0 + 8 w + 4 h + {0, 1, 2, 3} of this lane's column
+    float v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = 4 * wave + i;
+        v[i] = apply_act(((red[0][r][lane] + red[1][r][lane]) + red[2][r][lane]) + red[3][r][lane], p.act);
+    }
+    const int row0 = co0 + 8 * wave + 4 * h;
+    if (!col_ok) return;
+    if (p.y_pm) {
+        float *yp = p.y + ((size_t)b * p.L + col) * p.cout + row0;
+        if (row0 + 3 < p.cout) *reinterpret_cast<float4 *>(yp) = make_float4(v[0], v[1], v[2], v[3]);
+        else
+            for (int i = 0; i < 4; ++i)
+                if (row0 + i < p.cout) yp[i] = v[i];
+        return;
+    }
+    float *yp = p.y + ((size_t)b * p.cout + row0) * p.L + col;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (row0 + i < p.cout) yp[(size_t)i * p.L] = v[i];
+}
+
 // Dense layer + ReLU + max over groups of K consecutive positions (K in {32, 64, 128}; SA3's last layer over its 128 points,
 // reference pointnet_utils.py:336-343), direct-operand form: a workgroup = 4 waves x 32 positions x one 32-row output
 // tile, both operands prefetched 16 k-steps ahead (one accumulator chain per wave, so the sets are deep), ReLU and the
@@ -746,6 +836,20 @@ static CAPTRA_KNOB int g_pw_direct = 1;  // experiment knob: 0 = LDS-staged kern
 static CAPTRA_KNOB int g_pw_occ = 0;       // experiment knob: 0 / 4 = as built, 3 / 2 = fewer workgroups per CU
 extern "C" void captra_pw_set_occupancy(int occ) { g_pw_occ = occ; }
 static inline unsigned pw_occupancy_pad() { return g_pw_occ == 2 ? 60000u : (g_pw_occ == 3 ? 45000u : 0u); }
+// split-K form for launches of at most this many positions (b * l) and at least 128 input channels; 0 = never (default: every
+// layer is the k-ascending chain).  Set by EvalTrackModel for steps of one or two trajectories.
+static CAPTRA_KNOB int g_pw_splitk = 0;
+extern "C" void captra_pw_set_splitk(int max_positions) { g_pw_splitk = max_positions < 0 ? 0 : max_positions; }
+static inline bool pw_use_splitk(int b, const PwParams &p) {
+    return g_pw_splitk > 0 && (long long)b * p.L <= g_pw_splitk && p.cin >= 128 && (p.y_pm == 0 || p.cout % 4 == 0) &&
+           (long long)p.cin * p.L * 4 < (1ll << 31);
+}
+template <bool SRC2>
+static int launch_pw_splitk(int b, const PwParams &p, hipStream_t s) {
+    dim3 grid((unsigned)((p.L + 31) / 32), (p.cout + 31) / 32, b);
+    CAPTRA_LAUNCH("pointwise_mlp", (pw_splitk_kernel<SRC2>), grid, dim3(256), 0, s, p);
+    return captra_last_error();
+}
 static CAPTRA_KNOB int g_pw_dbg = 0;     // CAPTRA_ABLATIONS builds: PwParams::dbg of captra_pointwise_mlp_gn's launches
 extern "C" void captra_pw_set_dbg(int v) { g_pw_dbg = CAPTRA_ABLATIONS ? v : 0; }
 static CAPTRA_KNOB int g_pw_pair = 1;    // experiment knob: 0 = never the paired-column variant
@@ -837,6 +941,7 @@ extern "C" int captra_pointwise_mlp(int b, int cin, int cout, long long l, const
     PwParams p = {};
     p.cin = cin; p.cout = cout; p.ldw = (cout + 127) / 128 * 128; p.L = l; p.x = x; p.wt = wt_packed; p.bias = bias_packed;
     p.y = y; p.act = act;
+    if (pw_use_splitk(b, p)) return launch_pw_splitk<false>(b, p, (hipStream_t)stream);
     if (g_pw_direct) {
         const int err = launch_pw_direct(b, p, (hipStream_t)stream);
         if (err != -3) return err;
@@ -863,6 +968,7 @@ extern "C" int captra_pointwise_mlp2(int b, int cin, int csplit, int cout, long 
     PwParams p = {};
     p.cin = cin; p.cout = cout; p.ldw = (cout + 127) / 128 * 128; p.L = l; p.x = x; p.wt = wt_packed; p.bias = bias_packed;
     p.y = y; p.act = act; p.x2 = x2; p.csplit = csplit; p.x2_bcast = x2_bcast;
+    if (pw_use_splitk(b, p)) return launch_pw_splitk<true>(b, p, (hipStream_t)stream);
     if (waves22 < 2048) {
         dim3 grid((unsigned)((l + 63) / 64), (cout + 63) / 64, b);
         CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<1, 1, 2, 2, false, false, false, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
@@ -883,6 +989,7 @@ extern "C" int captra_pointwise_mlp_pm(int b, int cin, int cout, long long l, co
     PwParams p = {};
     p.cin = cin; p.cout = cout; p.ldw = (cout + 127) / 128 * 128; p.L = l; p.x = x; p.wt = wt_packed; p.bias = bias_packed;
     p.y = y; p.act = act; p.y_pm = 1;
+    if (pw_use_splitk(b, p)) return launch_pw_splitk<false>(b, p, (hipStream_t)stream);
     const int err = launch_pw_direct(b, p, (hipStream_t)stream);
     return err == -3 ? -2 : err;
 }

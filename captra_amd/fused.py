@@ -59,6 +59,24 @@ def canonicalize(pts, mean, rot, trans, scale, num_parts: int = 1, want_cn=True,
     return out_cn, out_n3
 
 
+SPLIT_K_MAX_TRAJECTORIES = int(os.environ.get("CAPTRA_SPLIT_K_TRAJ", "2"))   # 0 = every dense layer the k-ascending chain at every batch
+SPLIT_K_POSITIONS = 1024                                                        # launches of at most this many positions (b * l) split k
+
+
+@contextlib.contextmanager
+def split_k(on: bool):
+    """Dense layers launched inside with at most SPLIT_K_POSITIONS positions split k over a workgroup's four waves
+    (captra_pw_set_splitk: a fixed summation order, 1e-5 relative from the bit-exact chain).  The track step of one or two
+    trajectories runs under it -- its 128- / 512-point levels are single dependent MFMA chains on an idle chip otherwise."""
+    if on:
+        L.lib().captra_pw_set_splitk(C.c_int(SPLIT_K_POSITIONS))
+    try:
+        yield
+    finally:
+        if on:
+            L.lib().captra_pw_set_splitk(C.c_int(0))
+
+
 @contextlib.contextmanager
 def centre_window(m0: int, mc: int):
     """The set-abstraction launches inside process centres [m0, m0 + mc) of every cloud only (captra_set_centre_window): the

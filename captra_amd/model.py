@@ -174,6 +174,13 @@ class EvalTrackModel(BaseModel):
             return self._track_step(input, npcs_input, last_pose)
 
     def _track_step(self, input, npcs_input, last_pose):
+        from . import fused
+        few = (not self.training and input["points"].is_cuda and fused.mlp_dtype() == "fp32"
+               and 0 < len(input["points"]) <= fused.SPLIT_K_MAX_TRAJECTORIES)
+        with fused.split_k(few):
+            return self._track_step_body(input, npcs_input, last_pose)
+
+    def _track_step_body(self, input, npcs_input, last_pose):
         self._step_begin(input, npcs_input, last_pose)
         join = self._fork_rotation_net(input, npcs_input, last_pose) if self._overlap_nets(input) else None
         if join is None and "_geom" not in npcs_input and self._l1_stream_on(npcs_input):

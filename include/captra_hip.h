@@ -567,6 +567,8 @@ void captra_sa_fused_set_wn(int wn);        /* generic LDS kernel: sub-tile widt
 void captra_sa_fused_set_prof(unsigned long long *dev_counters); /* sa_wave_kernel: 10 device counters of phase timers, or NULL */
 void captra_pw_set_direct(int on);          /* dense layers: 1 = direct-operand kernel (default), 0 = LDS-staged kernel */
 void captra_ball_query_set_prune(int on);   /* ball query: 1 = small radii of 1024..4096-point clouds from a cell grid (exact; measured slower, off by default), 0 = index-order scan */
+void captra_pw_set_splitk(int max_positions); /* dense layers (captra_pointwise_mlp / _mlp2 / _pm): launches of <= max_positions (b * l) and >= 128 input channels split k over the four waves of a workgroup
+                                              * (partial tiles added in wave order: a fixed order, 1e-5 relative from the k-ascending chain); 0 = never (default) */
 void captra_sa_set_prezeroed(int on);      /* SA scales, slice-per-wave form (few clouds): 1 = the caller zeroed the whole output tensor (one fill per level), 0 = the launcher zeroes its channel slice (default) */
 void captra_pw_set_occupancy(int occ);      /* dense layers, 64x64 wave tiles: workgroups per CU, 0 / 4 = as built (default), 3 / 2 = fewer (measurements) */
 void captra_pw_set_dbg(int v);             /* dense layers of a GroupNorm chain: timing ablations (-DCAPTRA_ABLATIONS=1 builds only, results wrong; ignored otherwise) */

@@ -979,6 +979,45 @@ def test_rot_pool_compose_vs_reference_algebra(device, sym, P):
     np.testing.assert_allclose(rot.cpu().numpy(), r_ref.numpy(), atol=2e-6, rtol=0)
 
 
+@pytest.mark.parametrize("b,cin,cout,l,csplit,bcast,act", [(1, 515, 256, 128, 3, False, 1), (2, 1536, 512, 128, 512, True, 1), (1, 832, 512, 512, 320, False, 1),
+                                                          (1, 256, 512, 128, 0, False, 1), (2, 320, 128, 512, 0, False, 0), (1, 130, 70, 77, 0, False, 2)])
+def test_split_k_dense_layers_close_to_the_bit_exact_chain(device, b, cin, cout, l, csplit, bcast, act):
+    """fused.split_k (captra_pw_set_splitk): the dense layers of few-position launches with k dealt to a workgroup's four waves and
+    the partial tiles added in wave order -- within 1e-5 of the k-ascending chain (relative to the largest output), for the one-
+    and two-source layers of the 128- / 512-point levels (SA3's [xyz, feat], FP3's [points1, repeat(points2)], FP2's concat, SA2's
+    point-major pre-transform), odd shapes included; outside the context, and for launches above the position limit inside it,
+    the chain itself (bit-identical)."""
+    from captra_amd import fused, _lib as L
+    g = torch.Generator().manual_seed(cin + cout + l)
+    lin = fused.pack((torch.randn(cin, cout, generator=g) / cin ** 0.5).to(device), torch.randn(cout, generator=g).to(device))
+    if csplit:
+        x1 = torch.randn(b, csplit, l, generator=g).to(device)
+        x2 = (torch.randn(b, cin - csplit, 1, generator=g) if bcast else torch.randn(b, cin - csplit, l, generator=g)).to(device)
+        run = lambda: fused.pointwise_mlp2(x1, x2, lin, act)
+    else:
+        x = torch.randn(b, cin, l, generator=g).to(device)
+        run = lambda: fused.pointwise_mlp(x, lin, act)
+    ref = run()
+    with fused.split_k(True):
+        got = run()
+        big = fused.pointwise_mlp(torch.randn(3, cin, 512, generator=g).to(device), lin, act) if not csplit else None    # 1536 positions: above the limit
+    again = run()
+    assert torch.equal(again, ref)
+    scale = float(ref.abs().max())
+    assert float((got - ref).abs().max()) <= 1e-5 * max(scale, 1.0)
+    assert not torch.equal(got, ref) or cin < 256          # (it IS another summation order)
+    if big is not None:
+        assert big.shape == (3, cout, 512)
+    if not csplit and cout % 4 == 0:                        # the point-major form (SA2's pre-transformed first layer)
+        out_ref = torch.empty(b, l, cout, device=device)
+        out_got = torch.empty(b, l, cout, device=device)
+        with torch.cuda.device(device):
+            L.call("captra_pointwise_mlp_pm", b, cin, cout, l, L.ptr(x), L.ptr(lin.wt), L.ptr(lin.bias), 0, L.ptr(out_ref))
+            with fused.split_k(True):
+                L.call("captra_pointwise_mlp_pm", b, cin, cout, l, L.ptr(x), L.ptr(lin.wt), L.ptr(lin.bias), 0, L.ptr(out_got))
+        assert float((out_got - out_ref).abs().max()) <= 1e-5 * max(float(out_ref.abs().max()), 1.0)
+
+
 @pytest.mark.parametrize("cin,cout,l,batch,with_ab", [(128, 512, 4096, 5, False), (512, 256, 4096, 9, True), (128, 512, 4032, 5, False), (64, 128, 1030, 64, True)])
 def test_gn_chain_layer_statistics_epilogue_on_64x64_tiles(device, cin, cout, l, batch, with_ab):
     """captra_pointwise_mlp_gn at launch shapes that take the 64x64 wave tiles (>= 2048 of them; the rotation heads at >= 4 clouds): y is
