@@ -610,8 +610,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void p
 // ((p0 + p1) + p2) + p3 with the bias in p0: a fixed order, but not the single k-ascending chain -- results differ from the
 // bit-exact form in the last bits (tested at 1e-5 relative against it), so the launchers take this form only where the caller
 // asked for it (captra_pw_set_splitk: EvalTrackModel at <= 2 trajectories; north_star's tolerance is 1e-4 on the poses).
-template <bool SRC2>
+// AFF / ST: the layer inside a Conv -> GroupNorm -> ReLU chain (captra_pointwise_mlp_gn): the operand is relu(a x + b) per (cloud,
+// input channel), the epilogue also writes the raw output's (sum, sum of squares) per row and 32-column tile.
+template <bool SRC2, bool AFF = false, bool ST = false>
 __global__ __launch_bounds__(256) void pw_splitk_kernel(PwParams p) {
+    static_assert(!SRC2 || (!AFF && !ST), "two-source input: plain layers only");
     __shared__ float red[4][16][64];
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -646,10 +649,18 @@ __global__ __launch_bounds__(256) void pw_splitk_kernel(PwParams p) {
     }
     float4 a[2];
     float bv[2][4];
+    float2 gv[2][AFF ? 4 : 1];
+    const __amdgpu_buffer_rsrc_t gsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(AFF ? p.ab_in + (size_t)b * p.cin * 2 : p.wt), 0, AFF ? p.cin * 8 : 0, 0x00020000);
 #define SK_LOAD(s, q)                                                                                                    \
     a[s] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wsrc, woff, (q) * 1024, 0));                 \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j) bv[s][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xsrc, xoff(4 * (q) + j), 0, 0));
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                      \
+        bv[s][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xsrc, xoff(4 * (q) + j), 0, 0));       \
+        if (AFF) gv[s][j] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(gsrc, h * 8 + (4 * (q) + j) * 16, 0, 0)); \
+    }
 #define SK_MFMA(s)                                                                                                       \
+    if (AFF) {                                                                                                           \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) bv[s][j] = relu_bits(__builtin_fmaf(gv[s][j].x, bv[s][j], gv[s][j].y)); \
+    }                                                                                                                    \
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s].x, bv[s][0], acc, 0, 0, 0);                                          \
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s].y, bv[s][1], acc, 0, 0, 0);                                          \
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s].z, bv[s][2], acc, 0, 0, 0);                                          \
@@ -678,6 +689,20 @@ __global__ __launch_bounds__(256) void pw_splitk_kernel(PwParams p) {
         v[i] = apply_act(((red[0][r][lane] + red[1][r][lane]) + red[2][r][lane]) + red[3][r][lane], p.act);
     }
     const int row0 = co0 + 8 * wave + 4 * h;
+    if (ST) {
+        // (sum, sum of squares) of the raw outputs (act is none on this path) of rows row0 .. row0 + 3 over the tile's 32 columns
+        const int tcol = (int)(pos0 / 32);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float t = col_ok ? v[i] : 0.f;
+            const float sm = half_wave_sum(t), sq = half_wave_sum(t * t);
+            if ((lane & 31) == 16 && row0 + i < p.cout) {
+                float *d = p.stats_out + (((size_t)b * p.cout + row0 + i) * p.stats_t + tcol) * 2;
+                d[0] = sm;
+                d[1] = sq;
+            }
+        }
+    }
     if (!col_ok) return;
     if (p.y_pm) {
         float *yp = p.y + ((size_t)b * p.L + col) * p.cout + row0;
@@ -844,10 +869,12 @@ static inline bool pw_use_splitk(int b, const PwParams &p) {
     return g_pw_splitk > 0 && (long long)b * p.L <= g_pw_splitk && p.cin >= 128 && (p.y_pm == 0 || p.cout % 4 == 0) &&
            (long long)p.cin * p.L * 4 < (1ll << 31);
 }
-template <bool SRC2>
+template <bool SRC2, bool AFF = false, bool ST = false>
 static int launch_pw_splitk(int b, const PwParams &p, hipStream_t s) {
-    dim3 grid((unsigned)((p.L + 31) / 32), (p.cout + 31) / 32, b);
-    CAPTRA_LAUNCH("pointwise_mlp", (pw_splitk_kernel<SRC2>), grid, dim3(256), 0, s, p);
+    // (ST: the statistics table has an even number of 32-column tiles per row -- the 64-position workgroups of the chain form wrote
+    // both; a tile beyond the last position writes zeros there and stores nothing else)
+    dim3 grid((unsigned)(ST ? (p.L + 63) / 64 * 2 : (p.L + 31) / 32), (p.cout + 31) / 32, b);
+    CAPTRA_LAUNCH("pointwise_mlp", (pw_splitk_kernel<SRC2, AFF, ST>), grid, dim3(256), 0, s, p);
     return captra_last_error();
 }
 static CAPTRA_KNOB int g_pw_dbg = 0;     // CAPTRA_ABLATIONS builds: PwParams::dbg of captra_pointwise_mlp_gn's launches
@@ -1010,6 +1037,12 @@ extern "C" int captra_pointwise_mlp_gn(int b, int cin, int cout, long long l, co
     if (cout > 64 && waves22 < 2048) {
         // few positions (single-trajectory latency): 32x32 wave tiles, statistics per 32-column tile
         if (stats_out != nullptr && stats_t != (int)((l + 63) / 64) * 2) return -1;
+        if (pw_use_splitk(b, p)) {
+            if (ab_in != nullptr && stats_out != nullptr) return launch_pw_splitk<false, true, true>(b, p, s);
+            if (stats_out != nullptr) return launch_pw_splitk<false, false, true>(b, p, s);
+            if (ab_in != nullptr) return launch_pw_splitk<false, true, false>(b, p, s);
+            return launch_pw_splitk<false>(b, p, s);
+        }
         dim3 grid((unsigned)((l + 63) / 64), (cout + 63) / 64, b);
         if (ab_in != nullptr && stats_out != nullptr) {
             CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<1, 1, 2, 2, true, true>), grid, dim3(256), 0, s, p);

@@ -60,7 +60,8 @@ def canonicalize(pts, mean, rot, trans, scale, num_parts: int = 1, want_cn=True,
 
 
 SPLIT_K_MAX_TRAJECTORIES = int(os.environ.get("CAPTRA_SPLIT_K_TRAJ", "2"))   # 0 = every dense layer the k-ascending chain at every batch
-SPLIT_K_POSITIONS = 1024                                                        # launches of at most this many positions (b * l) split k
+SPLIT_K_POSITIONS = int(os.environ.get("CAPTRA_SPLIT_K_POSITIONS", "4096"))    # launches of at most this many positions (b * l) split k
+_split_k_on = False
 
 
 @contextlib.contextmanager
@@ -68,13 +69,16 @@ def split_k(on: bool):
     """Dense layers launched inside with at most SPLIT_K_POSITIONS positions split k over a workgroup's four waves
     (captra_pw_set_splitk: a fixed summation order, 1e-5 relative from the bit-exact chain).  The track step of one or two
     trajectories runs under it -- its 128- / 512-point levels are single dependent MFMA chains on an idle chip otherwise."""
+    global _split_k_on
     if on:
         L.lib().captra_pw_set_splitk(C.c_int(SPLIT_K_POSITIONS))
+        _split_k_on = True
     try:
         yield
     finally:
         if on:
             L.lib().captra_pw_set_splitk(C.c_int(0))
+            _split_k_on = False
 
 
 @contextlib.contextmanager
@@ -911,7 +915,10 @@ def mlp_chain3(x, layers, act3: int = ACT_RELU):
     l = x.numel() // max(B * shape[0], 1)
     if mlp_dtype() == "bf16":
         return mlp_chain_bf16(x, layers, [ACT_RELU, ACT_RELU, act3])
-    if not (USE_MLP_CHAIN and mlp_dtype() == "fp32" and shape in _CHAIN3_SHAPES and shape[0] * l * 4 < (1 << 31)):
+    # under split_k with few positions: three split-k launches (each fills the chip) instead of the one-launch chain, whose waves own
+    # 32 positions each -- 128 waves for one 4096-point cloud, every one a serial chain of the three layers (49 -> ~25 us)
+    few = _split_k_on and B * l <= SPLIT_K_POSITIONS
+    if few or not (USE_MLP_CHAIN and mlp_dtype() == "fp32" and shape in _CHAIN3_SHAPES and shape[0] * l * 4 < (1 << 31)):
         y = pointwise_mlp(x, layers[0], ACT_RELU)
         y = pointwise_mlp(y, layers[1], ACT_RELU)
         return pointwise_mlp(y, layers[2], act3)

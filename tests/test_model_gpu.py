@@ -1018,6 +1018,33 @@ def test_split_k_dense_layers_close_to_the_bit_exact_chain(device, b, cin, cout,
         assert float((out_got - out_ref).abs().max()) <= 1e-5 * max(float(out_ref.abs().max()), 1.0)
 
 
+@pytest.mark.parametrize("cin,cout,l,batch,with_ab", [(128, 512, 4096, 1, False), (512, 256, 4096, 1, True), (512, 512, 1000, 2, True), (130, 96, 75, 3, False)])
+def test_split_k_gn_chain_layers(device, cin, cout, l, batch, with_ab):
+    """The GroupNorm-chain layers (relu(a x + b) on load, raw-output statistics per 32-column tile) in the split-k form against the
+    chain form of the same launch shape: y within 1e-5, the (sum, sum of squares) partials within 1e-5 of the tile's absolute sum --
+    ragged tails and an odd number of 32-column tiles included (the table's padding tile is written, as zeros)."""
+    from captra_amd import fused
+    g = torch.Generator().manual_seed(cin + cout + l)
+    x = torch.randn(batch, cin, l, generator=g).to(device)
+    lin = fused.pack((torch.randn(cin, cout, generator=g) / cin ** 0.5).to(device), torch.randn(cout, generator=g).to(device))
+    ab = torch.stack([torch.rand(batch, cin, generator=g) + 0.5, torch.randn(batch, cin, generator=g) * 0.3], -1).to(device).contiguous() if with_ab else None
+    y0, s0 = fused.pointwise_mlp_gn(x, lin, ab, fused.ACT_NONE, True)
+    with fused.split_k(True):
+        s_probe = torch.full_like(s0, float("nan"))
+        y1, s1 = fused.pointwise_mlp_gn(x, lin, ab, fused.ACT_NONE, True)
+        y2 = fused.pointwise_mlp_gn(x, lin, ab, fused.ACT_RELU, False)
+    assert s1.shape == s0.shape and not torch.isnan(s1).any()
+    scale = max(float(y0.abs().max()), 1.0)
+    assert float((y1 - y0).abs().max()) <= 1e-5 * scale and float((y2 - torch.relu(y0)).abs().max()) <= 1e-5 * scale
+    t = s0.shape[2]
+    yd = torch.zeros(batch, cout, t * 32, dtype=torch.float64, device=device)
+    yd[:, :, :l] = y1.double()
+    yt = yd.reshape(batch, cout, t, 32)
+    want = torch.stack([yt.sum(-1), (yt * yt).sum(-1)], -1)
+    err = (s1.double() - want).abs()
+    assert float(err[..., 0].max()) <= 1e-5 * max(float(yt.abs().sum(-1).max()), 1.0) and float(err[..., 1].max()) <= 1e-5 * max(float(want[..., 1].max()), 1.0)
+
+
 @pytest.mark.parametrize("cin,cout,l,batch,with_ab", [(128, 512, 4096, 5, False), (512, 256, 4096, 9, True), (128, 512, 4032, 5, False), (64, 128, 1030, 64, True)])
 def test_gn_chain_layer_statistics_epilogue_on_64x64_tiles(device, cin, cout, l, batch, with_ab):
     """captra_pointwise_mlp_gn at launch shapes that take the 64x64 wave tiles (>= 2048 of them; the rotation heads at >= 4 clouds): y is
