@@ -43,12 +43,15 @@ def lane_streams(dev, lanes: int = 2):
 
 class TrackStepGraph:
     def __init__(self, model, points: torch.Tensor, points_mean: torch.Tensor, pose: dict, labels: torch.Tensor | None = None,
-                 warmup: int = 2, split_side=None):
+                 warmup: int = 2, split_side=None, allow_split_k: bool = True):
         """model: EvalTrackModel (eval mode, on the GPU); points (B,3,N), points_mean (B,3,1), pose: example inputs.
         split_side: a stream -> the step is captured as four linear graphs and its RotationNet branch replays on that stream
         (see SPLIT_OTF_LANES); None -> one graph, the networks as its two branches when model.overlap_nets."""
         self.model = model
         self.split_side = split_side
+        # a LANE of a larger batch (TrackLanes) must compute what the whole batch computes: the few-trajectory split-k rule of
+        # EvalTrackModel._track_step goes by the batch it sees, so it is switched off for sub-batches
+        self.allow_split_k = allow_split_k
         dev = points.device
         self.points = points.clone()
         self.points_mean = points_mean.clone()
@@ -102,7 +105,7 @@ class TrackStepGraph:
         self._graphs = [torch.cuda.CUDAGraph() for _ in range(4)]
         state = {}
 
-        few = fused.mlp_dtype() == "fp32" and 0 < len(self.points) <= fused.SPLIT_K_MAX_TRAJECTORIES     # (as EvalTrackModel._track_step)
+        few = self.allow_split_k and fused.mlp_dtype() == "fp32" and 0 < len(self.points) <= fused.SPLIT_K_MAX_TRAJECTORIES     # (as EvalTrackModel._track_step)
 
         def capture(g, pool, fn):
             with torch.cuda.graph(g, pool=pool, stream=cap, capture_error_mode="thread_local"), torch.no_grad(), fused.use_mlp_dtype(m.mlp_dtype), fused.split_k(few):
@@ -148,7 +151,12 @@ class TrackStepGraph:
         if self.labels is not None:
             input["labels"] = self.labels
             npcs_input["labels"] = self.labels
-        return self.model.track_step(input, npcs_input, self.pose)
+        prev = getattr(self.model, "_no_split_k", False)
+        self.model._no_split_k = prev or not self.allow_split_k
+        try:
+            return self.model.track_step(input, npcs_input, self.pose)
+        finally:
+            self.model._no_split_k = prev
 
     def stale(self) -> bool:
         """True when a module UNDER THIS GRAPH'S MODEL re-folded (or dropped) its weights after the capture: the replay would
@@ -208,7 +216,7 @@ class TrackLanes:
         dev = points.device
         per = B // lanes
         self.slices = [slice(l * per, (l + 1) * per) for l in range(lanes)]
-        self.graphs = [TrackStepGraph(model, points[s].contiguous(), points_mean[s].contiguous(), {k: v[s].contiguous() for k, v in pose.items()})
+        self.graphs = [TrackStepGraph(model, points[s].contiguous(), points_mean[s].contiguous(), {k: v[s].contiguous() for k, v in pose.items()}, allow_split_k=False)
                        for s in self.slices]
         self.streams = [torch.cuda.Stream(device=dev) for _ in range(lanes)]
         self.ring = [{k: torch.empty_like(v) for k, v in pose.items()} for _ in range(ring)]

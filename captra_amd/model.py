@@ -176,7 +176,7 @@ class EvalTrackModel(BaseModel):
     def _track_step(self, input, npcs_input, last_pose):
         from . import fused
         few = (not self.training and input["points"].is_cuda and fused.mlp_dtype() == "fp32"
-               and 0 < len(input["points"]) <= fused.SPLIT_K_MAX_TRAJECTORIES)
+               and 0 < len(input["points"]) <= fused.SPLIT_K_MAX_TRAJECTORIES and not getattr(self, "_no_split_k", False))
         with fused.split_k(few):
             return self._track_step_body(input, npcs_input, last_pose)
 
@@ -430,7 +430,7 @@ class EvalTrackModel(BaseModel):
             key = ("otf", tuple(feed[1]["points"].shape), str(dev))
             if self._graph is None or self._graph_key != key or any(g.stale() for g in self._graph):
                 self._graph = [TrackStepGraph(self, feed[1]["points"][s].contiguous(), feed[1]["points_mean"][s].contiguous(),
-                                              {k: v[s].contiguous() for k, v in pose0.items()}, split_side=side) for s, side in zip(slices, sides)]
+                                              {k: v[s].contiguous() for k, v in pose0.items()}, split_side=side, allow_split_k=False) for s, side in zip(slices, sides)]
                 self._graph_key = key
             graphs = self._graph
         lane_pose = [{k: v[s].clone() for k, v in pose0.items()} for s in slices]

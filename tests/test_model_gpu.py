@@ -510,10 +510,16 @@ def test_free_running_lanes_equal_eager(device, tag):
             f = model.feed_dict[i]
             got.append({k: v.clone() for k, v in lanes.gather(lanes.step(f["points"], f["points_mean"])).items()})
         if rep == 0:
-            for i in range(1, len(data)):
-                with torch.no_grad():
-                    _, pe = model.track_step(model.feed_dict[i], model.npcs_feed_dict[i], pe)
-                eager.append(pe)
+            # (lanes never take the few-trajectory split-k form -- a sub-batch must compute what the whole batch computes at any
+            # size --, so the eager comparand of this small test batch is run without it too)
+            model._no_split_k = True
+            try:
+                for i in range(1, len(data)):
+                    with torch.no_grad():
+                        _, pe = model.track_step(model.feed_dict[i], model.npcs_feed_dict[i], pe)
+                    eager.append(pe)
+            finally:
+                model._no_split_k = False
         for i, (a, b) in enumerate(zip(eager, got)):
             for k in a:
                 np.testing.assert_array_equal(a[k].cpu().numpy(), b[k].cpu().numpy(), err_msg=f"pass {rep} frame {i + 1} {k}")
