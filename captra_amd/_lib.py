@@ -156,6 +156,11 @@ def lib():
             l.captra_sa1_stream_set_fine.restype = None
             l.captra_sa1_stream_set_whole.argtypes = [_INT]
             l.captra_sa1_stream_set_whole.restype = None
+        if hasattr(l, "captra_sa_multi_begin"):
+            l.captra_sa_multi_begin.argtypes = []
+            l.captra_sa_multi_begin.restype = None
+            l.captra_sa_multi_end.argtypes = [_P]
+            l.captra_sa_multi_end.restype = _INT
         if hasattr(l, "captra_pw_set_splitk"):
             l.captra_pw_set_splitk.argtypes = [_INT]
             l.captra_pw_set_splitk.restype = None

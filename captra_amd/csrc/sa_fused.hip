@@ -627,8 +627,10 @@ constexpr int sl_lds_floats() {
     return SlShape<CF + 3, C1>::FLOATS + SlShape<C1, C2>::FLOATS + SlShape<C2, C3>::FLOATS + pad32c(C1) + pad32c(C2) + pad32c(C3);
 }
 
+// (the kernel's body as a device function of (workgroup, workgroups): sa_wave_lds_kernel runs one scale, sa_wave_lds3_kernel the three
+// scales of a level side by side in ONE launch, each on its own range of workgroups)
 template <int CF, int C1, int C2, int C3>
-__global__ __launch_bounds__(SL_WAVES * 64) __attribute__((amdgpu_waves_per_eu(4, 8))) void sa_wave_lds_kernel(SwParams p) {
+__device__ __forceinline__ void sl_body(const SwParams &p, const int blk, const int nblk) {
     constexpr int CIN1 = CF + 3;
     static_assert(CIN1 <= 8, "LDS-weight variant is for the small-input scales");
     using S1 = SlShape<CIN1, C1>;
@@ -650,7 +652,7 @@ __global__ __launch_bounds__(SL_WAVES * 64) __attribute__((amdgpu_waves_per_eu(4
     // centres out through a per-launch atomic counter instead was measured worse -- a centre is the unit, so the launch
     // ends up to a whole centre (4 slices, ~150 us with four waves per SIMD) late, and the atomic's return is waited for
     // at every centre end (674 / 298 / 210 us).
-    const int nwaves = (int)gridDim.x * SL_WAVES, gid = (int)blockIdx.x * SL_WAVES + wave;
+    const int nwaves = nblk * SL_WAVES, gid = blk * SL_WAVES + wave;
     const int ncentres = p.b * p.mc;                      // < 2^30 (launcher); centre c of the window = row crow(c) of (B, M)
     auto crow = [&](int c) { const int tb = c / p.mc; return tb * p.m + p.m0 + (c - tb * p.mc); };
     const int nslices = p.k / 32;
@@ -712,7 +714,7 @@ __global__ __launch_bounds__(SL_WAVES * 64) __attribute__((amdgpu_waves_per_eu(4
     for (int j = 0; j < S1::KST; ++j) x1[j] = 0.f;
     if (c < ncentres) gather_x1(c, id, ctr, x1);
     int zrun[S3::NT];
-    const bool sampled = blockIdx.x % 16 == 0;            // phase timers (captra_sa_fused_set_prof): a sample of workgroups
+    const bool sampled = blk % 16 == 0;            // phase timers (captra_sa_fused_set_prof): a sample of workgroups
     unsigned long long t_last = CAPTRA_PROF_ON(p.prof) ? __builtin_amdgcn_s_memtime() : 0ull;
     while (c < ncentres) {
         if (sl == 0 || split) {
@@ -772,6 +774,24 @@ __global__ __launch_bounds__(SL_WAVES * 64) __attribute__((amdgpu_waves_per_eu(4
     }
 }
 
+
+template <int CF, int C1, int C2, int C3>
+__global__ __launch_bounds__(SL_WAVES * 64) __attribute__((amdgpu_waves_per_eu(4, 8))) void sa_wave_lds_kernel(SwParams p) {
+    sl_body<CF, C1, C2, C3>(p, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// The three small-input scales of a level in one launch (few clouds: a scale's own launch is 64-256 workgroups of a chip that holds
+// 512, and the three ran one after the other): workgroups [0, g0) run scale 0, [g0, g0 + g1) scale 1, the rest scale 2 -- each
+// exactly what its own launch would have run (same workgroup count, same walk), so every output bit is the same.
+struct Sw3Params { SwParams s[3]; int g0, g1; };
+template <int CF>
+__global__ __launch_bounds__(SL_WAVES * 64) __attribute__((amdgpu_waves_per_eu(4, 8))) void sa_wave_lds3_kernel(Sw3Params q) {
+    const int blk = (int)blockIdx.x;
+    if (blk < q.g0) sl_body<CF, 32, 32, 64>(q.s[0], blk, q.g0);
+    else if (blk < q.g0 + q.g1) sl_body<CF, 64, 64, 128>(q.s[1], blk - q.g0, q.g1);
+    else sl_body<CF, 64, 96, 128>(q.s[2], blk - q.g0 - q.g1, (int)gridDim.x - q.g0 - q.g1);
+}
+
 }  // namespace
 
 // experiment knob (not part of the ABI): force the sub-tile width, 0 = heuristic
@@ -783,6 +803,49 @@ extern "C" void captra_sa_fused_set_mode(int mode) { g_sa_mode = mode; }
 static CAPTRA_KNOB int g_sa_split = 1;  // a wave per slice for small batches: 0 = never, 1 = heuristic, 2 = always (tests)
 extern "C" void captra_sa_fused_set_split(int v) { g_sa_split = v; }
 int captra_sa_split_knob() { return g_sa_split; }
+// The three small-input scales of a level as ONE launch (sa_wave_lds3_kernel): between captra_sa_multi_begin and captra_sa_multi_end
+// the LDS-weight scales are recorded instead of launched; the end launches them together when they are the level's three shapes in
+// order, none with a dynamic hand-out, else one after the other as they would have been.  Thread-local, not re-entrant.
+struct SlRecord {
+    SwParams q;
+    unsigned grid;
+    int code, cf, lds;
+    void (*launch)(const SwParams &, unsigned, int, hipStream_t);
+};
+static thread_local SlRecord g_sl_rec[3];
+static thread_local int g_sl_n = 0;
+static CAPTRA_KNOB int g_sl_collect = 0;
+template <int CF, int C1, int C2, int C3>
+static void sl_launch_one(const SwParams &q, unsigned grid, int lds, hipStream_t s) {
+    CAPTRA_LAUNCH("sa_scale_fused", (sa_wave_lds_kernel<CF, C1, C2, C3>), dim3(grid), dim3(SL_WAVES * 64), lds, s, q);
+}
+template <int CF>
+static void sl_launch_three(const SlRecord (&r)[3], hipStream_t s) {
+    constexpr int lds = sl_lds_floats<CF, 64, 96, 128>() * 4;
+    static CaptraDeviceOnce once;
+    if (once.first_use()) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(sa_wave_lds3_kernel<CF>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        once.done();
+    }
+    Sw3Params q3;
+    for (int i = 0; i < 3; ++i) q3.s[i] = r[i].q;
+    q3.g0 = (int)r[0].grid; q3.g1 = (int)r[1].grid;
+    CAPTRA_LAUNCH("sa_scale_fused", (sa_wave_lds3_kernel<CF>), dim3(r[0].grid + r[1].grid + r[2].grid), dim3(SL_WAVES * 64), lds, s, q3);
+}
+extern "C" void captra_sa_multi_begin() { g_sl_collect = 1; g_sl_n = 0; }
+extern "C" int captra_sa_multi_end(captra_stream_t stream) {
+    g_sl_collect = 0;
+    const int n = g_sl_n;
+    g_sl_n = 0;
+    hipStream_t s = (hipStream_t)stream;
+    bool together = n == 3 && g_sl_rec[0].cf == g_sl_rec[1].cf && g_sl_rec[1].cf == g_sl_rec[2].cf;
+    for (int i = 0; together && i < 3; ++i) together = g_sl_rec[i].code == i && g_sl_rec[i].q.dyn == nullptr;
+    if (together && g_sl_rec[0].cf == 0) sl_launch_three<0>(g_sl_rec, s);
+    else if (together && g_sl_rec[0].cf == 3) sl_launch_three<3>(g_sl_rec, s);
+    else
+        for (int i = 0; i < n; ++i) g_sl_rec[i].launch(g_sl_rec[i].q, g_sl_rec[i].grid, g_sl_rec[i].lds, s);
+    return captra_last_error();
+}
 // the caller zeroed the whole output tensor itself (one fill for every scale of a level instead of one per scale and cloud): the
 // slice-per-wave form then launches straight away
 static CAPTRA_KNOB int g_sa_prezeroed = 0;
@@ -878,6 +941,12 @@ extern "C" int captra_sa_scale_fused(int b, int n, int m, int k, int cfeat, int 
         q.dyn = (!q.split && k > 32 && wgs > 1) ? captra_sa_dyn_slot((hipStream_t)stream) : nullptr;                   \
         const unsigned grid_l = (unsigned)(wgs < resident ? wgs : resident);                                           \
         if (q.split && !g_sa_prezeroed) sl_zero_window(out, b, m, out_ctotal, co_off, c3, wm0, wmc, (hipStream_t)stream);                  \
+        if (g_sl_collect && g_sl_n < 3) {      /* captra_sa_multi_begin: recorded, launched by captra_sa_multi_end */       \
+            SlRecord &r = g_sl_rec[g_sl_n++];                                                                          \
+            r.q = q; r.grid = grid_l; r.cf = CF_; r.lds = lds_bytes; r.launch = sl_launch_one<CF_, C1_, C2_, C3_>;      \
+            r.code = (C1_ == 32 && C2_ == 32 && C3_ == 64) ? 0 : ((C1_ == 64 && C2_ == 64 && C3_ == 128) ? 1 : 2);     \
+            return 0;                                                                                                  \
+        }                                                                                                              \
         CAPTRA_LAUNCH("sa_scale_fused", kern, dim3(grid_l), dim3(SL_WAVES * 64), lds_bytes, (hipStream_t)stream, q);  \
         return captra_last_error();                                                                                    \
     }

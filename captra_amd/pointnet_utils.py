@@ -128,6 +128,9 @@ def _has_points(points):
     return points is not None and points.shape[1] > 0
 
 
+MULTI_SCALE_MAX_CLOUDS = int(__import__("os").environ.get("CAPTRA_MULTI_SCALE", "2"))   # 0 = a level's scales always one launch each
+
+
 class PointNetSetAbstractionMsg(_FoldCache, nn.Module):
     """Multi-scale-grouping set abstraction (reference pointnet_utils.py:191-250)."""
 
@@ -231,9 +234,21 @@ class PointNetSetAbstractionMsg(_FoldCache, nn.Module):
             # output -- ONE fill of the level's tensor here instead of a fill per scale and cloud in the launchers
             out.zero_()
             fused.L.lib().captra_sa_set_prezeroed(1)
+        # ... and the level's small-input scales recorded and launched TOGETHER (sa_wave_lds3_kernel: each on its own range of
+        # workgroups, bits unchanged) where a scale's own launch fills a fraction of the chip
+        together = prezero and B <= MULTI_SCALE_MAX_CLOUDS and (feat is None or feat.shape[1] <= 3)
+        if together:
+            fused.L.lib().captra_sa_multi_begin()
         try:
-            return self._forward_scales(folded, idx_list, feat, xyz_cn, new_xyz_n3, out, off, B)
+            res = self._forward_scales(folded, idx_list, feat, xyz_cn, new_xyz_n3, out, off, B)
+            if together:
+                together = False
+                with torch.cuda.device(xyz_cn.device):
+                    fused.L.check(fused.L.lib().captra_sa_multi_end(fused.L.stream_ptr()), "captra_sa_multi_end")
+            return res
         finally:
+            if together:                  # (an exception between begin and end: drop the recording mode)
+                fused.L.lib().captra_sa_multi_end(fused.L.stream_ptr())
             if prezero:
                 fused.L.lib().captra_sa_set_prezeroed(0)
 

@@ -567,6 +567,11 @@ void captra_sa_fused_set_wn(int wn);        /* generic LDS kernel: sub-tile widt
 void captra_sa_fused_set_prof(unsigned long long *dev_counters); /* sa_wave_kernel: 10 device counters of phase timers, or NULL */
 void captra_pw_set_direct(int on);          /* dense layers: 1 = direct-operand kernel (default), 0 = LDS-staged kernel */
 void captra_ball_query_set_prune(int on);   /* ball query: 1 = small radii of 1024..4096-point clouds from a cell grid (exact; measured slower, off by default), 0 = index-order scan */
+/* captra_sa_scale_fused calls between the two that take the LDS-weight kernels (the small-input scales) are recorded and launched by
+ * the end: as ONE launch when they are a level's three scales in order (each on its own range of workgroups, bits unchanged), else one
+ * after the other.  For steps of few clouds, where a scale's own launch fills a fraction of the chip.  Thread-local, not re-entrant. */
+void captra_sa_multi_begin(void);
+int captra_sa_multi_end(captra_stream_t stream);
 void captra_pw_set_splitk(int max_positions); /* dense layers (captra_pointwise_mlp / _mlp2 / _pm): launches of <= max_positions (b * l) and >= 128 input channels split k over the four waves of a workgroup
                                               * (partial tiles added in wave order: a fixed order, 1e-5 relative from the k-ascending chain); 0 = never (default) */
 void captra_sa_set_prezeroed(int on);      /* SA scales, slice-per-wave form (few clouds): 1 = the caller zeroed the whole output tensor (one fill per level), 0 = the launcher zeroes its channel slice (default) */

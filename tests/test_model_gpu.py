@@ -730,6 +730,32 @@ def test_backbone_vs_golden_and_oracle(device, tag, use_xyz, seed):
     np.testing.assert_array_equal(out.cpu().numpy(), ref)
 
 
+@pytest.mark.parametrize("use_xyz,batch", [(False, 1), (True, 2)])
+def test_level_scales_in_one_launch_equal_one_launch_each(device, use_xyz, batch):
+    """Few clouds: a level's three small-input scales recorded and launched together (captra_sa_multi_begin / _end ->
+    sa_wave_lds3_kernel, every scale on its own range of workgroups) against one launch per scale: every bit of the level's
+    output, with and without CoordinateNet's coordinate features."""
+    from captra_amd import pointnet_utils as PU
+    from captra_amd.backbones import PointNet2Msg
+    from captra_amd.configs import make_config
+    cfg = make_config("1")
+    net = PointNet2Msg(cfg, 128, use_xyz_feat=use_xyz)
+    net.load_state_dict(make_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, seed=5))
+    net = net.to(device).eval()
+    cloud_cn = _dev(nocs_batch(list(range(batch))).transpose(0, 2, 1), device)
+    outs = {}
+    keep = PU.MULTI_SCALE_MAX_CLOUDS
+    try:
+        for limit in (0, 2):
+            PU.MULTI_SCALE_MAX_CLOUDS = limit
+            with torch.no_grad():
+                outs[limit] = net.sa1(cloud_cn, cloud_cn if use_xyz else None)[1].clone()
+    finally:
+        PU.MULTI_SCALE_MAX_CLOUDS = keep
+    assert outs[0].shape == (batch, 320, 512) and float(outs[0].abs().max()) > 0
+    assert torch.equal(outs[0], outs[2])
+
+
 def test_backbone_16384_point_clouds_bit_exact_vs_oracle(device):
     """BASELINE.json configs[4] shape: S-uni16k clouds (16384 points uniform in a cube), sa1.npoint 2048,
     sa2.npoint 512, radii / nsample / MLPs unchanged.  FPS runs 2047 rounds over 16384 points,
