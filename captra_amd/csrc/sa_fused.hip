@@ -832,7 +832,10 @@ static void sl_launch_three(const SlRecord (&r)[3], hipStream_t s) {
     q3.g0 = (int)r[0].grid; q3.g1 = (int)r[1].grid;
     CAPTRA_LAUNCH("sa_scale_fused", (sa_wave_lds3_kernel<CF>), dim3(r[0].grid + r[1].grid + r[2].grid), dim3(SL_WAVES * 64), lds, s, q3);
 }
-extern "C" void captra_sa_multi_begin() { g_sl_collect = 1; g_sl_n = 0; }
+extern void captra_sp_multi_reset();                 // sa_pipe.hip: the second level's two scales, recorded the same way
+extern int captra_sp_multi_flush(hipStream_t s);
+int captra_sa_collecting() { return g_sl_collect; }
+extern "C" void captra_sa_multi_begin() { g_sl_collect = 1; g_sl_n = 0; captra_sp_multi_reset(); }
 extern "C" int captra_sa_multi_end(captra_stream_t stream) {
     g_sl_collect = 0;
     const int n = g_sl_n;
@@ -844,7 +847,9 @@ extern "C" int captra_sa_multi_end(captra_stream_t stream) {
     else if (together && g_sl_rec[0].cf == 3) sl_launch_three<3>(g_sl_rec, s);
     else
         for (int i = 0; i < n; ++i) g_sl_rec[i].launch(g_sl_rec[i].q, g_sl_rec[i].grid, g_sl_rec[i].lds, s);
-    return captra_last_error();
+    const int err = captra_last_error();
+    const int err2 = captra_sp_multi_flush(s);
+    return err != 0 ? err : err2;
 }
 // the caller zeroed the whole output tensor itself (one fill for every scale of a level instead of one per scale and cloud): the
 // slice-per-wave form then launches straight away

@@ -211,8 +211,9 @@ __device__ __forceinline__ void sp_layer(const float *wt, const float *bias_lds,
     for (int c = 0; c < S::NSETS; ++c) sp_epi_part<COUT, LAST, S::NSETS>(acc[LP & 1], LP, c, hout, zrun, mst, lane);
 }
 
+// (the kernel's body as a device function of (workgroup, workgroups): sa_wave_pipe2_kernel runs the level's two scales in one launch)
 template <int CF, int C1, int C2, int C3>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void sa_wave_pipe_kernel(SpParams p) {
+__device__ __forceinline__ void sp_body(const SpParams &p, const int blk, const int nblk) {
     using S1 = SwShape<CF + 3, C1>;
     using S2 = SwShape<C1, C2>;
     using S3 = SwShape<C2, C3>;
@@ -242,7 +243,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // A WAVE owns a centre (as in sa_wave_lds_kernel): it walks the centre's K neighbours in K / 32 slices and keeps the
     // last layer's running maximum in registers, so the four waves of a workgroup share nothing but the biases: no LDS
     // staging of maxima, no chunk barrier, no read-out pass.  Centres are walked statically: gid, gid + nwaves, ...
-    const int nwaves = (int)gridDim.x * 4, gid = (int)blockIdx.x * 4 + wave;
+    const int nwaves = nblk * 4, gid = blk * 4 + wave;
     const int ncentres = p.b * p.m;                       // < 2^30 (launcher)
     const int nslices = p.k / 32;
     // a slice's per-lane inputs: neighbour id, relative xyz operands, accumulator start values (gathered v1 rows)
@@ -265,7 +266,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             for (int q = 0; q < 4; ++q) g_[t][q] = vp[8 * t + 2 * q];       // rows 32t + 8q + 4 half + (0..3)
     };
 
-    const bool sampled = blockIdx.x % 16 == 0;
+    const bool sampled = blk % 16 == 0;
     unsigned long long t_last = CAPTRA_PROF_ON(p.prof) ? __builtin_amdgcn_s_memtime() : 0ull;
     float s[3][16];
     constexpr int START3 = S2::STEPS % 3;                     // ring slot of layer 3's first set (layer 2 starts in slot 0)
@@ -366,11 +367,48 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
 }
 
+
+template <int CF, int C1, int C2, int C3>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void sa_wave_pipe_kernel(SpParams p) {
+    sp_body<CF, C1, C2, C3>(p, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// The second level's two scales in one launch (few clouds: 64 + 128 workgroups of a chip that holds 256, one after the other
+// otherwise): workgroups [0, g0) run the first, the rest the second -- each exactly what its own launch would have run.
+struct Sp2Params { SpParams s[2]; int g0; };
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void sa_wave_pipe2_kernel(Sp2Params q) {
+    const int blk = (int)blockIdx.x;
+    if (blk < q.g0) sp_body<320, 128, 128, 256>(q.s[0], blk, q.g0);
+    else sp_body<320, 128, 196, 256>(q.s[1], blk - q.g0, (int)gridDim.x - q.g0);
+}
+
 }  // namespace
 
 extern unsigned long long *captra_sa_prof_ptr();   // sa_fused.hip: the debug counters set by captra_sa_fused_set_prof
 extern int captra_sa_split_knob();                  // sa_fused.hip: captra_sa_fused_set_split
 extern int captra_sa_prezeroed();                   // sa_fused.hip: captra_sa_set_prezeroed
+extern int captra_sa_collecting();                  // sa_fused.hip: between captra_sa_multi_begin and captra_sa_multi_end
+
+// the level's scales recorded between captra_sa_multi_begin / _end (sa_fused.hip), launched by captra_sp_multi_flush
+struct SpRecord { SpParams q; unsigned grid; int code; };
+static thread_local SpRecord g_sp_rec[2];
+static thread_local int g_sp_n = 0;
+void captra_sp_multi_reset() { g_sp_n = 0; }
+int captra_sp_multi_flush(hipStream_t s) {
+    const int n = g_sp_n;
+    g_sp_n = 0;
+    if (n == 2 && g_sp_rec[0].code == 0 && g_sp_rec[1].code == 1 && g_sp_rec[0].q.dyn == nullptr && g_sp_rec[1].q.dyn == nullptr) {
+        Sp2Params q2;
+        q2.s[0] = g_sp_rec[0].q; q2.s[1] = g_sp_rec[1].q; q2.g0 = (int)g_sp_rec[0].grid;
+        CAPTRA_LAUNCH("sa_scale_fused", sa_wave_pipe2_kernel, dim3(g_sp_rec[0].grid + g_sp_rec[1].grid), dim3(256), 0, s, q2);
+        return captra_last_error();
+    }
+    for (int i = 0; i < n; ++i) {
+        if (g_sp_rec[i].code == 0) { CAPTRA_LAUNCH("sa_scale_fused", (sa_wave_pipe_kernel<320, 128, 128, 256>), dim3(g_sp_rec[i].grid), dim3(256), 0, s, g_sp_rec[i].q); }
+        else { CAPTRA_LAUNCH("sa_scale_fused", (sa_wave_pipe_kernel<320, 128, 196, 256>), dim3(g_sp_rec[i].grid), dim3(256), 0, s, g_sp_rec[i].q); }
+    }
+    return captra_last_error();
+}
 extern int *captra_sa_dyn_slot(hipStream_t stream); // sa_fused.hip: captra_sa_set_dynamic
 
 // SA scale with a pre-transformed, POINT-major first layer (see include/captra_hip.h): v1pm (B,N,c1).
@@ -418,6 +456,11 @@ extern "C" int captra_sa_scale_pre_pm(int b, int n, int m, int k, int cfeat, int
 #define SPP_CASE(CF_, C1_, C2_, C3_)                                                                                  \
     if (cfeat == CF_ && c1 == C1_ && c2 == C2_ && c3 == C3_) {                                                        \
         auto kern = sa_wave_pipe_kernel<CF_, C1_, C2_, C3_>;                                                          \
+        if (captra_sa_collecting() && g_sp_n < 2) {                                                                   \
+            g_sp_rec[g_sp_n].q = q; g_sp_rec[g_sp_n].grid = grid; g_sp_rec[g_sp_n].code = (C2_ == 128 ? 0 : 1);        \
+            ++g_sp_n;                                                                                                 \
+            return 0;                                                                                                 \
+        }                                                                                                             \
         CAPTRA_LAUNCH("sa_scale_fused", kern, dim3(grid), dim3(256), 0, (hipStream_t)stream, q);                       \
         return captra_last_error();                                                                                   \
     }

@@ -234,9 +234,9 @@ class PointNetSetAbstractionMsg(_FoldCache, nn.Module):
             # output -- ONE fill of the level's tensor here instead of a fill per scale and cloud in the launchers
             out.zero_()
             fused.L.lib().captra_sa_set_prezeroed(1)
-        # ... and the level's small-input scales recorded and launched TOGETHER (sa_wave_lds3_kernel: each on its own range of
-        # workgroups, bits unchanged) where a scale's own launch fills a fraction of the chip
-        together = prezero and B <= MULTI_SCALE_MAX_CLOUDS and (feat is None or feat.shape[1] <= 3)
+        # ... and the level's scales recorded and launched TOGETHER (sa_wave_lds3_kernel / sa_wave_pipe2_kernel: each on its own range
+        # of workgroups, bits unchanged) where a scale's own launch fills a fraction of the chip
+        together = prezero and B <= MULTI_SCALE_MAX_CLOUDS
         if together:
             fused.L.lib().captra_sa_multi_begin()
         try:

@@ -749,11 +749,12 @@ def test_level_scales_in_one_launch_equal_one_launch_each(device, use_xyz, batch
         for limit in (0, 2):
             PU.MULTI_SCALE_MAX_CLOUDS = limit
             with torch.no_grad():
-                outs[limit] = net.sa1(cloud_cn, cloud_cn if use_xyz else None)[1].clone()
+                l1_xyz, l1 = net.sa1(cloud_cn, cloud_cn if use_xyz else None)
+                outs[limit] = (l1.clone(), net.sa2(l1_xyz, l1)[1].clone())        # (level 2: its two scales, sa_wave_pipe2_kernel)
     finally:
         PU.MULTI_SCALE_MAX_CLOUDS = keep
-    assert outs[0].shape == (batch, 320, 512) and float(outs[0].abs().max()) > 0
-    assert torch.equal(outs[0], outs[2])
+    assert outs[0][0].shape == (batch, 320, 512) and outs[0][1].shape == (batch, 512, 128) and float(outs[0][1].abs().max()) > 0
+    assert torch.equal(outs[0][0], outs[2][0]) and torch.equal(outs[0][1], outs[2][1])
 
 
 def test_backbone_16384_point_clouds_bit_exact_vs_oracle(device):
