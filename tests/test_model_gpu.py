@@ -1024,13 +1024,16 @@ def test_split_k_dense_layers_close_to_the_bit_exact_chain(device, b, cin, cout,
     g = torch.Generator().manual_seed(cin + cout + l)
     lin = fused.pack((torch.randn(cin, cout, generator=g) / cin ** 0.5).to(device), torch.randn(cout, generator=g).to(device))
     if csplit:
-        x1 = torch.randn(b, csplit, l, generator=g).to(device)
-        x2 = (torch.randn(b, cin - csplit, 1, generator=g) if bcast else torch.randn(b, cin - csplit, l, generator=g)).to(device)
+        n1, n2 = b * csplit * l, b * (cin - csplit) * (1 if bcast else l)
+        flat = torch.randn(n1 + n2, generator=g).to(device)          # (one allocation: the two sources within one buffer descriptor's reach)
+        x1, x2 = flat[:n1].view(b, csplit, l), flat[n1:].view(b, cin - csplit, 1 if bcast else l)
         run = lambda: fused.pointwise_mlp2(x1, x2, lin, act)
     else:
         x = torch.randn(b, cin, l, generator=g).to(device)
         run = lambda: fused.pointwise_mlp(x, lin, act)
     ref = run()
+    if ref is None:       # (pointwise_mlp2 declines when the allocator placed its two tensors more than 2^30 bytes apart: the caller concatenates)
+        pytest.skip("the two source tensors lie too far apart for one buffer descriptor in this process")
     with fused.split_k(True):
         got = run()
         big = fused.pointwise_mlp(torch.randn(3, cin, 512, generator=g).to(device), lin, act) if not csplit else None    # 1536 positions: above the limit
