@@ -1070,6 +1070,8 @@ extern "C" int captra_pointwise_mlp_gn(int b, int cin, int cout, long long l, co
         return captra_last_error();
     }
     if (stats_out != nullptr) return -2;   // statistics only from the 64x64 wave-tile configuration
+    // few positions and few output channels (a head's last layer at one trajectory: 16 workgroups, each wave a chain of cin / 2 steps)
+    if (pw_use_splitk(b, p)) return ab_in != nullptr ? launch_pw_splitk<false, true, false>(b, p, s) : launch_pw_splitk<false>(b, p, s);
     dim3 grid((unsigned)((l + 255) / 256), 1, b);
     if (cout > 32) {
         if (ab_in != nullptr) {

@@ -1054,6 +1054,20 @@ def test_split_k_dense_layers_close_to_the_bit_exact_chain(device, b, cin, cout,
         assert float((out_got - out_ref).abs().max()) <= 1e-5 * max(float(out_ref.abs().max()), 1.0)
 
 
+def test_split_k_head_output_layer(device):
+    """A head's last layer (256 -> 3, GroupNorm + ReLU on load, no statistics) in the split-k form against the chain form: 1e-5."""
+    from captra_amd import fused
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(1, 256, 4096, generator=g).to(device)
+    lin = fused.pack((torch.randn(256, 3, generator=g) / 16).to(device), torch.randn(3, generator=g).to(device))
+    ab = torch.stack([torch.rand(1, 256, generator=g) + 0.5, torch.randn(1, 256, generator=g) * 0.3], -1).to(device).contiguous()
+    ref = fused.pointwise_mlp_gn(x, lin, ab, fused.ACT_NONE, False)
+    with fused.split_k(True):
+        got = fused.pointwise_mlp_gn(x, lin, ab, fused.ACT_NONE, False)
+    assert got.shape == ref.shape == (1, 3, 4096) and not torch.equal(got, ref)
+    assert float((got - ref).abs().max()) <= 1e-5 * max(float(ref.abs().max()), 1.0)
+
+
 @pytest.mark.parametrize("cin,cout,l,batch,with_ab", [(128, 512, 4096, 1, False), (512, 256, 4096, 1, True), (512, 512, 1000, 2, True), (130, 96, 75, 3, False)])
 def test_split_k_gn_chain_layers(device, cin, cout, l, batch, with_ab):
     """The GroupNorm-chain layers (relu(a x + b) on load, raw-output statistics per 32-column tile) in the split-k form against the
