@@ -1034,7 +1034,9 @@ extern "C" int captra_pointwise_mlp_gn(int b, int cin, int cout, long long l, co
     p.y = y; p.act = act; p.ab_in = ab_in; p.stats_out = stats_out; p.stats_t = stats_t; p.dbg = g_pw_dbg;
     hipStream_t s = (hipStream_t)stream;
     const long long waves22 = ((l + 63) / 64) * ((cout + 63) / 64) * b;
-    if (cout > 64 && waves22 < 2048) {
+    // (the same rule as captra_pointwise_mlp_gn_tiles: under captra_pw_set_splitk every launch within its position limit takes the
+    // 32-column statistics tiles, split-k or -- fewer than 128 input channels -- the 32x32 chain form)
+    if (cout > 64 && (waves22 < 2048 || (g_pw_splitk > 0 && (long long)b * l <= g_pw_splitk))) {
         // few positions (single-trajectory latency): 32x32 wave tiles, statistics per 32-column tile
         if (stats_out != nullptr && stats_t != (int)((l + 63) / 64) * 2) return -1;
         if (pw_use_splitk(b, p)) {
@@ -1089,7 +1091,8 @@ extern "C" int captra_pointwise_mlp_gn(int b, int cin, int cout, long long l, co
 
 extern "C" int captra_pointwise_mlp_gn_tiles(int b, int cout, long long l) {
     const long long waves22 = ((l + 63) / 64) * ((cout + 63) / 64) * b;
-    return (cout > 64 && waves22 < 2048) ? (int)((l + 63) / 64) * 2 : (int)((l + 127) / 128) * 2;
+    const bool splitk = g_pw_splitk > 0 && (long long)b * l <= g_pw_splitk;       // (the split-k form: 32-column tiles; cin >= 128 is the caller's layer)
+    return (cout > 64 && (waves22 < 2048 || splitk)) ? (int)((l + 63) / 64) * 2 : (int)((l + 127) / 128) * 2;
 }
 
 extern "C" int captra_gn_finalize(int b, int c, int channels_per_group, int stats_t, long long n, float eps,

@@ -60,7 +60,7 @@ def canonicalize(pts, mean, rot, trans, scale, num_parts: int = 1, want_cn=True,
 
 
 SPLIT_K_MAX_TRAJECTORIES = int(os.environ.get("CAPTRA_SPLIT_K_TRAJ", "2"))   # 0 = every dense layer the k-ascending chain at every batch
-SPLIT_K_POSITIONS = int(os.environ.get("CAPTRA_SPLIT_K_POSITIONS", "4096"))    # launches of at most this many positions (b * l) split k
+SPLIT_K_POSITIONS = int(os.environ.get("CAPTRA_SPLIT_K_POSITIONS", "8192"))    # launches of at most this many positions (b * l) split k
 _split_k_on = False
 
 
