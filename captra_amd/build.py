@@ -76,7 +76,11 @@ def _stale(target: Path, deps: list[Path]) -> bool:
 MAX_ILP = ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]
 # sa_bf16.hip (round 5): the level-1 stream kernel's sampler rounds are 173 instructions with it and 200 (31 s_nop) without: 250 vs 274 us
 # for the 511 rounds; the bf16 SA scales in the same file do not move (same-box A/B of two builds)
-PER_SOURCE_FLAGS = {"sa_fused.hip": MAX_ILP, "mlp_chain.hip": MAX_ILP, "fps.hip": MAX_ILP, "sa_bf16.hip": MAX_ILP}
+# sa_x6.hip / dense_x6.hip: no SLP vectorisation -- packed fp32 VALU (v_pk_add_f32) beside MFMAs costs more than the two scalar
+# instructions it replaces (MI355X_MICROARCH.md "price of one filler beside MFMAs"); the operand split is written on scalars on purpose
+NO_SLP = ["-fno-slp-vectorize"]
+PER_SOURCE_FLAGS = {"sa_fused.hip": MAX_ILP, "mlp_chain.hip": MAX_ILP, "fps.hip": MAX_ILP, "sa_bf16.hip": MAX_ILP, "sa_x6.hip": NO_SLP,
+                    "dense_x6.hip": NO_SLP}
 
 
 def _compile_one(src: Path, force: bool, verbose: bool) -> Path:

@@ -197,7 +197,7 @@ def pack(wt_dense, bias_dense) -> PackedLinear:
 # BASELINE.json configs[2]; opt-in).  NOT process-global: a per-thread setting, normally entered by the model that owns it
 # (EvalTrackModel(cfg['mlp_dtype']) wraps its step in `use_mlp_dtype`), so two models / two host threads never see each
 # other's mode.
-MLP_DTYPES = ("fp32", "bf16")
+MLP_DTYPES = ("fp32", "bf16", "f32x6")
 _TLS = threading.local()
 
 
@@ -781,6 +781,55 @@ def sa_first_layer_pre(feat, lin: PackedLinear):
 
 
 USE_SA_PIPE = True       # SA2 scales on the pipelined kernel (csrc/sa_pipe.hip); False = sa_wave_kernel<..., PRE> (A/B, tests)
+
+
+# ---- f32x6: fp32-equivalent arithmetic on the bf16 matrix pipe (csrc/sa_x6.hip, csrc/dense_x6.hip) -------------------------------------
+# cfg['mlp_dtype'] = "f32x6": every operand of the wide shared-MLP layers is a three-way bf16 split (exact), six bf16 MFMAs per k-step,
+# fp32 accumulation.  Not bit-identical to the exact fmaf chain (fp32-roundoff-sized differences: tests/test_x6_gpu.py), 16 / 6 of
+# its matrix-pipe rate.  Layers without an f32x6 kernel run the exact fp32 path.
+_SA_X6_SHAPES = {(0, 32, 32, 64), (0, 64, 64, 128), (0, 64, 96, 128), (3, 32, 32, 64), (3, 64, 64, 128), (3, 64, 96, 128),
+                 (320, 128, 128, 256), (320, 128, 196, 256)}      # csrc/sa_x6.hip SX_CASE list
+USE_SA_X6 = os.environ.get("CAPTRA_SA_X6", "1") != "0"
+
+
+def sa_scale_x6_supported(cfeat, layers, k) -> bool:
+    return (USE_SA_X6 and mlp_dtype() == "f32x6" and len(layers) == 3 and k % 32 == 0
+            and (cfeat, layers[0].cout, layers[1].cout, layers[2].cout) in _SA_X6_SHAPES)
+
+
+def sa_x6_image(layers, cfeat: int, pre: bool) -> torch.Tensor:
+    """The weight image of one SA scale for captra_sa_scale_x6 (layers 2 / 3 as three-way bf16 split fragments + the fp32 biases),
+    built once on the device and cached with the scale's first layer."""
+    l1, l2, l3 = layers
+    key = ("sa_x6_img", cfeat, pre, id(l2), id(l3))
+    cache = l1._bf16
+    if key not in cache:
+        nbytes = L.lib().captra_sa_x6_image_bytes(cfeat, l1.cout, l2.cout, l3.cout)
+        img = torch.empty(nbytes, dtype=torch.uint8, device=l1.wt.device)
+        with torch.cuda.device(l1.wt.device):
+            L.call("captra_pack_sa_x6", cfeat, l1.cout, l2.cout, l3.cout, None if pre else L.ptr(l1.bias), L.ptr(l2.wt), L.ptr(l2.bias),
+                   L.ptr(l3.wt), L.ptr(l3.bias), L.ptr(img))
+        cache[key] = (img, l2, l3)          # the key holds ids: keep the layers it was built from alive with it
+    return cache[key][0]
+
+
+def sa_scale_x6(feat, xyz_cn, new_xyz_n3, idx, layers, out, co_off):
+    """One SA scale in the f32x6 arithmetic (captra_sa_scale_x6); wide inputs go through the pre-transformed first layer (exact fp32,
+    point-major, once per source point)."""
+    l1, l2, l3 = layers
+    B, _, N = xyz_cn.shape
+    _, M, K = idx.shape
+    cfeat = 0 if feat is None else feat.shape[1]
+    pre = cfeat + 3 > 6
+    src = sa_first_layer_pre_pm(feat, l1) if pre else feat
+    img = sa_x6_image(layers, cfeat, pre)
+    L.require_device(xyz_cn, new_xyz_n3, idx, out)
+    with torch.cuda.device(xyz_cn.device):
+        L.call("captra_sa_scale_x6", B, N, M, K, cfeat, l1.cout, l2.cout, l3.cout, 1 if pre else 0, L.ptr(src),
+               L.ptr(xyz_cn), L.ptr(new_xyz_n3), L.ptr(idx), L.ptr(l1.wt), L.ptr(img), L.ptr(out), out.shape[1], co_off)
+    _work("sa_scale_fused", flops=2.0 * B * M * K * ((3 if pre else cfeat + 3) * l1.cout + l1.cout * l2.cout + l2.cout * l3.cout),
+          nbytes=4.0 * B * ((l1.cout if pre else cfeat) * N + 3 * N + M * K + 3 * M + l3.cout * M))
+    return out
 
 
 def sa_scale_pipe_supported(cfeat, layers, m: int, k: int, b: int = 1, n: int = 1) -> bool:

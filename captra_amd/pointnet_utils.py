@@ -254,6 +254,10 @@ class PointNetSetAbstractionMsg(_FoldCache, nn.Module):
 
     def _forward_scales(self, folded, idx_list, feat, xyz_cn, new_xyz_n3, out, off, B):
         for layers, idx in zip(folded, idx_list):
+            if fused.sa_scale_x6_supported(0 if feat is None else feat.shape[1], layers, idx.shape[2]):
+                fused.sa_scale_x6(feat, xyz_cn, new_xyz_n3, idx, layers, out, off)      # cfg['mlp_dtype'] = "f32x6"
+                off += layers[-1].cout
+                continue
             if fused.sa_scale_bf16_supported(0 if feat is None else feat.shape[1], layers, idx.shape[2]):
                 fused.sa_scale_bf16(feat, xyz_cn, new_xyz_n3, idx, layers, out, off)
                 off += layers[-1].cout

@@ -235,6 +235,27 @@ int captra_sa_scale_bf16(int b, int n, int m, int k, int cfeat, int c1, int c2, 
                          const float *xyz_cn, const float *new_xyz, const int *idx, const unsigned char *img, float *out,
                          int out_ctotal, int co_off, captra_stream_t stream);
 
+/* f32x6: fp32-EQUIVALENT shared MLPs on the bf16 matrix pipe (opt-in arithmetic `mlp_dtype = "f32x6"`; the default path stays the
+ * exact fp32 fmaf chain).  Replaces, like the kernels above, the fp32 Conv2d 1x1 + BN + ReLU stacks of
+ * network/models/pointnet_utils.py:242-249 and blocks.py:118-135,168-193.  Every operand v is held as three bf16 numbers
+ * v0 = bf16(v), v1 = bf16(v - v0), v2 = bf16(v - v0 - v1) (RNE; v = v0 + v1 + v2 exactly for normal fp32 v) and a layer is
+ *     y = act(b + sum_k [w0 x0 + w0 x1 + w1 x0 + w1 x1 + w0 x2 + w2 x0]_k),
+ * six v_mfma_f32_32x32x16_bf16 per 16-wide k-step, products exact, fp32 accumulation: the three dropped products are <= 2^-24 |w x|
+ * each, so results differ from the exact chain by fp32-roundoff-sized terms (<= 2e-6 of a layer's largest output,
+ * tests/test_x6_gpu.py) -- NOT bit for bit -- at 16 / 6 of the fp32 matrix-pipe rate.
+ *   captra_sa_scale_x6 (csrc/sa_x6.hip): one SA scale, register-resident, as captra_sa_scale_bf16.  img: built once per scale by
+ *     captra_pack_sa_x6 (captra_sa_x6_image_bytes bytes) from the packed fp32 buffers of layers 2 / 3 (split fragment triples, k order
+ *     of the in-register hand-over) followed by the fp32 biases b1 (zeros when b1_packed is NULL), b2, b3.  w1_packed: the first
+ *     layer's packed fp32 buffer -- its 3..6 xyz / feature rows run on the exact v_mfma_f32_32x32x2_f32.  pre = 0: feat_or_v1 = feat
+ *     (B,cfeat,N) fp32 or NULL (cfeat = 0), cfeat + 3 <= 6; pre = 1: feat_or_v1 = v1 (B,N,c1) fp32 POINT-major = b1 + W1[feature rows] feat
+ *     (captra_pointwise_mlp_pm, exact).  k % 32 == 0.  Instantiated for the CAPTRA backbone shapes; -2 otherwise. */
+long long captra_sa_x6_image_bytes(int cfeat, int c1, int c2, int c3);
+int captra_pack_sa_x6(int cfeat, int c1, int c2, int c3, const float *b1_packed, const float *wt2_packed, const float *b2_packed,
+                      const float *wt3_packed, const float *b3_packed, unsigned char *img, captra_stream_t stream);
+int captra_sa_scale_x6(int b, int n, int m, int k, int cfeat, int c1, int c2, int c3, int pre, const float *feat_or_v1,
+                       const float *xyz_cn, const float *new_xyz, const int *idx, const float *w1_packed, const unsigned char *img,
+                       float *out, int out_ctotal, int co_off, captra_stream_t stream);
+
 /* bf16-NATIVE dense layers (csrc/dense_bf16.hip): activations in HBM as bf16, POINT-major (B,L,ceil32(C)), channels in SLOT
  * ORDER (inside every aligned block of 16 channels memory slot s holds channel perm[s] = {0,1,2,3,8,9,10,11,4,5,6,7,12,13,14,15},
  * the order in which a 32x32 MFMA accumulator tile hands its rows to a lane; padding channels are zero).  Same per-layer

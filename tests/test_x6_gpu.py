@@ -1,0 +1,66 @@
+"""GPU parity of the f32x6 arithmetic (cfg['mlp_dtype'] = "f32x6": three-way bf16 split of both operands, six bf16 MFMAs per
+k-step, fp32 accumulation -- csrc/sa_x6.hip, csrc/dense_x6.hip) against the oracle's exact k-ascending fmaf chain.
+
+The mode is NOT bit-identical to the exact chain; the contract (include/captra_hip.h "f32x6") is fp32-roundoff-sized differences:
+every kernel's output within 2e-6 of the layer's largest output of the exact chain, and -- one level up -- the reference-generated
+goldens within the same 1e-4 the exact path is held to (tests/test_x6_model_gpu.py)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ops as O
+
+pytestmark = pytest.mark.gpu
+X6_TOL = 2e-6          # of the output's largest magnitude
+
+
+def _dev(a, device):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+
+
+def _rel(got, ref):
+    return float(np.abs(got.astype(np.float64) - ref).max() / np.abs(ref).max())
+
+
+def _sa_case(rng, cfeat, chans, n, m, k, B):
+    xyz_cn = (rng.random((B, 3, n), dtype=np.float32) - 0.5)
+    feat = rng.standard_normal((B, cfeat, n)).astype(np.float32) if cfeat else None
+    new_xyz = (rng.random((B, m, 3), dtype=np.float32) - 0.5)
+    idx = rng.integers(0, n, (B, m, k)).astype(np.int32)
+    dims = (cfeat + 3,) + chans
+    layers = [((rng.standard_normal((dims[i], dims[i + 1])) / np.sqrt(dims[i])).astype(np.float32),
+               rng.standard_normal(dims[i + 1]).astype(np.float32)) for i in range(3)]
+    return xyz_cn, feat, new_xyz, idx, layers
+
+
+@pytest.mark.parametrize("cfeat,chans,n,m,k,B", [
+    (0, (32, 32, 64), 4096, 512, 32, 2), (3, (32, 32, 64), 300, 37, 32, 3),
+    (0, (64, 64, 128), 4096, 512, 64, 2), (3, (64, 64, 128), 1000, 130, 64, 2),
+    (0, (64, 96, 128), 4096, 512, 128, 2), (3, (64, 96, 128), 700, 41, 128, 3),
+    (320, (128, 128, 256), 512, 128, 64, 2), (320, (128, 128, 256), 333, 37, 32, 2),
+    (320, (128, 196, 256), 512, 128, 128, 2), (320, (128, 196, 256), 512, 128, 128, 5),
+    (320, (128, 196, 256), 200, 6, 64, 3), (320, (128, 196, 256), 700, 1, 128, 1),
+    (320, (128, 128, 256), 512, 128, 64, 33)])
+def test_sa_scale_x6_vs_exact_chain(device, cfeat, chans, n, m, k, B):
+    """One SA scale in the f32x6 arithmetic == the oracle's gather -> 3 x (conv + BN + ReLU) -> max in the exact fmaf chain within
+    2e-6 of the largest output: every instantiated shape, one / two / four slices per centre, centre counts that do not fill a
+    workgroup's waves, batches below and above the chip, channel offsets in the output (neighbouring channels untouched)."""
+    from captra_amd import fused
+    rng = np.random.default_rng(sum(chans) + n + k + B + cfeat)
+    xyz_cn, feat, new_xyz, idx, layers = _sa_case(rng, cfeat, chans, n, m, k, B)
+    packed = [fused.pack(_dev(w, device), _dev(b, device)) for w, b in layers]
+    with fused.use_mlp_dtype("f32x6"):
+        assert fused.sa_scale_x6_supported(cfeat, packed, k)
+        out = torch.full((B, chans[2] + 9, m), -1.0, device=device)
+        fused.sa_scale_x6(None if feat is None else _dev(feat, device), _dev(xyz_cn, device), _dev(new_xyz, device), _dev(idx, device),
+                          packed, out, 4)
+    x = O.sa_group(feat, xyz_cn, new_xyz, idx)
+    for w, b in layers:
+        x = O.pointwise_mlp(x, w, b, 1)
+    ref = O.max_over_k(x)
+    got = out.cpu().numpy()
+    assert (got[:, :4] == -1).all() and (got[:, 4 + chans[2]:] == -1).all()
+    err = _rel(got[:, 4:4 + chans[2]], ref)
+    assert err <= X6_TOL, err
+    # a plain bf16 product would be four orders of magnitude away: the tolerance is a statement about the split, not slack
+    assert err < 1e-5
