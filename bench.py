@@ -467,7 +467,7 @@ def config_leg(name: str, extra: list, timeout_s: int = 120):
     if res.returncode != 0 or not lines:
         return {"error": (res.stderr or res.stdout)[-500:], "command": " ".join(cmd[1:])}
     d = json.loads(lines[-1])
-    keep = ("metric", "value", "unit", "ms_per_step", "dtype", "steps", "roofline", "kernel_ms_per_step", "timed_blocks", "one_graph", "l1_stream")
+    keep = ("metric", "value", "unit", "ms_per_step", "dtype", "steps", "roofline", "kernel_ms_per_step", "timed_blocks", "one_graph", "l1_stream", "pose_match")
     out = {k: d[k] for k in keep if k in d}
     # compact (the main line has to fit the driver's 8 KB tail): what the leg ran is its command; the numbers stay
     out.pop("config", None)
@@ -475,6 +475,8 @@ def config_leg(name: str, extra: list, timeout_s: int = 120):
         out["timed_blocks"] = {k: out["timed_blocks"][k] for k in ("n", "ms_per_step_min", "ms_per_step_max") if k in out["timed_blocks"]}
     if isinstance(out.get("roofline"), dict):
         out["roofline"] = {k: out["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_measured", "avg_launch_us", "flops_per_launch", "share_of_kernel_time") if k in out["roofline"]}
+    if isinstance(out.get("pose_match"), dict):
+        out["pose_match"] = {k: out["pose_match"][k] for k in ("trajectories", "max_abs_dR", "max_abs_dt", "max_abs_ds", "agree_5deg5cm", "within_1e-4") if k in out["pose_match"]}
     if isinstance(out.get("kernel_ms_per_step"), dict):
         top = sorted(((k, v) for k, v in out["kernel_ms_per_step"].items() if not k.startswith("_")), key=lambda kv: -kv[1])[:5]
         out["kernel_ms_per_step"] = dict(top, _sum=out["kernel_ms_per_step"].get("_sum_captra_kernels"))
@@ -670,9 +672,11 @@ def main():
     ap.add_argument("--no-overlap", action="store_true",
                     help="run CoordinateNet and RotationNet one after the other instead of side by side on two streams (what the "
                          "per-kernel timing pass and the rocprofv3 recipes use: isolated kernel durations)")
-    ap.add_argument("--mlp-dtype", default="fp32", choices=["fp32", "bf16"],
+    ap.add_argument("--mlp-dtype", default="fp32", choices=["fp32", "bf16", "f32x6"],
                     help="fp32 = the metric's configuration (exact); bf16 = bf16 MFMA operands / fp32 accumulation for the shared "
-                         "MLPs (BASELINE.json configs[2]'s arithmetic) -- reported with dtype \"bf16\", not the headline")
+                         "MLPs (BASELINE.json configs[2]'s arithmetic) -- reported with dtype \"bf16\", not the headline; f32x6 = three-way "
+                         "bf16 split of both operands, six bf16 MFMAs per k-step, fp32 accumulation (fp32-equivalent: <= 2e-6 of the exact "
+                         "chain per layer) -- reported with dtype \"f32x6\", not the headline")
     ap.add_argument("--category", default="bottle", choices=sorted(WORKLOADS) + ["mix6"],
                     help="bottle = BASELINE.json configs[1] (the metric's configuration); the other object classes; mix6 = "
                          "BASELINE.json configs[2]'s serving mix: rank r tracks NOCS category 1 + r mod 6 with that category's weights")
@@ -686,7 +690,8 @@ def main():
         print(json.dumps(launch_plan(args.gpus)))
         return
     if args.leg:
-        args.no_cpu_baseline = args.no_otf = args.no_b1 = args.no_legs = args.no_pose_match = True
+        args.no_cpu_baseline = args.no_otf = args.no_b1 = args.no_legs = True
+        args.no_pose_match = args.mlp_dtype != "f32x6"          # (the f32x6 leg carries its own pose_match: the mode's claim is accuracy + speed)
         args.min_timed_s = min(args.min_timed_s, 2.0)
         args.repeats = min(args.repeats, 5)
     if not torch.cuda.is_available():
@@ -873,10 +878,10 @@ def main():
     out = {
         "metric": "tracked frames/sec (4096-pt clouds)", "value": round(frames / elapsed, 2), "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.mlp_dtype == "fp32" else "bf16",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": {"fp32": "f32", "bf16": "bf16", "f32x6": "f32x6"}[args.mlp_dtype],
         "data": "synthetic",
         "config": {"workload": f"{WORKLOADS[args.category][3]}, 4096 pts/frame, batch={B} trajectories per GPU, "
-                               + ("fp32" if args.mlp_dtype == "fp32" else "bf16 MFMA operands / fp32 accumulation in the shared MLPs (BASELINE.json configs[2]'s arithmetic; NOT the metric's configuration)")
+                               + ("fp32" if args.mlp_dtype == "fp32" else "f32x6: three-way bf16 split operands, six bf16 MFMAs per k-step, fp32 accumulation in the SA scales and the rotation heads' dense layers, exact fp32 elsewhere (opt-in; NOT the metric's configuration)" if args.mlp_dtype == "f32x6" else "bf16 MFMA operands / fp32 accumulation in the shared MLPs (BASELINE.json configs[2]'s arithmetic; NOT the metric's configuration)")
                                + (" (BASELINE.json configs[2]'s mix: rank r serves NOCS category 1 + r mod 6; rank 0's workload named here)" if getattr(args, "mix6", False)
                                   else " (BASELINE.json configs[1])" if args.category == "bottle" and args.mlp_dtype == "fp32" else " (BASELINE.json configs[3]: drawers)" if args.category == "drawers" else ""),
                    "points": 4096, "trajectories_per_gpu": B, "distinct_clouds_per_gpu": B,
@@ -914,23 +919,26 @@ def main():
         # (pointwise_mlp.hip: pointwise_mlp / sa_group_mlp / mlp_max entry points)
         # (the level-1 stream kernel's MLPs are timed with its sampler -- a latency-bound launch -- and stay out of the family)
         mlp = ["sa_scale_fused", "pointwise_mlp", "mlp_chain3", "coord_tail", "sa_group_mlp", "mlp_max", "neck_chain"]
+        if args.mlp_dtype == "f32x6":
+            # the mode's own kernels (csrc/sa_x6.hip, csrc/dense_x6.hip) against the bf16 peak / 6: six bf16 MFMAs per fp32-equivalent product
+            mlp = ["sa_scale_x6", "pointwise_mlp_x6"]
         mlp_ms = sum(fams[k]["ms_total"] for k in mlp if k in fams)
         mlp_launches = sum(fams[k]["launches"] for k in mlp if k in fams)
         mlp_flops = sum(fused.WORK["flops"].get(k, 0.0) for k in mlp)
         dominant = max(fams, key=lambda k: fams[k]["ms_total"]) if fams else None
         if mlp_ms > 0:
             ach = mlp_flops / (mlp_ms * 1e-3) / 1e12
-            peak = PEAK_F32_MFMA_TFLOPS if args.mlp_dtype == "fp32" else PEAK_BF16_MFMA_TFLOPS
+            peak = PEAK_F32_MFMA_TFLOPS if args.mlp_dtype == "fp32" else round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1) if args.mlp_dtype == "f32x6" else PEAK_BF16_MFMA_TFLOPS
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                                "frac": round(ach / peak, 4), "traffic": None,
                                "kernel": ("fp32 MFMA shared-MLP family: sa_wave_pipe_kernel (SA2 scales, dominant) + sa_wave_lds_kernel (SA1) + mlp_chain3_kernel + coord_tail_kernel + pw_direct_kernel"
-                                          if args.mlp_dtype == "fp32" else "bf16 MFMA family: sa2_bf16_kernel / sa_bf16_kernel + tb_head12p_kernel / tb_layer_kernel + chain_bf16_kernel + pw_bf16_kernel (the level-1 stream kernel's MLPs are timed with its sampler and not counted here)"),
+                                          if args.mlp_dtype == "fp32" else "f32x6 family: sa_x6_kernel (SA1 / SA2 scales) + dense_x6_kernel (rotation heads' 128 -> 512 -> 512 -> 256); fp32-equivalent flops against the bf16 MFMA peak / 6; the layers left on the exact fp32 kernels are not counted" if args.mlp_dtype == "f32x6" else "bf16 MFMA family: sa2_bf16_kernel / sa_bf16_kernel + tb_head12p_kernel / tb_layer_kernel + chain_bf16_kernel + pw_bf16_kernel (the level-1 stream kernel's MLPs are timed with its sampler and not counted here)"),
                                "avg_launch_us": round(1e3 * mlp_ms / max(mlp_launches, 1), 2),
                                "flops_per_launch": round(mlp_flops / max(mlp_launches, 1)),
                                "share_of_kernel_time": round(mlp_ms / max(total_ms, 1e-9), 3), "dominant_family": dominant}
             # the counter file of THIS configuration (tools/profile_round.sh <tag> <suffix> ...): bf16 / drawers have their own
-            sfx = ("_bf16" if args.mlp_dtype != "fp32" else "") + ("_drawers" if args.category == "drawers" else "")
-            mlp_prefixes = (["sa_bf16_kernel", "sa2_bf16_kernel", "tb_layer_kernel", "tb_head12_kernel", "tb_head12p_kernel", "neck_chain_kernel", "chain_bf16_kernel", "pw_bf16pm_kernel", "pw_bf16pm_affs_kernel", "pw_bf16_kernel"]
+            sfx = ("_f32x6" if args.mlp_dtype == "f32x6" else "_bf16" if args.mlp_dtype != "fp32" else "") + ("_drawers" if args.category == "drawers" else "")
+            mlp_prefixes = (["sa_x6_kernel", "dense_x6_kernel"] if args.mlp_dtype == "f32x6" else ["sa_bf16_kernel", "sa2_bf16_kernel", "tb_layer_kernel", "tb_head12_kernel", "tb_head12p_kernel", "neck_chain_kernel", "chain_bf16_kernel", "pw_bf16pm_kernel", "pw_bf16pm_affs_kernel", "pw_bf16_kernel"]
                             if args.mlp_dtype != "fp32" else
                             ["sa_wave_kernel", "sa_wave_lds_kernel", "sa_wave_pipe_kernel", "sa_fused_kernel", "mlp_chain3_kernel", "coord_tail_kernel", "pw_direct_kernel", "pw_direct_max_kernel", "pw_mlp_kernel"])
             traffic, src, why = pmc_traffic(mlp_prefixes, sfx)
@@ -971,8 +979,9 @@ def main():
             out["roofline"]["hbm_ops"] = {"frac": h["frac"], "sequence_frac": h["sequence"]["frac"], "per_level_frac": h["per_level"]["frac"],
                                           "query_and_group_frac": h["query_and_group"]["frac"], "query_and_group_sequence_frac": h["query_and_group"]["sequence_frac"],
                                           "peak_GB/s": PEAK_HBM_GBS}
-    if not args.no_pose_match and args.mlp_dtype == "fp32":
-        out["pose_match"] = pose_match(cfg, sd, data[last_frame], prev_pose, last_pose)
+    if not args.no_pose_match and args.mlp_dtype in ("fp32", "f32x6"):
+        # one trajectory of EACH lane (lanes are contiguous halves of the batch): the first and the last
+        out["pose_match"] = pose_match(cfg, sd, data[last_frame], prev_pose, last_pose, which=(0, B - 1) if B > 1 else (0,))
     if world == 1 and not args.no_otf and args.mlp_dtype == "fp32" and args.category == "bottle":
         # in a process of its own, as the tracker is run (`python -m captra_amd.track --nocs_otf True`): which hardware queues
         # the loop's streams get depends on how many streams the process has created before, and
@@ -988,7 +997,8 @@ def main():
         out["b1"] = json.loads(lines[-1]) if res.returncode == 0 and lines else {"error": (res.stderr or res.stdout)[-500:]}
     if world == 1 and not args.no_legs and args.mlp_dtype == "fp32" and args.category == "bottle":
         # BASELINE.json configs[2] (arithmetic), [3] and [4], each measured by this run in a process of its own
-        out["legs"] = {"bf16": config_leg("bf16", ["--mlp-dtype", "bf16", "--batch", str(B)]),
+        out["legs"] = {"f32x6": config_leg("f32x6", ["--mlp-dtype", "f32x6", "--batch", str(B)]),
+                       "bf16": config_leg("bf16", ["--mlp-dtype", "bf16", "--batch", str(B)]),
                        "drawers": config_leg("drawers", ["--category", "drawers", "--batch", str(B)]),
                        "backbone16k": config_leg("backbone16k", [])}
     fam = out.pop("_traffic_family", None)

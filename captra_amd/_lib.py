@@ -66,6 +66,8 @@ _SIGNATURES = {
     "captra_pack_sa_bf16": [_INT] * 5 + [_P] * 7 + [_P],
     "captra_sa_scale_bf16": [_INT] * 9 + [_P] * 6 + [_INT, _INT, _P],
     "captra_pack_sa_x6": [_INT] * 4 + [_P] * 6 + [_P],
+    "captra_pack_dense_x6": [_INT, _INT, _P, _P, _P],
+    "captra_pointwise_mlp_x6": [_INT, _INT, _INT, _LL, _P, _P, _P, _P, _INT, _P, _P, _INT, _P],
     "captra_sa_scale_x6": [_INT] * 9 + [_P] * 7 + [_INT, _INT, _P],
     "captra_query_and_group": [_INT, _INT, _INT, _F, _INT, _INT, _INT, _P, _P, _P, _P, _P, _P],
     "captra_neck_chain_bf16": [_INT, _INT, _LL, _INT, _P, _P, _P, _INT, _P, _P, _P, _P, _INT, _P, _P, _INT, _INT, _P, _P],
@@ -146,6 +148,9 @@ def lib():
         if hasattr(l, "captra_chain_bf16_image_bytes"):
             l.captra_chain_bf16_image_bytes.argtypes = [_INT, _INT]
             l.captra_chain_bf16_image_bytes.restype = _LL
+        if hasattr(l, "captra_dense_x6_image_bytes"):
+            l.captra_dense_x6_image_bytes.argtypes = [_INT, _INT]
+            l.captra_dense_x6_image_bytes.restype = _LL
         if hasattr(l, "captra_sa_x6_image_bytes"):
             l.captra_sa_x6_image_bytes.argtypes = [_INT] * 4
             l.captra_sa_x6_image_bytes.restype = _LL

@@ -1,0 +1,289 @@
+// f32x6 dense layer for gfx950: y = act(W x' + b) over (B, cin, L) -> (B, cout, L) with every product on
+// v_mfma_f32_32x32x16_bf16 as six bf16 products of three-way splits (arithmetic contract: include/captra_hip.h "f32x6", csrc/sa_x6.hip),
+// for the Conv1d -> GroupNorm -> ReLU chains of the rotation heads (reference network/models/blocks.py:150-165, 168-193):
+// x' = relu(a x + b) with the previous layer's per-(cloud, channel) GroupNorm coefficients applied while the operand is staged,
+// (sum, sum of squares) of the raw output per channel and 128 positions from the epilogue -- the interface of
+// captra_pointwise_mlp_gn (csrc/pointwise_mlp.hip), whose exact-fp32 kernels this replaces in the opt-in mode.
+//
+// Structure: a 256-position x 256-channel tile per workgroup of EIGHT waves (two per SIMD: one wave's operand split -- 70 VALU
+// per k-step -- runs under the other's MFMAs), a wave = 128 positions x 64 channels (128 accumulator registers).  k-steps of 16
+// channels through two LDS stages:
+//   weights   24 fragments (8 channel tiles x 3 parts) per k-step, LDS-DMA from the split image (captra_pack_dense_x6), three
+//             pieces per wave;
+//   positions every lane loads 8 channels of ONE position (dword loads, a wave = 2 rows x 128 B per instruction), applies the
+//             GroupNorm coefficients + ReLU, splits, and writes three 16-byte fragment slots: the fragment image is lane-linear
+//             both ways, no transposition anywhere.
+// The MFMAs are FLIPPED (positions = rows): a lane owns a channel, so the statistics are sums over its own registers and the
+// output leaves as 16-byte stores along the positions.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef int dx_i32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned dx_pack(float lo, float hi) {
+    const f32x2 f = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2));
+}
+__device__ __forceinline__ float dx_lo(unsigned p) { return __uint_as_float(p << 16); }
+__device__ __forceinline__ float dx_hi(unsigned p) { return __uint_as_float(p & 0xffff0000u); }
+__device__ __forceinline__ void dx_split2(float a, float b, unsigned &p0, unsigned &p1, unsigned &p2) {
+    p0 = dx_pack(a, b);
+    const float ra = a - dx_lo(p0), rb = b - dx_hi(p0);
+    p1 = dx_pack(ra, rb);
+    p2 = dx_pack(ra - dx_lo(p1), rb - dx_hi(p1));
+}
+__device__ __forceinline__ f32x16 dx_mfma(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+constexpr int DX_TP = 256, DX_TC = 256;                // positions / channels per workgroup
+constexpr int DX_ASTAGE = 24 * 1024, DX_BSTAGE = 24 * 1024, DX_STAGE = DX_ASTAGE + DX_BSTAGE;
+constexpr int DX_LDS = 2 * DX_STAGE;                   // + the coefficient table (cin x 8 bytes) behind it
+
+// ---- weight image: [channel block of 256][k-step][channel tile 0..7][part 0..2] fragments of 1 KiB; fragment lane l = channel
+// 256 cb + 32 t + (l & 31), k-slots 8 (l >> 5) .. + 7 = input channels 16 kk + 8 (l >> 5) + e (natural order) -------------------
+__global__ void pack_dense_x6_kernel(int cin, int cout, int ldw, const float *__restrict__ wt, unsigned char *__restrict__ img) {
+    const int kst = (cin + 15) / 16, ncb = (cout + DX_TC - 1) / DX_TC;
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long long)ncb * kst * 24 * 512) return;
+    const int el = (int)e & 7, lane = (int)(e >> 3) & 63;
+    const long long f = e >> 9;
+    const int part = (int)(f % 3), t = (int)((f / 3) % 8), kk = (int)((f / 24) % kst), cb = (int)(f / (24ll * kst));
+    const int ch = DX_TC * cb + 32 * t + (lane & 31), k = 16 * kk + 8 * (lane >> 5) + el;
+    const float v = (ch < cout && k < cin) ? wt[(size_t)k * ldw + ch] : 0.f;
+    const __bf16 h0 = (__bf16)v;
+    const float r1 = v - (float)h0;
+    const __bf16 h1 = (__bf16)r1;
+    const __bf16 h2 = (__bf16)(r1 - (float)h1);
+    const __bf16 h = part == 0 ? h0 : (part == 1 ? h1 : h2);
+    reinterpret_cast<unsigned short *>(img)[e] = __builtin_bit_cast(unsigned short, h);
+}
+
+struct DxParams {
+    int b, cin, cout, l;
+    const float *x;             // (B,cin,L)
+    const unsigned char *wimg;  // captra_pack_dense_x6
+    const float *bias;          // packed bias (cout, zero padded)
+    const float *ab;            // (B,cin,2) or null
+    int act;
+    float *y;                   // (B,cout,L)
+    float *stats;               // (B,cout,T,2), T = L / 128, or null
+    int npt, ncb;               // position tiles per cloud, channel blocks
+};
+
+#define DX_WAIT_VM(N) __builtin_amdgcn_s_waitcnt(((N) & 15) | (((N) >> 4) << 14) | 0x0F70)
+
+template <bool GN_IN, bool STATS>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void dense_x6_kernel(DxParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, col = lane & 31;
+    const int wm = wave & 3, wn = wave >> 2;            // this wave's 64-channel block / 128-position half of the tile
+    // workgroup -> (cloud, position tile, channel block): the channel blocks of one position tile are 8 workgroups apart, i.e. on
+    // the same XCD (workgroups go round the eight XCDs), so the second reading of a position tile's x is an L2 hit
+    const int per_cloud = p.npt * p.ncb;
+    const int bq = blockIdx.x / per_cloud, r = blockIdx.x - bq * per_cloud;
+    int pt, cb;
+    if (p.npt % 8 == 0) {
+        const int g = r / (8 * p.ncb), q = r - g * 8 * p.ncb;
+        cb = q >> 3; pt = g * 8 + (q & 7);
+    } else {
+        pt = r / p.ncb; cb = r - pt * p.ncb;
+    }
+    const int kst = p.cin >> 4;
+    const int p0 = pt * DX_TP;
+
+    const unsigned long long img_addr = reinterpret_cast<unsigned long long>(p.wimg) + (size_t)cb * kst * DX_ASTAGE;
+    const dx_i32x4 wsrc = {(int)(unsigned)img_addr, (int)(unsigned)(img_addr >> 32), kst * DX_ASTAGE, 0x00020000};
+    const unsigned lds0 = (unsigned)reinterpret_cast<size_t>((__attribute__((address_space(3))) unsigned char *)smem);
+    const unsigned voff16 = lane * 16;
+    // LDS-DMA of k-step kk's weight fragments into stage st: this wave's three pieces (asm: see csrc/sa_x6.hip)
+    auto issue_w = [&](int kk, int st) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const unsigned dst = lds0 + st * DX_STAGE + (wave * 3 + i) * 1024;
+            const unsigned soff = kk * DX_ASTAGE + (wave * 3 + i) * 1024;
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                         :: "s"(dst), "v"(voff16), "s"(wsrc), "s"(soff) : "memory");
+        }
+    };
+    // this lane's eight channels 16 kk + 8 h + (0..7) of position p0 + 32 wave + col
+    const float *xp = p.x + ((size_t)bq * p.cin + 8 * h) * p.l + p0 + 32 * wave + col;
+    auto load_x = [&](int kk, float (&xr)[8]) {
+        const float *q = xp + (size_t)16 * kk * p.l;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) xr[i] = q[(size_t)i * p.l];
+    };
+    float *abt = reinterpret_cast<float *>(smem + DX_LDS);
+    // GroupNorm coefficients + ReLU, split, three 16-byte fragment slots of position tile `wave`
+    auto stage_x = [&](int kk, int st, const float (&xr)[8]) {
+        float v[8];
+        if constexpr (GN_IN) {
+            const float4 *ap = reinterpret_cast<const float4 *>(abt + 2 * (16 * kk + 8 * h));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float4 c = ap[i];                 // (a, b) of two channels
+                v[2 * i] = relu_bits(__builtin_fmaf(c.x, xr[2 * i], c.y));        // (the exact kernels' form: csrc/pointwise_mlp.hip)
+                v[2 * i + 1] = relu_bits(__builtin_fmaf(c.z, xr[2 * i + 1], c.w));
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = xr[i];
+        }
+        u32x4 f0, f1, f2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            unsigned a0, a1, a2;
+            dx_split2(v[2 * i], v[2 * i + 1], a0, a1, a2);
+            f0[i] = a0; f1[i] = a1; f2[i] = a2;
+        }
+        unsigned char *bp = smem + st * DX_STAGE + DX_ASTAGE + wave * 3072 + lane * 16;
+        *reinterpret_cast<u32x4 *>(bp) = f0;
+        *reinterpret_cast<u32x4 *>(bp + 1024) = f1;
+        *reinterpret_cast<u32x4 *>(bp + 2048) = f2;
+    };
+
+    // ---- prologue -------------------------------------------------------------------------------------------------------------
+    if constexpr (GN_IN) {
+        const float *src = p.ab + (size_t)bq * p.cin * 2;
+        for (int e = tid; e < p.cin * 2; e += 512) abt[e] = src[e];
+    }
+    issue_w(0, 0);
+    float xr[8];
+    load_x(0, xr);
+    if constexpr (GN_IN) __syncthreads();
+    stage_x(0, 0, xr);
+    if (kst > 1) load_x(1, xr);
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) acc[tm][tn][rr] = 0.f;
+    DX_WAIT_VM(0);
+    __syncthreads();
+
+    // ---- k-steps ---------------------------------------------------------------------------------------------------------------
+#pragma unroll 1
+    for (int kk = 0; kk < kst; ++kk) {
+        const int st = kk & 1;
+        // the next k-step's operands: split what was loaded during the last phase, then ask for the k-step after it
+        if (kk + 1 < kst) {
+            stage_x(kk + 1, st ^ 1, xr);
+            if (kk + 2 < kst) load_x(kk + 2, xr);
+            issue_w(kk + 1, st ^ 1);
+        }
+        const unsigned char *ab_ = smem + st * DX_STAGE + lane * 16;
+        u32x4 wf[2][3];
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int s = 0; s < 3; ++s) wf[tm][s] = *reinterpret_cast<const u32x4 *>(ab_ + ((2 * wm + tm) * 3 + s) * 1024);
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) {
+            u32x4 xf[3];
+#pragma unroll
+            for (int s = 0; s < 3; ++s) xf[s] = *reinterpret_cast<const u32x4 *>(ab_ + DX_ASTAGE + ((4 * wn + tn) * 3 + s) * 1024);
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm) {
+                f32x16 a = acc[tm][tn];
+                a = dx_mfma(xf[0], wf[tm][2], a); a = dx_mfma(xf[2], wf[tm][0], a); a = dx_mfma(xf[1], wf[tm][1], a);
+                a = dx_mfma(xf[0], wf[tm][1], a); a = dx_mfma(xf[1], wf[tm][0], a); a = dx_mfma(xf[0], wf[tm][0], a);
+                acc[tm][tn] = a;
+            }
+        }
+        DX_WAIT_VM(0);                                  // this wave's weight pieces of the next k-step have landed ...
+        __syncthreads();                                // ... everybody's have, and everybody is done with this stage
+    }
+
+    // ---- epilogue: bias, activation, 16-byte stores along the positions; statistics of the raw output --------------------------
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+        const int ch = DX_TC * cb + 64 * wm + 32 * tm + col;
+        const float bias = p.bias[ch];
+        float s1 = 0.f, s2 = 0.f;
+        float *yp = p.y + ((size_t)bq * p.cout + ch) * p.l + p0 + 128 * wn + 4 * h;
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float4 v;
+                v.x = acc[tm][tn][4 * q + 0] + bias; v.y = acc[tm][tn][4 * q + 1] + bias;
+                v.z = acc[tm][tn][4 * q + 2] + bias; v.w = acc[tm][tn][4 * q + 3] + bias;
+                if constexpr (STATS) {
+                    s1 += (v.x + v.y) + (v.z + v.w);
+                    s2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+                }
+                v.x = apply_act(v.x, p.act); v.y = apply_act(v.y, p.act); v.z = apply_act(v.z, p.act); v.w = apply_act(v.w, p.act);
+                *reinterpret_cast<float4 *>(yp + 32 * tn + 8 * q) = v;
+            }
+        if constexpr (STATS) {
+            const auto w1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(s1), __float_as_uint(s1), false, false);
+            const auto w2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(s2), __float_as_uint(s2), false, false);
+            if (h == 0) {
+                const int T = p.l / 128;
+                float2 o;
+                o.x = __uint_as_float(w1[0]) + __uint_as_float(w1[1]);
+                o.y = __uint_as_float(w2[0]) + __uint_as_float(w2[1]);
+                *reinterpret_cast<float2 *>(p.stats + (((size_t)bq * p.cout + ch) * T + (p0 / 128 + wn)) * 2) = o;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" long long captra_dense_x6_image_bytes(int cin, int cout) {
+    if (cin < 1 || cout < 1) return -1;
+    return (long long)((cout + DX_TC - 1) / DX_TC) * ((cin + 15) / 16) * DX_ASTAGE;
+}
+
+// wt_packed: the layer's PACKED fp32 buffer (row-major part W'^T (cin, pad128(cout)))
+extern "C" int captra_pack_dense_x6(int cin, int cout, const float *wt_packed, unsigned char *img, captra_stream_t stream) {
+    if (cin < 1 || cout < 1 || wt_packed == nullptr || img == nullptr) return -1;
+    const long long n = captra_dense_x6_image_bytes(cin, cout) / 2;
+    CAPTRA_LAUNCH("pack_weights", pack_dense_x6_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, cin, cout,
+                  (cout + 127) / 128 * 128, wt_packed, img);
+    return captra_last_error();
+}
+
+// the stats_t captra_pointwise_mlp_x6 writes: one (sum, sum of squares) per channel and 128 positions
+extern "C" int captra_pointwise_mlp_x6_tiles(long long l) { return (int)(l / 128); }
+
+// As captra_pointwise_mlp_gn in the f32x6 arithmetic.  -2: shape outside the kernel (cin % 16, cout % 256, l % 256, cin > 1024).
+extern "C" int captra_pointwise_mlp_x6(int b, int cin, int cout, long long l, const float *x, const unsigned char *wimg, const float *bias_packed,
+                                       const float *ab_in, int act, float *y, float *stats_out, int stats_t, captra_stream_t stream) {
+    if (b < 0 || cin < 1 || cout < 1 || l < 0 || x == nullptr || wimg == nullptr || bias_packed == nullptr || y == nullptr) return -1;
+    if (cin % 16 != 0 || cout % DX_TC != 0 || l % DX_TP != 0 || cin > 1024 || l >= (1ll << 30)) return -2;
+    if (stats_out != nullptr && (act != ACT_NONE || stats_t != (int)(l / 128))) return -1;
+    if (b == 0 || l == 0) return 0;
+    DxParams p;
+    p.b = b; p.cin = cin; p.cout = cout; p.l = (int)l; p.x = x; p.wimg = wimg; p.bias = bias_packed; p.ab = ab_in; p.act = act; p.y = y;
+    p.stats = stats_out; p.npt = (int)(l / DX_TP); p.ncb = cout / DX_TC;
+    const long long grid = (long long)b * p.npt * p.ncb;
+    if (grid >= (1ll << 31)) return -2;
+    const int lds = DX_LDS + cin * 8;
+#define DX_LAUNCH(GN_, ST_)                                                                                             \
+    do {                                                                                                                \
+        auto kern = dense_x6_kernel<GN_, ST_>;                                                                          \
+        static CaptraDeviceOnce once;                                                                                   \
+        if (once.first_use()) {                                                                                         \
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, DX_LDS + 1024 * 8) != hipSuccess) \
+                return (int)hipGetLastError();                                                                          \
+            once.done();                                                                                                \
+        }                                                                                                               \
+        CAPTRA_LAUNCH("pointwise_mlp_x6", kern, dim3((unsigned)grid), dim3(512), lds, (hipStream_t)stream, p);          \
+    } while (0)
+    if (ab_in != nullptr) { if (stats_out != nullptr) DX_LAUNCH(true, true); else DX_LAUNCH(true, false); }
+    else { if (stats_out != nullptr) DX_LAUNCH(false, true); else DX_LAUNCH(false, false); }
+#undef DX_LAUNCH
+    return captra_last_error();
+}

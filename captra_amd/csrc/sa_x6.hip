@@ -237,7 +237,7 @@ __device__ __forceinline__ void sx_body(const SxParams &p, unsigned char *smem) 
 #pragma unroll
         for (int i = 0; i < S::chunk_frags(c) / 4; ++i)
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                         :: "s"(dst + i * 4096), "v"(voff16), "s"(wsrc), "s"(soff + i * 4096) : "memory", "m0");
+                         :: "s"(dst + i * 4096), "v"(voff16), "s"(wsrc), "s"(soff + i * 4096) : "memory");
     };
     // chunk c becomes readable (and chunk c + 1 goes on its way into the slot chunk c - 2 left: every wave is past that chunk's
     // last MFMA when it arrives here, so no LDS wait is needed in front of the barrier)

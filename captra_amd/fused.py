@@ -205,6 +205,11 @@ def mlp_dtype() -> str:
     return getattr(_TLS, "mlp_dtype", "fp32")
 
 
+def exact_path() -> bool:
+    """The exact-fp32 kernels' routes: the default arithmetic, and the f32x6 mode for every layer without an f32x6 kernel."""
+    return mlp_dtype() in ("fp32", "f32x6")
+
+
 def set_mlp_dtype(dtype: str) -> None:
     """Default of the calling thread (tools / ad-hoc scripts); models use `use_mlp_dtype`."""
     if dtype not in MLP_DTYPES:
@@ -251,7 +256,7 @@ def pointwise_mlp2(x, x2, lin: PackedLinear, act: int = ACT_RELU):
     """act(W [x; x2] + b) without building the concat (captra_pointwise_mlp2): x (B,c,l), x2 (B,c2,l) or (B,c2,1) (one vector per
     cloud, read for every position); exact fp32, bit-identical to pointwise_mlp on the concatenated tensor.  None when the shape is
     outside the kernel's range or the tensors lie too far apart for one buffer descriptor: the caller concatenates."""
-    if mlp_dtype() != "fp32" or lin.cout <= 64 or x.dim() != 3 or x2.dim() != 3:
+    if not exact_path() or lin.cout <= 64 or x.dim() != 3 or x2.dim() != 3:
         return None
     L.require_device(x, x2)
     B, c, l = x.shape
@@ -827,7 +832,7 @@ def sa_scale_x6(feat, xyz_cn, new_xyz_n3, idx, layers, out, co_off):
     with torch.cuda.device(xyz_cn.device):
         L.call("captra_sa_scale_x6", B, N, M, K, cfeat, l1.cout, l2.cout, l3.cout, 1 if pre else 0, L.ptr(src),
                L.ptr(xyz_cn), L.ptr(new_xyz_n3), L.ptr(idx), L.ptr(l1.wt), L.ptr(img), L.ptr(out), out.shape[1], co_off)
-    _work("sa_scale_fused", flops=2.0 * B * M * K * ((3 if pre else cfeat + 3) * l1.cout + l1.cout * l2.cout + l2.cout * l3.cout),
+    _work("sa_scale_x6", flops=2.0 * B * M * K * ((3 if pre else cfeat + 3) * l1.cout + l1.cout * l2.cout + l2.cout * l3.cout),
           nbytes=4.0 * B * ((l1.cout if pre else cfeat) * N + 3 * N + M * K + 3 * M + l3.cout * M))
     return out
 
@@ -913,10 +918,30 @@ USE_GN_FUSED = True      # Conv -> GroupNorm -> ReLU chains: statistics in the c
 
 def gn_chain_supported(x, cout: int) -> bool:
     """A conv whose output is group-normalised can emit the statistics itself when it runs in the 64x64 wave-tile
-    configuration of the direct kernel (csrc/pointwise_mlp.hip captra_pointwise_mlp_gn; fp32 path only)."""
+    configuration of the direct kernel (csrc/pointwise_mlp.hip captra_pointwise_mlp_gn; fp32 path -- and the f32x6 mode, whose
+    layers outside csrc/dense_x6.hip's shapes run these exact kernels)."""
     B, cin = x.shape[0], x.shape[1]
     l = x.numel() // max(B * cin, 1)
-    return USE_GN_FUSED and mlp_dtype() == "fp32" and cout > 64 and cin * l * 4 < (1 << 31)
+    return USE_GN_FUSED and mlp_dtype() in ("fp32", "f32x6") and cout > 64 and cin * l * 4 < (1 << 31)
+
+
+USE_DENSE_X6 = os.environ.get("CAPTRA_DENSE_X6", "1") != "0"
+
+
+def dense_x6_supported(cin: int, cout: int, l: int) -> bool:
+    """Shapes of captra_pointwise_mlp_x6 (csrc/dense_x6.hip: 256-channel x 256-position workgroup tiles, 16-wide k-steps)."""
+    return (USE_DENSE_X6 and mlp_dtype() == "f32x6" and cin % 16 == 0 and cin <= 1024 and cout % 256 == 0 and l % 256 == 0 and l > 0)
+
+
+def dense_x6_image(lin: PackedLinear) -> torch.Tensor:
+    """Three-way bf16 split fragment image of a layer for captra_pointwise_mlp_x6, built once and cached with the layer."""
+    key = ("dense_x6",)
+    if key not in lin._bf16:
+        img = torch.empty(L.lib().captra_dense_x6_image_bytes(lin.cin, lin.cout), dtype=torch.uint8, device=lin.wt.device)
+        with torch.cuda.device(lin.wt.device):
+            L.call("captra_pack_dense_x6", lin.cin, lin.cout, L.ptr(lin.wt), L.ptr(img))
+        lin._bf16[key] = img
+    return lin._bf16[key]
 
 
 def pointwise_mlp_gn(x, lin: PackedLinear, ab_in=None, act: int = ACT_NONE, want_stats: bool = False):
@@ -927,6 +952,15 @@ def pointwise_mlp_gn(x, lin: PackedLinear, ab_in=None, act: int = ACT_NONE, want
     assert lin.cin == cin and x.is_contiguous()
     l = x.numel() // max(B * cin, 1)
     y = torch.empty((B, lin.cout) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+    if dense_x6_supported(cin, lin.cout, l):
+        # cfg['mlp_dtype'] = "f32x6": six bf16 MFMAs per k-step on three-way splits; statistics per 128 positions
+        t = l // 128
+        stats = torch.empty(B, lin.cout, t, 2, dtype=torch.float32, device=x.device) if want_stats else None
+        with torch.cuda.device(x.device):
+            L.call("captra_pointwise_mlp_x6", B, cin, lin.cout, l, L.ptr(x), L.ptr(dense_x6_image(lin)), L.ptr(lin.bias), L.ptr(ab_in), act,
+                   L.ptr(y), L.ptr(stats), t)
+        _work("pointwise_mlp_x6", flops=2.0 * B * cin * lin.cout * l, nbytes=4.0 * B * l * (cin + lin.cout))
+        return (y, stats) if want_stats else y
     t = L.lib().captra_pointwise_mlp_gn_tiles(B, lin.cout, l)      # 64- or 32-position statistics tiles, by launch shape
     stats = torch.empty(B, lin.cout, t, 2, dtype=torch.float32, device=x.device) if want_stats else None
     with torch.cuda.device(x.device):
@@ -967,7 +1001,7 @@ def mlp_chain3(x, layers, act3: int = ACT_RELU):
     # under split_k with few positions: three split-k launches (each fills the chip) instead of the one-launch chain, whose waves own
     # 32 positions each -- 128 waves for one 4096-point cloud, every one a serial chain of the three layers (49 -> ~25 us)
     few = _split_k_on and B * l <= SPLIT_K_POSITIONS
-    if few or not (USE_MLP_CHAIN and mlp_dtype() == "fp32" and shape in _CHAIN3_SHAPES and shape[0] * l * 4 < (1 << 31)):
+    if few or not (USE_MLP_CHAIN and exact_path() and shape in _CHAIN3_SHAPES and shape[0] * l * 4 < (1 << 31)):
         y = pointwise_mlp(x, layers[0], ACT_RELU)
         y = pointwise_mlp(y, layers[1], ACT_RELU)
         return pointwise_mlp(y, layers[2], act3)
@@ -988,7 +1022,7 @@ _COORD_TAIL_SHAPES = {(134, 2, 3), (134, 4, 12), (134, 3, 9), (134, 2, 6)}   # c
 
 def coord_tail_supported(x, layers) -> bool:
     """layers = [fp1a, fp1b, conv1, seg, nocs hidden, nocs out] (PackedLinear)."""
-    if not (USE_COORD_TAIL and mlp_dtype() == "fp32" and len(layers) == 6):
+    if not (USE_COORD_TAIL and exact_path() and len(layers) == 6):
         return False
     l = x.numel() // max(x.shape[0] * x.shape[1], 1)
     widths_ok = all(lin.cout == 128 for lin in (layers[0], layers[1], layers[2], layers[4])) and all(lin.cin == 128 for lin in layers[1:])

@@ -175,7 +175,7 @@ class EvalTrackModel(BaseModel):
 
     def _track_step(self, input, npcs_input, last_pose):
         from . import fused
-        few = (not self.training and input["points"].is_cuda and fused.mlp_dtype() == "fp32"
+        few = (not self.training and input["points"].is_cuda and fused.exact_path()
                and 0 < len(input["points"]) <= fused.SPLIT_K_MAX_TRAJECTORIES and not getattr(self, "_no_split_k", False))
         with fused.split_k(few):
             return self._track_step_body(input, npcs_input, last_pose)

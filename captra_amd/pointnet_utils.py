@@ -228,7 +228,7 @@ class PointNetSetAbstractionMsg(_FoldCache, nn.Module):
                         off += layers[-1].cout
             return out
         off = 0
-        prezero = B <= 8 and fused.mlp_dtype() == "fp32" and len(folded) > 1
+        prezero = B <= 8 and fused.exact_path() and len(folded) > 1
         if prezero:
             # few clouds: the fp32 scales run a wave per neighbour slice and combine a centre's slices by an atomic max on a zeroed
             # output -- ONE fill of the level's tensor here instead of a fill per scale and cloud in the launchers
@@ -262,7 +262,7 @@ class PointNetSetAbstractionMsg(_FoldCache, nn.Module):
                 fused.sa_scale_bf16(feat, xyz_cn, new_xyz_n3, idx, layers, out, off)
                 off += layers[-1].cout
                 continue
-            if feat is not None and fused.mlp_dtype() == "fp32" and fused.sa_scale_pipe_supported(feat.shape[1], layers, idx.shape[1], idx.shape[2], b=B, n=feat.shape[2]):
+            if feat is not None and fused.exact_path() and fused.sa_scale_pipe_supported(feat.shape[1], layers, idx.shape[1], idx.shape[2], b=B, n=feat.shape[2]):
                 v1pm = fused.sa_first_layer_pre_pm(feat, layers[0])  # (B,N,c1) point-major: one 16-byte gather per register quad
                 fused.sa_scale_pre_pm(v1pm, xyz_cn, new_xyz_n3, idx, layers, out, off, feat.shape[1])
                 off += layers[-1].cout
@@ -362,7 +362,7 @@ class PointNetFeaturePropagation(_FoldCache, nn.Module):
             for i, lin in enumerate(layers[1:]):
                 y = fused.pointwise_mlp_bf16pm(y, lin, N, in_pm=True, out_pm=i < len(layers) - 2, act=fused.ACT_RELU)
             return y.view(B, layers[-1].cout, N)
-        if S == 1 and fuse and points1 is not None and points2.shape[2] == 1 and finish is None and fused.mlp_dtype() == "fp32":
+        if S == 1 and fuse and points1 is not None and points2.shape[2] == 1 and finish is None and fused.exact_path():
             # one source vector per cloud (pointnet_utils.py:265-270): the first layer reads [points1; repeat(points2)] from the two
             # tensors as they are (captra_pointwise_mlp2: rows in the concat's order, so the same bits) -- no repeat, no concat
             layers = list(self._fold(xyz1.device)) + ([tail] if tail is not None else [])

@@ -52,7 +52,7 @@ def parse_args(argv=None):
     parser.add_argument("--random_init", action="store_true", default=False,
                         help="no checkpoints: keep the freshly constructed (random) weights -- throughput runs only")
     parser.add_argument("--seed", type=int, default=0)
-    parser.add_argument("--mlp_dtype", default="fp32", choices=["fp32", "bf16"],
+    parser.add_argument("--mlp_dtype", default="fp32", choices=["fp32", "bf16", "f32x6"],
                         help="bf16: bf16 MFMA operands / fp32 accumulation in the shared MLPs (opt-in; default exact fp32)")
     parser.add_argument("--hipgraph", action="store_true", default=False,
                         help="replay one captured hipGraph per frame (same kernels, no per-launch host overhead)")

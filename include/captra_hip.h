@@ -256,6 +256,18 @@ int captra_sa_scale_x6(int b, int n, int m, int k, int cfeat, int c1, int c2, in
                        const float *xyz_cn, const float *new_xyz, const int *idx, const float *w1_packed, const unsigned char *img,
                        float *out, int out_ctotal, int co_off, captra_stream_t stream);
 
+/*   captra_pointwise_mlp_x6 (csrc/dense_x6.hip): captra_pointwise_mlp_gn in the f32x6 arithmetic -- x (B,cin,L) fp32 read as
+ *     relu(fmaf(a, x, b)) when ab_in (B,cin,2) is given, y (B,cout,L) = act(W x' + bias), stats_out (B,cout,stats_t,2) or NULL: (sum, sum of
+ *     squares) of the raw output per channel and 128 positions, stats_t = captra_pointwise_mlp_x6_tiles(l) = l / 128 (act must be
+ *     CAPTRA_ACT_NONE then) -- the layout captra_gn_finalize reduces.  wimg: captra_pack_dense_x6 of the layer's packed fp32 buffer
+ *     (captra_dense_x6_image_bytes bytes).  Shapes: cin % 16 == 0, cin <= 1024, cout % 256 == 0, l % 256 == 0 (the rotation heads' 128 ->
+ *     512 -> 512 -> 256 on 4096-point clouds, blocks.py:168-193); -2 otherwise (the caller runs captra_pointwise_mlp_gn). */
+long long captra_dense_x6_image_bytes(int cin, int cout);
+int captra_pack_dense_x6(int cin, int cout, const float *wt_packed, unsigned char *img, captra_stream_t stream);
+int captra_pointwise_mlp_x6_tiles(long long l);
+int captra_pointwise_mlp_x6(int b, int cin, int cout, long long l, const float *x, const unsigned char *wimg, const float *bias_packed,
+                            const float *ab_in, int act, float *y, float *stats_out, int stats_t, captra_stream_t stream);
+
 /* bf16-NATIVE dense layers (csrc/dense_bf16.hip): activations in HBM as bf16, POINT-major (B,L,ceil32(C)), channels in SLOT
  * ORDER (inside every aligned block of 16 channels memory slot s holds channel perm[s] = {0,1,2,3,8,9,10,11,4,5,6,7,12,13,14,15},
  * the order in which a 32x32 MFMA accumulator tile hands its rows to a lane; padding channels are zero).  Same per-layer

@@ -64,3 +64,43 @@ def test_sa_scale_x6_vs_exact_chain(device, cfeat, chans, n, m, k, B):
     assert err <= X6_TOL, err
     # a plain bf16 product would be four orders of magnitude away: the tolerance is a statement about the split, not slack
     assert err < 1e-5
+
+
+@pytest.mark.parametrize("cin,cout,L,B,gn_in,stats", [(128, 512, 4096, 2, False, True), (512, 512, 4096, 2, True, True),
+                                                       (512, 256, 4096, 3, True, True), (512, 256, 512, 2, True, False),
+                                                       (128, 256, 256, 1, False, False), (16, 256, 768, 2, True, True),
+                                                       (512, 512, 4096, 9, True, True)])
+def test_dense_x6_vs_exact_chain(device, cin, cout, L, B, gn_in, stats):
+    """The f32x6 dense layer of the GroupNorm chains (captra_pointwise_mlp_x6) == the exact kernel (captra_pointwise_mlp_gn, itself
+    bit-identical to the oracle's fmaf chain: test_model_gpu.py) on the same inputs within 2e-6 of the largest output -- with and
+    without the previous layer's GroupNorm coefficients on the input, one and two channel blocks, position-tile counts that are
+    and are not a multiple of eight -- and its statistics == sums of its own stored output (float64) to fp32 summation accuracy."""
+    from captra_amd import fused
+    rng = np.random.default_rng(cin + cout + L + B)
+    x = rng.standard_normal((B, cin, L)).astype(np.float32)
+    wt = (rng.standard_normal((cin, cout)) / np.sqrt(cin)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    ab = np.stack([rng.uniform(0.5, 1.5, (B, cin)), rng.standard_normal((B, cin)) * 0.3], axis=-1).astype(np.float32) if gn_in else None
+    lin = fused.pack(_dev(wt, device), _dev(b, device))
+    xd, abd = _dev(x, device), None if ab is None else _dev(ab, device)
+    with fused.use_mlp_dtype("fp32"):
+        ref = fused.pointwise_mlp_gn(xd, lin, abd, fused.ACT_NONE).cpu().numpy()
+    with fused.use_mlp_dtype("f32x6"):
+        assert fused.dense_x6_supported(cin, cout, L)
+        res = fused.pointwise_mlp_gn(xd, lin, abd, fused.ACT_NONE, want_stats=stats)
+    got = (res[0] if stats else res).cpu().numpy()
+    # the exact kernel against the oracle once more here, so that this test stands on its own
+    xin = x if ab is None else np.maximum(ab[:, :, 0:1] * x.astype(np.float64) + ab[:, :, 1:2], 0).astype(np.float32)
+    ora = O.pointwise_mlp(xin[:1], wt, b, 0)
+    assert np.abs(ref[:1] - ora).max() <= 2e-6 * np.abs(ora).max()
+    err = _rel(got, ref)
+    assert err <= X6_TOL, err
+    if stats:
+        st = res[1].cpu().numpy().astype(np.float64)                      # (B,cout,T,2)
+        assert st.shape == (B, cout, L // 128, 2)
+        g64 = got.astype(np.float64).reshape(B, cout, L // 128, 128)
+        np.testing.assert_allclose(st[..., 0], g64.sum(-1), rtol=0, atol=2e-4 * np.abs(g64).sum(-1).max())
+        np.testing.assert_allclose(st[..., 1], (g64 * g64).sum(-1), rtol=2e-6, atol=1e-4)
+    with fused.use_mlp_dtype("f32x6"):
+        relu = fused.pointwise_mlp_gn(xd, lin, abd, fused.ACT_RELU).cpu().numpy()
+    np.testing.assert_array_equal(relu, np.maximum(got, 0))
