@@ -5,10 +5,12 @@
 // (sum, sum of squares) of the raw output per channel and 128 positions from the epilogue -- the interface of
 // captra_pointwise_mlp_gn (csrc/pointwise_mlp.hip), whose exact-fp32 kernels this replaces in the opt-in mode.
 //
-// Structure: a 256-position x 256-channel tile per workgroup of EIGHT waves (two per SIMD: one wave's operand split -- 70 VALU
-// per k-step -- runs under the other's MFMAs), a wave = 128 positions x 64 channels (128 accumulator registers).  k-steps of 16
+// Structure: a 128-position x 256-channel tile per workgroup of FOUR waves, a wave = 128 positions x 64 channels (128 accumulator
+// registers), TWO workgroups per CU (76 KB of LDS each): one workgroup's operand split (70 VALU per wave and k-step), barriers,
+// prologue and store epilogue run under the other's MFMAs -- the first form, one 256 x 256 workgroup of eight waves per CU, left the
+// matrix pipe 54 % busy (profiles/r06a_bench_f32x6_pmc_summary.txt: twice as many wait as active cycles).  k-steps of 16
 // channels through two LDS stages:
-//   weights   24 fragments (8 channel tiles x 3 parts) per k-step, LDS-DMA from the split image (captra_pack_dense_x6), three
+//   weights   24 fragments (8 channel tiles x 3 parts) per k-step, LDS-DMA from the split image (captra_pack_dense_x6), six
 //             pieces per wave;
 //   positions every lane loads 8 channels of ONE position (dword loads, a wave = 2 rows x 128 B per instruction), applies the
 //             GroupNorm coefficients + ReLU, splits, and writes three 16-byte fragment slots: the fragment image is lane-linear
@@ -42,8 +44,8 @@ __device__ __forceinline__ f32x16 dx_mfma(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-constexpr int DX_TP = 256, DX_TC = 256;                // positions / channels per workgroup
-constexpr int DX_ASTAGE = 24 * 1024, DX_BSTAGE = 24 * 1024, DX_STAGE = DX_ASTAGE + DX_BSTAGE;
+constexpr int DX_TP = 128, DX_TC = 256;                // positions / channels per workgroup
+constexpr int DX_ASTAGE = 24 * 1024, DX_BSTAGE = 12 * 1024, DX_STAGE = DX_ASTAGE + DX_BSTAGE;
 constexpr int DX_LDS = 2 * DX_STAGE;                   // + the coefficient table (cin x 8 bytes) behind it
 
 // ---- weight image: [channel block of 256][k-step][channel tile 0..7][part 0..2] fragments of 1 KiB; fragment lane l = channel
@@ -80,12 +82,12 @@ struct DxParams {
 #define DX_WAIT_VM(N) __builtin_amdgcn_s_waitcnt(((N) & 15) | (((N) >> 4) << 14) | 0x0F70)
 
 template <bool GN_IN, bool STATS>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void dense_x6_kernel(DxParams p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void dense_x6_kernel(DxParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, col = lane & 31;
-    const int wm = wave & 3, wn = wave >> 2;            // this wave's 64-channel block / 128-position half of the tile
+    const int wm = wave;                                // this wave's 64-channel block of the tile (all of its 128 positions)
     // workgroup -> (cloud, position tile, channel block): the channel blocks of one position tile are 8 workgroups apart, i.e. on
     // the same XCD (workgroups go round the eight XCDs), so the second reading of a position tile's x is an L2 hit
     const int per_cloud = p.npt * p.ncb;
@@ -104,12 +106,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const dx_i32x4 wsrc = {(int)(unsigned)img_addr, (int)(unsigned)(img_addr >> 32), kst * DX_ASTAGE, 0x00020000};
     const unsigned lds0 = (unsigned)reinterpret_cast<size_t>((__attribute__((address_space(3))) unsigned char *)smem);
     const unsigned voff16 = lane * 16;
-    // LDS-DMA of k-step kk's weight fragments into stage st: this wave's three pieces (asm: see csrc/sa_x6.hip)
+    // LDS-DMA of k-step kk's weight fragments into stage st: this wave's six pieces (asm: see csrc/sa_x6.hip)
     auto issue_w = [&](int kk, int st) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const unsigned dst = lds0 + st * DX_STAGE + (wave * 3 + i) * 1024;
-            const unsigned soff = kk * DX_ASTAGE + (wave * 3 + i) * 1024;
+        for (int i = 0; i < 6; ++i) {
+            const unsigned dst = lds0 + st * DX_STAGE + (wave * 6 + i) * 1024;
+            const unsigned soff = kk * DX_ASTAGE + (wave * 6 + i) * 1024;
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                          :: "s"(dst), "v"(voff16), "s"(wsrc), "s"(soff) : "memory");
         }
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // ---- prologue -------------------------------------------------------------------------------------------------------------
     if constexpr (GN_IN) {
         const float *src = p.ab + (size_t)bq * p.cin * 2;
-        for (int e = tid; e < p.cin * 2; e += 512) abt[e] = src[e];
+        for (int e = tid; e < p.cin * 2; e += 256) abt[e] = src[e];
     }
     issue_w(0, 0);
     float xr[8];
@@ -191,7 +193,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int tn = 0; tn < 4; ++tn) {
             u32x4 xf[3];
 #pragma unroll
-            for (int s = 0; s < 3; ++s) xf[s] = *reinterpret_cast<const u32x4 *>(ab_ + DX_ASTAGE + ((4 * wn + tn) * 3 + s) * 1024);
+            for (int s = 0; s < 3; ++s) xf[s] = *reinterpret_cast<const u32x4 *>(ab_ + DX_ASTAGE + (tn * 3 + s) * 1024);
 #pragma unroll
             for (int tm = 0; tm < 2; ++tm) {
                 f32x16 a = acc[tm][tn];
@@ -210,7 +212,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int ch = DX_TC * cb + 64 * wm + 32 * tm + col;
         const float bias = p.bias[ch];
         float s1 = 0.f, s2 = 0.f;
-        float *yp = p.y + ((size_t)bq * p.cout + ch) * p.l + p0 + 128 * wn + 4 * h;
+        float *yp = p.y + ((size_t)bq * p.cout + ch) * p.l + p0 + 4 * h;
 #pragma unroll
         for (int tn = 0; tn < 4; ++tn)
 #pragma unroll
@@ -233,7 +235,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 float2 o;
                 o.x = __uint_as_float(w1[0]) + __uint_as_float(w1[1]);
                 o.y = __uint_as_float(w2[0]) + __uint_as_float(w2[1]);
-                *reinterpret_cast<float2 *>(p.stats + (((size_t)bq * p.cout + ch) * T + (p0 / 128 + wn)) * 2) = o;
+                *reinterpret_cast<float2 *>(p.stats + (((size_t)bq * p.cout + ch) * T + p0 / 128) * 2) = o;
             }
         }
     }
@@ -258,7 +260,7 @@ extern "C" int captra_pack_dense_x6(int cin, int cout, const float *wt_packed, u
 // the stats_t captra_pointwise_mlp_x6 writes: one (sum, sum of squares) per channel and 128 positions
 extern "C" int captra_pointwise_mlp_x6_tiles(long long l) { return (int)(l / 128); }
 
-// As captra_pointwise_mlp_gn in the f32x6 arithmetic.  -2: shape outside the kernel (cin % 16, cout % 256, l % 256, cin > 1024).
+// As captra_pointwise_mlp_gn in the f32x6 arithmetic.  -2: shape outside the kernel (cin % 16, cout % 256, l % 128, cin > 1024).
 extern "C" int captra_pointwise_mlp_x6(int b, int cin, int cout, long long l, const float *x, const unsigned char *wimg, const float *bias_packed,
                                        const float *ab_in, int act, float *y, float *stats_out, int stats_t, captra_stream_t stream) {
     if (b < 0 || cin < 1 || cout < 1 || l < 0 || x == nullptr || wimg == nullptr || bias_packed == nullptr || y == nullptr) return -1;
@@ -280,7 +282,7 @@ extern "C" int captra_pointwise_mlp_x6(int b, int cin, int cout, long long l, co
                 return (int)hipGetLastError();                                                                          \
             once.done();                                                                                                \
         }                                                                                                               \
-        CAPTRA_LAUNCH("pointwise_mlp_x6", kern, dim3((unsigned)grid), dim3(512), lds, (hipStream_t)stream, p);          \
+        CAPTRA_LAUNCH("pointwise_mlp_x6", kern, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, p);          \
     } while (0)
     if (ab_in != nullptr) { if (stats_out != nullptr) DX_LAUNCH(true, true); else DX_LAUNCH(true, false); }
     else { if (stats_out != nullptr) DX_LAUNCH(false, true); else DX_LAUNCH(false, false); }

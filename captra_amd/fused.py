@@ -929,8 +929,8 @@ USE_DENSE_X6 = os.environ.get("CAPTRA_DENSE_X6", "1") != "0"
 
 
 def dense_x6_supported(cin: int, cout: int, l: int) -> bool:
-    """Shapes of captra_pointwise_mlp_x6 (csrc/dense_x6.hip: 256-channel x 256-position workgroup tiles, 16-wide k-steps)."""
-    return (USE_DENSE_X6 and mlp_dtype() == "f32x6" and cin % 16 == 0 and cin <= 1024 and cout % 256 == 0 and l % 256 == 0 and l > 0)
+    """Shapes of captra_pointwise_mlp_x6 (csrc/dense_x6.hip: 256-channel x 128-position workgroup tiles, 16-wide k-steps)."""
+    return (USE_DENSE_X6 and mlp_dtype() == "f32x6" and cin % 16 == 0 and cin <= 1024 and cout % 256 == 0 and l % 128 == 0 and l > 0)
 
 
 def dense_x6_image(lin: PackedLinear) -> torch.Tensor:

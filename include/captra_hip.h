@@ -260,7 +260,7 @@ int captra_sa_scale_x6(int b, int n, int m, int k, int cfeat, int c1, int c2, in
  *     relu(fmaf(a, x, b)) when ab_in (B,cin,2) is given, y (B,cout,L) = act(W x' + bias), stats_out (B,cout,stats_t,2) or NULL: (sum, sum of
  *     squares) of the raw output per channel and 128 positions, stats_t = captra_pointwise_mlp_x6_tiles(l) = l / 128 (act must be
  *     CAPTRA_ACT_NONE then) -- the layout captra_gn_finalize reduces.  wimg: captra_pack_dense_x6 of the layer's packed fp32 buffer
- *     (captra_dense_x6_image_bytes bytes).  Shapes: cin % 16 == 0, cin <= 1024, cout % 256 == 0, l % 256 == 0 (the rotation heads' 128 ->
+ *     (captra_dense_x6_image_bytes bytes).  Shapes: cin % 16 == 0, cin <= 1024, cout % 256 == 0, l % 128 == 0 (the rotation heads' 128 ->
  *     512 -> 512 -> 256 on 4096-point clouds, blocks.py:168-193); -2 otherwise (the caller runs captra_pointwise_mlp_gn). */
 long long captra_dense_x6_image_bytes(int cin, int cout);
 int captra_pack_dense_x6(int cin, int cout, const float *wt_packed, unsigned char *img, captra_stream_t stream);
