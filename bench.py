@@ -620,6 +620,9 @@ def launch_plan(n: int) -> dict:
             "env": {"HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")},
             "cpu_binding": "each rank pins its host threads to its share of the cores NUMA-local to its GPU (sysfs local_cpulist; an even split of the allowed cores when unknown)",
             "ranks": [{"rank": r, "local_rank": r, "device": f"cuda:{r % have if share and have else r}",
+                       # what this rank tracks: the --category of the command line, or (mix6) NOCS category 1 + rank mod 6
+                       "category": (WORKLOADS[MIX6[r % 6]][0] if "mix6" in sys.argv else
+                                    WORKLOADS[sys.argv[sys.argv.index("--category") + 1]][0] if "--category" in sys.argv[:-1] and sys.argv[sys.argv.index("--category") + 1] in WORKLOADS else "1"),
                        "tracks": "32 trajectories (--batch), seeds (10 + rank) * 100 + b; category per --category (mix6: NOCS category 1 + rank mod 6)"}
                       for r in range(n)],
             "collective": "none (single rank)" if n == 1 else ("gloo (CAPTRA_BENCH_SHARE_GPU functional mode)" if share else

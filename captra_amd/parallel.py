@@ -2,8 +2,9 @@
 
 The reference is single-process / single-GPU (`cuda:%d`, configs/config.py:68; no torch.distributed
 anywhere).  The path shards over the batch of independent trajectories and nowhere
-else (frame i needs pose i-1; a cloud is never split): trajectory b lives on rank b mod G with a
-full copy of both nets' weights (15.8 MB), so the data path has NO collective.  The only exchange
+else (frame i needs pose i-1; a cloud is never split): every rank owns a CONTIGUOUS, balanced range of the
+trajectories (`shard_range`: the first `total % G` ranks hold one more) with a full copy of both nets'
+weights (15.8 MB), so the data path has NO collective.  The only exchange
 is the result: after each frame every rank contributes its packed pose records
 [R(9) t(3) s(1) valid(1)] x P fp32 per trajectory and receives everyone's — 56·P bytes per
 trajectory, latency-bound on xGMI.  One process per GPU, `torch.distributed`

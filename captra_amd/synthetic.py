@@ -156,6 +156,16 @@ PHYSICAL_SETUPS = {
     "drawers": ("drawers", "obj_info_sapien.yml", "arti", 7, 2, 24, 4324),
 }
 
+# G9p, second file (tests/golden/g9p_track_more.npz, same generator with --set more): the three rigid categories the first file
+# does not hold (bowl, can: symmetric; mug: not), and a FIVE-trajectory bottle batch -- more trajectories than
+# fused.SPLIT_K_MAX_TRAJECTORIES, so the free-running comparison pins the large-batch kernels (wave-per-centre SA scales, 64x64-tile
+# dense layers) to the reference end to end, not only the few-trajectory forms
+PHYSICAL_SETUPS_MORE = {
+    "bowl": ("2", "obj_info_nocs.yml", "nocs", 7, 2, 25, 4325),
+    "can": ("4", "obj_info_nocs.yml", "nocs", 7, 2, 26, 4326),
+    "mug": ("6", "obj_info_nocs.yml", "nocs", 7, 2, 27, 4327),
+    "bottle5": ("1", "obj_info_nocs.yml", "nocs", 5, 5, 29, 4328),
+}
 
 # ---- depth frames (the on-the-fly re-crop's input) -----------------------------------------------------------------------
 def make_frame(seed: int, height: int = 480, width: int = 640, dr: float = 0.0, dc: float = 0.0):

@@ -181,6 +181,26 @@ def yaxis_to_matrix(v):
     return np.stack([x, y, z], -1)
 
 
+def rot_pool_compose(raw, labels, prev_rotation, sym):
+    """The rotation read-out of PartCanonNet (reference networks.py:127-138 + 200-203, blocks.py:183-192, rotations.py:302-387,
+    part_dof_utils.py:124-141): raw (B,P,D,N) = head p's per-point output on cloud (b,p) (D = 3: a y axis; D = 6: ortho6d),
+    labels (B,N) (values >= P: background), prev_rotation (B,P,3,3) -> (R_prev . dR, dR), both (B,P,3,3).
+    Per point: normalise / ortho6d -> matrix; masked mean over the points labelled p (default (0,1,0) / identity when the part
+    has none); re-orthogonalise (from a y axis / Gram-Schmidt); compose with the previous rotation."""
+    B, P, D, N = raw.shape
+    delta = np.zeros((B, P, 3, 3), np.float32)
+    for p in range(P):
+        per_point = raw[:, p].transpose(0, 2, 1)                          # (B,N,D)
+        rep = _normalize(per_point) if sym else ortho6d_to_matrix(per_point).reshape(B, N, 9)   # blocks.py:183-192
+        mask = (labels == p).astype(np.float32)[..., None]               # (B,N,1)
+        cnt = mask.sum(1)
+        pooled = (rep * mask).sum(1) / np.maximum(cnt, np.float32(1.0))  # networks.py:133
+        default = np.array([0, 1, 0], np.float32) if sym else np.eye(3, dtype=np.float32).reshape(-1)
+        pooled = np.where(cnt > 0, pooled, default[None]).astype(np.float32)
+        delta[:, p] = yaxis_to_matrix(pooled) if sym else gram_schmidt(pooled.reshape(B, 3, 3))
+    return np.matmul(prev_rotation, delta).astype(np.float32), delta      # part_dof_utils.py:127
+
+
 def rot_head(sd, prefix, feat, sym):
     """MLPConv1d 128->512->512->256->D with GroupNorm(C/2) (blocks.py:148-165): (B,128,N) -> (B,D,N)."""
     x = torch.from_numpy(feat)
@@ -230,20 +250,12 @@ def track_step(sd, cfg, points, points_mean, last_pose, mlp="torch", gt_labels=N
     cam_p, _ = O.canonicalize(points, mean, last_pose["rotation"].reshape(B * P, 3, 3),
                               last_pose["translation"].reshape(B * P, 3), last_pose["scale"].reshape(B * P), P=P)
     feat_r = backbone(sd, "net.regress_net.encoder", pcfg, cam_p, False, mlp)
-    delta = np.zeros((B, P, 3, 3), np.float32)
+    raws = []
     for p in range(P):                                                    # only head p on cloud (b,p) is used
         fr = np.ascontiguousarray(feat_r.reshape(B, P, 128, N)[:, p])
         head = f"net.regress_net.pose_pred.rtvec_head.{p}"
-        raw = rot_head_exact(sd, head, fr) if mlp == "exact" else rot_head(sd, head, fr, sym)     # (B,D,N)
-        per_point = raw.transpose(0, 2, 1)                                # (B,N,D)
-        rep = _normalize(per_point) if sym else ortho6d_to_matrix(per_point).reshape(B, N, 9)   # blocks.py:183-192
-        mask = (labels == p).astype(np.float32)[..., None]               # (B,N,1)
-        cnt = mask.sum(1)
-        pooled = (rep * mask).sum(1) / np.maximum(cnt, np.float32(1.0))  # networks.py:133
-        default = np.array([0, 1, 0], np.float32) if sym else np.eye(3, dtype=np.float32).reshape(-1)
-        pooled = np.where(cnt > 0, pooled, default[None]).astype(np.float32)
-        delta[:, p] = yaxis_to_matrix(pooled) if sym else gram_schmidt(pooled.reshape(B, 3, 3))
-    rotation = np.matmul(last_pose["rotation"], delta).astype(np.float32)          # part_dof_utils.py:127
+        raws.append(rot_head_exact(sd, head, fr) if mlp == "exact" else rot_head(sd, head, fr, sym))     # (B,D,N)
+    rotation, _ = rot_pool_compose(np.stack(raws, axis=1), labels, last_pose["rotation"], sym)
     cam_points = (points + points_mean).astype(np.float32)
     scale, trans, valid = O.part_fit_st(labels, nocs.reshape(B, P, 3, N), cam_points, rotation, sym)
     v = valid.astype(bool)

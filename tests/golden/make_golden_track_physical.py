@@ -46,14 +46,17 @@ def patch_cuda_semantics(pu):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
+    ap.add_argument("--set", default="first", choices=["first", "more"],
+                    help="first: clouds.PHYSICAL_SETUPS -> g9p_track.npz; more: clouds.PHYSICAL_SETUPS_MORE -> g9p_track_more.npz")
     args = ap.parse_args()
+    setups, target = (SETUPS, "g9p_track.npz") if args.set == "first" else (clouds.PHYSICAL_SETUPS_MORE, "g9p_track_more.npz")
     pu = import_reference(args.ref)
     assert not pu.CUDA
     patch_cuda_semantics(pu)
     torch.set_num_threads(8)
     from trainer import Trainer
     out = {}
-    for tag, (cat, objcfg, kind, frames, batch, wseed, tseed) in SETUPS.items():
+    for tag, (cat, objcfg, kind, frames, batch, wseed, tseed) in setups.items():
         cfg = ref_cfg(args.ref, cat, objcfg)
         cfg["init_frame"]["gt"] = False
         with contextlib.redirect_stdout(io.StringIO()):
@@ -83,12 +86,12 @@ def main():
         print(f"{tag}: scale range [{scales.min():.4f}, {scales.max():.4f}], min softmax gap {gap_min:.2e}, "
               f"label counts per part min {np.min(counts)}")
         assert scales.min() > 0.05 and scales.max() < 2.0, "trajectory left the physical regime"
-        assert gap_min > 2e-5, "a point sits on a segmentation decision boundary: pick another seed"
+        assert gap_min > 2e-5, f"{tag}: a point sits on a segmentation decision boundary (gap {gap_min:.2e}): pick another seed"
         assert np.min(counts) > 16, "a part is left with a handful of points: pick another seed"
         out[f"{tag}_min_softmax_gap"] = np.float32(gap_min)
         out[f"{tag}_label_counts"] = np.asarray(counts, np.int32)
-    np.savez_compressed(HERE / "g9p_track.npz", **out)
-    print("wrote", HERE / "g9p_track.npz")
+    np.savez_compressed(HERE / target, **out)
+    print("wrote", HERE / target)
 
 
 if __name__ == "__main__":

@@ -65,13 +65,13 @@ def test_configs2_bf16_track_loop_5deg5cm_gate_all_six_categories(device, cat):
     assert any(not torch.equal(a["translation"], b["translation"]) for a, b in zip(poses["fp32"][1:], poses["bf16"][1:]))
 
 
-@pytest.mark.parametrize("tag", ["bottle", "camera", "laptop", "drawers"])
+@pytest.mark.parametrize("tag", ["bottle", "bowl", "camera", "can", "laptop", "mug", "drawers", "bottle5"])
 def test_configs2_bf16_track_loop_vs_reference_golden_5deg5cm(device, tag):
-    """Where the reference's own loop is pinned (golden G9p): the bf16 loop's poses against the REFERENCE's, 5 deg / 5 cm on
-    every (frame, trajectory, part) pair -- including the 4-part drawers (BASELINE.json configs[3]'s category)."""
-    cat, objcfg, kind, frames, batch, wseed, tseed = clouds.PHYSICAL_SETUPS[tag]
+    """Against the REFERENCE's own loop (goldens G9p: all six rigid categories of BASELINE.json configs[2], a five-trajectory batch,
+    and the 4-part drawers of configs[3]): the bf16 loop's poses within 5 deg / 5 cm on every (frame, trajectory, part) pair."""
+    cat, objcfg, kind, frames, batch, wseed, tseed = {**clouds.PHYSICAL_SETUPS, **clouds.PHYSICAL_SETUPS_MORE}[tag]
     trainer, cfg = _trainer(cat, device, "bf16", wseed, objcfg, kind)
-    g = np.load(G / "g9p_track.npz")
+    g = np.load(G / ("g9p_track.npz" if tag in clouds.PHYSICAL_SETUPS else "g9p_track_more.npz"))
     torch.manual_seed(tseed)
     pred, _ = trainer.test(clouds.make_trajectory(kind, batch, frames, seed=7), save=False, no_eval=True)
     ours = [{k: v.float().cpu() for k, v in p.items()} for p in pred["poses"]]

@@ -826,7 +826,7 @@ def _trainer_physical(tag, device, **cfg_over):
     from captra_amd.configs import make_config
     from captra_amd.trainer import Trainer
     from tests.weights import make_physical_state_dict
-    cat, objcfg, kind, frames, batch, wseed, tseed = clouds.PHYSICAL_SETUPS[tag]
+    cat, objcfg, kind, frames, batch, wseed, tseed = {**clouds.PHYSICAL_SETUPS, **clouds.PHYSICAL_SETUPS_MORE}[tag]
     cfg = make_config(cat, objcfg, experiment_dir="/tmp/captra_test_exp")
     cfg.update(cfg_over)
     trainer = Trainer(cfg)
@@ -859,6 +859,33 @@ def test_track_loop_vs_golden(device, tag, hipgraph):
         counts = [[int((lab[b] == p).sum()) for p in range(cfg["num_parts"])] for b in range(lab.shape[0])]
         np.testing.assert_array_equal(np.asarray(counts), g[f"{tag}_label_counts"][i - 1], err_msg=f"{tag} frame {i} label counts")
     assert "avg_pred" in loss_dict and any(k.startswith("5deg5cm") for k in loss_dict["avg_pred"])
+
+
+@pytest.mark.parametrize("hipgraph", [False, True])
+@pytest.mark.parametrize("tag", ["bowl", "can", "mug", "bottle5"])
+def test_track_loop_vs_golden_more(device, tag, hipgraph):
+    """The second G9p file: the reference's own free-running loop for the three rigid categories the first
+    file lacks, and a FIVE-trajectory bottle batch -- above fused.SPLIT_K_MAX_TRAJECTORIES, so this run takes the large-batch
+    kernels (wave-per-centre SA scales, 64x64-tile dense layers, no split-k) that the two-trajectory fixtures do not reach --
+    every pose of every frame within 1e-4, eager and captured."""
+    from captra_amd import fused
+    trainer, cfg, sd, data, tseed = _trainer_physical(tag, device, hipgraph=hipgraph)
+    if tag == "bottle5":
+        assert len(data[0]["points"]) == 5 > fused.SPLIT_K_MAX_TRAJECTORIES
+    trainer.model.use_graph = hipgraph
+    g = np.load(G / "g9p_track_more.npz")
+    torch.manual_seed(tseed)
+    pred_dict, _ = trainer.test(data, save=False, no_eval=True)
+    poses = pred_dict["poses"]
+    assert len(poses) == len(data)
+    for key in ("rotation", "translation", "scale"):
+        np.testing.assert_allclose(poses[0][key].cpu().numpy(), g[f"{tag}_0_{key}"], atol=1e-6, rtol=0)
+    for i in range(1, len(poses)):
+        for key in ("rotation", "scale", "translation"):
+            np.testing.assert_allclose(poses[i][key].cpu().numpy(), g[f"{tag}_{i}_{key}"], atol=TOL, rtol=0, err_msg=f"{tag} frame {i} {key}")
+        lab = torch.argmax(pred_dict["npcs_pred"][i]["seg"], dim=-2)
+        counts = [[int((lab[b] == p).sum()) for p in range(cfg["num_parts"])] for b in range(lab.shape[0])]
+        np.testing.assert_array_equal(np.asarray(counts), g[f"{tag}_label_counts"][i - 1], err_msg=f"{tag} frame {i} label counts")
 
 
 @pytest.mark.parametrize("tag", ["bottle", "camera", "drawers"])
@@ -1010,6 +1037,32 @@ def test_rot_pool_compose_vs_reference_algebra(device, sym, P):
     r_ref = torch.matmul(torch.from_numpy(prev), d_ref)
     np.testing.assert_allclose(delta.cpu().numpy(), d_ref.numpy(), atol=2e-6, rtol=0)
     np.testing.assert_allclose(rot.cpu().numpy(), r_ref.numpy(), atol=2e-6, rtol=0)
+
+
+@pytest.mark.parametrize("sym,P", [(True, 1), (False, 1), (False, 4), (True, 3)])
+def test_rot_pool_compose_vs_oracle(device, sym, P):
+    """The one-launch rotation read-out against the ORACLE's restatement of the reference (oracle/model.py rot_pool_compose:
+    networks.py:127-138, rotations.py:302-387, part_dof_utils.py:124-141 -- the function the oracle's track_step runs, pinned to the
+    reference's poses by goldens G9 / G9p), not against this package's own mirrors: empty parts (default axis / identity),
+    zero-length per-point vectors ((1,0,0) fallback), parallel ortho6d columns, background labels, one to four parts."""
+    from captra_amd import fused
+    rng = np.random.default_rng(170 + P + int(sym))
+    B, N, R = 4, 1500, (3 if sym else 6)
+    raw = rng.standard_normal((B, P, R, N)).astype(np.float32)
+    raw[0, 0, :, :7] = 0.0                                       # |v| = 0
+    if not sym:
+        raw[1, 0, 3:6, 7:12] = 2.5 * raw[1, 0, 0:3, 7:12]       # second ortho6d column parallel to the first: cross product 0
+    labels = rng.integers(0, P + 1, (B, N)).astype(np.int32)     # label P = background
+    if P > 1:
+        labels[1][labels[1] == P - 1] = P                        # trajectory 1: the last part has no points
+    labels[2][:] = P                                             # trajectory 2: every part empty
+    prev = np.stack([clouds._rot_y(0.3 * i) @ clouds._rot_x(0.1 * i) for i in range(B * P)]).reshape(B, P, 3, 3).astype(np.float32)
+    rot, delta = fused.rot_pool_compose(_dev(np.ascontiguousarray(raw.reshape(B * P, R, N)), device), _dev(labels, device), _dev(prev, device),
+                                        sym, want_delta=True)
+    r_ref, d_ref = OM.rot_pool_compose(raw, labels, prev, sym)
+    np.testing.assert_allclose(delta.cpu().numpy(), d_ref, atol=2e-6, rtol=0)
+    np.testing.assert_allclose(rot.cpu().numpy(), r_ref, atol=2e-6, rtol=0)
+    assert np.array_equal(d_ref[2], np.broadcast_to(np.eye(3, dtype=np.float32), (P, 3, 3)))       # (all parts empty: the default is the identity either way)
 
 
 @pytest.mark.parametrize("b,cin,cout,l,csplit,bcast,act", [(1, 515, 256, 128, 3, False, 1), (2, 1536, 512, 128, 512, True, 1), (1, 832, 512, 512, 320, False, 1),

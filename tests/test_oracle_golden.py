@@ -187,7 +187,7 @@ def test_g7_single_step_and_g9_trajectory(tag):
 def _physical_setup(tag):
     """The G9p fixture: physical-regime weights (tests/weights.make_physical_state_dict) on the seed-7 trajectories."""
     from tests.weights import make_physical_state_dict
-    cat, objcfg, kind, frames, batch, wseed, tseed = clouds.PHYSICAL_SETUPS[tag]
+    cat, objcfg, kind, frames, batch, wseed, tseed = {**clouds.PHYSICAL_SETUPS, **clouds.PHYSICAL_SETUPS_MORE}[tag]
     cfg = _cfg(cat, objcfg)
     from captra_amd.model import EvalTrackModel   # only to enumerate parameter names/shapes
     shapes = {k: tuple(v.shape) for k, v in EvalTrackModel(cfg).state_dict().items()}
@@ -202,13 +202,13 @@ def _physical_setup(tag):
     return cfg, sd, data, {k: v.numpy() for k, v in init.items()}
 
 
-@pytest.mark.parametrize("tag", ["bottle", "camera", "laptop", "drawers"])
+@pytest.mark.parametrize("tag", ["bottle", "camera", "laptop", "drawers", "bowl", "can", "mug"])
 def test_g9p_free_running_trajectory_every_frame_1e4(tag):
     """G9p: the reference's own EvalTrackModel loop under physical-regime weights.  The oracle runs FREE (each frame from
     its own previous pose, labels from its own segmentation) and every pose of every frame stays within the 1e-4
     contract of the reference's -- no teacher forcing, no loosened frames."""
     cfg, sd, data, init = _physical_setup(tag)
-    g = np.load(G / "g9p_track.npz")
+    g = np.load(G / ("g9p_track.npz" if tag in clouds.PHYSICAL_SETUPS else "g9p_track_more.npz"))      # (bowl / can / mug: the second file)
     for key in ("rotation", "translation", "scale"):
         np.testing.assert_allclose(init[key], g[f"{tag}_0_{key}"], atol=1e-6, rtol=0)
     poses, aux = OM.track(sd, cfg, data, init, "torch")

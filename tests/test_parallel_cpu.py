@@ -2,6 +2,7 @@
 import os
 import socket
 
+import pytest
 import torch
 import torch.multiprocessing as mp
 
@@ -147,7 +148,7 @@ def _run_track_world(tmp_path, world, tag, env_extra=None, extra_args=()):
     return res.stdout
 
 
-def _compare_track_worlds(tmp_path, tags):
+def _compare_track_worlds(tmp_path, tags, n_traj=5):
     import json
     import pickle
     import numpy as np
@@ -170,7 +171,7 @@ def _compare_track_worlds(tmp_path, tags):
             assert a == b, where
 
     base = sorted((tmp_path / tags[0] / "results" / "data").glob("*.pkl"))
-    assert len(base) == 5                               # one pickle per trajectory
+    assert len(base) == n_traj                          # one pickle per trajectory
     res0 = json.load(open(tmp_path / f"{tags[0]}_result.json"))
     for tag in tags[1:]:
         other = sorted((tmp_path / tag / "results" / "data").glob("*.pkl"))
@@ -185,7 +186,7 @@ def _compare_track_worlds(tmp_path, tags):
             assert len(n0) == len(n1) and all(set(b) <= set(a) or set(a) <= set(b) for a, b in zip(n0, n1))
             same(r0, r1, p0.name)
         res = json.load(open(tmp_path / f"{tag}_result.json"))
-        assert res["frames"] == res0["frames"] == 20
+        assert res["frames"] == res0["frames"] == 4 * n_traj
         assert sorted(res["loss"]) == sorted(res0["loss"]) and res["loss"]
         for k in res0["loss"]:
             assert abs(res["loss"][k] - res0["loss"][k]) <= 1e-6 * max(1.0, abs(res0["loss"][k])), k
@@ -204,6 +205,23 @@ def test_track_harness_shards_trajectories_over_ranks_gloo(tmp_path):
     assert "rank 0 of 2" in out2
     res = _compare_track_worlds(tmp_path, ["w1", "w2", "w3"])
     assert any(k.startswith("avg_pred/") for k in res["loss"])
+
+
+@pytest.mark.parametrize("n_traj", [5, 19])
+def test_track_harness_world8_gloo(tmp_path, n_traj):
+    """The 8-rank shape of one node, blind: captra_amd.track under torch.distributed.run with EIGHT ranks (gloo,
+    CPU).  5 trajectories: five ranks hold one each and three are EMPTY (they still take part in every frame's all-gather and in the
+    result gathering); 19 trajectories: uneven shards 3,3,3,2,2,2,2,2 with batch_size 2 (a rank's last round is short).  Rank 0's
+    result pickles are the world-1 run's bit for bit."""
+    from captra_amd.parallel import shard_range
+    sizes = [len(shard_range(n_traj, 8, r)) for r in range(8)]
+    assert sum(sizes) == n_traj and (0 in sizes) == (n_traj == 5) and max(sizes) - min(sizes) == 1
+    env = {"CAPTRA_TEST_HOST_STEP": "1", "CAPTRA_DIST_BACKEND": "gloo", "CUDA_VISIBLE_DEVICES": "", "HIP_VISIBLE_DEVICES": "",
+           "CAPTRA_TEST_NUM_TRAJ": str(n_traj), "OMP_NUM_THREADS": "1"}
+    _run_track_world(tmp_path, 1, "w1", env)
+    out8 = _run_track_world(tmp_path, 8, "w8", env)
+    assert "rank 0 of 8" in out8
+    _compare_track_worlds(tmp_path, ["w1", "w8"], n_traj)
 
 
 def test_bench_dry_run_prints_the_launch_plan_without_a_gpu():
@@ -259,4 +277,8 @@ def test_scale_tool_dry_run_lists_the_north_star_table():
     p8 = by["configs[1] bottle fp32 x8"]["launch_plan"]
     assert p8["gpus_requested"] == 8 and "nccl" in p8["collective"] and "cpu_binding" in p8
     assert "--category mix6 --mlp-dtype bf16" in by["configs[2] mix6 bf16 x8"]["command"]
+    # the mix6 plan serves all six rigid categories: rank r tracks category 1 + r mod 6
+    mix = by["configs[2] mix6 bf16 x8"]["launch_plan"]
+    cats = [r["category"] for r in mix["ranks"]]
+    assert cats == [str(1 + r % 6) for r in range(8)] and set(cats) == {"1", "2", "3", "4", "5", "6"}
     assert "--nproc-per-node=8" in by["configs[4] backbone16k x8"]["command"]

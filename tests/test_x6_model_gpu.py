@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 import torch
 
+from tests import clouds
 from tests.test_model_gpu import G, TOL, _dev, _trainer, _trainer_physical, nocs_batch
 from tests.weights import make_state_dict
 
@@ -66,7 +67,7 @@ def test_track_first_frame_f32x6_vs_golden_random_weights(device, tag):
 
 
 @pytest.mark.parametrize("hipgraph", [False, True])
-@pytest.mark.parametrize("tag", ["bottle", "camera", "laptop", "drawers"])
+@pytest.mark.parametrize("tag", ["bottle", "camera", "laptop", "drawers", "bowl", "can", "mug", "bottle5"])
 def test_track_loop_f32x6_vs_golden(device, tag, hipgraph):
     """FREE-RUNNING Trainer.test in the f32x6 arithmetic against the reference's own EvalTrackModel loop (golden G9p): every pose of
     every frame within 1e-4, the predicted label counts equal, eager and captured."""
@@ -74,7 +75,7 @@ def test_track_loop_f32x6_vs_golden(device, tag, hipgraph):
     trainer, cfg, sd, data, tseed = _trainer_physical(tag, device, hipgraph=hipgraph, mlp_dtype="f32x6")
     assert trainer.model.mlp_dtype == "f32x6"
     trainer.model.use_graph = hipgraph
-    g = np.load(G / "g9p_track.npz")
+    g = np.load(G / ("g9p_track.npz" if tag in clouds.PHYSICAL_SETUPS else "g9p_track_more.npz"))
     torch.manual_seed(tseed)
     _lib.prof_enable(not hipgraph)
     _lib.prof_reset()

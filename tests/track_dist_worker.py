@@ -47,7 +47,7 @@ def main():
     from captra_amd import track
     torch.manual_seed(0)
     res = track.main(["--obj_category", "1", "--experiment_dir", os.path.join(out_dir, world_tag), "--batch_size", "2",
-                      "--data", "synthetic", "--num_traj", "5", "--num_frames", "4", "--random_init", "--save",
+                      "--data", "synthetic", "--num_traj", os.environ.get("CAPTRA_TEST_NUM_TRAJ", "5"), "--num_frames", "4", "--random_init", "--save",
                       "--pose_perturb/r", "0", "--pose_perturb/t", "0", "--pose_perturb/s", "0"] + extra)
     if int(os.environ.get("RANK", "0")) == 0:
         import json
