@@ -231,7 +231,7 @@ def b1_leg(device, steps: int = 200, otf_frames: int = 24, reps: int = 5):
     _lib.prof_enable(False)
     fams = {n: _lib.prof_read(n)[0] / 20 for n in _lib.prof_names() if _lib.prof_read(n)[1]}
     out = {"unit": "ms per frame", "convention": "reference README.md:267 (--batch_size=1), model.py:319",
-           "pre_cropped": {"ms_per_frame": round(pre * 1e3, 4), "frames_per_s": round(1.0 / pre, 1), "launch": "hipGraph replay of the step, pose chained",
+           "pre_cropped": {"ms_per_frame": round(pre * 1e3, 4), "frames_per_s": round(1.0 / pre, 1), "launch": "hipGraph replay, pose chained",
                            "kernel_ms_per_frame_networks_in_sequence": {k: round(v, 3) for k, v in sorted(fams.items(), key=lambda kv: -kv[1])[:8]}}}
     del graph, model
     cfg = make_config("1", experiment_dir=tempfile.mkdtemp(prefix="captra_bench_b1_"), nocs_otf=True, **{"init_frame/gt": True})
@@ -263,7 +263,7 @@ def b1_leg(device, steps: int = 200, otf_frames: int = 24, reps: int = 5):
     _lib.prof_enable(False)
     crop = {n: _lib.prof_read(n)[0] / (otf_frames - 1) for n in ("crop_ball", "fps")}
     out["nocs_otf"] = {"ms_per_frame": round(med * 1e3, 4), "frames_per_s": round(1.0 / med, 1),
-                       "launch": "EvalTrackModel.test, nocs_otf=True: re-crop + captured step per frame, Python included",
+                       "launch": "EvalTrackModel.test, nocs_otf=True, Python included",
                        "kernel_ms_per_frame": {"crop_ball": round(crop["crop_ball"], 4),
                                                "fps": round(crop["fps"], 4)}}
     out["note"] = f"median of {reps} runs each"
@@ -437,13 +437,11 @@ def hbm_ops_roofline(batch: int, device, reps: int = 5):
            "sequence": {"ms": round(seq_plain, 3), "frac": frac(tot_b, seq_plain),
                         "multi_radius_ms": round(seq_multi, 3), "multi_radius_frac": frac(tot_b, seq_multi),
                         "per_level_ms": round(seq_lvl, 3), "per_level_frac": frac(tot_b, seq_lvl)},
-           "multi_radius": {"frac": frac(tot_b, sum(ms_multi.values())),
-                            "ball_query_ms": round(ms_multi["ball_query"], 3), "group_points_ms": round(ms_multi["group_points"], 3)},
            "per_level": {"frac": frac(tot_b, sum(ms_lvl.values())), "GB/s": round(tot_b / (sum(ms_lvl.values()) * 1e-3) / 1e9, 1),
                          "ball_query_ms": round(ms_lvl["ball_query"], 3), "group_points_ms": round(ms_lvl["group_points"], 3)},
            "query_and_group": {"launches": len(qg_calls), "bytes_per_frame": round(qg_bytes / B), "ms": round(ms_qg, 3), "frac": frac(qg_bytes, ms_qg),
                                "GB/s": round(qg_bytes / (ms_qg * 1e-3) / 1e9, 1), "sequence_ms": round(seq_qg, 3), "sequence_frac": frac(qg_bytes, seq_qg),
-                               "api": "pointnet_lib.pointnet2_utils.QueryAndGroup(radius, nsample)(xyz, new_xyz, features), one launch per call"},
+                               "api": "pointnet2_utils.QueryAndGroup, one launch per call"},
            "fill_probe_GB/s": round(fill_gbs, 1)}
     return out
 
@@ -467,20 +465,23 @@ def config_leg(name: str, extra: list, timeout_s: int = 120):
     if res.returncode != 0 or not lines:
         return {"error": (res.stderr or res.stdout)[-500:], "command": " ".join(cmd[1:])}
     d = json.loads(lines[-1])
-    keep = ("metric", "value", "unit", "ms_per_step", "dtype", "steps", "roofline", "kernel_ms_per_step", "timed_blocks", "one_graph", "l1_stream", "pose_match")
+    keep = ("metric", "value", "unit", "ms_per_step", "dtype", "roofline", "kernel_ms_per_step", "timed_blocks", "one_graph", "l1_stream", "pose_match")
     out = {k: d[k] for k in keep if k in d}
     # compact (the main line has to fit the driver's 8 KB tail): what the leg ran is its command; the numbers stay
     out.pop("config", None)
     if isinstance(out.get("timed_blocks"), dict):
         out["timed_blocks"] = {k: out["timed_blocks"][k] for k in ("n", "ms_per_step_min", "ms_per_step_max") if k in out["timed_blocks"]}
     if isinstance(out.get("roofline"), dict):
-        out["roofline"] = {k: out["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_measured", "avg_launch_us", "flops_per_launch", "share_of_kernel_time") if k in out["roofline"]}
+        # (bound "mfma", unit TFLOP/s as the main line's roofline: not repeated per leg -- the line has to fit 8 KB)
+        out["roofline"] = {k: out["roofline"][k] for k in ("achieved", "peak", "frac", "traffic", "traffic_measured", "avg_launch_us", "flops_per_launch", "share_of_kernel_time") if k in out["roofline"]}
     if isinstance(out.get("pose_match"), dict):
         out["pose_match"] = {k: out["pose_match"][k] for k in ("trajectories", "max_abs_dR", "max_abs_dt", "max_abs_ds", "agree_5deg5cm", "within_1e-4") if k in out["pose_match"]}
     if isinstance(out.get("kernel_ms_per_step"), dict):
-        top = sorted(((k, v) for k, v in out["kernel_ms_per_step"].items() if not k.startswith("_")), key=lambda kv: -kv[1])[:5]
+        top = sorted(((k, v) for k, v in out["kernel_ms_per_step"].items() if not k.startswith("_")), key=lambda kv: -kv[1])[:4]
         out["kernel_ms_per_step"] = dict(top, _sum=out["kernel_ms_per_step"].get("_sum_captra_kernels"))
     out.pop("metric", None)
+    if out.get("unit") == "frames/s":
+        out.pop("unit")                 # (as the main line; backbone16k keeps its clouds/s)
     out["command"] = " ".join(os.path.relpath(c, here) if c.startswith(here) else c for c in cmd[1:])
     out["leg_wall_s"] = round(time.perf_counter() - t0, 1)
     return out
@@ -1024,7 +1025,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(cfg, sd, args.cpu_budget)
         out["cpu_baseline"]["reference_cpu_path_in_authoring_container"] = {
             "value": 3.08, "unit": "frames/s", "cores": 8,
-            "note": "BASELINE.md section 2: recorded in the authoring container (the reference's Python cannot travel), not re-measured here"}
+            "note": "BASELINE.md section 2: recorded in the authoring container, not re-measured here"}
         out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
     print(json.dumps(out), flush=True)
     if dist is not None:

@@ -949,7 +949,8 @@ __device__ __forceinline__ void l1_mlps(const L1Params &p, int s, int b, int c0,
             if (nets & 2) l1_scale<CFB, C1, C2, C3, K, PF, CG>(p, p.net[1], s, b, c0, nc, smem);
         }
     }
-    if (fetcher) *next_ticket = (int)tn;
+    // (a workgroup gave up meanwhile: hand on the end-of-run sentinel, not a ticket fetched before the counter was lifted)
+    if (fetcher) *next_ticket = __hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ? 0x7fffffff : (int)tn;
 }
 
 template <int CFA, int CFB>
@@ -1084,7 +1085,8 @@ __global__ __launch_bounds__(256, 2) void l1_stream_kernel(L1Params p) {
     for (int it = 0;; ++it) {
         __syncthreads();                               // (every wave is out of the previous ticket's LDS; the ticket word is there)
         const int t = s_word[it & 1];
-        if (t >= total) break;
+        // (unsigned: once a workgroup gave up the counter sits at or above 0x7fffffff, which read as a signed ticket is negative)
+        if ((unsigned)t >= (unsigned)total) break;
         int c0, nc, smask, b, nets;                    // first centre, centres, scales (bit s; the widest first), cloud, networks
         if (t < n_whole) {
             c0 = 32 * (t / p.b); nc = 32; smask = 7; b = t % p.b; nets = NNET == 2 ? 3 : 1;
@@ -1138,10 +1140,12 @@ __global__ __launch_bounds__(256, 2) void l1_stream_kernel(L1Params p) {
         }
         __syncthreads();
         if (!s_word[2]) {
-            // gave up: flag it and push the ticket counter past the end, so that every other workgroup leaves at its next fetch
+            // gave up: flag it and lift the ticket counter to a sentinel past every ticket, so that every other workgroup leaves at its
+            // next fetch.  A maximum, not an addition: any number of workgroups giving up on the same stalled sampler leave the
+            // counter at >= 0x7fffffff (an added 1 << 30 per workgroup wrapped to small tickets after four of them)
             if (tid == 0) {
                 __hip_atomic_fetch_or(ctl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_fetch_add(ctl, 1u << 30, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_max(ctl, 0x7fffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             break;
         }

@@ -61,24 +61,29 @@ def canonicalize(pts, mean, rot, trans, scale, num_parts: int = 1, want_cn=True,
 
 SPLIT_K_MAX_TRAJECTORIES = int(os.environ.get("CAPTRA_SPLIT_K_TRAJ", "2"))   # 0 = every dense layer the k-ascending chain at every batch
 SPLIT_K_POSITIONS = int(os.environ.get("CAPTRA_SPLIT_K_POSITIONS", "8192"))    # launches of at most this many positions (b * l) split k
-_split_k_on = False
+_split_k_on = False          # (kept for readers of the module attribute; the live flag is per thread: _split_k_active())
+
+
+def _split_k_active() -> bool:
+    return getattr(_TLS, "split_k_on", False)
 
 
 @contextlib.contextmanager
 def split_k(on: bool):
     """Dense layers launched inside with at most SPLIT_K_POSITIONS positions split k over a workgroup's four waves
     (captra_pw_set_splitk: a fixed summation order, 1e-5 relative from the bit-exact chain).  The track step of one or two
-    trajectories runs under it -- its 128- / 512-point levels are single dependent MFMA chains on an idle chip otherwise."""
-    global _split_k_on
-    if on:
+    trajectories runs under it -- its 128- / 512-point levels are single dependent MFMA chains on an idle chip otherwise.
+    Re-entrant and per thread, like the C knob it drives (thread_local): the previous state is restored on exit."""
+    prev = _split_k_active()
+    if on and not prev:
         L.lib().captra_pw_set_splitk(C.c_int(SPLIT_K_POSITIONS))
-        _split_k_on = True
+        _TLS.split_k_on = True
     try:
         yield
     finally:
-        if on:
+        if on and not prev:
             L.lib().captra_pw_set_splitk(C.c_int(0))
-            _split_k_on = False
+            _TLS.split_k_on = False
 
 
 @contextlib.contextmanager
@@ -638,6 +643,8 @@ def sa1_stream_supported(n: int, sa_modules, cfeats) -> bool:
     for mod, cf in zip(sa_modules, cfeats):
         if mod.training or mod.knn or cf not in (0, 3) or tuple(mod.nsample_list) != _L1_STREAM_K or mod.npoint > 512 or mod.npoint % 32:
             return False
+        if list(mod.radius_list) != sorted(mod.radius_list):
+            return False        # the kernel's scan rejects against the LAST radius and fills the lists in list order: radii ascending
         if mod.npoint != first.npoint or tuple(mod.radius_list) != tuple(first.radius_list):
             return False
         folded = mod._folded
@@ -1000,7 +1007,7 @@ def mlp_chain3(x, layers, act3: int = ACT_RELU):
         return mlp_chain_bf16(x, layers, [ACT_RELU, ACT_RELU, act3])
     # under split_k with few positions: three split-k launches (each fills the chip) instead of the one-launch chain, whose waves own
     # 32 positions each -- 128 waves for one 4096-point cloud, every one a serial chain of the three layers (49 -> ~25 us)
-    few = _split_k_on and B * l <= SPLIT_K_POSITIONS
+    few = _split_k_active() and B * l <= SPLIT_K_POSITIONS
     if few or not (USE_MLP_CHAIN and exact_path() and shape in _CHAIN3_SHAPES and shape[0] * l * 4 < (1 << 31)):
         y = pointwise_mlp(x, layers[0], ACT_RELU)
         y = pointwise_mlp(y, layers[1], ACT_RELU)

@@ -228,7 +228,16 @@ class EvalTrackModel(BaseModel):
         npcs_input["_canon"], npcs_input["_geom"] = (cam[0], cam[1]), geom
         scratch = (geom["sa1"].get("pooled") or {}).get("_scratch")
         if scratch is not None:
+            # STICKY give-up word: the scratch is a fresh (eager) or re-zeroed (replayed) buffer every step, so its flag says
+            # something about ONE launch; this one-word OR -- a launch of the step like any other, captured and replayed with it --
+            # keeps every step's verdict until check_l1_stream() reads it (before results are written, and by the bench)
             self._l1_scratch = scratch
+            sticky = getattr(self, "_l1_sticky", None)
+            if (sticky is None or sticky.device != scratch.device) and not torch.cuda.is_current_stream_capturing():
+                # (never created inside a capture: its zero fill would be replayed with the step; the loops run a step eagerly first)
+                sticky = self._l1_sticky = torch.zeros(1, dtype=torch.int32, device=scratch.device)
+            if sticky is not None and sticky.device == scratch.device:
+                sticky.bitwise_or_(scratch.view(torch.int32)[-15:-14])
         return True
 
     def _l1_stream_on(self, npcs_input) -> bool:
@@ -240,11 +249,17 @@ class EvalTrackModel(BaseModel):
                 and not (self.track_cfg["gt_label"] or self.track_cfg["nocs2d_label"]))
 
     def check_l1_stream(self) -> None:
-        """Raises when a consumer of the last level-1 stream launch gave up waiting for its sampler (bounded spins; synchronises)."""
+        """Raises when a consumer of ANY level-1 stream launch since the last check gave up waiting for its sampler (bounded spins;
+        synchronises): the sticky word every step ORs its flag into, then the last launch's own flag."""
         from . import fused
+        sticky = getattr(self, "_l1_sticky", None)
         scratch = getattr(self, "_l1_scratch", None)
-        if scratch is not None and fused.sa1_stream_gave_up(scratch):
-            raise RuntimeError("level-1 stream kernel: a consumer workgroup gave up waiting for the sampler; the step's outputs are incomplete")
+        bad = (sticky is not None and bool(sticky.item())) or (scratch is not None and fused.sa1_stream_gave_up(scratch))
+        if sticky is not None:
+            sticky.zero_()
+        if bad:
+            raise RuntimeError("level-1 stream kernel: a consumer workgroup gave up waiting for the sampler in a step of this run; "
+                               "its outputs (and every pose after it) are incomplete")
 
     def _step_rot(self, input, npcs_input, last_pose):
         """RotationNet up to its heads' raw per-point output (needs nothing of CoordinateNet's but, for one part, its geometry)."""

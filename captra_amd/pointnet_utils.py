@@ -239,8 +239,9 @@ class PointNetSetAbstractionMsg(_FoldCache, nn.Module):
         together = prezero and B <= MULTI_SCALE_MAX_CLOUDS
         if together:
             fused.L.lib().captra_sa_multi_begin()
+        keep = []     # the scales' temporaries (v1): between begin and end the launchers only RECORD raw pointers to them -- alive until the launch
         try:
-            res = self._forward_scales(folded, idx_list, feat, xyz_cn, new_xyz_n3, out, off, B)
+            res = self._forward_scales(folded, idx_list, feat, xyz_cn, new_xyz_n3, out, off, B, keep)
             if together:
                 together = False
                 with torch.cuda.device(xyz_cn.device):
@@ -251,8 +252,9 @@ class PointNetSetAbstractionMsg(_FoldCache, nn.Module):
                 fused.L.lib().captra_sa_multi_end(fused.L.stream_ptr())
             if prezero:
                 fused.L.lib().captra_sa_set_prezeroed(0)
+            keep.clear()
 
-    def _forward_scales(self, folded, idx_list, feat, xyz_cn, new_xyz_n3, out, off, B):
+    def _forward_scales(self, folded, idx_list, feat, xyz_cn, new_xyz_n3, out, off, B, keep=None):
         for layers, idx in zip(folded, idx_list):
             if fused.sa_scale_x6_supported(0 if feat is None else feat.shape[1], layers, idx.shape[2]):
                 fused.sa_scale_x6(feat, xyz_cn, new_xyz_n3, idx, layers, out, off)      # cfg['mlp_dtype'] = "f32x6"
@@ -264,11 +266,15 @@ class PointNetSetAbstractionMsg(_FoldCache, nn.Module):
                 continue
             if feat is not None and fused.exact_path() and fused.sa_scale_pipe_supported(feat.shape[1], layers, idx.shape[1], idx.shape[2], b=B, n=feat.shape[2]):
                 v1pm = fused.sa_first_layer_pre_pm(feat, layers[0])  # (B,N,c1) point-major: one 16-byte gather per register quad
+                if keep is not None:
+                    keep.append(v1pm)
                 fused.sa_scale_pre_pm(v1pm, xyz_cn, new_xyz_n3, idx, layers, out, off, feat.shape[1])
                 off += layers[-1].cout
                 continue
             if feat is not None and fused.sa_scale_pre_supported(feat.shape[1], layers, idx.shape[2]):
                 v1 = fused.sa_first_layer_pre(feat, layers[0])      # (B,c1,N): once per source point, not per neighbour
+                if keep is not None:
+                    keep.append(v1)
                 fused.sa_scale_pre(v1, xyz_cn, new_xyz_n3, idx, layers, out, off, feat.shape[1])
                 off += layers[-1].cout
                 continue

@@ -162,7 +162,7 @@ PHYSICAL_SETUPS = {
 # dense layers) to the reference end to end, not only the few-trajectory forms
 PHYSICAL_SETUPS_MORE = {
     "bowl": ("2", "obj_info_nocs.yml", "nocs", 7, 2, 25, 4325),
-    "can": ("4", "obj_info_nocs.yml", "nocs", 7, 2, 26, 4326),
+    "can": ("4", "obj_info_nocs.yml", "nocs", 7, 2, 43, 4326),
     "mug": ("6", "obj_info_nocs.yml", "nocs", 7, 2, 27, 4327),
     "bottle5": ("1", "obj_info_nocs.yml", "nocs", 5, 5, 29, 4328),
 }

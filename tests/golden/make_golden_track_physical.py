@@ -48,6 +48,8 @@ def main():
     ap.add_argument("--ref", default="/root/reference")
     ap.add_argument("--set", default="first", choices=["first", "more"],
                     help="first: clouds.PHYSICAL_SETUPS -> g9p_track.npz; more: clouds.PHYSICAL_SETUPS_MORE -> g9p_track_more.npz")
+    ap.add_argument("--scan", nargs=2, metavar=("TAG", "WSEEDS"), default=None,
+                    help="seed search, nothing written: run TAG of the chosen set with each weight seed of the comma list and print its margins")
     args = ap.parse_args()
     setups, target = (SETUPS, "g9p_track.npz") if args.set == "first" else (clouds.PHYSICAL_SETUPS_MORE, "g9p_track_more.npz")
     pu = import_reference(args.ref)
@@ -56,6 +58,9 @@ def main():
     torch.set_num_threads(8)
     from trainer import Trainer
     out = {}
+    if args.scan:
+        base = setups[args.scan[0]]
+        setups = {f"{args.scan[0]}@{w}": base[:5] + (int(w),) + base[6:] for w in args.scan[1].split(",")}
     for tag, (cat, objcfg, kind, frames, batch, wseed, tseed) in setups.items():
         cfg = ref_cfg(args.ref, cat, objcfg)
         cfg["init_frame"]["gt"] = False
@@ -85,11 +90,15 @@ def main():
         scales = np.stack([out[f"{tag}_{i}_scale"] for i in range(len(poses))])
         print(f"{tag}: scale range [{scales.min():.4f}, {scales.max():.4f}], min softmax gap {gap_min:.2e}, "
               f"label counts per part min {np.min(counts)}")
+        if args.scan:
+            continue
         assert scales.min() > 0.05 and scales.max() < 2.0, "trajectory left the physical regime"
         assert gap_min > 2e-5, f"{tag}: a point sits on a segmentation decision boundary (gap {gap_min:.2e}): pick another seed"
         assert np.min(counts) > 16, "a part is left with a handful of points: pick another seed"
         out[f"{tag}_min_softmax_gap"] = np.float32(gap_min)
         out[f"{tag}_label_counts"] = np.asarray(counts, np.int32)
+    if args.scan:
+        return
     np.savez_compressed(HERE / target, **out)
     print("wrote", HERE / target)
 
