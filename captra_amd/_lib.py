@@ -7,7 +7,9 @@ which is what the reference's glue does with `at::cuda::getCurrentCUDAStream()`
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
+import threading
 import os
 from pathlib import Path
 
@@ -66,6 +68,7 @@ _SIGNATURES = {
     "captra_pack_sa_bf16": [_INT] * 5 + [_P] * 7 + [_P],
     "captra_sa_scale_bf16": [_INT] * 9 + [_P] * 6 + [_INT, _INT, _P],
     "captra_pack_sa_x6": [_INT] * 4 + [_P] * 6 + [_P],
+    "captra_sa_scales_multi": [_INT, _P, _P, _P],
     "captra_pack_dense_x6": [_INT, _INT, _P, _P, _P],
     "captra_pointwise_mlp_x6": [_INT, _INT, _INT, _LL, _P, _P, _P, _P, _INT, _P, _P, _INT, _P],
     "captra_sa_scale_x6": [_INT] * 9 + [_P] * 7 + [_INT, _INT, _P],
@@ -101,6 +104,71 @@ class CaptraHipError(RuntimeError):
     pass
 
 
+# ---- per-call launch options (include/captra_hip.h captra_launch_opts) ---------------------------------------------------------
+# The C library holds no product-affecting state: what a caller wants different from the defaults travels with every call.  The
+# HOST layer keeps the calling thread's wishes here (fused.split_k / fused.centre_window / graph.BackbonePipe set them) and `call`
+# hands them to the `_ex` form of the entry points that read them.
+class LaunchOpts(C.Structure):
+    _fields_ = [("splitk_positions", _INT), ("sa_prezeroed", _INT), ("centre_m0", _INT), ("centre_mc", _INT), ("reserved_cus", _INT),
+                ("dyn_slot", _P)]
+
+
+class SaScaleJob(C.Structure):
+    _fields_ = ([(k, _INT) for k in ("pre", "b", "n", "m", "k", "cfeat", "c1", "c2", "c3")]
+                + [(k, _P) for k in ("feat_or_v1", "xyz_cn", "new_xyz", "idx", "w1", "b1", "w2", "b2", "w3", "b3", "out")]
+                + [("out_ctotal", _INT), ("co_off", _INT)])
+
+
+EX_ENTRY_POINTS = {"captra_ball_query", "captra_ball_query_multi", "captra_pointwise_mlp", "captra_pointwise_mlp2", "captra_pointwise_mlp_pm",
+                   "captra_pointwise_mlp_gn", "captra_sa_scale_fused", "captra_sa_scale_pre_pm", "captra_sa_scale_bf16", "captra_head12_bf16"}
+_OPTS_TLS = threading.local()
+
+
+class _OptState:
+    __slots__ = ("splitk_positions", "sa_prezeroed", "centre_m0", "centre_mc", "reserved_cus", "dyn_pool", "dyn_slots", "dyn_next")
+
+    def __init__(self):
+        self.splitk_positions = self.sa_prezeroed = self.centre_m0 = self.centre_mc = self.reserved_cus = 0
+        self.dyn_pool, self.dyn_slots, self.dyn_next = 0, 0, 0
+
+
+def opt_state() -> _OptState:
+    st = getattr(_OPTS_TLS, "st", None)
+    if st is None:
+        st = _OPTS_TLS.st = _OptState()
+    return st
+
+
+@contextlib.contextmanager
+def launch_options(**kw):
+    """Options of the calling thread's launches inside the block (fields of captra_launch_opts; `dyn_pool` = (device pointer of
+    an int32 buffer, slots): every launch that hands its centres out dynamically takes the next slot, round robin).  Restored on exit."""
+    st = opt_state()
+    prev = {k: getattr(st, k) for k in _OptState.__slots__}
+    for k, v in kw.items():
+        if k == "dyn_pool":
+            st.dyn_pool, st.dyn_slots, st.dyn_next = (int(v[0]), int(v[1]), 0) if v else (0, 0, 0)
+        else:
+            setattr(st, k, int(v))
+    try:
+        yield
+    finally:
+        for k, v in prev.items():
+            setattr(st, k, v)
+
+
+def current_opts(name: str | None = None):
+    """The calling thread's options as a captra_launch_opts (None when they are the defaults)."""
+    st = opt_state()
+    dyn = 0
+    if st.dyn_slots > 0 and name in ("captra_sa_scale_fused", "captra_sa_scale_pre_pm"):
+        dyn = st.dyn_pool + 4 * (st.dyn_next % st.dyn_slots)
+        st.dyn_next += 1
+    if not (st.splitk_positions or st.sa_prezeroed or st.centre_mc > 0 or st.reserved_cus or dyn):
+        return None
+    return LaunchOpts(st.splitk_positions, st.sa_prezeroed, st.centre_m0, st.centre_mc, st.reserved_cus, dyn or None)
+
+
 def lib():
     """Load libcaptra_hip.so once; raise loudly if it is not built."""
     global _lib
@@ -117,6 +185,10 @@ def lib():
                 continue  # a stale build: call() raises when the symbol is actually needed
             fn.argtypes = args
             fn.restype = _INT
+            if name in EX_ENTRY_POINTS:
+                fx = getattr(l, name + "_ex")
+                fx.argtypes = args[:-1] + [_P, _P]
+                fx.restype = _INT
         l.captra_error_string.argtypes = [_INT]
         l.captra_error_string.restype = C.c_char_p
         l.captra_version.restype = C.c_char_p
@@ -166,17 +238,6 @@ def lib():
             l.captra_sa1_stream_set_fine.restype = None
             l.captra_sa1_stream_set_whole.argtypes = [_INT]
             l.captra_sa1_stream_set_whole.restype = None
-        if hasattr(l, "captra_sa_multi_begin"):
-            l.captra_sa_multi_begin.argtypes = []
-            l.captra_sa_multi_begin.restype = None
-            l.captra_sa_multi_end.argtypes = [_P]
-            l.captra_sa_multi_end.restype = _INT
-        if hasattr(l, "captra_pw_set_splitk"):
-            l.captra_pw_set_splitk.argtypes = [_INT]
-            l.captra_pw_set_splitk.restype = None
-        if hasattr(l, "captra_sa_set_prezeroed"):
-            l.captra_sa_set_prezeroed.argtypes = [_INT]
-            l.captra_sa_set_prezeroed.restype = None
         if hasattr(l, "captra_neck_chain_set_split"):
             l.captra_neck_chain_set_split.argtypes = [_INT]
             l.captra_neck_chain_set_split.restype = None
@@ -186,6 +247,8 @@ def lib():
         if hasattr(l, "captra_pointwise_mlp_gn_tiles"):
             l.captra_pointwise_mlp_gn_tiles.argtypes = [_INT, _INT, _LL]
             l.captra_pointwise_mlp_gn_tiles.restype = _INT
+            l.captra_pointwise_mlp_gn_tiles_ex.argtypes = [_INT, _INT, _LL, _P]
+            l.captra_pointwise_mlp_gn_tiles_ex.restype = _INT
         _lib = l
         # A/B switches for measurements (thread-local knobs of the library, set for the importing thread)
         import os
@@ -236,6 +299,11 @@ def call(name: str, *args) -> None:
         fn = getattr(lib(), name)
     except AttributeError as e:
         raise CaptraHipError(f"{LIB_PATH} does not export {name}: rebuild it (python captra_amd/build.py)") from e
+    if name in EX_ENTRY_POINTS:
+        o = current_opts(name)
+        if o is not None:
+            check(getattr(lib(), name + "_ex")(*args, C.byref(o), stream_ptr()), name + "_ex")
+            return
     check(fn(*args, stream_ptr()), name)
 
 

@@ -352,7 +352,7 @@ CAPTRA_KNOB int g_bq_cpw = 0;     // experiment knob: centres per wave, 0 / 1 = 
 CAPTRA_KNOB int g_bq_prune = 0;   // opt-in: 1 = small radii of 1024..4096-point clouds from the cell grid
 
 int launch_ball_query(int b, int n, int m, int nr, const float *radius, const int *nsample,
-                      const float *new_xyz, const float *xyz, int *const *idx, hipStream_t s) {
+                      const float *new_xyz, const float *xyz, int *const *idx, const captra_launch_opts *opts, hipStream_t s) {
     if (b < 0 || n < 0 || m < 0 || nr < 1 || nr > BQ_MAXR) return -1;
     if (b == 0 || m == 0) return 0;
     BqParams prm;
@@ -379,7 +379,7 @@ int launch_ball_query(int b, int n, int m, int nr, const float *radius, const in
     const bool one = !prune && g_bq_cpw != 2;
     const int cpw = one ? 1 : BQ_CPW;
     int wm0, wmc;
-    (void)captra_centre_window(m, &wm0, &wmc);
+    (void)captra_centre_window(opts, m, &wm0, &wmc);
     if (wmc == 0) return 0;
     prm.m0 = wm0; prm.mhi = wm0 + wmc;
     dim3 grid((wmc + BQ_WAVES * cpw - 1) / (BQ_WAVES * cpw), b);
@@ -425,14 +425,23 @@ int launch_ball_query(int b, int n, int m, int nr, const float *radius, const in
 extern "C" void captra_ball_query_set_prune(int on) { g_bq_prune = on; }
 extern "C" void captra_ball_query_set_cpw(int v) { g_bq_cpw = v; }
 
+extern "C" int captra_ball_query_ex(int b, int n, int m, float radius, int nsample, const float *new_xyz,
+                                    const float *xyz, int *idx, const captra_launch_opts *opts, captra_stream_t stream) {
+    int *idxs[1] = {idx};
+    return launch_ball_query(b, n, m, 1, &radius, &nsample, new_xyz, xyz, idxs, opts, (hipStream_t)stream);
+}
 extern "C" int captra_ball_query(int b, int n, int m, float radius, int nsample, const float *new_xyz,
                                  const float *xyz, int *idx, captra_stream_t stream) {
-    int *idxs[1] = {idx};
-    return launch_ball_query(b, n, m, 1, &radius, &nsample, new_xyz, xyz, idxs, (hipStream_t)stream);
+    return captra_ball_query_ex(b, n, m, radius, nsample, new_xyz, xyz, idx, nullptr, stream);
 }
 
+extern "C" int captra_ball_query_multi_ex(int b, int n, int m, int nr, const float *radius,
+                                          const int *nsample, const float *new_xyz, const float *xyz,
+                                          int *const *idx, const captra_launch_opts *opts, captra_stream_t stream) {
+    return launch_ball_query(b, n, m, nr, radius, nsample, new_xyz, xyz, idx, opts, (hipStream_t)stream);
+}
 extern "C" int captra_ball_query_multi(int b, int n, int m, int nr, const float *radius,
                                        const int *nsample, const float *new_xyz, const float *xyz,
                                        int *const *idx, captra_stream_t stream) {
-    return launch_ball_query(b, n, m, nr, radius, nsample, new_xyz, xyz, idx, (hipStream_t)stream);
+    return captra_ball_query_multi_ex(b, n, m, nr, radius, nsample, new_xyz, xyz, idx, nullptr, stream);
 }

@@ -2,10 +2,10 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "captra_hip.h"   // captra_launch_opts, captra_stream_t
 
 #define CAPTRA_WAVE 64
 
-typedef void *captra_stream_t;
 
 // ---- profiling hooks (prof.cpp) -------------------------------------------------------------
 // CAPTRA_LAUNCH brackets a kernel launch with HIP events on the launch stream when profiling
@@ -38,10 +38,17 @@ struct CaptraProfScope {
 #define CAPTRA_ABLATIONS 0
 #endif
 
-// prof.cpp: CUs the calling thread's persistent launches leave free (captra_set_reserved_cus)
-int captra_reserved_cus();
-// prof.cpp: the calling thread's centre window (captra_set_centre_window); true when one is set
-bool captra_centre_window(int m, int *m0, int *mc);
+// Per-call options (include/captra_hip.h captra_launch_opts; NULL = defaults): the library keeps no product-affecting state.
+// CUs a persistent launch leaves free
+static inline int captra_reserved_cus(const captra_launch_opts *o) { return (o != nullptr && o->reserved_cus > 0) ? o->reserved_cus : 0; }
+// the call's centre window clipped to [0, m); true when one is given
+static inline bool captra_centre_window(const captra_launch_opts *o, int m, int *m0, int *mc) {
+    if (o == nullptr || o->centre_mc <= 0) { *m0 = 0; *mc = m; return false; }
+    const int w0 = o->centre_m0 < 0 ? 0 : o->centre_m0;
+    *m0 = w0 < m ? w0 : m;
+    *mc = o->centre_mc < m - *m0 ? o->centre_mc : m - *m0;
+    return true;
+}
 
 static inline int captra_last_error() { return (int)hipGetLastError(); }
 

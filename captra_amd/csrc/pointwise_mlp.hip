@@ -863,10 +863,10 @@ extern "C" void captra_pw_set_occupancy(int occ) { g_pw_occ = occ; }
 static inline unsigned pw_occupancy_pad() { return g_pw_occ == 2 ? 60000u : (g_pw_occ == 3 ? 45000u : 0u); }
 // split-K form for launches of at most this many positions (b * l) and at least 128 input channels; 0 = never (default: every
 // layer is the k-ascending chain).  Set by EvalTrackModel for steps of one or two trajectories.
-static CAPTRA_KNOB int g_pw_splitk = 0;
-extern "C" void captra_pw_set_splitk(int max_positions) { g_pw_splitk = max_positions < 0 ? 0 : max_positions; }
-static inline bool pw_use_splitk(int b, const PwParams &p) {
-    return g_pw_splitk > 0 && (long long)b * p.L <= g_pw_splitk && p.cin >= 128 && (p.y_pm == 0 || p.cout % 4 == 0) &&
+// (captra_launch_opts::splitk_positions of the call -- no state in the library: include/captra_hip.h section 3)
+static inline int pw_splitk_of(const captra_launch_opts *o) { return (o != nullptr && o->splitk_positions > 0) ? o->splitk_positions : 0; }
+static inline bool pw_use_splitk(int splitk_pos, int b, const PwParams &p) {
+    return splitk_pos > 0 && (long long)b * p.L <= splitk_pos && p.cin >= 128 && (p.y_pm == 0 || p.cout % 4 == 0) &&
            (long long)p.cin * p.L * 4 < (1ll << 31);
 }
 template <bool SRC2, bool AFF = false, bool ST = false>
@@ -961,14 +961,15 @@ extern "C" int captra_pack_weights(int cin, int cout, const float *wt, const flo
     return err != 0 ? err : captra_pack_weights_frag(cin, cout, wt_packed, stream);   // the fragment-ordered image behind it
 }
 
-extern "C" int captra_pointwise_mlp(int b, int cin, int cout, long long l, const float *x, const float *wt_packed,
-                                    const float *bias_packed, int act, float *y, captra_stream_t stream) {
+extern "C" int captra_pointwise_mlp_ex(int b, int cin, int cout, long long l, const float *x, const float *wt_packed,
+                                    const float *bias_packed, int act, float *y, const captra_launch_opts *opts, captra_stream_t stream) {
+    const int splitk_pos = pw_splitk_of(opts);
     if (b < 0 || cin < 1 || cout < 1 || l < 0 || act < 0 || act > 2) return -1;
     if (b == 0 || l == 0) return 0;
     PwParams p = {};
     p.cin = cin; p.cout = cout; p.ldw = (cout + 127) / 128 * 128; p.L = l; p.x = x; p.wt = wt_packed; p.bias = bias_packed;
     p.y = y; p.act = act;
-    if (pw_use_splitk(b, p)) return launch_pw_splitk<false>(b, p, (hipStream_t)stream);
+    if (pw_use_splitk(splitk_pos, b, p)) return launch_pw_splitk<false>(b, p, (hipStream_t)stream);
     if (g_pw_direct) {
         const int err = launch_pw_direct(b, p, (hipStream_t)stream);
         if (err != -3) return err;
@@ -977,14 +978,19 @@ extern "C" int captra_pointwise_mlp(int b, int cin, int cout, long long l, const
     if (vec) return launch_pw<PRO_PLAIN, EPI_STORE, true>(b, p, (hipStream_t)stream, "pointwise_mlp");
     return launch_pw<PRO_PLAIN, EPI_STORE, false>(b, p, (hipStream_t)stream, "pointwise_mlp");
 }
+extern "C" int captra_pointwise_mlp(int b, int cin, int cout, long long l, const float *x, const float *wt_packed,
+                                    const float *bias_packed, int act, float *y, captra_stream_t stream) {
+    return captra_pointwise_mlp_ex(b, cin, cout, l, x, wt_packed, bias_packed, act, y, nullptr, stream);
+}
 
 // The layer on the channel concat [x; x2] WITHOUT building it (SA3's [xyz, feat], pointnet_utils.py:171-188; FP3's
 // [points1, repeat(points2)], pointnet_utils.py:265-270): x (B,csplit,L), x2 (B,cin - csplit,L), or (B,cin - csplit) with x2_bcast
 // (one vector per cloud, the same for every position).  The operand rows are read in the concat's order, so the k-ascending chain
 // -- and every output bit -- is that of captra_pointwise_mlp on the concatenated tensor.  -2 outside the direct kernel's small-launch
 // shape or when the two tensors lie more than 2^30 bytes apart (the caller concatenates).
-extern "C" int captra_pointwise_mlp2(int b, int cin, int csplit, int cout, long long l, const float *x, const float *x2, int x2_bcast,
-                                     const float *wt_packed, const float *bias_packed, int act, float *y, captra_stream_t stream) {
+extern "C" int captra_pointwise_mlp2_ex(int b, int cin, int csplit, int cout, long long l, const float *x, const float *x2, int x2_bcast,
+                                     const float *wt_packed, const float *bias_packed, int act, float *y, const captra_launch_opts *opts, captra_stream_t stream) {
+    const int splitk_pos = pw_splitk_of(opts);
     if (b < 0 || cin < 2 || csplit < 1 || csplit >= cin || cout < 1 || l < 0 || act < 0 || act > 2 || x2 == nullptr) return -1;
     if (b == 0 || l == 0) return 0;
     const long long span1 = (long long)b * csplit * l * 4, span2 = (long long)b * (cin - csplit) * (x2_bcast ? 1 : l) * 4;
@@ -995,7 +1001,7 @@ extern "C" int captra_pointwise_mlp2(int b, int cin, int csplit, int cout, long 
     PwParams p = {};
     p.cin = cin; p.cout = cout; p.ldw = (cout + 127) / 128 * 128; p.L = l; p.x = x; p.wt = wt_packed; p.bias = bias_packed;
     p.y = y; p.act = act; p.x2 = x2; p.csplit = csplit; p.x2_bcast = x2_bcast;
-    if (pw_use_splitk(b, p)) return launch_pw_splitk<true>(b, p, (hipStream_t)stream);
+    if (pw_use_splitk(splitk_pos, b, p)) return launch_pw_splitk<true>(b, p, (hipStream_t)stream);
     if (waves22 < 2048) {
         dim3 grid((unsigned)((l + 63) / 64), (cout + 63) / 64, b);
         CAPTRA_LAUNCH("pointwise_mlp", (pw_direct_kernel<1, 1, 2, 2, false, false, false, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
@@ -1005,26 +1011,36 @@ extern "C" int captra_pointwise_mlp2(int b, int cin, int csplit, int cout, long 
     }
     return captra_last_error();
 }
+extern "C" int captra_pointwise_mlp2(int b, int cin, int csplit, int cout, long long l, const float *x, const float *x2, int x2_bcast,
+                                     const float *wt_packed, const float *bias_packed, int act, float *y, captra_stream_t stream) {
+    return captra_pointwise_mlp2_ex(b, cin, csplit, cout, l, x, x2, x2_bcast, wt_packed, bias_packed, act, y, nullptr, stream);
+}
 
 // The same layer with a POINT-major result y (B,L,cout): what a consumer that gathers whole points reads with 16-byte loads
 // (the SA2 scales' pre-transformed first layer, csrc/sa_pipe.hip).  Direct-operand kernel only: -2 outside its range.
-extern "C" int captra_pointwise_mlp_pm(int b, int cin, int cout, long long l, const float *x, const float *wt_packed,
-                                       const float *bias_packed, int act, float *y, captra_stream_t stream) {
+extern "C" int captra_pointwise_mlp_pm_ex(int b, int cin, int cout, long long l, const float *x, const float *wt_packed,
+                                       const float *bias_packed, int act, float *y, const captra_launch_opts *opts, captra_stream_t stream) {
+    const int splitk_pos = pw_splitk_of(opts);
     if (b < 0 || cin < 1 || cout < 1 || l < 0 || act < 0 || act > 2) return -1;
     if (cout % 4 != 0 || (reinterpret_cast<uintptr_t>(y) & 15) != 0) return -2;
     if (b == 0 || l == 0) return 0;
     PwParams p = {};
     p.cin = cin; p.cout = cout; p.ldw = (cout + 127) / 128 * 128; p.L = l; p.x = x; p.wt = wt_packed; p.bias = bias_packed;
     p.y = y; p.act = act; p.y_pm = 1;
-    if (pw_use_splitk(b, p)) return launch_pw_splitk<false>(b, p, (hipStream_t)stream);
+    if (pw_use_splitk(splitk_pos, b, p)) return launch_pw_splitk<false>(b, p, (hipStream_t)stream);
     const int err = launch_pw_direct(b, p, (hipStream_t)stream);
     return err == -3 ? -2 : err;
 }
+extern "C" int captra_pointwise_mlp_pm(int b, int cin, int cout, long long l, const float *x, const float *wt_packed,
+                                       const float *bias_packed, int act, float *y, captra_stream_t stream) {
+    return captra_pointwise_mlp_pm_ex(b, cin, cout, l, x, wt_packed, bias_packed, act, y, nullptr, stream);
+}
 
 // Dense layer inside a Conv -> GroupNorm -> ReLU chain (see include/captra_hip.h).
-extern "C" int captra_pointwise_mlp_gn(int b, int cin, int cout, long long l, const float *x, const float *wt_packed,
+extern "C" int captra_pointwise_mlp_gn_ex(int b, int cin, int cout, long long l, const float *x, const float *wt_packed,
                                        const float *bias_packed, const float *ab_in, int act, float *y, float *stats_out,
-                                       int stats_t, captra_stream_t stream) {
+                                       int stats_t, const captra_launch_opts *opts, captra_stream_t stream) {
+    const int splitk_pos = pw_splitk_of(opts);
     if (b < 0 || cin < 1 || cout < 1 || l < 0 || act < 0 || act > 2) return -1;
     if (stats_out != nullptr && act != ACT_NONE) return -1;           // statistics are those of the raw output
     if ((long long)cin * l * 4 >= (1ll << 31)) return -2;
@@ -1036,10 +1052,10 @@ extern "C" int captra_pointwise_mlp_gn(int b, int cin, int cout, long long l, co
     const long long waves22 = ((l + 63) / 64) * ((cout + 63) / 64) * b;
     // (the same rule as captra_pointwise_mlp_gn_tiles: under captra_pw_set_splitk every launch within its position limit takes the
     // 32-column statistics tiles, split-k or -- fewer than 128 input channels -- the 32x32 chain form)
-    if (cout > 64 && (waves22 < 2048 || (g_pw_splitk > 0 && (long long)b * l <= g_pw_splitk))) {
+    if (cout > 64 && (waves22 < 2048 || (splitk_pos > 0 && (long long)b * l <= splitk_pos))) {
         // few positions (single-trajectory latency): 32x32 wave tiles, statistics per 32-column tile
         if (stats_out != nullptr && stats_t != (int)((l + 63) / 64) * 2) return -1;
-        if (pw_use_splitk(b, p)) {
+        if (pw_use_splitk(splitk_pos, b, p)) {
             if (ab_in != nullptr && stats_out != nullptr) return launch_pw_splitk<false, true, true>(b, p, s);
             if (stats_out != nullptr) return launch_pw_splitk<false, false, true>(b, p, s);
             if (ab_in != nullptr) return launch_pw_splitk<false, true, false>(b, p, s);
@@ -1073,7 +1089,7 @@ extern "C" int captra_pointwise_mlp_gn(int b, int cin, int cout, long long l, co
     }
     if (stats_out != nullptr) return -2;   // statistics only from the 64x64 wave-tile configuration
     // few positions and few output channels (a head's last layer at one trajectory: 16 workgroups, each wave a chain of cin / 2 steps)
-    if (pw_use_splitk(b, p)) return ab_in != nullptr ? launch_pw_splitk<false, true, false>(b, p, s) : launch_pw_splitk<false>(b, p, s);
+    if (pw_use_splitk(splitk_pos, b, p)) return ab_in != nullptr ? launch_pw_splitk<false, true, false>(b, p, s) : launch_pw_splitk<false>(b, p, s);
     dim3 grid((unsigned)((l + 255) / 256), 1, b);
     if (cout > 32) {
         if (ab_in != nullptr) {
@@ -1088,12 +1104,19 @@ extern "C" int captra_pointwise_mlp_gn(int b, int cin, int cout, long long l, co
     }
     return captra_last_error();
 }
+extern "C" int captra_pointwise_mlp_gn(int b, int cin, int cout, long long l, const float *x, const float *wt_packed,
+                                       const float *bias_packed, const float *ab_in, int act, float *y, float *stats_out,
+                                       int stats_t, captra_stream_t stream) {
+    return captra_pointwise_mlp_gn_ex(b, cin, cout, l, x, wt_packed, bias_packed, ab_in, act, y, stats_out, stats_t, nullptr, stream);
+}
 
-extern "C" int captra_pointwise_mlp_gn_tiles(int b, int cout, long long l) {
+extern "C" int captra_pointwise_mlp_gn_tiles_ex(int b, int cout, long long l, const captra_launch_opts *opts) {
+    const int splitk_pos = pw_splitk_of(opts);
     const long long waves22 = ((l + 63) / 64) * ((cout + 63) / 64) * b;
-    const bool splitk = g_pw_splitk > 0 && (long long)b * l <= g_pw_splitk;       // (the split-k form: 32-column tiles; cin >= 128 is the caller's layer)
+    const bool splitk = splitk_pos > 0 && (long long)b * l <= splitk_pos;       // (the split-k form: 32-column tiles; cin >= 128 is the caller's layer)
     return (cout > 64 && (waves22 < 2048 || splitk)) ? (int)((l + 63) / 64) * 2 : (int)((l + 127) / 128) * 2;
 }
+extern "C" int captra_pointwise_mlp_gn_tiles(int b, int cout, long long l) { return captra_pointwise_mlp_gn_tiles_ex(b, cout, l, nullptr); }
 
 extern "C" int captra_gn_finalize(int b, int c, int channels_per_group, int stats_t, long long n, float eps,
                                   const float *stats, const float *gamma, const float *beta, float *ab,

@@ -125,29 +125,7 @@ const char *captra_error_string(int err) {
 
 const char *captra_version(void) { return "captra_hip 0.1 (gfx950)"; }
 
-// Persistent kernels (one workgroup per CU slot, centres walked statically) launched by the calling thread size their grid for
-// `n` CUs fewer: a schedule that runs one-workgroup-per-cloud samplers on another stream at the same time (captra_amd/graph.py
-// BackbonePipe) keeps every persistent workgroup resident that way.  A workgroup that finds its CU taken starts when another
-// one ENDS, i.e. the launch takes twice as long (measured: the MLP stage of configs[4] 2.05 -> 3.4 ms with 8 of 256 CUs masked).
-static thread_local int g_reserved_cus = 0;
-// Centre WINDOW of the next set-abstraction launches of the calling thread (captra_ball_query_multi, captra_sa_scale_fused on
-// the LDS-weights kernels, captra_sa_scale_bf16 on the small-input scales): they process centres [m0, m0 + mc) of every cloud
-// and leave the rest of their (B, M, ...) outputs alone.  What lets a level's ball query + shared MLPs start on the first
-// centres while the sampler is still picking the later ones (captra_fps_gather_part; captra_amd/backbones.py).  mc <= 0: all.
-static thread_local int g_win_m0 = 0, g_win_mc = 0;
-void captra_set_centre_window(int m0, int mc) { g_win_m0 = m0 < 0 ? 0 : m0; g_win_mc = mc < 0 ? 0 : mc; }
-void captra_set_reserved_cus(int n) { g_reserved_cus = n < 0 ? 0 : n; }
-
 }  // extern "C"
-
-int captra_reserved_cus() { return g_reserved_cus; }
-// -> true when a window is set; (m0, mc) clipped to [0, m)
-bool captra_centre_window(int m, int *m0, int *mc) {
-    if (g_win_mc <= 0) { *m0 = 0; *mc = m; return false; }
-    *m0 = g_win_m0 < m ? g_win_m0 : m;
-    *mc = g_win_mc < m - *m0 ? g_win_mc : m - *m0;
-    return true;
-}
 
 
 // ---- zeroing as a kernel (common.h: captra_zero_async) ---------------------------------------------------------------------

@@ -749,9 +749,9 @@ extern "C" int captra_pack_sa_bf16(int cfeat, int c1, int c2, int c3, int pre, c
 
 // One SA scale.  pre = 0: feat_or_v1 = feat (B,cfeat,N) fp32 (cfeat + 3 <= 6); pre = 1: feat_or_v1 = v1 (B,N,c1) fp32 POINT-major
 // = b1 + W1[feature rows] feat.  img: captra_pack_sa_bf16 with the same (cfeat, c1, c2, c3, pre).
-extern "C" int captra_sa_scale_bf16(int b, int n, int m, int k, int cfeat, int c1, int c2, int c3, int pre, const float *feat_or_v1,
+extern "C" int captra_sa_scale_bf16_ex(int b, int n, int m, int k, int cfeat, int c1, int c2, int c3, int pre, const float *feat_or_v1,
                                     const float *xyz_cn, const float *new_xyz, const int *idx, const unsigned char *img, float *out,
-                                    int out_ctotal, int co_off, captra_stream_t stream) {
+                                    int out_ctotal, int co_off, const captra_launch_opts *opts, captra_stream_t stream) {
     if (b < 0 || n < 1 || m < 0 || k < 1 || cfeat < 0 || c1 < 1 || c2 < 1 || c3 < 1) return -1;
     if (out_ctotal < co_off + c3 || co_off < 0) return -1;
     if (b == 0 || m == 0) return 0;
@@ -763,7 +763,7 @@ extern "C" int captra_sa_scale_bf16(int b, int n, int m, int k, int cfeat, int c
     p.prof = captra_sa_prof_ptr();
     {
         int wm0, wmc;
-        const bool win = captra_centre_window(m, &wm0, &wmc);
+        const bool win = captra_centre_window(opts, m, &wm0, &wmc);
         if (win && pre) return -2;            // a centre window is the small-input scales' only (sa_bf16_kernel)
         p.m0 = wm0; p.mhi = wm0 + wmc;
     }
@@ -813,6 +813,11 @@ extern "C" int captra_sa_scale_bf16(int b, int n, int m, int k, int cfeat, int c
 #undef SB_CASE1
 #undef SB_MATCH
     return -2;
+}
+extern "C" int captra_sa_scale_bf16(int b, int n, int m, int k, int cfeat, int c1, int c2, int c3, int pre, const float *feat_or_v1,
+                                    const float *xyz_cn, const float *new_xyz, const int *idx, const unsigned char *img, float *out,
+                                    int out_ctotal, int co_off, captra_stream_t stream) {
+    return captra_sa_scale_bf16_ex(b, n, m, k, cfeat, c1, c2, c3, pre, feat_or_v1, xyz_cn, new_xyz, idx, img, out, out_ctotal, co_off, nullptr, stream);
 }
 
 // Only the two forms the tests compare (bit 0: the small-input scales without gather prefetch / fragment ring, bit 3: the SA2 scales on

@@ -803,18 +803,21 @@ extern "C" void captra_sa_fused_set_mode(int mode) { g_sa_mode = mode; }
 static CAPTRA_KNOB int g_sa_split = 1;  // a wave per slice for small batches: 0 = never, 1 = heuristic, 2 = always (tests)
 extern "C" void captra_sa_fused_set_split(int v) { g_sa_split = v; }
 int captra_sa_split_knob() { return g_sa_split; }
-// The three small-input scales of a level as ONE launch (sa_wave_lds3_kernel): between captra_sa_multi_begin and captra_sa_multi_end
-// the LDS-weight scales are recorded instead of launched; the end launches them together when they are the level's three shapes in
-// order, none with a dynamic hand-out, else one after the other as they would have been.  Thread-local, not re-entrant.
+// The three small-input scales of a level as ONE launch (sa_wave_lds3_kernel): captra_sa_scales_multi (end of this file) hands
+// every job's launcher a COLLECTOR on its own stack; the LDS-weight scales are recorded into it instead of launched and flushed at
+// the end -- together when they are the level's three shapes in order, none with a dynamic hand-out, else one after the other as
+// they would have been.  No state outside the call: any number of host threads may run it at once.
 struct SlRecord {
     SwParams q;
     unsigned grid;
     int code, cf, lds;
     void (*launch)(const SwParams &, unsigned, int, hipStream_t);
 };
-static thread_local SlRecord g_sl_rec[3];
-static thread_local int g_sl_n = 0;
-static CAPTRA_KNOB int g_sl_collect = 0;
+struct SlCollect {
+    SlRecord rec[3];
+    int n = 0;
+    alignas(16) unsigned char sp[1024];      // sa_pipe.hip's records of the second level's scales (captra_sp_collect_*)
+};
 template <int CF, int C1, int C2, int C3>
 static void sl_launch_one(const SwParams &q, unsigned grid, int lds, hipStream_t s) {
     CAPTRA_LAUNCH("sa_scale_fused", (sa_wave_lds_kernel<CF, C1, C2, C3>), dim3(grid), dim3(SL_WAVES * 64), lds, s, q);
@@ -832,30 +835,21 @@ static void sl_launch_three(const SlRecord (&r)[3], hipStream_t s) {
     q3.g0 = (int)r[0].grid; q3.g1 = (int)r[1].grid;
     CAPTRA_LAUNCH("sa_scale_fused", (sa_wave_lds3_kernel<CF>), dim3(r[0].grid + r[1].grid + r[2].grid), dim3(SL_WAVES * 64), lds, s, q3);
 }
-extern void captra_sp_multi_reset();                 // sa_pipe.hip: the second level's two scales, recorded the same way
-extern int captra_sp_multi_flush(hipStream_t s);
-int captra_sa_collecting() { return g_sl_collect; }
-extern "C" void captra_sa_multi_begin() { g_sl_collect = 1; g_sl_n = 0; captra_sp_multi_reset(); }
-extern "C" int captra_sa_multi_end(captra_stream_t stream) {
-    g_sl_collect = 0;
-    const int n = g_sl_n;
-    g_sl_n = 0;
-    hipStream_t s = (hipStream_t)stream;
-    bool together = n == 3 && g_sl_rec[0].cf == g_sl_rec[1].cf && g_sl_rec[1].cf == g_sl_rec[2].cf;
-    for (int i = 0; together && i < 3; ++i) together = g_sl_rec[i].code == i && g_sl_rec[i].q.dyn == nullptr;
-    if (together && g_sl_rec[0].cf == 0) sl_launch_three<0>(g_sl_rec, s);
-    else if (together && g_sl_rec[0].cf == 3) sl_launch_three<3>(g_sl_rec, s);
+extern void captra_sp_collect_init(void *buf, size_t bytes);      // sa_pipe.hip: the second level's two scales, recorded the same way
+extern int captra_sp_collect_flush(void *buf, hipStream_t s);
+static int sl_collect_flush(SlCollect &c, hipStream_t s) {
+    const int n = c.n;
+    c.n = 0;
+    bool together = n == 3 && c.rec[0].cf == c.rec[1].cf && c.rec[1].cf == c.rec[2].cf;
+    for (int i = 0; together && i < 3; ++i) together = c.rec[i].code == i && c.rec[i].q.dyn == nullptr;
+    if (together && c.rec[0].cf == 0) sl_launch_three<0>(c.rec, s);
+    else if (together && c.rec[0].cf == 3) sl_launch_three<3>(c.rec, s);
     else
-        for (int i = 0; i < n; ++i) g_sl_rec[i].launch(g_sl_rec[i].q, g_sl_rec[i].grid, g_sl_rec[i].lds, s);
+        for (int i = 0; i < n; ++i) c.rec[i].launch(c.rec[i].q, c.rec[i].grid, c.rec[i].lds, s);
     const int err = captra_last_error();
-    const int err2 = captra_sp_multi_flush(s);
+    const int err2 = captra_sp_collect_flush(c.sp, s);
     return err != 0 ? err : err2;
 }
-// the caller zeroed the whole output tensor itself (one fill for every scale of a level instead of one per scale and cloud): the
-// slice-per-wave form then launches straight away
-static CAPTRA_KNOB int g_sa_prezeroed = 0;
-extern "C" void captra_sa_set_prezeroed(int on) { g_sa_prezeroed = on; }
-int captra_sa_prezeroed() { return g_sa_prezeroed; }
 // the slice-per-wave form's zeroed output: channels [co_off, co_off + c3), centres [m0, m0 + mc) of every cloud
 static void sl_zero_window(float *out, int b, int m, int out_ctotal, int co_off, int c3, int m0, int mc, hipStream_t stream) {
     if (m0 == 0 && mc == m) {
@@ -871,28 +865,24 @@ static void sl_zero_window(float *out, int b, int m, int out_ctotal, int co_off,
     for (int bb = 0; bb < b; ++bb)
         (void)hipMemset2DAsync(out + ((size_t)bb * out_ctotal + co_off) * m + m0, (size_t)m * 4, 0, (size_t)mc * 4, c3, stream);
 }
-// Dynamic centre hand-out of the persistent SA kernels (sa_wave_lds_kernel, sa_wave_pipe_kernel): a caller-owned device buffer
-// of `nslots` ints; every launch of the calling thread takes the next slot (round robin), zeroes it on its stream and counts
-// its centres through it.  (nullptr, 0) = static walk (default).  A captured graph owns the slots its launches were given.
-static CAPTRA_KNOB int *g_sa_dyn_pool = nullptr;
-static CAPTRA_KNOB int g_sa_dyn_slots = 0, g_sa_dyn_next = 0;
-extern "C" void captra_sa_set_dynamic(int *pool, int nslots) { g_sa_dyn_pool = pool; g_sa_dyn_slots = pool ? nslots : 0; g_sa_dyn_next = 0; }
-int *captra_sa_dyn_slot(hipStream_t stream) {
-    if (g_sa_dyn_pool == nullptr || g_sa_dyn_slots < 1) return nullptr;
-    int *slot = g_sa_dyn_pool + (g_sa_dyn_next++ % g_sa_dyn_slots);
-    if (hipMemsetAsync(slot, 0, sizeof(int), stream) != hipSuccess) return nullptr;
-    return slot;
+// Dynamic centre hand-out of the persistent SA kernels (sa_wave_lds_kernel, sa_wave_pipe_kernel): the call's own device int
+// (captra_launch_opts::dyn_slot), zeroed here on the launch's stream; the launch counts its centres through it.  NULL = static walk.
+// A captured graph owns the slots its launches were given.
+int *captra_sa_dyn_slot(const captra_launch_opts *o, hipStream_t stream) {
+    if (o == nullptr || o->dyn_slot == nullptr) return nullptr;
+    if (hipMemsetAsync(o->dyn_slot, 0, sizeof(int), stream) != hipSuccess) return nullptr;
+    return o->dyn_slot;
 }
 static unsigned long long *g_sa_prof = nullptr;  // device buffer of 10 counters: sa_wave_kernel's opt-in phase timers
 extern "C" void captra_sa_fused_set_prof(unsigned long long *dev_counters) { g_sa_prof = dev_counters; }
 unsigned long long *captra_sa_prof_ptr() { return g_sa_prof; }
 
 // One SA scale, fused (see include/captra_hip.h).
-extern "C" int captra_sa_scale_fused(int b, int n, int m, int k, int cfeat, int c1, int c2, int c3,
-                                     const float *feat, const float *xyz_cn, const float *new_xyz, const int *idx,
-                                     const float *w1, const float *b1, const float *w2, const float *b2,
-                                     const float *w3, const float *b3, float *out, int out_ctotal, int co_off,
-                                     captra_stream_t stream) {
+static int sa_scale_fused_impl(int b, int n, int m, int k, int cfeat, int c1, int c2, int c3,
+                               const float *feat, const float *xyz_cn, const float *new_xyz, const int *idx,
+                               const float *w1, const float *b1, const float *w2, const float *b2,
+                               const float *w3, const float *b3, float *out, int out_ctotal, int co_off,
+                               const captra_launch_opts *opts, SlCollect *col, captra_stream_t stream) {
     if (b < 0 || n < 1 || m < 0 || k < 1 || cfeat < 0 || c1 < 1 || c2 < 1 || c3 < 1) return -1;
     if (cfeat > 0 && feat == nullptr) return -1;
     if (out_ctotal < co_off + c3 || co_off < 0) return -1;
@@ -930,11 +920,11 @@ extern "C" int captra_sa_scale_fused(int b, int n, int m, int k, int cfeat, int 
             packed = ((per_cu > 0 ? per_cu : 1) << 16) | (prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256); \
             resident_slot.store(packed, std::memory_order_relaxed);                                                    \
         }                                                                                                              \
-        /* (captra_set_reserved_cus: CUs another stream's samplers hold -- every persistent workgroup must be resident) */ \
-        const int cus_l = (packed & 0xffff) - captra_reserved_cus() > 0 ? (packed & 0xffff) - captra_reserved_cus() : 1; \
+        /* (captra_launch_opts::reserved_cus: CUs another stream's samplers hold -- every persistent workgroup must be resident) */ \
+        const int cus_l = (packed & 0xffff) - captra_reserved_cus(opts) > 0 ? (packed & 0xffff) - captra_reserved_cus(opts) : 1; \
         const int resident = (packed >> 16) * cus_l;                                                                   \
         int wm0, wmc;                                                                                                  \
-        (void)captra_centre_window(m, &wm0, &wmc);                                                                     \
+        (void)captra_centre_window(opts, m, &wm0, &wmc);                                                               \
         if (wmc == 0) return 0;                                                                                        \
         q.m0 = wm0; q.mc = wmc;                                                                                        \
         const long long centres = (long long)b * wmc;          /* a wave per centre: 8 centres per workgroup round */           \
@@ -943,11 +933,11 @@ extern "C" int captra_sa_scale_fused(int b, int n, int m, int k, int cfeat, int 
         const long long units = q.split ? centres * (k / 32) : centres;                                                \
         const long long wgs = (units + SL_WAVES - 1) / SL_WAVES;                                                       \
         q.b = b;                                                                                                       \
-        q.dyn = (!q.split && k > 32 && wgs > 1) ? captra_sa_dyn_slot((hipStream_t)stream) : nullptr;                   \
+        q.dyn = (!q.split && k > 32 && wgs > 1 && col == nullptr) ? captra_sa_dyn_slot(opts, (hipStream_t)stream) : nullptr; \
         const unsigned grid_l = (unsigned)(wgs < resident ? wgs : resident);                                           \
-        if (q.split && !g_sa_prezeroed) sl_zero_window(out, b, m, out_ctotal, co_off, c3, wm0, wmc, (hipStream_t)stream);                  \
-        if (g_sl_collect && g_sl_n < 3) {      /* captra_sa_multi_begin: recorded, launched by captra_sa_multi_end */       \
-            SlRecord &r = g_sl_rec[g_sl_n++];                                                                          \
+        if (q.split && !(opts != nullptr && opts->sa_prezeroed)) sl_zero_window(out, b, m, out_ctotal, co_off, c3, wm0, wmc, (hipStream_t)stream);                  \
+        if (col != nullptr && col->n < 3) {    /* captra_sa_scales_multi: recorded, launched by its flush */                \
+            SlRecord &r = col->rec[col->n++];                                                                          \
             r.q = q; r.grid = grid_l; r.cf = CF_; r.lds = lds_bytes; r.launch = sl_launch_one<CF_, C1_, C2_, C3_>;      \
             r.code = (C1_ == 32 && C2_ == 32 && C3_ == 64) ? 0 : ((C1_ == 64 && C2_ == 64 && C3_ == 128) ? 1 : 2);     \
             return 0;                                                                                                  \
@@ -962,7 +952,7 @@ extern "C" int captra_sa_scale_fused(int b, int n, int m, int k, int cfeat, int 
         SL_CASE(3, 64, 64, 128)
         SL_CASE(3, 64, 96, 128)
 #undef SL_CASE
-        { int a0, ac; if (captra_centre_window(m, &a0, &ac)) return -2; }   // a centre window is the LDS-weights kernels' only
+        { int a0, ac; if (captra_centre_window(opts, m, &a0, &ac)) return -2; }   // a centre window is the LDS-weights kernels' only
 #define SW_CASE(CF_, C1_, C2_, C3_)                                                                                  \
     if (cfeat == CF_ && c1 == C1_ && c2 == C2_ && c3 == C3_ && (long long)cfeat * n * 4 < (1ll << 31)) {             \
         CAPTRA_LAUNCH("sa_scale_fused", (sa_wave_kernel<CF_, C1_, C2_, C3_>), gridw, dim3(256), 0, (hipStream_t)stream, q); \
@@ -1002,6 +992,48 @@ extern "C" int captra_sa_scale_fused(int b, int n, int m, int k, int cfeat, int 
         CAPTRA_LAUNCH("sa_scale_fused", sa_fused_kernel<1>, grid, dim3(256), lds32, (hipStream_t)stream, p);
     }
     return captra_last_error();
+}
+
+extern "C" int captra_sa_scale_fused_ex(int b, int n, int m, int k, int cfeat, int c1, int c2, int c3,
+                                        const float *feat, const float *xyz_cn, const float *new_xyz, const int *idx,
+                                        const float *w1, const float *b1, const float *w2, const float *b2,
+                                        const float *w3, const float *b3, float *out, int out_ctotal, int co_off,
+                                        const captra_launch_opts *opts, captra_stream_t stream) {
+    return sa_scale_fused_impl(b, n, m, k, cfeat, c1, c2, c3, feat, xyz_cn, new_xyz, idx, w1, b1, w2, b2, w3, b3, out, out_ctotal, co_off, opts, nullptr, stream);
+}
+extern "C" int captra_sa_scale_fused(int b, int n, int m, int k, int cfeat, int c1, int c2, int c3,
+                                     const float *feat, const float *xyz_cn, const float *new_xyz, const int *idx,
+                                     const float *w1, const float *b1, const float *w2, const float *b2,
+                                     const float *w3, const float *b3, float *out, int out_ctotal, int co_off,
+                                     captra_stream_t stream) {
+    return sa_scale_fused_impl(b, n, m, k, cfeat, c1, c2, c3, feat, xyz_cn, new_xyz, idx, w1, b1, w2, b2, w3, b3, out, out_ctotal, co_off, nullptr, nullptr, stream);
+}
+
+// sa_pipe.hip: captra_sa_scale_pre_pm with a collector (NULL = launch)
+extern int captra_sa_scale_pre_pm_impl(int b, int n, int m, int k, int cfeat, int c1, int c2, int c3, const float *v1pm,
+                                       const float *xyz_cn, const float *new_xyz, const int *idx, const float *w1,
+                                       const float *w2, const float *b2, const float *w3, const float *b3, float *out,
+                                       int out_ctotal, int co_off, const captra_launch_opts *opts, void *spbuf, captra_stream_t stream);
+
+// A level's scales in one call (include/captra_hip.h): every job through its own launcher with a collector on THIS stack frame,
+// then the flush.  A job whose shape takes no recordable kernel launches at once (in order); an error ends the call after the flush
+// of what was recorded.
+extern "C" int captra_sa_scales_multi(int njobs, const captra_sa_scale_job *jobs, const captra_launch_opts *opts, captra_stream_t stream) {
+    if (njobs < 0 || njobs > 4 || (njobs > 0 && jobs == nullptr)) return -1;
+    SlCollect col;
+    captra_sp_collect_init(col.sp, sizeof(col.sp));
+    captra_launch_opts o = opts != nullptr ? *opts : captra_launch_opts{};
+    o.dyn_slot = nullptr;                               // (the one-launch forms walk statically; two launches cannot share a slot)
+    int err = 0;
+    for (int i = 0; i < njobs && err == 0; ++i) {
+        const captra_sa_scale_job &j = jobs[i];
+        err = j.pre ? captra_sa_scale_pre_pm_impl(j.b, j.n, j.m, j.k, j.cfeat, j.c1, j.c2, j.c3, j.feat_or_v1, j.xyz_cn, j.new_xyz, j.idx, j.w1,
+                                                  j.w2, j.b2, j.w3, j.b3, j.out, j.out_ctotal, j.co_off, &o, col.sp, stream)
+                    : sa_scale_fused_impl(j.b, j.n, j.m, j.k, j.cfeat, j.c1, j.c2, j.c3, j.feat_or_v1, j.xyz_cn, j.new_xyz, j.idx, j.w1, j.b1,
+                                          j.w2, j.b2, j.w3, j.b3, j.out, j.out_ctotal, j.co_off, &o, &col, stream);
+    }
+    const int ferr = sl_collect_flush(col, (hipStream_t)stream);
+    return err != 0 ? err : ferr;
 }
 
 // SA scale with a pre-transformed first layer (see sw_layer1_pre and include/captra_hip.h): v1 (B,c1,N) replaces feat.

@@ -386,37 +386,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
 extern unsigned long long *captra_sa_prof_ptr();   // sa_fused.hip: the debug counters set by captra_sa_fused_set_prof
 extern int captra_sa_split_knob();                  // sa_fused.hip: captra_sa_fused_set_split
-extern int captra_sa_prezeroed();                   // sa_fused.hip: captra_sa_set_prezeroed
-extern int captra_sa_collecting();                  // sa_fused.hip: between captra_sa_multi_begin and captra_sa_multi_end
+extern int *captra_sa_dyn_slot(const captra_launch_opts *o, hipStream_t stream);   // sa_fused.hip: captra_launch_opts::dyn_slot
 
-// the level's scales recorded between captra_sa_multi_begin / _end (sa_fused.hip), launched by captra_sp_multi_flush
+// the level's scales recorded by captra_sa_scales_multi (sa_fused.hip) into ITS collector's buffer, launched by the flush
 struct SpRecord { SpParams q; unsigned grid; int code; };
-static thread_local SpRecord g_sp_rec[2];
-static thread_local int g_sp_n = 0;
-void captra_sp_multi_reset() { g_sp_n = 0; }
-int captra_sp_multi_flush(hipStream_t s) {
-    const int n = g_sp_n;
-    g_sp_n = 0;
-    if (n == 2 && g_sp_rec[0].code == 0 && g_sp_rec[1].code == 1 && g_sp_rec[0].q.dyn == nullptr && g_sp_rec[1].q.dyn == nullptr) {
+struct SpCollect { SpRecord rec[2]; int n; };
+void captra_sp_collect_init(void *buf, size_t bytes) {
+    static_assert(sizeof(SpCollect) <= 1024, "SlCollect::sp (sa_fused.hip) holds an SpCollect");
+    if (buf != nullptr && bytes >= sizeof(SpCollect)) static_cast<SpCollect *>(buf)->n = 0;
+}
+int captra_sp_collect_flush(void *buf, hipStream_t s) {
+    SpCollect &c = *static_cast<SpCollect *>(buf);
+    const int n = c.n;
+    c.n = 0;
+    if (n == 2 && c.rec[0].code == 0 && c.rec[1].code == 1 && c.rec[0].q.dyn == nullptr && c.rec[1].q.dyn == nullptr) {
         Sp2Params q2;
-        q2.s[0] = g_sp_rec[0].q; q2.s[1] = g_sp_rec[1].q; q2.g0 = (int)g_sp_rec[0].grid;
-        CAPTRA_LAUNCH("sa_scale_fused", sa_wave_pipe2_kernel, dim3(g_sp_rec[0].grid + g_sp_rec[1].grid), dim3(256), 0, s, q2);
+        q2.s[0] = c.rec[0].q; q2.s[1] = c.rec[1].q; q2.g0 = (int)c.rec[0].grid;
+        CAPTRA_LAUNCH("sa_scale_fused", sa_wave_pipe2_kernel, dim3(c.rec[0].grid + c.rec[1].grid), dim3(256), 0, s, q2);
         return captra_last_error();
     }
     for (int i = 0; i < n; ++i) {
-        if (g_sp_rec[i].code == 0) { CAPTRA_LAUNCH("sa_scale_fused", (sa_wave_pipe_kernel<320, 128, 128, 256>), dim3(g_sp_rec[i].grid), dim3(256), 0, s, g_sp_rec[i].q); }
-        else { CAPTRA_LAUNCH("sa_scale_fused", (sa_wave_pipe_kernel<320, 128, 196, 256>), dim3(g_sp_rec[i].grid), dim3(256), 0, s, g_sp_rec[i].q); }
+        if (c.rec[i].code == 0) { CAPTRA_LAUNCH("sa_scale_fused", (sa_wave_pipe_kernel<320, 128, 128, 256>), dim3(c.rec[i].grid), dim3(256), 0, s, c.rec[i].q); }
+        else { CAPTRA_LAUNCH("sa_scale_fused", (sa_wave_pipe_kernel<320, 128, 196, 256>), dim3(c.rec[i].grid), dim3(256), 0, s, c.rec[i].q); }
     }
     return captra_last_error();
 }
-extern int *captra_sa_dyn_slot(hipStream_t stream); // sa_fused.hip: captra_sa_set_dynamic
 
 // SA scale with a pre-transformed, POINT-major first layer (see include/captra_hip.h): v1pm (B,N,c1).
 // -2: shape not instantiated / not tileable (the caller takes captra_sa_scale_pre).
-extern "C" int captra_sa_scale_pre_pm(int b, int n, int m, int k, int cfeat, int c1, int c2, int c3, const float *v1pm,
-                                      const float *xyz_cn, const float *new_xyz, const int *idx, const float *w1,
-                                      const float *w2, const float *b2, const float *w3, const float *b3, float *out,
-                                      int out_ctotal, int co_off, captra_stream_t stream) {
+int captra_sa_scale_pre_pm_impl(int b, int n, int m, int k, int cfeat, int c1, int c2, int c3, const float *v1pm,
+                                const float *xyz_cn, const float *new_xyz, const int *idx, const float *w1,
+                                const float *w2, const float *b2, const float *w3, const float *b3, float *out,
+                                int out_ctotal, int co_off, const captra_launch_opts *opts, void *spbuf, captra_stream_t stream) {
+    SpCollect *col = static_cast<SpCollect *>(spbuf);
     if (b < 0 || n < 1 || m < 0 || k < 1 || cfeat < 1 || c1 < 1 || c2 < 1 || c3 < 1 || v1pm == nullptr) return -1;
     if (out_ctotal < co_off + c3 || co_off < 0) return -1;
     if (k % 32 != 0 || 128 % k != 0) return -2;
@@ -436,7 +438,7 @@ extern "C" int captra_sa_scale_pre_pm(int b, int n, int m, int k, int cfeat, int
         cus = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
         cus_of[dev & 127].store(cus, std::memory_order_relaxed);
     }
-    cus = cus - captra_reserved_cus() > 0 ? cus - captra_reserved_cus() : 1;     // (captra_set_reserved_cus)
+    cus = cus - captra_reserved_cus(opts) > 0 ? cus - captra_reserved_cus(opts) : 1;     // (captra_launch_opts::reserved_cus)
     // one workgroup (4 waves, one per SIMD) per CU; a wave per centre
     const long long centres = (long long)b * m;
     if (centres >= (1ll << 30)) return -2;
@@ -444,8 +446,8 @@ extern "C" int captra_sa_scale_pre_pm(int b, int n, int m, int k, int cfeat, int
     q.split = (split_knob != 0 && k > 32 && (split_knob == 2 || centres < 4ll * cus)) ? 1 : 0;     // fewer centres than resident waves
     const long long wgs = ((q.split ? centres * (k / 32) : centres) + 3) / 4;
     const unsigned grid = (unsigned)(wgs < cus ? wgs : cus);
-    q.dyn = (!q.split && k > 32 && wgs > 1) ? captra_sa_dyn_slot((hipStream_t)stream) : nullptr;
-    if (q.split && !captra_sa_prezeroed()) {
+    q.dyn = (!q.split && k > 32 && wgs > 1 && col == nullptr) ? captra_sa_dyn_slot(opts, (hipStream_t)stream) : nullptr;
+    if (q.split && !(opts != nullptr && opts->sa_prezeroed)) {
         // (zeroed by a kernel per cloud where the rows allow it, not by a memset node: common.h captra_zero_async)
         if (b <= 8 && ((size_t)c3 * m * 4) % 16 == 0 && (reinterpret_cast<uintptr_t>(out + (size_t)co_off * m) & 15) == 0 && ((size_t)out_ctotal * m * 4) % 16 == 0) {
             for (int bb = 0; bb < b; ++bb) (void)captra_zero_async(out + ((size_t)bb * out_ctotal + co_off) * m, (size_t)c3 * m * 4, (hipStream_t)stream);
@@ -456,9 +458,9 @@ extern "C" int captra_sa_scale_pre_pm(int b, int n, int m, int k, int cfeat, int
 #define SPP_CASE(CF_, C1_, C2_, C3_)                                                                                  \
     if (cfeat == CF_ && c1 == C1_ && c2 == C2_ && c3 == C3_) {                                                        \
         auto kern = sa_wave_pipe_kernel<CF_, C1_, C2_, C3_>;                                                          \
-        if (captra_sa_collecting() && g_sp_n < 2) {                                                                   \
-            g_sp_rec[g_sp_n].q = q; g_sp_rec[g_sp_n].grid = grid; g_sp_rec[g_sp_n].code = (C2_ == 128 ? 0 : 1);        \
-            ++g_sp_n;                                                                                                 \
+        if (col != nullptr && col->n < 2) {                                                                           \
+            col->rec[col->n].q = q; col->rec[col->n].grid = grid; col->rec[col->n].code = (C2_ == 128 ? 0 : 1);       \
+            ++col->n;                                                                                                 \
             return 0;                                                                                                 \
         }                                                                                                             \
         CAPTRA_LAUNCH("sa_scale_fused", kern, dim3(grid), dim3(256), 0, (hipStream_t)stream, q);                       \
@@ -468,4 +470,17 @@ extern "C" int captra_sa_scale_pre_pm(int b, int n, int m, int k, int cfeat, int
     SPP_CASE(320, 128, 196, 256)
 #undef SPP_CASE
     return -2;
+}
+
+extern "C" int captra_sa_scale_pre_pm_ex(int b, int n, int m, int k, int cfeat, int c1, int c2, int c3, const float *v1pm,
+                                         const float *xyz_cn, const float *new_xyz, const int *idx, const float *w1,
+                                         const float *w2, const float *b2, const float *w3, const float *b3, float *out,
+                                         int out_ctotal, int co_off, const captra_launch_opts *opts, captra_stream_t stream) {
+    return captra_sa_scale_pre_pm_impl(b, n, m, k, cfeat, c1, c2, c3, v1pm, xyz_cn, new_xyz, idx, w1, w2, b2, w3, b3, out, out_ctotal, co_off, opts, nullptr, stream);
+}
+extern "C" int captra_sa_scale_pre_pm(int b, int n, int m, int k, int cfeat, int c1, int c2, int c3, const float *v1pm,
+                                      const float *xyz_cn, const float *new_xyz, const int *idx, const float *w1,
+                                      const float *w2, const float *b2, const float *w3, const float *b3, float *out,
+                                      int out_ctotal, int co_off, captra_stream_t stream) {
+    return captra_sa_scale_pre_pm_impl(b, n, m, k, cfeat, c1, c2, c3, v1pm, xyz_cn, new_xyz, idx, w1, w2, b2, w3, b3, out, out_ctotal, co_off, nullptr, nullptr, stream);
 }

@@ -812,9 +812,9 @@ extern "C" int captra_dense_bf16_tile(int b, int cin, int cout, long long l, con
 // Layers 1 + 2 of a Conv -> GroupNorm -> ReLU head in one launch (cin <= 128 -> 512 -> 512).  ab1 == NULL: the statistics
 // pass -- stats (B,T,512,2) receives y1's partial sums (y1 = W1 x + b1), nothing else is written.  ab1 != NULL (from
 // captra_gn_finalize_tm on those): y2 = W2 bf16(relu(a1 y1 + b1')) + b2 stored raw as (B,L,512) bf16 slot order, stats = y2's.
-extern "C" int captra_head12_bf16(int b, int cin, long long l, const void *x, const unsigned char *w1img, const float *bias1_packed,
+extern "C" int captra_head12_bf16_ex(int b, int cin, long long l, const void *x, const unsigned char *w1img, const float *bias1_packed,
                                   const float *ab1, const unsigned char *w2img, const float *bias2_packed, void *y2, float *stats,
-                                  captra_stream_t stream) {
+                                  const captra_launch_opts *opts, captra_stream_t stream) {
     if (b < 0 || cin < 1 || cin > 128 || l < 0 || stats == nullptr) return -1;
     if (ab1 != nullptr && (w2img == nullptr || y2 == nullptr || bias2_packed == nullptr)) return -1;
     if (l * 512 * 2 >= (1ll << 31)) return -2;
@@ -842,7 +842,7 @@ extern "C" int captra_head12_bf16(int b, int cin, long long l, const void *x, co
         once.done();
     }
     const int cus_dev = cus_of[dev & 127].load() > 0 ? cus_of[dev & 127].load() : 256;
-    const int cus = cus_dev - captra_reserved_cus() > 0 ? cus_dev - captra_reserved_cus() : 1;      // (captra_set_reserved_cus)
+    const int cus = cus_dev - captra_reserved_cus(opts) > 0 ? cus_dev - captra_reserved_cus(opts) : 1;      // (captra_launch_opts::reserved_cus)
     const long long tpc = (l + TB_P - 1) / TB_P, ntiles = (long long)b * tpc;
     if (g_tb_persist && ntiles > cus && ntiles < (1ll << 30)) {
         // persistent: one workgroup per CU, contiguous runs of tiles
@@ -855,4 +855,9 @@ extern "C" int captra_head12_bf16(int b, int cin, long long l, const void *x, co
     }
     CAPTRA_LAUNCH("pointwise_mlp", tb_head12_kernel<1>, grid, dim3(512), 131072, s, p);
     return captra_last_error();
+}
+extern "C" int captra_head12_bf16(int b, int cin, long long l, const void *x, const unsigned char *w1img, const float *bias1_packed,
+                                  const float *ab1, const unsigned char *w2img, const float *bias2_packed, void *y2, float *stats,
+                                  captra_stream_t stream) {
+    return captra_head12_bf16_ex(b, cin, l, x, w1img, bias1_packed, ab1, w2img, bias2_packed, y2, stats, nullptr, stream);
 }

@@ -71,30 +71,27 @@ def _split_k_active() -> bool:
 @contextlib.contextmanager
 def split_k(on: bool):
     """Dense layers launched inside with at most SPLIT_K_POSITIONS positions split k over a workgroup's four waves
-    (captra_pw_set_splitk: a fixed summation order, 1e-5 relative from the bit-exact chain).  The track step of one or two
-    trajectories runs under it -- its 128- / 512-point levels are single dependent MFMA chains on an idle chip otherwise.
-    Re-entrant and per thread, like the C knob it drives (thread_local): the previous state is restored on exit."""
+    (captra_launch_opts::splitk_positions of every call: a fixed summation order, 1e-5 relative from the bit-exact chain).  The
+    track step of one or two trajectories runs under it -- its 128- / 512-point levels are single dependent MFMA chains on an idle
+    chip otherwise.  Re-entrant and per thread (the options are the host layer's, the C library keeps no state)."""
     prev = _split_k_active()
     if on and not prev:
-        L.lib().captra_pw_set_splitk(C.c_int(SPLIT_K_POSITIONS))
         _TLS.split_k_on = True
-    try:
+        with L.launch_options(splitk_positions=SPLIT_K_POSITIONS):
+            try:
+                yield
+            finally:
+                _TLS.split_k_on = False
+    else:
         yield
-    finally:
-        if on and not prev:
-            L.lib().captra_pw_set_splitk(C.c_int(0))
-            _TLS.split_k_on = False
 
 
 @contextlib.contextmanager
 def centre_window(m0: int, mc: int):
-    """The set-abstraction launches inside process centres [m0, m0 + mc) of every cloud only (captra_set_centre_window): the
-    ball query and the small-input SA scales of the centres a streamed sampler (`fps_gather_part`) has picked so far."""
-    L.lib().captra_set_centre_window(C.c_int(int(m0)), C.c_int(int(mc)))
-    try:
+    """The set-abstraction launches inside process centres [m0, m0 + mc) of every cloud only (captra_launch_opts::centre_m0 /
+    centre_mc): the ball query and the small-input SA scales of the centres a streamed sampler (`fps_gather_part`) has picked so far."""
+    with L.launch_options(centre_m0=int(m0), centre_mc=int(mc)):
         yield
-    finally:
-        L.lib().captra_set_centre_window(C.c_int(0), C.c_int(0))
 
 
 def ball_query_multi(radii, nsamples, xyz_n3, new_xyz_n3, outs=None):
@@ -868,16 +865,20 @@ def sa_first_layer_pre_pm(feat, lin: PackedLinear):
     return out
 
 
-def sa_scale_pre_pm(v1pm, xyz_cn, new_xyz_n3, idx, layers, out, co_off, cfeat):
-    """One SA scale from the point-major pre-transformed first layer (captra_sa_scale_pre_pm)."""
+def sa_scale_pre_pm(v1pm, xyz_cn, new_xyz_n3, idx, layers, out, co_off, cfeat, jobs=None):
+    """One SA scale from the point-major pre-transformed first layer (captra_sa_scale_pre_pm).  `jobs`: as sa_scale_fused."""
     l1, l2, l3 = layers
     L.require_device(v1pm, xyz_cn, new_xyz_n3, idx, out)
     B, _, N = xyz_cn.shape
     _, M, K = idx.shape
-    with torch.cuda.device(xyz_cn.device):
-        L.call("captra_sa_scale_pre_pm", B, N, M, K, cfeat, l1.cout, l2.cout, l3.cout, L.ptr(v1pm), L.ptr(xyz_cn),
-               L.ptr(new_xyz_n3), L.ptr(idx), L.ptr(l1.wt), L.ptr(l2.wt), L.ptr(l2.bias), L.ptr(l3.wt), L.ptr(l3.bias),
-               L.ptr(out), out.shape[1], co_off)
+    if jobs is not None:
+        jobs.append(L.SaScaleJob(1, B, N, M, K, cfeat, l1.cout, l2.cout, l3.cout, L.ptr(v1pm), L.ptr(xyz_cn), L.ptr(new_xyz_n3), L.ptr(idx),
+                                 L.ptr(l1.wt), None, L.ptr(l2.wt), L.ptr(l2.bias), L.ptr(l3.wt), L.ptr(l3.bias), L.ptr(out), out.shape[1], co_off))
+    else:
+        with torch.cuda.device(xyz_cn.device):
+            L.call("captra_sa_scale_pre_pm", B, N, M, K, cfeat, l1.cout, l2.cout, l3.cout, L.ptr(v1pm), L.ptr(xyz_cn),
+                   L.ptr(new_xyz_n3), L.ptr(idx), L.ptr(l1.wt), L.ptr(l2.wt), L.ptr(l2.bias), L.ptr(l3.wt), L.ptr(l3.bias),
+                   L.ptr(out), out.shape[1], co_off)
     _work("sa_scale_fused", flops=2.0 * B * M * K * (3 * l1.cout + l1.cout * l2.cout + l2.cout * l3.cout),
           nbytes=4.0 * B * (l1.cout * N + 3 * N + M * K + 3 * M + l3.cout * M))
     return out
@@ -968,7 +969,8 @@ def pointwise_mlp_gn(x, lin: PackedLinear, ab_in=None, act: int = ACT_NONE, want
                    L.ptr(y), L.ptr(stats), t)
         _work("pointwise_mlp_x6", flops=2.0 * B * cin * lin.cout * l, nbytes=4.0 * B * l * (cin + lin.cout))
         return (y, stats) if want_stats else y
-    t = L.lib().captra_pointwise_mlp_gn_tiles(B, lin.cout, l)      # 64- or 32-position statistics tiles, by launch shape
+    o = L.current_opts()
+    t = L.lib().captra_pointwise_mlp_gn_tiles_ex(B, lin.cout, l, C.byref(o) if o is not None else None)      # 64- or 32-position statistics tiles, by launch shape
     stats = torch.empty(B, lin.cout, t, 2, dtype=torch.float32, device=x.device) if want_stats else None
     with torch.cuda.device(x.device):
         L.call("captra_pointwise_mlp_gn", B, cin, lin.cout, l, L.ptr(x), L.ptr(lin.wt), L.ptr(lin.bias), L.ptr(ab_in), act,
@@ -1093,8 +1095,20 @@ def sa_scale_fusable(k: int, layers) -> bool:
     return USE_SA_FUSED and len(layers) == 3 and k % 32 == 0 and 128 % k == 0 and all(l.cout <= 256 for l in layers)
 
 
-def sa_scale_fused(feat, xyz_cn, new_xyz_n3, idx, layers, out, co_off: int):
-    """Whole SA scale in one launch: layers = [PackedLinear] * 3; writes out[:, co_off:co_off+c3, :]."""
+def sa_scales_multi(jobs, device) -> None:
+    """A level's recorded scales (the `jobs=` lists of sa_scale_fused / sa_scale_pre_pm) in ONE call: captra_sa_scales_multi runs
+    them as one launch where they are the level's shapes in order, else one after the other -- the job table is this call's
+    argument, nothing is remembered between calls."""
+    arr = (L.SaScaleJob * len(jobs))(*jobs)
+    o = L.current_opts()
+    with torch.cuda.device(device):
+        L.check(L.lib().captra_sa_scales_multi(len(jobs), C.cast(arr, C.c_void_p), C.byref(o) if o is not None else None, L.stream_ptr()),
+                "captra_sa_scales_multi")
+
+
+def sa_scale_fused(feat, xyz_cn, new_xyz_n3, idx, layers, out, co_off: int, jobs=None):
+    """Whole SA scale in one launch: layers = [PackedLinear] * 3; writes out[:, co_off:co_off+c3, :].  `jobs` (a list): the call is
+    appended as a job for sa_scales_multi instead of launched."""
     L.require_device(feat, xyz_cn, new_xyz_n3, idx, out, *[t for l in layers for t in (l.wt, l.bias)])
     B, _, N = xyz_cn.shape
     _, M, K = idx.shape
@@ -1103,9 +1117,13 @@ def sa_scale_fused(feat, xyz_cn, new_xyz_n3, idx, layers, out, co_off: int):
     (w1, b1), (w2, b2), (w3, b3) = (l1.wt, l1.bias), (l2.wt, l2.bias), (l3.wt, l3.bias)
     c1, c2, c3 = l1.cout, l2.cout, l3.cout
     assert l1.cin == cfeat + 3 and l2.cin == c1 and l3.cin == c2
-    with torch.cuda.device(xyz_cn.device):
-        L.call("captra_sa_scale_fused", B, N, M, K, cfeat, c1, c2, c3, L.ptr(feat), L.ptr(xyz_cn), L.ptr(new_xyz_n3),
-               L.ptr(idx), L.ptr(w1), L.ptr(b1), L.ptr(w2), L.ptr(b2), L.ptr(w3), L.ptr(b3), L.ptr(out), out.shape[1], co_off)
+    if jobs is not None:
+        jobs.append(L.SaScaleJob(0, B, N, M, K, cfeat, c1, c2, c3, L.ptr(feat), L.ptr(xyz_cn), L.ptr(new_xyz_n3), L.ptr(idx), L.ptr(w1), L.ptr(b1),
+                                 L.ptr(w2), L.ptr(b2), L.ptr(w3), L.ptr(b3), L.ptr(out), out.shape[1], co_off))
+    else:
+        with torch.cuda.device(xyz_cn.device):
+            L.call("captra_sa_scale_fused", B, N, M, K, cfeat, c1, c2, c3, L.ptr(feat), L.ptr(xyz_cn), L.ptr(new_xyz_n3),
+                   L.ptr(idx), L.ptr(w1), L.ptr(b1), L.ptr(w2), L.ptr(b2), L.ptr(w3), L.ptr(b3), L.ptr(out), out.shape[1], co_off)
     _work("sa_scale_fused", flops=2.0 * B * M * K * ((cfeat + 3) * c1 + c1 * c2 + c2 * c3),
           nbytes=4.0 * B * ((cfeat + 3) * N + M * K + 3 * M + c3 * M))
     return out

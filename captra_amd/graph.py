@@ -312,7 +312,7 @@ class BackbonePipe:
         # high-priority geometry stream does not change that, a CU-masked MLP stream makes it worse: 3.86 ms, the masked
         # kernels run 2.05 -> 3.38 ms because every grid sized for 256 CUs then takes a second round).
         # What the MLP graph does instead (CAPTRA_PIPE_DYNAMIC, default on): its SA kernels hand their centres out through a
-        # counter (captra_sa_set_dynamic), so a workgroup that becomes resident late finds the work done; `reserve` then
+        # counter (captra_launch_opts::dyn_slot), so a workgroup that becomes resident late finds the work done; `reserve` then
         # defaults to 0.
         B, _, N = x.shape
         self.dynamic = os.environ.get("CAPTRA_PIPE_DYNAMIC", "1") != "0"
@@ -343,15 +343,11 @@ class BackbonePipe:
             gg, gm = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.graph(gg, stream=cap, capture_error_mode="thread_local"), torch.no_grad():
                 geom = self._geometry(s)
-            _lib.lib().captra_set_reserved_cus(ctypes.c_int(self.reserve))
-            if self.dynamic:
-                _lib.lib().captra_sa_set_dynamic(ctypes.c_void_p(self._dyn_pool[s].data_ptr()), ctypes.c_int(64))
-            try:
+            # (per-call options of the launches captured here: captra_launch_opts::reserved_cus / dyn_slot -- a slot of this graph's
+            # own pool per launch, round robin; the C library remembers nothing)
+            with _lib.launch_options(reserved_cus=self.reserve, dyn_pool=(self._dyn_pool[s].data_ptr(), 64) if self.dynamic else None):
                 with torch.cuda.graph(gm, stream=cap, capture_error_mode="thread_local"), torch.no_grad():
                     out = net(self.x[s], input_n3=self.x_n3[s], geom=geom)
-            finally:
-                _lib.lib().captra_set_reserved_cus(ctypes.c_int(0))
-                _lib.lib().captra_sa_set_dynamic(ctypes.c_void_p(0), ctypes.c_int(0))
             self.g_geom.append(gg); self.g_mlp.append(gm); self.geom.append(geom); self.out.append(out)
         self.geom_ready = [torch.cuda.Event() for _ in range(depth)]
         self.mlp_done = [None] * depth

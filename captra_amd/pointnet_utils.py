@@ -233,28 +233,18 @@ class PointNetSetAbstractionMsg(_FoldCache, nn.Module):
             # few clouds: the fp32 scales run a wave per neighbour slice and combine a centre's slices by an atomic max on a zeroed
             # output -- ONE fill of the level's tensor here instead of a fill per scale and cloud in the launchers
             out.zero_()
-            fused.L.lib().captra_sa_set_prezeroed(1)
-        # ... and the level's scales recorded and launched TOGETHER (sa_wave_lds3_kernel / sa_wave_pipe2_kernel: each on its own range
-        # of workgroups, bits unchanged) where a scale's own launch fills a fraction of the chip
-        together = prezero and B <= MULTI_SCALE_MAX_CLOUDS
-        if together:
-            fused.L.lib().captra_sa_multi_begin()
-        keep = []     # the scales' temporaries (v1): between begin and end the launchers only RECORD raw pointers to them -- alive until the launch
-        try:
-            res = self._forward_scales(folded, idx_list, feat, xyz_cn, new_xyz_n3, out, off, B, keep)
-            if together:
-                together = False
-                with torch.cuda.device(xyz_cn.device):
-                    fused.L.check(fused.L.lib().captra_sa_multi_end(fused.L.stream_ptr()), "captra_sa_multi_end")
-            return res
-        finally:
-            if together:                  # (an exception between begin and end: drop the recording mode)
-                fused.L.lib().captra_sa_multi_end(fused.L.stream_ptr())
-            if prezero:
-                fused.L.lib().captra_sa_set_prezeroed(0)
-            keep.clear()
+        # ... and the level's scales handed over TOGETHER (captra_sa_scales_multi -> sa_wave_lds3_kernel / sa_wave_pipe2_kernel: each
+        # scale on its own range of workgroups, bits unchanged) where a scale's own launch fills a fraction of the chip
+        jobs = [] if (prezero and B <= MULTI_SCALE_MAX_CLOUDS) else None
+        keep = []     # the scales' temporaries (v1): the job table holds raw pointers to them -- alive until the launch
+        with fused.L.launch_options(sa_prezeroed=1 if prezero else 0):
+            res = self._forward_scales(folded, idx_list, feat, xyz_cn, new_xyz_n3, out, off, B, keep, jobs)
+            if jobs:
+                fused.sa_scales_multi(jobs, xyz_cn.device)
+        keep.clear()
+        return res
 
-    def _forward_scales(self, folded, idx_list, feat, xyz_cn, new_xyz_n3, out, off, B, keep=None):
+    def _forward_scales(self, folded, idx_list, feat, xyz_cn, new_xyz_n3, out, off, B, keep=None, jobs=None):
         for layers, idx in zip(folded, idx_list):
             if fused.sa_scale_x6_supported(0 if feat is None else feat.shape[1], layers, idx.shape[2]):
                 fused.sa_scale_x6(feat, xyz_cn, new_xyz_n3, idx, layers, out, off)      # cfg['mlp_dtype'] = "f32x6"
@@ -268,7 +258,7 @@ class PointNetSetAbstractionMsg(_FoldCache, nn.Module):
                 v1pm = fused.sa_first_layer_pre_pm(feat, layers[0])  # (B,N,c1) point-major: one 16-byte gather per register quad
                 if keep is not None:
                     keep.append(v1pm)
-                fused.sa_scale_pre_pm(v1pm, xyz_cn, new_xyz_n3, idx, layers, out, off, feat.shape[1])
+                fused.sa_scale_pre_pm(v1pm, xyz_cn, new_xyz_n3, idx, layers, out, off, feat.shape[1], jobs=jobs)
                 off += layers[-1].cout
                 continue
             if feat is not None and fused.sa_scale_pre_supported(feat.shape[1], layers, idx.shape[2]):
@@ -279,7 +269,7 @@ class PointNetSetAbstractionMsg(_FoldCache, nn.Module):
                 off += layers[-1].cout
                 continue
             if fused.sa_scale_fusable(idx.shape[2], layers):
-                fused.sa_scale_fused(feat, xyz_cn, new_xyz_n3, idx, layers, out, off)
+                fused.sa_scale_fused(feat, xyz_cn, new_xyz_n3, idx, layers, out, off, jobs=jobs)
                 off += layers[-1].cout
                 continue
             y = fused.sa_group_mlp(feat, xyz_cn, new_xyz_n3, idx, layers[0])

@@ -27,6 +27,27 @@ extern "C" {
 
 typedef void *captra_stream_t; /* hipStream_t */
 
+/* PER-CALL launch options.  The library holds NO product-affecting state (the reference boundary has none: `extern THCState *state`
+ * is declared and unused, pointnet_lib/src/ball_query.cpp:8; every wrapper of pointnet2_api.cpp:10-25 is a pure function of its
+ * arguments): what a caller wants different from the defaults travels with the call, as the last argument before the stream of the
+ * `_ex` form of an entry point.  NULL, or a zeroed struct, = the defaults = the plain entry point.  Fields an entry point does not
+ * read are ignored by it. */
+typedef struct captra_launch_opts {
+    int splitk_positions; /* dense layers (captra_pointwise_mlp / _mlp2 / _pm / _gn): a launch of at most this many positions (b * l) and
+                           * >= 128 input channels splits k over the four waves of a workgroup (partial tiles added in wave order: a
+                           * fixed order, 1e-5 relative from the k-ascending chain); 0 = never */
+    int sa_prezeroed;     /* SA scales, slice-per-wave form (few clouds): 1 = the caller zeroed the whole output tensor (one fill per
+                           * level), 0 = the launcher zeroes its channel slice */
+    int centre_m0, centre_mc; /* centre WINDOW: captra_ball_query[_multi], captra_sa_scale_fused (LDS-weights kernels) and
+                           * captra_sa_scale_bf16 (small-input scales) process centres [m0, m0 + mc) of every cloud and leave the rest of
+                           * their (B, M, ...) outputs untouched (streamed sampling: captra_fps_gather_part); mc <= 0 = all centres.  Entry
+                           * points / shapes that cannot honour a window return -2 when one is given */
+    int reserved_cus;     /* persistent launches size their grid for this many CUs fewer (another stream's one-workgroup-per-cloud
+                           * samplers hold them: every persistent workgroup stays resident) */
+    int *dyn_slot;        /* dynamic centre hand-out of the persistent SA kernels: ONE caller-owned device int per launch, zeroed by the
+                           * launch on its stream; workgroups that become resident late find the work done.  Same bits.  NULL = static walk */
+} captra_launch_opts;
+
 /* ------------------------------------------------------------------------------------------
  * Section 1 — the ten pointnet2_cuda operators (pointnet2_api.cpp:10-25)
  * ---------------------------------------------------------------------------------------- */
@@ -46,6 +67,9 @@ int captra_furthest_point_sampling(int b, int n, int m, const float *xyz, float 
  * leaves the caller's pre-zeroed buffer untouched, pointnet2_utils.py:261). */
 int captra_ball_query(int b, int n, int m, float radius, int nsample, const float *new_xyz,
                       const float *xyz, int *idx, captra_stream_t stream);
+int captra_ball_query_ex(int b, int n, int m, float radius, int nsample, const float *new_xyz,
+                      const float *xyz, int *idx, const captra_launch_opts *opts,
+        captra_stream_t stream);   /* the same with per-call options */
 
 /* Replaces group_points_wrapper (group_points.cpp:25-36, kernel group_points_gpu.cu:47-66).
  * points (B,C,N) f32, idx (B,npoints,nsample) i32 -> out (B,C,npoints,nsample). */
@@ -136,6 +160,10 @@ int captra_canonicalize_planes(int b, int p, int n, const float *pts, const floa
 int captra_ball_query_multi(int b, int n, int m, int nr, const float *radius, const int *nsample,
                             const float *new_xyz, const float *xyz, int *const *idx,
                             captra_stream_t stream);
+int captra_ball_query_multi_ex(int b, int n, int m, int nr, const float *radius, const int *nsample,
+                            const float *new_xyz, const float *xyz, int *const *idx,
+                            const captra_launch_opts *opts,
+        captra_stream_t stream);   /* the same with per-call options */
 
 /* PACKED WEIGHTS.  The shared-MLP kernels take a layer's weights W^T (cin rows, cout columns; BatchNorm folded in) as ONE
  * buffer of captra_packed_weight_floats(cin, cout) floats holding two images of the same numbers:
@@ -161,6 +189,9 @@ int captra_pack_weights_frag(int cin, int cout, float *wt_packed, captra_stream_
  * (what v_mfma_f32_32x32x2_f32 computes), then the activation. */
 int captra_pointwise_mlp(int b, int cin, int cout, long long l, const float *x, const float *wt,
                          const float *bias, int act, float *y, captra_stream_t stream);
+int captra_pointwise_mlp_ex(int b, int cin, int cout, long long l, const float *x, const float *wt,
+                         const float *bias, int act, float *y, const captra_launch_opts *opts,
+        captra_stream_t stream);   /* the same with per-call options */
 
 /* First layer of a set-abstraction scale with the group-and-concat fused into the operand load
  * (group_operation + "-= centre" + cat, pointnet_utils.py:234-240):
@@ -189,6 +220,11 @@ int captra_sa_scale_fused(int b, int n, int m, int k, int cfeat, int c1, int c2,
                           const float *xyz_cn, const float *new_xyz, const int *idx, const float *w1,
                           const float *b1, const float *w2, const float *b2, const float *w3, const float *b3,
                           float *out, int out_ctotal, int co_off, captra_stream_t stream);
+int captra_sa_scale_fused_ex(int b, int n, int m, int k, int cfeat, int c1, int c2, int c3, const float *feat,
+                          const float *xyz_cn, const float *new_xyz, const int *idx, const float *w1,
+                          const float *b1, const float *w2, const float *b2, const float *w3, const float *b3,
+                          float *out, int out_ctotal, int co_off, const captra_launch_opts *opts,
+        captra_stream_t stream);   /* the same with per-call options */
 
 /* Dense layer inside a Conv1d -> GroupNorm -> ReLU chain (the rotation heads, blocks.py:150-165) without the separate
  * normalisation pass.  As captra_pointwise_mlp, plus:
@@ -203,7 +239,12 @@ int captra_sa_scale_fused(int b, int n, int m, int k, int cfeat, int c1, int c2,
 int captra_pointwise_mlp_gn(int b, int cin, int cout, long long l, const float *x, const float *wt_packed,
                             const float *bias_packed, const float *ab_in, int act, float *y, float *stats_out,
                             int stats_t, captra_stream_t stream);
-int captra_pointwise_mlp_gn_tiles(int b, int cout, long long l);   /* the stats_t captra_pointwise_mlp_gn expects for this shape */
+int captra_pointwise_mlp_gn_ex(int b, int cin, int cout, long long l, const float *x, const float *wt_packed,
+                            const float *bias_packed, const float *ab_in, int act, float *y, float *stats_out,
+                            int stats_t, const captra_launch_opts *opts,
+        captra_stream_t stream);   /* the same with per-call options */
+int captra_pointwise_mlp_gn_tiles(int b, int cout, long long l);
+int captra_pointwise_mlp_gn_tiles_ex(int b, int cout, long long l, const captra_launch_opts *opts);   /* (the split-k form has its own tile size) */   /* the stats_t captra_pointwise_mlp_gn expects for this shape */
 int captra_gn_finalize(int b, int c, int channels_per_group, int stats_t, long long n, float eps, const float *stats,
                        const float *gamma, const float *beta, float *ab, captra_stream_t stream);
 
@@ -234,6 +275,10 @@ int captra_pack_sa_bf16(int cfeat, int c1, int c2, int c3, int pre, const float 
 int captra_sa_scale_bf16(int b, int n, int m, int k, int cfeat, int c1, int c2, int c3, int pre, const float *feat_or_v1,
                          const float *xyz_cn, const float *new_xyz, const int *idx, const unsigned char *img, float *out,
                          int out_ctotal, int co_off, captra_stream_t stream);
+int captra_sa_scale_bf16_ex(int b, int n, int m, int k, int cfeat, int c1, int c2, int c3, int pre, const float *feat_or_v1,
+                         const float *xyz_cn, const float *new_xyz, const int *idx, const unsigned char *img, float *out,
+                         int out_ctotal, int co_off, const captra_launch_opts *opts,
+        captra_stream_t stream);   /* the same with per-call options */
 
 /* f32x6: fp32-EQUIVALENT shared MLPs on the bf16 matrix pipe (opt-in arithmetic `mlp_dtype = "f32x6"`; the default path stays the
  * exact fp32 fmaf chain).  Replaces, like the kernels above, the fp32 Conv2d 1x1 + BN + ReLU stacks of
@@ -329,6 +374,10 @@ int captra_gemv_bf16(int b, int cin, int cout, const float *x, const float *wt_p
 int captra_head12_bf16(int b, int cin, long long l, const void *x, const unsigned char *w1img, const float *bias1_packed,
                        const float *ab1, const unsigned char *w2img, const float *bias2_packed, void *y2, float *stats,
                        captra_stream_t stream);
+int captra_head12_bf16_ex(int b, int cin, long long l, const void *x, const unsigned char *w1img, const float *bias1_packed,
+                       const float *ab1, const unsigned char *w2img, const float *bias2_packed, void *y2, float *stats,
+                       const captra_launch_opts *opts,
+        captra_stream_t stream);   /* the same with per-call options */
 
 /* bf16 mode, register-resident dense CHAIN (csrc/sa_bf16.hip): FP1's shared MLP + the backbone's conv1 (+ CoordinateNet's two heads)
  * in one launch.  x (B,c0,L) fp32, c0 <= 144 -> three 128-wide Conv+BN+ReLU layers; feat_pm (B,L,128) bf16 slot order receives the
@@ -377,16 +426,11 @@ int captra_fps_gather_ragged(int b, int n_stride, const int *n_per_cloud, int m,
  * minima from part to part (every part writes it; every part but the one starting at 0 reads it); idx / new_xyz_* are the whole
  * sampling's buffers.  Parts launched in order on one stream produce the one launch's picks bit for bit (sampling_gpu.cu:93-209
  * is one loop; this cuts it at j0).  Between two parts the caller may run whatever needs only the centres picked so far -- the
- * ball query and the shared MLPs of those centres, with captra_set_centre_window -- on other streams, so that the sampler's
+ * ball query and the shared MLPs of those centres, with captra_launch_opts::centre_m0 / centre_mc -- on other streams, so that the sampler's
  * dependent rounds, one workgroup per cloud, no longer stand alone at the head of a frame.  -2: cloud outside the
  * register-resident kernel (> 8191 points). */
 int captra_fps_gather_part(int b, int n, int m, int j0, int j1, const float *xyz, float *state, int *idx, float *new_xyz_n3,
                            float *new_xyz_cn, captra_stream_t stream);
-/* The next captra_ball_query[_multi] / captra_sa_scale_fused (LDS-weights kernels: the small-input scales) / captra_sa_scale_bf16
- * (small-input scales) launches of the calling thread process centres [m0, m0 + mc) of every cloud only and leave the rest of
- * their (B, M, ...) outputs untouched; mc <= 0 = all centres (default).  Entry points that cannot honour a window return -2 while
- * one is set.  Thread-local. */
-void captra_set_centre_window(int m0, int mc);
 
 /* A module of the backbone's NECK in the bf16 mode as ONE launch (csrc/neck_bf16.hip): nl = 2 or 3 layers act(b + W x), ReLU between them,
  * on tiles of 64 positions with every hidden activation in LDS as the next layer's operand image and the weights streamed from the
@@ -460,6 +504,11 @@ int captra_sa_scale_pre_pm(int b, int n, int m, int k, int cfeat, int c1, int c2
                            const float *xyz_cn, const float *new_xyz, const int *idx, const float *w1, const float *w2,
                            const float *b2, const float *w3, const float *b3, float *out, int out_ctotal, int co_off,
                            captra_stream_t stream);
+int captra_sa_scale_pre_pm_ex(int b, int n, int m, int k, int cfeat, int c1, int c2, int c3, const float *v1pm,
+                           const float *xyz_cn, const float *new_xyz, const int *idx, const float *w1, const float *w2,
+                           const float *b2, const float *w3, const float *b3, float *out, int out_ctotal, int co_off,
+                           const captra_launch_opts *opts,
+        captra_stream_t stream);   /* the same with per-call options */
 
 /* captra_pointwise_mlp2: the same layer on the channel concat [x; x2] WITHOUT building it -- SA3's [xyz, feat] of
  * sample_and_group_all (pointnet_utils.py:171-188) and FP3's [points1, repeat(points2)] (pointnet_utils.py:265-270).  x (B,csplit,L),
@@ -468,10 +517,16 @@ int captra_sa_scale_pre_pm(int b, int n, int m, int k, int cfeat, int c1, int c2
  * (cout <= 64) or the tensors lie more than 2^30 bytes apart -- the caller concatenates. */
 int captra_pointwise_mlp2(int b, int cin, int csplit, int cout, long long l, const float *x, const float *x2, int x2_bcast,
                           const float *wt_packed, const float *bias_packed, int act, float *y, captra_stream_t stream);
+int captra_pointwise_mlp2_ex(int b, int cin, int csplit, int cout, long long l, const float *x, const float *x2, int x2_bcast,
+                          const float *wt_packed, const float *bias_packed, int act, float *y, const captra_launch_opts *opts,
+        captra_stream_t stream);   /* the same with per-call options */
 /* captra_pointwise_mlp with a POINT-major result y (B,l,cout) (cout % 4 == 0, y 16-byte aligned; -2 otherwise or when the
  * layer is outside the direct-operand kernel's 32-bit offset range). */
 int captra_pointwise_mlp_pm(int b, int cin, int cout, long long l, const float *x, const float *wt_packed,
                             const float *bias_packed, int act, float *y, captra_stream_t stream);
+int captra_pointwise_mlp_pm_ex(int b, int cin, int cout, long long l, const float *x, const float *wt_packed,
+                            const float *bias_packed, int act, float *y, const captra_launch_opts *opts,
+        captra_stream_t stream);   /* the same with per-call options */
 
 /* Three dense layers in one launch: y (B,c3,l) = act3(W3 relu(W2 relu(W1 x + b1) + b2) + b3), x (B,c0,l); packed
  * weights (captra_pack_weights).  Replaces the FP1 shared MLP + conv1/bn1/ReLU tail of PointNet2Msg
@@ -564,20 +619,28 @@ int captra_rot_pool_compose(int b, int p, int n, int sym, int diag_only, const f
 int captra_procrustes_rot3(int nb, int n, const float *src, const float *tgt, float *rot,
                            captra_stream_t stream);
 
+/* A set-abstraction LEVEL's scales in one call: njobs (<= 4) jobs, each the argument list of captra_sa_scale_fused (pre = 0:
+ * feat_or_v1 = feat) or captra_sa_scale_pre_pm (pre = 1: feat_or_v1 = v1pm, b1 unused).  When the jobs are a level's three
+ * small-input scales in order ([cf+3 -> 32 -> 32 -> 64], [-> 64 -> 64 -> 128], [-> 64 -> 96 -> 128]) -- and / or the second level's
+ * two ([323 -> 128 -> 128 -> 256], [-> 128 -> 196 -> 256]) -- they run as ONE launch, each on its own range of workgroups (bits
+ * unchanged: every workgroup does what its scale's own launch would have done); otherwise one launch after the other, exactly
+ * as the per-scale calls.  For steps of few clouds, where a scale's own launch fills a fraction of the chip.  opts->dyn_slot is
+ * ignored (the one-launch forms walk statically).  A pure function of its arguments: safe from any number of host threads. */
+typedef struct captra_sa_scale_job {
+    int pre, b, n, m, k, cfeat, c1, c2, c3;
+    const float *feat_or_v1, *xyz_cn, *new_xyz;
+    const int *idx;
+    const float *w1, *b1, *w2, *b2, *w3, *b3;      /* packed buffers of the three layers */
+    float *out;
+    int out_ctotal, co_off;
+} captra_sa_scale_job;
+int captra_sa_scales_multi(int njobs, const captra_sa_scale_job *jobs, const captra_launch_opts *opts, captra_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Section 3 — introspection
  * ---------------------------------------------------------------------------------------- */
 const char *captra_error_string(int err);
 const char *captra_version(void);
-/* Host-side helper of the pipelined schedules (captra_amd/graph.py): the calling thread's launches of PERSISTENT kernels (grid =
- * CU slots, static work split: the fp32 SA scales, the fused bf16 head pair) are sized for n CUs fewer, so that all of their
- * workgroups are resident while another stream's one-workgroup-per-cloud samplers hold n CUs.  Thread-local; 0 = whole device. */
-void captra_set_reserved_cus(int n);
-/* Dynamic centre hand-out of the persistent SA kernels: pool = a caller-owned DEVICE buffer of nslots ints; every launch of the
- * calling thread takes the next slot (round robin), zeroes it on its stream and hands its centres out through it instead of the
- * static walk -- workgroups that become resident late (another stream's samplers hold their CUs) then find the work done instead
- * of doubling the launch's time.  Same bits.  (NULL, 0) = static (default).  Thread-local. */
-void captra_sa_set_dynamic(int *pool, int nslots);
 /* Per-kernel HIP-event timing: when enabled every launcher brackets its kernel with events on
  * its own stream.  captra_prof_read synchronises the recorded events and returns accumulated
  * milliseconds / launch count for `name` (the kernel family, e.g. "ball_query"). */
@@ -586,10 +649,10 @@ void captra_prof_reset(void);
 int captra_prof_read(const char *name, double *total_ms, long long *launches);
 int captra_prof_names(char *buf, int buflen);
 
-/* ---- 4. Experiment switches (NOT part of the stable ABI; used by tests/ and tools/ to cross-check variants that compute the
- *         same bits).  Each switch is THREAD-LOCAL: it affects launches made by the calling host thread only, so the
- *         operators above keep the reference boundary's "no global state" property for every other thread / GPU of the
- *         process.  Defaults (0; 1 for captra_pw_set_direct / captra_pw_set_pair) select the production kernels. ---- */
+/* ---- 4. MEASUREMENT switches (NOT part of the stable ABI; used by tests/ and tools/ to cross-check or time variants that compute
+ *         the same bits).  Nothing the product path needs is set here: what a caller wants different from the defaults travels with
+ *         the call (captra_launch_opts).  Each switch is THREAD-LOCAL: it affects launches made by the calling host thread only.
+ *         Defaults (0; 1 for captra_pw_set_direct / captra_pw_set_pair) select the production kernels. ---- */
 void captra_fps_set_waves(int waves);       /* FPS: waves per cloud (0 = heuristic) */
 void captra_fps_set_pruned_min(int n);     /* FPS: clouds of >= n points take the pruned kernel (default 8192; 0 = never) */
 void captra_fps_set_stats(unsigned long long *dev_counters); /* pruned FPS: accumulate 6 counters {bucket updates, refreshes, cycles of 4 phases} (NULL = off) */
@@ -600,14 +663,6 @@ void captra_sa_fused_set_wn(int wn);        /* generic LDS kernel: sub-tile widt
 void captra_sa_fused_set_prof(unsigned long long *dev_counters); /* sa_wave_kernel: 10 device counters of phase timers, or NULL */
 void captra_pw_set_direct(int on);          /* dense layers: 1 = direct-operand kernel (default), 0 = LDS-staged kernel */
 void captra_ball_query_set_prune(int on);   /* ball query: 1 = small radii of 1024..4096-point clouds from a cell grid (exact; measured slower, off by default), 0 = index-order scan */
-/* captra_sa_scale_fused calls between the two that take the LDS-weight kernels (the small-input scales) are recorded and launched by
- * the end: as ONE launch when they are a level's three scales in order (each on its own range of workgroups, bits unchanged), else one
- * after the other.  For steps of few clouds, where a scale's own launch fills a fraction of the chip.  Thread-local, not re-entrant. */
-void captra_sa_multi_begin(void);
-int captra_sa_multi_end(captra_stream_t stream);
-void captra_pw_set_splitk(int max_positions); /* dense layers (captra_pointwise_mlp / _mlp2 / _pm): launches of <= max_positions (b * l) and >= 128 input channels split k over the four waves of a workgroup
-                                              * (partial tiles added in wave order: a fixed order, 1e-5 relative from the k-ascending chain); 0 = never (default) */
-void captra_sa_set_prezeroed(int on);      /* SA scales, slice-per-wave form (few clouds): 1 = the caller zeroed the whole output tensor (one fill per level), 0 = the launcher zeroes its channel slice (default) */
 void captra_pw_set_occupancy(int occ);      /* dense layers, 64x64 wave tiles: workgroups per CU, 0 / 4 = as built (default), 3 / 2 = fewer (measurements) */
 void captra_pw_set_dbg(int v);             /* dense layers of a GroupNorm chain: timing ablations (-DCAPTRA_ABLATIONS=1 builds only, results wrong; ignored otherwise) */
 void captra_pw_set_pair(int on);            /* dense layers: 1 = paired column tiles where L is even (default), 0 = never */

@@ -232,7 +232,7 @@ def test_pointwise_mlp_two_sources_equals_concat_bit_for_bit(device, c1, c2, cou
                                                   (320, (128, 196, 256), 512, 128, 128, 33), (320, (128, 128, 256), 512, 128, 64, 17),
                                                   (0, (64, 96, 128), 700, 41, 128, 1)])
 def test_sa_scale_dynamic_centre_hand_out_bit_exact(device, cfeat, chans, n, m, k, B):
-    """captra_sa_set_dynamic: the persistent SA kernels take their centres from a zeroed counter instead of the static walk
+    """captra_launch_opts::dyn_slot (host layer: _lib.launch_options(dyn_pool=...)): the persistent SA kernels take their centres from a zeroed counter instead of the static walk
     (a workgroup that becomes resident late finds the work done).  Which wave computes a centre changes nothing: the launch
     with the counter, the static launch and (through the other tests) the oracle agree bit for bit; every launch takes a
     fresh slot of the caller's pool and leaves the number of hand-outs in it (>= the centres)."""
@@ -260,10 +260,9 @@ def test_sa_scale_dynamic_centre_hand_out_bit_exact(device, cfeat, chans, n, m, 
     pool = torch.full((4,), 12345, dtype=torch.int32, device=device)
     try:
         want = run()
-        _lib.lib().captra_sa_set_dynamic(ctypes.c_void_p(pool.data_ptr()), ctypes.c_int(4))
-        got = [run() for _ in range(3)]
+        with _lib.launch_options(dyn_pool=(pool.data_ptr(), 4)):
+            got = [run() for _ in range(3)]
     finally:
-        _lib.lib().captra_sa_set_dynamic(ctypes.c_void_p(0), ctypes.c_int(0))
         _lib.lib().captra_sa_fused_set_split(ctypes.c_int(1))
     for g in got:
         assert torch.equal(g, want)
@@ -732,7 +731,7 @@ def test_backbone_vs_golden_and_oracle(device, tag, use_xyz, seed):
 
 @pytest.mark.parametrize("use_xyz,batch", [(False, 1), (True, 2)])
 def test_level_scales_in_one_launch_equal_one_launch_each(device, use_xyz, batch):
-    """Few clouds: a level's three small-input scales recorded and launched together (captra_sa_multi_begin / _end ->
+    """Few clouds: a level's three small-input scales handed over together (captra_sa_scales_multi ->
     sa_wave_lds3_kernel, every scale on its own range of workgroups) against one launch per scale: every bit of the level's
     output, with and without CoordinateNet's coordinate features."""
     from captra_amd import pointnet_utils as PU
@@ -755,6 +754,70 @@ def test_level_scales_in_one_launch_equal_one_launch_each(device, use_xyz, batch
         PU.MULTI_SCALE_MAX_CLOUDS = keep
     assert outs[0][0].shape == (batch, 320, 512) and outs[0][1].shape == (batch, 512, 128) and float(outs[0][1].abs().max()) > 0
     assert torch.equal(outs[0][0], outs[2][0]) and torch.equal(outs[0][1], outs[2][1])
+
+
+def test_sa_scales_multi_from_two_host_threads_concurrently(device):
+    """The C ABI holds no state: two host threads, each with its own stream, tensors and job table, call the
+    multi-scale path (captra_sa_scales_multi: a level's three small-input scales as one launch, and the second level's two) at
+    the same time, many times over, one of them under other per-call options (a pre-zeroed output) -- every result equals the
+    thread's own per-scale launches bit for bit."""
+    import threading
+    from captra_amd import _lib, fused
+    rng = np.random.default_rng(99)
+
+    def make(cfeat, shapes, n, m, B):
+        xyz_cn = _dev(rng.random((B, 3, n), dtype=np.float32) - 0.5, device)
+        feat = _dev(rng.standard_normal((B, cfeat, n)).astype(np.float32), device) if cfeat else None
+        new_xyz = _dev(rng.random((B, m, 3), dtype=np.float32) - 0.5, device)
+        scales = []
+        for chans, k in shapes:
+            dims = (cfeat + 3,) + chans
+            packed = [fused.pack(_dev((rng.standard_normal((dims[i], dims[i + 1])) / np.sqrt(dims[i])).astype(np.float32), device),
+                                 _dev(rng.standard_normal(dims[i + 1]).astype(np.float32), device)) for i in range(3)]
+            scales.append((packed, _dev(rng.integers(0, n, (B, m, k)).astype(np.int32), device)))
+        return xyz_cn, feat, new_xyz, scales
+
+    work = {0: make(3, [((32, 32, 64), 32), ((64, 64, 128), 64), ((64, 96, 128), 128)], 1024, 128, 2),
+            1: make(320, [((128, 128, 256), 64), ((128, 196, 256), 128)], 512, 128, 1)}
+    errors, results = [], {}
+
+    def run(tid, together):
+        xyz_cn, feat, new_xyz, scales = work[tid]
+        ctot = sum(p[-1].cout for p, _ in scales)
+        out = torch.zeros(xyz_cn.shape[0], ctot, new_xyz.shape[1], device=device)
+        jobs, keep, off = ([] if together else None), [], 0
+        with _lib.launch_options(sa_prezeroed=1 if tid == 1 else 0):
+            for packed, idx in scales:
+                if feat is not None and feat.shape[1] > 3:
+                    v1 = fused.sa_first_layer_pre_pm(feat, packed[0])
+                    keep.append(v1)
+                    fused.sa_scale_pre_pm(v1, xyz_cn, new_xyz, idx, packed, out, off, feat.shape[1], jobs=jobs)
+                else:
+                    fused.sa_scale_fused(feat, xyz_cn, new_xyz, idx, packed, out, off, jobs=jobs)
+                off += packed[-1].cout
+            if jobs:
+                fused.sa_scales_multi(jobs, device)
+        return out
+
+    def worker(tid):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream(device=device)):
+                want = run(tid, False)
+                for _ in range(25):
+                    got = run(tid, True)
+                    torch.cuda.current_stream().synchronize()
+                    if not torch.equal(got, want):
+                        errors.append((tid, float((got - want).abs().max())))
+                results[tid] = True
+        except Exception as e:              # noqa: BLE001
+            errors.append((tid, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in (0, 1)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors and results == {0: True, 1: True}, errors
 
 
 def test_backbone_16384_point_clouds_bit_exact_vs_oracle(device):
@@ -1068,7 +1131,7 @@ def test_rot_pool_compose_vs_oracle(device, sym, P):
 @pytest.mark.parametrize("b,cin,cout,l,csplit,bcast,act", [(1, 515, 256, 128, 3, False, 1), (2, 1536, 512, 128, 512, True, 1), (1, 832, 512, 512, 320, False, 1),
                                                           (1, 256, 512, 128, 0, False, 1), (2, 320, 128, 512, 0, False, 0), (1, 130, 70, 77, 0, False, 2)])
 def test_split_k_dense_layers_close_to_the_bit_exact_chain(device, b, cin, cout, l, csplit, bcast, act):
-    """fused.split_k (captra_pw_set_splitk): the dense layers of few-position launches with k dealt to a workgroup's four waves and
+    """fused.split_k (captra_launch_opts::splitk_positions): the dense layers of few-position launches with k dealt to a workgroup's four waves and
     the partial tiles added in wave order -- within 1e-5 of the k-ascending chain (relative to the largest output), for the one-
     and two-source layers of the 128- / 512-point levels (SA3's [xyz, feat], FP3's [points1, repeat(points2)], FP2's concat, SA2's
     point-major pre-transform), odd shapes included; outside the context, and for launches above the position limit inside it,

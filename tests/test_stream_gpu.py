@@ -1,4 +1,4 @@
-"""Streamed level-1 sampling (captra_fps_gather_part + captra_set_centre_window): the sampler cut into parts and the ball query /
+"""Streamed level-1 sampling (captra_fps_gather_part + captra_launch_opts::centre_m0 / centre_mc): the sampler cut into parts and the ball query /
 small-input SA scales run per window of centres must produce what the one-launch forms produce, bit for bit -- furthest-point
 sampling is one loop (reference sampling_gpu.cu:93-209), a centre's neighbour list and pooled features depend on that centre
 only (ball_query_gpu.cu:9-45, pointnet_utils.py:228-248)."""
