@@ -58,15 +58,19 @@ __device__ __forceinline__ void sx_split2(float a, float b, unsigned &p0, unsign
 __device__ __forceinline__ f32x16 sx_mfma(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
-// the six products of one k-step, small terms first.  FLIP: activations are the A operand (rows = positions)
+// the six products of one k-step as TWO accumulator chains issued alternately -- `lo` takes the three small products (2^-16 of the
+// leading one), `hi` the three large ones; a tile's result is hi + lo.  Back-to-back MFMAs on ONE accumulator run at the issue rate only
+// while nothing sits between them: every ds_read / VALU the scheduler puts into such a chain costs ~43 cycles (MI355X_MICROARCH.md),
+// and a k-step carries three fragment reads -- one chain ran the matrix pipe at 0.62-0.68; between MFMAs on different accumulators a
+// filler costs ~6.  FLIP: activations are the A operand (rows = positions)
 template <bool FLIP>
-__device__ __forceinline__ void sx_group(f32x16 &acc, const u32x4 (&w)[3], const u32x4 &x0, const u32x4 &x1, const u32x4 &x2) {
+__device__ __forceinline__ void sx_group(f32x16 &hi, f32x16 &lo, const u32x4 (&w)[3], const u32x4 &x0, const u32x4 &x1, const u32x4 &x2) {
     if constexpr (FLIP) {
-        acc = sx_mfma(x0, w[2], acc); acc = sx_mfma(x2, w[0], acc); acc = sx_mfma(x1, w[1], acc);
-        acc = sx_mfma(x0, w[1], acc); acc = sx_mfma(x1, w[0], acc); acc = sx_mfma(x0, w[0], acc);
+        lo = sx_mfma(x0, w[2], lo); hi = sx_mfma(x0, w[1], hi); lo = sx_mfma(x2, w[0], lo);
+        hi = sx_mfma(x1, w[0], hi); lo = sx_mfma(x1, w[1], lo); hi = sx_mfma(x0, w[0], hi);
     } else {
-        acc = sx_mfma(w[2], x0, acc); acc = sx_mfma(w[0], x2, acc); acc = sx_mfma(w[1], x1, acc);
-        acc = sx_mfma(w[1], x0, acc); acc = sx_mfma(w[0], x1, acc); acc = sx_mfma(w[0], x0, acc);
+        lo = sx_mfma(w[2], x0, lo); hi = sx_mfma(w[1], x0, hi); lo = sx_mfma(w[0], x2, lo);
+        hi = sx_mfma(w[0], x1, hi); lo = sx_mfma(w[1], x1, lo); hi = sx_mfma(w[0], x0, hi);
     }
 }
 __device__ __forceinline__ float sx_max3(float a, float b, float c) {
@@ -181,6 +185,11 @@ __device__ __forceinline__ void sx_split_unit(const f32x16 &acc, int t, int u, u
     const float a = relu_bits(acc[8 * jj + 2 * i]), b = relu_bits(acc[8 * jj + 2 * i + 1]);
     unsigned p0, p1, p2;
     sx_split2(a, b, p0, p1, p2);
+    // pin the unit HERE: left alone, LLVM sinks the whole split (pure arithmetic) down to its first use -- the next layer's first
+    // MFMA -- five tiles' worth of it end up in one block that no MFMA covers and their accumulators stay live until then (the
+    // 196-wide scale spills); the scheduling barriers around a group do not bind IR-level sinking, an asm statement that
+    // "modifies" the three results does.  (With ONE accumulator chain per tile the pinned units cost more than they hid: 384 -> 453 us.)
+    asm volatile("" : "+v"(p0), "+v"(p1), "+v"(p2));
     hout[0][2 * t + jj][i] = p0;
     hout[1][2 * t + jj][i] = p1;
     hout[2][2 * t + jj][i] = p2;
@@ -243,9 +252,13 @@ __device__ __forceinline__ void sx_body(const SxParams &p, unsigned char *smem) 
     // last MFMA when it arrives here, so no LDS wait is needed in front of the barrier)
     auto acquire = [&](int c) {
         if constexpr (RING) {
+#if !defined(CAPTRA_SX_ABL) || CAPTRA_SX_ABL < 2          // (timing ablations, results wrong: 1 = no LDS-DMA after start-up, 2 = no barrier either)
             SX_WAIT_VM(0);
             __builtin_amdgcn_s_barrier();
+#endif
+#if !defined(CAPTRA_SX_ABL) || CAPTRA_SX_ABL < 1
             issue_chunk((c + 1) % S::NCH);
+#endif
         }
     };
     auto wbase = [&](int c) -> const unsigned char * {
@@ -383,7 +396,7 @@ __device__ __forceinline__ void sx_body(const SxParams &p, unsigned char *smem) 
         __builtin_amdgcn_sched_barrier(0);
 
         // ---- layers 2 and 3: G groups of six MFMAs; tile tau accumulates in acc[tau & 1], tile tau - 1 is read out behind them ------
-        f32x16 acc[2];
+        f32x16 acc[2], accl[2];                         // (hi, lo) chains of tile tau in acc[tau & 1], accl[tau & 1]; merged into acc at read-out
         sx_static_for<0, G>([&](auto gi_c) __attribute__((always_inline)) {
             constexpr int gi = decltype(gi_c)::value;
             constexpr bool l3 = gi >= G2;
@@ -403,6 +416,8 @@ __device__ __forceinline__ void sx_body(const SxParams &p, unsigned char *smem) 
                 load_g4(cn, id_n, g4);
             }
             if (kk == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accl[tau & 1][r] = 0.f;
                 if (!l3) {
                     const float4 *bp = reinterpret_cast<const float4 *>(bias_lds + S::B2OFF + 32 * t + 4 * h);
 #pragma unroll
@@ -416,6 +431,8 @@ __device__ __forceinline__ void sx_body(const SxParams &p, unsigned char *smem) 
                 }
             }
             // ---- deferred read-outs issued with this group ----
+            if constexpr (tau > 0 && kk == (kst > 1 ? 1 : 0) && !(l3 && t == 0 && !DEFER_LAST))
+                acc[(tau - 1) & 1] += accl[(tau - 1) & 1];                 // the finished tile: hi + lo
             if constexpr (!l3 && t == 0) {
                 // layer 1's later tiles: the four units of k-step kk + 1
                 constexpr int ks = kk + 1;
@@ -439,8 +456,8 @@ __device__ __forceinline__ void sx_body(const SxParams &p, unsigned char *smem) 
                 for (int i = 0; i < 8; ++i) z[t - 1] = sx_max3(z[t - 1], acc[(tau - 1) & 1][2 * i], acc[(tau - 1) & 1][2 * i + 1]);
             }
             // ---- the six products ----
-            if (!l3) sx_group<false>(acc[tau & 1], wr[gi & 1], h1[0][kk], h1[1][kk], h1[2][kk]);
-            else sx_group<true>(acc[tau & 1], wr[gi & 1], h2[0][kk], h2[1][kk], h2[2][kk]);
+            if (!l3) sx_group<false>(acc[tau & 1], accl[tau & 1], wr[gi & 1], h1[0][kk], h1[1][kk], h1[2][kk]);
+            else sx_group<true>(acc[tau & 1], accl[tau & 1], wr[gi & 1], h2[0][kk], h2[1][kk], h2[2][kk]);
             // one MFMA, then a sixth of the group's VALU work: each of them issues while an MFMA executes
             {
                 constexpr int per = (sx_group_valu(l3, t, kk, S::NT2, S::KST2, S::KST3, DEFER_LAST) + 5) / 6;
@@ -455,12 +472,14 @@ __device__ __forceinline__ void sx_body(const SxParams &p, unsigned char *smem) 
             __builtin_amdgcn_sched_barrier(0);
             // layer 2's last tile, when it cannot be read out under layer 3
             if constexpr (!l3 && gi == G2 - 1 && !DEFER_LAST) {
+                acc[tau & 1] += accl[tau & 1];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) sx_split_unit<S::KST3>(acc[tau & 1], S::NT2 - 1, u, h2);
             }
         });
         {
             constexpr int TL = S::NCH - 1;
+            acc[TL & 1] += accl[TL & 1];
 #pragma unroll
             for (int i = 0; i < 8; ++i) z[S::NT3 - 1] = sx_max3(z[S::NT3 - 1], acc[TL & 1][2 * i], acc[TL & 1][2 * i + 1]);
         }
