@@ -270,6 +270,32 @@ def b1_leg(device, steps: int = 200, otf_frames: int = 24, reps: int = 5):
     return out
 
 
+def ball_query_scanned_fraction(points_cn, pn_cfg) -> float:
+    """Share of the N x M pair tests per (cloud, level) the index-order scan actually makes before its early exit (every radius'
+    list full: bq_scan.h), on THESE clouds -- a torch restatement of the exit rule on the sampled centres: a centre's scan ends
+    with the 64-point chunk in which its slowest list takes its K-th hit (at N when a list never fills).  Measurement only."""
+    import torch
+    from captra_amd import fused
+    xyz = points_cn.transpose(1, 2).contiguous()                       # (B,N,3)
+    scanned = total = 0.0
+    for lvl in ("sa1", "sa2"):
+        c = pn_cfg[lvl]
+        _, new_n3, _ = fused.fps_gather(xyz, int(c["npoint"]))
+        d2 = ((new_n3[:, :, None, :] - xyz[:, None, :, :]) ** 2).sum(-1)        # (B,M,N)
+        n = xyz.shape[1]
+        end = torch.zeros(d2.shape[:2], dtype=torch.long, device=xyz.device)
+        for r, k in zip(c["radius_list"], c["nsample_list"]):
+            cnt = (d2 < float(r) ** 2).cumsum(-1, dtype=torch.int32)
+            full = cnt[..., -1] >= int(k)
+            pos = (cnt >= int(k)).to(torch.int8).argmax(-1) + 1           # points read up to and including the K-th hit
+            end = torch.maximum(end, torch.where(full, pos, torch.full_like(pos, n)))
+        end = torch.clamp((end + 63) // 64 * 64, max=n)
+        scanned += float(end.sum().item())
+        total += float(end.numel() * n)
+        xyz = new_n3.contiguous()
+    return scanned / max(total, 1.0)
+
+
 def hbm_ops_roofline(batch: int, device, reps: int = 5):
     """The drop-in ops ball_query + group_points (SURVEY.md §8d "materialised-op" byte definition: ball query
     12N + 12M + 4MK, group 4CN + 4MK + 4CMK bytes per cloud) on the workload's SA1 / SA2 shapes for one frame
@@ -962,8 +988,16 @@ def main():
             pairs = fused.WORK["flops"].get("ball_query", 0.0)
             sec = bq["ms_total"] * 1e-3
             peak_pairs = 256 * 4 * 2.4e9 * 64 / 8.0              # one wave-instruction per 2 cycles per SIMD, 8 instructions per 64 lanes x 2 tests ... upper bound
+            # (the scan leaves a centre when every radius' list is full -- count the pairs it makes, not N x M)
+            try:
+                share = ball_query_scanned_fraction(data[last_frame]["points"].to(device), cfg["pointnet"]["camera"])
+            except Exception:                                   # noqa: BLE001  (measurement only: never fails the line)
+                share = None
+            pairs_nm = pairs
+            pairs = pairs * share if share else pairs
             out["roofline_ball_query"] = {"bound": "valu", "unit": "pair tests/s", "achieved": round(pairs / sec) if pairs else None,
                                           "peak": round(peak_pairs), "frac": round(pairs / sec / peak_pairs, 4) if pairs else None,
+                                          "scanned_share_of_NxM": round(share, 4) if share else None, "NxM_per_s": round(pairs_nm / sec) if pairs_nm else None,
                                           "algorithmic_GB/s": round(nbytes / sec / 1e9, 1),
                                           "avg_launch_us": round(1e3 * bq["ms_total"] / bq["launches"], 2)}
         out["kernel_ms_per_step"] = {k: round(v["ms_total"] / timed_steps, 3) for k, v in sorted(fams.items(), key=lambda kv: -kv[1]["ms_total"])}
