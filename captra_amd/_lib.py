@@ -82,6 +82,8 @@ _SIGNATURES = {
     "captra_fps_gather_part": [_INT, _INT, _INT, _INT, _INT, _P, _P, _P, _P, _P, _P],
     "captra_crop_ball": [_INT, _INT, _INT, _INT, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "captra_crop_box": [_INT, _INT, _INT, C.c_double, _P, _P, _P, _P, _P, _P, _P],
+    "captra_otf_candidates": [_INT, _INT, _INT, _INT, _P, _P, _P, _P, _P, _P],
+    "captra_otf_finish": [_INT, _INT, _INT, _INT] + [_P] * 11 + [_P],
     "captra_sa_scale_pre": [_INT] * 8 + [_P] * 9 + [_P, _INT, _INT, _P],
     "captra_sa_scale_pre_pm": [_INT] * 8 + [_P] * 9 + [_P, _INT, _INT, _P],
     "captra_pointwise_mlp_pm": [_INT, _INT, _INT, _LL, _P, _P, _P, _INT, _P, _P],

@@ -122,6 +122,69 @@ __global__ void crop_box_kernel(int b, int h, int w, double radius_factor, const
     radius[i] = r;
 }
 
+// ---- the re-crop's candidate lists and its read-out without the host --------------------------------------
+// What the host did between the crop and the sampler, from the member counts it fetched (captra_amd/nocs_otf.py, reference
+// data_utils.py:138-162 farthest_point_sample's caller / nocs_data_process.py:92-109): the candidate list of an instance is its
+// member table repeated until it holds at least num_points entries (list doubling: candidate j = member j mod count, length =
+// count * 2^k), thinned by a random permutation when longer than 5 num_points (the host's generator: a RARE path here).
+// otf_candidates_kernel builds the lists (fp32 coordinates, the sampler's input) and their lengths on the device and raises the
+// rare-path word; otf_finish_kernel turns the sampler's picks into the frame's tensors (reference nocs_data_process.py:43-50,
+// 227-236: points, labels 0 = object / 1 = background, ground-truth NOCS of the object's points) in the layouts the networks read.
+__device__ __forceinline__ int otf_list_length(int c, int num_points) {
+    int len = c;
+    while (len < num_points) len *= 2;
+    return len;
+}
+
+__global__ __launch_bounds__(256) void otf_candidates_kernel(int cap, int stride, int num_points, const double *__restrict__ pts,
+                                                             const int *__restrict__ counts, float *__restrict__ cand,
+                                                             int *__restrict__ lens, int *__restrict__ info) {
+    const int b = blockIdx.y;
+    const int c = counts[b * 2];
+    const int cc = c < 1 ? 1 : (c > stride ? stride : c);           // rare rows clamped: every access stays inside its buffer
+    const int len = otf_list_length(cc, num_points);
+    const int keep = len < stride ? len : stride;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        lens[b] = keep;
+        if (c < 10 || c > stride || len > stride) atomicOr(info, 1);
+        atomicMax(info + 1, c > cap ? cap : otf_list_length(c < 1 ? 1 : c, num_points));
+    }
+    const double *pb = pts + (size_t)b * cap * 3;
+    float *cb = cand + (size_t)b * stride * 3;
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < stride; j += gridDim.x * 256) {
+        float x = 0.f, y = 0.f, z = 0.f;
+        if (j < keep) {
+            const double *q = pb + (size_t)(j % cc) * 3;
+            x = (float)q[0]; y = (float)q[1]; z = (float)q[2];
+        }
+        cb[(size_t)j * 3 + 0] = x; cb[(size_t)j * 3 + 1] = y; cb[(size_t)j * 3 + 2] = z;
+    }
+}
+
+__global__ __launch_bounds__(256) void otf_finish_kernel(int cap, int stride, int n, const double *__restrict__ pts,
+                                                         const unsigned char *__restrict__ obj, const int *__restrict__ counts,
+                                                         const int *__restrict__ picks, const float *__restrict__ mean,
+                                                         const double *__restrict__ rot, const double *__restrict__ trans,
+                                                         const double *__restrict__ scale, float *__restrict__ points_cn,
+                                                         long long *__restrict__ labels, float *__restrict__ nocs_cn) {
+    const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int c = counts[b * 2];
+    const int cc = c < 1 ? 1 : (c > stride ? stride : c);
+    const int m = picks[(size_t)b * n + i] % cc;                      // candidate -> member
+    const double *q = pts + ((size_t)b * cap + m) * 3;
+    const bool o = obj[(size_t)b * cap + m] != 0;
+    const double *R = rot + (size_t)b * 9, *t = trans + (size_t)b * 3;
+    const double s = scale[b];
+    const double x0 = (q[0] - t[0]) / s, x1 = (q[1] - t[1]) / s, x2 = (q[2] - t[2]) / s;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        points_cn[((size_t)b * 3 + a) * n + i] = (float)q[a] - mean[b * 3 + a];
+        nocs_cn[((size_t)b * 3 + a) * n + i] = o ? (float)((x0 * R[a] + x1 * R[3 + a]) + x2 * R[6 + a]) : 0.f;
+    }
+    labels[(size_t)b * n + i] = o ? 0 : 1;
+}
+
 }  // namespace
 
 extern "C" int captra_crop_box(int b, int h, int w, double radius_factor, const float *trans, const float *scale, const double *kmat,
@@ -140,5 +203,30 @@ extern "C" int captra_crop_ball(int b, int h, int w, int cap, const int *depth, 
     if (b == 0) return 0;
     CAPTRA_LAUNCH("crop_ball", crop_ball_kernel, dim3(b), dim3(CB_T), 0, (hipStream_t)stream, h, w, cap, depth, mask, box,
                   center, radius, kinv, pts, obj, pix, counts);
+    return captra_last_error();
+}
+
+// The candidate lists of a re-crop and the ragged sampler's per-cloud counts, from the crop's device-resident member counts (see the
+// kernels above).  cand (B,stride,3) fp32, lens (B,), info: 4 ints, zeroed here on the stream, [0] = a rare-path instance was met
+// (< 10 members, or a list longer than `stride`), [1] = the longest list.  num_points <= stride.
+extern "C" int captra_otf_candidates(int b, int cap, int stride, int num_points, const double *pts, const int *counts, float *cand,
+                                     int *lens, int *info, captra_stream_t stream) {
+    if (b < 0 || cap < 1 || stride < 1 || num_points < 1 || num_points > stride) return -1;
+    if (b == 0) return 0;
+    if (captra_zero_async(info, 16, (hipStream_t)stream) != 0) return -1;
+    CAPTRA_LAUNCH("crop_ball", otf_candidates_kernel, dim3((unsigned)((stride + 1023) / 1024), b), dim3(256), 0, (hipStream_t)stream, cap, stride,
+                  num_points, pts, counts, cand, lens, info);
+    return captra_last_error();
+}
+
+// picks (B,n) = the sampler's indices into the candidate lists -> points_cn (B,3,n) fp32 = member coordinates - mean (B,3),
+// labels (B,n) int64 (0 object / 1 background), nocs_cn (B,3,n) fp32 = ((p - trans) / scale) R of the object's points in float64, 0 elsewhere.
+extern "C" int captra_otf_finish(int b, int cap, int stride, int n, const double *pts, const unsigned char *obj, const int *counts,
+                                 const int *picks, const float *mean, const double *rot, const double *trans, const double *scale,
+                                 float *points_cn, long long *labels, float *nocs_cn, captra_stream_t stream) {
+    if (b < 0 || cap < 1 || stride < 1 || n < 1) return -1;
+    if (b == 0) return 0;
+    CAPTRA_LAUNCH("crop_ball", otf_finish_kernel, dim3((unsigned)((n + 255) / 256), b), dim3(256), 0, (hipStream_t)stream, cap, stride, n, pts, obj,
+                  counts, picks, mean, rot, trans, scale, points_cn, labels, nocs_cn);
     return captra_last_error();
 }

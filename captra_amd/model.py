@@ -63,6 +63,38 @@ class BaseModel(nn.Module):
             self.per_diff_dict.setdefault(f"{instance}_{track_num}_{frame_i}", {}).update(get_ith_from_batch(per_diff, i))
 
 
+OTF_FIRST_BOUND = 5                 # the first frame's stride bound, in units of N (5 N = the longest list the fast path takes)
+OTF_DEFER = os.environ.get("CAPTRA_OTF_DEFER", "1") != "0"     # nocs_otf: no round trip for the crops' member counts either (A/B: 0 = the synchronous stage)
+
+
+class _OtfCheck:
+    """The deferred verdict of one frame's sync-free re-crop: the device word [rare-path instance met, longest candidate list]
+    (captra_amd/nocs_otf.py) on its way to pinned host memory behind the crop launch.  `read()` -- called when the NEXT frame is
+    about to be enqueued -- waits for that copy (work enqueued a frame ago: the host's only wait, and the GPU never waits for the
+    host) and returns (rare, longest)."""
+    _pinned: list = []
+
+    def __init__(self, info):
+        self.host = _OtfCheck._pinned.pop() if _OtfCheck._pinned else torch.empty(4, dtype=torch.int32).pin_memory()
+        self.host.copy_(info, non_blocking=True)
+        self.event = torch.cuda.Event()
+        self.event.record()
+
+    def read(self):
+        self.event.synchronize()
+        rare, longest = int(self.host[0]), int(self.host[1])
+        _OtfCheck._pinned.append(self.host)
+        return bool(rare), longest
+
+
+def _otf_bound(longest: int, n: int) -> int:
+    """The sampler's padded stride for the next frame: the last frame's longest candidate list + 3 %, in steps of 1024, within
+    [N, 5 N] (a list that outgrows it is a rare-path instance: the frame runs again on the synchronous stage).  Tight on purpose: the
+    pruned sampler keeps a cloud's buckets in registers up to 16384 points and spills slots to LDS beyond (fps_pruned.hip), and a
+    tracked object's crop changes by a few points per frame."""
+    return int(min(5 * n, max(n, -(-(longest + longest // 32) // 1024) * 1024)))
+
+
 OTF_POSE_ON_DEVICE = os.environ.get("CAPTRA_OTF_POSE_ON_DEVICE", "1") != "0"   # nocs_otf: the crop box from the device-resident pose (A/B: 0 = via the host)
 _OTF_LANE_STREAMS: dict = {}      # device index -> the two lane streams of EvalTrackModel._forward_otf_lanes
 
@@ -371,11 +403,13 @@ class EvalTrackModel(BaseModel):
             self._graph.set_pose(pose)
         return self._graph
 
-    def _recrop_slice(self, i, input, last_pose, sl):
+    def _recrop_slice(self, i, input, last_pose, sl, defer=None):
         """nocs_otf (reference model.py:425-452) for the trajectories `sl` of frame i: re-crop around the pose predicted for
         frame i-1 -- on the device (captra_amd/nocs_otf.py: one crop launch + one ragged sampling launch).  `last_pose` holds
-        those trajectories only.  -> (points (b,3,N) mean-subtracted, labels (b,N), nocs (b,3,N)).  Two host round trips on
-        the CURRENT stream: the predicted centre / scale, and the crops' member counts."""
+        those trajectories only.  -> (points (b,3,N) mean-subtracted, labels (b,N), nocs (b,3,N)).  With the pose on the device the
+        stage's one host round trip is the crops' member counts; `defer` (an int: upper bound of the candidate lists' length) takes
+        that one away too (nocs_otf.full_data_batch_arrays) and appends the device word [rare-path instance met, longest list] to
+        the result -- the caller reads it a frame late (_OtfCheck) and runs the frame again without `defer` when it is set."""
         from .nocs_otf import full_data_batch_arrays, to_host
         pre = input.get("pre_fetched")
         if pre is None:
@@ -397,18 +431,30 @@ class EvalTrackModel(BaseModel):
         trans_d, scale_d = last_pose["translation"][:, self.root].reshape(b, 3), last_pose["scale"][:, self.root].reshape(b)
         if OTF_POSE_ON_DEVICE and depth.is_cuda and trans_d.dtype == torch.float32 and scale_d.dtype == torch.float32:
             # the crop's box / centre / radius derived on the device from the pose (captra_crop_box): no round trip for the pose
-            full = full_data_batch_arrays(depth, mask, None, None, gt64, N, stacked=True, pose_dev=(trans_d, scale_d, float(self.radius)), gt_dev=gtd)
+            full = full_data_batch_arrays(depth, mask, None, None, gt64, N, stacked=True, pose_dev=(trans_d, scale_d, float(self.radius)), gt_dev=gtd,
+                                          defer=defer, mean=npcs["points_mean"][sl])
+            if defer is not None:
+                return full["points_cn"], full["labels"], full["nocs_cn"], full["_info"]
         else:
+            defer = None
             cs = to_host(torch.cat([trans_d, scale_d.reshape(b, 1)], dim=1).double())
             full = full_data_batch_arrays(depth, mask, cs[:, :3], self.radius * cs[:, 3], gt64, N, stacked=True)
         points = (full["points"].float() - npcs["points_mean"][sl].reshape(b, 1, 3)).transpose(1, 2).contiguous()
         return points, full["labels"].contiguous(), full["nocs"].float().transpose(1, 2).contiguous()
 
-    def _recrop(self, i, input, last_pose):
-        """The whole batch of frame i re-cropped in place (input / npcs feed dicts)."""
+    def _recrop(self, i, input, last_pose, defer=None):
+        """The whole batch of frame i re-cropped in place (input / npcs feed dicts); -> the deferred check's device word or None."""
         npcs = self.npcs_feed_dict[i]
-        input["points"], input["labels"], npcs["nocs"] = self._recrop_slice(i, input, last_pose, slice(None))
+        res = self._recrop_slice(i, input, last_pose, slice(None), defer=defer)
+        input["points"], input["labels"], npcs["nocs"] = res[:3]
         npcs["points"], npcs["labels"] = input["points"], input["labels"]
+        return res[3] if len(res) > 3 else None
+
+    def _otf_defer_usable(self, input) -> bool:
+        """The re-crop without its round trip: pose on the device, no per-frame hook that publishes a frame's pose at once (the
+        distributed harness's exchange: a frame that is run again a frame later would already be out)."""
+        return (OTF_DEFER and OTF_POSE_ON_DEVICE and self.nocs_otf and input["points"].is_cuda and not self.training
+                and self.frame_hook is None)
 
     # ---- nocs_otf at batch >= 32: two lanes of trajectories, half a frame apart ------------------------------------------
     def _otf_lanes_usable(self, input) -> bool:
@@ -452,38 +498,50 @@ class EvalTrackModel(BaseModel):
         for st in streams:
             st.wait_stream(cur)
         pred_poses, npcs_pred = [pose0], [None]
-        sampled = None      # recorded on a lane's stream when its re-crop (crop + sampling launch) of the current frame is enqueued
-        for i in range(1, len(feed)):
-            input, npcs_in = feed[i], self.npcs_feed_dict[i]
-            frame_nums.append([p.split(".")[-2].split("/")[-1] for p in input["meta"]["path"]])
-            consume_noise_draws(feed[i - 1]["gt_part"], self.pose_perturb_cfg)
-            parts, done = [], []
+        state = {"sampled": None}      # recorded on a lane's stream when its re-crop (crop + sampling launch) of the current frame is enqueued
+        N = feed[1]["points"].shape[2]
+        defer_ok = self._otf_defer_usable(feed[1])
+
+        def run_frame(i, poses_in, bounds):
+            """Frame i of both lanes from the poses entering it; bounds[l] = the sync-free re-crop's stride bound of lane l or None
+            (the synchronous stage).  -> (parts, events, poses out, deferred checks)."""
+            input = feed[i]
+            parts, done, poses_out, checks = [], [], [], []
             for l, s in enumerate(slices):
-                if sampled is not None:
-                    # the other lane's sampling of ITS current frame is over before this lane starts to sample: the two
-                    # samplers never share the chip (each runs under the other lane's networks), whatever phase the lanes
-                    # would drift into by themselves.  The host has nothing else to do meanwhile.
-                    sampled.synchronize()
                 with torch.cuda.stream(streams[l]):
-                    pts, labels, nocs = self._recrop_slice(i, input, lane_pose[l], s)
-                    sampled = torch.cuda.Event()
-                    sampled.record(streams[l])
+                    if state["sampled"] is not None:
+                        # the other lane's sampling of ITS current frame is over before this lane starts to sample: the two
+                        # samplers never share the chip (each runs under the other lane's networks), whatever phase the lanes
+                        # would drift into by themselves.  A GPU-side wait: the host goes on enqueuing.
+                        if bounds[l] is not None:
+                            streams[l].wait_event(state["sampled"])
+                        else:
+                            state["sampled"].synchronize()
+                    res = self._recrop_slice(i, input, poses_in[l], s, defer=bounds[l])
+                    pts, labels, nocs = res[:3]
+                    checks.append(_OtfCheck(res[3]) if len(res) > 3 and res[3] is not None else None)
+                    state["sampled"] = torch.cuda.Event()
+                    state["sampled"].record(streams[l])
                     mean = input["points_mean"][s]
                     if graphs is not None:
-                        out = graphs[l].replay(pts, mean, lane_pose[l])
+                        out = graphs[l].replay(pts, mean, poses_in[l])
                         pose = {k: v.clone() for k, v in out.items()}
                         cur_npcs = {k: v.clone() for k, v in graphs[l].npcs_pred.items() if torch.is_tensor(v)}
                     else:
                         lin = {"points": pts, "points_mean": mean, "meta": {}, "labels": labels}
                         lnp = {"points": pts, "points_mean": mean, "labels": labels}
-                        cur_npcs, pose = self.track_step(lin, lnp, lane_pose[l])
+                        cur_npcs, pose = self.track_step(lin, lnp, poses_in[l])
                         cur_npcs = {k: v for k, v in cur_npcs.items() if torch.is_tensor(v)}
-                    lane_pose[l] = pose
+                    poses_out.append(pose)
                     ev = torch.cuda.Event()
                     ev.record(streams[l])
                 parts.append((pts, labels, nocs, pose, cur_npcs))
                 done.append(ev)
-            # the frame's batch-wide tensors, assembled on the caller's stream (GPU-side waits: the lanes do not stop)
+            return parts, done, poses_out, checks
+
+        def commit(i, parts, done, replace):
+            """The frame's batch-wide tensors, assembled on the caller's stream (GPU-side waits: the lanes do not stop)."""
+            input, npcs_in = feed[i], self.npcs_feed_dict[i]
             for ev in done:
                 cur.wait_event(ev)
             for part in parts:
@@ -497,10 +555,41 @@ class EvalTrackModel(BaseModel):
             npcs_in["nocs"] = torch.cat([p[2] for p in parts])
             npcs_in["points"], npcs_in["labels"] = input["points"], input["labels"]
             pose = {k: torch.cat([p[3][k] for p in parts]) for k in parts[0][3]}
-            npcs_pred.append({k: torch.cat([p[4][k] for p in parts]) for k in parts[0][4]})
-            pred_poses.append(pose)
+            npcs = {k: torch.cat([p[4][k] for p in parts]) for k in parts[0][4]}
+            if replace:
+                npcs_pred[i], pred_poses[i] = npcs, pose
+            else:
+                npcs_pred.append(npcs)
+                pred_poses.append(pose)
+            return pose
+
+        bounds = [OTF_FIRST_BOUND * N if defer_ok else None] * len(slices)
+        pending = None                  # (frame, poses that entered it, its deferred checks)
+        for i in range(1, len(feed)):
+            frame_nums.append([p.split(".")[-2].split("/")[-1] for p in feed[i]["meta"]["path"]])
+            consume_noise_draws(feed[i - 1]["gt_part"], self.pose_perturb_cfg)
+            if pending is not None:
+                pi, pin, checks = pending
+                pending = None
+                verdicts = [c.read() for c in checks if c is not None]
+                if any(r for r, _ in verdicts):
+                    # a rare-path instance in the previous frame: that frame once more, both lanes, on the synchronous stage
+                    parts, done, lane_pose, _ = run_frame(pi, pin, [None] * len(slices))
+                    commit(pi, parts, done, replace=True)
+                elif verdicts:
+                    bounds = [_otf_bound(longest, N) for _, longest in verdicts]
+            poses_in = lane_pose
+            parts, done, lane_pose, checks = run_frame(i, poses_in, bounds)
+            pose = commit(i, parts, done, replace=False)
+            if any(c is not None for c in checks):
+                pending = (i, poses_in, checks)
             if self.frame_hook is not None:
                 self.frame_hook(i, pose)
+        if pending is not None:
+            pi, pin, checks = pending
+            if any(c.read()[0] for c in checks if c is not None):
+                parts, done, lane_pose, _ = run_frame(pi, pin, [None] * len(slices))
+                commit(pi, parts, done, replace=True)
         for st in streams:
             cur.wait_stream(st)
         return pred_poses, npcs_pred
@@ -524,6 +613,7 @@ class EvalTrackModel(BaseModel):
         with torch.no_grad():
             if len(self.feed_dict) > 1 and self._lanes_usable(self.feed_dict[1]):
                 lanes = self._lanes_for(self.feed_dict[1], pred_poses[0])
+            pending, bound = None, OTF_FIRST_BOUND * self.feed_dict[0]["points"].shape[2]
             for i, input in enumerate(self.feed_dict):
                 frame_nums.append([p.split(".")[-2].split("/")[-1] for p in input["meta"]["path"]])
                 if i == 0:
@@ -540,17 +630,34 @@ class EvalTrackModel(BaseModel):
                 # the reference draws (and discards) a perturbed pose every frame (model.py:414);
                 # draw it too so that seeded runs consume the generator identically
                 consume_noise_draws(self.feed_dict[i - 1]["gt_part"], self.pose_perturb_cfg)
-                last_pose = {k: v.clone() for k, v in pred_poses[-1].items()}
-                if self.nocs_otf:
-                    self._recrop(i, input, last_pose)
-                if self._graph_usable(input):
-                    cur_npcs, pose = self._graph_step(input, last_pose)
-                else:
-                    cur_npcs, pose = self.track_step(input, self.npcs_feed_dict[i], last_pose)
+                def run(fi, finput, defer):
+                    lp = {k: v.clone() for k, v in pred_poses[fi - 1].items()}
+                    info = self._recrop(fi, finput, lp, defer=defer) if self.nocs_otf else None
+                    if self._graph_usable(finput):
+                        out = self._graph_step(finput, lp)
+                    else:
+                        out = self.track_step(finput, self.npcs_feed_dict[fi], lp)
+                    return out, info
+
+                if pending is not None:
+                    # the PREVIOUS frame's deferred verdict: a rare-path instance -> that frame once more, synchronously
+                    rare, longest = pending.read()
+                    pending = None
+                    if rare:
+                        (npcs_pred[i - 1], pred_poses[i - 1]), _ = run(i - 1, self.feed_dict[i - 1], None)
+                    else:
+                        bound = _otf_bound(longest, input["points"].shape[2])
+                defer = bound if (self.nocs_otf and self._otf_defer_usable(input)) else None
+                (cur_npcs, pose), info = run(i, input, defer)
+                if info is not None:
+                    pending = _OtfCheck(info)
                 npcs_pred.append(cur_npcs)
                 pred_poses.append(pose)
                 if self.frame_hook is not None:
                     self.frame_hook(i, pose)
+            if pending is not None and pending.read()[0]:
+                last = len(self.feed_dict) - 1
+                (npcs_pred[last], pred_poses[last]), _ = run(last, self.feed_dict[last], None)
         self.pred_dict = {"poses": pred_poses, "npcs_pred": npcs_pred}
         self.check_l1_stream()
         if save:

@@ -240,15 +240,29 @@ def _intrinsics_on_device(intrinsics, dev) -> torch.Tensor:
     return _KMAT_DEV[key]
 
 
+_ARANGE: dict = {}
+
+
+def _arange(n: int, dev) -> torch.Tensor:
+    key = (n, str(dev))
+    if key not in _ARANGE:
+        _ARANGE[key] = torch.arange(n, device=dev)
+    return _ARANGE[key]
+
+
 def full_data_batch_arrays(depth, mask, centers, radii_in, gt, num_points: int, intrinsics=NOCS_REAL_INTRINSICS, stacked: bool = True,
-                           pose_dev=None, gt_dev=None):
+                           pose_dev=None, gt_dev=None, defer=None, mean=None):
     """full_data_batch on already-stacked inputs (the track loop's form: no per-trajectory Python on the frame's critical
     path): depth (B,H,W), mask (B,H,W) device tensors; centers (B,3), radii_in (B,) float64 host arrays (radius as handed to
     full_data_from_depth: clamped to 0.05 inside); gt = {'rotation' (B,3,3), 'translation' (B,3), 'scale' (B,)} float64 host arrays.
     `pose_dev` = (translation (B,3) fp32, scale (B,) fp32, radius_factor) ON THE DEVICE instead of centers / radii_in (pass None
     for both): the crop's box, centre and radius are then derived there (captra_crop_box: the same float64 operations) and the
     pose never visits the host -- the stage's ONE round trip is the member counts.  `gt_dev`: the same three arrays as float64 DEVICE
-    tensors (uploaded once with the trajectory), used instead of three uploads per frame."""
+    tensors (uploaded once with the trajectory), used instead of three uploads per frame.
+    `defer` (with pose_dev; an int = upper bound of the candidate lists' length): NO round trip at all -- see the branch below; the
+    result is then {'points_cn' (B,3,N) fp32 = points - `mean` (B,3), 'labels' (B,N), 'nocs_cn' (B,3,N) fp32, '_info'}: the
+    frame's tensors in the networks' layouts (captra_otf_finish) and the device int32 word [a rare-path instance was met, longest
+    list, ..] for the caller to read a frame late."""
     from . import _lib as L, fused
     dev = depth.device
     B = depth.shape[0]
@@ -288,6 +302,36 @@ def full_data_batch_arrays(depth, mask, centers, radii_in, gt, num_points: int, 
         with torch.cuda.device(dev):
             L.call("captra_crop_ball", B, H, W, CROP_CAP, L.ptr(depth), L.ptr(mask), hp + 8 * ndbl, hp,
                    hp + 8 * 3 * B, hp + 8 * 4 * B, L.ptr(pts), L.ptr(obj), L.ptr(pix), L.ptr(counts))
+    if defer is not None and pose_dev is not None:
+        # ---- NO round trip: the candidate lists' lengths, the member table and the ragged sampler's
+        # per-cloud counts are derived from the crop's counts ON THE DEVICE; the sampler's padded stride is an upper bound the
+        # caller knows without them (`defer` = that bound: the previous frame's longest list with a margin, at most 5 N).  What
+        # the host would have decided from the counts -- an instance on a rare path (< 10 members: radius growth; a list longer
+        # than the bound or than 5 N: thinning, which draws from numpy's generator on the host) -- comes back as a device word
+        # [any rare instance, longest list] the caller reads one frame LATE and, when set, answers by running the frame again on
+        # the synchronous path below.  Rare rows are clamped so that every launch stays inside its buffers; their output is unused.
+        stride = int(min(max(int(defer), num_points), 5 * num_points))
+        cand = torch.empty(B, stride, 3, dtype=torch.float32, device=dev)
+        lens = torch.empty(B, dtype=torch.int32, device=dev)
+        info = torch.empty(4, dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            L.call("captra_otf_candidates", B, CROP_CAP, stride, num_points, L.ptr(pts), L.ptr(counts), L.ptr(cand), L.ptr(lens), L.ptr(info))
+        res = fused.fps_gather(cand, num_points, n_per_cloud=lens)
+        if gt_dev is not None:
+            rot, trans, scale = (gt_dev["rotation"].reshape(B, 3, 3).contiguous(), gt_dev["translation"].reshape(B, 3).contiguous(),
+                                 gt_dev["scale"].reshape(B).contiguous())
+        else:
+            rot = to_device(np.ascontiguousarray(np.asarray(gt["rotation"], np.float64).reshape(B, 3, 3)), dev)
+            trans = to_device(np.ascontiguousarray(np.asarray(gt["translation"], np.float64).reshape(B, 3)), dev)
+            scale = to_device(np.ascontiguousarray(np.asarray(gt["scale"], np.float64).reshape(B)), dev)
+        mean_d = (torch.zeros(B, 3, dtype=torch.float32, device=dev) if mean is None else mean.reshape(B, 3).float().contiguous())
+        points_cn = torch.empty(B, 3, num_points, dtype=torch.float32, device=dev)
+        labels = torch.empty(B, num_points, dtype=torch.int64, device=dev)
+        nocs_cn = torch.empty(B, 3, num_points, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            L.call("captra_otf_finish", B, CROP_CAP, stride, num_points, L.ptr(pts), L.ptr(obj), L.ptr(counts), L.ptr(res[0]), L.ptr(mean_d),
+                   L.ptr(rot), L.ptr(trans), L.ptr(scale), L.ptr(points_cn), L.ptr(labels), L.ptr(nocs_cn))
+        return {"points_cn": points_cn, "labels": labels, "nocs_cn": nocs_cn, "_info": info}
     n_members = to_host(counts[:, 0].contiguous())                                               # the one sync of the stage
     if pose_dev is not None and any(int(c) < 10 or int(c) > CROP_CAP for c in n_members):
         # a rare-path instance (radius growth / more members than the table holds) takes the torch path, which wants the centre on the host

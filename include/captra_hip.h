@@ -412,6 +412,18 @@ int captra_crop_ball(int b, int h, int w, int cap, const int *depth, const unsig
  * with numpy's operation order and int32 truncation.  What captra_crop_ball reads: no host round trip between the pose and the crop. */
 int captra_crop_box(int b, int h, int w, double radius_factor, const float *trans, const float *scale, const double *kmat, int *box,
                     double *center, double *radius, captra_stream_t stream);
+/* The rest of the re-crop without the host (csrc/crop.hip; reference nocs_data_process.py:92-109, 43-50, 227-236): the candidate
+ * lists of the crops (member table repeated until >= num_points entries) as the sampler's fp32 input with their lengths, from the
+ * DEVICE-resident member counts of captra_crop_ball -- cand (B,stride,3), lens (B,) for captra_fps_gather_ragged, info[4] (zeroed
+ * by the call): [0] != 0 when an instance is on a rare path (< 10 members: the crop's radius grows; a list longer than stride <= 5
+ * num_points: thinning by the host's generator) whose frame the caller runs again with the host in the loop, [1] = longest list --
+ * and the sampler's picks turned into the frame's tensors in the networks' layouts: points - mean (B,3,n) fp32, labels (B,n)
+ * int64, ground-truth NOCS (B,3,n) fp32 of the object's points (float64 arithmetic, rot (B,3,3), trans (B,3), scale (B,) float64). */
+int captra_otf_candidates(int b, int cap, int stride, int num_points, const double *pts, const int *counts, float *cand, int *lens,
+                          int *info, captra_stream_t stream);
+int captra_otf_finish(int b, int cap, int stride, int n, const double *pts, const unsigned char *obj, const int *counts,
+                      const int *picks, const float *mean, const double *rot, const double *trans, const double *scale,
+                      float *points_cn, long long *labels, float *nocs_cn, captra_stream_t stream);
 
 /* Ragged batch of the same operation: the clouds are padded to n_stride points each (xyz (B,n_stride,3)) and cloud i
  * samples m of its FIRST n_per_cloud[i] points (device array of B ints, 1 <= n_per_cloud[i] <= n_stride; NULL = all

@@ -273,6 +273,54 @@ def test_track_loop_otf_vs_reference_loop_golden(device, tag, hipgraph):
             np.testing.assert_allclose(pose[key].cpu().numpy(), G15[f"{tag}_{i}_{key}"], atol=1e-4, rtol=0, err_msg=f"{key} of frame {i}")
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["deferred", "lanes_deferred", "every_frame_rare", "lanes_every_frame_rare"])
+def test_track_loop_otf_deferred_check_replays_rare_frames(device, mode, monkeypatch):
+    """The re-crop without a host round trip (captra_amd/model.py _OtfCheck: the member counts stay on the device, the verdict
+    'a rare-path instance was met' is read one frame late) against the SYNCHRONOUS stage (CAPTRA_OTF_DEFER off: what golden G15
+    pins) from the same start, bit for bit, in two regimes: as shipped, and with a stride bound so small that EVERY frame's lists
+    outgrow it -- every frame is flagged, read a frame late and run again on the synchronous stage, the last one after the loop --
+    for the single-batch loop and for the two lanes.  A replayed frame leaves nothing of its first run behind."""
+    import captra_amd.model as M
+    from captra_amd.configs import make_config
+    from captra_amd.synthetic import OTF_LOOP_SETUPS, make_otf_trajectory, make_physical_state_dict
+    from captra_amd.trainer import Trainer
+    lanes = mode.startswith("lanes")
+    reads = []
+    orig = M._OtfCheck.read
+    monkeypatch.setattr(M._OtfCheck, "read", lambda self: (reads.append(orig(self)), reads[-1])[1])
+    if mode.endswith("rare"):
+        monkeypatch.setattr(M, "_otf_bound", lambda longest, n: n)          # 4096: every ~15 k list is "rare"
+        monkeypatch.setattr(M, "OTF_FIRST_BOUND", 1)
+    tags = ["a", "b"]
+    setups = [OTF_LOOP_SETUPS[t] for t in tags]
+    frames, wseed = setups[0][0], setups[0][2]
+    cfg = make_config("1", experiment_dir="/tmp/captra_otf_defer_test", nocs_otf=True, hipgraph=True)
+    cfg["device"] = device
+    cfg["init_frame"]["gt"] = True
+    trainer = Trainer(cfg)
+    model = trainer.model
+    model.load_state_dict(make_physical_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, wseed, 1, True, "nocs"))
+    reps = 16 if lanes else 1
+    parts = [make_otf_trajectory(1, frames, seed=s[1]) for s in setups for _ in range(reps)] if lanes else [make_otf_trajectory(1, frames, seed=setups[0][1])]
+    data = _cat_trajectories(parts) if len(parts) > 1 else parts[0]
+    model.otf_lanes = lanes
+    torch.manual_seed(setups[0][3]); np.random.seed(setups[0][3])
+    pred, _ = trainer.test(data, save=False, no_eval=True)
+    assert len(reads) >= frames - 1                        # every frame's verdict was read ...
+    assert all(r for r, _ in reads) == mode.endswith("rare") and any(r for r, _ in reads) == mode.endswith("rare")   # ... and said what the regime implies
+    # the same loop on the synchronous stage from the same start is the comparand (init_frame.gt: no seeded noise in the start pose)
+    monkeypatch.setattr(M, "OTF_DEFER", False)
+    clouds = [model.feed_dict[i]["points"].clone() for i in range(1, frames)]
+    torch.manual_seed(setups[0][3]); np.random.seed(setups[0][3])
+    data2 = _cat_trajectories([make_otf_trajectory(1, frames, seed=s[1]) for s in setups for _ in range(reps)]) if lanes else make_otf_trajectory(1, frames, seed=setups[0][1])
+    pred2, _ = trainer.test(data2, save=False, no_eval=True)
+    for i in range(1, frames):
+        assert torch.equal(clouds[i - 1], model.feed_dict[i]["points"]), f"cloud of frame {i}"
+        for key in ("rotation", "translation", "scale"):
+            assert torch.equal(pred["poses"][i][key], pred2["poses"][i][key]), (key, i)
+
+
 def _cat_trajectories(parts):
     """Concatenate single-trajectory frame lists (captra_amd.synthetic.make_otf_trajectory(1, ...)) along the batch axis."""
     out = []
