@@ -69,6 +69,9 @@ _SIGNATURES = {
     "captra_sa_scale_bf16": [_INT] * 9 + [_P] * 6 + [_INT, _INT, _P],
     "captra_pack_sa_x6": [_INT] * 4 + [_P] * 6 + [_P],
     "captra_sa_scales_multi": [_INT, _P, _P, _P],
+    "captra_pack_chain_x6": [_INT, _INT, _INT, _INT, _LL, _LL, _P, _P, _P, _P],
+    "captra_mlp_chain3_x6": [_INT, _INT, _LL, _P, _P, _INT, _P, _P],
+    "captra_coord_tail_x6": [_INT, _INT, _INT, _INT, _LL, _P, _P, _INT, _P, _P, _P],
     "captra_pack_dense_x6": [_INT, _INT, _P, _P, _P],
     "captra_pointwise_mlp_x6": [_INT, _INT, _INT, _LL, _P, _P, _P, _P, _INT, _P, _P, _INT, _P],
     "captra_sa_scale_x6": [_INT] * 9 + [_P] * 7 + [_INT, _INT, _P],

@@ -80,7 +80,7 @@ MAX_ILP = ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]
 # instructions it replaces (MI355X_MICROARCH.md "price of one filler beside MFMAs"); the operand split is written on scalars on purpose
 NO_SLP = ["-fno-slp-vectorize"]
 PER_SOURCE_FLAGS = {"sa_fused.hip": MAX_ILP, "mlp_chain.hip": MAX_ILP, "fps.hip": MAX_ILP, "sa_bf16.hip": MAX_ILP, "sa_x6.hip": NO_SLP,
-                    "dense_x6.hip": NO_SLP}
+                    "dense_x6.hip": NO_SLP, "chain_x6.hip": NO_SLP}
 
 
 def _compile_one(src: Path, force: bool, verbose: bool) -> Path:

@@ -1010,6 +1010,8 @@ def mlp_chain3(x, layers, act3: int = ACT_RELU):
     # under split_k with few positions: three split-k launches (each fills the chip) instead of the one-launch chain, whose waves own
     # 32 positions each -- 128 waves for one 4096-point cloud, every one a serial chain of the three layers (49 -> ~25 us)
     few = _split_k_active() and B * l <= SPLIT_K_POSITIONS
+    if not few and chain_x6_supported(shape[0], [lin.cout for lin in layers], B * l):
+        return mlp_chain3_x6(x, layers, act3)
     if few or not (USE_MLP_CHAIN and exact_path() and shape in _CHAIN3_SHAPES and shape[0] * l * 4 < (1 << 31)):
         y = pointwise_mlp(x, layers[0], ACT_RELU)
         y = pointwise_mlp(y, layers[1], ACT_RELU)
@@ -1029,9 +1031,55 @@ USE_COORD_TAIL = True
 _COORD_TAIL_SHAPES = {(134, 2, 3), (134, 4, 12), (134, 3, 9), (134, 2, 6)}   # csrc/mlp_chain.hip TAIL_CASE list
 
 
+USE_CHAIN_X6 = os.environ.get("CAPTRA_CHAIN_X6", "1") != "0"
+CHAIN_X6_MIN_POSITIONS = 16384        # below: the exact kernels (a chain wave owns 32 positions: few positions leave the chip idle either way)
+
+
+def chain_x6_supported(c0: int, widths, positions: int) -> bool:
+    """The f32x6 chain kernels (csrc/chain_x6.hip): c0 in {131, 134} -> 128 -> 128 -> 128 [+ the CoordinateNet heads]."""
+    return (USE_CHAIN_X6 and mlp_dtype() == "f32x6" and c0 in (131, 134) and positions >= CHAIN_X6_MIN_POSITIONS
+            and all(w == 128 for w in widths[:3]))
+
+
+def chain_x6_image(layers) -> torch.Tensor:
+    """The weight image of a chain for captra_mlp_chain3_x6 / captra_coord_tail_x6 (every layer's split fragment triples, then 128
+    fp32 bias slots per layer), built once on the device and cached with the chain's first layer."""
+    key = ("chain_x6_img",) + tuple(id(lin) for lin in layers[1:])
+    cache = layers[0]._bf16
+    if key not in cache:
+        nl = len(layers)
+        cin = (C.c_int * nl)(*[lin.cin for lin in layers])
+        cout = (C.c_int * nl)(*[lin.cout for lin in layers])
+        L.lib().captra_chain_x6_image_bytes.restype = C.c_longlong
+        nbytes = L.lib().captra_chain_x6_image_bytes(nl, cin, cout)
+        frag_total = nbytes - nl * 128 * 4
+        img = torch.empty(nbytes, dtype=torch.uint8, device=layers[0].wt.device)
+        off = 0
+        with torch.cuda.device(img.device):
+            for i, lin in enumerate(layers):
+                L.call("captra_pack_chain_x6", i, lin.cin, lin.cout, 1 if i == 0 else 0, off, frag_total, L.ptr(lin.wt), L.ptr(lin.bias), L.ptr(img))
+                off += ((lin.cout + 31) // 32) * ((((lin.cin + 15) // 16) * 3 + 3) // 4 * 4) * 1024
+        assert off == frag_total
+        cache[key] = (img, list(layers))
+    return cache[key][0]
+
+
+def mlp_chain3_x6(x, layers, act3: int = ACT_RELU):
+    """mlp_chain3 in the f32x6 arithmetic (captra_mlp_chain3_x6)."""
+    B, c0 = x.shape[:2]
+    l = x.numel() // max(B * c0, 1)
+    img = chain_x6_image(layers)
+    L.require_device(x)
+    out = torch.empty((B, 128) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        L.call("captra_mlp_chain3_x6", B, c0, l, L.ptr(x), L.ptr(img), act3, L.ptr(out))
+    _work("mlp_chain3", flops=2.0 * B * l * (c0 * 128 + 2 * 128 * 128), nbytes=4.0 * B * l * (c0 + 128))
+    return out
+
+
 def coord_tail_supported(x, layers) -> bool:
     """layers = [fp1a, fp1b, conv1, seg, nocs hidden, nocs out] (PackedLinear)."""
-    if not (USE_COORD_TAIL and exact_path() and len(layers) == 6):
+    if not (USE_COORD_TAIL and (exact_path() or mlp_dtype() == "f32x6") and len(layers) == 6):
         return False
     l = x.numel() // max(x.shape[0] * x.shape[1], 1)
     widths_ok = all(lin.cout == 128 for lin in (layers[0], layers[1], layers[2], layers[4])) and all(lin.cin == 128 for lin in layers[1:])
@@ -1046,6 +1094,12 @@ def coord_tail(x, layers, nocs_act: int = ACT_SIGMOID_M05):
     l = x.numel() // max(B * c0, 1)
     seg = torch.empty((B, layers[3].cout) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
     nocs = torch.empty((B, layers[5].cout) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+    if chain_x6_supported(c0, [lin.cout for lin in layers], B * l) and not _split_k_active():
+        img = chain_x6_image(layers)
+        with torch.cuda.device(x.device):
+            L.call("captra_coord_tail_x6", B, c0, layers[3].cout, layers[5].cout, l, L.ptr(x), L.ptr(img), nocs_act, L.ptr(seg), L.ptr(nocs))
+        _work("coord_tail", flops=2.0 * B * l * sum(lin.cin * lin.cout for lin in layers), nbytes=4.0 * B * l * (c0 + layers[3].cout + layers[5].cout))
+        return seg, nocs
     wp = (ctypes.c_void_p * 6)(*[lin.wt.data_ptr() for lin in layers])
     bp = (ctypes.c_void_p * 6)(*[lin.bias.data_ptr() for lin in layers])
     with torch.cuda.device(x.device):

@@ -313,6 +313,17 @@ int captra_pointwise_mlp_x6_tiles(long long l);
 int captra_pointwise_mlp_x6(int b, int cin, int cout, long long l, const float *x, const unsigned char *wimg, const float *bias_packed,
                             const float *ab_in, int act, float *y, float *stats_out, int stats_t, captra_stream_t stream);
 
+/* f32x6 dense CHAINS (csrc/chain_x6.hip): captra_mlp_chain3 / captra_coord_tail in the f32x6 arithmetic, c0 in {131, 134} -> 128 -> 128
+ * -> 128 [-> seg_dim; -> 128 -> nocs_dim].  img: captra_chain_x6_image_bytes(nl, cin[], cout[]) bytes, filled layer by layer with
+ * captra_pack_chain_x6(l, cin, cout, natural = (l == 0), frag_off = bytes of the fragments of the layers before l, total_frag_bytes,
+ * the layer's packed fp32 weights and bias) -- split fragment triples of every layer, then 128 fp32 bias slots per layer. */
+long long captra_chain_x6_image_bytes(int nl, const int *cin, const int *cout);
+int captra_pack_chain_x6(int l, int cin, int cout, int natural, long long frag_off, long long total_frag_bytes, const float *wt_packed,
+                         const float *bias_packed, unsigned char *img, captra_stream_t stream);
+int captra_mlp_chain3_x6(int b, int c0, long long l, const float *x, const unsigned char *img, int act3, float *y, captra_stream_t stream);
+int captra_coord_tail_x6(int b, int c0, int seg_dim, int nocs_dim, long long l, const float *x, const unsigned char *img, int nocs_act,
+                         float *seg, float *nocs, captra_stream_t stream);
+
 /* bf16-NATIVE dense layers (csrc/dense_bf16.hip): activations in HBM as bf16, POINT-major (B,L,ceil32(C)), channels in SLOT
  * ORDER (inside every aligned block of 16 channels memory slot s holds channel perm[s] = {0,1,2,3,8,9,10,11,4,5,6,7,12,13,14,15},
  * the order in which a 32x32 MFMA accumulator tile hands its rows to a lane; padding channels are zero).  Same per-layer

@@ -104,3 +104,48 @@ def test_dense_x6_vs_exact_chain(device, cin, cout, L, B, gn_in, stats):
     with fused.use_mlp_dtype("f32x6"):
         relu = fused.pointwise_mlp_gn(xd, lin, abd, fused.ACT_RELU).cpu().numpy()
     np.testing.assert_array_equal(relu, np.maximum(got, 0))
+
+
+@pytest.mark.parametrize("c0,B,l,act3", [(131, 8, 4096, 1), (134, 8, 4096, 1), (131, 3, 11000, 0), (134, 33, 1000, 1)])
+def test_mlp_chain3_x6_vs_exact_chain(device, c0, B, l, act3):
+    """FP1's shared MLP + conv1 as one f32x6 launch (csrc/chain_x6.hip: every layer incl. the 131 / 134-channel first one on six
+    bf16 MFMAs per k-step, activations in registers, weights round an LDS ring) == the oracle's exact chain within 2e-6 of the
+    largest output: full and ragged slices, a slice count that does not fill a workgroup's four waves."""
+    from captra_amd import fused
+    rng = np.random.default_rng(c0 + l + B)
+    x = rng.standard_normal((B, c0, l)).astype(np.float32)
+    dims = (c0, 128, 128, 128)
+    layers = [((rng.standard_normal((dims[i], dims[i + 1])) / np.sqrt(dims[i])).astype(np.float32),
+               rng.standard_normal(dims[i + 1]).astype(np.float32)) for i in range(3)]
+    packed = [fused.pack(_dev(w, device), _dev(b, device)) for w, b in layers]
+    with fused.use_mlp_dtype("f32x6"):
+        assert fused.chain_x6_supported(c0, [128, 128, 128], B * l)
+        got = fused.mlp_chain3(_dev(x, device), packed, act3).cpu().numpy()
+    ref = x
+    for i, (w, b) in enumerate(layers):
+        ref = O.pointwise_mlp(ref, w, b, 1 if i < 2 else act3)
+    err = _rel(got, ref)
+    assert err <= X6_TOL, err
+
+
+@pytest.mark.parametrize("seg_dim,nocs_dim,B,l", [(2, 3, 8, 4096), (4, 12, 9, 4000), (2, 6, 33, 1000)])
+def test_coord_tail_x6_vs_exact_chain(device, seg_dim, nocs_dim, B, l):
+    """CoordinateNet's tail (FP1 + conv1 + segmentation head + NOCS head: six layers, two stored outputs) as one f32x6 launch ==
+    the oracle's exact layers: logits within 2e-6 of the largest, NOCS coordinates (behind the sigmoid) within 1e-6 absolute."""
+    from captra_amd import fused
+    rng = np.random.default_rng(seg_dim + nocs_dim + l)
+    c0 = 134
+    x = rng.standard_normal((B, c0, l)).astype(np.float32)
+    dims = [(c0, 128), (128, 128), (128, 128), (128, seg_dim), (128, 128), (128, nocs_dim)]
+    layers = [((rng.standard_normal(d) / np.sqrt(d[0])).astype(np.float32), rng.standard_normal(d[1]).astype(np.float32)) for d in dims]
+    packed = [fused.pack(_dev(w, device), _dev(b, device)) for w, b in layers]
+    with fused.use_mlp_dtype("f32x6"):
+        assert fused.coord_tail_supported(_dev(x, device), packed) and fused.chain_x6_supported(c0, [128] * 3, B * l)
+        seg, nocs = fused.coord_tail(_dev(x, device), packed)
+    feat = x
+    for w, b in layers[:3]:
+        feat = O.pointwise_mlp(feat, w, b, 1)
+    assert _rel(seg.cpu().numpy(), O.pointwise_mlp(feat, layers[3][0], layers[3][1], 0)) <= X6_TOL
+    hid = O.pointwise_mlp(feat, layers[4][0], layers[4][1], 1)
+    raw = O.pointwise_mlp(hid, layers[5][0], layers[5][1], 0)
+    np.testing.assert_allclose(nocs.cpu().numpy(), 1.0 / (1.0 + np.exp(-raw.astype(np.float64))) - 0.5, atol=1e-6, rtol=0)
