@@ -951,7 +951,7 @@ def main():
         mlp = ["sa_scale_fused", "pointwise_mlp", "mlp_chain3", "coord_tail", "sa_group_mlp", "mlp_max", "neck_chain"]
         if args.mlp_dtype == "f32x6":
             # the mode's own kernels (csrc/sa_x6.hip, csrc/dense_x6.hip) against the bf16 peak / 6: six bf16 MFMAs per fp32-equivalent product
-            mlp = ["sa_scale_x6", "pointwise_mlp_x6"]
+            mlp = ["sa_scale_x6", "pointwise_mlp_x6", "mlp_chain3_x6", "coord_tail_x6"]
         mlp_ms = sum(fams[k]["ms_total"] for k in mlp if k in fams)
         mlp_launches = sum(fams[k]["launches"] for k in mlp if k in fams)
         mlp_flops = sum(fused.WORK["flops"].get(k, 0.0) for k in mlp)
@@ -962,13 +962,13 @@ def main():
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                                "frac": round(ach / peak, 4), "traffic": None,
                                "kernel": ("fp32 MFMA shared-MLP family: sa_wave_pipe_kernel (SA2 scales, dominant) + sa_wave_lds_kernel (SA1) + mlp_chain3_kernel + coord_tail_kernel + pw_direct_kernel"
-                                          if args.mlp_dtype == "fp32" else "f32x6 family: sa_x6_kernel (SA1 / SA2 scales) + dense_x6_kernel (rotation heads' 128 -> 512 -> 512 -> 256); fp32-equivalent flops against the bf16 MFMA peak / 6; the layers left on the exact fp32 kernels are not counted" if args.mlp_dtype == "f32x6" else "bf16 MFMA family: sa2_bf16_kernel / sa_bf16_kernel + tb_head12p_kernel / tb_layer_kernel + chain_bf16_kernel + pw_bf16_kernel (the level-1 stream kernel's MLPs are timed with its sampler and not counted here)"),
+                                          if args.mlp_dtype == "fp32" else "f32x6 family: sa_x6_kernel (SA1 / SA2 scales) + dense_x6_kernel (rotation heads' 128 -> 512 -> 512 -> 256) + chain_x6_kernel (FP1 + conv1, CoordinateNet tail); fp32-equivalent flops against the bf16 MFMA peak / 6; the layers left on the exact fp32 kernels are not counted" if args.mlp_dtype == "f32x6" else "bf16 MFMA family: sa2_bf16_kernel / sa_bf16_kernel + tb_head12p_kernel / tb_layer_kernel + chain_bf16_kernel + pw_bf16_kernel (the level-1 stream kernel's MLPs are timed with its sampler and not counted here)"),
                                "avg_launch_us": round(1e3 * mlp_ms / max(mlp_launches, 1), 2),
                                "flops_per_launch": round(mlp_flops / max(mlp_launches, 1)),
                                "share_of_kernel_time": round(mlp_ms / max(total_ms, 1e-9), 3), "dominant_family": dominant}
             # the counter file of THIS configuration (tools/profile_round.sh <tag> <suffix> ...): bf16 / drawers have their own
             sfx = ("_f32x6" if args.mlp_dtype == "f32x6" else "_bf16" if args.mlp_dtype != "fp32" else "") + ("_drawers" if args.category == "drawers" else "")
-            mlp_prefixes = (["sa_x6_kernel", "dense_x6_kernel"] if args.mlp_dtype == "f32x6" else ["sa_bf16_kernel", "sa2_bf16_kernel", "tb_layer_kernel", "tb_head12_kernel", "tb_head12p_kernel", "neck_chain_kernel", "chain_bf16_kernel", "pw_bf16pm_kernel", "pw_bf16pm_affs_kernel", "pw_bf16_kernel"]
+            mlp_prefixes = (["sa_x6_kernel", "dense_x6_kernel", "chain_x6_kernel"] if args.mlp_dtype == "f32x6" else ["sa_bf16_kernel", "sa2_bf16_kernel", "tb_layer_kernel", "tb_head12_kernel", "tb_head12p_kernel", "neck_chain_kernel", "chain_bf16_kernel", "pw_bf16pm_kernel", "pw_bf16pm_affs_kernel", "pw_bf16_kernel"]
                             if args.mlp_dtype != "fp32" else
                             ["sa_wave_kernel", "sa_wave_lds_kernel", "sa_wave_pipe_kernel", "sa_fused_kernel", "mlp_chain3_kernel", "coord_tail_kernel", "pw_direct_kernel", "pw_direct_max_kernel", "pw_mlp_kernel"])
             traffic, src, why = pmc_traffic(mlp_prefixes, sfx)

@@ -1073,7 +1073,7 @@ def mlp_chain3_x6(x, layers, act3: int = ACT_RELU):
     out = torch.empty((B, 128) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
         L.call("captra_mlp_chain3_x6", B, c0, l, L.ptr(x), L.ptr(img), act3, L.ptr(out))
-    _work("mlp_chain3", flops=2.0 * B * l * (c0 * 128 + 2 * 128 * 128), nbytes=4.0 * B * l * (c0 + 128))
+    _work("mlp_chain3_x6", flops=2.0 * B * l * (c0 * 128 + 2 * 128 * 128), nbytes=4.0 * B * l * (c0 + 128))
     return out
 
 
@@ -1098,7 +1098,7 @@ def coord_tail(x, layers, nocs_act: int = ACT_SIGMOID_M05):
         img = chain_x6_image(layers)
         with torch.cuda.device(x.device):
             L.call("captra_coord_tail_x6", B, c0, layers[3].cout, layers[5].cout, l, L.ptr(x), L.ptr(img), nocs_act, L.ptr(seg), L.ptr(nocs))
-        _work("coord_tail", flops=2.0 * B * l * sum(lin.cin * lin.cout for lin in layers), nbytes=4.0 * B * l * (c0 + layers[3].cout + layers[5].cout))
+        _work("coord_tail_x6", flops=2.0 * B * l * sum(lin.cin * lin.cout for lin in layers), nbytes=4.0 * B * l * (c0 + layers[3].cout + layers[5].cout))
         return seg, nocs
     wp = (ctypes.c_void_p * 6)(*[lin.wt.data_ptr() for lin in layers])
     bp = (ctypes.c_void_p * 6)(*[lin.bias.data_ptr() for lin in layers])
