@@ -567,7 +567,6 @@ class EvalTrackModel(BaseModel):
         pending = None                  # (frame, poses that entered it, its deferred checks)
         for i in range(1, len(feed)):
             frame_nums.append([p.split(".")[-2].split("/")[-1] for p in feed[i]["meta"]["path"]])
-            consume_noise_draws(feed[i - 1]["gt_part"], self.pose_perturb_cfg)
             if pending is not None:
                 pi, pin, checks = pending
                 pending = None
@@ -578,6 +577,7 @@ class EvalTrackModel(BaseModel):
                     commit(pi, parts, done, replace=True)
                 elif verdicts:
                     bounds = [_otf_bound(longest, N) for _, longest in verdicts]
+            consume_noise_draws(feed[i - 1]["gt_part"], self.pose_perturb_cfg)      # (after a replay: see forward())
             poses_in = lane_pose
             parts, done, lane_pose, checks = run_frame(i, poses_in, bounds)
             pose = commit(i, parts, done, replace=False)
@@ -627,9 +627,6 @@ class EvalTrackModel(BaseModel):
                     if self.frame_hook is not None:
                         self.frame_hook(i, pred_poses[-1])
                     continue
-                # the reference draws (and discards) a perturbed pose every frame (model.py:414);
-                # draw it too so that seeded runs consume the generator identically
-                consume_noise_draws(self.feed_dict[i - 1]["gt_part"], self.pose_perturb_cfg)
                 def run(fi, finput, defer):
                     lp = {k: v.clone() for k, v in pred_poses[fi - 1].items()}
                     info = self._recrop(fi, finput, lp, defer=defer) if self.nocs_otf else None
@@ -647,6 +644,10 @@ class EvalTrackModel(BaseModel):
                         (npcs_pred[i - 1], pred_poses[i - 1]), _ = run(i - 1, self.feed_dict[i - 1], None)
                     else:
                         bound = _otf_bound(longest, input["points"].shape[2])
+                # the reference draws (and discards) a perturbed pose every frame (model.py:414); draw it too so that seeded runs
+                # consume the generator identically -- AFTER a replay of the previous frame (its thinning permutations come out of
+                # the same numpy generator and precede this frame's draw in the reference's order)
+                consume_noise_draws(self.feed_dict[i - 1]["gt_part"], self.pose_perturb_cfg)
                 defer = bound if (self.nocs_otf and self._otf_defer_usable(input)) else None
                 (cur_npcs, pose), info = run(i, input, defer)
                 if info is not None:
