@@ -81,7 +81,7 @@ struct DxParams {
 
 #define DX_WAIT_VM(N) __builtin_amdgcn_s_waitcnt(((N) & 15) | (((N) >> 4) << 14) | 0x0F70)
 
-template <bool GN_IN, bool STATS>
+template <bool GN_IN, bool STATS, bool TR = true>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void dense_x6_kernel(DxParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -212,7 +212,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         __syncthreads();                                // ... everybody's have, and everybody is done with this stage
     }
 
-    // ---- epilogue: bias, activation, 16-byte stores along the positions; statistics of the raw output --------------------------
+    // ---- epilogue: bias, activation, statistics of the raw output (a lane owns a channel: sums over its own registers) ------------
+    // TR: the tile leaves through LDS so that a store instruction writes whole rows -- 32 lanes x 16 bytes = the 512 contiguous bytes
+    // of a channel's 128 positions, two channels per instruction.  Straight from the accumulators (!TR) a lane's float4 is 4 of its
+    // channel's positions: one instruction = 64 pieces of 16 bytes in 32 different rows, and the layer ran at 1.8 TB/s of stores.
+    // The wave's 32-channel half tile goes to ITS OWN 16.5 KiB of the (now idle) operand stages, rows padded to 132 words: no barrier.
+    constexpr int TR_ROW = 132;
+    float *trw = reinterpret_cast<float *>(smem) + wave * (32 * TR_ROW);
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm) {
         const int ch = DX_TC * cb + 64 * wm + 32 * tm + col;
@@ -231,8 +237,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     s2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
                 }
                 v.x = apply_act(v.x, p.act); v.y = apply_act(v.y, p.act); v.z = apply_act(v.z, p.act); v.w = apply_act(v.w, p.act);
-                *reinterpret_cast<float4 *>(yp + 32 * tn + 8 * q) = v;
+                if constexpr (TR) *reinterpret_cast<float4 *>(trw + col * TR_ROW + 32 * tn + 8 * q + 4 * h) = v;
+                else *reinterpret_cast<float4 *>(yp + 32 * tn + 8 * q) = v;
             }
+        if constexpr (TR) {
+            // (same wave wrote it: LDS operations of a wave complete in order, the compiler's lgkmcnt wait covers the read-after-write)
+            float *yr = p.y + ((size_t)bq * p.cout + DX_TC * cb + 64 * wm + 32 * tm + h) * p.l + p0 + 4 * col;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float4 v = *reinterpret_cast<const float4 *>(trw + (2 * r + h) * TR_ROW + 4 * col);
+                *reinterpret_cast<float4 *>(yr + (size_t)(2 * r) * p.l) = v;
+            }
+        }
         if constexpr (STATS) {
             const auto w1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(s1), __float_as_uint(s1), false, false);
             const auto w2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(s2), __float_as_uint(s2), false, false);
@@ -279,9 +295,10 @@ extern "C" int captra_pointwise_mlp_x6(int b, int cin, int cout, long long l, co
     const long long grid = (long long)b * p.npt * p.ncb;
     if (grid >= (1ll << 31)) return -2;
     const int lds = DX_LDS + cin * 8;
+    static const bool dx_tr = [] { const char *e = getenv("CAPTRA_DX_TR"); return e == nullptr || e[0] != '0'; }();
 #define DX_LAUNCH(GN_, ST_)                                                                                             \
     do {                                                                                                                \
-        auto kern = dense_x6_kernel<GN_, ST_>;                                                                          \
+        auto kern = dx_tr ? dense_x6_kernel<GN_, ST_, true> : dense_x6_kernel<GN_, ST_, false>;                         \
         static CaptraDeviceOnce once;                                                                                   \
         if (once.first_use()) {                                                                                         \
             if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, DX_LDS + 1024 * 8) != hipSuccess) \

@@ -61,6 +61,11 @@ def canonicalize(pts, mean, rot, trans, scale, num_parts: int = 1, want_cn=True,
 
 SPLIT_K_MAX_TRAJECTORIES = int(os.environ.get("CAPTRA_SPLIT_K_TRAJ", "2"))   # 0 = every dense layer the k-ascending chain at every batch
 SPLIT_K_POSITIONS = int(os.environ.get("CAPTRA_SPLIT_K_POSITIONS", "8192"))    # launches of at most this many positions (b * l) split k
+# f32x6 mode, any number of trajectories: the layers that stay on the exact fp32 MFMA (SA3 / FP3 / FP2 / the SA2 pre-transform: 128 ..
+# 512 points per cloud) are single dependent chains of cin / 2 MFMAs per wave, and the mode has no bit-exact contract, so they MAY split
+# k.  Measured (tools/ab_round6.sh, 32 trajectories in two lanes, same box): 3.376 ms off, 3.378 at 2048 positions, 3.40-3.41 at 8192 /
+# 16384 -- the other lane's kernels already fill the chip under those chains and the 32 x 32 split tiles re-read more.  Off.
+X6_SPLIT_K_POSITIONS = int(os.environ.get("CAPTRA_X6_SPLIT_K_POSITIONS", "0"))
 _split_k_on = False          # (kept for readers of the module attribute; the live flag is per thread: _split_k_active())
 
 
@@ -68,20 +73,40 @@ def _split_k_active() -> bool:
     return getattr(_TLS, "split_k_on", False)
 
 
+def _split_k_limit() -> int:
+    """Position limit (b * l) of the split-k form on this thread, 0 outside `split_k`."""
+    return getattr(_TLS, "split_k_limit", 0) if _split_k_active() else 0
+
+
+def split_k_rule(n_traj: int, allow_few: bool = True) -> int:
+    """The position limit a track step of `n_traj` trajectories runs its dense layers under (0 = the k-ascending chain everywhere):
+    SPLIT_K_POSITIONS for one or two trajectories (`allow_few`: not for the lanes of a larger exact-fp32 batch, which must repeat the
+    eager step's bits), X6_SPLIT_K_POSITIONS for every f32x6 step."""
+    if n_traj <= 0 or not exact_path():
+        return 0
+    if allow_few and n_traj <= SPLIT_K_MAX_TRAJECTORIES:
+        return SPLIT_K_POSITIONS
+    return X6_SPLIT_K_POSITIONS if mlp_dtype() == "f32x6" else 0
+
+
 @contextlib.contextmanager
-def split_k(on: bool):
-    """Dense layers launched inside with at most SPLIT_K_POSITIONS positions split k over a workgroup's four waves
+def split_k(on):
+    """Dense layers launched inside with at most `on` positions (True: SPLIT_K_POSITIONS) split k over a workgroup's four waves
     (captra_launch_opts::splitk_positions of every call: a fixed summation order, 1e-5 relative from the bit-exact chain).  The
     track step of one or two trajectories runs under it -- its 128- / 512-point levels are single dependent MFMA chains on an idle
-    chip otherwise.  Re-entrant and per thread (the options are the host layer's, the C library keeps no state)."""
+    chip otherwise -- and every f32x6 step (`split_k_rule`).  Re-entrant and per thread (the options are the host layer's, the C
+    library keeps no state)."""
     prev = _split_k_active()
-    if on and not prev:
+    limit = SPLIT_K_POSITIONS if on is True else int(on or 0)
+    if limit > 0 and not prev:
         _TLS.split_k_on = True
-        with L.launch_options(splitk_positions=SPLIT_K_POSITIONS):
+        _TLS.split_k_limit = limit
+        with L.launch_options(splitk_positions=limit):
             try:
                 yield
             finally:
                 _TLS.split_k_on = False
+                _TLS.split_k_limit = 0
     else:
         yield
 
@@ -1009,7 +1034,7 @@ def mlp_chain3(x, layers, act3: int = ACT_RELU):
         return mlp_chain_bf16(x, layers, [ACT_RELU, ACT_RELU, act3])
     # under split_k with few positions: three split-k launches (each fills the chip) instead of the one-launch chain, whose waves own
     # 32 positions each -- 128 waves for one 4096-point cloud, every one a serial chain of the three layers (49 -> ~25 us)
-    few = _split_k_active() and B * l <= SPLIT_K_POSITIONS
+    few = B * l <= _split_k_limit()
     if not few and chain_x6_supported(shape[0], [lin.cout for lin in layers], B * l):
         return mlp_chain3_x6(x, layers, act3)
     if few or not (USE_MLP_CHAIN and exact_path() and shape in _CHAIN3_SHAPES and shape[0] * l * 4 < (1 << 31)):
@@ -1094,7 +1119,7 @@ def coord_tail(x, layers, nocs_act: int = ACT_SIGMOID_M05):
     l = x.numel() // max(B * c0, 1)
     seg = torch.empty((B, layers[3].cout) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
     nocs = torch.empty((B, layers[5].cout) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
-    if chain_x6_supported(c0, [lin.cout for lin in layers], B * l) and not _split_k_active():
+    if chain_x6_supported(c0, [lin.cout for lin in layers], B * l) and not B * l <= _split_k_limit():
         img = chain_x6_image(layers)
         with torch.cuda.device(x.device):
             L.call("captra_coord_tail_x6", B, c0, layers[3].cout, layers[5].cout, l, L.ptr(x), L.ptr(img), nocs_act, L.ptr(seg), L.ptr(nocs))

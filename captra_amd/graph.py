@@ -105,7 +105,8 @@ class TrackStepGraph:
         self._graphs = [torch.cuda.CUDAGraph() for _ in range(4)]
         state = {}
 
-        few = self.allow_split_k and fused.exact_path() and 0 < len(self.points) <= fused.SPLIT_K_MAX_TRAJECTORIES     # (as EvalTrackModel._track_step)
+        with fused.use_mlp_dtype(m.mlp_dtype):
+            few = fused.split_k_rule(len(self.points), allow_few=self.allow_split_k)     # (as EvalTrackModel._track_step)
 
         def capture(g, pool, fn):
             with torch.cuda.graph(g, pool=pool, stream=cap, capture_error_mode="thread_local"), torch.no_grad(), fused.use_mlp_dtype(m.mlp_dtype), fused.split_k(few):

@@ -207,8 +207,8 @@ class EvalTrackModel(BaseModel):
 
     def _track_step(self, input, npcs_input, last_pose):
         from . import fused
-        few = (not self.training and input["points"].is_cuda and fused.exact_path()
-               and 0 < len(input["points"]) <= fused.SPLIT_K_MAX_TRAJECTORIES and not getattr(self, "_no_split_k", False))
+        few = (fused.split_k_rule(len(input["points"]), allow_few=not getattr(self, "_no_split_k", False))
+               if not self.training and input["points"].is_cuda else 0)
         with fused.split_k(few):
             return self._track_step_body(input, npcs_input, last_pose)
 
