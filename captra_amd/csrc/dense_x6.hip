@@ -6,18 +6,22 @@
 // captra_pointwise_mlp_gn (csrc/pointwise_mlp.hip), whose exact-fp32 kernels this replaces in the opt-in mode.
 //
 // Structure: a 128-position x 256-channel tile per workgroup of FOUR waves, a wave = 128 positions x 64 channels (128 accumulator
-// registers), TWO workgroups per CU (76 KB of LDS each): one workgroup's operand split (70 VALU per wave and k-step), barriers,
-// prologue and store epilogue run under the other's MFMAs -- the first form, one 256 x 256 workgroup of eight waves per CU, left the
-// matrix pipe 54 % busy (profiles/r06a_bench_f32x6_pmc_summary.txt: twice as many wait as active cycles).  k-steps of 16
-// channels through two LDS stages:
-//   weights   24 fragments (8 channel tiles x 3 parts) per k-step, LDS-DMA from the split image (captra_pack_dense_x6), six
-//             pieces per wave;
+// registers), TWO workgroups per CU: one workgroup's operand split (70 VALU per wave and k-step), barriers, prologue and store
+// epilogue run under the other's MFMAs -- the first form, one 256 x 256 workgroup of eight waves per CU, left the matrix pipe 54 % busy
+// (profiles/r06a_bench_f32x6_pmc_summary.txt: twice as many wait as active cycles).  k-steps of 16 channels:
 //   positions every lane loads 8 channels of ONE position (dword loads, a wave = 2 rows x 128 B per instruction), applies the
-//             GroupNorm coefficients + ReLU, splits, and writes three 16-byte fragment slots: the fragment image is lane-linear
-//             both ways, no transposition anywhere.
-// The MFMAs are FLIPPED (positions = rows): a lane owns a channel, so the statistics are sums over its own registers and the
-// output leaves as 16-byte stores along the positions.
+//             GroupNorm coefficients + ReLU, splits, and writes three 16-byte fragment slots of a two-stage LDS buffer: the fragment
+//             image is lane-linear both ways, no transposition anywhere.  The split of k-step kk + 1 runs in four pieces BETWEEN the
+//             MFMA groups of k-step kk (pinned with masked sched_barriers: the scheduler otherwise sinks all of it behind the last MFMA);
+//   weights   a wave's own six fragments (2 channel tiles x 3 parts, from the split image of captra_pack_dense_x6) straight into
+//             REGISTERS, two sets: a k-step runs its two channel tiles one after the other and re-loads each tile's three fragments
+//             with k-step kk + 2's as soon as its 24 MFMAs have issued.  (Until late round 6 they came through LDS by LDS-DMA, two
+//             stages: a k-step's pieces then had ONE k-step of MFMAs to arrive in, waited for in front of the barrier -- 3-10 % slower
+//             per launch, tools/ab_round6.sh; that form remains for cin % 32 != 0 and as CAPTRA_DX_WREG=0.)
+// The MFMAs are FLIPPED (positions = rows): a lane owns a channel, so the statistics are sums over its own registers; the output
+// tile leaves through LDS as whole 512-byte rows.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -79,9 +83,16 @@ struct DxParams {
     int npt, ncb;               // position tiles per cloud, channel blocks
 };
 
+// timing ablations (-DCAPTRA_DX_ABL=n, results wrong): 1 no wait for the k-step's loads, 2 no weight DMA after start-up, 3 no position
+// loads after start-up, 4 neither wait nor barrier
+#ifdef CAPTRA_DX_ABL
+#define DX_ABL CAPTRA_DX_ABL
+#else
+#define DX_ABL 0
+#endif
 #define DX_WAIT_VM(N) __builtin_amdgcn_s_waitcnt(((N) & 15) | (((N) >> 4) << 14) | 0x0F70)
 
-template <bool GN_IN, bool STATS, bool TR = true>
+template <bool GN_IN, bool STATS, bool WREG>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void dense_x6_kernel(DxParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -115,6 +126,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                          :: "s"(dst), "v"(voff16), "s"(wsrc), "s"(soff) : "memory");
         }
+    };
+    // WREG: this wave's six weight fragments of a k-step go straight into registers -- nobody else reads them, and through LDS (two
+    // stages) a k-step's pieces had ONE k-step of MFMAs to arrive in: the kernel ran at the L2 round trip.  Two register sets: a k-step
+    // runs its row tiles one after the other, and each half's three fragments are re-loaded with k-step kk + 2's as soon as its 24
+    // MFMAs have issued (1.5 k-steps ahead of their use)
+    u32x4 wr[WREG ? 2 : 1][2][3];
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *)(p.wimg + (size_t)cb * kst * DX_ASTAGE), 0, kst * DX_ASTAGE, 0x00020000);
+    auto load_w = [&](auto setc, auto tmc, int kk) {
+        constexpr int SET = decltype(setc)::value, TM = decltype(tmc)::value;
+#pragma unroll
+        for (int s3 = 0; s3 < 3; ++s3)
+            wr[WREG ? SET : 0][TM][s3] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, (int)voff16, kk * DX_ASTAGE + ((2 * wm + TM) * 3 + s3) * 1024, 0));
     };
     // this lane's eight channels 16 kk + 8 h + (0..7) of position p0 + 32 wave + col
     const float *xp = p.x + ((size_t)bq * p.cin + 8 * h) * p.l + p0 + 32 * wave + col;
@@ -152,17 +175,53 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         *reinterpret_cast<u32x4 *>(bp + 2048) = f2;
     };
 
+    // WREG: the same in four pieces (two channels each) that a k-step places between its MFMA groups -- staged in one piece at the top
+    // of the k-step, the split was a phase of ~85 instructions no MFMA of this wave covered
+    u32x4 sf0, sf1, sf2;
+    auto stage_piece = [&](auto ic, int kk, int st, const float (&xs)[8]) {
+        constexpr int i = decltype(ic)::value;
+        float v0 = xs[2 * i], v1 = xs[2 * i + 1];
+        if constexpr (GN_IN) {
+            const float4 c = reinterpret_cast<const float4 *>(abt + 2 * (16 * kk + 8 * h))[i];
+            v0 = relu_bits(__builtin_fmaf(c.x, v0, c.y));
+            v1 = relu_bits(__builtin_fmaf(c.z, v1, c.w));
+        }
+        unsigned a0, a1, a2;
+        dx_split2(v0, v1, a0, a1, a2);
+        sf0[i] = a0; sf1[i] = a1; sf2[i] = a2;
+        if constexpr (i == 3) {
+            unsigned char *bp = smem + st * DX_STAGE + DX_ASTAGE + wave * 3072 + lane * 16;
+            *reinterpret_cast<u32x4 *>(bp) = sf0;
+            *reinterpret_cast<u32x4 *>(bp + 1024) = sf1;
+            *reinterpret_cast<u32x4 *>(bp + 2048) = sf2;
+        }
+    };
+
     // ---- prologue -------------------------------------------------------------------------------------------------------------
     if constexpr (GN_IN) {
         const float *src = p.ab + (size_t)bq * p.cin * 2;
         for (int e = tid; e < p.cin * 2; e += 256) abt[e] = src[e];
     }
-    issue_w(0, 0);
     float xr[8];
-    load_x(0, xr);
+    float xq[WREG ? 8 : 1];                              // WREG: the second position set (k-steps of odd parity)
+    if constexpr (WREG) {
+        load_x(0, xr);
+        load_w(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, 0);
+        load_w(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, 0);
+    } else {
+        issue_w(0, 0);
+        load_x(0, xr);
+    }
     if constexpr (GN_IN) __syncthreads();
     stage_x(0, 0, xr);
-    if (kst > 1) load_x(1, xr);
+    if constexpr (WREG) load_x(1, xq);
+    else if (kst > 1) load_x(1, xr);
+    {
+        if constexpr (WREG) {
+            load_w(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, 1);
+            load_w(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, 1);
+        }
+    }
     f32x16 acc[2][4];
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm)
@@ -174,16 +233,68 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     __syncthreads();
 
     // ---- k-steps ---------------------------------------------------------------------------------------------------------------
-#pragma unroll 1
-    for (int kk = 0; kk < kst; ++kk) {
+    auto kstep = [&](auto setc, int kk) {
+        constexpr int SET = decltype(setc)::value;
         const int st = kk & 1;
         // the next k-step's operands: split what was loaded during the last phase, then ask for the k-step after it
-        if (kk + 1 < kst) {
+        if constexpr (WREG) {
+            // straight-line on purpose (clamped k-steps instead of branches: what the last k-steps stage and load is never used): at a
+            // join the compiler's vmcnt bookkeeping assumes the path with the fewest loads in flight and waited for ALL of them.
+            // Positions before weights: loads return in order, and the wait for the positions at the next split leaves the weights in flight
+            // Two position sets: k-step kk asks for k-step kk + 2's at its top (into the set k-step kk - 1 has used up) and splits
+            // k-step kk + 1's, loaded a k-step ago, between its MFMA groups.
+            if constexpr (SET == 0) load_x(kk + 2 < kst ? kk + 2 : kst - 1, xr);
+            else load_x(kk + 2 < kst ? kk + 2 : kst - 1, xq);
+        } else if (kk + 1 < kst) {
             stage_x(kk + 1, st ^ 1, xr);
-            if (kk + 2 < kst) load_x(kk + 2, xr);
-            issue_w(kk + 1, st ^ 1);
+            {
+#if DX_ABL != 3
+                load_x(kk + 2 < kst ? kk + 2 : kst - 1, xr);        // (always issued, clamped: the load counts stay static)
+#endif
+#if DX_ABL != 2
+                issue_w(kk + 1, st ^ 1);
+#endif
+            }
         }
         const unsigned char *ab_ = smem + st * DX_STAGE + lane * 16;
+        if constexpr (WREG) {
+            auto half = [&](auto tmc) {
+                constexpr int TM = decltype(tmc)::value;
+#pragma unroll
+                for (int tn = 0; tn < 4; tn += 2) {
+                    u32x4 xa[3], xb[3];
+#pragma unroll
+                    for (int s = 0; s < 3; ++s) {
+                        xa[s] = *reinterpret_cast<const u32x4 *>(ab_ + DX_ASTAGE + (tn * 3 + s) * 1024);
+                        xb[s] = *reinterpret_cast<const u32x4 *>(ab_ + DX_ASTAGE + ((tn + 1) * 3 + s) * 1024);
+                    }
+                    // two position tiles' chains issued alternately (see below)
+                    f32x16 a = acc[TM][tn], b = acc[TM][tn + 1];
+                    a = dx_mfma(xa[0], wr[SET][TM][2], a); b = dx_mfma(xb[0], wr[SET][TM][2], b);
+                    a = dx_mfma(xa[2], wr[SET][TM][0], a); b = dx_mfma(xb[2], wr[SET][TM][0], b);
+                    a = dx_mfma(xa[1], wr[SET][TM][1], a); b = dx_mfma(xb[1], wr[SET][TM][1], b);
+                    a = dx_mfma(xa[0], wr[SET][TM][1], a); b = dx_mfma(xb[0], wr[SET][TM][1], b);
+                    a = dx_mfma(xa[1], wr[SET][TM][0], a); b = dx_mfma(xb[1], wr[SET][TM][0], b);
+                    a = dx_mfma(xa[0], wr[SET][TM][0], a); b = dx_mfma(xb[0], wr[SET][TM][0], b);
+                    acc[TM][tn] = a; acc[TM][tn + 1] = b;
+                    const int kn = kk + 1 < kst ? kk + 1 : kst - 1;
+                    // (the piece stays between the two MFMA groups: fragment reads, loads and scalar code may cross the fences, VALU, LDS
+                    // writes and MFMAs may not -- left alone the scheduler sinks the whole split behind the k-step's last MFMA)
+                    __builtin_amdgcn_sched_barrier(0x124);
+                    if (tn == 0) {
+                        if constexpr (SET == 0) stage_piece(std::integral_constant<int, 2 * TM>{}, kn, st ^ 1, xq);
+                        else stage_piece(std::integral_constant<int, 2 * TM>{}, kn, st ^ 1, xr);
+                    } else {
+                        if constexpr (SET == 0) stage_piece(std::integral_constant<int, 2 * TM + 1>{}, kn, st ^ 1, xq);
+                        else stage_piece(std::integral_constant<int, 2 * TM + 1>{}, kn, st ^ 1, xr);
+                    }
+                    __builtin_amdgcn_sched_barrier(0x124);
+                }
+                load_w(setc, tmc, kk + 2 < kst ? kk + 2 : kst - 1);
+            };
+            half(std::integral_constant<int, 0>{});
+            half(std::integral_constant<int, 1>{});
+        } else {
         u32x4 wf[2][3];
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm)
@@ -208,15 +319,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 acc[0][tn] = a; acc[1][tn] = b;
             }
         }
-        DX_WAIT_VM(0);                                  // this wave's weight pieces of the next k-step have landed ...
+        }
+        if constexpr (!WREG) {
+#if DX_ABL != 1 && DX_ABL != 4
+            DX_WAIT_VM(0);                              // this wave's weight pieces of the next k-step have landed ...
+#endif
+        }
+#if DX_ABL != 4
         __syncthreads();                                // ... everybody's have, and everybody is done with this stage
+#endif
+    };
+    if constexpr (WREG) {
+#pragma unroll 1
+        for (int kk = 0; kk < kst; kk += 2) {          // (kst even: the launcher's rule for this form)
+            kstep(std::integral_constant<int, 0>{}, kk);
+            kstep(std::integral_constant<int, 1>{}, kk + 1);
+        }
+    } else {
+#pragma unroll 1
+        for (int kk = 0; kk < kst; ++kk) kstep(std::integral_constant<int, 0>{}, kk);
     }
 
     // ---- epilogue: bias, activation, statistics of the raw output (a lane owns a channel: sums over its own registers) ------------
-    // TR: the tile leaves through LDS so that a store instruction writes whole rows -- 32 lanes x 16 bytes = the 512 contiguous bytes
-    // of a channel's 128 positions, two channels per instruction.  Straight from the accumulators (!TR) a lane's float4 is 4 of its
-    // channel's positions: one instruction = 64 pieces of 16 bytes in 32 different rows, and the layer ran at 1.8 TB/s of stores.
-    // The wave's 32-channel half tile goes to ITS OWN 16.5 KiB of the (now idle) operand stages, rows padded to 132 words: no barrier.
+    // The tile leaves through LDS so that a store instruction writes whole rows -- 32 lanes x 16 bytes = the 512 contiguous bytes of a
+    // channel's 128 positions, two channels per instruction (straight from the accumulators a lane's float4 is 4 of ITS channel's
+    // positions, one instruction = 64 pieces of 16 bytes in 32 rows: 3 % slower per launch, tools/ab_round6.sh).  The wave's 32-channel
+    // half tile goes to ITS OWN 16.5 KiB of the (now idle) operand stages, rows padded to 132 words: no barrier.
     constexpr int TR_ROW = 132;
     float *trw = reinterpret_cast<float *>(smem) + wave * (32 * TR_ROW);
 #pragma unroll
@@ -224,7 +352,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int ch = DX_TC * cb + 64 * wm + 32 * tm + col;
         const float bias = p.bias[ch];
         float s1 = 0.f, s2 = 0.f;
-        float *yp = p.y + ((size_t)bq * p.cout + ch) * p.l + p0 + 4 * h;
 #pragma unroll
         for (int tn = 0; tn < 4; ++tn)
 #pragma unroll
@@ -237,10 +364,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     s2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
                 }
                 v.x = apply_act(v.x, p.act); v.y = apply_act(v.y, p.act); v.z = apply_act(v.z, p.act); v.w = apply_act(v.w, p.act);
-                if constexpr (TR) *reinterpret_cast<float4 *>(trw + col * TR_ROW + 32 * tn + 8 * q + 4 * h) = v;
-                else *reinterpret_cast<float4 *>(yp + 32 * tn + 8 * q) = v;
+                *reinterpret_cast<float4 *>(trw + col * TR_ROW + 32 * tn + 8 * q + 4 * h) = v;
             }
-        if constexpr (TR) {
+        {
             // (same wave wrote it: LDS operations of a wave complete in order, the compiler's lgkmcnt wait covers the read-after-write)
             float *yr = p.y + ((size_t)bq * p.cout + DX_TC * cb + 64 * wm + 32 * tm + h) * p.l + p0 + 4 * col;
 #pragma unroll
@@ -295,10 +421,10 @@ extern "C" int captra_pointwise_mlp_x6(int b, int cin, int cout, long long l, co
     const long long grid = (long long)b * p.npt * p.ncb;
     if (grid >= (1ll << 31)) return -2;
     const int lds = DX_LDS + cin * 8;
-    static const bool dx_tr = [] { const char *e = getenv("CAPTRA_DX_TR"); return e == nullptr || e[0] != '0'; }();
+    static const bool dx_wreg = [] { const char *e = getenv("CAPTRA_DX_WREG"); return e == nullptr || e[0] != '0'; }();
 #define DX_LAUNCH(GN_, ST_)                                                                                             \
     do {                                                                                                                \
-        auto kern = dx_tr ? dense_x6_kernel<GN_, ST_, true> : dense_x6_kernel<GN_, ST_, false>;                         \
+        auto kern = (dx_wreg && cin % 32 == 0) ? dense_x6_kernel<GN_, ST_, true> : dense_x6_kernel<GN_, ST_, false>; \
         static CaptraDeviceOnce once;                                                                                   \
         if (once.first_use()) {                                                                                         \
             if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, DX_LDS + 1024 * 8) != hipSuccess) \
