@@ -84,7 +84,8 @@ struct DxParams {
 };
 
 // timing ablations (-DCAPTRA_DX_ABL=n, results wrong): 1 no wait for the k-step's loads, 2 no weight DMA after start-up, 3 no position
-// loads after start-up, 4 neither wait nor barrier
+// loads after start-up, 4 neither wait nor barrier; register-weight form: 5 MFMAs + fragment reads + barrier only (no loads, no
+// split after start-up), 6 the same without the barrier, 8 as 5 with the weight loads
 #ifdef CAPTRA_DX_ABL
 #define DX_ABL CAPTRA_DX_ABL
 #else
@@ -243,8 +244,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             // Positions before weights: loads return in order, and the wait for the positions at the next split leaves the weights in flight
             // Two position sets: k-step kk asks for k-step kk + 2's at its top (into the set k-step kk - 1 has used up) and splits
             // k-step kk + 1's, loaded a k-step ago, between its MFMA groups.
+#if DX_ABL < 5
             if constexpr (SET == 0) load_x(kk + 2 < kst ? kk + 2 : kst - 1, xr);
             else load_x(kk + 2 < kst ? kk + 2 : kst - 1, xq);
+#endif
         } else if (kk + 1 < kst) {
             stage_x(kk + 1, st ^ 1, xr);
             {
@@ -280,6 +283,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     const int kn = kk + 1 < kst ? kk + 1 : kst - 1;
                     // (the piece stays between the two MFMA groups: fragment reads, loads and scalar code may cross the fences, VALU, LDS
                     // writes and MFMAs may not -- left alone the scheduler sinks the whole split behind the k-step's last MFMA)
+#if DX_ABL < 5
                     __builtin_amdgcn_sched_barrier(0x124);
                     if (tn == 0) {
                         if constexpr (SET == 0) stage_piece(std::integral_constant<int, 2 * TM>{}, kn, st ^ 1, xq);
@@ -289,8 +293,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         else stage_piece(std::integral_constant<int, 2 * TM + 1>{}, kn, st ^ 1, xr);
                     }
                     __builtin_amdgcn_sched_barrier(0x124);
+#endif
                 }
+#if DX_ABL < 5 || DX_ABL == 8
                 load_w(setc, tmc, kk + 2 < kst ? kk + 2 : kst - 1);
+#endif
             };
             half(std::integral_constant<int, 0>{});
             half(std::integral_constant<int, 1>{});
@@ -325,7 +332,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             DX_WAIT_VM(0);                              // this wave's weight pieces of the next k-step have landed ...
 #endif
         }
-#if DX_ABL != 4
+#if DX_ABL != 4 && DX_ABL != 6
         __syncthreads();                                // ... everybody's have, and everybody is done with this stage
 #endif
     };

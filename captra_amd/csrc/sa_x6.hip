@@ -300,20 +300,37 @@ __device__ __forceinline__ void sx_body(const SxParams &p, unsigned char *smem) 
 
     // ---- a slice's per-lane inputs (this lane: position `col` of the slice, input rows of half h) ------------------------------
     auto load_id = [&](int c, int sl) -> int { return p.idx[(size_t)c * p.k + sl * 32 + col]; };
-    auto load_bt = [&](int c, int id_, float (&bt_)[S::KS1]) {
+    // The gathered input rows arrive RAW (value, what to subtract from it) and become layer 1's operand at the START of the slice that
+    // uses them: branch-free loads whose first use lies a whole layer 3 away.  (Written as `v = row[id] - centre` under `if (has_next)`,
+    // load and subtraction shared a basic block and a scheduling region: s_waitcnt vmcnt(0) straight behind every gather, in the middle
+    // of layers 2 / 3 -- three exposed round trips per slice.)
+    auto load_bt = [&](int c, int id_, float (&raw_)[S::KS1], float (&sub_)[S::KS1]) {
         const int tb = c / p.m;
         const float *cp = p.new_xyz + (size_t)c * 3;
 #pragma unroll
         for (int j = 0; j < S::KS1; ++j) {
             const int a = 2 * j + h;
             if constexpr (PRE) {
-                bt_[j] = a < 3 ? p.xyz_cn[((size_t)tb * 3 + a) * p.n + id_] - cp[a] : 0.f;
+                // (the ring kernels keep the direct form: their chunk hand-over waits for every load in flight anyway, and the 196-wide
+                // scale has no registers to spare for the raw pair)
+                raw_[j] = a < 3 ? p.xyz_cn[((size_t)tb * 3 + a) * p.n + id_] - cp[a] : 0.f;
+                sub_[j] = 0.f;
             } else {
-                float v = 0.f;
-                if (a < CF) v = p.feat[((size_t)tb * CF + a) * p.n + id_];
-                else if (a < CF + 3) v = p.xyz_cn[((size_t)tb * 3 + (a - CF)) * p.n + id_] - cp[a - CF];
-                bt_[j] = v;
+                const int ax = a - CF < 0 ? 0 : (a - CF > 2 ? 2 : a - CF);
+                const float *xrow = p.xyz_cn + ((size_t)tb * 3 + ax) * p.n;
+                const float *row = xrow;
+                if constexpr (CF > 0) row = a < CF ? p.feat + ((size_t)tb * CF + a) * p.n : xrow;
+                raw_[j] = row[id_];
+                sub_[j] = cp[ax];
             }
+        }
+    };
+    auto finish_bt = [&](const float (&raw_)[S::KS1], const float (&sub_)[S::KS1], float (&bt_)[S::KS1]) {
+#pragma unroll
+        for (int j = 0; j < S::KS1; ++j) {
+            const int a = 2 * j + h;
+            if constexpr (PRE) bt_[j] = raw_[j];
+            else bt_[j] = a < CF ? raw_[j] : (a < CF + 3 ? raw_[j] - sub_[j] : 0.f);
         }
     };
     constexpr int NG4 = PRE ? S::NT1 : 1;
@@ -332,11 +349,11 @@ __device__ __forceinline__ void sx_body(const SxParams &p, unsigned char *smem) 
     int c = job * WAVES + wave, sl = 0;
     int ce = c < ncentres ? c : ncentres - 1;           // (a spare wave recomputes the last centre and stores nothing)
     int id = 0;
-    float bt[S::KS1];
+    float bt[S::KS1], braw[S::KS1], bsub[S::KS1];
     float4 g4[NG4][4];
     if (job < njobs) {
         id = load_id(ce, 0);
-        load_bt(ce, id, bt);
+        load_bt(ce, id, braw, bsub);
         load_g4(ce, id, g4);
     }
     float z[S::NT3];
@@ -367,6 +384,7 @@ __device__ __forceinline__ void sx_body(const SxParams &p, unsigned char *smem) 
         int id_n = 0;
 
         u32x4 h1[3][S::KST2], h2[3][S::KST3];
+        finish_bt(braw, bsub, bt);
         // ---- layer 1 (fp32 MFMA, exact): from the bias / the gathered v1 rows ------------------------------------------------------
         f32x16 acc1[S::NT1];
 #pragma unroll
@@ -409,10 +427,14 @@ __device__ __forceinline__ void sx_body(const SxParams &p, unsigned char *smem) 
             // fragments of the next group (the next slice's first group behind the last one: the weights repeat)
             if (gi + 1 < G) wload(gi + 1, wr[(gi + 1) & 1]);
             else wload(0, wr[(gi + 1) & 1]);
-            // the next slice's inputs: ids under layer 2, the gathers under layer 3
-            if (gi == 1 && has_next) id_n = load_id(cn, sn);
-            if (gi == G2 + 1 && has_next) {
-                load_bt(cn, id_n, bt);
+            // the next slice's inputs: ids under layer 2, the gathers under layer 3 (resident-image kernels: always asked for -- behind the
+            // last slice they are the clamped centre's again and nobody reads them; no branch, nothing of a load's use in its own region)
+            if (gi == 1 && (!PRE || has_next)) id_n = load_id(cn, sn);
+            if (gi == G2 + 1 && (!PRE || has_next)) {
+                // (the id becomes visible HERE: its sign extension for the 64-bit addresses otherwise sits straight behind the load, a wait
+                // for the round trip in the middle of layer 2)
+                if constexpr (!PRE) asm volatile("" : "+v"(id_n));
+                load_bt(cn, id_n, braw, bsub);
                 load_g4(cn, id_n, g4);
             }
             if (kk == 0) {
