@@ -43,6 +43,7 @@ _SIGNATURES = {
     "captra_ball_query_multi": [_INT, _INT, _INT, _INT, _P, _P, _P, _P, _P, _P],
     "captra_pack_weights": [_INT, _INT, _P, _P, _P, _P, _P],
     "captra_pointwise_mlp": [_INT, _INT, _INT, _LL, _P, _P, _P, _INT, _P, _P],
+    "captra_pointwise_mlp_cb": [_INT, _INT, _INT, _LL, _P, _P, _P, _INT, _P, _P],
     "captra_pointwise_mlp2": [_INT, _INT, _INT, _INT, _LL, _P, _P, _INT, _P, _P, _INT, _P, _P],
     "captra_sa_group_mlp": [_INT, _INT, _INT, _INT, _INT, _INT, _P, _P, _P, _P, _P, _P, _P, _P],
     "captra_mlp_max": [_INT, _INT, _INT, _INT, _INT, _P, _P, _P, _P, _INT, _INT, _P],

@@ -48,6 +48,7 @@ struct PwParams {
     const float *x;       // PRO_PLAIN: (B,cin,L)
     const float *wt;      // packed (ceil32(cin), ldw)
     const float *bias;    // packed (ldw)
+    long long bias_bs;    // floats between two clouds' biases (0: one bias for all; captra_pointwise_mlp_cb)
     float *y;
     int act;
     // PRO_GROUP
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(PW_THREADS) void pw_mlp_kernel(PwParams p) {
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
-        const float *bp = p.bias + co0 + (wm * TM + tm) * 32 + 4 * (lane >> 5);
+        const float *bp = p.bias + (size_t)blockIdx.z * p.bias_bs + co0 + (wm * TM + tm) * 32 + 4 * (lane >> 5);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float bv = bp[(r & 3) + 8 * (r >> 2)];  // packed bias: in bounds, zero beyond cout
@@ -444,7 +445,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void p
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
-        const float *bp = p.bias + co0 + tm * 32 + 4 * (lane >> 5);
+        const float *bp = p.bias + (size_t)b * p.bias_bs + co0 + tm * 32 + 4 * (lane >> 5);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float bv = bp[(r & 3) + 8 * (r >> 2)];
@@ -643,7 +644,7 @@ __global__ __launch_bounds__(256) void pw_splitk_kernel(PwParams p) {
     const int woff = blockIdx.y * kq * 1024 + lane * 16;
     f32x16 acc;
     {
-        const float *bp = p.bias + co0 + 4 * h;
+        const float *bp = p.bias + (size_t)b * p.bias_bs + co0 + 4 * h;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = wave == 0 ? bp[(r & 3) + 8 * (r >> 2)] : 0.f;
     }
@@ -981,6 +982,21 @@ extern "C" int captra_pointwise_mlp_ex(int b, int cin, int cout, long long l, co
 extern "C" int captra_pointwise_mlp(int b, int cin, int cout, long long l, const float *x, const float *wt_packed,
                                     const float *bias_packed, int act, float *y, captra_stream_t stream) {
     return captra_pointwise_mlp_ex(b, cin, cout, l, x, wt_packed, bias_packed, act, y, nullptr, stream);
+}
+
+// The layer with a bias PER CLOUD: bias_bc (B, ceil128(cout)), zero beyond cout -- y[b] = act(W x[b] + bias_bc[b]).  What a layer on
+// [x; repeat(v)] (one vector v per cloud: pointnet_utils.py:265-270) becomes once the caller has formed W2 v + b per cloud; NOT the
+// k-ascending chain over the concat (the f32x6 mode's FP3: captra_amd/pointnet_utils.py), per launch the same contract as
+// captra_pointwise_mlp.  -2: shape outside the direct kernels.
+extern "C" int captra_pointwise_mlp_cb(int b, int cin, int cout, long long l, const float *x, const float *wt_packed,
+                                       const float *bias_bc, int act, float *y, captra_stream_t stream) {
+    if (b < 0 || cin < 1 || cout < 1 || l < 0 || act < 0 || act > 2 || bias_bc == nullptr) return -1;
+    if (b == 0 || l == 0) return 0;
+    PwParams p = {};
+    p.cin = cin; p.cout = cout; p.ldw = (cout + 127) / 128 * 128; p.L = l; p.x = x; p.wt = wt_packed; p.bias = bias_bc; p.bias_bs = p.ldw;
+    p.y = y; p.act = act;
+    const int err = launch_pw_direct(b, p, (hipStream_t)stream);
+    return err == -3 ? -2 : err;
 }
 
 // The layer on the channel concat [x; x2] WITHOUT building it (SA3's [xyz, feat], pointnet_utils.py:171-188; FP3's

@@ -299,6 +299,29 @@ def pointwise_mlp2(x, x2, lin: PackedLinear, act: int = ACT_RELU):
     return out
 
 
+X6_FP_HOIST = os.environ.get("CAPTRA_X6_FP_HOIST", "1") != "0"   # f32x6: a layer on [x; repeat(v)] as W1 x + (W2 v + b)
+
+
+def pointwise_mlp_cloud_bias(x, v, lin: PackedLinear, act: int = ACT_RELU):
+    """act(W [x; repeat(v)] + b) as act(W1 x + (W2 v + b)): x (B,c,l), v (B,c2,1) one vector per cloud.  The bracket is one small
+    product per cloud (split-k: a single position is one dependent chain otherwise) and becomes the layer's bias per cloud
+    (captra_pointwise_mlp_cb) -- c instead of c + c2 input channels at every position (FP3: 512 instead of 1536).  NOT the k-ascending
+    chain over the concat, so only where the arithmetic has no bit-exact contract (the f32x6 mode); None outside its shapes."""
+    if not (X6_FP_HOIST and mlp_dtype() == "f32x6" and x.dim() == 3 and v.dim() == 3 and v.shape[2] == 1 and lin.cout % 128 == 0
+            and lin.cout > 64 and x.shape[1] >= 32 and lin.cin == x.shape[1] + v.shape[1]):
+        return None
+    L.require_device(x, v)
+    B, c, l = x.shape
+    with split_k(True):
+        bias_bc = pointwise_mlp(v, lin.trailing_rows(c), ACT_NONE)             # (B,cout,1) = W2 v + b
+    lead = lin.leading_rows(c)
+    out = torch.empty(B, lin.cout, l, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        L.call("captra_pointwise_mlp_cb", B, c, lin.cout, l, L.ptr(x), L.ptr(lead.wt), L.ptr(bias_bc), act, L.ptr(out))
+    _work("pointwise_mlp", flops=2.0 * B * lin.cout * (c * l + v.shape[1]), nbytes=4.0 * B * l * (c + lin.cout))
+    return out
+
+
 def pm_channels(c: int) -> int:
     """Channel stride of a point-major bf16 tensor (include/captra_hip.h "bf16-NATIVE dense layers")."""
     return (c + 31) // 32 * 32

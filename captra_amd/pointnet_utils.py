@@ -362,7 +362,10 @@ class PointNetFeaturePropagation(_FoldCache, nn.Module):
             # one source vector per cloud (pointnet_utils.py:265-270): the first layer reads [points1; repeat(points2)] from the two
             # tensors as they are (captra_pointwise_mlp2: rows in the concat's order, so the same bits) -- no repeat, no concat
             layers = list(self._fold(xyz1.device)) + ([tail] if tail is not None else [])
-            y = fused.pointwise_mlp2(points1.contiguous(), points2.contiguous(), layers[0], fused.ACT_RELU)
+            # f32x6 (no bit-exact contract): the repeated vector's share of the first layer once per cloud, as its bias
+            y = fused.pointwise_mlp_cloud_bias(points1.contiguous(), points2.contiguous(), layers[0], fused.ACT_RELU)
+            if y is None:
+                y = fused.pointwise_mlp2(points1.contiguous(), points2.contiguous(), layers[0], fused.ACT_RELU)
             if y is not None:
                 for lin in layers[1:]:
                     y = fused.pointwise_mlp(y, lin, fused.ACT_RELU)

@@ -192,6 +192,12 @@ int captra_pointwise_mlp(int b, int cin, int cout, long long l, const float *x, 
 int captra_pointwise_mlp_ex(int b, int cin, int cout, long long l, const float *x, const float *wt,
                          const float *bias, int act, float *y, const captra_launch_opts *opts,
         captra_stream_t stream);   /* the same with per-call options */
+/* The same layer with a bias PER CLOUD, bias_bc (B, ceil128(cout)) f32, zero beyond cout: y[b] = act(W x[b] + bias_bc[b]).
+ * For a layer on [x; repeat(v)] with one vector v per cloud (pointnet_utils.py:265-270) after the caller has formed
+ * bias_bc[b] = W2 v[b] + bias (captra_pointwise_mlp with l = 1): a third of the products, but not the k-ascending chain over the
+ * concat -- the f32x6 mode uses it, the exact mode keeps captra_pointwise_mlp2.  -2: shape outside the direct kernels. */
+int captra_pointwise_mlp_cb(int b, int cin, int cout, long long l, const float *x, const float *wt,
+                            const float *bias_bc, int act, float *y, captra_stream_t stream);
 
 /* First layer of a set-abstraction scale with the group-and-concat fused into the operand load
  * (group_operation + "-= centre" + cat, pointnet_utils.py:234-240):

@@ -149,3 +149,29 @@ def test_coord_tail_x6_vs_exact_chain(device, seg_dim, nocs_dim, B, l):
     hid = O.pointwise_mlp(feat, layers[4][0], layers[4][1], 1)
     raw = O.pointwise_mlp(hid, layers[5][0], layers[5][1], 0)
     np.testing.assert_allclose(nocs.cpu().numpy(), 1.0 / (1.0 + np.exp(-raw.astype(np.float64))) - 0.5, atol=1e-6, rtol=0)
+
+
+@pytest.mark.parametrize("B,c,c2,cout,l", [(2, 512, 1024, 256, 128), (16, 512, 1024, 256, 128), (3, 64, 96, 128, 200), (1, 32, 40, 384, 1)])
+def test_layer_on_repeated_vector_as_cloud_bias_vs_exact_chain(device, B, c, c2, cout, l):
+    """f32x6 mode: act(W [x; repeat(v)] + b) evaluated as act(W1 x + (W2 v + b)) (captra_pointwise_mlp_cb after the per-cloud product;
+    FeaturePropagation with one source vector per cloud, reference pointnet_utils.py:265-270) against the oracle's k-ascending chain
+    over the concat: fp32 re-association only.  Outside the mode the exact two-source kernel stays (None)."""
+    from captra_amd import fused
+    rng = np.random.default_rng(B + c + cout + l)
+    x = rng.standard_normal((B, c, l)).astype(np.float32)
+    v = rng.standard_normal((B, c2, 1)).astype(np.float32)
+    w = (rng.standard_normal((c + c2, cout)) / np.sqrt(c + c2)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    lin = fused.pack(_dev(w, device), _dev(b, device))
+    assert fused.pointwise_mlp_cloud_bias(_dev(x, device), _dev(v, device), lin) is None        # exact mode: not this path
+    with fused.use_mlp_dtype("f32x6"):
+        got = fused.pointwise_mlp_cloud_bias(_dev(x, device), _dev(v, device), lin, fused.ACT_RELU)
+    assert got is not None and got.shape == (B, cout, l)
+    xc = np.concatenate([x, np.repeat(v, l, axis=2)], axis=1)
+    chain = O.pointwise_mlp(xc, w, b, 1)
+    # Two fp32 summation orders of up to 1536 terms differ by more than the mode's 2e-6 on their own (measured 2.0-2.5e-6 of the largest
+    # output between this and the k-ascending chain), so both are held against the float64 result: this path is no further from it
+    # than twice the chain's own rounding (+ 5e-7), and within 3e-6 of the largest output
+    ref64 = np.maximum(np.einsum("kc,bkl->bcl", w.astype(np.float64), xc.astype(np.float64)) + b.astype(np.float64)[None, :, None], 0.0)
+    e_got, e_chain = _rel(got.cpu().numpy(), ref64), _rel(chain, ref64)
+    assert e_got <= 3e-6 and e_got <= 2.0 * e_chain + 5e-7, (e_got, e_chain)
