@@ -307,7 +307,8 @@ def pointwise_mlp_cloud_bias(x, v, lin: PackedLinear, act: int = ACT_RELU):
     product per cloud (split-k: a single position is one dependent chain otherwise) and becomes the layer's bias per cloud
     (captra_pointwise_mlp_cb) -- c instead of c + c2 input channels at every position (FP3: 512 instead of 1536).  NOT the k-ascending
     chain over the concat, so only where the arithmetic has no bit-exact contract (the f32x6 mode); None outside its shapes."""
-    if not (X6_FP_HOIST and mlp_dtype() == "f32x6" and x.dim() == 3 and v.dim() == 3 and v.shape[2] == 1 and lin.cout % 128 == 0
+    # (not under the few-trajectory split-k rule: there the two-source layer itself splits k over a workgroup's waves)
+    if not (X6_FP_HOIST and mlp_dtype() == "f32x6" and not _split_k_active() and x.dim() == 3 and v.dim() == 3 and v.shape[2] == 1 and lin.cout % 128 == 0
             and lin.cout > 64 and x.shape[1] >= 32 and lin.cin == x.shape[1] + v.shape[1]):
         return None
     L.require_device(x, v)
