@@ -69,6 +69,8 @@ def test_sa_scale_x6_vs_exact_chain(device, cfeat, chans, n, m, k, B):
 @pytest.mark.parametrize("cin,cout,L,B,gn_in,stats", [(128, 512, 4096, 2, False, True), (512, 512, 4096, 2, True, True),
                                                        (512, 256, 4096, 3, True, True), (512, 256, 512, 2, True, False),
                                                        (128, 256, 256, 1, False, False), (16, 256, 768, 2, True, True), (64, 512, 384, 2, True, True),
+                                                       (48, 256, 256, 2, True, True), (176, 512, 128, 3, False, True),     # cin % 32 != 0: the LDS-DMA form
+
                                                        (512, 512, 4096, 9, True, True)])
 def test_dense_x6_vs_exact_chain(device, cin, cout, L, B, gn_in, stats):
     """The f32x6 dense layer of the GroupNorm chains (captra_pointwise_mlp_x6) == the exact kernel (captra_pointwise_mlp_gn, itself
